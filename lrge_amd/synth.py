@@ -1,0 +1,139 @@
+"""Synthetic long-read sets for the BASELINE.json configs.
+
+The reference publishes no benchmark inputs, so every config is a seeded synthetic set:
+uniform random genome, reads sampled uniformly on either strand, lognormal (ONT) or normal (HiFi)
+lengths, independent per-base substitution / insertion / deletion errors.  numpy's PCG64 bit
+generator is used throughout, so a (config, seed) pair is reproducible on the same image.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[_a] = _b
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_CODE = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _CODE[_c] = _i
+
+
+@dataclass
+class ReadBatch:
+    """Reads as the overlap API takes them: concatenated ASCII + offsets + names."""
+    bases: np.ndarray      # uint8 ASCII, concatenated
+    offsets: np.ndarray    # uint64 [n+1]
+    names: list            # list[bytes]
+    starts: np.ndarray     # int64 genome start of each read (truth)
+    ends: np.ndarray       # int64 genome end (exclusive) of the error-free source interval
+    strands: np.ndarray    # int8
+
+    @property
+    def n(self):
+        return len(self.names)
+
+    def lens(self):
+        return np.diff(self.offsets).astype(np.int64)
+
+    def slice(self, lo, hi):
+        o = self.offsets
+        return ReadBatch(self.bases[int(o[lo]):int(o[hi])].copy(), (o[lo:hi + 1] - o[lo]).astype(np.uint64),
+                         self.names[lo:hi], self.starts[lo:hi], self.ends[lo:hi], self.strands[lo:hi])
+
+    def seqs(self):
+        o = self.offsets
+        return [self.bases[int(o[i]):int(o[i + 1])].tobytes() for i in range(self.n)]
+
+
+PLATFORMS = {
+    # total error split sub/ins/del; length model
+    "ont": dict(sub=0.024, ins=0.016, dele=0.020, kind="lognormal", mu=np.log(6000.0), sigma=0.6,
+                lo=500, hi=60000),
+    "hifi": dict(sub=0.002, ins=0.0015, dele=0.0015, kind="normal", mu=15000.0, sigma=2000.0,
+                 lo=5000, hi=25000),
+}
+
+
+def random_genome(size, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return _ACGT[rng.integers(0, 4, size=size, dtype=np.uint8)]
+
+
+def _read_lengths(rng, n, p, gsize):
+    if p["kind"] == "lognormal":
+        l = rng.lognormal(p["mu"], p["sigma"], size=n)
+    else:
+        l = rng.normal(p["mu"], p["sigma"], size=n)
+    l = np.clip(l, p["lo"], min(p["hi"], gsize)).astype(np.int64)
+    return l
+
+
+def sample_reads(genome, n, platform="ont", seed=1, name_prefix="r", name_start=0, n_rate=0.0):
+    """Sample n error-laden reads.  seed drives placement (seed) and errors (seed+1)."""
+    p = PLATFORMS[platform]
+    g = len(genome)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    erng = np.random.Generator(np.random.PCG64(seed + 1))
+    lens = _read_lengths(rng, n, p, g)
+    starts = (rng.random(n) * (g - lens + 1)).astype(np.int64)
+    strands = rng.integers(0, 2, size=n, dtype=np.int8)
+    ps, pi, pd = p["sub"], p["ins"], p["dele"]
+    chunks, out_lens = [], np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        src = genome[starts[i]:starts[i] + lens[i]]
+        if strands[i]:
+            src = _COMP[src[::-1]]
+        u = erng.random(len(src))
+        is_sub = u < ps
+        is_ins = (u >= ps) & (u < ps + pi)
+        is_del = (u >= ps + pi) & (u < ps + pi + pd)
+        b = src.copy()
+        if is_sub.any():
+            code = _CODE[b[is_sub]]
+            b[is_sub] = _ACGT[(code + erng.integers(1, 4, size=code.size, dtype=np.uint8)) & 3]
+        reps = np.ones(len(src), dtype=np.int64)
+        reps[is_del] = 0
+        reps[is_ins] = 2
+        o = np.repeat(b, reps)
+        if is_ins.any():  # second copy of an "ins" base becomes a random base
+            idx = np.cumsum(reps)[is_ins] - 1
+            o[idx] = _ACGT[erng.integers(0, 4, size=idx.size, dtype=np.uint8)]
+        if n_rate > 0:
+            nm = erng.random(len(o)) < n_rate
+            o[nm] = ord("N")
+        if len(o) == 0:
+            o = src[:1].copy()
+        chunks.append(o)
+        out_lens[i] = len(o)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(out_lens, out=offsets[1:])
+    bases = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)
+    names = [b"%s%08d" % (name_prefix.encode(), name_start + i) for i in range(n)]
+    return ReadBatch(bases, offsets, names, starts, starts + lens, strands)
+
+
+# The five BASELINE.json configs.  "twoset": first Q reads are queries, the
+# last T are targets (file order of Appendix C); "ava": all N reads.
+CONFIGS = {
+    "c2_bact_twoset": dict(genome=4_400_000, seed=4401, platform="ont", mode="twoset", Q=5000, T=10000),
+    "c3_yeast_ava": dict(genome=12_000_000, seed=1201, platform="ont", mode="ava", N=20000),
+    "c4_dmel_twoset": dict(genome=143_000_000, seed=14301, platform="ont", mode="twoset", Q=50000, T=100000),
+    "c5_human_twoset": dict(genome=3_100_000_000, seed=31001, platform="hifi", mode="twoset", Q=100000, T=2000000),
+    # reduced cases for tests / smoke
+    "tiny_twoset": dict(genome=200_000, seed=77, platform="ont", mode="twoset", Q=60, T=300),
+    "tiny_ava": dict(genome=100_000, seed=78, platform="ont", mode="ava", N=200),
+    "tiny_hifi": dict(genome=300_000, seed=79, platform="hifi", mode="twoset", Q=20, T=120),
+}
+
+
+def make_config(name, scale=1.0):
+    """Return (genome_size, queries, targets) for twoset or (genome_size, reads, None) for ava."""
+    c = CONFIGS[name]
+    gsize = int(c["genome"] * scale)
+    genome = random_genome(gsize, c["seed"])
+    if c["mode"] == "twoset":
+        q, t = max(1, int(c["Q"] * scale)), max(1, int(c["T"] * scale))
+        reads = sample_reads(genome, q + t, c["platform"], seed=c["seed"] + 1)
+        return gsize, reads.slice(0, q), reads.slice(q, q + t)
+    n = max(2, int(c["N"] * scale))
+    return gsize, sample_reads(genome, n, c["platform"], seed=c["seed"] + 1), None

@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- reads overlapped/sec of the liblrge overlap hot path on MI355X.
+
+One "step" = one full pass of the hot path over one batch of synthetic reads that are already
+resident (2-bit packed) in HBM: minimizer index build over the target set, sketch + seed + chain
+of every query, distinct-target counts, per-read estimates, median.  Workload at N=1 is
+BASELINE.json configs[1]: the 4.4 Mbp bacterial ONT set, two-set -Q 5000 -T 10000 (preset ava-ont,
+which is what the reference CLI always runs: lrge/src/main.rs:56-85 never forwards -P).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards by query read, so
+every rank holds the full target index (built redundantly, no data-path collective) and its own
+Q query reads ("weak": per-GPU work fixed); one RCCL all_gather over xGMI collects the per-read
+estimate vectors.  value = reads all ranks processed / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2_bact_twoset")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the config (debug only; invalid as a result)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(q, t, budget_s):
+    """The oracle ("port" of the liblrge/minimap2-2.30 path) timed on the host cores, on a bounded
+    sample: the full target index is built once (timed), then as many query reads as fit in the
+    budget are mapped with all cores; the index cost is pro-rated over the sampled fraction."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    opt = O.make_opt(O.PRESET_AVA_ONT, dual=True)
+    T = O.ReadSet(t.seqs(), t.names)
+    t0 = time.perf_counter()
+    ix = O.Index(T, opt)
+    t_index = time.perf_counter() - t0
+    done, t_map, chunk = 0, 0.0, max(64, 8 * cores)
+    counts = []
+    while done < q.n and t_map < budget_s:
+        hi = min(q.n, done + chunk)
+        sub = q.slice(done, hi)
+        Q = O.ReadSet(sub.seqs(), sub.names)
+        t1 = time.perf_counter()
+        rc, c, _ = ix.twoset_counts(Q, threads=cores)
+        t_map += time.perf_counter() - t1
+        assert rc == 0
+        counts.append(c)
+        done = hi
+    frac = done / q.n
+    reads_per_s = done / (t_map + t_index * frac)
+    return dict(value=reads_per_s, unit="reads/s", cores=cores, kind="port",
+                sample="first %d of %d query reads mapped on %d threads (%.1f s) against the full %d-read target index "
+                       "(built single-threaded in %.1f s, pro-rated x%.3f)" % (done, q.n, cores, t_map, t.n, t_index, frac),
+                map_only_reads_per_s=done / t_map), np.concatenate(counts) if counts else np.zeros(0, np.uint32), ix.mid_occ
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    import torch
+    import torch.distributed as dist
+    from lrge_amd import engine, synth
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic inputs (untimed) ----
+    cfg = synth.CONFIGS[a.config]
+    assert cfg["mode"] == "twoset", "bench.py times the two-set forward path"
+    gsize = int(cfg["genome"] * a.scale)
+    Qn, Tn = max(1, int(cfg["Q"] * a.scale)), max(1, int(cfg["T"] * a.scale))
+    genome = synth.random_genome(gsize, cfg["seed"])
+    t = synth.sample_reads(genome, Tn, cfg["platform"], seed=cfg["seed"] + 1, name_prefix="t")
+    # weak scaling: every rank draws its own Q query reads (rank 0's are the BASELINE set)
+    q = synth.sample_reads(genome, Qn, cfg["platform"], seed=cfg["seed"] + 101 + 7 * rank, name_prefix="q%d_" % rank)
+
+    ctx = engine.Context(local_rank)
+    qr, tr = engine.name_ranks(q.names, t.names)
+    Qd = ctx.upload(q.bases, q.offsets, qr)      # resident in HBM, 2-bit packed, before the timed region
+    Td = ctx.upload(t.bases, t.offsets, tr)
+    qlens = q.lens()
+    avg_t = np.float32(t.lens().sum()) / np.float32(t.n)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        ix = engine.Index(ctx, Td, 0)
+        tb = dict(ix.build_timings)
+        counts, has = ix.overlap_twoset(Qd)
+        tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
+        est = ctx.estimates(counts, qlens, float(avg_t), t.n, 100)
+        ix.free()
+        if world > 1:   # the one collective of the path: per-read estimate vectors over RCCL/xGMI
+            mine = torch.from_numpy(est).cuda()
+            allv = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)
+            est_all = torch.cat(allv).cpu().numpy()
+        else:
+            est_all = est
+        med = engine.median(est_all, True, 0.15, 0.65)
+        return counts, est_all, med, tb, tm, cn, st
+
+    for _ in range(a.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    acc_tb, acc_tm, acc_cn = {}, {}, {}
+    for _ in range(a.steps):
+        counts, est_all, med, tb, tm, cn, st = step()
+        for k, v in tb.items(): acc_tb[k] = acc_tb.get(k, 0.0) + v
+        for k, v in tm.items(): acc_tm[k] = acc_tm.get(k, 0.0) + v
+        for k, v in cn.items(): acc_cn[k] = acc_cn.get(k, 0) + v
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        K = a.steps
+        ms_per_step = elapsed * 1e3 / K
+        value = world * Qn * K / elapsed
+        # ---- roofline of the dominant kernel (k_chain_lds), HBM-bound by construction ----
+        # algorithmic bytes per launch = 16 B per anchor read (8 B key + 8 B value) + 4 B flag per group,
+        # the "16*H anchor in for chaining" term of B_q, restricted to what a launch covers.
+        launches = max(1, acc_cn.get("chain_launches", 0))
+        chain_ms = acc_tm.get("chain", 0.0)
+        alg_bytes = 16.0 * acc_cn.get("chain_anchors", 0) / launches
+        avg_launch_ms = chain_ms / launches
+        achieved = alg_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "chain_pmc.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("k_chain_lds_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
+        L = float(q.lens().sum()); M = acc_cn.get("query_minimizers", 0) / K; H = acc_cn.get("anchors", 0) / K
+        B_q = L / 4 + 32 * M + 8 * H + 32 * H + 4 * Qn
+        B_idx = float(t.lens().sum()) / 4 + 16 * st["n_minimizers"]
+        e2e_gbps = (B_q + B_idx) / (ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "reads overlapped/sec (whole node)", "value": value, "unit": "reads/s",
+            "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 keys / i32 chain scores / f32 gap penalty", "data": "synthetic",
+            "config": {"workload": "%s: %.1f Mbp genome, ONT reads, two-set forward -Q %d -T %d per GPU, preset ava-ont, dual=yes"
+                                   % (a.config, gsize / 1e6, Qn, Tn),
+                       "query_reads_per_gpu": Qn, "target_reads": Tn, "parallelism": "query-sharded x%d, index replicated" % world,
+                       "scale": a.scale},
+            "genome_size_true": gsize,
+            "genome_size_estimate": None if med[1] is None else float(med[1]),
+            "genome_size_abs_error": None if med[1] is None else abs(float(med[1]) - gsize),
+            "estimate_q15_q65": [None if med[0] is None else float(med[0]), None if med[2] is None else float(med[2])],
+            "mid_occ": st["mid_occ"],
+            "roofline": {"bound": "hbm", "kernel": "k_chain_lds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_ms, "launches_per_step": launches / K,
+                         "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS},
+            "stage_ms_per_step": {**{"index_" + k: v / K for k, v in acc_tb.items() if v and k != "total"},
+                                  **{k: v / K for k, v in acc_tm.items() if v}},
+            "work_per_step": {k: v / K for k, v in acc_cn.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            cb, ccounts, cmid = cpu_baseline(q, t, a.cpu_seconds)
+            out["cpu_baseline"] = cb
+            out["gpu_vs_cpu"] = value / cb["value"]
+            n = len(ccounts)
+            out["parity_vs_oracle_sample"] = {"reads": n, "counts_equal": bool(np.array_equal(ccounts, counts[:n])),
+                                              "mid_occ_equal": bool(cmid == st["mid_occ"])}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

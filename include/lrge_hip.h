@@ -1,0 +1,170 @@
+/*
+ * lrge_hip.h -- C ABI of the MI355X-native overlap engine (liblrge_hip.so).
+ *
+ * Drop-in boundary for liblrge's overlap hot path.  The reference crosses its FFI seam once per
+ * read (mm_map); a GPU wants batches, so each entry point below replaces a *group* of reference
+ * calls.  All functions return 0 on success or a negative LRGE_ERR_* code; the message for the
+ * last failure on a context is returned by lrge_hip_last_error().  Caller owns every input and
+ * output buffer; the library owns the ctx / seqset / index handles (free with *_free/_destroy).
+ * No callee-allocated memory crosses the ABI.  A ctx serves one call at a time.
+ *
+ * Reference interfaces replaced (paths under /root/reference/liblrge/src):
+ *   lrge_hip_ctx_create        <- ThreadLocalBuffer / mm_tbuf_init (minimap2/thread_buf.rs:7-42)
+ *   lrge_hip_seqset_upload     <- the (name, seq) records fed to Aligner::map / the FASTA read by
+ *                                 mm_idx_reader_read (twoset.rs:216-241, minimap2/aligner.rs:171-185)
+ *   lrge_hip_index_build       <- AlignerWrapper::new -> Aligner::builder/preset/dual/with_index
+ *                                 (minimap2/aligner.rs:310-328, :53-122, :144-197): mm_set_opt,
+ *                                 mm_idx_reader_open/read/close, mm_mapopt_update
+ *   lrge_hip_overlap_twoset    <- TwoSetStrategy::align_reads (twoset.rs:204-367): per-read
+ *                                 Aligner::map (aligner.rs:204-303) + distinct-target counting
+ *   lrge_hip_overlap_inverse   <- TwoSetStrategy::align_reads_inverse (twoset.rs:370-584)
+ *   lrge_hip_overlap_ava       <- AvaStrategy::align_reads (ava.rs:165-366)
+ *   lrge_hip_estimates         <- estimate::per_read_estimate (estimate.rs:142-157)
+ *   lrge_hip_median            <- estimate::median + calculate_quantile (estimate.rs:80-132)
+ *   lrge_hip_chains            <- the Vec<PafRecord> of Aligner::map (aligner.rs:244-291,
+ *                                 minimap2/mapping.rs:10-54), batched
+ */
+#ifndef LRGE_HIP_H
+#define LRGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes map 1:1 onto LrgeError variants (error.rs:6-33) */
+#define LRGE_OK                 0
+#define LRGE_ERR_IO            -1  /* IoError */
+#define LRGE_ERR_PARSE         -2  /* FastqParseError */
+#define LRGE_ERR_TOO_MANY      -3  /* TooManyReadsError */
+#define LRGE_ERR_TOO_FEW       -4  /* TooFewReadsError */
+#define LRGE_ERR_DEVICE        -5  /* ThreadError class: HIP runtime / device failures */
+#define LRGE_ERR_MAP           -6  /* MapError: "No index" / "Sequence is empty" (aligner.rs:210-216) */
+#define LRGE_ERR_DUPLICATE_ID  -7  /* DuplicateReadIdentifier (ava.rs:195-199, twoset.rs:439-449) */
+#define LRGE_ERR_PAF_WRITE     -8  /* PafWriteError */
+#define LRGE_ERR_INVALID       -9  /* bad argument (no reference equivalent: would not compile in Rust) */
+
+#define LRGE_PRESET_AVA_ONT 0   /* Preset::AvaOnt, "-k15 -Xw5 -e0 -m100 -r2k" (preset.rs:26) */
+#define LRGE_PRESET_AVA_PB  1   /* Preset::AvaPb,  "-Hk19 -Xw5 -e0 -m100"     (preset.rs:24) */
+
+typedef struct lrge_hip_ctx    lrge_hip_ctx;
+typedef struct lrge_hip_seqset lrge_hip_seqset;
+typedef struct lrge_hip_index  lrge_hip_index;
+
+/* Builder knobs that reach the hot path (twoset/builder.rs:41-185, ava/builder.rs:38-153). */
+typedef struct {
+    int32_t remove_internal;     /* -F: drop overlaps the reference calls "internal" */
+    float   max_overhang_ratio;  /* --max-overhang-ratio, default 0.2 (cli.rs:7) */
+} lrge_hip_params;
+
+/* One chain = one mm_reg1_t = one PafRecord (aligner.rs:253-290). */
+typedef struct {
+    uint32_t query;      /* index of the query read in its seqset */
+    uint32_t target;     /* rid: index of the target read in the indexed seqset */
+    int32_t  rev;        /* strand: 0 '+', 1 '-' */
+    int32_t  score;      /* s1 */
+    int32_t  cnt;        /* cm */
+    int32_t  qs, qe;     /* query_start / query_end */
+    int32_t  rs, re;     /* target_start / target_end */
+    int32_t  mlen, blen; /* match_len / block_len */
+    int32_t  reserved;
+} lrge_hip_chain;
+
+/* Stage timings of the last overlap/index call on a ctx, in milliseconds (HIP events on the
+   ctx stream).  Index into the array with LRGE_T_*. */
+enum {
+    LRGE_T_PACK = 0, LRGE_T_SKETCH, LRGE_T_INDEX_SORT, LRGE_T_INDEX_TABLE, LRGE_T_QFILTER,
+    LRGE_T_LOOKUP, LRGE_T_EXPAND, LRGE_T_ANCHOR_SORT, LRGE_T_GROUP, LRGE_T_CHAIN /* k_chain_lds launches */,
+    LRGE_T_CHAIN_GLB /* k_chain_glb launches */, LRGE_T_COUNT, LRGE_T_TOTAL, LRGE_T_N
+};
+/* Work counters of the last overlap call (for the roofline's algorithmic bytes). */
+enum {
+    LRGE_C_QUERY_BASES = 0, LRGE_C_QUERY_MINIMIZERS, LRGE_C_ANCHORS, LRGE_C_GROUPS,
+    LRGE_C_GROUPS_CHAINED, LRGE_C_CHAIN_LAUNCHES /* k_chain_lds */, LRGE_C_BATCHES,
+    LRGE_C_CHAIN_ANCHORS /* anchors read by k_chain_lds */, LRGE_C_CHAIN_GLB_LAUNCHES, LRGE_C_CHAIN_GLB_ANCHORS,
+    LRGE_C_N
+};
+
+int  lrge_hip_device_count(int *n);
+int  lrge_hip_ctx_create(int device, lrge_hip_ctx **out);
+void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx);
+const char *lrge_hip_last_error(const lrge_hip_ctx *ctx);
+
+/*
+ * Upload a read set and pack it 2-bit (+ ambiguity mask) in HBM.
+ *   bases     concatenated ASCII sequence bytes, offsets[n] bytes
+ *   offsets   n+1 byte offsets into bases
+ *   name_rank n lexicographic ranks of the read identifiers (header up to first whitespace,
+ *             io.rs:199-204) computed over the UNION of all sets that will meet in one overlap
+ *             call; equal names <=> equal rank.  Replaces strcmp(qname, tname) in minimap2's
+ *             skip_seed and the name keys of liblrge's HashSet/HashMap.  NULL = all distinct.
+ */
+int  lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, const uint64_t *offsets,
+                            uint32_t n, const uint32_t *name_rank, lrge_hip_seqset **out);
+void lrge_hip_seqset_free(lrge_hip_seqset *s);
+uint32_t lrge_hip_seqset_size(const lrge_hip_seqset *s);
+
+/* Build the minimizer index over `targets` with the given preset (also fixes mid_occ). */
+int  lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset,
+                          lrge_hip_index **out);
+void lrge_hip_index_free(lrge_hip_index *ix);
+int  lrge_hip_index_stats(const lrge_hip_index *ix, uint64_t *n_minimizers, uint64_t *n_keys,
+                          int32_t *mid_occ);
+
+/*
+ * Two-set forward (dual = yes).  counts[q] = number of distinct target names among the kept
+ * mappings of query q (twoset.rs:286-302); has_mapping[q] = 1 unless mappings.is_empty()
+ * (twoset.rs:303-309).  Both arrays have lrge_hip_seqset_size(queries) entries.
+ * A zero-length query is LRGE_ERR_MAP ("Sequence is empty").
+ */
+int  lrge_hip_overlap_twoset(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
+                             const lrge_hip_seqset *queries, const lrge_hip_params *p,
+                             uint32_t *counts, uint32_t *has_mapping);
+/*
+ * Inverse two-set (--use-min-ref): `ix` indexes the QUERY set, `streamed` is the target set.
+ * counts[i] (one per indexed read) += 1 for every streamed read with a kept mapping onto it
+ * (twoset.rs:485-524).  Duplicate identifiers among the indexed reads: LRGE_ERR_DUPLICATE_ID.
+ */
+int  lrge_hip_overlap_inverse(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
+                              const lrge_hip_seqset *streamed, const lrge_hip_params *p,
+                              uint32_t *counts);
+/*
+ * All-vs-all (dual = no): `ix` must index `reads` itself.  counts[i] = symmetric overlap count
+ * (ava.rs:271-306).  Duplicate identifiers: LRGE_ERR_DUPLICATE_ID.
+ */
+int  lrge_hip_overlap_ava(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
+                          const lrge_hip_seqset *reads, const lrge_hip_params *p,
+                          uint32_t *counts);
+
+/* Every chain of every query (the PafRecord stream), unordered.  *n_out receives the number of
+   chains found; only the first `cap` are written.  dual: 1 = two-set flags, 0 = AVA flags. */
+int  lrge_hip_chains(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries,
+                     int dual, lrge_hip_chain *out, uint64_t cap, uint64_t *n_out);
+
+/* per_read_estimate over n reads on the device (f32, no contraction). out[i] = +inf if counts[i]==0 */
+int  lrge_hip_estimates(lrge_hip_ctx *ctx, const uint32_t *counts, const uint32_t *read_lens,
+                        uint32_t n, float avg_target_len, uint64_t n_target_reads,
+                        uint32_t overlap_thresh, float *out);
+/* Host tail: median and optional quantiles of the (finite) estimates.  has_* mirror Option<f32>.
+   out = {lower, median, upper}, ok[i] = 1 if that slot is Some. */
+int  lrge_hip_median(const float *estimates, uint64_t n, int finite, int has_lower, float lower_q,
+                     int has_upper, float upper_q, float out[3], int ok[3]);
+
+/* Stage-level introspection (parity tests, profiling). */
+int  lrge_hip_sketch_dump(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, int preset, uint64_t *x,
+                          uint64_t *y, uint64_t cap, uint64_t *n_out);
+int  lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, uint64_t *keys,
+                         uint64_t *pos, uint64_t cap, uint64_t *n_out);
+int  lrge_hip_anchors_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
+                           const lrge_hip_seqset *queries, int dual, uint32_t query, uint64_t *x,
+                           uint64_t *y, uint64_t cap, uint64_t *n_out);
+int  lrge_hip_last_timings(const lrge_hip_ctx *ctx, float ms[LRGE_T_N]);
+int  lrge_hip_last_counters(const lrge_hip_ctx *ctx, uint64_t c[LRGE_C_N]);
+const char *lrge_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

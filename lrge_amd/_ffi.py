@@ -1,0 +1,87 @@
+"""ctypes binding of include/lrge_hip.h.  There is no CPU fallback: if liblrge_hip.so is missing
+or no HIP device is usable, every compute entry point raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB_PATH
+
+OK = 0
+ERR_IO, ERR_PARSE, ERR_TOO_MANY, ERR_TOO_FEW, ERR_DEVICE, ERR_MAP, ERR_DUPLICATE_ID, ERR_PAF_WRITE, ERR_INVALID = \
+    -1, -2, -3, -4, -5, -6, -7, -8, -9
+PRESET_AVA_ONT, PRESET_AVA_PB = 0, 1
+
+T_NAMES = ["pack", "sketch", "index_sort", "index_table", "qfilter", "lookup", "expand", "anchor_sort", "group",
+           "chain", "chain_glb", "count", "total"]
+C_NAMES = ["query_bases", "query_minimizers", "anchors", "groups", "groups_chained", "chain_launches", "batches",
+           "chain_anchors", "chain_glb_launches", "chain_glb_anchors"]
+
+EXPORTS = [
+    "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error",
+    "lrge_hip_seqset_upload", "lrge_hip_seqset_free", "lrge_hip_seqset_size",
+    "lrge_hip_index_build", "lrge_hip_index_free", "lrge_hip_index_stats",
+    "lrge_hip_overlap_twoset", "lrge_hip_overlap_inverse", "lrge_hip_overlap_ava", "lrge_hip_chains",
+    "lrge_hip_estimates", "lrge_hip_median",
+    "lrge_hip_sketch_dump", "lrge_hip_index_dump", "lrge_hip_anchors_dump",
+    "lrge_hip_last_timings", "lrge_hip_last_counters", "lrge_hip_version",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("remove_internal", C.c_int32), ("max_overhang_ratio", C.c_float)]
+
+
+CHAIN = np.dtype([("query", "<u4"), ("target", "<u4"), ("rev", "<i4"), ("score", "<i4"), ("cnt", "<i4"),
+                  ("qs", "<i4"), ("qe", "<i4"), ("rs", "<i4"), ("re", "<i4"), ("mlen", "<i4"), ("blen", "<i4"),
+                  ("reserved", "<i4")])
+
+_lib = None
+
+
+class LrgeHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lrge_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load liblrge_hip.so (built in-tree by lrge_amd.build / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("liblrge_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                           "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.lrge_hip_version.restype = C.c_char_p
+    L.lrge_hip_last_error.restype = C.c_char_p
+    L.lrge_hip_last_error.argtypes = [vp]
+    L.lrge_hip_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.lrge_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.lrge_hip_ctx_destroy.argtypes = [vp]
+    L.lrge_hip_ctx_destroy.restype = None
+    L.lrge_hip_seqset_upload.argtypes = [vp, vp, vp, C.c_uint32, vp, C.POINTER(vp)]
+    L.lrge_hip_seqset_free.argtypes = [vp]
+    L.lrge_hip_seqset_free.restype = None
+    L.lrge_hip_seqset_size.argtypes = [vp]
+    L.lrge_hip_seqset_size.restype = C.c_uint32
+    L.lrge_hip_index_build.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.lrge_hip_index_free.argtypes = [vp]
+    L.lrge_hip_index_free.restype = None
+    L.lrge_hip_index_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    L.lrge_hip_overlap_twoset.argtypes = [vp, vp, vp, C.POINTER(Params), vp, vp]
+    L.lrge_hip_overlap_inverse.argtypes = [vp, vp, vp, C.POINTER(Params), vp]
+    L.lrge_hip_overlap_ava.argtypes = [vp, vp, vp, C.POINTER(Params), vp]
+    L.lrge_hip_chains.argtypes = [vp, vp, vp, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.lrge_hip_estimates.argtypes = [vp, vp, vp, C.c_uint32, C.c_float, C.c_uint64, C.c_uint32, vp]
+    L.lrge_hip_median.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
+                                  C.POINTER(C.c_float * 3), C.POINTER(C.c_int * 3)]
+    L.lrge_hip_sketch_dump.argtypes = [vp, vp, C.c_int, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.lrge_hip_index_dump.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.lrge_hip_anchors_dump.argtypes = [vp, vp, vp, C.c_int, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.lrge_hip_last_timings.argtypes = [vp, C.POINTER(C.c_float * len(T_NAMES))]
+    L.lrge_hip_last_counters.argtypes = [vp, C.POINTER(C.c_uint64 * len(C_NAMES))]
+    _lib = L
+    return L

@@ -1,0 +1,187 @@
+// internal.h -- shared host-side structures of liblrge_hip (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lrge_hip.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef int64_t i64;
+typedef int32_t i32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+#define WAVE 64
+
+// Effective minimap2 parameters for one preset (mm2:options.c).
+struct Preset {
+    int k, w, hpc;
+    int bw, max_gap, max_skip, max_iter, min_cnt, min_sc;
+    int min_mid_occ, max_mid_occ;
+    float mid_occ_frac, q_occ_frac;
+    float pen_gap, pen_skip;  // chain_gap_scale*0.01*k evaluated in double then narrowed
+};
+
+inline Preset make_preset(int preset) {
+    Preset p;
+    p.w = 5; p.max_gap = 5000; p.max_skip = 25; p.max_iter = 5000; p.min_cnt = 3; p.min_sc = 100;
+    p.min_mid_occ = 10; p.max_mid_occ = 1000000; p.mid_occ_frac = 2e-4f; p.q_occ_frac = 0.01f;
+    if (preset == LRGE_PRESET_AVA_PB) { p.k = 19; p.hpc = 1; p.bw = 500; }
+    else { p.k = 15; p.hpc = 0; p.bw = 2000; }
+    p.pen_gap = (float)((double)0.8f * 0.01 * (double)p.k);
+    p.pen_skip = (float)((double)0.0f * 0.01 * (double)p.k);
+    return p;
+}
+
+// Caching device allocator: blocks are reused across calls, freed when the ctx dies.
+struct DevPool {
+    struct Blk { void *p; size_t cap; bool used; };
+    std::vector<Blk> blks;
+    size_t total = 0;
+    void *alloc(size_t bytes, hipError_t *err) {
+        if (bytes == 0) bytes = 256;
+        bytes = (bytes + 255) & ~(size_t)255;
+        int best = -1;
+        for (size_t i = 0; i < blks.size(); ++i)
+            if (!blks[i].used && blks[i].cap >= bytes && (best < 0 || blks[i].cap < blks[best].cap)) best = (int)i;
+        if (best >= 0 && blks[best].cap <= bytes * 2 + (1 << 20)) { blks[best].used = true; return blks[best].p; }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {  // drop the cache and retry once
+            trim();
+            e = hipMalloc(&p, bytes);
+        }
+        if (e != hipSuccess) { *err = e; return nullptr; }
+        blks.push_back({p, bytes, true});
+        total += bytes;
+        return p;
+    }
+    void release(void *p) {
+        if (!p) return;
+        for (auto &b : blks) if (b.p == p) { b.used = false; return; }
+    }
+    void trim() {
+        std::vector<Blk> keep;
+        for (auto &b : blks) { if (b.used) keep.push_back(b); else { (void)hipFree(b.p); total -= b.cap; } }
+        blks.swap(keep);
+    }
+    void destroy() { for (auto &b : blks) (void)hipFree(b.p); blks.clear(); total = 0; }
+};
+
+struct lrge_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    DevPool pool;
+    float ms[LRGE_T_N];
+    u64 counters[LRGE_C_N];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cu = 256;
+};
+
+struct lrge_hip_seqset {
+    lrge_hip_ctx *ctx;
+    u32 n = 0;
+    u64 total_bases = 0;
+    u64 n_words = 0;            // 32-base words in the packed image (reads start on a word)
+    u32 max_len = 0;
+    bool has_empty = false;
+    bool has_rank = false;
+    bool dup_rank = false;      // two reads share a rank (duplicate identifier)
+    // device
+    u64 *d_pack = nullptr;      // 2-bit codes, 32 bases per word, base i at bits [2i,2i+1]
+    u32 *d_nmask = nullptr;     // 1 bit per base: non-ACGTU
+    u64 *d_woff = nullptr;      // [n+1] word offset of each read
+    u32 *d_len = nullptr;       // [n]
+    u32 *d_rank = nullptr;      // [n]
+    // host copies needed for planning
+    std::vector<u64> h_woff;
+    std::vector<u32> h_len;
+    std::vector<u32> h_rank;
+};
+
+struct lrge_hip_index {
+    lrge_hip_ctx *ctx;
+    const lrge_hip_seqset *seqs;
+    int preset_id;
+    Preset P;
+    u64 n_mz = 0, n_keys = 0;
+    int mid_occ = 0;
+    u64 *d_pos = nullptr;       // [n_mz] y values grouped by key, ascending within a key
+    u64 *d_skey = nullptr;      // [n_mz] sorted keys (kept for index_dump / tests)
+    u64 *d_ht_key = nullptr;    // open-addressing table
+    u64 *d_ht_val = nullptr;    // start<<24 | min(count, 2^24-1)
+    u64 ht_mask = 0;
+};
+
+#define LRGE_SET_ERR(ctx, ...)                                  \
+    do {                                                        \
+        char _b[512];                                           \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                  \
+        (ctx)->err = _b;                                        \
+    } while (0)
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            LRGE_SET_ERR(ctx, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__,   \
+                         __LINE__, #call);                                                     \
+            return LRGE_ERR_DEVICE;                                                            \
+        }                                                                                      \
+    } while (0)
+
+#define KCHK(ctx) HIPCHK(ctx, hipGetLastError())
+
+// RAII list of pool allocations released at scope exit.
+struct Scratch {
+    lrge_hip_ctx *ctx;
+    std::vector<void *> ptrs;
+    explicit Scratch(lrge_hip_ctx *c) : ctx(c) {}
+    ~Scratch() { for (void *p : ptrs) ctx->pool.release(p); }
+    template <typename T> T *get(size_t n) {
+        hipError_t e = hipSuccess;
+        void *p = ctx->pool.alloc(n * sizeof(T), &e);
+        if (!p) { LRGE_SET_ERR(ctx, "device allocation of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e)); return nullptr; }
+        ptrs.push_back(p);
+        return (T *)p;
+    }
+    void drop(void *p) {
+        for (size_t i = 0; i < ptrs.size(); ++i) if (ptrs[i] == p) { ptrs.erase(ptrs.begin() + i); break; }
+        ctx->pool.release(p);
+    }
+    // hand ownership to the caller (not released at scope exit)
+    void keep(void *p) {
+        for (size_t i = 0; i < ptrs.size(); ++i) if (ptrs[i] == p) { ptrs.erase(ptrs.begin() + i); break; }
+    }
+};
+
+#define ALLOC_OR_FAIL(var, sc, T, n)                  \
+    T *var = (sc).get<T>(n);                          \
+    if (!var) return LRGE_ERR_DEVICE;
+
+struct StageTimer {
+    lrge_hip_ctx *ctx;
+    int slot;
+    hipEvent_t a, b;
+    StageTimer(lrge_hip_ctx *c, int s) : ctx(c), slot(s) {
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, ctx->stream);
+    }
+    void stop() {
+        (void)hipEventRecord(b, ctx->stream);
+        (void)hipEventSynchronize(b);
+        float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+        ctx->ms[slot] += ms;
+    }
+    ~StageTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+};
+
+static inline u32 ceil_log2_u64(u64 v) { u32 b = 0; while (b < 64 && (1ULL << b) < v) ++b; return b; }
+static inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }

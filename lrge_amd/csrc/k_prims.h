@@ -1,0 +1,210 @@
+// k_prims.h -- device-wide exclusive scan and stable LSD radix sort (64-bit key, 64-bit value),
+// written for gfx950: 64-lane wavefronts, ballot-based digit matching, LDS counters.
+#pragma once
+#include "internal.h"
+
+// ------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ULL << lane_id()) - 1ULL; }
+
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 o = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of u32 (n < 2^32, totals < 2^32).  SCAN_TILE items per 256-thread block.
+// ------------------------------------------------------------------------------------------
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 16
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const u32 *in, u64 n, u32 *block_sums) {
+    __shared__ u32 wsum[SCAN_THREADS / 64];
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) s += in[base + i];
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) t += wsum[w];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+// single block: in-place exclusive scan of up to any n (loops), writes total to *total
+__global__ __launch_bounds__(1024) void k_scan_small(u32 *data, u32 n, u32 *total) {
+    __shared__ u32 wsum[16];
+    __shared__ u32 carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 base = 0; base < n; base += 1024) {
+        u32 i = base + threadIdx.x;
+        u32 v = i < n ? data[i] : 0;
+        u32 inc = wave_incl_scan_u32(v);
+        if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        u32 woff = 0;
+        for (u32 w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
+        u32 carry = carry_s;
+        if (i < n) data[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32 *in, u32 *out, u64 n, const u32 *block_offs,
+                                                            u32 *total) {
+    __shared__ u32 wsum[SCAN_THREADS / 64];
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 v[SCAN_ITEMS];
+    u32 s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = base + i < n ? in[base + i] : 0; s += v[i]; }
+    u32 inc = wave_incl_scan_u32(s);
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u32 off = block_offs[blockIdx.x];
+    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
+    off += inc - s;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) out[base + i] = off; off += v[i]; }
+    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total = off;
+}
+
+// out may alias in.  d_total (device u32) receives the grand total (may be null).
+static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32 *out, u64 n, u32 *d_total) {
+    if (n == 0) {
+        if (d_total) HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, ctx->stream));
+        return LRGE_OK;
+    }
+    u64 nb = div_up(n, SCAN_TILE);
+    ALLOC_OR_FAIL(bs, sc, u32, nb + 1);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((u32)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, n, bs);
+    KCHK(ctx);
+    if (nb <= 8192) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, bs, (u32)nb, (u32 *)nullptr);
+        KCHK(ctx);
+    } else {
+        int rc = scan_exclusive_u32(ctx, sc, bs, bs, nb, nullptr);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_scan_apply, dim3((u32)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, bs, d_total);
+    KCHK(ctx);
+    sc.drop(bs);
+    return LRGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stable LSD radix sort, 8 bits per pass.  Tile order inside a block is wave-major:
+//   item(tile, w, r, lane) = tile*RS_TILE + w*RS_ITEMS*64 + r*64 + lane
+// so that per-wave running digit counters give a stable rank.
+// ------------------------------------------------------------------------------------------
+#define RS_THREADS 256
+#define RS_WAVES (RS_THREADS / 64)
+#define RS_ITEMS 16
+#define RS_TILE (RS_THREADS * RS_ITEMS)
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
+                                                        u32 *__restrict__ hist) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    u64 base = (u64)blockIdx.x * RS_TILE + (u64)(threadIdx.x >> 6) * (RS_ITEMS * 64) + lane_id();
+#pragma unroll 4
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        u64 i = base + (u64)r * 64;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    hist[(u64)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict__ keys_in, const u64 *__restrict__ vals_in,
+                                                           u64 *__restrict__ keys_out, u64 *__restrict__ vals_out, u64 n,
+                                                           int shift, u32 nb, const u32 *__restrict__ hist_scanned) {
+    __shared__ u32 cnt[RS_WAVES][256];
+    const u32 w = threadIdx.x >> 6, lane = lane_id();
+    for (u32 i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    u64 base = (u64)blockIdx.x * RS_TILE + (u64)w * (RS_ITEMS * 64) + lane;
+    u64 k[RS_ITEMS];
+    u32 rank[RS_ITEMS];
+    const u64 lt = lanemask_lt();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        u64 i = base + (u64)r * 64;
+        bool valid = i < n;
+        k[r] = valid ? keys_in[i] : ~0ULL;
+        u32 d = (u32)(k[r] >> shift) & 255;
+        u64 m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            u64 bal = __ballot((d >> b) & 1);
+            m &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        // m = lanes (valid) with my digit
+        u32 before = (u32)__popcll(m & lt);
+        u32 leader = (u32)__ffsll((unsigned long long)m) - 1;
+        u32 old = 0;
+        if (valid && lane == leader) { old = cnt[w][d]; cnt[w][d] = old + (u32)__popcll(m); }
+        old = __shfl(old, valid ? leader : lane, 64);
+        rank[r] = old + before;
+    }
+    __syncthreads();
+    {   // thread d: turn per-wave totals into global destinations
+        u32 d = threadIdx.x;
+        u32 run = hist_scanned[(u64)d * nb + blockIdx.x];
+#pragma unroll
+        for (int ww = 0; ww < RS_WAVES; ++ww) { u32 t = cnt[ww][d]; cnt[ww][d] = run; run += t; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        u64 i = base + (u64)r * 64;
+        if (i < n) {
+            u32 d = (u32)(k[r] >> shift) & 255;
+            u32 dst = cnt[w][d] + rank[r];
+            keys_out[dst] = k[r];
+            vals_out[dst] = vals_in[i];
+        }
+    }
+}
+
+// Sorts (keys, vals) by bits [begin_bit, begin_bit + nbits) of the key (rounded up to whole bytes).  Ping-pongs between (k0,v0) and (k1,v1);
+// *res_k / *res_v point at the buffers holding the result.
+static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u64 *k1, u64 *v1, u64 n, int begin_bit,
+                            int nbits, u64 **res_k, u64 **res_v) {
+    *res_k = k0; *res_v = v0;
+    if (n <= 1 || nbits <= 0) return LRGE_OK;
+    if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
+    u32 nb = (u32)div_up(n, RS_TILE);
+    ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * nb);
+    int passes = (nbits + 7) / 8;
+    u64 *ki = k0, *vi = v0, *ko = k1, *vo = v1;
+    for (int p = 0; p < passes; ++p) {
+        int shift = begin_bit + p * 8;
+        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist);
+        KCHK(ctx);
+        u64 *t = ki; ki = ko; ko = t;
+        t = vi; vi = vo; vo = t;
+    }
+    sc.drop(hist);
+    *res_k = ki; *res_v = vi;
+    return LRGE_OK;
+}

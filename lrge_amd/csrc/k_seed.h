@@ -1,0 +1,163 @@
+// k_seed.h -- query-side seeding: K4a query occurrence filter (mm_seed_mz_flt), K3 lookup +
+// mid_occ filter (mm_seed_collect_all / mm_collect_matches with occ_dist = 0), K4 expansion into
+// anchors with skip_seed (mm2:map.c collect_seed_hits), group discovery on the sorted anchors.
+#pragma once
+#include "internal.h"
+#include "k_index.h"
+
+struct KeyLayout {      // composite anchor sort key: qlocal | rid | rev | rpos
+    u32 bits_rpos, bits_rid, bits_q;
+    __host__ __device__ u32 sh_rev() const { return bits_rpos; }
+    __host__ __device__ u32 sh_rid() const { return bits_rpos + 1; }
+    __host__ __device__ u32 sh_q() const { return bits_rpos + 1 + bits_rid; }
+    __host__ __device__ u32 total() const { return bits_rpos + 1 + bits_rid + bits_q; }
+};
+
+struct SeedParams {
+    const u64 *ht_key, *ht_val; u64 ht_mask;
+    const u64 *pos;            // index position lists
+    const u32 *t_len, *t_rank; // indexed reads
+    const u32 *q_len, *q_rank; // query reads
+    int mid_occ;
+    int check_names;           // both sets carry ranks
+    int no_dual;               // MM_F_NO_DUAL (AVA)
+};
+
+// K3: one lane per query minimizer.  hn = raw list length (0 when absent, filtered by mid_occ, or
+// removed by the query occurrence filter), hv = hits that survive skip_seed.
+__global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 n_mz,
+                                                SeedParams sp, u32 *__restrict__ hs, u32 *__restrict__ hn,
+                                                u32 *__restrict__ hv) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_mz) return;
+    u64 x = qx[i];
+    u32 n = 0, v = 0; u64 st = 0;
+    if (x != 0) {  // x == 0: removed by k_qocc_mark
+        u32 cnt;
+        if (ht_lookup(sp.ht_key, sp.ht_val, sp.ht_mask, x >> 8, &st, &cnt)) {
+            if ((i64)cnt <= (i64)sp.mid_occ) n = cnt;  // m[i].n > max_occ -> flt
+        }
+    }
+    v = n;
+    if (n && sp.check_names) {
+        u64 y = qy[i];
+        u32 q = (u32)(y >> 32), qpos = (u32)y >> 1;
+        u32 qr = sp.q_rank[q], ql = sp.q_len[q];
+        v = 0;
+        for (u32 j = 0; j < n; ++j) {
+            u64 r = sp.pos[st + j];
+            u32 rid = (u32)(r >> 32);
+            u32 tr = sp.t_rank[rid];
+            bool skip = false;
+            if (qr == tr && sp.t_len[rid] == ql && ((u32)r >> 1) == qpos) skip = true;  // NO_DIAG, exact diagonal
+            if (sp.no_dual && qr > tr) skip = true;                                     // NO_DUAL, cmp > 0
+            v += skip ? 0 : 1;
+        }
+    }
+    hs[i] = (u32)st; hn[i] = n; hv[i] = v;
+}
+
+// per-query sum of hv (one wave per query)
+__global__ __launch_bounds__(256) void k_query_anchor_totals(const u32 *__restrict__ hv, const u32 *__restrict__ qmz_off,
+                                                             u32 nq, u32 *__restrict__ totals) {
+    u32 q = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    u32 b = qmz_off[q], e = qmz_off[q + 1];
+    u32 s = 0;
+    for (u32 i = b + lane_id(); i < e; i += 64) s += hv[i];
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if (lane_id() == 0) totals[q] = s;
+}
+
+// K4: one lane per query minimizer of the batch; writes (key, val) anchors at aoff[i].
+__global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 mz_begin,
+                                                u64 mz_end, SeedParams sp, const u32 *__restrict__ hs,
+                                                const u32 *__restrict__ hn, const u32 *__restrict__ aoff, u32 q0,
+                                                KeyLayout kl, u64 *__restrict__ akey, u64 *__restrict__ aval) {
+    u64 i = mz_begin + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mz_end) return;
+    u32 n = hn[i];
+    if (n == 0) return;
+    u64 x = qx[i], y = qy[i];
+    u32 q = (u32)(y >> 32), qpos = (u32)y >> 1, qstrand = (u32)y & 1, span = (u32)x & 0xff;
+    u32 ql = sp.q_len[q];
+    u32 qr = sp.check_names ? sp.q_rank[q] : 0;
+    u64 st = hs[i];
+    u32 o = aoff[i - mz_begin];
+    u64 qpart = (u64)(q - q0) << kl.sh_q();
+    u32 yq_rev = ql - (qpos + 1 - span) - 1;
+    for (u32 j = 0; j < n; ++j) {
+        u64 r = sp.pos[st + j];
+        u32 rid = (u32)(r >> 32), rpos = (u32)r >> 1;
+        u64 self = 0;
+        if (sp.check_names) {
+            u32 tr = sp.t_rank[rid];
+            if (qr == tr && sp.t_len[rid] == ql) {
+                if (rpos == qpos) continue;
+                if (((u32)r & 1) == qstrand) self = 1ULL << 43;  // MM_SEED_SELF (unused by chaining)
+            }
+            if (sp.no_dual && qr > tr) continue;
+        }
+        bool rev = ((u32)r & 1) != qstrand;
+        akey[o] = qpart | (u64)rid << kl.sh_rid() | (u64)(rev ? 1 : 0) << kl.sh_rev() | rpos;
+        aval[o] = self | (u64)span << 32 | (rev ? yq_rev : qpos);
+        ++o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4a: query occurrence filter.  Pairs (q<<40-ish | x) are sorted by the host wrapper; here a run of
+// identical (q, x) longer than both thresholds zeroes qx of all its members.
+// ------------------------------------------------------------------------------------------
+__global__ void k_qocc_keys(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 n, u64 *__restrict__ k_hi,
+                            u64 *__restrict__ v_idx) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    k_hi[i] = qx[i];
+    v_idx[i] = (qy[i] >> 32) << 32 | (u32)i;  // value carries (query, original index); needs n < 2^32
+}
+
+// After a stable sort by x (bits 0..2k+8) and then by query (value hi) -- done as two key sorts --
+// runs of equal (query, x) are adjacent.  One lane per element finds its run by scanning (runs are
+// short except for the pathological ones this filter exists for, so the heads do the work).
+__global__ void k_qocc_mark(const u64 *__restrict__ sx, const u64 *__restrict__ sv, u64 n,
+                            const u32 *__restrict__ qmz_off, int mid_occ, float q_occ_frac, u64 *__restrict__ qx) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 x = sx[i]; u32 q = (u32)(sv[i] >> 32);
+    if (i > 0 && sx[i - 1] == x && (u32)(sv[i - 1] >> 32) == q) return;  // not a run head
+    u64 j = i + 1;
+    while (j < n && sx[j] == x && (u32)(sv[j] >> 32) == q) ++j;
+    i32 cnt = (i32)(j - i);
+    u32 nq = qmz_off[q + 1] - qmz_off[q];
+    if ((i64)nq <= (i64)mid_occ) return;                                   // mv->n <= q_occ_max: filter off
+    if (cnt > mid_occ && (float)cnt > (float)(u64)nq * q_occ_frac)
+        for (u64 t = i; t < j; ++t) qx[(u32)sv[t]] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// groups on the sorted anchors: a group = one (query, target, strand)
+// ------------------------------------------------------------------------------------------
+__global__ void k_group_heads(const u64 *__restrict__ skey, u64 n, u32 bits_rpos, u32 *__restrict__ head) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (i == 0 || (skey[i] >> bits_rpos) != (skey[i - 1] >> bits_rpos)) ? 1u : 0u;
+}
+
+#define N_BINS 5
+struct BinLimits { u32 lim[N_BINS]; };  // bin b holds groups with n <= lim[b] (last = unbounded)
+
+__global__ void k_group_bin(const u32 *__restrict__ gstart, u32 n_groups, u64 n_anchors, u32 min_n, BinLimits bl,
+                            u32 *__restrict__ bin_count, u32 *__restrict__ bin_list /* [N_BINS][n_groups] */,
+                            unsigned long long *__restrict__ bin_anchors) {
+    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    u64 e = (g + 1 < n_groups) ? gstart[g + 1] : n_anchors;
+    u32 n = (u32)(e - gstart[g]);
+    if (n < min_n) return;
+    int b = N_BINS - 1;
+    for (int t = N_BINS - 2; t >= 0; --t) if (n <= bl.lim[t]) b = t;
+    u32 slot = atomicAdd(&bin_count[b], 1u);
+    bin_list[(u64)b * n_groups + slot] = g;
+    atomicAdd(&bin_anchors[b], (unsigned long long)n);
+}

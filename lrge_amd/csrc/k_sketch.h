@@ -1,0 +1,255 @@
+// k_sketch.h -- K0 pack (ASCII -> 2-bit + ambiguity mask) and K1 minimizer sketch.
+//
+// K1 restates minimap2's mm_sketch (mm2:sketch.c; called from mm_idx_gen for targets and from
+// collect_minimizers inside mm_map for queries -- aligner.rs:181-185, :231-241) as a data-parallel
+// kernel: a read is cut into chunks of SK_CHUNK bases, one lane per chunk.  The sequential state of
+// mm_sketch at position i is a pure function of the last w+k-1 steps, so each lane replays a halo of
+// w+k-1 steps in front of its chunk and then emits exactly the minimizers the scalar loop would emit
+// for the steps it owns.  The w-entry window lives in registers as a shift register (w is a
+// template constant, so every index is static), which replaces the scalar code's ring buffer.
+#pragma once
+#include "internal.h"
+#include "k_prims.h"
+
+#define SK_CHUNK 128            // bases per lane
+#define SK_THREADS 256
+
+// ------------------------------------------------------------------------------------------
+// K0: one thread per 32-base word of the packed image
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 nt4_code(u8 c) {
+    // A/a=0 C/c=1 G/g=2 T/t/U/u=3 else 4 (mm2: seq_nt4_table)
+    u32 u = c & 0xDF;  // upper-case
+    u32 r = 4;
+    r = (u == 'A') ? 0 : r;
+    r = (u == 'C') ? 1 : r;
+    r = (u == 'G') ? 2 : r;
+    r = (u == 'T' || u == 'U') ? 3 : r;
+    // (c & 0xDF) maps a few non-letters onto letters ('!'..): only letters may match
+    bool is_alpha = (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
+    return is_alpha ? r : 4;
+}
+
+__global__ __launch_bounds__(256) void k_pack(const u8 *__restrict__ ascii, const u64 *__restrict__ boff,
+                                              const u64 *__restrict__ woff, u32 n_reads, u64 n_words,
+                                              u64 *__restrict__ pack, u32 *__restrict__ nmask) {
+    u64 wid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wid >= n_words) return;
+    // read r with woff[r] <= wid < woff[r+1]
+    u32 lo = 0, hi = n_reads;
+    while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (woff[mid] <= wid) lo = mid; else hi = mid; }
+    u32 r = lo;
+    u64 pos0 = (wid - woff[r]) * 32;
+    u64 len = boff[r + 1] - boff[r];
+    const u8 *src = ascii + boff[r] + pos0;
+    u64 w = 0; u32 m = 0;
+    u32 cnt = (u32)(len - pos0 < 32 ? len - pos0 : 32);
+    for (u32 i = 0; i < cnt; ++i) {
+        u32 c = nt4_code(src[i]);
+        w |= (u64)(c & 3) << (2 * i);
+        m |= (c >> 2) << i;
+    }
+    if (cnt < 32) m |= ~0u << cnt;  // padding past the end of the read is "ambiguous"
+    pack[wid] = w;
+    nmask[wid] = m;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mm_hash64(u64 key, u64 mask) {  // mm2:sketch.c:hash64
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+struct BaseReader {  // sequential reader over the packed image of one read
+    const u64 *pack; const u32 *nmask;
+    u64 wbase; u64 w; u32 m; i32 cur_word;
+    __device__ __forceinline__ void init(const u64 *p, const u32 *nm, u64 word_base) { pack = p; nmask = nm; wbase = word_base; cur_word = -1; w = 0; m = 0; }
+    __device__ __forceinline__ u32 get(i32 pos) {  // returns 0..3, or 4 for ambiguous
+        i32 wi = pos >> 5;
+        if (wi != cur_word) { cur_word = wi; w = pack[wbase + wi]; m = nmask[wbase + wi]; }
+        u32 sh = pos & 31;
+        return ((m >> sh) & 1) ? 4u : (u32)((w >> (2 * sh)) & 3);
+    }
+};
+
+template <int W>
+struct MinWindow {  // shift-register form of mm_sketch's ring buffer + running minimum
+    u64 wx[W], wy[W];
+    u64 minx, miny;
+    int mi;  // index of the current minimum inside the window (W-1 = newest), -1 = evicted
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < W; ++j) { wx[j] = ~0ULL; wy[j] = ~0ULL; }
+        minx = miny = ~0ULL; mi = 0;
+    }
+    // One step of the scalar loop after `info` was computed.  l is the valid-base count AFTER this
+    // step's increment.  emit(x,y) is called in exactly the scalar order.
+    template <int K, typename Emit>
+    __device__ __forceinline__ void step(u64 ix, u64 iy, int l, Emit &&emit) {
+        const bool evicted = (mi == 0);
+#pragma unroll
+        for (int j = 0; j + 1 < W; ++j) { wx[j] = wx[j + 1]; wy[j] = wy[j + 1]; }
+        wx[W - 1] = ix; wy[W - 1] = iy;
+        mi -= 1;
+        if (l == W + K - 1 && minx != ~0ULL) {  // first full window: flush identical minima
+#pragma unroll
+            for (int j = 0; j + 1 < W; ++j)
+                if (minx == wx[j] && wy[j] != miny) emit(wx[j], wy[j]);
+        }
+        if (ix <= minx) {
+            if (l >= W + K && minx != ~0ULL) emit(minx, miny);
+            minx = ix; miny = iy; mi = W - 1;
+        } else if (evicted) {
+            if (l >= W + K - 1 && minx != ~0ULL) emit(minx, miny);
+            minx = ~0ULL;
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+                if (minx >= wx[j]) { minx = wx[j]; miny = wy[j]; mi = j; }
+            if (l >= W + K - 1 && minx != ~0ULL) {
+#pragma unroll
+                for (int j = 0; j < W; ++j)
+                    if (minx == wx[j] && miny != wy[j]) emit(wx[j], wy[j]);
+            }
+        }
+    }
+};
+
+// Runs the state machine over one chunk.  Emission callback is only invoked for owned steps.
+template <int K, int W, bool HPC, typename Emit>
+__device__ __forceinline__ void sketch_chunk(const u64 *pack, const u32 *nmask, u64 word_base, i32 len, u32 rid,
+                                             i32 s, i32 e, Emit &&emit) {
+    constexpr u64 mask = (1ULL << (2 * K)) - 1;
+    constexpr int shift1 = 2 * (K - 1);
+    constexpr int HALO = W + K - 1;
+    BaseReader rd; rd.init(pack, nmask, word_base);
+    MinWindow<W> win; win.init();
+    u64 kf = 0, kr = 0;
+    int l = 0;
+    // HPC run-length queue of the last <=K runs (power-of-two ring)
+    u8 hq[HPC ? 32 : 1]; int hq_front = 0, hq_count = 0, kmer_span = 0;
+    (void)hq; (void)hq_front; (void)hq_count;
+
+    // ---- find the replay start h: HALO steps before the first owned step ----
+    i32 h;
+    if (!HPC) {
+        h = s - HALO; if (h < 0) h = 0;
+    } else {
+        // first owned step = first run (or N) that STARTS in [s, e)
+        i32 p = s;
+        if (p > 0) {  // skip the tail of a run that began before s
+            u32 prev = rd.get(p - 1);
+            if (prev < 4) { while (p < len && rd.get(p) == prev) ++p; }
+        }
+        if (p >= e || p >= len) {
+            // this chunk starts no step; it still owns the end-of-read flush if it holds the last base
+            if (!(e == len && s < len)) return;
+        }
+        s = p;  // first owned step start (may be >= e: then only the final flush can be ours)
+        // walk back HALO steps
+        h = s;
+        int steps = 0;
+        while (h > 0 && steps < HALO) {
+            u32 c = rd.get(h - 1);
+            --h;
+            if (c < 4) { while (h > 0 && rd.get(h - 1) == c) --h; }
+            ++steps;
+        }
+    }
+
+    i32 i = h;
+    while (i < len) {
+        if (i >= e) break;  // steps starting at or beyond e belong to later chunks
+        const i32 step_start = i;
+        u32 c = rd.get(i);
+        u64 ix = ~0ULL, iy = ~0ULL;
+        if (c < 4) {
+            if (HPC) {
+                i32 run = 1;
+                while (i + run < len && rd.get(i + run) == c) ++run;
+                i += run - 1;  // i = last base of the run
+                int rl = run > 255 ? 255 : run;  // spans >= 256 invalidate the k-mer anyway
+                hq[(hq_count++ + hq_front) & 31] = (u8)rl;
+                kmer_span += rl;
+                if (hq_count > K) { kmer_span -= hq[hq_front]; hq_front = (hq_front + 1) & 31; --hq_count; }
+            } else kmer_span = l + 1 < K ? l + 1 : K;
+            kf = (kf << 2 | c) & mask;
+            kr = (kr >> 2) | (u64)(3 ^ c) << shift1;
+            // K is odd for both presets, so kf == kr (strand-symmetric k-mer) cannot happen
+            const u32 z = kf < kr ? 0 : 1;
+            ++l; if (l > W + K) l = W + K;  // only thresholds up to W+K are ever tested
+            if (l >= K && kmer_span < 256) {
+                ix = mm_hash64(z ? kr : kf, mask) << 8 | (u64)kmer_span;
+                iy = (u64)rid << 32 | (u64)(u32)i << 1 | z;
+            }
+        } else { l = 0; hq_count = hq_front = 0; kmer_span = 0; }
+        const bool owned = step_start >= s;
+        win.template step<K>(ix, iy, l, [&](u64 x, u64 y) { if (owned) emit(x, y); });
+        ++i;
+    }
+    if (e == len && win.minx != ~0ULL) emit(win.minx, win.miny);  // final flush by the last chunk
+}
+
+// HPC clamps run lengths to 255 in the queue; a clamped run makes kmer_span >= 255+... only when
+// the true span is >= 256 too, except the single case span == 255 exactly built from one 255-run and
+// K-1 ... (impossible: K-1 >= 14 further runs add >= 14).  So `kmer_span < 256` is decided identically.
+
+struct ChunkMap {  // chunk id -> (read, first base)
+    const u32 *chunk_start;  // [n_reads+1] prefix of ceil(len/SK_CHUNK)
+    u32 n_reads;
+    __device__ __forceinline__ u32 find(u32 c) const {
+        u32 lo = 0, hi = n_reads;
+        while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (chunk_start[mid] <= c) lo = mid; else hi = mid; }
+        return lo;
+    }
+};
+
+template <int K, int W, bool HPC>
+__global__ __launch_bounds__(SK_THREADS) void k_sketch_count(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
+                                                            const u64 *__restrict__ woff, const u32 *__restrict__ lens,
+                                                            ChunkMap cm, u32 n_chunks, u32 *__restrict__ counts) {
+    u32 c = blockIdx.x * SK_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    u32 r = cm.find(c);
+    i32 len = (i32)lens[r];
+    i32 s = (i32)(c - cm.chunk_start[r]) * SK_CHUNK;
+    i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
+    u32 n = 0;
+    sketch_chunk<K, W, HPC>(pack, nmask, woff[r], len, r, s, e, [&](u64, u64) { ++n; });
+    counts[c] = n;
+}
+
+template <int K, int W, bool HPC, bool INDEX_KEYS>
+__global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
+                                                            const u64 *__restrict__ woff, const u32 *__restrict__ lens,
+                                                            ChunkMap cm, u32 n_chunks, const u32 *__restrict__ offs,
+                                                            u64 *__restrict__ out_x, u64 *__restrict__ out_y) {
+    u32 c = blockIdx.x * SK_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    u32 r = cm.find(c);
+    i32 len = (i32)lens[r];
+    i32 s = (i32)(c - cm.chunk_start[r]) * SK_CHUNK;
+    i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
+    u32 o = offs[c];
+    sketch_chunk<K, W, HPC>(pack, nmask, woff[r], len, r, s, e, [&](u64 x, u64 y) {
+        out_x[o] = INDEX_KEYS ? (x >> 8) : x;  // the index keeps only the hash, queries keep hash<<8|span
+        out_y[o] = y;
+        ++o;
+    });
+}
+
+// per-read minimizer offsets from per-chunk offsets: mz_off[r] = offs[chunk_start[r]]
+__global__ void k_read_mz_offsets(const u32 *__restrict__ chunk_start, const u32 *__restrict__ offs, u32 n_reads,
+                                  u32 n_chunks, const u32 *__restrict__ d_total, u32 *__restrict__ mz_off) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_reads) return;
+    u32 c = chunk_start[r];
+    mz_off[r] = (r == n_reads || c >= n_chunks) ? *d_total : offs[c];
+}

@@ -1,0 +1,765 @@
+// lrge_hip.hip -- extern "C" entry points of liblrge_hip.so (see include/lrge_hip.h) and the host
+// orchestration of the kernels in k_*.h.  gfx950 only; no CPU fallback: every entry point that
+// computes fails with LRGE_ERR_DEVICE when no HIP device is usable.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "internal.h"
+#include "k_prims.h"
+#include "k_sketch.h"
+#include "k_index.h"
+#include "k_seed.h"
+#include "k_chain.h"
+
+static thread_local std::string g_last_error;  // failures that happen before a ctx exists
+
+extern "C" const char *lrge_hip_version(void) { return "lrge_hip 0.1.0 (gfx950)"; }
+
+extern "C" int lrge_hip_device_count(int *n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; g_last_error = hipGetErrorString(e); return LRGE_ERR_DEVICE; }
+    *n = c;
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0 || device < 0 || device >= c) {
+        g_last_error = "no usable HIP device";
+        return LRGE_ERR_DEVICE;
+    }
+    lrge_hip_ctx *ctx = new lrge_hip_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        g_last_error = "hipSetDevice/hipStreamCreate failed";
+        delete ctx;
+        return LRGE_ERR_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    memset(ctx->ms, 0, sizeof(ctx->ms));
+    memset(ctx->counters, 0, sizeof(ctx->counters));
+    *out = ctx;
+    return LRGE_OK;
+}
+
+extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->pool.destroy();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *lrge_hip_last_error(const lrge_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int lrge_hip_last_timings(const lrge_hip_ctx *ctx, float ms[LRGE_T_N]) {
+    if (!ctx) return LRGE_ERR_INVALID;
+    memcpy(ms, ctx->ms, sizeof(ctx->ms));
+    return LRGE_OK;
+}
+extern "C" int lrge_hip_last_counters(const lrge_hip_ctx *ctx, uint64_t c[LRGE_C_N]) {
+    if (!ctx) return LRGE_ERR_INVALID;
+    memcpy(c, ctx->counters, sizeof(ctx->counters));
+    return LRGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// read sets
+// ------------------------------------------------------------------------------------------
+extern "C" int lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, const uint64_t *offsets, uint32_t n,
+                                      const uint32_t *name_rank, lrge_hip_seqset **out) {
+    if (!ctx || !out || (n && (!bases || !offsets))) return LRGE_ERR_INVALID;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    lrge_hip_seqset *s = new lrge_hip_seqset();
+    s->ctx = ctx; s->n = n;
+    s->h_woff.resize((size_t)n + 1); s->h_len.resize(n ? n : 1);
+    u64 w = 0;
+    for (u32 i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] >= (1ULL << 31)) {
+            LRGE_SET_ERR(ctx, "read %u: bad offsets or length >= 2^31", i); delete s; return LRGE_ERR_INVALID;
+        }
+        u32 len = (u32)(offsets[i + 1] - offsets[i]);
+        s->h_woff[i] = w; s->h_len[i] = len;
+        w += (len + 31) / 32;
+        if (len == 0) s->has_empty = true;
+        if (len > s->max_len) s->max_len = len;
+    }
+    s->h_woff[n] = w; s->n_words = w;
+    s->total_bases = n ? offsets[n] - offsets[0] : 0;
+    if (name_rank) {
+        s->has_rank = true;
+        s->h_rank.assign(name_rank, name_rank + n);
+        std::vector<u32> tmp(s->h_rank);
+        std::sort(tmp.begin(), tmp.end());
+        for (u32 i = 1; i < n; ++i) if (tmp[i] == tmp[i - 1]) { s->dup_rank = true; break; }
+    }
+    auto fail = [&](const char *what, hipError_t e) {
+        LRGE_SET_ERR(ctx, "seqset_upload: %s: %s", what, hipGetErrorString(e));
+        lrge_hip_seqset_free(s);
+        return LRGE_ERR_DEVICE;
+    };
+    hipError_t e;
+    size_t nw = (size_t)(w ? w : 1);
+    if ((e = hipMalloc((void **)&s->d_pack, nw * 8)) != hipSuccess) return fail("hipMalloc pack", e);
+    if ((e = hipMalloc((void **)&s->d_nmask, nw * 4)) != hipSuccess) return fail("hipMalloc nmask", e);
+    if ((e = hipMalloc((void **)&s->d_woff, ((size_t)n + 1) * 8)) != hipSuccess) return fail("hipMalloc woff", e);
+    if ((e = hipMalloc((void **)&s->d_len, (size_t)(n ? n : 1) * 4)) != hipSuccess) return fail("hipMalloc len", e);
+    if ((e = hipMalloc((void **)&s->d_rank, (size_t)(n ? n : 1) * 4)) != hipSuccess) return fail("hipMalloc rank", e);
+    if ((e = hipMemcpyAsync(s->d_woff, s->h_woff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("copy woff", e);
+    if (n) {
+        if ((e = hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("copy len", e);
+        if (name_rank && (e = hipMemcpyAsync(s->d_rank, name_rank, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("copy rank", e);
+    }
+    if (w) {
+        // stage ASCII + byte offsets, pack on the device, drop the staging buffers
+        u8 *d_ascii = nullptr; u64 *d_boff = nullptr;
+        u64 nbytes = s->total_bases;
+        if ((e = hipMalloc((void **)&d_ascii, nbytes)) != hipSuccess) return fail("hipMalloc ascii", e);
+        if ((e = hipMalloc((void **)&d_boff, ((size_t)n + 1) * 8)) != hipSuccess) { (void)hipFree(d_ascii); return fail("hipMalloc boff", e); }
+        std::vector<u64> rel((size_t)n + 1);
+        for (u32 i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
+        e = hipMemcpyAsync(d_ascii, bases + offsets[0], nbytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_boff, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            StageTimer t(ctx, LRGE_T_PACK);
+            hipLaunchKernelGGL(k_pack, dim3((u32)div_up(w, 256)), dim3(256), 0, ctx->stream, d_ascii, d_boff, s->d_woff, n, w,
+                               s->d_pack, s->d_nmask);
+            e = hipGetLastError();
+            t.stop();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_ascii); (void)hipFree(d_boff);
+        if (e != hipSuccess) return fail("pack", e);
+    } else {
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail("sync", e);
+    }
+    *out = s;
+    return LRGE_OK;
+}
+
+extern "C" void lrge_hip_seqset_free(lrge_hip_seqset *s) {
+    if (!s) return;
+    (void)hipFree(s->d_pack); (void)hipFree(s->d_nmask); (void)hipFree(s->d_woff); (void)hipFree(s->d_len); (void)hipFree(s->d_rank);
+    delete s;
+}
+extern "C" uint32_t lrge_hip_seqset_size(const lrge_hip_seqset *s) { return s ? s->n : 0; }
+
+// ------------------------------------------------------------------------------------------
+// sketch driver
+// ------------------------------------------------------------------------------------------
+struct SketchOut {
+    u64 *x = nullptr, *y = nullptr;   // pool memory (owned by the caller's Scratch)
+    u32 *mz_off = nullptr;            // [n+1] per-read offsets
+    u64 n = 0;
+};
+
+template <int K, int W, bool HPC>
+static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o) {
+    std::vector<u32> cs((size_t)s->n + 1);
+    u64 nc = 0;
+    for (u32 i = 0; i < s->n; ++i) { cs[i] = (u32)nc; nc += (s->h_len[i] + SK_CHUNK - 1) / SK_CHUNK; }
+    cs[s->n] = (u32)nc;
+    if (nc >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
+    u32 n_chunks = (u32)nc;
+    ALLOC_OR_FAIL(d_cs, sc, u32, (size_t)s->n + 1);
+    ALLOC_OR_FAIL(d_cnt, sc, u32, (size_t)n_chunks + 1);
+    ALLOC_OR_FAIL(d_total, sc, u32, 1);
+    ALLOC_OR_FAIL(d_mzoff, sc, u32, (size_t)s->n + 1);
+    HIPCHK(ctx, hipMemcpyAsync(d_cs, cs.data(), ((size_t)s->n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // cs is a stack-lifetime host buffer
+    ChunkMap cm{d_cs, s->n};
+    u32 total = 0;
+    if (n_chunks) {
+        hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0, ctx->stream,
+                           s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, d_cnt, d_cnt, n_chunks, d_total);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, ctx->stream));
+    }
+    ALLOC_OR_FAIL(dx, sc, u64, (size_t)total + 1);
+    ALLOC_OR_FAIL(dy, sc, u64, (size_t)total + 1);
+    if (n_chunks) {
+        if (index_keys)
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0,
+                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy);
+        else
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0,
+                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy);
+        KCHK(ctx);
+    }
+    hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, ctx->stream, d_cs, d_cnt, s->n,
+                       n_chunks, d_total, d_mzoff);
+    KCHK(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    sc.drop(d_cs); sc.drop(d_cnt); sc.drop(d_total);
+    o->x = dx; o->y = dy; o->mz_off = d_mzoff; o->n = total;
+    return LRGE_OK;
+}
+
+static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o) {
+    StageTimer t(ctx, LRGE_T_SKETCH);
+    int rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o)
+                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o);
+    t.stop();
+    return rc;
+}
+
+extern "C" int lrge_hip_sketch_dump(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, int preset, uint64_t *x, uint64_t *y,
+                                    uint64_t cap, uint64_t *n_out) {
+    if (!ctx || !s || !n_out) return LRGE_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch sc(ctx);
+    SketchOut o;
+    int rc = sketch_device(ctx, sc, s, preset, false, &o);
+    if (rc) return rc;
+    *n_out = o.n;
+    u64 m = o.n < cap ? o.n : cap;
+    if (m && x) HIPCHK(ctx, hipMemcpy(x, o.x, m * 8, hipMemcpyDeviceToHost));
+    if (m && y) HIPCHK(ctx, hipMemcpy(y, o.y, m * 8, hipMemcpyDeviceToHost));
+    return LRGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// index
+// ------------------------------------------------------------------------------------------
+extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_index **out) {
+    if (!ctx || !targets || !out) return LRGE_ERR_INVALID;
+    if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    memset(ctx->ms, 0, sizeof(ctx->ms));
+    StageTimer t_total(ctx, LRGE_T_TOTAL);
+    Scratch sc(ctx);
+    Preset P = make_preset(preset);
+    SketchOut so;
+    int rc = sketch_device(ctx, sc, targets, preset, true, &so);
+    if (rc) return rc;
+    sc.drop(so.mz_off);
+    const u64 M = so.n;
+    if (M >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32 minimizers (got %llu)", (unsigned long long)M); return LRGE_ERR_TOO_MANY; }
+
+    u64 *skey = so.x, *spos = so.y;
+    {
+        StageTimer t(ctx, LRGE_T_INDEX_SORT);
+        ALLOC_OR_FAIL(k1, sc, u64, M + 1);
+        ALLOC_OR_FAIL(v1, sc, u64, M + 1);
+        u64 *rk, *rv;
+        rc = radix_sort_pairs(ctx, sc, so.x, so.y, k1, v1, M, 0, 2 * P.k, &rk, &rv);
+        if (rc) return rc;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        skey = rk; spos = rv;
+        sc.drop(rk == so.x ? k1 : so.x);
+        sc.drop(rv == so.y ? v1 : so.y);
+        t.stop();
+    }
+
+    lrge_hip_index *ix = new lrge_hip_index();
+    ix->ctx = ctx; ix->seqs = targets; ix->preset_id = preset; ix->P = P; ix->n_mz = M;
+    u32 n_runs = 0;
+    const u32 max_bin = (u32)P.max_mid_occ + 1;
+    std::vector<u32> occ;
+    {
+        StageTimer t(ctx, LRGE_T_INDEX_TABLE);
+        u32 *d_runstart = nullptr;
+        if (M) {
+            ALLOC_OR_FAIL(head, sc, u32, M);
+            ALLOC_OR_FAIL(runid, sc, u32, M);
+            ALLOC_OR_FAIL(d_nr, sc, u32, 1);
+            hipLaunchKernelGGL(k_run_heads, dim3((u32)div_up(M, 256)), dim3(256), 0, ctx->stream, skey, M, head);
+            KCHK(ctx);
+            rc = scan_exclusive_u32(ctx, sc, head, runid, M, d_nr);
+            if (rc) { delete ix; return rc; }
+            HIPCHK(ctx, hipMemcpyAsync(&n_runs, d_nr, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            d_runstart = sc.get<u32>((size_t)n_runs + 1);
+            if (!d_runstart) { delete ix; return LRGE_ERR_DEVICE; }
+            hipLaunchKernelGGL(k_run_starts, dim3((u32)div_up(M, 256)), dim3(256), 0, ctx->stream, head, runid, M, d_runstart);
+            KCHK(ctx);
+            sc.drop(head); sc.drop(runid); sc.drop(d_nr);
+        }
+        u64 cap = 1024;
+        while (cap < 2 * (u64)n_runs) cap <<= 1;
+        ix->ht_mask = cap - 1;
+        ix->n_keys = n_runs;
+        u64 *htk = sc.get<u64>(cap), *htv = sc.get<u64>(cap);
+        u32 *d_occ = sc.get<u32>((size_t)max_bin + 1);
+        if (!htk || !htv || !d_occ) { delete ix; return LRGE_ERR_DEVICE; }
+        HIPCHK(ctx, hipMemsetAsync(htk, 0xFF, cap * 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(htv, 0, cap * 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_occ, 0, ((size_t)max_bin + 1) * 4, ctx->stream));
+        if (n_runs) {
+            hipLaunchKernelGGL(k_table_insert, dim3((u32)div_up(n_runs, 256)), dim3(256), 0, ctx->stream, skey, d_runstart, n_runs, M,
+                               htk, htv, ix->ht_mask, d_occ, max_bin);
+            KCHK(ctx);
+        }
+        occ.resize((size_t)max_bin + 1);
+        HIPCHK(ctx, hipMemcpyAsync(occ.data(), d_occ, ((size_t)max_bin + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        sc.drop(d_occ);
+        if (d_runstart) sc.drop(d_runstart);
+        ix->d_ht_key = htk; ix->d_ht_val = htv; sc.keep(htk); sc.keep(htv);
+        t.stop();
+    }
+    // mm_idx_cal_max_occ + mm_mapopt_update clamps (mm2:index.c, mm2:options.c; aligner.rs:189)
+    {
+        int thres;
+        if (n_runs == 0) thres = INT32_MAX;
+        else {
+            u32 kth = (u32)((1. - (double)P.mid_occ_frac) * (double)n_runs);
+            u64 cum = 0; u32 v = max_bin;
+            for (u32 b = 0; b <= max_bin; ++b) { cum += occ[b]; if (cum > kth) { v = b; break; } }
+            thres = (int)v + 1;
+        }
+        if (thres < P.min_mid_occ) thres = P.min_mid_occ;
+        if (P.max_mid_occ > P.min_mid_occ && thres > P.max_mid_occ) thres = P.max_mid_occ;
+        ix->mid_occ = thres;
+    }
+    ix->d_pos = spos; ix->d_skey = skey; sc.keep(spos); sc.keep(skey);
+    t_total.stop();
+    *out = ix;
+    return LRGE_OK;
+}
+
+extern "C" void lrge_hip_index_free(lrge_hip_index *ix) {
+    if (!ix) return;
+    ix->ctx->pool.release(ix->d_pos); ix->ctx->pool.release(ix->d_skey);
+    ix->ctx->pool.release(ix->d_ht_key); ix->ctx->pool.release(ix->d_ht_val);
+    delete ix;
+}
+
+extern "C" int lrge_hip_index_stats(const lrge_hip_index *ix, uint64_t *n_minimizers, uint64_t *n_keys, int32_t *mid_occ) {
+    if (!ix) return LRGE_ERR_INVALID;
+    if (n_minimizers) *n_minimizers = ix->n_mz;
+    if (n_keys) *n_keys = ix->n_keys;
+    if (mid_occ) *mid_occ = ix->mid_occ;
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, uint64_t *keys, uint64_t *pos, uint64_t cap,
+                                   uint64_t *n_out) {
+    if (!ctx || !ix || !n_out) return LRGE_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *n_out = ix->n_mz;
+    u64 m = ix->n_mz < cap ? ix->n_mz : cap;
+    if (m && keys) HIPCHK(ctx, hipMemcpy(keys, ix->d_skey, m * 8, hipMemcpyDeviceToHost));
+    if (m && pos) HIPCHK(ctx, hipMemcpy(pos, ix->d_pos, m * 8, hipMemcpyDeviceToHost));
+    return LRGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// overlap core
+// ------------------------------------------------------------------------------------------
+enum { MODE_TWOSET = 0, MODE_INVERSE = 1, MODE_AVA = 2 };
+
+struct OverlapJob {
+    int mode;
+    int dual;                       // 1: NO_DUAL cleared, 0: set
+    lrge_hip_params prm;
+    // outputs (host)
+    u32 *counts = nullptr;          // size: nq (twoset) or n_indexed (inverse / ava)
+    u32 *has_map = nullptr;
+    lrge_hip_chain *chains = nullptr; u64 chain_cap = 0; u64 *n_chains = nullptr;
+    // anchors of one query instead of chaining
+    bool dump_anchors = false; u32 dump_query = 0; u64 *ax = nullptr, *ay = nullptr; u64 acap = 0; u64 *an = nullptr;
+};
+
+static u64 env_u64(const char *name, u64 dflt) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return strtoull(v, nullptr, 10);
+}
+
+static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *Q, OverlapJob &job) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    memset(ctx->ms, 0, sizeof(ctx->ms));
+    memset(ctx->counters, 0, sizeof(ctx->counters));
+    if (Q->has_empty && !job.dump_anchors) {  // aligner.rs:214-216 -> LrgeError::MapError aborts the run
+        LRGE_SET_ERR(ctx, "Error mapping read: Sequence is empty");
+        return LRGE_ERR_MAP;
+    }
+    const lrge_hip_seqset *T = ix->seqs;
+    const Preset &P = ix->P;
+    const u32 nq = Q->n, nt = T->n;
+    StageTimer t_total(ctx, LRGE_T_TOTAL);
+    Scratch sc(ctx);
+    const u32 n_out = job.mode == MODE_TWOSET ? nq : nt;
+    ALLOC_OR_FAIL(d_counts, sc, u32, (size_t)n_out + 1);
+    ALLOC_OR_FAIL(d_hasmap, sc, u32, (size_t)nq + 1);
+    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, ((size_t)n_out + 1) * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_hasmap, 0, ((size_t)nq + 1) * 4, ctx->stream));
+    unsigned long long *d_nchains = nullptr; lrge_hip_chain *d_chains = nullptr;
+    if (job.n_chains) {
+        d_nchains = (unsigned long long *)sc.get<u64>(1);
+        d_chains = sc.get<lrge_hip_chain>(job.chain_cap ? job.chain_cap : 1);
+        if (!d_nchains || !d_chains) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemsetAsync(d_nchains, 0, 8, ctx->stream));
+    }
+    ctx->counters[LRGE_C_QUERY_BASES] = Q->total_bases;
+    if (nq == 0 || nt == 0) {
+        if (job.counts) memset(job.counts, 0, (size_t)n_out * 4);
+        if (job.has_map) memset(job.has_map, 0, (size_t)nq * 4);
+        if (job.n_chains) *job.n_chains = 0;
+        if (job.an) *job.an = 0;
+        t_total.stop();
+        return LRGE_OK;
+    }
+
+    // ---- 1. sketch the queries ----
+    SketchOut so;
+    int rc = sketch_device(ctx, sc, Q, ix->preset_id, false, &so);
+    if (rc) return rc;
+    const u64 Mq = so.n;
+    ctx->counters[LRGE_C_QUERY_MINIMIZERS] = Mq;
+    if (Mq >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "query set limited to < 2^32 minimizers"); return LRGE_ERR_TOO_MANY; }
+    std::vector<u32> h_mzoff((size_t)nq + 1);
+    HIPCHK(ctx, hipMemcpyAsync(h_mzoff.data(), so.mz_off, ((size_t)nq + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+
+    // ---- 2. query occurrence filter (mm_seed_mz_flt) ----
+    if (Mq > 0 && P.q_occ_frac > 0.0f && ix->mid_occ > 0) {
+        StageTimer t(ctx, LRGE_T_QFILTER);
+        // only queries with more minimizers than mid_occ can be affected
+        bool any = false;
+        for (u32 q = 0; q < nq && !any; ++q) any = (i64)(h_mzoff[q + 1] - h_mzoff[q]) > (i64)ix->mid_occ;
+        if (any) {
+            ALLOC_OR_FAIL(ka, sc, u64, Mq); ALLOC_OR_FAIL(va, sc, u64, Mq);
+            ALLOC_OR_FAIL(kb, sc, u64, Mq); ALLOC_OR_FAIL(vb, sc, u64, Mq);
+            hipLaunchKernelGGL(k_qocc_keys, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, so.y, Mq, ka, va);
+            KCHK(ctx);
+            u64 *rk, *rv;
+            rc = radix_sort_pairs(ctx, sc, ka, va, kb, vb, Mq, 0, 2 * P.k + 8, &rk, &rv);   // by x
+            if (rc) return rc;
+            u64 *ok = (rk == ka) ? kb : ka, *ov = (rv == va) ? vb : va;
+            u64 *rk2, *rv2;
+            // then (stable) by query id held in bits [32, 32+bits) of the value: swap roles
+            rc = radix_sort_pairs(ctx, sc, rv, rk, ov, ok, Mq, 32, (int)ceil_log2_u64((u64)nq + 1), &rk2, &rv2);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_qocc_mark, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, rv2 /* x */, rk2 /* (q,idx) */, Mq,
+                               so.mz_off, ix->mid_occ, P.q_occ_frac, so.x);
+            KCHK(ctx);
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            sc.drop(ka); sc.drop(va); sc.drop(kb); sc.drop(vb);
+        }
+        t.stop();
+    }
+
+    // ---- 3. lookup ----
+    SeedParams sp;
+    sp.ht_key = ix->d_ht_key; sp.ht_val = ix->d_ht_val; sp.ht_mask = ix->ht_mask; sp.pos = ix->d_pos;
+    sp.t_len = T->d_len; sp.t_rank = T->d_rank; sp.q_len = Q->d_len; sp.q_rank = Q->d_rank;
+    sp.mid_occ = ix->mid_occ;
+    sp.check_names = (Q->has_rank && T->has_rank) ? 1 : 0;   // qname == NULL in minimap2 skips skip_seed entirely
+    sp.no_dual = job.dual ? 0 : 1;
+    ALLOC_OR_FAIL(hs, sc, u32, Mq + 1); ALLOC_OR_FAIL(hn, sc, u32, Mq + 1); ALLOC_OR_FAIL(hv, sc, u32, Mq + 1);
+    ALLOC_OR_FAIL(d_qtot, sc, u32, (size_t)nq + 1);
+    std::vector<u32> h_qtot((size_t)nq + 1, 0);
+    {
+        StageTimer t(ctx, LRGE_T_LOOKUP);
+        if (Mq) {
+            hipLaunchKernelGGL(k_lookup, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, so.y, Mq, sp, hs, hn, hv);
+            KCHK(ctx);
+        }
+        hipLaunchKernelGGL(k_query_anchor_totals, dim3((u32)div_up(nq, 4)), dim3(256), 0, ctx->stream, hv, so.mz_off, nq, d_qtot);
+        KCHK(ctx);
+        HIPCHK(ctx, hipMemcpyAsync(h_qtot.data(), d_qtot, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        t.stop();
+    }
+
+    // ---- 4. batches ----
+    const u64 batch_cap = env_u64("LRGE_HIP_BATCH_ANCHORS", 1ULL << 27);
+    KeyLayout kl;
+    kl.bits_rpos = std::max<u32>(1, ceil_log2_u64((u64)T->max_len + 1));
+    kl.bits_rid = std::max<u32>(1, ceil_log2_u64((u64)nt));
+    const u32 max_bits_q = 63 - (kl.bits_rpos + 1 + kl.bits_rid);
+    const u32 min_n = std::max<u32>((u32)P.min_cnt, (u32)div_up((u64)P.min_sc, P.hpc ? 255 : (u64)P.k));
+    BinLimits bl; bl.lim[0] = 64; bl.lim[1] = 256; bl.lim[2] = 1024; bl.lim[3] = 4096; bl.lim[4] = 0xFFFFFFFFu;
+    ChainParams cp;
+    cp.max_dist_x = std::max(P.max_gap, P.bw); cp.max_dist_y = std::max(P.max_gap, P.bw);
+    cp.bw = P.bw; cp.max_skip = P.max_skip; cp.max_iter = P.max_iter; cp.min_cnt = P.min_cnt; cp.min_sc = P.min_sc;
+    cp.max_drop = P.bw; cp.pen_gap = P.pen_gap; cp.pen_skip = P.pen_skip;
+    cp.remove_internal = job.prm.remove_internal ? (job.mode == MODE_INVERSE ? 2 : 1) : 0;
+    cp.max_overhang_ratio = job.prm.max_overhang_ratio;
+    cp.want_all = (job.n_chains != nullptr || cp.remove_internal) ? 1 : 0;
+    cp.q_len = Q->d_len; cp.t_len = T->d_len;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_chain_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 17 + 64));
+        attr_set = true;
+    }
+
+    u32 q0 = job.dump_anchors ? job.dump_query : 0;
+    const u32 q_end = job.dump_anchors ? job.dump_query + 1 : nq;
+    while (q0 < q_end) {
+        u32 q1 = q0; u64 A = 0;
+        while (q1 < q_end && (q1 - q0) < (1u << std::min<u32>(max_bits_q, 24)) && (q1 == q0 || A + h_qtot[q1] <= batch_cap)) { A += h_qtot[q1]; ++q1; }
+        if (A >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "query %u alone yields %llu anchors (limit 2^32)", q0, (unsigned long long)A); return LRGE_ERR_TOO_MANY; }
+        ctx->counters[LRGE_C_BATCHES] += 1;
+        const u64 mb = h_mzoff[q0], me = h_mzoff[q1];
+        kl.bits_q = std::max<u32>(1, ceil_log2_u64((u64)(q1 - q0)));
+        cp.kl = kl; cp.q0 = q0;
+        if (A == 0 || me == mb) { q0 = q1; continue; }
+        ctx->counters[LRGE_C_ANCHORS] += A;
+        Scratch bsc(ctx);
+        u64 *akey, *aval, *akey2, *aval2, *skey, *sval;
+        {
+            StageTimer t(ctx, LRGE_T_EXPAND);
+            u32 *aoff = bsc.get<u32>(me - mb + 1);
+            akey = bsc.get<u64>(A); aval = bsc.get<u64>(A); akey2 = bsc.get<u64>(A); aval2 = bsc.get<u64>(A);
+            if (!aoff || !akey || !aval || !akey2 || !aval2) return LRGE_ERR_DEVICE;
+            rc = scan_exclusive_u32(ctx, bsc, hv + mb, aoff, me - mb, nullptr);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_expand, dim3((u32)div_up(me - mb, 256)), dim3(256), 0, ctx->stream, so.x, so.y, mb, me, sp, hs, hn, aoff,
+                               q0, kl, akey, aval);
+            KCHK(ctx);
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            bsc.drop(aoff);
+            t.stop();
+        }
+        {
+            StageTimer t(ctx, LRGE_T_ANCHOR_SORT);
+            rc = radix_sort_pairs(ctx, bsc, akey, aval, akey2, aval2, A, 0, (int)kl.total(), &skey, &sval);
+            if (rc) return rc;
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            bsc.drop(skey == akey ? akey2 : akey);
+            bsc.drop(sval == aval ? aval2 : aval);
+            t.stop();
+        }
+        if (job.dump_anchors) {
+            *job.an = A;
+            u64 m = A < job.acap ? A : job.acap;
+            std::vector<u64> hk(m), hvv(m);
+            if (m) {
+                HIPCHK(ctx, hipMemcpy(hk.data(), skey, m * 8, hipMemcpyDeviceToHost));
+                HIPCHK(ctx, hipMemcpy(hvv.data(), sval, m * 8, hipMemcpyDeviceToHost));
+            }
+            const u64 rmask = (1ULL << kl.bits_rpos) - 1;
+            // back to minimap2's mm128 anchor encoding and array order: the device orders groups
+            // (target, strand) so that both strands of a pair are adjacent, minimap2 orders them
+            // (strand, target); a stable re-sort by x keeps the order inside every group.
+            std::vector<std::pair<u64, u64>> tmp(m);
+            for (u64 i = 0; i < m; ++i) {
+                u64 k = hk[i];
+                u64 rev = (k >> kl.sh_rev()) & 1, rid = (k >> kl.sh_rid()) & ((1ULL << kl.bits_rid) - 1);
+                tmp[i] = {rev << 63 | rid << 32 | (k & rmask), hvv[i]};
+            }
+            std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<u64, u64> &a, const std::pair<u64, u64> &b) { return a.first < b.first; });
+            for (u64 i = 0; i < m; ++i) { job.ax[i] = tmp[i].first; job.ay[i] = tmp[i].second; }
+            t_total.stop();
+            return LRGE_OK;
+        }
+        // groups
+        u32 G = 0; u32 *gstart, *gflags, *bin_count, *bin_list;
+        u32 h_bins[N_BINS];
+        unsigned long long h_bin_anchors[N_BINS];
+        {
+            StageTimer t(ctx, LRGE_T_GROUP);
+            u32 *head = bsc.get<u32>(A), *gid = bsc.get<u32>(A), *d_G = bsc.get<u32>(1);
+            if (!head || !gid || !d_G) return LRGE_ERR_DEVICE;
+            hipLaunchKernelGGL(k_group_heads, dim3((u32)div_up(A, 256)), dim3(256), 0, ctx->stream, skey, A, kl.bits_rpos, head);
+            KCHK(ctx);
+            rc = scan_exclusive_u32(ctx, bsc, head, gid, A, d_G);
+            if (rc) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(&G, d_G, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            gstart = bsc.get<u32>((size_t)G + 1); gflags = bsc.get<u32>((size_t)G + 1);
+            bin_count = bsc.get<u32>(N_BINS); bin_list = bsc.get<u32>((size_t)N_BINS * G + 1);
+            unsigned long long *bin_anchors = (unsigned long long *)bsc.get<u64>(N_BINS);
+            if (!gstart || !gflags || !bin_count || !bin_list || !bin_anchors) return LRGE_ERR_DEVICE;
+            HIPCHK(ctx, hipMemsetAsync(bin_anchors, 0, N_BINS * 8, ctx->stream));
+            hipLaunchKernelGGL(k_run_starts, dim3((u32)div_up(A, 256)), dim3(256), 0, ctx->stream, head, gid, A, gstart);
+            KCHK(ctx);
+            HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(bin_count, 0, N_BINS * 4, ctx->stream));
+            hipLaunchKernelGGL(k_group_bin, dim3((u32)div_up(G, 256)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, bl, bin_count, bin_list, bin_anchors);
+            KCHK(ctx);
+            HIPCHK(ctx, hipMemcpyAsync(h_bins, bin_count, N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_bin_anchors, bin_anchors, N_BINS * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            bsc.drop(head); bsc.drop(gid); bsc.drop(d_G);
+            t.stop();
+        }
+        ctx->counters[LRGE_C_GROUPS] += G;
+        {
+            GroupOut go; go.flags = gflags; go.chains = d_chains; go.n_chains = d_nchains; go.chain_cap = job.chain_cap;
+            // biggest groups first: their waves run longest
+            if (h_bins[N_BINS - 1]) {
+                StageTimer t(ctx, LRGE_T_CHAIN_GLB);
+                i32 *gX = bsc.get<i32>(A), *gY = bsc.get<i32>(A), *gF = bsc.get<i32>(A), *gP = bsc.get<i32>(A), *gT = bsc.get<i32>(A);
+                u8 *gS = bsc.get<u8>(A);
+                if (!gX || !gY || !gF || !gP || !gT || !gS) return LRGE_ERR_DEVICE;
+                hipLaunchKernelGGL(k_chain_glb, dim3(h_bins[N_BINS - 1]), dim3(64), 0, ctx->stream, skey, sval, gstart, G, A,
+                                   bin_list + (u64)(N_BINS - 1) * G, h_bins[N_BINS - 1], gX, gY, gF, gP, gT, gS, cp, go);
+                KCHK(ctx);
+                t.stop();
+                ctx->counters[LRGE_C_CHAIN_GLB_LAUNCHES] += 1;
+                ctx->counters[LRGE_C_CHAIN_GLB_ANCHORS] += h_bin_anchors[N_BINS - 1];
+                ctx->counters[LRGE_C_GROUPS_CHAINED] += h_bins[N_BINS - 1];
+            }
+            StageTimer t(ctx, LRGE_T_CHAIN);
+            for (int b = N_BINS - 2; b >= 0; --b) {
+                if (!h_bins[b]) continue;
+                u32 cap = bl.lim[b];
+                hipLaunchKernelGGL(k_chain_lds, dim3(h_bins[b]), dim3(64), (size_t)cap * 17 + 64, ctx->stream, skey, sval, gstart, G, A,
+                                   bin_list + (u64)b * G, h_bins[b], cap, cp, go);
+                KCHK(ctx);
+                ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+                ctx->counters[LRGE_C_CHAIN_ANCHORS] += h_bin_anchors[b];
+                ctx->counters[LRGE_C_GROUPS_CHAINED] += h_bins[b];
+            }
+            t.stop();
+        }
+        {
+            StageTimer t(ctx, LRGE_T_COUNT);
+            CountParams cnp; cnp.kl = kl; cnp.q0 = q0; cnp.mode = job.mode;
+            cnp.q_rank = Q->has_rank ? Q->d_rank : nullptr; cnp.t_rank = T->has_rank ? T->d_rank : nullptr;
+            cnp.t_dup = T->dup_rank ? 1 : 0;
+            hipLaunchKernelGGL(k_count, dim3((u32)div_up(G, 256)), dim3(256), 0, ctx->stream, skey, gstart, gflags, G, cnp, d_counts, d_hasmap);
+            KCHK(ctx);
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            t.stop();
+        }
+        q0 = q1;
+    }
+    if (job.counts) HIPCHK(ctx, hipMemcpyAsync(job.counts, d_counts, (size_t)n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (job.has_map) HIPCHK(ctx, hipMemcpyAsync(job.has_map, d_hasmap, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (job.n_chains) {
+        unsigned long long nchn = 0;
+        HIPCHK(ctx, hipMemcpy(&nchn, d_nchains, 8, hipMemcpyDeviceToHost));
+        *job.n_chains = nchn;
+        u64 m = nchn < job.chain_cap ? nchn : job.chain_cap;
+        if (m && job.chains) HIPCHK(ctx, hipMemcpy(job.chains, d_chains, m * sizeof(lrge_hip_chain), hipMemcpyDeviceToHost));
+    }
+    if (job.an && job.dump_anchors) *job.an = 0;
+    t_total.stop();
+    return LRGE_OK;
+}
+
+static int check_common(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *q) {
+    if (!ctx) return LRGE_ERR_INVALID;
+    if (!ix) { LRGE_SET_ERR(ctx, "No index"); return LRGE_ERR_MAP; }   // aligner.rs:210-212
+    if (!q) { LRGE_SET_ERR(ctx, "null read set"); return LRGE_ERR_INVALID; }
+    if (ix->ctx != ctx || q->ctx != ctx) { LRGE_SET_ERR(ctx, "index / read set belong to another context"); return LRGE_ERR_INVALID; }
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_overlap_twoset(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries,
+                                       const lrge_hip_params *p, uint32_t *counts, uint32_t *has_mapping) {
+    int rc = check_common(ctx, ix, queries);
+    if (rc) return rc;
+    OverlapJob job; job.mode = MODE_TWOSET; job.dual = 1;
+    job.prm = p ? *p : lrge_hip_params{0, 0.2f};
+    job.counts = counts; job.has_map = has_mapping;
+    return run_overlap(ctx, ix, queries, job);
+}
+
+extern "C" int lrge_hip_overlap_inverse(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *streamed,
+                                        const lrge_hip_params *p, uint32_t *counts) {
+    int rc = check_common(ctx, ix, streamed);
+    if (rc) return rc;
+    if (ix->seqs->dup_rank) { LRGE_SET_ERR(ctx, "Duplicate read identifier in the indexed set"); return LRGE_ERR_DUPLICATE_ID; }
+    OverlapJob job; job.mode = MODE_INVERSE; job.dual = 1;
+    job.prm = p ? *p : lrge_hip_params{0, 0.2f};
+    job.counts = counts;
+    return run_overlap(ctx, ix, streamed, job);
+}
+
+extern "C" int lrge_hip_overlap_ava(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *reads,
+                                    const lrge_hip_params *p, uint32_t *counts) {
+    int rc = check_common(ctx, ix, reads);
+    if (rc) return rc;
+    if (ix->seqs != reads) { LRGE_SET_ERR(ctx, "all-vs-all needs the index built over the same read set"); return LRGE_ERR_INVALID; }
+    if (reads->dup_rank) { LRGE_SET_ERR(ctx, "Duplicate read identifier"); return LRGE_ERR_DUPLICATE_ID; }
+    OverlapJob job; job.mode = MODE_AVA; job.dual = 0;
+    job.prm = p ? *p : lrge_hip_params{0, 0.2f};
+    job.counts = counts;
+    return run_overlap(ctx, ix, reads, job);
+}
+
+extern "C" int lrge_hip_chains(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries, int dual,
+                               lrge_hip_chain *out, uint64_t cap, uint64_t *n_out) {
+    int rc = check_common(ctx, ix, queries);
+    if (rc) return rc;
+    if (!n_out) return LRGE_ERR_INVALID;
+    OverlapJob job; job.mode = MODE_TWOSET; job.dual = dual ? 1 : 0;
+    job.prm = lrge_hip_params{0, 0.2f};
+    job.chains = out; job.chain_cap = out ? cap : 0; job.n_chains = n_out;
+    return run_overlap(ctx, ix, queries, job);
+}
+
+extern "C" int lrge_hip_anchors_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries, int dual,
+                                     uint32_t query, uint64_t *x, uint64_t *y, uint64_t cap, uint64_t *n_out) {
+    int rc = check_common(ctx, ix, queries);
+    if (rc) return rc;
+    if (!n_out || query >= queries->n) return LRGE_ERR_INVALID;
+    OverlapJob job; job.mode = MODE_TWOSET; job.dual = dual ? 1 : 0;
+    job.prm = lrge_hip_params{0, 0.2f};
+    job.dump_anchors = true; job.dump_query = query; job.ax = x; job.ay = y; job.acap = (x && y) ? cap : 0; job.an = n_out;
+    *n_out = 0;
+    return run_overlap(ctx, ix, queries, job);
+}
+
+// ------------------------------------------------------------------------------------------
+// estimates
+// ------------------------------------------------------------------------------------------
+extern "C" int lrge_hip_estimates(lrge_hip_ctx *ctx, const uint32_t *counts, const uint32_t *read_lens, uint32_t n,
+                                  float avg_target_len, uint64_t n_target_reads, uint32_t overlap_thresh, float *out) {
+    if (!ctx || (n && (!counts || !read_lens || !out))) return LRGE_ERR_INVALID;
+    if (n == 0) return LRGE_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch sc(ctx);
+    ALLOC_OR_FAIL(dc, sc, u32, n); ALLOC_OR_FAIL(dl, sc, u32, n); ALLOC_OR_FAIL(d_out, sc, float, n);
+    HIPCHK(ctx, hipMemcpyAsync(dc, counts, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dl, read_lens, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    // `n_target_reads as f32`, `2.0 * ovlap_thresh as f32` (estimate.rs:153-156)
+    float nt = (float)n_target_reads, two_thr = 2.0f * (float)overlap_thresh;
+    hipLaunchKernelGGL(k_estimate, dim3((u32)div_up(n, 256)), dim3(256), 0, ctx->stream, dc, dl, n, avg_target_len, nt, two_thr, d_out);
+    KCHK(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LRGE_OK;
+}
+
+// estimate.rs:80-132.  f32 arithmetic, no contraction (this TU is built with -ffp-contract=off).
+static bool quantile_f32(const std::vector<float> &d, float q, float *out) {
+    if (d.empty()) return false;
+    size_t n = d.size();
+    volatile float pos = q * (float)(n - 1);
+    size_t idx = (size_t)floorf(pos);
+    volatile float frac = pos - (float)idx;
+    if (idx + 1 < n) {
+        volatile float lo = d[idx] * (1.0f - frac);
+        volatile float hi = d[idx + 1] * frac;
+        *out = lo + hi;
+    } else *out = d[idx];
+    return true;
+}
+
+extern "C" int lrge_hip_median(const float *estimates, uint64_t n, int finite, int has_lower, float lower_q, int has_upper,
+                               float upper_q, float out[3], int ok[3]) {
+    if (!out || !ok || (n && !estimates)) return LRGE_ERR_INVALID;
+    ok[0] = ok[1] = ok[2] = 0; out[0] = out[1] = out[2] = 0.f;
+    if (!has_lower && has_upper) return LRGE_ERR_INVALID;  // the reference panics here (estimate.rs:109)
+    if ((has_lower && !(lower_q >= 0.f && lower_q <= 1.f)) || (has_upper && !(upper_q >= 0.f && upper_q <= 1.f)))
+        return LRGE_ERR_INVALID;                           // "Quantile must be between 0.0 and 1.0"
+    std::vector<float> v;
+    v.reserve(n);
+    for (u64 i = 0; i < n; ++i) if (!finite || std::isfinite(estimates[i])) v.push_back(estimates[i]);
+    if (v.empty()) return LRGE_OK;
+    std::sort(v.begin(), v.end());
+    ok[1] = quantile_f32(v, 0.5f, &out[1]);
+    if (has_lower) ok[0] = quantile_f32(v, lower_q, &out[0]);
+    if (has_upper) ok[2] = quantile_f32(v, upper_q, &out[2]);
+    return LRGE_OK;
+}

@@ -1,0 +1,208 @@
+"""Thin object wrappers over the C ABI: Context / SeqSet / Index.
+
+The boundary mirrors liblrge's minimap2 wrapper (liblrge/src/minimap2/aligner.rs): an Index is
+what AlignerWrapper::new builds (preset + dual + index over the target file), and the overlap
+calls are the batched form of Aligner::map plus liblrge's counting shells.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import LrgeHipError, Params
+
+
+def name_ranks(*name_lists):
+    """Lexicographic (strcmp) ranks over the union of several name lists; equal names share a rank.
+    Returns one uint32 array per input list."""
+    allnames = [n if isinstance(n, bytes) else n.encode() for lst in name_lists for n in lst]
+    if not allnames:
+        return [np.zeros(0, dtype=np.uint32) for _ in name_lists]
+    arr = np.array(allnames, dtype=object)
+    order = sorted(range(len(allnames)), key=lambda i: allnames[i])  # bytes compare == strcmp without NULs
+    ranks = np.zeros(len(allnames), dtype=np.uint32)
+    r = 0
+    for j, i in enumerate(order):
+        if j > 0 and allnames[i] != allnames[order[j - 1]]:
+            r = j
+        ranks[i] = r
+    out, k = [], 0
+    for lst in name_lists:
+        out.append(ranks[k:k + len(lst)].copy())
+        k += len(lst)
+    return out
+
+
+class Context:
+    def __init__(self, device=0):
+        self._lib = _ffi.lib()
+        h = C.c_void_p()
+        rc = self._lib.lrge_hip_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise LrgeHipError(rc, self._lib.lrge_hip_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LrgeHipError(rc, self._lib.lrge_hip_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.lrge_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def timings(self):
+        a = (C.c_float * len(_ffi.T_NAMES))()
+        self._lib.lrge_hip_last_timings(self.h, C.byref(a))
+        return dict(zip(_ffi.T_NAMES, [float(x) for x in a]))
+
+    def counters(self):
+        a = (C.c_uint64 * len(_ffi.C_NAMES))()
+        self._lib.lrge_hip_last_counters(self.h, C.byref(a))
+        return dict(zip(_ffi.C_NAMES, [int(x) for x in a]))
+
+    def upload(self, bases, offsets, ranks=None):
+        return SeqSet(self, bases, offsets, ranks)
+
+    def estimates(self, counts, read_lens, avg_target_len, n_target_reads, overlap_thresh=100):
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        lens = np.ascontiguousarray(read_lens, dtype=np.uint32)
+        out = np.zeros(max(counts.size, 1), dtype=np.float32)
+        self._check(self._lib.lrge_hip_estimates(self.h, counts.ctypes.data, lens.ctypes.data, counts.size,
+                                                 C.c_float(avg_target_len), int(n_target_reads), overlap_thresh,
+                                                 out.ctypes.data))
+        return out[:counts.size]
+
+
+def median(estimates, finite=True, lower=None, upper=None):
+    """estimate.rs:80-132 on the host side of the library."""
+    v = np.ascontiguousarray(estimates, dtype=np.float32)
+    out = (C.c_float * 3)()
+    ok = (C.c_int * 3)()
+    rc = _ffi.lib().lrge_hip_median(v.ctypes.data if v.size else None, v.size, int(finite),
+                                    int(lower is not None), lower or 0.0, int(upper is not None), upper or 0.0,
+                                    C.byref(out), C.byref(ok))
+    if rc != 0:
+        raise LrgeHipError(rc, "invalid quantile arguments")
+    return tuple(np.float32(out[i]) if ok[i] else None for i in range(3))
+
+
+class SeqSet:
+    def __init__(self, ctx, bases, offsets, ranks=None):
+        self.ctx = ctx
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.n = offsets.size - 1
+        self.lens = np.diff(offsets).astype(np.uint32)
+        r = None if ranks is None else np.ascontiguousarray(ranks, dtype=np.uint32)
+        h = C.c_void_p()
+        ctx._check(ctx._lib.lrge_hip_seqset_upload(ctx.h, bases.ctypes.data if bases.size else None,
+                                                   offsets.ctypes.data, self.n,
+                                                   None if r is None else r.ctypes.data, C.byref(h)))
+        self.h = h
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx._lib.lrge_hip_seqset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def sketch(self, preset):
+        n = C.c_uint64()
+        self.ctx._check(self.ctx._lib.lrge_hip_sketch_dump(self.ctx.h, self.h, preset, None, None, 0, C.byref(n)))
+        x = np.zeros(max(n.value, 1), dtype=np.uint64)
+        y = np.zeros(max(n.value, 1), dtype=np.uint64)
+        self.ctx._check(self.ctx._lib.lrge_hip_sketch_dump(self.ctx.h, self.h, preset, x.ctypes.data, y.ctypes.data,
+                                                           n.value, C.byref(n)))
+        return x[:n.value], y[:n.value]
+
+
+class Index:
+    """AlignerWrapper::new(target_file, threads, preset, dual) -- aligner.rs:310-328."""
+
+    def __init__(self, ctx, targets, preset=_ffi.PRESET_AVA_ONT):
+        self.ctx, self.targets, self.preset = ctx, targets, preset
+        h = C.c_void_p()
+        ctx._check(ctx._lib.lrge_hip_index_build(ctx.h, targets.h, preset, C.byref(h)))
+        self.h = h
+        self.build_timings = ctx.timings()
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx._lib.lrge_hip_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_int32()
+        self.ctx._lib.lrge_hip_index_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(n_minimizers=a.value, n_keys=b.value, mid_occ=c.value)
+
+    def dump(self):
+        n = C.c_uint64()
+        self.ctx._check(self.ctx._lib.lrge_hip_index_dump(self.ctx.h, self.h, None, None, 0, C.byref(n)))
+        k = np.zeros(max(n.value, 1), dtype=np.uint64)
+        p = np.zeros(max(n.value, 1), dtype=np.uint64)
+        self.ctx._check(self.ctx._lib.lrge_hip_index_dump(self.ctx.h, self.h, k.ctypes.data, p.ctypes.data, n.value,
+                                                          C.byref(n)))
+        return k[:n.value], p[:n.value]
+
+    def _params(self, remove_internal, ratio):
+        return Params(int(bool(remove_internal)), float(ratio))
+
+    def overlap_twoset(self, queries, remove_internal=False, max_overhang_ratio=0.2):
+        counts = np.zeros(max(queries.n, 1), dtype=np.uint32)
+        has = np.zeros(max(queries.n, 1), dtype=np.uint32)
+        p = self._params(remove_internal, max_overhang_ratio)
+        self.ctx._check(self.ctx._lib.lrge_hip_overlap_twoset(self.ctx.h, self.h, queries.h, C.byref(p),
+                                                              counts.ctypes.data, has.ctypes.data))
+        return counts[:queries.n], has[:queries.n]
+
+    def overlap_inverse(self, streamed, remove_internal=False, max_overhang_ratio=0.2):
+        counts = np.zeros(max(self.targets.n, 1), dtype=np.uint32)
+        p = self._params(remove_internal, max_overhang_ratio)
+        self.ctx._check(self.ctx._lib.lrge_hip_overlap_inverse(self.ctx.h, self.h, streamed.h, C.byref(p),
+                                                               counts.ctypes.data))
+        return counts[:self.targets.n]
+
+    def overlap_ava(self, remove_internal=False, max_overhang_ratio=0.2):
+        counts = np.zeros(max(self.targets.n, 1), dtype=np.uint32)
+        p = self._params(remove_internal, max_overhang_ratio)
+        self.ctx._check(self.ctx._lib.lrge_hip_overlap_ava(self.ctx.h, self.h, self.targets.h, C.byref(p),
+                                                           counts.ctypes.data))
+        return counts[:self.targets.n]
+
+    def chains(self, queries, dual=True):
+        n = C.c_uint64()
+        self.ctx._check(self.ctx._lib.lrge_hip_chains(self.ctx.h, self.h, queries.h, int(dual), None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=_ffi.CHAIN)
+        self.ctx._check(self.ctx._lib.lrge_hip_chains(self.ctx.h, self.h, queries.h, int(dual), out.ctypes.data,
+                                                      n.value, C.byref(n)))
+        return out[:n.value]
+
+    def anchors(self, queries, q, dual=True):
+        n = C.c_uint64()
+        self.ctx._check(self.ctx._lib.lrge_hip_anchors_dump(self.ctx.h, self.h, queries.h, int(dual), q, None, None, 0,
+                                                            C.byref(n)))
+        x = np.zeros(max(n.value, 1), dtype=np.uint64)
+        y = np.zeros(max(n.value, 1), dtype=np.uint64)
+        self.ctx._check(self.ctx._lib.lrge_hip_anchors_dump(self.ctx.h, self.h, queries.h, int(dual), q, x.ctypes.data,
+                                                            y.ctypes.data, n.value, C.byref(n)))
+        return x[:n.value], y[:n.value]

@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library loads, exports every symbol include/lrge_hip.h declares, and fails
+loudly (no CPU fallback) when no device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "lrge_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lrge_hip_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported():
+    from lrge_amd import _ffi
+    L = _ffi.lib()
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+    assert set(syms) == set(_ffi.EXPORTS)
+    assert b"gfx950" in L.lrge_hip_version()
+
+
+def test_no_cpu_fallback_without_device():
+    if has_gpu():
+        pytest.skip("a GPU is present")
+    from lrge_amd import engine
+    with pytest.raises(Exception) as ei:
+        engine.Context(0)
+    assert "-5" in str(ei.value)    # LRGE_ERR_DEVICE
+
+
+def test_host_median_matches_reference_kats():
+    # lrge_hip_median is host code (estimate.rs:80-132): same KATs as the oracle
+    from lrge_amd import engine
+    inf = float("inf")
+    assert engine.median(np.arange(1, 11, dtype=np.float32), False, 0.15, 0.65) == \
+        (np.float32(2.35), np.float32(5.5), np.float32(6.85))
+    d = np.array([1, 2, 3, 4, 5, 6, inf, inf, inf, inf], dtype=np.float32)
+    assert engine.median(d, False, 0.15, 0.65) == (np.float32(2.35), np.float32(5.5), np.float32(inf))
+    assert engine.median(np.array([1, 3, 5, 7], dtype=np.float32), False) == (None, np.float32(4.0), None)
+    assert engine.median(np.zeros(0, dtype=np.float32)) == (None, None, None)
+    assert engine.median(np.array([1, inf], dtype=np.float32), True) == (None, np.float32(1.0), None)
+    with pytest.raises(Exception):
+        engine.median(np.ones(3, dtype=np.float32), True, 1.1, None)   # "Quantile must be between 0.0 and 1.0"
+    with pytest.raises(Exception):
+        engine.median(np.ones(3, dtype=np.float32), True, None, 0.5)   # reference panics (estimate.rs:109)
+
+
+def test_name_ranks_follow_strcmp():
+    from lrge_amd import engine
+    a, b = engine.name_ranks([b"r2", b"r10", b"R1"], [b"r10", b"a"])
+    # byte order: "R1" < "a" < "r10" < "r2"
+    assert a.tolist() == [4, 2, 0] and b.tolist() == [2, 1]

@@ -1,0 +1,203 @@
+"""GPU: stage-by-stage parity of the HIP path (through the C ABI) against the CPU oracle.
+Bit-exact for every integer stage; f32 estimates compared with tolerance 0 ulp."""
+import numpy as np
+import pytest
+
+from conftest import to_arrays
+
+pytestmark = pytest.mark.gpu
+
+PRESETS = {"ont": 0, "pb": 1}
+TANDEM_SELF = np.uint64((1 << 42) | (1 << 43))   # MM_SEED_TANDEM / MM_SEED_SELF: unused by chaining
+
+
+def _upload(ctx, seqs, ranks=None):
+    b, o = to_arrays(seqs)
+    return ctx.upload(b, o, ranks)
+
+
+def _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset, dual=True):
+    from lrge_amd import engine
+    qr, tr = engine.name_ranks(qnames, tnames)
+    Qd, Td = _upload(ctx, qseqs, qr), _upload(ctx, tseqs, tr)
+    ixd = engine.Index(ctx, Td, PRESETS[preset])
+    opt = oracle.make_opt(oracle.PRESET_AVA_PB if preset == "pb" else oracle.PRESET_AVA_ONT, dual=dual)
+    To, Qo = oracle.ReadSet(tseqs, tnames), oracle.ReadSet(qseqs, qnames)
+    ixo = oracle.Index(To, opt)
+    return Qd, Td, ixd, Qo, To, ixo
+
+
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_sketch_parity(ctx, oracle, edge_set, preset):
+    qseqs, qnames, tseqs, tnames = edge_set
+    seqs = tseqs + [b"", b"A", b"ACGTTGCA" * 3]            # empty and tiny reads keep their rid
+    S = _upload(ctx, seqs)
+    x, y = S.sketch(PRESETS[preset])
+    k, hpc = (19, True) if preset == "pb" else (15, False)
+    exp = [oracle.sketch(s, 5, k, rid=i, is_hpc=hpc) for i, s in enumerate(seqs) if len(s)]
+    ex = np.concatenate([e["x"] for e in exp]); ey = np.concatenate([e["y"] for e in exp])
+    assert len(x) == len(ex), "minimizer count differs: %d vs %d" % (len(x), len(ex))
+    bad = np.nonzero((x != ex) | (y != ey))[0]
+    assert bad.size == 0, "first mismatch at %d: read %d" % (bad[0], int(ey[bad[0]] >> 32))
+
+
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_index_parity(ctx, oracle, edge_set, preset):
+    qseqs, qnames, tseqs, tnames = edge_set
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset)
+    st = ixd.stats()
+    assert st["n_minimizers"] == ixo.n_minimizers
+    assert st["n_keys"] == ixo.n_keys
+    assert st["mid_occ"] == ixo.mid_occ
+    keys, pos = ixd.dump()
+    mz = ixo.minimizers()
+    order = np.lexsort((mz["y"], mz["x"] >> np.uint64(8)))       # (hash, y) ascending == mm_idx_get lists
+    assert np.array_equal(keys, (mz["x"] >> np.uint64(8))[order])
+    assert np.array_equal(pos, mz["y"][order])
+
+
+@pytest.mark.parametrize("preset,dual", [("ont", True), ("ont", False), ("pb", True)])
+def test_anchor_parity(ctx, oracle, edge_set, preset, dual):
+    qseqs, qnames, tseqs, tnames = edge_set
+    if not dual:   # all-vs-all flags: queries are the targets themselves (self/diagonal, NO_DUAL)
+        qseqs, qnames = tseqs, tnames
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset, dual)
+    checked = 0
+    for q in range(len(qseqs)):
+        if len(qseqs[q]) == 0:
+            continue
+        x, y = ixd.anchors(Qd, q, dual=dual)
+        a = ixo.anchors(qseqs[q], qnames[q])
+        assert len(x) == len(a), "query %d: %d anchors vs oracle %d" % (q, len(x), len(a))
+        assert np.array_equal(x, a["x"]), "query %d: anchor x differs" % q
+        assert np.array_equal(y & ~TANDEM_SELF, a["y"] & ~TANDEM_SELF), "query %d: anchor y differs" % q
+        checked += len(x)
+    assert checked > 1000
+
+
+def _chain_rows(arr, fields):
+    rows = np.stack([arr[f].astype(np.int64) for f in fields], axis=1)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+def _oracle_chains(ixo, qseqs, qnames):
+    rows = []
+    for q in range(len(qseqs)):
+        if len(qseqs[q]) == 0:
+            continue
+        for r in ixo.map(qseqs[q], qnames[q]):
+            rows.append((q, r["rid"], r["rev"], r["score"], r["cnt"], r["qs"], r["qe"], r["rs"], r["re"], r["mlen"], r["blen"]))
+    a = np.array(rows, dtype=np.int64).reshape(-1, 11)
+    return a[np.lexsort(a.T[::-1])]
+
+
+@pytest.mark.parametrize("preset,dual", [("ont", True), ("ont", False), ("pb", True)])
+def test_chain_parity(ctx, oracle, edge_set, preset, dual):
+    qseqs, qnames, tseqs, tnames = edge_set
+    if not dual:
+        qseqs, qnames = tseqs, tnames
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset, dual)
+    got = _chain_rows(ixd.chains(Qd, dual=dual),
+                      ["query", "target", "rev", "score", "cnt", "qs", "qe", "rs", "re", "mlen", "blen"])
+    exp = _oracle_chains(ixo, qseqs, qnames)
+    assert got.shape == exp.shape, "chain count %d vs oracle %d" % (len(got), len(exp))
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, "first differing chain: got %s expected %s" % (got[bad[0]], exp[bad[0]])
+    assert len(exp) > 50
+
+
+@pytest.mark.parametrize("platform,preset", [("ont", "ont"), ("hifi", "pb"), ("hifi", "ont")])
+def test_twoset_counts_and_estimates(ctx, oracle, tiny_ont, tiny_hifi, platform, preset):
+    from lrge_amd import engine
+    ds = tiny_ont if platform == "ont" else tiny_hifi
+    qseqs, tseqs = ds.q.seqs(), ds.t.seqs()
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, ds.q.names, tseqs, ds.t.names, preset)
+    counts, has = ixd.overlap_twoset(Qd)
+    rc, ecounts, ehas = ixo.twoset_counts(Qo, threads=8)
+    assert rc == 0
+    assert np.array_equal(counts, ecounts), "counts differ at %s" % np.nonzero(counts != ecounts)[0][:10]
+    assert np.array_equal(has, ehas)
+    assert counts.sum() > 0
+    # -F (remove_internal) uses chain coordinates
+    for ratio in (0.2, 0.05):
+        c2, h2 = ixd.overlap_twoset(Qd, remove_internal=True, max_overhang_ratio=ratio)
+        rc, ec2, eh2 = ixo.twoset_counts(Qo, remove_internal=True, ratio=ratio, threads=8)
+        assert np.array_equal(c2, ec2) and np.array_equal(h2, eh2)
+    # per-read estimates on the device: f32, 0 ulp
+    lens = ds.q.lens()
+    avg = np.float32(ds.t.lens().sum()) / np.float32(ds.t.n)
+    est = ctx.estimates(counts, lens, float(avg), ds.t.n, 100)
+    exp = np.array([oracle.per_read_estimate(int(l), float(avg), ds.t.n, int(c), 100) for l, c in zip(lens, counts)],
+                   dtype=np.float32)
+    assert np.array_equal(est.view(np.uint32), exp.view(np.uint32))
+    assert engine.median(est, True, 0.15, 0.65) == oracle.median(exp, True, 0.15, 0.65)
+
+
+def test_inverse_counts(ctx, oracle, tiny_ont):
+    ds = tiny_ont
+    # index = QUERY set, streamed = TARGET set (twoset.rs:596-599)
+    Sd, Id, ixd, So, Io, ixo = _both_sets(ctx, oracle, ds.t.seqs(), ds.t.names, ds.q.seqs(), ds.q.names, "ont")
+    for rem in (False, True):
+        got = ixd.overlap_inverse(Sd, remove_internal=rem)
+        rc, exp = ixo.inverse_counts(So, remove_internal=rem, threads=8)
+        assert rc == 0 and np.array_equal(got, exp)
+    assert got.sum() > 0
+
+
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_ava_counts(ctx, oracle, preset):
+    from lrge_amd import engine, synth
+    g, reads, _ = synth.make_config("tiny_ava")
+    seqs, names = reads.seqs(), list(reads.names)
+    # shuffle the names so that rank order != index order (NO_DUAL works on names)
+    rng = np.random.Generator(np.random.PCG64(11))
+    names = [b"x%05d" % v for v in rng.permutation(len(names))]
+    (ranks,) = engine.name_ranks(names)
+    Rd = _upload(ctx, seqs, ranks)
+    ixd = engine.Index(ctx, Rd, PRESETS[preset])
+    opt = oracle.make_opt(oracle.PRESET_AVA_PB if preset == "pb" else oracle.PRESET_AVA_ONT, dual=False)
+    Ro = oracle.ReadSet(seqs, names)
+    ixo = oracle.Index(Ro, opt)
+    for rem in (False, True):
+        got = ixd.overlap_ava(remove_internal=rem)
+        rc, exp = ixo.ava_counts(remove_internal=rem, threads=8)
+        assert rc == 0 and np.array_equal(got, exp), np.nonzero(got != exp)[0][:10]
+    assert got.sum() > 0 and got.sum() % 2 == 0
+
+
+def test_error_paths(ctx, oracle):
+    from lrge_amd import engine, synth, _ffi
+    g, reads, _ = synth.make_config("tiny_ava", scale=0.2)
+    seqs, names = reads.seqs(), list(reads.names)
+    names[3] = names[1]
+    (ranks,) = engine.name_ranks(names)
+    Rd = _upload(ctx, seqs, ranks)
+    ixd = engine.Index(ctx, Rd, 0)
+    with pytest.raises(_ffi.LrgeHipError) as ei:
+        ixd.overlap_ava()
+    assert ei.value.code == _ffi.ERR_DUPLICATE_ID
+    # empty query sequence -> MapError "Sequence is empty" (aligner.rs:214-216)
+    Qd = _upload(ctx, [seqs[0], b"", seqs[2]])
+    with pytest.raises(_ffi.LrgeHipError) as ei:
+        ixd.overlap_twoset(Qd)
+    assert ei.value.code == _ffi.ERR_MAP and "empty" in str(ei.value)
+    # forward two-set tolerates duplicate target identifiers and counts a name once
+    Q2 = _upload(ctx, seqs[:10], engine.name_ranks([b"q%d" % i for i in range(10)], names)[0])
+    Rd2 = _upload(ctx, seqs, engine.name_ranks([b"q%d" % i for i in range(10)], names)[1])
+    ix2 = engine.Index(ctx, Rd2, 0)
+    got, has = ix2.overlap_twoset(Q2)
+    opt = oracle.make_opt(oracle.PRESET_AVA_ONT, dual=True)
+    ixo = oracle.Index(oracle.ReadSet(seqs, names), opt)
+    rc, exp, ehas = ixo.twoset_counts(oracle.ReadSet(seqs[:10], [b"q%d" % i for i in range(10)]), threads=2)
+    assert np.array_equal(got, exp) and np.array_equal(has, ehas)
+
+
+def test_batching_is_invisible(ctx, oracle, tiny_ont, monkeypatch):
+    """Forcing many small anchor batches must not change the counts."""
+    ds = tiny_ont
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, ds.q.seqs(), ds.q.names, ds.t.seqs(), ds.t.names, "ont")
+    ref, _ = ixd.overlap_twoset(Qd)
+    monkeypatch.setenv("LRGE_HIP_BATCH_ANCHORS", "20000")
+    small, _ = ixd.overlap_twoset(Qd)
+    assert ctx.counters()["batches"] > 3
+    assert np.array_equal(ref, small)

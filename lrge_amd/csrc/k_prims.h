@@ -18,6 +18,56 @@ __device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
     return v;
 }
 
+// DPP wave scans (gfx9 family: row_shr within 16-lane rows, then row_bcast:15 / row_bcast:31 to
+// stitch the four rows).  These stay in the VALU pipeline; __shfl_up would go through ds_bpermute.
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_BCAST15 0x142
+#define DPP_BCAST31 0x143
+#define DPP_WAVE_SHR1 0x138
+
+// inclusive max-scan over the 64 lanes
+__device__ __forceinline__ i32 wave_incl_max_i32(i32 v, i32 identity) {
+    i32 o;
+    o = __builtin_amdgcn_update_dpp(identity, v, DPP_ROW_SHR(1), 0xf, 0xf, false); v = v > o ? v : o;
+    o = __builtin_amdgcn_update_dpp(identity, v, DPP_ROW_SHR(2), 0xf, 0xf, false); v = v > o ? v : o;
+    o = __builtin_amdgcn_update_dpp(identity, v, DPP_ROW_SHR(4), 0xf, 0xf, false); v = v > o ? v : o;
+    o = __builtin_amdgcn_update_dpp(identity, v, DPP_ROW_SHR(8), 0xf, 0xf, false); v = v > o ? v : o;
+    o = __builtin_amdgcn_update_dpp(identity, v, DPP_BCAST15, 0xa, 0xf, false); v = v > o ? v : o;
+    o = __builtin_amdgcn_update_dpp(identity, v, DPP_BCAST31, 0xc, 0xf, false); v = v > o ? v : o;
+    return v;
+}
+// value of the previous lane (lane 0 gets `identity`)
+__device__ __forceinline__ i32 wave_shr1_i32(i32 v, i32 identity) {
+    return __builtin_amdgcn_update_dpp(identity, v, DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+// inclusive scan of the monoid of maps x -> max(x + a, b) under composition (earlier lanes first)
+__device__ __forceinline__ void wave_incl_clampadd(i32 &a, i32 &b, i32 neg_big) {
+#define CLAMPADD_STEP(ctrl, rmask)                                                        \
+    {                                                                                     \
+        i32 ao = __builtin_amdgcn_update_dpp(0, a, ctrl, rmask, 0xf, false);              \
+        i32 bo = __builtin_amdgcn_update_dpp(neg_big, b, ctrl, rmask, 0xf, false);        \
+        i32 nb = bo + a;                                                                  \
+        b = nb > b ? nb : b;                                                              \
+        a = ao + a;                                                                       \
+    }
+    CLAMPADD_STEP(DPP_ROW_SHR(1), 0xf)
+    CLAMPADD_STEP(DPP_ROW_SHR(2), 0xf)
+    CLAMPADD_STEP(DPP_ROW_SHR(4), 0xf)
+    CLAMPADD_STEP(DPP_ROW_SHR(8), 0xf)
+    CLAMPADD_STEP(DPP_BCAST15, 0xa)
+    CLAMPADD_STEP(DPP_BCAST31, 0xc)
+#undef CLAMPADD_STEP
+}
+// wave-wide maximum of a packed (score << 32 | index) key; every lane receives the result
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        u64 o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // exclusive scan of u32 (n < 2^32, totals < 2^32).  SCAN_TILE items per 256-thread block.
 // ------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 #include "k_index.h"
 #include "k_seed.h"
 #include "k_chain.h"
+#include "k_chain_reg.h"
 
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
 
@@ -229,6 +230,12 @@ extern "C" int lrge_hip_sketch_dump(lrge_hip_ctx *ctx, const lrge_hip_seqset *s,
     return LRGE_OK;
 }
 
+static u64 env_u64(const char *name, u64 dflt) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return strtoull(v, nullptr, 10);
+}
+
 // ------------------------------------------------------------------------------------------
 // index
 // ------------------------------------------------------------------------------------------
@@ -241,6 +248,10 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     StageTimer t_total(ctx, LRGE_T_TOTAL);
     Scratch sc(ctx);
     Preset P = make_preset(preset);
+    // test-only overrides of two chaining heuristics, so that parity tests can drive the rarely taken
+    // paths (no max_skip break -> candidates beyond the register window; tight max_iter clamp)
+    P.max_skip = (int)env_u64("LRGE_HIP_DEBUG_MAX_SKIP", (u64)P.max_skip);
+    P.max_iter = (int)env_u64("LRGE_HIP_DEBUG_MAX_ITER", (u64)P.max_iter);
     SketchOut so;
     int rc = sketch_device(ctx, sc, targets, preset, true, &so);
     if (rc) return rc;
@@ -373,11 +384,6 @@ struct OverlapJob {
     bool dump_anchors = false; u32 dump_query = 0; u64 *ax = nullptr, *ay = nullptr; u64 acap = 0; u64 *an = nullptr;
 };
 
-static u64 env_u64(const char *name, u64 dflt) {
-    const char *v = getenv(name);
-    if (!v || !*v) return dflt;
-    return strtoull(v, nullptr, 10);
-}
 
 static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *Q, OverlapJob &job) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -494,7 +500,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     cp.q_len = Q->d_len; cp.t_len = T->d_len;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_chain_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 17 + 64));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_chain_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 18 + 64));
         attr_set = true;
     }
 
@@ -592,32 +598,64 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         ctx->counters[LRGE_C_GROUPS] += G;
         {
             GroupOut go; go.flags = gflags; go.chains = d_chains; go.n_chains = d_nchains; go.chain_cap = job.chain_cap;
-            // biggest groups first: their waves run longest
-            if (h_bins[N_BINS - 1]) {
-                StageTimer t(ctx, LRGE_T_CHAIN_GLB);
-                i32 *gX = bsc.get<i32>(A), *gY = bsc.get<i32>(A), *gF = bsc.get<i32>(A), *gP = bsc.get<i32>(A), *gT = bsc.get<i32>(A);
-                u8 *gS = bsc.get<u8>(A);
-                if (!gX || !gY || !gF || !gP || !gT || !gS) return LRGE_ERR_DEVICE;
-                hipLaunchKernelGGL(k_chain_glb, dim3(h_bins[N_BINS - 1]), dim3(64), 0, ctx->stream, skey, sval, gstart, G, A,
-                                   bin_list + (u64)(N_BINS - 1) * G, h_bins[N_BINS - 1], gX, gY, gF, gP, gT, gS, cp, go);
-                KCHK(ctx);
+            const char *cm = getenv("LRGE_HIP_CHAIN");
+            const int chain_mode = (cm && !strcmp(cm, "lds")) ? 1 : (cm && !strcmp(cm, "glb")) ? 2 : 0;
+            if (chain_mode == 0) {
+                // default: register-window kernel, every group size in one launch, largest groups first
+                u32 total_blocks = 0; u64 total_anch = 0;
+                RegChainArgs ra;
+                ra.akey = skey; ra.aval = sval; ra.gstart = gstart; ra.n_groups = G; ra.n_anchors = A; ra.list = bin_list;
+                for (int k = 0; k < N_BINS; ++k) {
+                    int b = N_BINS - 1 - k;
+                    ra.bin_first[k] = total_blocks; ra.bin_of[k] = (u32)b;
+                    total_blocks += h_bins[b]; total_anch += h_bin_anchors[b];
+                }
+                ra.n_blocks = total_blocks;
+                if (total_blocks) {
+                    StageTimer t(ctx, LRGE_T_CHAIN);
+                    ra.grec = bsc.get<u64>(A); ra.tmark = bsc.get<u32>(A);
+                    if (!ra.grec || !ra.tmark) return LRGE_ERR_DEVICE;
+                    HIPCHK(ctx, hipMemsetAsync(ra.tmark, 0, A * 4, ctx->stream));
+                    hipLaunchKernelGGL(k_chain_reg, dim3(total_blocks), dim3(64), 0, ctx->stream, ra, cp, go);
+                    KCHK(ctx);
+                    t.stop();
+                    ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+                    ctx->counters[LRGE_C_CHAIN_ANCHORS] += total_anch;
+                    ctx->counters[LRGE_C_GROUPS_CHAINED] += total_blocks;
+                }
+            } else {
+                const int first_lds_bin = chain_mode == 2 ? -1 : N_BINS - 2;   // "glb": everything through the generic kernel
+                u32 n_glb = 0; u64 a_glb = 0;
+                for (int b = N_BINS - 1; b > first_lds_bin; --b) { n_glb += h_bins[b]; a_glb += h_bin_anchors[b]; }
+                if (n_glb) {
+                    StageTimer t(ctx, LRGE_T_CHAIN_GLB);
+                    i32 *gX = bsc.get<i32>(A), *gY = bsc.get<i32>(A), *gF = bsc.get<i32>(A), *gP = bsc.get<i32>(A), *gT = bsc.get<i32>(A);
+                    u8 *gS = bsc.get<u8>(A);
+                    if (!gX || !gY || !gF || !gP || !gT || !gS) return LRGE_ERR_DEVICE;
+                    for (int b = N_BINS - 1; b > first_lds_bin; --b) {
+                        if (!h_bins[b]) continue;
+                        hipLaunchKernelGGL(k_chain_glb, dim3(h_bins[b]), dim3(64), 0, ctx->stream, skey, sval, gstart, G, A,
+                                           bin_list + (u64)b * G, h_bins[b], gX, gY, gF, gP, gT, gS, cp, go);
+                        KCHK(ctx);
+                        ctx->counters[LRGE_C_CHAIN_GLB_LAUNCHES] += 1;
+                    }
+                    t.stop();
+                    ctx->counters[LRGE_C_CHAIN_GLB_ANCHORS] += a_glb;
+                    ctx->counters[LRGE_C_GROUPS_CHAINED] += n_glb;
+                }
+                StageTimer t(ctx, LRGE_T_CHAIN);
+                for (int b = first_lds_bin; b >= 0; --b) {
+                    if (!h_bins[b]) continue;
+                    u32 cap = bl.lim[b];
+                    hipLaunchKernelGGL(k_chain_lds, dim3(h_bins[b]), dim3(64), (size_t)cap * 18 + 64, ctx->stream, skey, sval, gstart, G, A,
+                                       bin_list + (u64)b * G, h_bins[b], cap, cp, go);
+                    KCHK(ctx);
+                    ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+                    ctx->counters[LRGE_C_CHAIN_ANCHORS] += h_bin_anchors[b];
+                    ctx->counters[LRGE_C_GROUPS_CHAINED] += h_bins[b];
+                }
                 t.stop();
-                ctx->counters[LRGE_C_CHAIN_GLB_LAUNCHES] += 1;
-                ctx->counters[LRGE_C_CHAIN_GLB_ANCHORS] += h_bin_anchors[N_BINS - 1];
-                ctx->counters[LRGE_C_GROUPS_CHAINED] += h_bins[N_BINS - 1];
             }
-            StageTimer t(ctx, LRGE_T_CHAIN);
-            for (int b = N_BINS - 2; b >= 0; --b) {
-                if (!h_bins[b]) continue;
-                u32 cap = bl.lim[b];
-                hipLaunchKernelGGL(k_chain_lds, dim3(h_bins[b]), dim3(64), (size_t)cap * 17 + 64, ctx->stream, skey, sval, gstart, G, A,
-                                   bin_list + (u64)b * G, h_bins[b], cap, cp, go);
-                KCHK(ctx);
-                ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
-                ctx->counters[LRGE_C_CHAIN_ANCHORS] += h_bin_anchors[b];
-                ctx->counters[LRGE_C_GROUPS_CHAINED] += h_bins[b];
-            }
-            t.stop();
         }
         {
             StageTimer t(ctx, LRGE_T_COUNT);

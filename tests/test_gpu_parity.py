@@ -201,3 +201,31 @@ def test_batching_is_invisible(ctx, oracle, tiny_ont, monkeypatch):
     small, _ = ixd.overlap_twoset(Qd)
     assert ctx.counters()["batches"] > 3
     assert np.array_equal(ref, small)
+
+
+@pytest.mark.parametrize("kernel", ["reg", "lds", "glb"])
+@pytest.mark.parametrize("max_skip,max_iter", [(25, 5000), (100000, 5000), (100000, 40), (3, 90)])
+def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, monkeypatch, kernel, max_skip, max_iter):
+    """All three chain kernels (register-window, LDS, global) against the oracle, including the
+    paths the default heuristics almost never take: no max_skip break (the candidate loop walks the
+    whole 5000-bp window, far past the 64 anchors held in registers) and a tight max_iter clamp.
+    HiFi reads give dense anchor groups (hundreds of anchors inside one window)."""
+    monkeypatch.setenv("LRGE_HIP_CHAIN", kernel)
+    monkeypatch.setenv("LRGE_HIP_DEBUG_MAX_SKIP", str(max_skip))
+    monkeypatch.setenv("LRGE_HIP_DEBUG_MAX_ITER", str(max_iter))
+    ds = tiny_hifi
+    qseqs, tseqs = ds.q.seqs()[:8], ds.t.seqs()
+    qnames = ds.q.names[:8]
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, ds.t.names, "ont")
+    ixo.opt.max_chain_skip = max_skip
+    ixo.opt.max_chain_iter = max_iter
+    got = _chain_rows(ixd.chains(Qd, dual=True),
+                      ["query", "target", "rev", "score", "cnt", "qs", "qe", "rs", "re", "mlen", "blen"])
+    exp = _oracle_chains(ixo, qseqs, qnames)
+    assert got.shape == exp.shape, "chain count %d vs oracle %d" % (len(got), len(exp))
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, "first differing chain: got %s expected %s" % (got[bad[0]], exp[bad[0]])
+    assert len(exp) > 20
+    counts, has = ixd.overlap_twoset(Qd)
+    rc, ecounts, ehas = ixo.twoset_counts(Qo, threads=8)
+    assert np.array_equal(counts, ecounts) and np.array_equal(has, ehas)

@@ -1,0 +1,140 @@
+"""CPU: host-side logic above the C ABI -- strategy builders, read splitting (reference tests
+twoset.rs:659-701, lib.rs:206-266), read_id (io.rs:304-347), query sharding and the gloo collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from lrge_amd import parallel, readio, twoset, ava
+
+
+def test_unique_random_set_properties():
+    # lib.rs:206-266: size, range, uniqueness, repeatability with a seed, panic when k > n
+    s = twoset.unique_random_set(10, 100, seed=42)
+    assert len(s) == 10 and len(set(s.tolist())) == 10 and s.max() < 100
+    assert np.array_equal(s, twoset.unique_random_set(10, 100, seed=42))
+    assert not np.array_equal(s, twoset.unique_random_set(10, 100, seed=43))
+    assert sorted(twoset.unique_random_set(7, 7, seed=1).tolist()) == list(range(7))
+    with pytest.raises(ValueError):
+        twoset.unique_random_set(11, 10)
+
+
+def test_split_into_sets_sizes():
+    # twoset.rs:659-701
+    a, b = twoset.split_into_sets([1, 2, 3, 4, 5], 2)
+    assert a == {4, 5} and b == {1, 2, 3}            # the LAST sampled indices become the first set
+    a, b = twoset.split_into_sets([1, 2, 3], 5)
+    assert a == {1, 2, 3} and b == set()
+    a, b = twoset.split_into_sets([], 2)
+    assert a == set() and b == set()
+    a, b = twoset.split_into_sets([1, 2, 3], 0)
+    assert a == set() and b == {1, 2, 3}
+
+
+def test_read_id_whitespace_rule():
+    # io.rs:304-347
+    assert readio.read_id(b"read1 desc more") == b"read1"
+    assert readio.read_id(b"read1\tdesc") == b"read1"
+    assert readio.read_id(b"read1") == b"read1"
+    assert readio.read_id(b"") == b""
+
+
+def test_fastx_parsing(tmp_path):
+    fa = tmp_path / "x.fa"
+    fa.write_bytes(b">r1 d\nACGT\nAC\n>r2\nGG\n")
+    assert list(readio.iter_records(str(fa))) == [(b"r1", b"ACGTAC"), (b"r2", b"GG")]
+    fq = tmp_path / "x.fq"
+    fq.write_bytes(b"@r1 d\nACGT\n+\nIIII\n@r2\nGG\n+\nII\n")
+    assert list(readio.iter_records(str(fq))) == [(b"r1", b"ACGT"), (b"r2", b"GG")]
+    import gzip
+    gz = tmp_path / "x.fa.gz"
+    gz.write_bytes(gzip.compress(b">a\nAC\n"))
+    assert list(readio.iter_records(str(gz))) == [(b"a", b"AC")]
+
+
+def _reads(n):
+    return [b"r%d" % i for i in range(n)], [b"ACGT" * (5 + i % 3) for i in range(n)]
+
+
+def test_twoset_split_guards():
+    # twoset.rs:137-151: n <= Q -> TooFewReads; n < T+Q -> T = n - Q
+    from lrge_amd import LrgeError
+    s = twoset.Builder().target_num_reads(10).query_num_reads(5).seed(1).build(_reads(5))
+    with pytest.raises(LrgeError) as ei:
+        s.split_fastq()
+    assert ei.value.kind == "TooFewReadsError"
+    s = twoset.Builder().target_num_reads(10).query_num_reads(5).seed(1).build(_reads(12))
+    (tn, ts), (qn, qs), avg = s.split_fastq()
+    assert s.target_num_reads == 7 and len(tn) == 7 and len(qn) == 5 and not set(tn) & set(qn)
+    assert avg == np.float32(sum(map(len, ts))) / np.float32(7)
+    s = twoset.Builder().target_num_reads(4).query_num_reads(3).seed(7).build(_reads(50))
+    (tn, ts), (qn, qs), avg = s.split_fastq()
+    assert len(tn) == 4 and len(qn) == 3
+    idx = [int(x[1:]) for x in tn]
+    assert idx == sorted(idx)                      # written in file order (iter_records)
+
+
+def test_builder_defaults_and_ava_clamp():
+    b = twoset.Builder()
+    assert (b._t, b._q, b._ratio, b._threads, b._use_min_ref) == (10_000, 5_000, 0.2, 1, False)   # twoset/builder.rs:22-39
+    assert b.remove_internal(False, 0.5)._ratio == 0.2       # ratio only overridden when the flag is on (builder.rs:90-96)
+    assert b.remove_internal(True, 0.5)._ratio == 0.5
+    assert ava.Builder()._n == 25_000                        # ava.rs:62
+    s = ava.Builder().num_reads(100).seed(3).build(_reads(30))
+    rn, rs, sum_len = s.subsample_reads()
+    assert s.num_reads == 30 and len(rn) == 30 and sum_len == sum(map(len, rs))   # ava.rs:122-128
+
+
+def test_shard_by_bases():
+    lens = np.array([10, 10, 10, 10, 40, 10, 10], dtype=np.int64)
+    b = parallel.shard_by_bases(lens, 2)
+    assert b[0] == 0 and b[-1] == 7 and len(b) == 3
+    left = lens[:b[1]].sum()
+    assert abs(left - lens.sum() / 2) <= 40
+    b8 = parallel.shard_by_bases(lens, 8)
+    assert b8 == sorted(b8) and b8[0] == 0 and b8[-1] == 7 and len(b8) == 9
+    assert parallel.shard_by_bases([], 4) == [0, 0, 0, 0, 0]
+    rr = [parallel.shard_round_robin(10, r, 3).tolist() for r in range(3)]
+    assert sorted(sum(rr, [])) == list(range(10))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lens = np.arange(1, 12) * 100
+        full = (np.arange(11, dtype=np.float32) + 0.5) * 1000
+
+        def overlap_fn(lo, hi):                       # stands in for the per-rank GPU call
+            return full[lo:hi], int(rank == 0)
+        allv, no_map, (lo, hi) = parallel.twoset_forward_sharded(overlap_fn, lens, rank, world)
+        counts = np.zeros(5, dtype=np.uint32); counts[rank] = 3; counts[4] = 1
+        tot = parallel.allreduce_counts_u32(counts)
+        q.put((rank, allv.tolist(), no_map, lo, hi, tot.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_gather_and_allreduce():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    full = ((np.arange(11, dtype=np.float32) + 0.5) * 1000).tolist()
+    ranges = []
+    for rank, allv, no_map, lo, hi, tot in sorted(res):
+        assert allv == full                      # every rank ends with the whole vector, in query order
+        assert no_map == 1
+        assert tot == [3, 3, 0, 0, 2]
+        ranges.append((lo, hi))
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 11

@@ -115,8 +115,7 @@ struct lrge_hip_index {
     int mid_occ = 0;
     u64 *d_pos = nullptr;       // [n_mz] y values grouped by key, ascending within a key
     u64 *d_skey = nullptr;      // [n_mz] sorted keys (kept for index_dump / tests)
-    u64 *d_ht_key = nullptr;    // open-addressing table
-    u64 *d_ht_val = nullptr;    // start<<24 | min(count, 2^24-1)
+    u64 *d_ht = nullptr;        // open-addressing table of {key, start<<24 | min(count, 2^24-1)} pairs
     u64 ht_mask = 0;
 };
 

@@ -32,10 +32,10 @@ __global__ void k_run_starts(const u32 *__restrict__ head, const u32 *__restrict
 
 #define OCC_LDS_BINS 2048
 // per-run: insert into the table, histogram the run length (clamped to max_bin)
+// table entry = {key, start<<24 | count} in one 16-byte slot: insert and lookup touch one line
 __global__ __launch_bounds__(256) void k_table_insert(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
-                                                      u32 n_runs, u64 n, u64 *__restrict__ ht_key,
-                                                      u64 *__restrict__ ht_val, u64 ht_mask, u32 *__restrict__ occ_hist,
-                                                      u32 max_bin) {
+                                                      u32 n_runs, u64 n, u64 *__restrict__ ht, u64 ht_mask,
+                                                      u32 *__restrict__ occ_hist, u32 max_bin) {
     __shared__ u32 lh[OCC_LDS_BINS];
     for (u32 i = threadIdx.x; i < OCC_LDS_BINS; i += blockDim.x) lh[i] = 0;
     __syncthreads();
@@ -47,11 +47,11 @@ __global__ __launch_bounds__(256) void k_table_insert(const u64 *__restrict__ sk
         u64 key = skey[st];
         u64 slot = ht_slot_hash(key) & ht_mask;
         for (;;) {
-            u64 prev = atomicCAS((unsigned long long *)&ht_key[slot], (unsigned long long)HT_EMPTY, (unsigned long long)key);
+            u64 prev = atomicCAS((unsigned long long *)&ht[2 * slot], (unsigned long long)HT_EMPTY, (unsigned long long)key);
             if (prev == HT_EMPTY) break;  // keys are distinct per run, so no "already present" case
             slot = (slot + 1) & ht_mask;
         }
-        ht_val[slot] = (u64)st << HT_CNT_BITS | (cnt < HT_CNT_MAX ? cnt : HT_CNT_MAX);
+        ht[2 * slot + 1] = (u64)st << HT_CNT_BITS | (cnt < HT_CNT_MAX ? cnt : HT_CNT_MAX);
         u32 b = cnt < max_bin ? cnt : max_bin;
         if (b < OCC_LDS_BINS) atomicAdd(&lh[b], 1u); else atomicAdd(&occ_hist[b], 1u);
     }
@@ -60,13 +60,12 @@ __global__ __launch_bounds__(256) void k_table_insert(const u64 *__restrict__ sk
         if (lh[i]) atomicAdd(&occ_hist[i], lh[i]);
 }
 
-__device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht_key, const u64 *__restrict__ ht_val, u64 ht_mask,
-                                          u64 key, u64 *start, u32 *cnt) {
+__device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 ht_mask, u64 key, u64 *start, u32 *cnt) {
     u64 slot = ht_slot_hash(key) & ht_mask;
     for (;;) {
-        u64 k = ht_key[slot];
-        if (k == key) { u64 v = ht_val[slot]; *start = v >> HT_CNT_BITS; *cnt = (u32)(v & HT_CNT_MAX); return true; }
-        if (k == HT_EMPTY) return false;
+        const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
+        if (e.x == key) { *start = e.y >> HT_CNT_BITS; *cnt = (u32)(e.y & HT_CNT_MAX); return true; }
+        if (e.x == HT_EMPTY) return false;
         slot = (slot + 1) & ht_mask;
     }
 }

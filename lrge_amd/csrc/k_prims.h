@@ -184,11 +184,18 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict__ keys_in, const u64 *__restrict__ vals_in,
                                                            u64 *__restrict__ keys_out, u64 *__restrict__ vals_out, u64 n,
                                                            int shift, u32 nb, const u32 *__restrict__ hist_scanned) {
-    __shared__ u32 cnt[RS_WAVES][256];
+    // 1. per-wave stable ranks (ballot digit matching + per-wave LDS counters)
+    // 2. block-local destinations: the tile is first reordered through LDS so that each digit's
+    //    items are contiguous, then written out as coalesced runs (one run per digit per tile)
+    __shared__ u32 cnt[RS_WAVES][256];   // per-wave digit counts -> block-local start of (wave, digit)
+    __shared__ u32 gbase[256];           // global destination of the tile's digit run minus its local start
+    __shared__ u32 wtot[RS_WAVES];
+    __shared__ u64 stage[RS_TILE];       // 32 KB: keys, then values
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     for (u32 i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    u64 base = (u64)blockIdx.x * RS_TILE + (u64)w * (RS_ITEMS * 64) + lane;
+    const u64 tile0 = (u64)blockIdx.x * RS_TILE;
+    const u64 base = tile0 + (u64)w * (RS_ITEMS * 64) + lane;
     u64 k[RS_ITEMS];
     u32 rank[RS_ITEMS];
     const u64 lt = lanemask_lt();
@@ -204,7 +211,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
             u64 bal = __ballot((d >> b) & 1);
             m &= ((d >> b) & 1) ? bal : ~bal;
         }
-        // m = lanes (valid) with my digit
         u32 before = (u32)__popcll(m & lt);
         u32 leader = (u32)__ffsll((unsigned long long)m) - 1;
         u32 old = 0;
@@ -213,22 +219,49 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         rank[r] = old + before;
     }
     __syncthreads();
-    {   // thread d: turn per-wave totals into global destinations
-        u32 d = threadIdx.x;
-        u32 run = hist_scanned[(u64)d * nb + blockIdx.x];
+    {   // thread d: digit totals -> exclusive scan over digits -> local starts per (wave, digit)
+        const u32 d = threadIdx.x;
+        u32 c[RS_WAVES], tot = 0;
 #pragma unroll
-        for (int ww = 0; ww < RS_WAVES; ++ww) { u32 t = cnt[ww][d]; cnt[ww][d] = run; run += t; }
+        for (int ww = 0; ww < RS_WAVES; ++ww) { c[ww] = cnt[ww][d]; tot += c[ww]; }
+        u32 inc = wave_incl_scan_u32(tot);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        u32 dstart = inc - tot;
+        for (u32 ww = 0; ww < w; ++ww) dstart += wtot[ww];
+        gbase[d] = hist_scanned[(u64)d * nb + blockIdx.x] - dstart;
+        u32 run = dstart;
+#pragma unroll
+        for (int ww = 0; ww < RS_WAVES; ++ww) { cnt[ww][d] = run; run += c[ww]; }
+    }
+    __syncthreads();
+    const u32 n_tile = (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
+    u32 lpos[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        u64 i = base + (u64)r * 64;
+        u32 d = (u32)(k[r] >> shift) & 255;
+        lpos[r] = cnt[w][d] + rank[r];
+        if (i < n) stage[lpos[r]] = k[r];
+    }
+    __syncthreads();
+    u64 ko[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        u32 p = (u32)r * RS_THREADS + threadIdx.x;
+        if (p < n_tile) { ko[r] = stage[p]; keys_out[gbase[(u32)(ko[r] >> shift) & 255] + p] = ko[r]; }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         u64 i = base + (u64)r * 64;
-        if (i < n) {
-            u32 d = (u32)(k[r] >> shift) & 255;
-            u32 dst = cnt[w][d] + rank[r];
-            keys_out[dst] = k[r];
-            vals_out[dst] = vals_in[i];
-        }
+        if (i < n) stage[lpos[r]] = vals_in[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        u32 p = (u32)r * RS_THREADS + threadIdx.x;
+        if (p < n_tile) vals_out[gbase[(u32)(ko[r] >> shift) & 255] + p] = stage[p];
     }
 }
 

@@ -14,7 +14,7 @@ struct KeyLayout {      // composite anchor sort key: qlocal | rid | rev | rpos
 };
 
 struct SeedParams {
-    const u64 *ht_key, *ht_val; u64 ht_mask;
+    const u64 *ht; u64 ht_mask;
     const u64 *pos;            // index position lists
     const u32 *t_len, *t_rank; // indexed reads
     const u32 *q_len, *q_rank; // query reads
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, cons
     u32 n = 0, v = 0; u64 st = 0;
     if (x != 0) {  // x == 0: removed by k_qocc_mark
         u32 cnt;
-        if (ht_lookup(sp.ht_key, sp.ht_val, sp.ht_mask, x >> 8, &st, &cnt)) {
+        if (ht_lookup(sp.ht, sp.ht_mask, x >> 8, &st, &cnt)) {
             if ((i64)cnt <= (i64)sp.mid_occ) n = cnt;  // m[i].n > max_occ -> flt
         }
     }
@@ -151,13 +151,30 @@ __global__ void k_group_bin(const u32 *__restrict__ gstart, u32 n_groups, u64 n_
                             u32 *__restrict__ bin_count, u32 *__restrict__ bin_list /* [N_BINS][n_groups] */,
                             unsigned long long *__restrict__ bin_anchors) {
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_groups) return;
-    u64 e = (g + 1 < n_groups) ? gstart[g + 1] : n_anchors;
-    u32 n = (u32)(e - gstart[g]);
-    if (n < min_n) return;
-    int b = N_BINS - 1;
-    for (int t = N_BINS - 2; t >= 0; --t) if (n <= bl.lim[t]) b = t;
-    u32 slot = atomicAdd(&bin_count[b], 1u);
-    bin_list[(u64)b * n_groups + slot] = g;
-    atomicAdd(&bin_anchors[b], (unsigned long long)n);
+    int b = -1; u32 n = 0;
+    if (g < n_groups) {
+        u64 e = (g + 1 < n_groups) ? gstart[g + 1] : n_anchors;
+        n = (u32)(e - gstart[g]);
+        if (n >= min_n) {
+            b = N_BINS - 1;
+            for (int t = N_BINS - 2; t >= 0; --t) if (n <= bl.lim[t]) b = t;
+        }
+    }
+    // one atomic per (wave, bin) instead of one per group
+#pragma unroll
+    for (int t = 0; t < N_BINS; ++t) {
+        const u64 m = __ballot(b == t);
+        if (m == 0) continue;
+        u32 tot = n;   // wave sum of n over the lanes of this bin
+        if (b != t) tot = 0;
+        for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+        const u32 leader = (u32)__ffsll((unsigned long long)m) - 1;
+        u32 base = 0;
+        if (lane_id() == leader) {
+            base = atomicAdd(&bin_count[t], (u32)__popcll(m));
+            atomicAdd(&bin_anchors[t], (unsigned long long)tot);
+        }
+        base = __shfl(base, leader, 64);
+        if (b == t) bin_list[(u64)t * n_groups + base + (u32)__popcll(m & lanemask_lt())] = g;
+    }
 }

@@ -302,15 +302,14 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         while (cap < 2 * (u64)n_runs) cap <<= 1;
         ix->ht_mask = cap - 1;
         ix->n_keys = n_runs;
-        u64 *htk = sc.get<u64>(cap), *htv = sc.get<u64>(cap);
+        u64 *ht = sc.get<u64>(2 * cap);
         u32 *d_occ = sc.get<u32>((size_t)max_bin + 1);
-        if (!htk || !htv || !d_occ) { delete ix; return LRGE_ERR_DEVICE; }
-        HIPCHK(ctx, hipMemsetAsync(htk, 0xFF, cap * 8, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(htv, 0, cap * 8, ctx->stream));
+        if (!ht || !d_occ) { delete ix; return LRGE_ERR_DEVICE; }
+        HIPCHK(ctx, hipMemsetAsync(ht, 0xFF, 2 * cap * 8, ctx->stream));   // key = HT_EMPTY
         HIPCHK(ctx, hipMemsetAsync(d_occ, 0, ((size_t)max_bin + 1) * 4, ctx->stream));
         if (n_runs) {
             hipLaunchKernelGGL(k_table_insert, dim3((u32)div_up(n_runs, 256)), dim3(256), 0, ctx->stream, skey, d_runstart, n_runs, M,
-                               htk, htv, ix->ht_mask, d_occ, max_bin);
+                               ht, ix->ht_mask, d_occ, max_bin);
             KCHK(ctx);
         }
         occ.resize((size_t)max_bin + 1);
@@ -318,7 +317,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         sc.drop(d_occ);
         if (d_runstart) sc.drop(d_runstart);
-        ix->d_ht_key = htk; ix->d_ht_val = htv; sc.keep(htk); sc.keep(htv);
+        ix->d_ht = ht; sc.keep(ht);
         t.stop();
     }
     // mm_idx_cal_max_occ + mm_mapopt_update clamps (mm2:index.c, mm2:options.c; aligner.rs:189)
@@ -344,7 +343,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
 extern "C" void lrge_hip_index_free(lrge_hip_index *ix) {
     if (!ix) return;
     ix->ctx->pool.release(ix->d_pos); ix->ctx->pool.release(ix->d_skey);
-    ix->ctx->pool.release(ix->d_ht_key); ix->ctx->pool.release(ix->d_ht_val);
+    ix->ctx->pool.release(ix->d_ht);
     delete ix;
 }
 
@@ -461,7 +460,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
 
     // ---- 3. lookup ----
     SeedParams sp;
-    sp.ht_key = ix->d_ht_key; sp.ht_val = ix->d_ht_val; sp.ht_mask = ix->ht_mask; sp.pos = ix->d_pos;
+    sp.ht = ix->d_ht; sp.ht_mask = ix->ht_mask; sp.pos = ix->d_pos;
     sp.t_len = T->d_len; sp.t_rank = T->d_rank; sp.q_len = Q->d_len; sp.q_rank = Q->d_rank;
     sp.mid_occ = ix->mid_occ;
     sp.check_names = (Q->has_rank && T->has_rank) ? 1 : 0;   // qname == NULL in minimap2 skips skip_seed entirely

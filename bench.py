@@ -150,7 +150,7 @@ def main():
         K = a.steps
         ms_per_step = elapsed * 1e3 / K
         value = world * Qn * K / elapsed
-        # ---- roofline of the dominant kernel (k_chain_lds), HBM-bound by construction ----
+        # ---- roofline of the dominant kernel (k_chain_reg) against the HBM roof ----
         # algorithmic bytes per launch = 16 B per anchor read (8 B key + 8 B value) + 4 B flag per group,
         # the "16*H anchor in for chaining" term of B_q, restricted to what a launch covers.
         launches = max(1, acc_cn.get("chain_launches", 0))
@@ -162,7 +162,7 @@ def main():
         pj = os.path.join(ROOT, "profiles", "chain_pmc.json")
         if os.path.exists(pj):
             try:
-                traffic = json.load(open(pj)).get("k_chain_lds_hbm_bytes_per_launch")
+                traffic = json.load(open(pj)).get("k_chain_reg_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
@@ -184,7 +184,7 @@ def main():
             "genome_size_abs_error": None if med[1] is None else abs(float(med[1]) - gsize),
             "estimate_q15_q65": [None if med[0] is None else float(med[0]), None if med[2] is None else float(med[2])],
             "mid_occ": st["mid_occ"],
-            "roofline": {"bound": "hbm", "kernel": "k_chain_lds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": os.environ.get("LRGE_HIP_CHAIN", "reg") == "reg" and "k_chain_reg" or "k_chain_lds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_ms, "launches_per_step": launches / K,
                          "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS},

@@ -1,6 +1,9 @@
 // k_index.h -- K2 index build on top of the sorted (hash, y) stream, K2b occurrence threshold,
 // K3 lookup.  Restates mm2:index.c worker_post / mm_idx_get / mm_idx_cal_max_occ as:
 //   sorted keys -> run heads -> open-addressing table  hash -> (start, count)  into pos[].
+// (A bucket directory over the sorted distinct keys was tried instead of the table: minimizer hashes
+// are window minima, i.e. heavily skewed toward small values, which starves the top buckets and
+// crowds the bottom ones; the hash table is indifferent to the key distribution.)
 // The position list of a key is the y values in ascending order (the reference re-sorts every list
 // by y, and the sketch stream is already ascending in y, so a STABLE key sort yields that order).
 #pragma once
@@ -39,8 +42,10 @@ __global__ __launch_bounds__(256) void k_table_insert(const u64 *__restrict__ sk
     __shared__ u32 lh[OCC_LDS_BINS];
     for (u32 i = threadIdx.x; i < OCC_LDS_BINS; i += blockDim.x) lh[i] = 0;
     __syncthreads();
-    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n_runs) {
+    // grid-stride with a small grid: the histogram flush below hits the same few global addresses from
+    // every block, so the number of blocks (not of runs) sets that serialised cost
+    for (u64 rr = (u64)blockIdx.x * blockDim.x + threadIdx.x; rr < n_runs; rr += (u64)gridDim.x * blockDim.x) {
+        const u32 r = (u32)rr;
         u32 st = run_start[r];
         u64 en = (r + 1 < n_runs) ? run_start[r + 1] : n;
         u32 cnt = (u32)(en - st);
@@ -52,8 +57,17 @@ __global__ __launch_bounds__(256) void k_table_insert(const u64 *__restrict__ sk
             slot = (slot + 1) & ht_mask;
         }
         ht[2 * slot + 1] = (u64)st << HT_CNT_BITS | (cnt < HT_CNT_MAX ? cnt : HT_CNT_MAX);
-        u32 b = cnt < max_bin ? cnt : max_bin;
-        if (b < OCC_LDS_BINS) atomicAdd(&lh[b], 1u); else atomicAdd(&occ_hist[b], 1u);
+        const u32 hb = cnt < max_bin ? cnt : max_bin;
+        // most runs have length 1 or 2: count those per wave with a ballot instead of 64 conflicting
+        // LDS atomics on one address
+        const u64 m1 = __ballot(hb == 1), m2 = __ballot(hb == 2);
+        const u32 leader = (u32)__ffsll((unsigned long long)__ballot(true)) - 1;
+        if (lane_id() == leader) {
+            if (m1) atomicAdd(&lh[1], (u32)__popcll(m1));
+            if (m2) atomicAdd(&lh[2], (u32)__popcll(m2));
+        }
+        if (hb > 2) { if (hb < OCC_LDS_BINS) atomicAdd(&lh[hb], 1u); else atomicAdd(&occ_hist[hb], 1u); }
+        else if (hb == 0) atomicAdd(&lh[0], 1u);
     }
     __syncthreads();
     for (u32 i = threadIdx.x; i < OCC_LDS_BINS && i <= max_bin; i += blockDim.x)

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, cons
     if (i >= n_mz) return;
     u64 x = qx[i];
     u32 n = 0, v = 0; u64 st = 0;
-    if (x != 0) {  // x == 0: removed by k_qocc_mark
+    {
         u32 cnt;
         if (ht_lookup(sp.ht, sp.ht_mask, x >> 8, &st, &cnt)) {
             if ((i64)cnt <= (i64)sp.mid_occ) n = cnt;  // m[i].n > max_occ -> flt
@@ -106,22 +106,30 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
 }
 
 // ------------------------------------------------------------------------------------------
-// K4a: query occurrence filter.  Pairs (q<<40-ish | x) are sorted by the host wrapper; here a run of
-// identical (q, x) longer than both thresholds zeroes qx of all its members.
+// K4a: query occurrence filter (mm2:seed.c mm_seed_mz_flt), run on the minimizers that have usable
+// hits.  (x, query|index) pairs are sorted by x and then stably by query; a run of identical
+// (query, x) longer than both thresholds removes all its members (hn = hv = 0).
 // ------------------------------------------------------------------------------------------
-__global__ void k_qocc_keys(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 n, u64 *__restrict__ k_hi,
-                            u64 *__restrict__ v_idx) {
+__global__ void k_qocc_flag(const u32 *__restrict__ hn, u64 n, u32 *__restrict__ flag) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    k_hi[i] = qx[i];
-    v_idx[i] = (qy[i] >> 32) << 32 | (u32)i;  // value carries (query, original index); needs n < 2^32
+    flag[i] = hn[i] ? 1u : 0u;
 }
 
-// After a stable sort by x (bits 0..2k+8) and then by query (value hi) -- done as two key sorts --
-// runs of equal (query, x) are adjacent.  One lane per element finds its run by scanning (runs are
-// short except for the pathological ones this filter exists for, so the heads do the work).
+__global__ void k_qocc_keys(const u64 *__restrict__ qx, const u64 *__restrict__ qy, const u32 *__restrict__ flag,
+                            const u32 *__restrict__ fpos, u64 n, u64 *__restrict__ k_x, u64 *__restrict__ v_idx) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const u32 o = fpos[i];
+    k_x[o] = qx[i];
+    v_idx[o] = (qy[i] >> 32) << 32 | (u32)i;  // value carries (query, original index); needs n < 2^32
+}
+
+// One lane per element; run heads do the work (runs are short except for the pathological ones this
+// filter exists for).
 __global__ void k_qocc_mark(const u64 *__restrict__ sx, const u64 *__restrict__ sv, u64 n,
-                            const u32 *__restrict__ qmz_off, int mid_occ, float q_occ_frac, u64 *__restrict__ qx) {
+                            const u32 *__restrict__ qmz_off, int mid_occ, float q_occ_frac, u32 *__restrict__ hn,
+                            u32 *__restrict__ hv) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 x = sx[i]; u32 q = (u32)(sv[i] >> 32);
@@ -132,7 +140,7 @@ __global__ void k_qocc_mark(const u64 *__restrict__ sx, const u64 *__restrict__ 
     u32 nq = qmz_off[q + 1] - qmz_off[q];
     if ((i64)nq <= (i64)mid_occ) return;                                   // mv->n <= q_occ_max: filter off
     if (cnt > mid_occ && (float)cnt > (float)(u64)nq * q_occ_frac)
-        for (u64 t = i; t < j; ++t) qx[(u32)sv[t]] = 0;
+        for (u64 t = i; t < j; ++t) { hn[(u32)sv[t]] = 0; hv[(u32)sv[t]] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -145,36 +153,36 @@ __global__ void k_group_heads(const u64 *__restrict__ skey, u64 n, u32 bits_rpos
 }
 
 #define N_BINS 5
+#define GB_CHUNK 8192   // groups per block in k_group_bin
 struct BinLimits { u32 lim[N_BINS]; };  // bin b holds groups with n <= lim[b] (last = unbounded)
 
 __global__ void k_group_bin(const u32 *__restrict__ gstart, u32 n_groups, u64 n_anchors, u32 min_n, BinLimits bl,
                             u32 *__restrict__ bin_count, u32 *__restrict__ bin_list /* [N_BINS][n_groups] */,
                             unsigned long long *__restrict__ bin_anchors) {
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    int b = -1; u32 n = 0;
-    if (g < n_groups) {
-        u64 e = (g + 1 < n_groups) ? gstart[g + 1] : n_anchors;
-        n = (u32)(e - gstart[g]);
-        if (n >= min_n) {
-            b = N_BINS - 1;
+    // Each block owns a contiguous chunk of GB_CHUNK groups: count per bin in LDS, reserve the list
+    // slots with ONE global atomic per (block, bin) -- every block hits the same N_BINS addresses, so
+    // the block count sets the serialised cost -- then fill.  Order inside a bin is irrelevant.
+    __shared__ u32 lcnt[N_BINS], lbase[N_BINS], lfill[N_BINS];
+    __shared__ unsigned long long lanch[N_BINS];
+    if (threadIdx.x < N_BINS) { lcnt[threadIdx.x] = 0; lfill[threadIdx.x] = 0; lanch[threadIdx.x] = 0; }
+    __syncthreads();
+    const u64 c0 = (u64)blockIdx.x * GB_CHUNK;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (u64 gg = c0 + threadIdx.x; gg < c0 + GB_CHUNK && gg < n_groups; gg += blockDim.x) {
+            const u32 g = (u32)gg;
+            const u64 e = (g + 1 < n_groups) ? gstart[g + 1] : n_anchors;
+            const u32 n = (u32)(e - gstart[g]);
+            if (n < min_n) continue;
+            int b = N_BINS - 1;
             for (int t = N_BINS - 2; t >= 0; --t) if (n <= bl.lim[t]) b = t;
+            if (pass == 0) { atomicAdd(&lcnt[b], 1u); atomicAdd(&lanch[b], (unsigned long long)n); }
+            else bin_list[(u64)b * n_groups + lbase[b] + atomicAdd(&lfill[b], 1u)] = g;
         }
-    }
-    // one atomic per (wave, bin) instead of one per group
-#pragma unroll
-    for (int t = 0; t < N_BINS; ++t) {
-        const u64 m = __ballot(b == t);
-        if (m == 0) continue;
-        u32 tot = n;   // wave sum of n over the lanes of this bin
-        if (b != t) tot = 0;
-        for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
-        const u32 leader = (u32)__ffsll((unsigned long long)m) - 1;
-        u32 base = 0;
-        if (lane_id() == leader) {
-            base = atomicAdd(&bin_count[t], (u32)__popcll(m));
-            atomicAdd(&bin_anchors[t], (unsigned long long)tot);
+        __syncthreads();
+        if (pass == 0 && threadIdx.x < N_BINS && lcnt[threadIdx.x]) {
+            lbase[threadIdx.x] = atomicAdd(&bin_count[threadIdx.x], lcnt[threadIdx.x]);
+            atomicAdd(&bin_anchors[threadIdx.x], lanch[threadIdx.x]);
         }
-        base = __shfl(base, leader, 64);
-        if (b == t) bin_list[(u64)t * n_groups + base + (u32)__popcll(m & lanemask_lt())] = g;
+        __syncthreads();
     }
 }

@@ -308,13 +308,25 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         HIPCHK(ctx, hipMemsetAsync(ht, 0xFF, 2 * cap * 8, ctx->stream));   // key = HT_EMPTY
         HIPCHK(ctx, hipMemsetAsync(d_occ, 0, ((size_t)max_bin + 1) * 4, ctx->stream));
         if (n_runs) {
-            hipLaunchKernelGGL(k_table_insert, dim3((u32)div_up(n_runs, 256)), dim3(256), 0, ctx->stream, skey, d_runstart, n_runs, M,
-                               ht, ix->ht_mask, d_occ, max_bin);
+            hipLaunchKernelGGL(k_table_insert, dim3((u32)std::min<u64>(div_up(n_runs, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                               skey, d_runstart, n_runs, M, ht, ix->ht_mask, d_occ, max_bin);
             KCHK(ctx);
         }
-        occ.resize((size_t)max_bin + 1);
-        HIPCHK(ctx, hipMemcpyAsync(occ.data(), d_occ, ((size_t)max_bin + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        // the k-th smallest occurrence count almost always sits in the first few bins: fetch 16 KB of
+        // the histogram first, the whole 4 MB only if the prefix does not reach the k-th element
+        occ.assign((size_t)max_bin + 1, 0);
+        const size_t head_bins = std::min<size_t>(4096, (size_t)max_bin + 1);
+        HIPCHK(ctx, hipMemcpyAsync(occ.data(), d_occ, head_bins * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        {
+            const u32 kth = n_runs ? (u32)((1. - (double)P.mid_occ_frac) * (double)n_runs) : 0;
+            u64 cum = 0;
+            for (size_t b = 0; b < head_bins; ++b) cum += occ[b];
+            if (n_runs && cum <= kth) {
+                HIPCHK(ctx, hipMemcpyAsync(occ.data(), d_occ, ((size_t)max_bin + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            }
+        }
         sc.drop(d_occ);
         if (d_runstart) sc.drop(d_runstart);
         ix->d_ht = ht; sc.keep(ht);
@@ -430,35 +442,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     HIPCHK(ctx, hipMemcpyAsync(h_mzoff.data(), so.mz_off, ((size_t)nq + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 
-    // ---- 2. query occurrence filter (mm_seed_mz_flt) ----
-    if (Mq > 0 && P.q_occ_frac > 0.0f && ix->mid_occ > 0) {
-        StageTimer t(ctx, LRGE_T_QFILTER);
-        // only queries with more minimizers than mid_occ can be affected
-        bool any = false;
-        for (u32 q = 0; q < nq && !any; ++q) any = (i64)(h_mzoff[q + 1] - h_mzoff[q]) > (i64)ix->mid_occ;
-        if (any) {
-            ALLOC_OR_FAIL(ka, sc, u64, Mq); ALLOC_OR_FAIL(va, sc, u64, Mq);
-            ALLOC_OR_FAIL(kb, sc, u64, Mq); ALLOC_OR_FAIL(vb, sc, u64, Mq);
-            hipLaunchKernelGGL(k_qocc_keys, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, so.y, Mq, ka, va);
-            KCHK(ctx);
-            u64 *rk, *rv;
-            rc = radix_sort_pairs(ctx, sc, ka, va, kb, vb, Mq, 0, 2 * P.k + 8, &rk, &rv);   // by x
-            if (rc) return rc;
-            u64 *ok = (rk == ka) ? kb : ka, *ov = (rv == va) ? vb : va;
-            u64 *rk2, *rv2;
-            // then (stable) by query id held in bits [32, 32+bits) of the value: swap roles
-            rc = radix_sort_pairs(ctx, sc, rv, rk, ov, ok, Mq, 32, (int)ceil_log2_u64((u64)nq + 1), &rk2, &rv2);
-            if (rc) return rc;
-            hipLaunchKernelGGL(k_qocc_mark, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, rv2 /* x */, rk2 /* (q,idx) */, Mq,
-                               so.mz_off, ix->mid_occ, P.q_occ_frac, so.x);
-            KCHK(ctx);
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            sc.drop(ka); sc.drop(va); sc.drop(kb); sc.drop(vb);
-        }
-        t.stop();
-    }
-
-    // ---- 3. lookup ----
+    // ---- 2. lookup ----
     SeedParams sp;
     sp.ht = ix->d_ht; sp.ht_mask = ix->ht_mask; sp.pos = ix->d_pos;
     sp.t_len = T->d_len; sp.t_rank = T->d_rank; sp.q_len = Q->d_len; sp.q_rank = Q->d_rank;
@@ -468,12 +452,56 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     ALLOC_OR_FAIL(hs, sc, u32, Mq + 1); ALLOC_OR_FAIL(hn, sc, u32, Mq + 1); ALLOC_OR_FAIL(hv, sc, u32, Mq + 1);
     ALLOC_OR_FAIL(d_qtot, sc, u32, (size_t)nq + 1);
     std::vector<u32> h_qtot((size_t)nq + 1, 0);
+    if (Mq) {
+        StageTimer t(ctx, LRGE_T_LOOKUP);
+        hipLaunchKernelGGL(k_lookup, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, so.y, Mq, sp, hs, hn, hv);
+        KCHK(ctx);
+        t.stop();
+    }
+
+    // ---- 3. query occurrence filter (mm_seed_mz_flt) ----
+    // minimap2 applies it before the lookup; the result is the same afterwards, restricted to the
+    // minimizers that still have hits: every occurrence of a value x in one query gets the same lookup
+    // result, so the per-query multiplicity of x is fully visible inside that subset, and values without
+    // (usable) hits contribute no anchors whether removed or not.
+    if (Mq > 0 && P.q_occ_frac > 0.0f && ix->mid_occ > 0) {
+        StageTimer t(ctx, LRGE_T_QFILTER);
+        bool any = false;   // only queries with more minimizers than mid_occ can be affected
+        for (u32 q = 0; q < nq && !any; ++q) any = (i64)(h_mzoff[q + 1] - h_mzoff[q]) > (i64)ix->mid_occ;
+        if (any) {
+            ALLOC_OR_FAIL(flag, sc, u32, Mq); ALLOC_OR_FAIL(fpos, sc, u32, Mq); ALLOC_OR_FAIL(d_ns, sc, u32, 1);
+            hipLaunchKernelGGL(k_qocc_flag, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hn, Mq, flag);
+            KCHK(ctx);
+            rc = scan_exclusive_u32(ctx, sc, flag, fpos, Mq, d_ns);
+            if (rc) return rc;
+            u32 Ms = 0;
+            HIPCHK(ctx, hipMemcpyAsync(&Ms, d_ns, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (Ms > (u32)ix->mid_occ) {
+                ALLOC_OR_FAIL(ka, sc, u64, Ms); ALLOC_OR_FAIL(va, sc, u64, Ms);
+                ALLOC_OR_FAIL(kb, sc, u64, Ms); ALLOC_OR_FAIL(vb, sc, u64, Ms);
+                hipLaunchKernelGGL(k_qocc_keys, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, so.y, flag, fpos, Mq, ka, va);
+                KCHK(ctx);
+                u64 *rk, *rv;
+                rc = radix_sort_pairs(ctx, sc, ka, va, kb, vb, Ms, 0, 2 * P.k + 8, &rk, &rv);   // by x
+                if (rc) return rc;
+                u64 *ok = (rk == ka) ? kb : ka, *ov = (rv == va) ? vb : va;
+                u64 *rk2, *rv2;
+                // then (stable) by query id held in bits [32, 32+bits) of the value: swap roles
+                rc = radix_sort_pairs(ctx, sc, rv, rk, ov, ok, Ms, 32, (int)ceil_log2_u64((u64)nq + 1), &rk2, &rv2);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_qocc_mark, dim3((u32)div_up(Ms, 256)), dim3(256), 0, ctx->stream, rv2 /* x */, rk2 /* (q,idx) */,
+                                   (u64)Ms, so.mz_off, ix->mid_occ, P.q_occ_frac, hn, hv);
+                KCHK(ctx);
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                sc.drop(ka); sc.drop(va); sc.drop(kb); sc.drop(vb);
+            }
+            sc.drop(flag); sc.drop(fpos); sc.drop(d_ns);
+        }
+        t.stop();
+    }
     {
         StageTimer t(ctx, LRGE_T_LOOKUP);
-        if (Mq) {
-            hipLaunchKernelGGL(k_lookup, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, so.y, Mq, sp, hs, hn, hv);
-            KCHK(ctx);
-        }
         hipLaunchKernelGGL(k_query_anchor_totals, dim3((u32)div_up(nq, 4)), dim3(256), 0, ctx->stream, hv, so.mz_off, nq, d_qtot);
         KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(h_qtot.data(), d_qtot, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -586,7 +614,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             KCHK(ctx);
             HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
             HIPCHK(ctx, hipMemsetAsync(bin_count, 0, N_BINS * 4, ctx->stream));
-            hipLaunchKernelGGL(k_group_bin, dim3((u32)div_up(G, 256)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, bl, bin_count, bin_list, bin_anchors);
+            hipLaunchKernelGGL(k_group_bin, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, bl, bin_count, bin_list, bin_anchors);
             KCHK(ctx);
             HIPCHK(ctx, hipMemcpyAsync(h_bins, bin_count, N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(h_bin_anchors, bin_anchors, N_BINS * 8, hipMemcpyDeviceToHost, ctx->stream));

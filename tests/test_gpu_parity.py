@@ -229,3 +229,33 @@ def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, monkeypatch, kerne
     counts, has = ixd.overlap_twoset(Qd)
     rc, ecounts, ehas = ixo.twoset_counts(Qo, threads=8)
     assert np.array_equal(counts, ecounts) and np.array_equal(has, ehas)
+
+
+def test_query_occurrence_filter(ctx, oracle):
+    """mm_seed_mz_flt in isolation: the query repeats a 60-mer 30 times; the targets cover that 60-mer
+    only ~3x, so the index keeps it (count <= mid_occ) and only the QUERY-side filter (cnt > mid_occ and
+    > 1% of the query's minimizers) removes its anchors."""
+    from lrge_amd import synth
+    genome = synth.random_genome(60_000, 777)
+    t = synth.sample_reads(genome, 30, "ont", seed=9)
+    motif = genome[10000:10060].tobytes()
+    q_rep = motif * 30 + genome[20000:23000].tobytes()
+    q_ctl = genome[9000:12000].tobytes()                 # same locus, no repeat: keeps its anchors
+    qseqs, qnames = [q_rep, q_ctl], [b"qrep", b"qctl"]
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, t.seqs(), t.names, "ont")
+    assert ixo.mid_occ == 10
+    mz = oracle.sketch(q_rep, 5, 15)
+    vals, cnts = np.unique(mz["x"], return_counts=True)
+    assert (cnts > 10).any(), "the query must hold minimizer values repeated more than mid_occ times"
+    rep_with_hits = sum(1 for v, c in zip(vals, cnts) if c > 10 and len(ixo.get(int(v) >> 8)) > 0)
+    assert rep_with_hits > 0, "and some of them must have index hits, otherwise the filter is moot"
+    for q in range(2):
+        x, y = ixd.anchors(Qd, q, dual=True)
+        a = ixo.anchors(qseqs[q], qnames[q])
+        assert np.array_equal(x, a["x"]) and np.array_equal(y & ~TANDEM_SELF, a["y"] & ~TANDEM_SELF)
+    # with the filter disabled the oracle finds strictly more anchors for the repeat query
+    ixo.opt.q_occ_frac = 0.0
+    assert len(ixo.anchors(q_rep, b"qrep")) > len(ixd.anchors(Qd, 0, dual=True)[0])
+    ixo.opt.q_occ_frac = 0.01
+    got = _chain_rows(ixd.chains(Qd, dual=True), ["query", "target", "rev", "score", "cnt", "qs", "qe", "rs", "re", "mlen", "blen"])
+    assert np.array_equal(got, _oracle_chains(ixo, qseqs, qnames))

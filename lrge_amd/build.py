@@ -36,5 +36,20 @@ def build_lib(force=False, verbose=False):
     return LIB_PATH
 
 
+CLI_PATH = os.path.join(LIB_DIR, "lrge-hip")
+
+
+def build_cli(force=False):
+    """The C++ host mirror (include/lrge_hip.hpp) + lrge-compatible driver, linked against liblrge_hip.so."""
+    src = os.path.join(os.path.dirname(_HERE), "tools", "lrge_hip_cli.cpp")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "lrge_hip.hpp")
+    if not force and os.path.exists(CLI_PATH) and os.path.getmtime(CLI_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr),
+                                                                                    os.path.getmtime(LIB_PATH)):
+        return CLI_PATH
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI_PATH, src, "-L" + LIB_DIR, "-llrge_hip", "-lz",
+                           "-Wl,-rpath,$ORIGIN"])
+    return CLI_PATH
+
+
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))

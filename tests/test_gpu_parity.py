@@ -259,3 +259,40 @@ def test_query_occurrence_filter(ctx, oracle):
     ixo.opt.q_occ_frac = 0.01
     got = _chain_rows(ixd.chains(Qd, dual=True), ["query", "target", "rev", "score", "cnt", "qs", "qe", "rs", "re", "mlen", "blen"])
     assert np.array_equal(got, _oracle_chains(ixo, qseqs, qnames))
+
+
+def test_cpp_host_mirror_cli(ctx, oracle, tmp_path):
+    """The C++ Estimate/AvaStrategy/TwoSetStrategy mirror (include/lrge_hip.hpp) driven through the
+    lrge-compatible CLI: all-vs-all over every read of the file is independent of the sampling RNG, so
+    the printed estimate must equal the median of the oracle's per-read estimates bit for bit."""
+    import subprocess
+    from lrge_amd import build as B, synth
+    from lrge_amd import ava as pyava
+    cli = B.build_cli()
+    g, reads, _ = synth.make_config("tiny_ava")
+    fa = tmp_path / "reads.fa"
+    with open(fa, "wb") as fh:
+        for n, s in zip(reads.names, reads.seqs()):
+            fh.write(b">" + n + b" some description\n" + s + b"\n")
+    out = subprocess.run([cli, "-n", str(reads.n), "-f", "-s", "3", str(fa)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = np.float32(float(out.stdout.strip()))
+    assert "Estimated genome size" in out.stderr and "Running all-vs-all strategy" in out.stderr
+    # oracle expectation
+    opt = oracle.make_opt(oracle.PRESET_AVA_ONT, dual=False)
+    ixo = oracle.Index(oracle.ReadSet(reads.seqs(), reads.names), opt)
+    rc, counts = ixo.ava_counts(threads=8)
+    avg = np.float32(reads.lens().sum()) / np.float32(reads.n - 1)
+    est = np.array([oracle.per_read_estimate(int(l), float(avg), reads.n - 1, int(c), 100) for l, c in zip(reads.lens(), counts)],
+                   dtype=np.float32)
+    lo, med, hi = oracle.median(est, True, 0.15, 0.65)
+    assert got == med
+    # the Python mirror agrees as well
+    r = pyava.Builder().num_reads(reads.n).seed(3).build((reads.names, reads.seqs())).estimate(True, 0.15, 0.65)
+    assert np.float32(r.estimate) == med and np.float32(r.lower) == lo and np.float32(r.upper) == hi
+    assert r.no_mapping_count == int((counts == 0).sum())
+    # two-set through the CLI: runs and reports a plausible size; too few reads is the reference's error
+    out = subprocess.run([cli, "-T", "150", "-Q", "50", "-s", "1", str(fa)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 0.5 * g < float(out.stdout) < 2.0 * g, (out.stdout, out.stderr)
+    out = subprocess.run([cli, "-T", "10", "-Q", "500", str(fa)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1 and "is <= query number of reads" in out.stderr

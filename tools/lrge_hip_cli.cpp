@@ -1,0 +1,127 @@
+// lrge_hip_cli.cpp -- flag-for-flag mirror of the `lrge` command line (lrge/src/cli.rs:9-87,
+// lrge/src/main.rs:32-123) driving the MI355X overlap engine through include/lrge_hip.hpp.
+// Input: plain or gzip FASTA/FASTQ (the reference's BAM/CRAM/zstd/bz2/xz readers are host I/O outside
+// the hot path: SURVEY.md 8f-4).  Like the reference CLI, -P is parsed but NOT forwarded to the
+// builders (lrge/src/main.rs:56-85), so the preset is always ava-ont; pass --honour-platform to
+// forward it (what the library API does).
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "../include/lrge_hip.hpp"
+
+static std::string read_id(const std::string &h) {   // io.rs:199-204
+    size_t i = 0;
+    while (i < h.size() && !(h[i] == ' ' || h[i] == '\t' || h[i] == '\n' || h[i] == '\r' || h[i] == '\v' || h[i] == '\f')) ++i;
+    return h.substr(0, i);
+}
+
+static bool gz_getline(gzFile f, std::string &out) {
+    out.clear();
+    char buf[1 << 16];
+    for (;;) {
+        if (!gzgets(f, buf, sizeof(buf))) return !out.empty();
+        out += buf;
+        if (!out.empty() && out.back() == '\n') { out.pop_back(); if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
+    }
+}
+
+static lrge::Reads load_fastx(const std::string &path) {
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) throw lrge::LrgeError(LRGE_ERR_IO, "cannot open " + path);
+    lrge::Reads r;
+    std::string line, seq;
+    if (!gz_getline(f, line)) { gzclose(f); return r; }
+    if (line[0] == '>') {
+        std::string name = read_id(line.substr(1));
+        while (gz_getline(f, line)) {
+            if (!line.empty() && line[0] == '>') { r.names.push_back(name); r.seqs.push_back(seq); seq.clear(); name = read_id(line.substr(1)); }
+            else seq += line;
+        }
+        r.names.push_back(name); r.seqs.push_back(seq);
+    } else if (line[0] == '@') {
+        for (;;) {
+            std::string name = read_id(line.substr(1)), s, plus, qual;
+            if (!gz_getline(f, s) || !gz_getline(f, plus) || !gz_getline(f, qual)) { gzclose(f); throw lrge::LrgeError(LRGE_ERR_PARSE, "truncated FASTQ record"); }
+            r.names.push_back(name); r.seqs.push_back(s);
+            if (!gz_getline(f, line)) break;
+        }
+    } else { gzclose(f); throw lrge::LrgeError(LRGE_ERR_PARSE, "unrecognised sequence file"); }
+    gzclose(f);
+    return r;
+}
+
+int main(int argc, char **argv) {
+    std::string input, output = "-", platform = "ont";
+    std::optional<size_t> T = 10000, Q = 5000, N;
+    bool T_set = false, Q_set = false, filter = false, with_inf = false, precise = false, use_min_ref = false, honour_platform = false;
+    float q1 = lrge::LOWER_QUANTILE, q3 = lrge::UPPER_QUANTILE, ratio = 0.2f;
+    size_t threads = 1; std::optional<uint64_t> seed; int quiet = 0, verbose = 0, device = 0;
+    auto need = [&](int &i) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "error: missing value for %s\n", argv[i]); exit(2); } return argv[++i]; };
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-o" || a == "--output") output = need(i);
+        else if (a == "-T" || a == "--target") { T = strtoull(need(i), 0, 10); T_set = true; }
+        else if (a == "-Q" || a == "--query") { Q = strtoull(need(i), 0, 10); Q_set = true; }
+        else if (a == "-n" || a == "--num") N = strtoull(need(i), 0, 10);
+        else if (a == "-P" || a == "--platform") { platform = need(i); if (platform != "ont" && platform != "pb") { fprintf(stderr, "error: invalid platform\n"); return 2; } }
+        else if (a == "-F" || a == "--filter-contained") filter = true;
+        else if (a == "-t" || a == "--threads") threads = strtoull(need(i), 0, 10);
+        else if (a == "-C" || a == "--keep-temp") {}
+        else if (a == "-D" || a == "--temp") need(i);
+        else if (a == "-s" || a == "--seed") seed = strtoull(need(i), 0, 10);
+        else if (a == "-8" || a == "--inf") with_inf = true;
+        else if (a == "-f" || a == "--float-my-boat") precise = true;
+        else if (a == "--q1") q1 = strtof(need(i), 0);
+        else if (a == "--q3") q3 = strtof(need(i), 0);
+        else if (a == "--max-overhang-ratio") ratio = strtof(need(i), 0);
+        else if (a == "--use-min-ref") use_min_ref = true;
+        else if (a == "--honour-platform") honour_platform = true;
+        else if (a == "--device") device = atoi(need(i));
+        else if (a == "-q" || a == "--quiet") ++quiet; else if (a == "-qq") quiet += 2; else if (a == "-qqq") quiet += 3;
+        else if (a == "-v" || a == "--verbose") ++verbose; else if (a == "-vv") verbose += 2;
+        else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
+        else input = a;
+    }
+    if (input.empty()) { fprintf(stderr, "error: the following required arguments were not provided: <INPUT>\n"); return 2; }
+    if (N && (T_set || Q_set)) { fprintf(stderr, "error: the argument '--num <INT>' cannot be used with '--target'/'--query'\n"); return 2; }
+    if (!(q1 >= 0.f && q1 <= 0.5f) || !(q3 >= 0.5f && q3 <= 1.f) || !(ratio >= 0.f && ratio <= 1.f)) { fprintf(stderr, "error: quantile/ratio out of range\n"); return 2; }
+    if (quiet && verbose) { fprintf(stderr, "error: --quiet cannot be used with --verbose\n"); return 2; }
+    const bool info = quiet == 0;
+    try {
+        lrge::Reads reads = load_fastx(input);
+        const lrge::Platform pf = (honour_platform && platform == "pb") ? lrge::Platform::PacBio : lrge::Platform::Nanopore;
+        lrge::twoset::TwoSetStrategy ts(reads); lrge::ava::AvaStrategy as(reads);
+        lrge::Estimate *st;
+        if (N) {
+            if (info) fprintf(stderr, "[INFO] Running all-vs-all strategy with %zu reads\n", *N);
+            as = lrge::ava::Builder().num_reads(*N).remove_internal(filter, ratio).threads(threads).seed(seed).platform(pf).device(device).build(reads);
+            st = &as;
+        } else {
+            if (info) fprintf(stderr, "[INFO] Running two-set strategy with %zu target reads and %zu query reads\n", *T, *Q);
+            ts = lrge::twoset::Builder().target_num_reads(*T).query_num_reads(*Q).remove_internal(filter, ratio).use_min_ref(use_min_ref)
+                     .threads(threads).seed(seed).platform(pf).device(device).build(reads);
+            st = &ts;
+        }
+        lrge::EstimateResult r = st->estimate(!with_inf, q1, q3);
+        if (quiet < 2) for (auto &w : (N ? as.warnings : ts.warnings)) fprintf(stderr, "[WARN] %s\n", w.c_str());
+        if (!r.estimate) { fprintf(stderr, "Error: %s\n", with_inf ? "No estimates were generated" : "No finite estimates were generated"); return 1; }
+        if (info) {
+            std::string msg = "Estimated genome size: " + lrge::format_estimate(*r.estimate);
+            if (r.lower && r.upper) msg += " (IQR: " + lrge::format_estimate(*r.lower) + " - " + lrge::format_estimate(*r.upper) + ")";
+            fprintf(stderr, "[INFO] %s\n", msg.c_str());
+        }
+        FILE *out = output == "-" ? stdout : fopen(output.c_str(), "w");
+        if (!out) { fprintf(stderr, "Error: Failed to create output file\n"); return 1; }
+        if (precise) fprintf(out, "%.9g\n", (double)*r.estimate); else fprintf(out, "%.0f\n", (double)*r.estimate);
+        if (out != stdout) fclose(out);
+        if (info) fprintf(stderr, "[INFO] Done!\n");
+    } catch (const lrge::LrgeError &e) {
+        fprintf(stderr, "Error: Failed to generate estimate\n\nCaused by:\n    %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

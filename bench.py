@@ -66,7 +66,8 @@ def cpu_baseline(q, t, budget_s):
     reads_per_s = done / (t_map + t_index * frac)
     return dict(value=reads_per_s, unit="reads/s", cores=cores, kind="port",
                 sample="first %d of %d query reads mapped on %d threads (%.1f s) against the full %d-read target index "
-                       "(built single-threaded in %.1f s, pro-rated x%.3f)" % (done, q.n, cores, t_map, t.n, t_index, frac),
+                       "(built in %.1f s: sketch + bucket sort on the same threads, scatter serial; pro-rated x%.3f)"
+                       % (done, q.n, cores, t_map, t.n, t_index, frac),
                 map_only_reads_per_s=done / t_map), np.concatenate(counts) if counts else np.zeros(0, np.uint32), ix.mid_occ
 
 
@@ -85,8 +86,10 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("LRGE_BENCH_FORCE_DIST") == "1"   # the switch lets a 1-GPU box exercise RCCL
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- synthetic inputs (untimed) ----
@@ -108,7 +111,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -119,7 +122,7 @@ def main():
         tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
         est = ctx.estimates(counts, qlens, float(avg_t), t.n, 100)
         ix.free()
-        if world > 1:   # the one collective of the path: per-read estimate vectors over RCCL/xGMI
+        if use_dist:    # the one collective of the path: per-read estimate vectors over RCCL/xGMI
             mine = torch.from_numpy(est).cuda()
             allv = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(allv, mine)
@@ -141,7 +144,7 @@ def main():
         for k, v in cn.items(): acc_cn[k] = acc_cn.get(k, 0) + v
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -200,7 +203,7 @@ def main():
             out["parity_vs_oracle_sample"] = {"reads": n, "counts_equal": bool(np.array_equal(ccounts, counts[:n])),
                                               "mid_occ_equal": bool(cmid == st["mid_occ"])}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
 

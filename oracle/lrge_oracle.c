@@ -338,9 +338,24 @@ lo_index_t *lo_index_build(const char *bases, const uint64_t *offs, uint32_t n,
         ix->name[i] = (char *)malloc(strlen(nm) + 1);
         strcpy(ix->name[i], nm);
         ix->len[i] = (int32_t)(offs[i + 1] - offs[i]);
-        if (ix->len[i] > 0) /* zero-length targets keep a rid but are not sketched */
-            sketch_into(bases + offs[i], ix->len[i], opt->w, opt->k, (uint32_t)i, opt->is_hpc, &v);
         ni[i].s = ix->name[i]; ni[i].i = (uint32_t)i;
+    }
+    {   /* sketch every read (minimap2 does this with its index threads: aligner.rs:181-185); reads are
+           sketched independently and concatenated in rid order, so the result is thread-count independent */
+        vec128_t *per = (vec128_t *)calloc(n ? n : 1, sizeof(vec128_t));
+        int64_t r;
+        uint64_t tot = 0;
+#pragma omp parallel for schedule(dynamic, 16)
+        for (r = 0; r < (int64_t)n; ++r)
+            if (ix->len[r] > 0) /* zero-length targets keep a rid but are not sketched */
+                sketch_into(bases + offs[r], ix->len[r], opt->w, opt->k, (uint32_t)r, opt->is_hpc, &per[r]);
+        for (i = 0; i < n; ++i) tot += (uint64_t)per[i].n;
+        v.a = (lo_mm128_t *)malloc((tot ? tot : 1) * sizeof(lo_mm128_t)); v.n = v.m = (int64_t)tot;
+        for (i = 0, tot = 0; i < n; ++i) {
+            if (per[i].n) memcpy(v.a + tot, per[i].a, (size_t)per[i].n * sizeof(lo_mm128_t));
+            tot += (uint64_t)per[i].n; free(per[i].a);
+        }
+        free(per);
     }
     qsort(ni, n, sizeof(nameidx_t), cmp_name);
     for (i = 0, j = 0; i < n; ++i) {
@@ -351,8 +366,25 @@ lo_index_t *lo_index_build(const char *bases, const uint64_t *offs, uint32_t n,
 
     ix->n_mz = (uint64_t)v.n; ix->mz = v.a;
     hy = (hy_t *)malloc((ix->n_mz ? ix->n_mz : 1) * sizeof(hy_t));
-    for (i = 0; i < ix->n_mz; ++i) { hy[i].h = v.a[i].x >> 8; hy[i].y = v.a[i].y; }
-    qsort(hy, ix->n_mz, sizeof(hy_t), cmp_hy);
+    {   /* sort by (hash, y): bucket on the top 12 hash bits (buckets concatenate into the global order),
+           then sort the buckets in parallel */
+        const int shift = 2 * opt->k > 12 ? 2 * opt->k - 12 : 0;
+        uint64_t *bstart = (uint64_t *)calloc(4097 + 1, 8), *fill;
+        int64_t b;
+        for (i = 0; i < ix->n_mz; ++i) ++bstart[((v.a[i].x >> 8) >> shift) + 1];
+        for (i = 0; i < 4096; ++i) bstart[i + 1] += bstart[i];
+        fill = (uint64_t *)malloc(4097 * 8);
+        memcpy(fill, bstart, 4097 * 8);
+        for (i = 0; i < ix->n_mz; ++i) {
+            uint64_t h = v.a[i].x >> 8, d = fill[h >> shift]++;
+            hy[d].h = h; hy[d].y = v.a[i].y;
+        }
+        free(fill);
+#pragma omp parallel for schedule(dynamic, 8)
+        for (b = 0; b < 4096; ++b)
+            if (bstart[b + 1] > bstart[b]) qsort(hy + bstart[b], bstart[b + 1] - bstart[b], sizeof(hy_t), cmp_hy);
+        free(bstart);
+    }
     for (i = 0, j = 0; i < ix->n_mz; ++i)
         if (i == 0 || hy[i].h != hy[i - 1].h) ++j;
     ix->n_keys = j;

@@ -1,0 +1,124 @@
+#!/usr/bin/env python
+"""Run one BASELINE.json config (lrge_amd.synth.CONFIGS) on one MI355X and print a JSON line for the
+table in BASELINE.md: timings, genome-size accuracy, and a parity spot-check against the CPU oracle
+on a sample of reads (the oracle is only the checker here).
+
+  python tools/run_config.py c3_yeast_ava --check 64
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--preset", default=None, help="ont|pb (default: ont, like the reference CLI)")
+    ap.add_argument("--check", type=int, default=32, help="reads spot-checked against the oracle (0 = none)")
+    ap.add_argument("--repeat", type=int, default=2)
+    a = ap.parse_args()
+    from lrge_amd import engine, synth
+    cfg = synth.CONFIGS[a.config]
+    preset = 1 if a.preset == "pb" else 0
+    t0 = time.perf_counter()
+    gsize, q, t = synth.make_config(a.config, a.scale)
+    t_gen = time.perf_counter() - t0
+    ctx = engine.Context(0)
+    out = {"config": a.config, "scale": a.scale, "preset": "ava-pb" if preset else "ava-ont", "mode": cfg["mode"],
+           "genome_size_true": gsize, "data_gen_s": round(t_gen, 1)}
+    if cfg["mode"] == "twoset":
+        t1 = time.perf_counter()
+        qr, tr = engine.name_ranks(q.names, t.names)
+        Qd, Td = ctx.upload(q.bases, q.offsets, qr), ctx.upload(t.bases, t.offsets, tr)
+        out["upload_s"] = round(time.perf_counter() - t1, 3)
+        best = None
+        for _ in range(a.repeat):
+            t1 = time.perf_counter()
+            ix = engine.Index(ctx, Td, preset)
+            tb = dict(ix.build_timings)
+            counts, has = ix.overlap_twoset(Qd)
+            tm, cn, st = ctx.timings(), ctx.counters(), ix.stats()
+            avg = np.float32(t.lens().sum()) / np.float32(t.n)
+            est = ctx.estimates(counts, q.lens(), float(avg), t.n, 100)
+            med = engine.median(est, True, 0.15, 0.65)
+            dt = time.perf_counter() - t1
+            ix.free()
+            if best is None or dt < best[0]:
+                best = (dt, tb, tm, cn, st, med, counts, has)
+        dt, tb, tm, cn, st, med, counts, has = best
+        out.update(n_query=q.n, n_target=t.n, step_s=round(dt, 4), reads_per_s=round(q.n / dt, 1),
+                   index_ms=round(tb["total"], 2), overlap_ms=round(tm["total"], 2),
+                   no_mapping=int((has == 0).sum()))
+        if a.check:
+            from oracle import oracle as O
+            opt = O.make_opt(O.PRESET_AVA_PB if preset else O.PRESET_AVA_ONT, dual=True)
+            t1 = time.perf_counter()
+            ixo = O.Index(O.ReadSet(t.seqs(), t.names), opt)
+            sub = q.slice(0, min(a.check, q.n))
+            rc, ec, eh = ixo.twoset_counts(O.ReadSet(sub.seqs(), sub.names), threads=os.cpu_count())
+            out["oracle_check"] = {"reads": sub.n, "counts_equal": bool(np.array_equal(ec, counts[:sub.n])),
+                                   "mid_occ_equal": bool(ixo.mid_occ == st["mid_occ"]), "oracle_s": round(time.perf_counter() - t1, 1)}
+    else:
+        reads = q
+        t1 = time.perf_counter()
+        (ranks,) = engine.name_ranks(reads.names)
+        Rd = ctx.upload(reads.bases, reads.offsets, ranks)
+        out["upload_s"] = round(time.perf_counter() - t1, 3)
+        best = None
+        for _ in range(a.repeat):
+            t1 = time.perf_counter()
+            ix = engine.Index(ctx, Rd, preset)
+            tb = dict(ix.build_timings)
+            counts = ix.overlap_ava()
+            tm, cn, st = ctx.timings(), ctx.counters(), ix.stats()
+            avg = np.float32(reads.lens().sum()) / np.float32(reads.n - 1)
+            est = ctx.estimates(counts, reads.lens(), float(avg), reads.n - 1, 100)
+            med = engine.median(est, True, 0.15, 0.65)
+            dt = time.perf_counter() - t1
+            ix.free()
+            if best is None or dt < best[0]:
+                best = (dt, tb, tm, cn, st, med, counts)
+        dt, tb, tm, cn, st, med, counts = best
+        out.update(n_reads=reads.n, step_s=round(dt, 4), reads_per_s=round(reads.n / dt, 1), index_ms=round(tb["total"], 2),
+                   overlap_ms=round(tm["total"], 2), no_mapping=int((counts == 0).sum()))
+        if a.check:
+            # all-vs-all counts are symmetric, so a sample cannot be checked in isolation: check the
+            # per-read chain targets of a sample instead (distinct targets found from that read's side)
+            from oracle import oracle as O
+            opt = O.make_opt(O.PRESET_AVA_PB if preset else O.PRESET_AVA_ONT, dual=False)
+            t1 = time.perf_counter()
+            ixo = O.Index(O.ReadSet(reads.seqs(), reads.names), opt)
+            n = min(a.check, reads.n)
+            sub = reads.slice(0, n)
+            Sd = ctx.upload(sub.bases, sub.offsets, ranks[:n])
+            ix = engine.Index(ctx, Rd, preset)
+            ch = ix.chains(Sd, dual=False)
+            got = sorted(set((int(c["query"]), int(c["target"])) for c in ch))
+            exp = sorted(set((qi, int(r["rid"])) for qi in range(n) for r in ixo.map(sub.seqs()[qi], sub.names[qi])))
+            ix.free()
+            out["oracle_check"] = {"reads": n, "pairs_equal": got == exp, "pairs": len(exp), "mid_occ_equal": bool(ixo.mid_occ == st["mid_occ"]),
+                                   "oracle_s": round(time.perf_counter() - t1, 1)}
+    M, H = cn["query_minimizers"], cn["anchors"]
+    qbases = cn["query_bases"]
+    B = qbases / 4 + 32 * M + 40 * H + 4 * (out.get("n_query") or out.get("n_reads"))
+    out.update(mid_occ=st["mid_occ"], n_minimizers_index=st["n_minimizers"], anchors=H, groups=cn["groups"], groups_chained=cn["groups_chained"],
+               batches=cn["batches"], estimate=None if med[1] is None else float(med[1]),
+               abs_err=None if med[1] is None else abs(float(med[1]) - gsize),
+               rel_err=None if med[1] is None else abs(float(med[1]) - gsize) / gsize,
+               q15_q65=[None if med[0] is None else float(med[0]), None if med[2] is None else float(med[2])],
+               stage_ms={**{"index_" + k: round(v, 2) for k, v in tb.items() if v and k != "total"}, **{k: round(v, 2) for k, v in tm.items() if v}},
+               alg_GBps_whole_path=round((B + sum(1 for _ in [0]) * 0 + (st["n_minimizers"] * 16)) / dt / 1e9, 1))
+    print(json.dumps(out))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,7 @@ struct DevPool {
     void destroy() { for (auto &b : blks) (void)hipFree(b.p); blks.clear(); total = 0; }
 };
 
+struct TimerRec;
 struct lrge_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -81,8 +82,14 @@ struct lrge_hip_ctx {
     DevPool pool;
     float ms[LRGE_T_N];
     u64 counters[LRGE_C_N];
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 256;
+    std::vector<struct TimerRec> timers;     // pending event pairs of the current call
+    std::vector<hipEvent_t> event_pool;      // recycled events
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+    }
+    void resolve_timers();                   // call after the stream has been synchronised
 };
 
 struct lrge_hip_seqset {
@@ -165,22 +172,39 @@ struct Scratch {
     T *var = (sc).get<T>(n);                          \
     if (!var) return LRGE_ERR_DEVICE;
 
+// Stage timing without extra synchronisation: a StageTimer records a HIP event pair on the ctx stream;
+// the pairs are turned into milliseconds once, by resolve_timers(), after the call's final sync.
+struct TimerRec { int slot; hipEvent_t a, b; };
+
 struct StageTimer {
     lrge_hip_ctx *ctx;
     int slot;
-    hipEvent_t a, b;
-    StageTimer(lrge_hip_ctx *c, int s) : ctx(c), slot(s) {
-        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-        (void)hipEventRecord(a, ctx->stream);
-    }
-    void stop() {
-        (void)hipEventRecord(b, ctx->stream);
-        (void)hipEventSynchronize(b);
-        float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
-        ctx->ms[slot] += ms;
-    }
-    ~StageTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    hipEvent_t a = nullptr, b = nullptr;
+    bool stopped = false;
+    StageTimer(lrge_hip_ctx *c, int s);
+    void stop();
+    ~StageTimer() { if (!stopped) stop(); }
 };
 
 static inline u32 ceil_log2_u64(u64 v) { u32 b = 0; while (b < 64 && (1ULL << b) < v) ++b; return b; }
 static inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
+
+inline StageTimer::StageTimer(lrge_hip_ctx *c, int s) : ctx(c), slot(s) {
+    a = ctx->get_event(); b = ctx->get_event();
+    (void)hipEventRecord(a, ctx->stream);
+}
+inline void StageTimer::stop() {
+    if (stopped) return;
+    stopped = true;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->timers.push_back(TimerRec{slot, a, b});
+}
+inline void lrge_hip_ctx::resolve_timers() {
+    for (auto &t : timers) {
+        (void)hipEventSynchronize(t.b);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) this->ms[t.slot] += ms;
+        event_pool.push_back(t.a); event_pool.push_back(t.b);
+    }
+    timers.clear();
+}

@@ -41,6 +41,7 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
     memset(ctx->counters, 0, sizeof(ctx->counters));
     *out = ctx;
@@ -51,6 +52,8 @@ extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ctx->resolve_timers();
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->pool.destroy();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -135,6 +138,7 @@ extern "C" int lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, cons
             t.stop();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        ctx->resolve_timers();
         (void)hipFree(d_ascii); (void)hipFree(d_boff);
         if (e != hipSuccess) return fail("pack", e);
     } else {
@@ -201,7 +205,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, ctx->stream, d_cs, d_cnt, s->n,
                        n_chunks, d_total, d_mzoff);
     KCHK(ctx);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
     sc.drop(d_cs); sc.drop(d_cnt); sc.drop(d_total);
     o->x = dx; o->y = dy; o->mz_off = d_mzoff; o->n = total;
     return LRGE_OK;
@@ -225,6 +229,7 @@ extern "C" int lrge_hip_sketch_dump(lrge_hip_ctx *ctx, const lrge_hip_seqset *s,
     if (rc) return rc;
     *n_out = o.n;
     u64 m = o.n < cap ? o.n : cap;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
     if (m && x) HIPCHK(ctx, hipMemcpy(x, o.x, m * 8, hipMemcpyDeviceToHost));
     if (m && y) HIPCHK(ctx, hipMemcpy(y, o.y, m * 8, hipMemcpyDeviceToHost));
     return LRGE_OK;
@@ -244,6 +249,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
     StageTimer t_total(ctx, LRGE_T_TOTAL);
     Scratch sc(ctx);
@@ -267,7 +273,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         u64 *rk, *rv;
         rc = radix_sort_pairs(ctx, sc, so.x, so.y, k1, v1, M, 0, 2 * P.k, &rk, &rv);
         if (rc) return rc;
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
         skey = rk; spos = rv;
         sc.drop(rk == so.x ? k1 : so.x);
         sc.drop(rv == so.y ? v1 : so.y);
@@ -348,6 +354,8 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     }
     ix->d_pos = spos; ix->d_skey = skey; sc.keep(spos); sc.keep(skey);
     t_total.stop();
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->resolve_timers();
     *out = ix;
     return LRGE_OK;
 }
@@ -373,6 +381,7 @@ extern "C" int lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     *n_out = ix->n_mz;
     u64 m = ix->n_mz < cap ? ix->n_mz : cap;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
     if (m && keys) HIPCHK(ctx, hipMemcpy(keys, ix->d_skey, m * 8, hipMemcpyDeviceToHost));
     if (m && pos) HIPCHK(ctx, hipMemcpy(pos, ix->d_pos, m * 8, hipMemcpyDeviceToHost));
     return LRGE_OK;
@@ -398,6 +407,7 @@ struct OverlapJob {
 
 static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *Q, OverlapJob &job) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
     memset(ctx->counters, 0, sizeof(ctx->counters));
     if (Q->has_empty && !job.dump_anchors) {  // aligner.rs:214-216 -> LrgeError::MapError aborts the run
@@ -428,6 +438,8 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         if (job.n_chains) *job.n_chains = 0;
         if (job.an) *job.an = 0;
         t_total.stop();
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->resolve_timers();
         return LRGE_OK;
     }
 
@@ -493,7 +505,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                 hipLaunchKernelGGL(k_qocc_mark, dim3((u32)div_up(Ms, 256)), dim3(256), 0, ctx->stream, rv2 /* x */, rk2 /* (q,idx) */,
                                    (u64)Ms, so.mz_off, ix->mid_occ, P.q_occ_frac, hn, hv);
                 KCHK(ctx);
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
                 sc.drop(ka); sc.drop(va); sc.drop(kb); sc.drop(vb);
             }
             sc.drop(flag); sc.drop(fpos); sc.drop(d_ns);
@@ -555,7 +567,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             hipLaunchKernelGGL(k_expand, dim3((u32)div_up(me - mb, 256)), dim3(256), 0, ctx->stream, so.x, so.y, mb, me, sp, hs, hn, aoff,
                                q0, kl, akey, aval);
             KCHK(ctx);
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
             bsc.drop(aoff);
             t.stop();
         }
@@ -563,7 +575,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             StageTimer t(ctx, LRGE_T_ANCHOR_SORT);
             rc = radix_sort_pairs(ctx, bsc, akey, aval, akey2, aval2, A, 0, (int)kl.total(), &skey, &sval);
             if (rc) return rc;
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
             bsc.drop(skey == akey ? akey2 : akey);
             bsc.drop(sval == aval ? aval2 : aval);
             t.stop();
@@ -573,6 +585,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             u64 m = A < job.acap ? A : job.acap;
             std::vector<u64> hk(m), hvv(m);
             if (m) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
                 HIPCHK(ctx, hipMemcpy(hk.data(), skey, m * 8, hipMemcpyDeviceToHost));
                 HIPCHK(ctx, hipMemcpy(hvv.data(), sval, m * 8, hipMemcpyDeviceToHost));
             }
@@ -589,6 +602,8 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<u64, u64> &a, const std::pair<u64, u64> &b) { return a.first < b.first; });
             for (u64 i = 0; i < m; ++i) { job.ax[i] = tmp[i].first; job.ay[i] = tmp[i].second; }
             t_total.stop();
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->resolve_timers();
             return LRGE_OK;
         }
         // groups
@@ -691,7 +706,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             cnp.t_dup = T->dup_rank ? 1 : 0;
             hipLaunchKernelGGL(k_count, dim3((u32)div_up(G, 256)), dim3(256), 0, ctx->stream, skey, gstart, gflags, G, cnp, d_counts, d_hasmap);
             KCHK(ctx);
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
             t.stop();
         }
         q0 = q1;
@@ -701,6 +716,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (job.n_chains) {
         unsigned long long nchn = 0;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
         HIPCHK(ctx, hipMemcpy(&nchn, d_nchains, 8, hipMemcpyDeviceToHost));
         *job.n_chains = nchn;
         u64 m = nchn < job.chain_cap ? nchn : job.chain_cap;
@@ -708,6 +724,8 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     }
     if (job.an && job.dump_anchors) *job.an = 0;
     t_total.stop();
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->resolve_timers();
     return LRGE_OK;
 }
 

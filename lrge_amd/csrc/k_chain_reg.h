@@ -93,13 +93,13 @@ struct GroupView {   // what the out-of-line paths need to reach a group's data 
 // when the loop broke before the start was determined.
 struct SlowTail { i32 st, max_f, max_j, end_j; };   // returned by value: nothing in the hot loop may be address-taken
 __device__ __noinline__ SlowTail chain_slow_tail(GroupView V, ChainParams P, i32 i, i32 xi, i32 yi, i32 lower, bool far_push,
-                                                 i32 far_p, i32 max_f, i32 max_j, i32 n_skip) {
+                                                 i32 far_p, i32 max_f, i32 max_j, i32 n_skip, i32 first_base) {
     const i32 lane = (i32)lane_id();
     const u32 stamp = (u32)i + 1;
     i32 end_j = lower - 1, st = lower;
     if (far_push) V.tmark[far_p] = stamp;
     drain_stores();
-    for (i32 base = i - 65; base >= lower; base -= 64) {
+    for (i32 base = first_base; base >= lower; base -= 64) {
         const i32 jj = base - lane;
         const bool inb = jj >= lower;
         i32 xj = 0, yj = 0, sj = 0, fj = 0, pj = -1;
@@ -125,11 +125,12 @@ __device__ __noinline__ SlowTail chain_slow_tail(GroupView V, ChainParams P, i32
 
 // Slow path 2: max_ii must be re-derived over a window longer than the registers.  `best` holds the
 // per-lane candidates from the register window; returns the wave-wide best key (f << 32 | j).
-__device__ __noinline__ u64 chain_slow_rescan(GroupView V, ChainParams P, i32 i, i32 xi, i32 lower, i32 st, u64 best) {
+__device__ __noinline__ u64 chain_slow_rescan(GroupView V, ChainParams P, i32 i, i32 xi, i32 lower, i32 st, u64 best,
+                                              i32 first_base) {
     const i32 lane = (i32)lane_id();
     if (st < 0) {   // window start not determined yet
         st = lower;
-        for (i32 base = i - 65; base >= lower; base -= 64) {
+        for (i32 base = first_base; base >= lower; base -= 64) {
             const i32 jj = base - lane;
             const bool reach = jj >= lower && (i32)(V.gk[jj >= 0 ? jj : 0] & V.rmask) + P.max_dist_x >= xi;
             const i32 n_reach = (i32)__popcll(__ballot(reach));
@@ -137,7 +138,7 @@ __device__ __noinline__ u64 chain_slow_rescan(GroupView V, ChainParams P, i32 i,
         }
     }
     drain_stores();
-    for (i32 jj = i - 65 - lane; jj >= st; jj -= 64) {
+    for (i32 jj = first_base - lane; jj >= st; jj -= 64) {
         const u64 key = (u64)(u32)grec_f(ld_u64_l2(V.grec + jj)) << 32 | (u32)jj;
         best = key > best ? key : best;
     }
@@ -246,14 +247,14 @@ __global__ __launch_bounds__(64) void k_chain_reg(RegChainArgs R, ChainParams P,
             if (!brk) {
                 const bool far_push = s != SC_NONE && wp >= 0 && tl >= 64;
                 const SlowTail r = chain_slow_tail(V, P, i, xi, yi, lower, far_push, wp, max_f, max_j,
-                                                   __builtin_amdgcn_readlane(ns, 63));
+                                                   __builtin_amdgcn_readlane(ns, 63), i - 65);
                 st = r.st; max_f = r.max_f; max_j = r.max_j; end_j = r.end_j;
             }
         }
         // ---- max_ii bookkeeping (the "best f in the window" shortcut) ----
         if (mi < 0 || xi - mi_x > maxdx) {
             u64 best = actv >= 0 ? ((u64)(u32)wf << 32 | (u32)(i - 1 - lane)) : 0;   // f > 0; ties keep the larger j
-            if (beyond) best = chain_slow_rescan(V, P, i, xi, i - max_iter > 0 ? i - max_iter : 0, st, best);
+            if (beyond) best = chain_slow_rescan(V, P, i, xi, i - max_iter > 0 ? i - max_iter : 0, st, best, i - 65);
             best = wave_max_u64(best);
             const u32 bhi = RFL((u32)(best >> 32)), blo = RFL((u32)best);
             if (bhi == 0) mi = -1;

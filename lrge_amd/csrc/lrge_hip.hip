@@ -12,6 +12,7 @@
 #include "k_seed.h"
 #include "k_chain.h"
 #include "k_chain_reg.h"
+#include "k_chain_hw.h"
 
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
 
@@ -607,9 +608,14 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             return LRGE_OK;
         }
         // groups
-        u32 G = 0; u32 *gstart, *gflags, *bin_count, *bin_list;
-        u32 h_bins[N_BINS];
-        unsigned long long h_bin_anchors[N_BINS];
+        // LRGE_HIP_CHAIN selects the chain kernel: default "hw" (two groups per wavefront), "reg" (one group
+        // per wavefront, register window), "lds" / "glb" (earlier forms, kept as on-device references)
+        const char *cm = getenv("LRGE_HIP_CHAIN");
+        const int chain_mode = (cm && !strcmp(cm, "lds")) ? 1 : (cm && !strcmp(cm, "glb")) ? 2 : (cm && !strcmp(cm, "reg")) ? 3 : 0;
+        u32 G = 0; u32 *gstart, *gflags, *bin_count = nullptr, *bin_list = nullptr, *hw_list = nullptr;
+        u32 h_bins[N_BINS] = {0, 0, 0, 0, 0};
+        unsigned long long h_bin_anchors[N_BINS] = {0, 0, 0, 0, 0};
+        u32 n_chained = 0; unsigned long long a_chained = 0;
         {
             StageTimer t(ctx, LRGE_T_GROUP);
             u32 *head = bsc.get<u32>(A), *gid = bsc.get<u32>(A), *d_G = bsc.get<u32>(1);
@@ -621,29 +627,71 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             HIPCHK(ctx, hipMemcpyAsync(&G, d_G, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             gstart = bsc.get<u32>((size_t)G + 1); gflags = bsc.get<u32>((size_t)G + 1);
-            bin_count = bsc.get<u32>(N_BINS); bin_list = bsc.get<u32>((size_t)N_BINS * G + 1);
-            unsigned long long *bin_anchors = (unsigned long long *)bsc.get<u64>(N_BINS);
-            if (!gstart || !gflags || !bin_count || !bin_list || !bin_anchors) return LRGE_ERR_DEVICE;
-            HIPCHK(ctx, hipMemsetAsync(bin_anchors, 0, N_BINS * 8, ctx->stream));
+            if (!gstart || !gflags) return LRGE_ERR_DEVICE;
             hipLaunchKernelGGL(k_run_starts, dim3((u32)div_up(A, 256)), dim3(256), 0, ctx->stream, head, gid, A, gstart);
             KCHK(ctx);
             HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
-            HIPCHK(ctx, hipMemsetAsync(bin_count, 0, N_BINS * 4, ctx->stream));
-            hipLaunchKernelGGL(k_group_bin, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, bl, bin_count, bin_list, bin_anchors);
-            KCHK(ctx);
-            HIPCHK(ctx, hipMemcpyAsync(h_bins, bin_count, N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(h_bin_anchors, bin_anchors, N_BINS * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             bsc.drop(head); bsc.drop(gid); bsc.drop(d_G);
+            if (chain_mode == 0) {
+                // groups worth chaining, sorted by size (largest first) so that k_chain_hw pairs equals
+                u32 *d_cnt = bsc.get<u32>(2);
+                unsigned long long *d_anch = (unsigned long long *)bsc.get<u64>(1);
+                if (!d_cnt || !d_anch) return LRGE_ERR_DEVICE;
+                HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(d_anch, 0, 8, ctx->stream));
+                hipLaunchKernelGGL(k_group_count, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, d_cnt, d_anch);
+                KCHK(ctx);
+                HIPCHK(ctx, hipMemcpyAsync(&n_chained, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(&a_chained, d_anch, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                if (n_chained) {
+                    u64 *k0 = bsc.get<u64>(n_chained), *v0 = bsc.get<u64>(n_chained), *k1 = bsc.get<u64>(n_chained), *v1 = bsc.get<u64>(n_chained);
+                    hw_list = bsc.get<u32>(n_chained);
+                    if (!k0 || !v0 || !k1 || !v1 || !hw_list) return LRGE_ERR_DEVICE;
+                    hipLaunchKernelGGL(k_group_fill, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, d_cnt + 1, k0, v0);
+                    KCHK(ctx);
+                    u64 *rk, *rv;
+                    rc = radix_sort_pairs(ctx, bsc, k0, v0, k1, v1, n_chained, 0, 16, &rk, &rv);   // keys: 65535 - min(n, 65535)
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(k_vals_to_u32, dim3((u32)div_up(n_chained, 256)), dim3(256), 0, ctx->stream, rv, n_chained, hw_list);
+                    KCHK(ctx);
+                    bsc.drop(k0); bsc.drop(v0); bsc.drop(k1); bsc.drop(v1);
+                }
+                bsc.drop(d_cnt); bsc.drop(d_anch);
+            } else {
+                bin_count = bsc.get<u32>(N_BINS); bin_list = bsc.get<u32>((size_t)N_BINS * G + 1);
+                unsigned long long *bin_anchors = (unsigned long long *)bsc.get<u64>(N_BINS);
+                if (!bin_count || !bin_list || !bin_anchors) return LRGE_ERR_DEVICE;
+                HIPCHK(ctx, hipMemsetAsync(bin_anchors, 0, N_BINS * 8, ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(bin_count, 0, N_BINS * 4, ctx->stream));
+                hipLaunchKernelGGL(k_group_bin, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, bl, bin_count, bin_list, bin_anchors);
+                KCHK(ctx);
+                HIPCHK(ctx, hipMemcpyAsync(h_bins, bin_count, N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(h_bin_anchors, bin_anchors, N_BINS * 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            }
             t.stop();
         }
         ctx->counters[LRGE_C_GROUPS] += G;
         {
             GroupOut go; go.flags = gflags; go.chains = d_chains; go.n_chains = d_nchains; go.chain_cap = job.chain_cap;
-            const char *cm = getenv("LRGE_HIP_CHAIN");
-            const int chain_mode = (cm && !strcmp(cm, "lds")) ? 1 : (cm && !strcmp(cm, "glb")) ? 2 : 0;
             if (chain_mode == 0) {
-                // default: register-window kernel, every group size in one launch, largest groups first
+                if (n_chained) {
+                    StageTimer t(ctx, LRGE_T_CHAIN);
+                    HwChainArgs ha;
+                    ha.akey = skey; ha.aval = sval; ha.gstart = gstart; ha.n_groups = G; ha.n_anchors = A; ha.list = hw_list; ha.n_list = n_chained;
+                    ha.grec = bsc.get<u64>(A); ha.tmark = bsc.get<u32>(A);
+                    if (!ha.grec || !ha.tmark) return LRGE_ERR_DEVICE;
+                    HIPCHK(ctx, hipMemsetAsync(ha.tmark, 0, A * 4, ctx->stream));
+                    hipLaunchKernelGGL(k_chain_hw, dim3((n_chained + 1) / 2), dim3(64), 0, ctx->stream, ha, cp, go);
+                    KCHK(ctx);
+                    t.stop();
+                    ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+                    ctx->counters[LRGE_C_CHAIN_ANCHORS] += a_chained;
+                    ctx->counters[LRGE_C_GROUPS_CHAINED] += n_chained;
+                }
+            } else if (chain_mode == 3) {
+                // register-window kernel, one group per wavefront, every group size in one launch, largest bins first
                 u32 total_blocks = 0; u64 total_anch = 0;
                 RegChainArgs ra;
                 ra.akey = skey; ra.aval = sval; ra.gstart = gstart; ra.n_groups = G; ra.n_anchors = A; ra.list = bin_list;

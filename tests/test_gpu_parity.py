@@ -203,7 +203,7 @@ def test_batching_is_invisible(ctx, oracle, tiny_ont, monkeypatch):
     assert np.array_equal(ref, small)
 
 
-@pytest.mark.parametrize("kernel", ["reg", "lds", "glb"])
+@pytest.mark.parametrize("kernel", ["hw", "reg", "lds", "glb"])
 @pytest.mark.parametrize("max_skip,max_iter", [(25, 5000), (100000, 5000), (100000, 40), (3, 90)])
 def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, monkeypatch, kernel, max_skip, max_iter):
     """All three chain kernels (register-window, LDS, global) against the oracle, including the

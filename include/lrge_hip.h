@@ -69,7 +69,8 @@ typedef struct {
     int32_t  qs, qe;     /* query_start / query_end */
     int32_t  rs, re;     /* target_start / target_end */
     int32_t  mlen, blen; /* match_len / block_len */
-    int32_t  reserved;
+    int32_t  n_seeds;    /* kept query seeds spanned by the chain: n_tot of mm_est_err before its two end
+                            corrections; with cnt (= n_match) and the query's avg_k it gives dv */
 } lrge_hip_chain;
 
 /* Stage timings of the last overlap/index call on a ctx, in milliseconds (HIP events on the
@@ -142,6 +143,14 @@ int  lrge_hip_overlap_ava(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
    chains found; only the first `cap` are written.  dual: 1 = two-set flags, 0 = AVA flags. */
 int  lrge_hip_chains(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries,
                      int dual, lrge_hip_chain *out, uint64_t cap, uint64_t *n_out);
+
+/* Per-query seed statistics that complete the PafRecord tags (aligner.rs:262-270): rep_len = rl
+   (query bases covered by seeds whose index occurrence exceeds mid_occ), and sum_span / n_kept, whose
+   ratio (as f32) is mm_est_err's avg_k.  dv = n_match >= n_tot ? 0 : (float)(1.0 - pow((double)n_match /
+   n_tot, 1.0 / avg_k)) with n_match = cnt and n_tot = n_seeds + [qs > avg_k && rs > avg_k] +
+   [qlen - qs > avg_k && tlen - re > avg_k]  (mm2:esterr.c).  Arrays have one entry per query. */
+int  lrge_hip_paf_stats(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries,
+                        int32_t *rep_len, uint64_t *sum_span, uint32_t *n_kept);
 
 /* per_read_estimate over n reads on the device (f32, no contraction). out[i] = +inf if counts[i]==0 */
 int  lrge_hip_estimates(lrge_hip_ctx *ctx, const uint32_t *counts, const uint32_t *read_lens,

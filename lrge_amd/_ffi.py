@@ -22,7 +22,7 @@ EXPORTS = [
     "lrge_hip_seqset_upload", "lrge_hip_seqset_free", "lrge_hip_seqset_size",
     "lrge_hip_index_build", "lrge_hip_index_free", "lrge_hip_index_stats",
     "lrge_hip_overlap_twoset", "lrge_hip_overlap_inverse", "lrge_hip_overlap_ava", "lrge_hip_chains",
-    "lrge_hip_estimates", "lrge_hip_median",
+    "lrge_hip_estimates", "lrge_hip_median", "lrge_hip_paf_stats",
     "lrge_hip_sketch_dump", "lrge_hip_index_dump", "lrge_hip_anchors_dump",
     "lrge_hip_last_timings", "lrge_hip_last_counters", "lrge_hip_version",
 ]
@@ -34,7 +34,7 @@ class Params(C.Structure):
 
 CHAIN = np.dtype([("query", "<u4"), ("target", "<u4"), ("rev", "<i4"), ("score", "<i4"), ("cnt", "<i4"),
                   ("qs", "<i4"), ("qe", "<i4"), ("rs", "<i4"), ("re", "<i4"), ("mlen", "<i4"), ("blen", "<i4"),
-                  ("reserved", "<i4")])
+                  ("n_seeds", "<i4")])
 
 _lib = None
 
@@ -75,6 +75,7 @@ def lib():
     L.lrge_hip_overlap_inverse.argtypes = [vp, vp, vp, C.POINTER(Params), vp]
     L.lrge_hip_overlap_ava.argtypes = [vp, vp, vp, C.POINTER(Params), vp]
     L.lrge_hip_chains.argtypes = [vp, vp, vp, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.lrge_hip_paf_stats.argtypes = [vp, vp, vp, vp, vp, vp]
     L.lrge_hip_estimates.argtypes = [vp, vp, vp, C.c_uint32, C.c_float, C.c_uint64, C.c_uint32, vp]
     L.lrge_hip_median.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                                   C.POINTER(C.c_float * 3), C.POINTER(C.c_int * 3)]

@@ -232,7 +232,7 @@ __device__ void chain_group(const GroupMem<IdxT> M, i32 n, const ChainParams &P,
                 if (slot < out.chain_cap) {
                     lrge_hip_chain c;
                     c.query = qid; c.target = rid; c.rev = (i32)rev; c.score = sc; c.cnt = cnt;
-                    c.qs = qs; c.qe = qe; c.rs = rs; c.re = re; c.mlen = mlen; c.blen = blen; c.reserved = 0;
+                    c.qs = qs; c.qe = qe; c.rs = rs; c.re = re; c.mlen = mlen; c.blen = blen; c.n_seeds = 0;   /* only the hw/reg kernels fill it */
                     out.chains[slot] = c;
                 }
             }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64) void k_chain_lds(const u64 *__restrict__ akey, 
                 if (slot < out.chain_cap) {
                     lrge_hip_chain c;
                     c.query = qid; c.target = rid; c.rev = (i32)rev; c.score = sc; c.cnt = cnt;
-                    c.qs = qs; c.qe = qe; c.rs = rs; c.re = re; c.mlen = mlen; c.blen = blen; c.reserved = 0;
+                    c.qs = qs; c.qe = qe; c.rs = rs; c.re = re; c.mlen = mlen; c.blen = blen; c.n_seeds = 0;   /* only the hw/reg kernels fill it */
                     out.chains[slot] = c;
                 }
             }

@@ -369,7 +369,11 @@ __global__ __launch_bounds__(64) void k_chain_reg(RegChainArgs R, ChainParams P,
                 if (slot < out.chain_cap) {
                     lrge_hip_chain c;
                     c.query = qid; c.target = rid; c.rev = (i32)rev; c.score = sc; c.cnt = cnt;
-                    c.qs = qs; c.qe = qe; c.rs = rs; c.re = re; c.mlen = mlen; c.blen = blen; c.reserved = 0;
+                    c.qs = qs; c.qe = qe; c.rs = rs; c.re = re; c.mlen = mlen; c.blen = blen;
+                    {   // entries of minimap2's mini_pos[] spanned by the chain (kept-seed ranks ride in the anchor values)
+                        const i32 r0 = (i32)(vf >> AVAL_RANK_SHIFT), r1 = (i32)(vt >> AVAL_RANK_SHIFT);
+                        c.n_seeds = (r1 > r0 ? r1 - r0 : r0 - r1) + 1;
+                    }
                     out.chains[slot] = c;
                 }
             }

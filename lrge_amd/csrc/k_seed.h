@@ -23,38 +23,44 @@ struct SeedParams {
     int no_dual;               // MM_F_NO_DUAL (AVA)
 };
 
-// K3: one lane per query minimizer.  hn = raw list length (0 when absent, filtered by mid_occ, or
-// removed by the query occurrence filter), hv = hits that survive skip_seed.
-__global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 n_mz,
-                                                SeedParams sp, u32 *__restrict__ hs, u32 *__restrict__ hn,
-                                                u32 *__restrict__ hv) {
+// K3: one lane per query minimizer: probe the index.  hs = list start, hc = raw list length (0 when
+// the hash is absent).  The mid_occ filter and skip_seed are applied by k_seed_counts, after the query
+// occurrence filter had its say.
+__global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, u64 n_mz, SeedParams sp,
+                                                u32 *__restrict__ hs, u32 *__restrict__ hc) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_mz) return;
-    u64 x = qx[i];
-    u32 n = 0, v = 0; u64 st = 0;
-    {
-        u32 cnt;
-        if (ht_lookup(sp.ht, sp.ht_mask, x >> 8, &st, &cnt)) {
-            if ((i64)cnt <= (i64)sp.mid_occ) n = cnt;  // m[i].n > max_occ -> flt
-        }
-    }
-    v = n;
+    u64 st = 0; u32 cnt = 0;
+    if (!ht_lookup(sp.ht, sp.ht_mask, qx[i] >> 8, &st, &cnt)) { st = 0; cnt = 0; }
+    hs[i] = (u32)st; hc[i] = cnt;
+}
+
+// hn = list length of a KEPT seed (0 when absent, removed by mm_seed_mz_flt, or n > mid_occ -> flt),
+// hv = hits that survive skip_seed.
+__global__ __launch_bounds__(256) void k_seed_counts(const u64 *__restrict__ qy, u64 n_mz, SeedParams sp,
+                                                     const u32 *__restrict__ hs, const u32 *__restrict__ hc,
+                                                     u32 *__restrict__ hn, u32 *__restrict__ hv) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_mz) return;
+    const u32 c = hc[i];
+    const u32 n = (c != 0 && (i64)c <= (i64)sp.mid_occ) ? c : 0;   // m[i].n > max_occ -> flt
+    u32 v = n;
     if (n && sp.check_names) {
-        u64 y = qy[i];
-        u32 q = (u32)(y >> 32), qpos = (u32)y >> 1;
-        u32 qr = sp.q_rank[q], ql = sp.q_len[q];
+        const u64 y = qy[i], st = hs[i];
+        const u32 q = (u32)(y >> 32), qpos = (u32)y >> 1;
+        const u32 qr = sp.q_rank[q], ql = sp.q_len[q];
         v = 0;
         for (u32 j = 0; j < n; ++j) {
-            u64 r = sp.pos[st + j];
-            u32 rid = (u32)(r >> 32);
-            u32 tr = sp.t_rank[rid];
+            const u64 r = sp.pos[st + j];
+            const u32 rid = (u32)(r >> 32);
+            const u32 tr = sp.t_rank[rid];
             bool skip = false;
             if (qr == tr && sp.t_len[rid] == ql && ((u32)r >> 1) == qpos) skip = true;  // NO_DIAG, exact diagonal
             if (sp.no_dual && qr > tr) skip = true;                                     // NO_DUAL, cmp > 0
             v += skip ? 0 : 1;
         }
     }
-    hs[i] = (u32)st; hn[i] = n; hv[i] = v;
+    hn[i] = n; hv[i] = v;
 }
 
 // per-query sum of hv (one wave per query)
@@ -69,10 +75,16 @@ __global__ __launch_bounds__(256) void k_query_anchor_totals(const u32 *__restri
     if (lane_id() == 0) totals[q] = s;
 }
 
+// anchor value layout: rank<<44 | SELF<<43 | span<<32 | qpos, where rank = index of the seed among the
+// query's kept seeds = its index in minimap2's mini_pos[] (what mm_est_err needs for dv)
+#define AVAL_RANK_SHIFT 44
+#define AVAL_LOW_MASK ((1ULL << AVAL_RANK_SHIFT) - 1)
+
 // K4: one lane per query minimizer of the batch; writes (key, val) anchors at aoff[i].
 __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 mz_begin,
                                                 u64 mz_end, SeedParams sp, const u32 *__restrict__ hs,
-                                                const u32 *__restrict__ hn, const u32 *__restrict__ aoff, u32 q0,
+                                                const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
+                                                const u32 *__restrict__ krank, const u32 *__restrict__ qmz_off, u32 q0,
                                                 KeyLayout kl, u64 *__restrict__ akey, u64 *__restrict__ aval) {
     u64 i = mz_begin + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= mz_end) return;
@@ -86,6 +98,7 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
     u32 o = aoff[i - mz_begin];
     u64 qpart = (u64)(q - q0) << kl.sh_q();
     u32 yq_rev = ql - (qpos + 1 - span) - 1;
+    const u64 rank = (u64)((krank[i] - krank[qmz_off[q]]) & 0xFFFFFu) << AVAL_RANK_SHIFT;
     for (u32 j = 0; j < n; ++j) {
         u64 r = sp.pos[st + j];
         u32 rid = (u32)(r >> 32), rpos = (u32)r >> 1;
@@ -100,20 +113,20 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
         }
         bool rev = ((u32)r & 1) != qstrand;
         akey[o] = qpart | (u64)rid << kl.sh_rid() | (u64)(rev ? 1 : 0) << kl.sh_rev() | rpos;
-        aval[o] = self | (u64)span << 32 | (rev ? yq_rev : qpos);
+        aval[o] = rank | self | (u64)span << 32 | (rev ? yq_rev : qpos);
         ++o;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K4a: query occurrence filter (mm2:seed.c mm_seed_mz_flt), run on the minimizers that have usable
-// hits.  (x, query|index) pairs are sorted by x and then stably by query; a run of identical
-// (query, x) longer than both thresholds removes all its members (hn = hv = 0).
+// K4a: query occurrence filter (mm2:seed.c mm_seed_mz_flt), run on the minimizers that are present in
+// the index.  (x, query|index) pairs are sorted by x and then stably by query; a run of identical
+// (query, x) longer than both thresholds removes all its members (hc = 0: as if absent).
 // ------------------------------------------------------------------------------------------
-__global__ void k_qocc_flag(const u32 *__restrict__ hn, u64 n, u32 *__restrict__ flag) {
+__global__ void k_flag_nonzero(const u32 *__restrict__ v, u64 n, u32 *__restrict__ flag) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    flag[i] = hn[i] ? 1u : 0u;
+    flag[i] = v[i] ? 1u : 0u;
 }
 
 __global__ void k_qocc_keys(const u64 *__restrict__ qx, const u64 *__restrict__ qy, const u32 *__restrict__ flag,
@@ -128,8 +141,7 @@ __global__ void k_qocc_keys(const u64 *__restrict__ qx, const u64 *__restrict__ 
 // One lane per element; run heads do the work (runs are short except for the pathological ones this
 // filter exists for).
 __global__ void k_qocc_mark(const u64 *__restrict__ sx, const u64 *__restrict__ sv, u64 n,
-                            const u32 *__restrict__ qmz_off, int mid_occ, float q_occ_frac, u32 *__restrict__ hn,
-                            u32 *__restrict__ hv) {
+                            const u32 *__restrict__ qmz_off, int mid_occ, float q_occ_frac, u32 *__restrict__ hc) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 x = sx[i]; u32 q = (u32)(sv[i] >> 32);
@@ -140,7 +152,29 @@ __global__ void k_qocc_mark(const u64 *__restrict__ sx, const u64 *__restrict__ 
     u32 nq = qmz_off[q + 1] - qmz_off[q];
     if ((i64)nq <= (i64)mid_occ) return;                                   // mv->n <= q_occ_max: filter off
     if (cnt > mid_occ && (float)cnt > (float)(u64)nq * q_occ_frac)
-        for (u64 t = i; t < j; ++t) { hn[(u32)sv[t]] = 0; hv[(u32)sv[t]] = 0; }
+        for (u64 t = i; t < j; ++t) hc[(u32)sv[t]] = 0;
+}
+
+// Per-query PAF statistics (mm2:seed.c mm_collect_matches, mm2:esterr.c mm_est_err): rep_len = length of
+// the query covered by filtered (n > mid_occ) seeds, sum_span / n_kept -> avg_k of the kept seeds.
+__global__ void k_query_paf_stats(const u64 *__restrict__ qx, const u64 *__restrict__ qy, const u32 *__restrict__ hc,
+                                  const u32 *__restrict__ qmz_off, u32 nq, int mid_occ, i32 *__restrict__ rep_len,
+                                  u64 *__restrict__ sum_span, u32 *__restrict__ n_kept) {
+    u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    i32 rep_st = 0, rep_en = 0, rl = 0; u64 ss = 0; u32 nk = 0;
+    for (u32 i = qmz_off[q]; i < qmz_off[q + 1]; ++i) {
+        const u32 c = hc[i];
+        if (c == 0) continue;
+        const i32 span = (i32)(qx[i] & 0xff);
+        if ((i64)c > (i64)mid_occ) {
+            const i32 en = (i32)((u32)qy[i] >> 1) + 1, st = en - span;
+            if (st > rep_en) { rl += rep_en - rep_st; rep_st = st; rep_en = en; }
+            else rep_en = en;
+        } else { ss += (u64)span; ++nk; }
+    }
+    rl += rep_en - rep_st;
+    rep_len[q] = rl; sum_span[q] = ss; n_kept[q] = nk;
 }
 
 // ------------------------------------------------------------------------------------------

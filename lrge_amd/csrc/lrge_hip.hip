@@ -403,6 +403,8 @@ struct OverlapJob {
     lrge_hip_chain *chains = nullptr; u64 chain_cap = 0; u64 *n_chains = nullptr;
     // anchors of one query instead of chaining
     bool dump_anchors = false; u32 dump_query = 0; u64 *ax = nullptr, *ay = nullptr; u64 acap = 0; u64 *an = nullptr;
+    // per-query PAF statistics instead of chaining
+    bool paf_stats = false; i32 *rep_len = nullptr; u64 *sum_span = nullptr; u32 *n_kept = nullptr;
 };
 
 
@@ -438,6 +440,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         if (job.has_map) memset(job.has_map, 0, (size_t)nq * 4);
         if (job.n_chains) *job.n_chains = 0;
         if (job.an) *job.an = 0;
+        if (job.paf_stats) { memset(job.rep_len, 0, (size_t)nq * 4); memset(job.sum_span, 0, (size_t)nq * 8); memset(job.n_kept, 0, (size_t)nq * 4); }
         t_total.stop();
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         ctx->resolve_timers();
@@ -462,28 +465,29 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     sp.mid_occ = ix->mid_occ;
     sp.check_names = (Q->has_rank && T->has_rank) ? 1 : 0;   // qname == NULL in minimap2 skips skip_seed entirely
     sp.no_dual = job.dual ? 0 : 1;
-    ALLOC_OR_FAIL(hs, sc, u32, Mq + 1); ALLOC_OR_FAIL(hn, sc, u32, Mq + 1); ALLOC_OR_FAIL(hv, sc, u32, Mq + 1);
+    ALLOC_OR_FAIL(hs, sc, u32, Mq + 1); ALLOC_OR_FAIL(hc, sc, u32, Mq + 1);
+    ALLOC_OR_FAIL(hn, sc, u32, Mq + 1); ALLOC_OR_FAIL(hv, sc, u32, Mq + 1); ALLOC_OR_FAIL(krank, sc, u32, Mq + 1);
     ALLOC_OR_FAIL(d_qtot, sc, u32, (size_t)nq + 1);
     std::vector<u32> h_qtot((size_t)nq + 1, 0);
     if (Mq) {
         StageTimer t(ctx, LRGE_T_LOOKUP);
-        hipLaunchKernelGGL(k_lookup, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, so.y, Mq, sp, hs, hn, hv);
+        hipLaunchKernelGGL(k_lookup, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, Mq, sp, hs, hc);
         KCHK(ctx);
         t.stop();
     }
 
     // ---- 3. query occurrence filter (mm_seed_mz_flt) ----
     // minimap2 applies it before the lookup; the result is the same afterwards, restricted to the
-    // minimizers that still have hits: every occurrence of a value x in one query gets the same lookup
-    // result, so the per-query multiplicity of x is fully visible inside that subset, and values without
-    // (usable) hits contribute no anchors whether removed or not.
+    // minimizers present in the index: every occurrence of a value x in one query gets the same lookup
+    // result, so the per-query multiplicity of x is fully visible inside that subset, and absent values
+    // contribute nothing whether removed or not.  A removed minimizer is marked absent (hc = 0).
     if (Mq > 0 && P.q_occ_frac > 0.0f && ix->mid_occ > 0) {
         StageTimer t(ctx, LRGE_T_QFILTER);
         bool any = false;   // only queries with more minimizers than mid_occ can be affected
         for (u32 q = 0; q < nq && !any; ++q) any = (i64)(h_mzoff[q + 1] - h_mzoff[q]) > (i64)ix->mid_occ;
         if (any) {
             ALLOC_OR_FAIL(flag, sc, u32, Mq); ALLOC_OR_FAIL(fpos, sc, u32, Mq); ALLOC_OR_FAIL(d_ns, sc, u32, 1);
-            hipLaunchKernelGGL(k_qocc_flag, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hn, Mq, flag);
+            hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hc, Mq, flag);
             KCHK(ctx);
             rc = scan_exclusive_u32(ctx, sc, flag, fpos, Mq, d_ns);
             if (rc) return rc;
@@ -504,17 +508,42 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                 rc = radix_sort_pairs(ctx, sc, rv, rk, ov, ok, Ms, 32, (int)ceil_log2_u64((u64)nq + 1), &rk2, &rv2);
                 if (rc) return rc;
                 hipLaunchKernelGGL(k_qocc_mark, dim3((u32)div_up(Ms, 256)), dim3(256), 0, ctx->stream, rv2 /* x */, rk2 /* (q,idx) */,
-                                   (u64)Ms, so.mz_off, ix->mid_occ, P.q_occ_frac, hn, hv);
+                                   (u64)Ms, so.mz_off, ix->mid_occ, P.q_occ_frac, hc);
                 KCHK(ctx);
-                // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
                 sc.drop(ka); sc.drop(va); sc.drop(kb); sc.drop(vb);
             }
             sc.drop(flag); sc.drop(fpos); sc.drop(d_ns);
         }
         t.stop();
     }
+    if (job.paf_stats) {   // per-query seed statistics only (rl, avg_k ingredients)
+        ALLOC_OR_FAIL(d_rl, sc, i32, (size_t)nq); ALLOC_OR_FAIL(d_ss, sc, u64, (size_t)nq); ALLOC_OR_FAIL(d_nk, sc, u32, (size_t)nq);
+        hipLaunchKernelGGL(k_query_paf_stats, dim3((u32)div_up(nq, 64)), dim3(64), 0, ctx->stream, so.x, so.y, hc, so.mz_off, nq, ix->mid_occ,
+                           d_rl, d_ss, d_nk);
+        KCHK(ctx);
+        HIPCHK(ctx, hipMemcpyAsync(job.rep_len, d_rl, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(job.sum_span, d_ss, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(job.n_kept, d_nk, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        t_total.stop();
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->resolve_timers();
+        return LRGE_OK;
+    }
     {
         StageTimer t(ctx, LRGE_T_LOOKUP);
+        if (Mq) {
+            hipLaunchKernelGGL(k_seed_counts, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.y, Mq, sp, hs, hc, hn, hv);
+            KCHK(ctx);
+            // rank of every kept seed inside its query (= its index in minimap2's mini_pos[])
+            ALLOC_OR_FAIL(kflag, sc, u32, Mq);
+            hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hn, Mq, kflag);
+            KCHK(ctx);
+            rc = scan_exclusive_u32(ctx, sc, kflag, krank, Mq, krank + Mq);
+            if (rc) return rc;
+            sc.drop(kflag);
+        } else {
+            HIPCHK(ctx, hipMemsetAsync(krank, 0, 4, ctx->stream));
+        }
         hipLaunchKernelGGL(k_query_anchor_totals, dim3((u32)div_up(nq, 4)), dim3(256), 0, ctx->stream, hv, so.mz_off, nq, d_qtot);
         KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(h_qtot.data(), d_qtot, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -566,7 +595,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             rc = scan_exclusive_u32(ctx, bsc, hv + mb, aoff, me - mb, nullptr);
             if (rc) return rc;
             hipLaunchKernelGGL(k_expand, dim3((u32)div_up(me - mb, 256)), dim3(256), 0, ctx->stream, so.x, so.y, mb, me, sp, hs, hn, aoff,
-                               q0, kl, akey, aval);
+                               krank, so.mz_off, q0, kl, akey, aval);
             KCHK(ctx);
             // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
             bsc.drop(aoff);
@@ -598,7 +627,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             for (u64 i = 0; i < m; ++i) {
                 u64 k = hk[i];
                 u64 rev = (k >> kl.sh_rev()) & 1, rid = (k >> kl.sh_rid()) & ((1ULL << kl.bits_rid) - 1);
-                tmp[i] = {rev << 63 | rid << 32 | (k & rmask), hvv[i]};
+                tmp[i] = {rev << 63 | rid << 32 | (k & rmask), hvv[i] & AVAL_LOW_MASK};   // drop the seed rank
             }
             std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<u64, u64> &a, const std::pair<u64, u64> &b) { return a.first < b.first; });
             for (u64 i = 0; i < m; ++i) { job.ax[i] = tmp[i].first; job.ay[i] = tmp[i].second; }
@@ -826,6 +855,18 @@ extern "C" int lrge_hip_chains(lrge_hip_ctx *ctx, const lrge_hip_index *ix, cons
     OverlapJob job; job.mode = MODE_TWOSET; job.dual = dual ? 1 : 0;
     job.prm = lrge_hip_params{0, 0.2f};
     job.chains = out; job.chain_cap = out ? cap : 0; job.n_chains = n_out;
+    return run_overlap(ctx, ix, queries, job);
+}
+
+extern "C" int lrge_hip_paf_stats(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries, int32_t *rep_len,
+                                  uint64_t *sum_span, uint32_t *n_kept) {
+    int rc = check_common(ctx, ix, queries);
+    if (rc) return rc;
+    if (!rep_len || !sum_span || !n_kept) return LRGE_ERR_INVALID;
+    OverlapJob job; job.mode = MODE_TWOSET; job.dual = 1;
+    job.prm = lrge_hip_params{0, 0.2f};
+    job.paf_stats = true; job.rep_len = rep_len; job.sum_span = sum_span; job.n_kept = n_kept;
+    if (queries->n == 0) return LRGE_OK;
     return run_overlap(ctx, ix, queries, job);
 }
 

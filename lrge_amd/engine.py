@@ -197,6 +197,14 @@ class Index:
                                                       n.value, C.byref(n)))
         return out[:n.value]
 
+    def paf_stats(self, queries):
+        """Per-query (rep_len, sum_span, n_kept): the rl tag and the ingredients of mm_est_err's avg_k."""
+        n = max(queries.n, 1)
+        rl = np.zeros(n, dtype=np.int32); ss = np.zeros(n, dtype=np.uint64); nk = np.zeros(n, dtype=np.uint32)
+        self.ctx._check(self.ctx._lib.lrge_hip_paf_stats(self.ctx.h, self.h, queries.h, rl.ctypes.data, ss.ctypes.data,
+                                                         nk.ctypes.data))
+        return rl[:queries.n], ss[:queries.n], nk[:queries.n]
+
     def anchors(self, queries, q, dual=True):
         n = C.c_uint64()
         self.ctx._check(self.ctx._lib.lrge_hip_anchors_dump(self.ctx.h, self.h, queries.h, int(dual), q, None, None, 0,

@@ -296,3 +296,37 @@ def test_cpp_host_mirror_cli(ctx, oracle, tmp_path):
     assert out.returncode == 0 and 0.5 * g < float(out.stdout) < 2.0 * g, (out.stdout, out.stderr)
     out = subprocess.run([cli, "-T", "10", "-Q", "500", str(fa)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 1 and "is <= query number of reads" in out.stderr
+
+
+@pytest.mark.parametrize("preset,dual", [("ont", True), ("ont", False), ("pb", True)])
+def test_paf_lines(ctx, oracle, edge_set, tiny_hifi, preset, dual):
+    """Every PafRecord field (incl. dv, rl) for every chain: HIP path + host dv == oracle, compared as
+    the multiset of formatted PAF lines (mapping.rs serialisers)."""
+    from lrge_amd import paf
+    qseqs, qnames, tseqs, tnames = edge_set
+    if preset == "pb":     # dense HiFi chains exercise dv > 0 with long seed spans
+        qseqs, qnames = tiny_hifi.q.seqs()[:10] + qseqs[-10:], list(tiny_hifi.q.names[:10]) + qnames[-10:]
+        tseqs, tnames = tiny_hifi.t.seqs() + tseqs[-10:], list(tiny_hifi.t.names) + tnames[-10:]
+    if not dual:
+        qseqs, qnames = tseqs, tnames
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset, dual)
+    chains = ixd.chains(Qd, dual=dual)
+    rl, ss, nk = ixd.paf_stats(Qd)
+    qlens = [len(s) for s in qseqs]; tlens = [len(s) for s in tseqs]
+    got = sorted(paf.paf_lines(chains, qnames, qlens, tnames, tlens, rl, ss, nk))
+    exp = []
+    for q in range(len(qseqs)):
+        if len(qseqs[q]) == 0:
+            continue
+        for r in ixo.map(qseqs[q], qnames[q]):
+            t = int(r["rid"])
+            exp.append("\t".join([qnames[q].decode(), str(qlens[q]), str(r["qs"]), str(r["qe"]), "-" if r["rev"] else "+",
+                                  tnames[t].decode(), str(tlens[t]), str(r["rs"]), str(r["re"]), str(r["mlen"]), str(r["blen"]), "0",
+                                  "tp:A:S", "cm:i:%d" % r["cnt"], "s1:i:%d" % r["score"], "dv:f:" + paf.format_dv(r["dv"]),
+                                  "rl:i:%d" % r["rep_len"]]))
+    exp.sort()
+    assert len(got) == len(exp) and len(exp) > 50
+    bad = [i for i, (a, b) in enumerate(zip(got, exp)) if a != b]
+    assert not bad, "first differing PAF line:\n%s\n%s" % (got[bad[0]], exp[bad[0]])
+    assert any("dv:f:0." in l for l in exp)                  # non-zero divergences are exercised
+    assert any(not l.endswith("rl:i:0") for l in exp)        # and so is a non-zero rl

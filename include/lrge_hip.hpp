@@ -115,6 +115,10 @@ inline std::vector<uint32_t> unique_random_set(size_t k, uint32_t n, std::option
 }
 }  // namespace detail
 
+inline std::vector<std::string> paf_lines(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *qs, int dual,
+                                          const std::vector<const std::string *> &qn, const std::vector<uint32_t> &qlen,
+                                          const std::vector<const std::string *> &tn, const std::vector<uint32_t> &tlen);
+
 // ------------------------------------------------------------------------------------------
 // two-set strategy
 // ------------------------------------------------------------------------------------------
@@ -133,6 +137,7 @@ public:
     Platform platform = Platform::Nanopore;
     int device = 0;
     std::vector<std::string> warnings;
+    std::vector<std::string> *paf_sink = nullptr;   // when set, receives the lines of overlaps.paf (the reference always writes it)
 
     explicit TwoSetStrategy(const Reads &r) : input(&r) {}
 
@@ -180,10 +185,12 @@ public:
         if (use_min_ref && target_num_bases > query_num_bases) {
             detail::Index ix(ctx, Q, preset);
             ctx.check(lrge_hip_overlap_inverse(ctx.h, ix.h, T.h, &p, counts.data()));
+            if (paf_sink) *paf_sink = paf_lines(ctx.h, ix.h, T.h, 1, tn, T.lens, qn, Q.lens);
             for (uint32_t c : counts) no_mapping += c == 0;                       // twoset.rs:545-569
         } else {
             detail::Index ix(ctx, T, preset);
             ctx.check(lrge_hip_overlap_twoset(ctx.h, ix.h, Q.h, &p, counts.data(), has.data()));
+            if (paf_sink) *paf_sink = paf_lines(ctx.h, ix.h, Q.h, 1, qn, Q.lens, tn, T.lens);
             for (uint32_t h : has) no_mapping += h == 0;                          // twoset.rs:303-309
         }
         std::vector<float> est(counts.size());
@@ -234,6 +241,7 @@ public:
     Platform platform = Platform::Nanopore;
     int device = 0;
     std::vector<std::string> warnings;
+    std::vector<std::string> *paf_sink = nullptr;
 
     explicit AvaStrategy(const Reads &r) : input(&r) {}
 
@@ -258,6 +266,7 @@ public:
         lrge_hip_params p{remove_internal ? 1 : 0, max_overhang_ratio};
         std::vector<uint32_t> counts(R.lens.size());
         ctx.check(lrge_hip_overlap_ava(ctx.h, ix.h, R.h, &p, counts.data()));
+        if (paf_sink) *paf_sink = paf_lines(ctx.h, ix.h, R.h, 0, rn, R.lens, rn, R.lens);
         const size_t n_target = num_reads - 1;                                   // ava.rs:339-346
         const float avg = (float)num_bases / (float)n_target;
         std::vector<float> est(counts.size());
@@ -290,6 +299,43 @@ public:
     }
 };
 }  // namespace ava
+
+// overlaps.paf (twoset.rs:246-250,289-293; mapping.rs:81-177): one line per chain, unordered like the reference
+inline std::vector<std::string> paf_lines(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *qs, int dual,
+                                          const std::vector<const std::string *> &qn, const std::vector<uint32_t> &qlen,
+                                          const std::vector<const std::string *> &tn, const std::vector<uint32_t> &tlen) {
+    uint64_t n = 0;
+    int rc = lrge_hip_chains(ctx, ix, qs, dual, nullptr, 0, &n);
+    if (rc) throw LrgeError(rc, lrge_hip_last_error(ctx));
+    std::vector<lrge_hip_chain> ch(n ? n : 1);
+    rc = lrge_hip_chains(ctx, ix, qs, dual, ch.data(), n, &n);
+    if (rc) throw LrgeError(rc, lrge_hip_last_error(ctx));
+    std::vector<int32_t> rl(qn.size() + 1); std::vector<uint64_t> ss(qn.size() + 1); std::vector<uint32_t> nk(qn.size() + 1);
+    rc = lrge_hip_paf_stats(ctx, ix, qs, rl.data(), ss.data(), nk.data());
+    if (rc) throw LrgeError(rc, lrge_hip_last_error(ctx));
+    std::vector<std::string> out;
+    char buf[512];
+    for (uint64_t i = 0; i < n; ++i) {
+        const lrge_hip_chain &c = ch[i];
+        const uint32_t q = c.query, t = c.target;
+        float dv = -1.0f;                                     // mm2:esterr.c mm_est_err
+        if (nk[q]) {
+            const float avg_k = (float)ss[q] / (float)nk[q];
+            int n_tot = c.n_seeds;
+            if ((float)c.qs > avg_k && (float)c.rs > avg_k) ++n_tot;
+            if ((float)((int)qlen[q] - c.qs) > avg_k && (float)((int)tlen[t] - c.re) > avg_k) ++n_tot;
+            dv = c.cnt >= n_tot ? 0.0f : (float)(1.0 - std::pow((double)c.cnt / n_tot, 1.0 / avg_k));
+        }
+        char dvs[32];
+        if (dv < 1.1920929e-07f) snprintf(dvs, sizeof(dvs), "0"); else snprintf(dvs, sizeof(dvs), "%.4f", (double)dv);   // mapping.rs:136-147
+        snprintf(buf, sizeof(buf), "\t%u\t%d\t%d\t%c\t", qlen[q], c.qs, c.qe, c.rev ? '-' : '+');
+        std::string line = *qn[q] + buf + *tn[t];
+        snprintf(buf, sizeof(buf), "\t%u\t%d\t%d\t%d\t%d\t0\ttp:A:S\tcm:i:%d\ts1:i:%d\tdv:f:%s\trl:i:%d", tlen[t], c.rs, c.re, c.mlen, c.blen,
+                 c.cnt, c.score, dvs, rl[q]);
+        out.push_back(line + buf);
+    }
+    return out;
+}
 
 // lrge/src/utils.rs:19-49
 inline std::string format_estimate(float estimate) {

@@ -291,6 +291,17 @@ def test_cpp_host_mirror_cli(ctx, oracle, tmp_path):
     r = pyava.Builder().num_reads(reads.n).seed(3).build((reads.names, reads.seqs())).estimate(True, 0.15, 0.65)
     assert np.float32(r.estimate) == med and np.float32(r.lower) == lo and np.float32(r.upper) == hi
     assert r.no_mapping_count == int((counts == 0).sum())
+    # -C/-D keep overlaps.paf: same multiset of lines as the Python PAF emitter (itself checked against the oracle)
+    from lrge_amd import engine, paf
+    out = subprocess.run([cli, "-n", str(reads.n), "-C", "-D", str(tmp_path), str(fa)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cli_lines = sorted(open(tmp_path / "overlaps.paf").read().splitlines())
+    (ranks,) = engine.name_ranks(reads.names)
+    Rd = ctx.upload(reads.bases, reads.offsets, ranks)
+    ixd = engine.Index(ctx, Rd, 0)
+    rl, ss, nk = ixd.paf_stats(Rd)
+    py_lines = sorted(paf.paf_lines(ixd.chains(Rd, dual=False), reads.names, reads.lens(), reads.names, reads.lens(), rl, ss, nk))
+    assert cli_lines == py_lines and len(py_lines) > 100
     # two-set through the CLI: runs and reports a plausible size; too few reads is the reference's error
     out = subprocess.run([cli, "-T", "150", "-Q", "50", "-s", "1", str(fa)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and 0.5 * g < float(out.stdout) < 2.0 * g, (out.stdout, out.stderr)

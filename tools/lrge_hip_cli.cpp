@@ -60,6 +60,7 @@ int main(int argc, char **argv) {
     bool T_set = false, Q_set = false, filter = false, with_inf = false, precise = false, use_min_ref = false, honour_platform = false;
     float q1 = lrge::LOWER_QUANTILE, q3 = lrge::UPPER_QUANTILE, ratio = 0.2f;
     size_t threads = 1; std::optional<uint64_t> seed; int quiet = 0, verbose = 0, device = 0;
+    bool keep_temp = false; std::string temp_dir;
     auto need = [&](int &i) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "error: missing value for %s\n", argv[i]); exit(2); } return argv[++i]; };
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -70,8 +71,8 @@ int main(int argc, char **argv) {
         else if (a == "-P" || a == "--platform") { platform = need(i); if (platform != "ont" && platform != "pb") { fprintf(stderr, "error: invalid platform\n"); return 2; } }
         else if (a == "-F" || a == "--filter-contained") filter = true;
         else if (a == "-t" || a == "--threads") threads = strtoull(need(i), 0, 10);
-        else if (a == "-C" || a == "--keep-temp") {}
-        else if (a == "-D" || a == "--temp") need(i);
+        else if (a == "-C" || a == "--keep-temp") keep_temp = true;
+        else if (a == "-D" || a == "--temp") temp_dir = need(i);
         else if (a == "-s" || a == "--seed") seed = strtoull(need(i), 0, 10);
         else if (a == "-8" || a == "--inf") with_inf = true;
         else if (a == "-f" || a == "--float-my-boat") precise = true;
@@ -106,7 +107,16 @@ int main(int argc, char **argv) {
                      .threads(threads).seed(seed).platform(pf).device(device).build(reads);
             st = &ts;
         }
+        std::vector<std::string> paf;
+        if (keep_temp) { ts.paf_sink = &paf; as.paf_sink = &paf; }   // -C keeps overlaps.paf (main.rs:37-48, twoset.rs:246-250)
         lrge::EstimateResult r = st->estimate(!with_inf, q1, q3);
+        if (keep_temp) {
+            const std::string dir = temp_dir.empty() ? "." : temp_dir;
+            std::ofstream pf(dir + "/overlaps.paf");
+            if (!pf) { fprintf(stderr, "Error: Failed to write PAF record\n"); return 1; }
+            for (auto &l : paf) pf << l << "\n";
+            if (info) fprintf(stderr, "[INFO] Created temporary directory at %s\n", dir.c_str());
+        }
         if (quiet < 2) for (auto &w : (N ? as.warnings : ts.warnings)) fprintf(stderr, "[WARN] %s\n", w.c_str());
         if (!r.estimate) { fprintf(stderr, "Error: %s\n", with_inf ? "No estimates were generated" : "No finite estimates were generated"); return 1; }
         if (info) {

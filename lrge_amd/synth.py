@@ -119,6 +119,8 @@ CONFIGS = {
     "c3_yeast_ava": dict(genome=12_000_000, seed=1201, platform="ont", mode="ava", N=20000),
     "c4_dmel_twoset": dict(genome=143_000_000, seed=14301, platform="ont", mode="twoset", Q=50000, T=100000),
     "c5_human_twoset": dict(genome=3_100_000_000, seed=31001, platform="hifi", mode="twoset", Q=100000, T=2000000),
+    # C5 at one tenth of its size: same coverage (10x targets), fits the 2^32-entry limits of this round
+    "c5_human_tenth": dict(genome=310_000_000, seed=31001, platform="hifi", mode="twoset", Q=10000, T=200000),
     # reduced cases for tests / smoke
     "tiny_twoset": dict(genome=200_000, seed=77, platform="ont", mode="twoset", Q=60, T=300),
     "tiny_ava": dict(genome=100_000, seed=78, platform="ont", mode="ava", N=200),

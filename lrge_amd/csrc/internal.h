@@ -78,6 +78,8 @@ struct TimerRec;
 struct lrge_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // side stream: k_chain_lpg runs beside k_chain_hw (both are latency-, not throughput-bound)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     DevPool pool;
     float ms[LRGE_T_N];

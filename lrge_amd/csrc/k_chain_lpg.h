@@ -1,0 +1,239 @@
+// k_chain_lpg.h -- K6, lane-per-group form: SIXTY-FOUR groups per wavefront.
+//
+// k_chain_hw resolves the order-dependent state of mg_lchain_dp's predecessor loop with cross-lane
+// scans; that costs ~195 VALU instructions per step of two anchors, of which comput_sc is ~35 -- the
+// kernel is bound by VALU issue (4 cycles per wave64 instruction), not by memory.  Here every LANE owns
+// one (query, target, strand) group and runs the plain sequential loop over its candidates, so the
+// scans disappear: a candidate costs ~60 lane-operations and one wave instruction serves 64 groups.
+//   * the last 32 anchors of each lane's group live in VGPR arrays (fully unrolled loops, static
+//     indices), shifted by one slot per step;
+//   * the t[] marks of the sequential loop become a 32-bit register mask (a mark is only ever read
+//     in the step that wrote it);
+//   * anchor i of every lane is prefetched one step ahead; (f, p) leave as one 8-byte store per lane;
+//   * candidates beyond the 32-anchor window and long max_ii rescans continue per lane through HBM
+//     with the same arithmetic (exact, rare);
+//   * backtrack: every lane tracks its best chain end during the DP and walks that one chain; when the
+//     first chain is accepted and no records are wanted that settles the group's flags, otherwise the
+//     group falls back to the wave-wide backtrack_group().
+// A step takes ~2000 instructions regardless of the group size, so the latency per anchor is ~10x
+// that of k_chain_hw: groups above LPG_MAX_N anchors stay on k_chain_hw (the host splits the sorted
+// list), everything else -- ~90 % of the anchors of the headline workload -- runs here.
+#pragma once
+#include "k_chain_hw.h"
+
+#define LPG_W 32
+#define LPG_MAX_N_DEFAULT 448
+
+struct LpgChainArgs {
+    const u64 *akey, *aval;
+    const u32 *gstart;
+    u32 n_groups; u64 n_anchors;
+    const u32 *list;   // groups for this kernel, largest first
+    u32 n_list;
+    u64 *grec;         // [n_anchors]
+    u32 *tmark;        // [n_anchors] zero-initialised
+};
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
+    const u32 li = blockIdx.x * 64 + threadIdx.x;
+    const bool has = li < R.n_list;
+    const u32 g = has ? R.list[li] : 0;
+    const u32 s0 = has ? R.gstart[g] : 0;
+    const u32 e0 = has ? ((g + 1 < R.n_groups) ? R.gstart[g + 1] : (u32)R.n_anchors) : 0;
+    const i32 n = (i32)(e0 - s0);
+    i32 n_max = n;
+    n_max = wave_incl_max_i32(n_max, 0);
+    n_max = __builtin_amdgcn_readlane(n_max, 63);
+    const u64 rmask = (1ULL << P.kl.bits_rpos) - 1;
+    const u64 *gk = R.akey + s0, *gv = R.aval + s0;
+    u64 *grec = R.grec + s0;
+    u32 *tmark = R.tmark + s0;
+
+    const i32 maxdx = P.max_dist_x, bw = P.bw, max_skip = P.max_skip, max_iter = P.max_iter, min_sc = P.min_sc;
+    const u32 dqlim = (u32)(P.max_dist_x < P.max_dist_y ? P.max_dist_x : P.max_dist_y);
+    const float pen_gap = P.pen_gap, pen_skip = P.pen_skip;
+
+    // window: slot k <-> anchor i-1-k.  WO = one-hot of (j - p[j] - 1), 0 when there is no predecessor or it
+    // lies >= 32 anchors back: shifted left by k+1 it is the mark that candidate k leaves on a later candidate.
+    i32 WX[LPG_W], WY[LPG_W], WF[LPG_W], WS[LPG_W];
+    u32 WO[LPG_W];
+#pragma unroll
+    // empty slots (i < 32) must never be candidates: y = INT32_MAX makes dq <= 0, f = 0 loses every max_ii rescan
+    for (int k = 0; k < LPG_W; ++k) { WX[k] = 0; WY[k] = INT32_MAX; WF[k] = 0; WS[k] = 0; WO[k] = 0; }
+    i32 mi = -1, mi_x = 0, mi_y = 0, mi_f = 0, mi_sp = 0;
+    u64 bkey = 0;                                   // best chain end: f << 32 | i  (f >= min_sc)
+    u64 nk = 0, nv = 0;
+    if (n > 0) { nk = gk[0]; nv = gv[0]; }
+
+    for (i32 i = 0; i < n_max; ++i) {
+        const bool alive = i < n;
+        const u64 ck = nk, cv = nv;
+        if (i + 1 < n) { nk = gk[i + 1]; nv = gv[i + 1]; }
+        const i32 xi = (i32)(ck & rmask), yi = (i32)(u32)cv, spi = (i32)((cv >> 32) & 0xff);
+        const i32 navail = i < max_iter ? i : max_iter;         // candidates j in [i - navail, i - 1]
+        const i32 kcap = navail < LPG_W ? navail : LPG_W;
+        const bool more = navail > LPG_W;
+        const i32 lower = i - navail;
+
+        // The sequential predecessor loop, one candidate per unrolled step.  All per-lane state is integer
+        // VGPR state and every predicate is a single compare feeding a select, so the step stays on the VALU
+        // (no SGPR mask logic on the critical path):
+        //   thr    = max_f while the loop is live, INT32_MAX once it has stopped (nothing improves any more)
+        //   n_skip = very negative once stopped (no further break)
+        //   s      = SC_NONE for a candidate that is out of reach / fails comput_sc
+        i32 max_f = spi, thr = alive ? spi : INT32_MAX, max_j = -1, n_skip = 0, end_b = -1, n_reach = 0;
+        u32 marks = 0;
+#pragma unroll
+        for (int k = 0; k < LPG_W; ++k) {
+            const i32 j = i - 1 - k;
+            const i32 dr = xi - WX[k], dq = yi - WY[k], spj = WS[k];
+            // comput_sc (same operations in the same order as comput_sc_dev)
+            const i32 dg = dr < dq ? dr : dq;
+            const i32 mx = dr < dq ? dq : dr;
+            const i32 dd = mx - dg;
+            const i32 sc0 = spj < dg ? spj : dg;
+            const float lin_pen = pen_gap * (float)dd + pen_skip * (float)dg;
+            float log_pen = mg_log2_dev((float)(dd + 1));
+            log_pen = dd >= 1 ? log_pen : 0.0f;
+            const i32 pen = (i32)(lin_pen + .5f * log_pen);
+            i32 pen_ap = dg > spj ? pen : 0;
+            pen_ap = dd != 0 ? pen : pen_ap;
+            i32 s = sc0 - pen_ap + WF[k];
+            s = (u32)(dq - 1) < dqlim ? s : SC_NONE;
+            s = (u32)(dr - 1) < (u32)maxdx ? s : SC_NONE;      // 1 <= dr <= max_dist_x: in reach and dr != 0
+            s = dd <= bw ? s : SC_NONE;
+            n_reach += dr <= maxdx ? 1 : 0;
+            const bool improve = s > thr;
+            const i32 bit = (i32)((marks >> k) & 1u);
+            const i32 bv = s != SC_NONE ? bit : 0;
+            const i32 dec = n_skip > 1 ? n_skip - 1 : 0;
+            n_skip = improve ? dec : n_skip + bv;
+            max_f = improve ? s : max_f;
+            thr = improve ? s : thr;
+            max_j = improve ? j : max_j;
+            const bool brk = n_skip > max_skip;
+            end_b = brk ? j : end_b;
+            thr = brk ? INT32_MAX : thr;
+            n_skip = brk ? NEG_BIG : n_skip;
+            marks |= s != SC_NONE ? (WO[k] << (k + 1)) : 0u;
+        }
+        // end of the loop: a break, the window start (x out of reach / max_iter), or more candidates behind the window
+        const bool broke = thr == INT32_MAX;                     // (also true for lanes that are not alive)
+        n_reach = n_reach < kcap ? n_reach : kcap;               // empty slots may have counted as "in reach"
+        i32 end_j = broke ? end_b : i - 1 - n_reach;
+        const bool cont = !broke && more && n_reach == LPG_W;
+        if (__ballot(cont)) {
+            // rare: a lane's loop runs past its 32-anchor window; continue that lane's loop through HBM
+            if (cont) {
+                const u32 stamp = (u32)i + 1;
+                // marks the window candidates left on anchors behind the window (all were valid and reached)
+                for (i32 k = 0; k < LPG_W; ++k) {
+                    const i32 j = i - 1 - k;
+                    const u64 v = gv[j];
+                    if (comput_sc_dev(xi, yi, (i32)(gk[j] & rmask), (i32)(u32)v, (i32)((v >> 32) & 0xff), P) == SC_NONE) continue;
+                    const i32 pj = grec_p(ld_u64_l2(grec + j));
+                    if (pj >= 0 && pj < i - LPG_W) tmark[pj] = stamp;
+                }
+                drain_stores();
+                i32 j = i - 1 - LPG_W;
+                for (;; --j) {
+                    if (j < lower) { end_j = j; break; }
+                    const i32 xj = (i32)(gk[j] & rmask);
+                    if (xi - xj > maxdx) { end_j = j; break; }
+                    const u64 v = gv[j], r = ld_u64_l2(grec + j);
+                    const i32 sc = comput_sc_dev(xi, yi, xj, (i32)(u32)v, (i32)((v >> 32) & 0xff), P);
+                    if (sc == SC_NONE) continue;
+                    const i32 s = sc + grec_f(r);
+                    if (s > max_f) { max_f = s; max_j = j; if (n_skip > 0) --n_skip; }
+                    else if (ld_u32_l2(tmark + j) == stamp) { if (++n_skip > max_skip) { end_j = j; break; } }
+                    const i32 pj = grec_p(r);
+                    if (pj >= 0) { tmark[pj] = stamp; drain_stores(); }
+                }
+            }
+        }
+        // ---- max_ii bookkeeping (mm2:lchain.c, the "best f in reach" shortcut) ----
+        const bool need_rescan = alive && (mi < 0 || xi - mi_x > maxdx);
+        if (__ballot(need_rescan)) {
+            i32 bf = 0, bj = -1;      // f > 0 always
+#pragma unroll
+            for (int k = 0; k < LPG_W; ++k) {
+                const bool in = xi - WX[k] <= maxdx && WF[k] > bf;
+                bf = in ? WF[k] : bf;
+                bj = in ? i - 1 - k : bj;
+            }
+            if (need_rescan) {
+                if (more && xi - WX[LPG_W - 1] <= maxdx) {
+                    drain_stores();
+                    for (i32 j = i - 1 - LPG_W; j >= lower; --j) {
+                        if (xi - (i32)(gk[j] & rmask) > maxdx) break;
+                        const i32 f = grec_f(ld_u64_l2(grec + j));
+                        if (f > bf) { bf = f; bj = j; }
+                    }
+                }
+                if (bj < 0) mi = -1;
+                else {
+                    const u64 k = gk[bj], v = gv[bj];
+                    mi = bj; mi_f = bf; mi_x = (i32)(k & rmask); mi_y = (i32)(u32)v; mi_sp = (i32)((v >> 32) & 0xff);
+                }
+            }
+        }
+        const bool shortcut = alive && mi >= 0 && mi < end_j;
+        if (__ballot(shortcut)) {
+            const i32 tmp = comput_sc_dev(xi, yi, mi_x, mi_y, mi_sp, P);
+            if (shortcut && tmp != SC_NONE && max_f < tmp + mi_f) { max_f = tmp + mi_f; max_j = mi; }
+        }
+        if (alive && (mi < 0 || (xi - mi_x <= maxdx && mi_f < max_f))) { mi = i; mi_x = xi; mi_y = yi; mi_f = max_f; mi_sp = spi; }
+        if (alive) {
+            grec[i] = grec_make(max_f, max_j);
+            const u64 key = (u64)(u32)max_f << 32 | (u32)i;
+            bkey = (max_f >= min_sc && key > bkey) ? key : bkey;
+        }
+        // shift the window, insert anchor i at slot 0
+        const u32 reli = (u32)(i - 1 - max_j);                       // >= 32 (or "no predecessor"): no mark inside the window
+        const u32 oh = (max_j >= 0 && reli < 32u) ? 1u << reli : 0u;
+#pragma unroll
+        for (int k = LPG_W - 1; k > 0; --k) { WX[k] = WX[k - 1]; WY[k] = WY[k - 1]; WF[k] = WF[k - 1]; WS[k] = WS[k - 1]; WO[k] = WO[k - 1]; }
+        WX[0] = xi; WY[0] = yi; WF[0] = max_f; WS[0] = spi; WO[0] = oh;
+    }
+    drain_stores();
+
+    // ---------------- backtrack ----------------
+    // Per lane: the best chain end and its walk (mg_chain_bk_end).  Nothing has been claimed yet, so this
+    // is exactly the first iteration of backtrack_group(); anything it cannot settle falls back to it.
+    const bool need_records = out.chains != nullptr || P.remove_internal != 0;
+    u32 flags = 0;
+    bool fb = false;
+    if (has && bkey != 0) {
+        const i32 zx = (i32)(u32)(bkey >> 32), top = (i32)(u32)bkey;
+        i32 i = top, max_i = top, max_s = 0, depth = 0, cnt = 0;
+        u64 r = ld_u64_l2(grec + top);
+        for (;;) {
+            i = grec_p(r);
+            ++depth;
+            i32 s;
+            if (i < 0) s = zx;
+            else { r = ld_u64_l2(grec + i); s = zx - grec_f(r); }
+            if (s > max_s) { max_s = s; max_i = i; cnt = depth; }
+            else if (max_s - s > P.max_drop) break;
+            if (i < 0) break;
+        }
+        const i32 sc = max_i == top ? 0 : max_s;
+        const bool accepted = sc >= P.min_sc && cnt > 0 && cnt >= P.min_cnt;
+        if (accepted && !need_records) flags = 3u;
+        else fb = true;
+    }
+    u64 fbm = __ballot(fb);
+    while (fbm) {
+        const i32 l = (i32)__ffsll((unsigned long long)fbm) - 1;
+        fbm &= fbm - 1;
+        const u32 s0l = __builtin_amdgcn_readlane(s0, l);
+        const i32 nl = __builtin_amdgcn_readlane(n, l);
+        const u64 k0 = R.akey[s0l];
+        const u32 rev = RFL((u32)(k0 >> P.kl.sh_rev()) & 1);
+        const u32 rid = RFL((u32)(k0 >> P.kl.sh_rid()) & ((1u << P.kl.bits_rid) - 1));
+        const u32 qid = RFL(P.q0 + (u32)(k0 >> P.kl.sh_q()));
+        const u32 f = backtrack_group(R.akey + s0l, R.aval + s0l, R.grec + s0l, nl, rmask, qid, rid, rev, P, out);
+        if ((i32)lane_id() == l) flags = f;
+    }
+    if (has) out.flags[g] = flags;
+}

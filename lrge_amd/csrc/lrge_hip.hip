@@ -13,6 +13,7 @@
 #include "k_chain.h"
 #include "k_chain_reg.h"
 #include "k_chain_hw.h"
+#include "k_chain_lpg.h"
 
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
 
@@ -35,7 +36,10 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     }
     lrge_hip_ctx *ctx = new lrge_hip_ctx();
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         g_last_error = "hipSetDevice/hipStreamCreate failed";
         delete ctx;
         return LRGE_ERR_DEVICE;
@@ -56,6 +60,9 @@ extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
     ctx->resolve_timers();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->pool.destroy();
+    (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join);
+    (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -641,6 +648,15 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         // per wavefront, register window), "lds" / "glb" (earlier forms, kept as on-device references)
         const char *cm = getenv("LRGE_HIP_CHAIN");
         const int chain_mode = (cm && !strcmp(cm, "lds")) ? 1 : (cm && !strcmp(cm, "glb")) ? 2 : (cm && !strcmp(cm, "reg")) ? 3 : 0;
+        // mode 0 splits the size-sorted group list: groups above lpg_max anchors go to k_chain_hw (short
+        // latency per anchor), the rest to k_chain_lpg (64 groups per wavefront).  "hw" / "lpg" force one kernel.
+        u32 lpg_max = LPG_MAX_N_DEFAULT;
+        if (const char *e = getenv("LRGE_HIP_LPG_MAX")) lpg_max = (u32)strtoul(e, nullptr, 10);
+        if (cm && !strcmp(cm, "hw")) lpg_max = 0;
+        if (cm && !strcmp(cm, "lpg")) lpg_max = 0xFFFFFFFFu;
+        if (lpg_max && (cp.want_all || d_chains) && !(cm && !strcmp(cm, "lpg"))) lpg_max = 0;   // records: wave-wide backtrack anyway
+        if (cp.max_iter < LPG_W) lpg_max = 0;    // (debug knob only) k_chain_lpg assumes every window slot is a candidate
+        u32 n_big = 0;
         u32 G = 0; u32 *gstart, *gflags, *bin_count = nullptr, *bin_list = nullptr, *hw_list = nullptr;
         u32 h_bins[N_BINS] = {0, 0, 0, 0, 0};
         unsigned long long h_bin_anchors[N_BINS] = {0, 0, 0, 0, 0};
@@ -663,14 +679,15 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             bsc.drop(head); bsc.drop(gid); bsc.drop(d_G);
             if (chain_mode == 0) {
                 // groups worth chaining, sorted by size (largest first) so that k_chain_hw pairs equals
-                u32 *d_cnt = bsc.get<u32>(2);
+                u32 *d_cnt = bsc.get<u32>(4);
                 unsigned long long *d_anch = (unsigned long long *)bsc.get<u64>(1);
                 if (!d_cnt || !d_anch) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));
                 HIPCHK(ctx, hipMemsetAsync(d_anch, 0, 8, ctx->stream));
-                hipLaunchKernelGGL(k_group_count, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, d_cnt, d_anch);
+                hipLaunchKernelGGL(k_group_count, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, lpg_max, d_cnt, d_anch);
                 KCHK(ctx);
                 HIPCHK(ctx, hipMemcpyAsync(&n_chained, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(&n_big, d_cnt + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipMemcpyAsync(&a_chained, d_anch, 8, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
                 if (n_chained) {
@@ -708,14 +725,36 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                 if (n_chained) {
                     StageTimer t(ctx, LRGE_T_CHAIN);
                     HwChainArgs ha;
-                    ha.akey = skey; ha.aval = sval; ha.gstart = gstart; ha.n_groups = G; ha.n_anchors = A; ha.list = hw_list; ha.n_list = n_chained;
+                    ha.akey = skey; ha.aval = sval; ha.gstart = gstart; ha.n_groups = G; ha.n_anchors = A; ha.list = hw_list; ha.n_list = n_big;
                     ha.grec = bsc.get<u64>(A); ha.tmark = bsc.get<u32>(A);
                     if (!ha.grec || !ha.tmark) return LRGE_ERR_DEVICE;
                     HIPCHK(ctx, hipMemsetAsync(ha.tmark, 0, A * 4, ctx->stream));
-                    hipLaunchKernelGGL(k_chain_hw, dim3((n_chained + 1) / 2), dim3(64), 0, ctx->stream, ha, cp, go);
-                    KCHK(ctx);
+                    // the list is sorted by min(n, 65535) descending, so [0, n_big) are exactly the groups above lpg_max
+                    // the two kernels touch disjoint groups; k_chain_lpg goes to the side stream so that its long
+                    // wavefronts run beside k_chain_hw's (fork / join with events, no host sync)
+                    const bool both = n_big && n_chained > n_big;
+                    if (both) {
+                        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+                        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                    }
+                    if (n_chained > n_big) {
+                        LpgChainArgs la;
+                        la.akey = skey; la.aval = sval; la.gstart = gstart; la.n_groups = G; la.n_anchors = A;
+                        la.list = hw_list + n_big; la.n_list = n_chained - n_big; la.grec = ha.grec; la.tmark = ha.tmark;
+                        hipLaunchKernelGGL(k_chain_lpg, dim3((la.n_list + 63) / 64), dim3(64), 0, both ? ctx->stream2 : ctx->stream, la, cp, go);
+                        KCHK(ctx);
+                        ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+                    }
+                    if (n_big) {
+                        hipLaunchKernelGGL(k_chain_hw, dim3((n_big + 1) / 2), dim3(64), 0, ctx->stream, ha, cp, go);
+                        KCHK(ctx);
+                        ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+                    }
+                    if (both) {
+                        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+                        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                    }
                     t.stop();
-                    ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
                     ctx->counters[LRGE_C_CHAIN_ANCHORS] += a_chained;
                     ctx->counters[LRGE_C_GROUPS_CHAINED] += n_chained;
                 }

@@ -203,14 +203,18 @@ def test_batching_is_invisible(ctx, oracle, tiny_ont, monkeypatch):
     assert np.array_equal(ref, small)
 
 
-@pytest.mark.parametrize("kernel", ["hw", "reg", "lds", "glb"])
+@pytest.mark.parametrize("kernel", ["hw", "lpg", "auto64", "reg", "lds", "glb"])
 @pytest.mark.parametrize("max_skip,max_iter", [(25, 5000), (100000, 5000), (100000, 40), (3, 90)])
 def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, monkeypatch, kernel, max_skip, max_iter):
-    """All three chain kernels (register-window, LDS, global) against the oracle, including the
+    """Every chain kernel (half-wave, lane-per-group, register-window, LDS, global) against the oracle, including the
     paths the default heuristics almost never take: no max_skip break (the candidate loop walks the
     whole 5000-bp window, far past the 64 anchors held in registers) and a tight max_iter clamp.
     HiFi reads give dense anchor groups (hundreds of anchors inside one window)."""
-    monkeypatch.setenv("LRGE_HIP_CHAIN", kernel)
+    if kernel == "auto64":     # the default split (big groups -> k_chain_hw, the rest -> k_chain_lpg) at a low threshold
+        monkeypatch.delenv("LRGE_HIP_CHAIN", raising=False)
+        monkeypatch.setenv("LRGE_HIP_LPG_MAX", "64")
+    else:
+        monkeypatch.setenv("LRGE_HIP_CHAIN", kernel)
     monkeypatch.setenv("LRGE_HIP_DEBUG_MAX_SKIP", str(max_skip))
     monkeypatch.setenv("LRGE_HIP_DEBUG_MAX_ITER", str(max_iter))
     ds = tiny_hifi

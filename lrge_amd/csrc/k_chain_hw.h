@@ -39,6 +39,24 @@ __device__ __forceinline__ i32 half_shr1_i32(i32 v, i32 fill, i32 hl) {
     return hl == 0 ? fill : o;
 }
 
+// A 64-record block of grec held one record per lane, so that the (wave-uniform) pointer chase of the
+// backtrack hops through registers: chains mostly step 1..3 anchors back, and a dependent HBM/L2 load per
+// hop (~1 us) was the critical path of long groups.  get(i) reloads the block (coalesced, ending at i)
+// only when i falls outside it.  The block is a snapshot: reset() after any store to grec.
+struct RecBlock {
+    u64 v; i32 lo;
+    __device__ __forceinline__ void reset() { lo = INT32_MAX; }
+    __device__ __forceinline__ u64 get(const u64 *grec, i32 n, i32 i) {
+        if (i < lo || i >= lo + 64) {
+            lo = i > 63 ? i - 63 : 0;
+            const i32 idx = lo + (i32)lane_id();
+            v = idx < n ? ld_u64_l2(grec + idx) : 0;
+        }
+        const i32 d = i - lo;
+        return (u64)(u32)__builtin_amdgcn_readlane((i32)(u32)v, d) | (u64)(u32)__builtin_amdgcn_readlane((i32)(u32)(v >> 32), d) << 32;
+    }
+};
+
 // mg_chain_backtrack for one group, wave-wide (identical to the second phase of k_chain_reg)
 __device__ __noinline__ u32 backtrack_group(const u64 *gk, const u64 *gv, u64 *grec, i32 n, u64 rmask, u32 qid, u32 rid,
                                             u32 rev, ChainParams P, GroupOut out) {
@@ -59,13 +77,14 @@ __device__ __noinline__ u32 backtrack_group(const u64 *gk, const u64 *gv, u64 *g
         if (zx == 0) break;
         const i32 top = (i32)RFL((u32)best);
         i32 i = top, max_i = top, max_s = 0, depth = 0, cnt = 0;
-        u64 r = ld_u64_l2(grec + top);
+        RecBlock blk; blk.reset();
+        u64 r = blk.get(grec, n, top);
         for (;;) {   // mg_chain_bk_end (its t[]=2 marks are dead: p[i] < i)
             i = RFL(grec_p(r));
             ++depth;
             i32 s;
             if (i < 0) s = zx;
-            else { r = ld_u64_l2(grec + i); s = zx - RFL(grec_f(r)); }
+            else { r = blk.get(grec, n, i); s = zx - RFL(grec_f(r)); }
             if (s > max_s) { max_s = s; max_i = i; cnt = depth; }
             else if (max_s - s > P.max_drop) break;
             if (i < 0 || (RFL(grec_state(r)) & 3) != 0) break;
@@ -77,7 +96,7 @@ __device__ __noinline__ u32 backtrack_group(const u64 *gk, const u64 *gv, u64 *g
         for (i = top; i != max_i;) {
             if (lane == 0) gstate[(u64)i * 8 + 7] = 1;
             first = i;
-            const i32 pi = RFL(grec_p(ld_u64_l2(grec + i)));
+            const i32 pi = RFL(grec_p(blk.get(grec, n, i)));   // (p is never rewritten: the snapshot stays valid for it)
             if (accepted && pi != max_i) {
                 const u64 ki = gk[i], vi = gv[i], kp = gk[pi], vp = gv[pi];
                 const i32 span = RFL((i32)((vi >> 32) & 0xff));

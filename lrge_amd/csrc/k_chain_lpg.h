@@ -22,7 +22,7 @@
 #include "k_chain_hw.h"
 
 #define LPG_W 32
-#define LPG_MAX_N_DEFAULT 448
+#define LPG_MAX_N_DEFAULT 512
 
 struct LpgChainArgs {
     const u64 *akey, *aval;
@@ -34,7 +34,12 @@ struct LpgChainArgs {
     u32 *tmark;        // [n_anchors] zero-initialised
 };
 
+// PENTAB: with chain_skip_scale == 0 (every preset lrge uses) comput_sc's penalty depends on dd alone --
+// (i32)(pen_gap * dd + .5 * mg_log2(dd + 1)), and 0 for dd == 0 -- so it is tabulated once per wavefront in
+// LDS ([0, bw] + one "out of band" entry) with the very same f32 operations, and a candidate needs no f32 math.
+template <bool PENTAB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
+    extern __shared__ i32 pen_tab[];
     const u32 li = blockIdx.x * 64 + threadIdx.x;
     const bool has = li < R.n_list;
     const u32 g = has ? R.list[li] : 0;
@@ -52,6 +57,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const i32 maxdx = P.max_dist_x, bw = P.bw, max_skip = P.max_skip, max_iter = P.max_iter, min_sc = P.min_sc;
     const u32 dqlim = (u32)(P.max_dist_x < P.max_dist_y ? P.max_dist_x : P.max_dist_y);
     const float pen_gap = P.pen_gap, pen_skip = P.pen_skip;
+
+    const u32 tabn = (u32)bw + 1;
+    if (PENTAB) {
+        for (u32 d = threadIdx.x; d < tabn; d += 64) {
+            const float lin_pen = pen_gap * (float)(i32)d + pen_skip * 0.0f;
+            float log_pen = mg_log2_dev((float)(i32)(d + 1));
+            log_pen = d >= 1 ? log_pen : 0.0f;
+            pen_tab[d] = (i32)(lin_pen + .5f * log_pen);
+        }
+        if (threadIdx.x == 0) pen_tab[tabn] = 1 << 30;            // dd > bw: pushes s below NEG_BIG
+        __syncthreads();
+    }
 
     // window: slot k <-> anchor i-1-k.  WO = one-hot of (j - p[j] - 1), 0 when there is no predecessor or it
     // lies >= 32 anchors back: shifted left by k+1 it is the mark that candidate k leaves on a later candidate.
@@ -75,53 +92,85 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const bool more = navail > LPG_W;
         const i32 lower = i - navail;
 
-        // The sequential predecessor loop, one candidate per unrolled step.  All per-lane state is integer
-        // VGPR state and every predicate is a single compare feeding a select, so the step stays on the VALU
-        // (no SGPR mask logic on the critical path):
-        //   thr    = max_f while the loop is live, INT32_MAX once it has stopped (nothing improves any more)
-        //   n_skip = very negative once stopped (no further break)
-        //   s      = SC_NONE for a candidate that is out of reach / fails comput_sc
-        i32 max_f = spi, thr = alive ? spi : INT32_MAX, max_j = -1, n_skip = 0, end_b = -1, n_reach = 0;
-        u32 marks = 0;
+        // Phase A -- comput_sc(i, j) + f[j] for the 32 window candidates.  Nothing here depends on the loop's
+        // running state, so the 32 evaluations (and their LDS lookups) overlap freely.
+        //   S[k] = a value below NEG_BIG for a candidate that is out of reach / fails comput_sc
+        i32 S[LPG_W];
+        i32 n_reach = 0;
+        if (PENTAB) {
+            // all 32 table lookups are issued before the first one is consumed (LDS latency is paid once)
+            i32 DG[LPG_W], PEN[LPG_W];
+#pragma unroll
+            for (int k = 0; k < LPG_W; ++k) {
+                const i32 dr = xi - WX[k], dq = yi - WY[k];
+                const i32 dg = dr < dq ? dr : dq;
+                const i32 mx = dr < dq ? dq : dr;
+                const u32 dd = (u32)(mx - dg);
+                DG[k] = dg;
+                PEN[k] = (i32)(dd < tabn ? dd : tabn);
+            }
+#pragma unroll
+            for (int k = 0; k < LPG_W; ++k) PEN[k] = pen_tab[PEN[k]];
+#pragma unroll
+            for (int k = 0; k < LPG_W; ++k) {
+                const i32 dr = xi - WX[k], dq = yi - WY[k], spj = WS[k];
+                i32 s = (spj < DG[k] ? spj : DG[k]) - PEN[k] + WF[k];
+                s = (u32)(dq - 1) < dqlim ? s : SC_NONE;
+                s = (u32)(dr - 1) < (u32)maxdx ? s : SC_NONE;      // 1 <= dr <= max_dist_x: in reach and dr != 0
+                n_reach += dr <= maxdx ? 1 : 0;
+                S[k] = s;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < LPG_W; ++k) {   // same operations in the same order as comput_sc_dev
+                const i32 dr = xi - WX[k], dq = yi - WY[k], spj = WS[k];
+                const i32 dg = dr < dq ? dr : dq;
+                const i32 mx = dr < dq ? dq : dr;
+                const u32 dd = (u32)(mx - dg);
+                const i32 sc0 = spj < dg ? spj : dg;
+                const float lin_pen = pen_gap * (float)(i32)dd + pen_skip * (float)dg;
+                float log_pen = mg_log2_dev((float)(i32)(dd + 1));
+                log_pen = dd >= 1 ? log_pen : 0.0f;
+                const i32 pen = (i32)(lin_pen + .5f * log_pen);
+                i32 pen_ap = dg > spj ? pen : 0;
+                pen_ap = dd != 0 ? pen : pen_ap;
+                i32 s = sc0 - pen_ap + WF[k];
+                s = dd <= (u32)bw ? s : SC_NONE;
+                s = (u32)(dq - 1) < dqlim ? s : SC_NONE;
+                s = (u32)(dr - 1) < (u32)maxdx ? s : SC_NONE;
+                n_reach += dr <= maxdx ? 1 : 0;
+                S[k] = s;
+            }
+        }
+        // Phase B -- the sequential predecessor loop over those candidates.  All per-lane state is integer VGPR
+        // state and every predicate is one compare feeding a select (no SGPR mask logic on the critical path):
+        //   lim = INT32_MAX while the loop is live, INT32_MIN once it has stopped (or for a lane past the end of
+        //         its group): min(S[k], lim) then makes every later candidate invalid, so nothing changes any more
+        i32 max_f = spi, max_k = -1, end_k = -1, lim = alive ? INT32_MAX : INT32_MIN;
+        u32 n_skip = 0, marks = 0;
 #pragma unroll
         for (int k = 0; k < LPG_W; ++k) {
-            const i32 j = i - 1 - k;
-            const i32 dr = xi - WX[k], dq = yi - WY[k], spj = WS[k];
-            // comput_sc (same operations in the same order as comput_sc_dev)
-            const i32 dg = dr < dq ? dr : dq;
-            const i32 mx = dr < dq ? dq : dr;
-            const i32 dd = mx - dg;
-            const i32 sc0 = spj < dg ? spj : dg;
-            const float lin_pen = pen_gap * (float)dd + pen_skip * (float)dg;
-            float log_pen = mg_log2_dev((float)(dd + 1));
-            log_pen = dd >= 1 ? log_pen : 0.0f;
-            const i32 pen = (i32)(lin_pen + .5f * log_pen);
-            i32 pen_ap = dg > spj ? pen : 0;
-            pen_ap = dd != 0 ? pen : pen_ap;
-            i32 s = sc0 - pen_ap + WF[k];
-            s = (u32)(dq - 1) < dqlim ? s : SC_NONE;
-            s = (u32)(dr - 1) < (u32)maxdx ? s : SC_NONE;      // 1 <= dr <= max_dist_x: in reach and dr != 0
-            s = dd <= bw ? s : SC_NONE;
-            n_reach += dr <= maxdx ? 1 : 0;
-            const bool improve = s > thr;
-            const i32 bit = (i32)((marks >> k) & 1u);
-            const i32 bv = s != SC_NONE ? bit : 0;
-            const i32 dec = n_skip > 1 ? n_skip - 1 : 0;
+            const i32 s = S[k] < lim ? S[k] : lim;
+            const bool improve = s > max_f;
+            const bool valid = s > NEG_BIG;
+            const u32 bv = valid ? (marks >> k) & 1u : 0u;
+            const u32 dec = n_skip ? n_skip - 1 : 0u;
             n_skip = improve ? dec : n_skip + bv;
             max_f = improve ? s : max_f;
-            thr = improve ? s : thr;
-            max_j = improve ? j : max_j;
-            const bool brk = n_skip > max_skip;
-            end_b = brk ? j : end_b;
-            thr = brk ? INT32_MAX : thr;
-            n_skip = brk ? NEG_BIG : n_skip;
-            marks |= s != SC_NONE ? (WO[k] << (k + 1)) : 0u;
+            max_k = improve ? k : max_k;
+            const bool brk = n_skip > (u32)max_skip;
+            end_k = brk ? k : end_k;
+            lim = brk ? INT32_MIN : lim;
+            n_skip = brk ? 0u : n_skip;
+            marks |= (valid ? WO[k] : 0u) << (k + 1);
         }
+        i32 max_j = max_k < 0 ? -1 : i - 1 - max_k;
+        const i32 end_b = end_k < 0 ? -1 : i - 1 - end_k;
         // end of the loop: a break, the window start (x out of reach / max_iter), or more candidates behind the window
-        const bool broke = thr == INT32_MAX;                     // (also true for lanes that are not alive)
+        const bool broke = end_b >= 0;
         n_reach = n_reach < kcap ? n_reach : kcap;               // empty slots may have counted as "in reach"
         i32 end_j = broke ? end_b : i - 1 - n_reach;
-        const bool cont = !broke && more && n_reach == LPG_W;
+        const bool cont = alive && !broke && more && n_reach == LPG_W;
         if (__ballot(cont)) {
             // rare: a lane's loop runs past its 32-anchor window; continue that lane's loop through HBM
             if (cont) {
@@ -145,7 +194,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     if (sc == SC_NONE) continue;
                     const i32 s = sc + grec_f(r);
                     if (s > max_f) { max_f = s; max_j = j; if (n_skip > 0) --n_skip; }
-                    else if (ld_u32_l2(tmark + j) == stamp) { if (++n_skip > max_skip) { end_j = j; break; } }
+                    else if (ld_u32_l2(tmark + j) == stamp) { if (++n_skip > (u32)max_skip) { end_j = j; break; } }
                     const i32 pj = grec_p(r);
                     if (pj >= 0) { tmark[pj] = stamp; drain_stores(); }
                 }

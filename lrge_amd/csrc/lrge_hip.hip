@@ -741,7 +741,9 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                         LpgChainArgs la;
                         la.akey = skey; la.aval = sval; la.gstart = gstart; la.n_groups = G; la.n_anchors = A;
                         la.list = hw_list + n_big; la.n_list = n_chained - n_big; la.grec = ha.grec; la.tmark = ha.tmark;
-                        hipLaunchKernelGGL(k_chain_lpg, dim3((la.n_list + 63) / 64), dim3(64), 0, both ? ctx->stream2 : ctx->stream, la, cp, go);
+                        const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !getenv("LRGE_HIP_LPG_NOTAB");
+                        if (pentab) hipLaunchKernelGGL(k_chain_lpg<true>, dim3((la.n_list + 63) / 64), dim3(64), ((size_t)cp.bw + 2) * 4, both ? ctx->stream2 : ctx->stream, la, cp, go);
+                        else hipLaunchKernelGGL(k_chain_lpg<false>, dim3((la.n_list + 63) / 64), dim3(64), 0, both ? ctx->stream2 : ctx->stream, la, cp, go);
                         KCHK(ctx);
                         ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
                     }

@@ -22,6 +22,7 @@
 #include "k_chain_hw.h"
 
 #define LPG_W 32
+#define LPG_B 16   // candidates per evaluate / resolve block
 #define LPG_MAX_N_DEFAULT 512
 
 struct LpgChainArgs {
@@ -38,7 +39,7 @@ struct LpgChainArgs {
 // (i32)(pen_gap * dd + .5 * mg_log2(dd + 1)), and 0 for dd == 0 -- so it is tabulated once per wavefront in
 // LDS ([0, bw] + one "out of band" entry) with the very same f32 operations, and a candidate needs no f32 math.
 template <bool PENTAB>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
     extern __shared__ i32 pen_tab[];
     const u32 li = blockIdx.x * 64 + threadIdx.x;
     const bool has = li < R.n_list;
@@ -92,77 +93,85 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const bool more = navail > LPG_W;
         const i32 lower = i - navail;
 
-        // Phase A -- comput_sc(i, j) + f[j] for the 32 window candidates.  Nothing here depends on the loop's
-        // running state, so the 32 evaluations (and their LDS lookups) overlap freely.
+        // The 32 window candidates are handled in blocks of LPG_B, each in two phases.
+        // Phase A -- comput_sc(i, j) + f[j].  Nothing here depends on the loop's running state, so the evaluations
+        // of a block (and their LDS lookups, all issued before the first is consumed) overlap freely, also with
+        // phase B of the block before.
         //   S[k] = a value below NEG_BIG for a candidate that is out of reach / fails comput_sc
-        i32 S[LPG_W];
-        i32 n_reach = 0;
-        if (PENTAB) {
-            // all 32 table lookups are issued before the first one is consumed (LDS latency is paid once)
-            i32 DG[LPG_W], PEN[LPG_W];
-#pragma unroll
-            for (int k = 0; k < LPG_W; ++k) {
-                const i32 dr = xi - WX[k], dq = yi - WY[k];
-                const i32 dg = dr < dq ? dr : dq;
-                const i32 mx = dr < dq ? dq : dr;
-                const u32 dd = (u32)(mx - dg);
-                DG[k] = dg;
-                PEN[k] = (i32)(dd < tabn ? dd : tabn);
-            }
-#pragma unroll
-            for (int k = 0; k < LPG_W; ++k) PEN[k] = pen_tab[PEN[k]];
-#pragma unroll
-            for (int k = 0; k < LPG_W; ++k) {
-                const i32 dr = xi - WX[k], dq = yi - WY[k], spj = WS[k];
-                i32 s = (spj < DG[k] ? spj : DG[k]) - PEN[k] + WF[k];
-                s = (u32)(dq - 1) < dqlim ? s : SC_NONE;
-                s = (u32)(dr - 1) < (u32)maxdx ? s : SC_NONE;      // 1 <= dr <= max_dist_x: in reach and dr != 0
-                n_reach += dr <= maxdx ? 1 : 0;
-                S[k] = s;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < LPG_W; ++k) {   // same operations in the same order as comput_sc_dev
-                const i32 dr = xi - WX[k], dq = yi - WY[k], spj = WS[k];
-                const i32 dg = dr < dq ? dr : dq;
-                const i32 mx = dr < dq ? dq : dr;
-                const u32 dd = (u32)(mx - dg);
-                const i32 sc0 = spj < dg ? spj : dg;
-                const float lin_pen = pen_gap * (float)(i32)dd + pen_skip * (float)dg;
-                float log_pen = mg_log2_dev((float)(i32)(dd + 1));
-                log_pen = dd >= 1 ? log_pen : 0.0f;
-                const i32 pen = (i32)(lin_pen + .5f * log_pen);
-                i32 pen_ap = dg > spj ? pen : 0;
-                pen_ap = dd != 0 ? pen : pen_ap;
-                i32 s = sc0 - pen_ap + WF[k];
-                s = dd <= (u32)bw ? s : SC_NONE;
-                s = (u32)(dq - 1) < dqlim ? s : SC_NONE;
-                s = (u32)(dr - 1) < (u32)maxdx ? s : SC_NONE;
-                n_reach += dr <= maxdx ? 1 : 0;
-                S[k] = s;
-            }
-        }
         // Phase B -- the sequential predecessor loop over those candidates.  All per-lane state is integer VGPR
         // state and every predicate is one compare feeding a select (no SGPR mask logic on the critical path):
         //   lim = INT32_MAX while the loop is live, INT32_MIN once it has stopped (or for a lane past the end of
         //         its group): min(S[k], lim) then makes every later candidate invalid, so nothing changes any more
+        i32 n_reach = 0;
         i32 max_f = spi, max_k = -1, end_k = -1, lim = alive ? INT32_MAX : INT32_MIN;
         u32 n_skip = 0, marks = 0;
 #pragma unroll
-        for (int k = 0; k < LPG_W; ++k) {
-            const i32 s = S[k] < lim ? S[k] : lim;
-            const bool improve = s > max_f;
-            const bool valid = s > NEG_BIG;
-            const u32 bv = valid ? (marks >> k) & 1u : 0u;
-            const u32 dec = n_skip ? n_skip - 1 : 0u;
-            n_skip = improve ? dec : n_skip + bv;
-            max_f = improve ? s : max_f;
-            max_k = improve ? k : max_k;
-            const bool brk = n_skip > (u32)max_skip;
-            end_k = brk ? k : end_k;
-            lim = brk ? INT32_MIN : lim;
-            n_skip = brk ? 0u : n_skip;
-            marks |= (valid ? WO[k] : 0u) << (k + 1);
+        for (int kb = 0; kb < LPG_W; kb += LPG_B) {
+            i32 S[LPG_B];
+            if (PENTAB) {
+                i32 DG[LPG_B], PEN[LPG_B];
+#pragma unroll
+                for (int b = 0; b < LPG_B; ++b) {
+                    const int k = kb + b;
+                    const i32 dr = xi - WX[k], dq = yi - WY[k];
+                    const i32 dg = dr < dq ? dr : dq;
+                    const i32 mx = dr < dq ? dq : dr;
+                    const u32 dd = (u32)(mx - dg);
+                    DG[b] = dg;
+                    PEN[b] = (i32)(dd < tabn ? dd : tabn);
+                }
+#pragma unroll
+                for (int b = 0; b < LPG_B; ++b) PEN[b] = pen_tab[PEN[b]];
+#pragma unroll
+                for (int b = 0; b < LPG_B; ++b) {
+                    const int k = kb + b;
+                    const i32 dr = xi - WX[k], dq = yi - WY[k], spj = WS[k];
+                    i32 s = (spj < DG[b] ? spj : DG[b]) - PEN[b] + WF[k];
+                    s = (u32)(dq - 1) < dqlim ? s : SC_NONE;
+                    s = (u32)(dr - 1) < (u32)maxdx ? s : SC_NONE;      // 1 <= dr <= max_dist_x: in reach and dr != 0
+                    n_reach += dr <= maxdx ? 1 : 0;
+                    S[b] = s;
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < LPG_B; ++b) {   // same operations in the same order as comput_sc_dev
+                    const int k = kb + b;
+                    const i32 dr = xi - WX[k], dq = yi - WY[k], spj = WS[k];
+                    const i32 dg = dr < dq ? dr : dq;
+                    const i32 mx = dr < dq ? dq : dr;
+                    const u32 dd = (u32)(mx - dg);
+                    const i32 sc0 = spj < dg ? spj : dg;
+                    const float lin_pen = pen_gap * (float)(i32)dd + pen_skip * (float)dg;
+                    float log_pen = mg_log2_dev((float)(i32)(dd + 1));
+                    log_pen = dd >= 1 ? log_pen : 0.0f;
+                    const i32 pen = (i32)(lin_pen + .5f * log_pen);
+                    i32 pen_ap = dg > spj ? pen : 0;
+                    pen_ap = dd != 0 ? pen : pen_ap;
+                    i32 s = sc0 - pen_ap + WF[k];
+                    s = dd <= (u32)bw ? s : SC_NONE;
+                    s = (u32)(dq - 1) < dqlim ? s : SC_NONE;
+                    s = (u32)(dr - 1) < (u32)maxdx ? s : SC_NONE;
+                    n_reach += dr <= maxdx ? 1 : 0;
+                    S[b] = s;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < LPG_B; ++b) {
+                const int k = kb + b;
+                const i32 s = S[b] < lim ? S[b] : lim;
+                const bool improve = s > max_f;
+                const bool valid = s > NEG_BIG;
+                const u32 bv = valid ? (marks >> k) & 1u : 0u;
+                const u32 dec = n_skip ? n_skip - 1 : 0u;
+                n_skip = improve ? dec : n_skip + bv;
+                max_f = improve ? s : max_f;
+                max_k = improve ? k : max_k;
+                const bool brk = n_skip > (u32)max_skip;
+                end_k = brk ? k : end_k;
+                lim = brk ? INT32_MIN : lim;
+                n_skip = brk ? 0u : n_skip;
+                marks |= (valid ? WO[k] : 0u) << (k + 1);
+            }
         }
         i32 max_j = max_k < 0 ? -1 : i - 1 - max_k;
         const i32 end_b = end_k < 0 ? -1 : i - 1 - end_k;

@@ -80,41 +80,79 @@ __global__ __launch_bounds__(256) void k_query_anchor_totals(const u32 *__restri
 #define AVAL_RANK_SHIFT 44
 #define AVAL_LOW_MASK ((1ULL << AVAL_RANK_SHIFT) - 1)
 
-// K4: one lane per query minimizer of the batch; writes (key, val) anchors at aoff[i].
+// K4: expand the kept seeds of the batch into anchors.  One wavefront owns 64 consecutive query
+// minimizers; their hit lists are concatenated into one "raw" index space (wave scan of hn) and the
+// lanes walk that space 64 hits at a time: each lane finds its (minimizer, hit) by a 6-step search
+// through the scanned counts, applies skip_seed, and the survivors are compacted with a ballot so that
+// both the reads of the position lists and the (key, val) writes are consecutive across the wave.
+// Output order = minimizer order, then list order, exactly as collect_seed_hits emits them.
 __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 mz_begin,
                                                 u64 mz_end, SeedParams sp, const u32 *__restrict__ hs,
                                                 const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
                                                 const u32 *__restrict__ krank, const u32 *__restrict__ qmz_off, u32 q0,
                                                 KeyLayout kl, u64 *__restrict__ akey, u64 *__restrict__ aval) {
-    u64 i = mz_begin + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= mz_end) return;
-    u32 n = hn[i];
-    if (n == 0) return;
-    u64 x = qx[i], y = qy[i];
-    u32 q = (u32)(y >> 32), qpos = (u32)y >> 1, qstrand = (u32)y & 1, span = (u32)x & 0xff;
-    u32 ql = sp.q_len[q];
-    u32 qr = sp.check_names ? sp.q_rank[q] : 0;
-    u64 st = hs[i];
-    u32 o = aoff[i - mz_begin];
-    u64 qpart = (u64)(q - q0) << kl.sh_q();
-    u32 yq_rev = ql - (qpos + 1 - span) - 1;
-    const u64 rank = (u64)((krank[i] - krank[qmz_off[q]]) & 0xFFFFFu) << AVAL_RANK_SHIFT;
-    for (u32 j = 0; j < n; ++j) {
-        u64 r = sp.pos[st + j];
-        u32 rid = (u32)(r >> 32), rpos = (u32)r >> 1;
-        u64 self = 0;
-        if (sp.check_names) {
-            u32 tr = sp.t_rank[rid];
-            if (qr == tr && sp.t_len[rid] == ql) {
-                if (rpos == qpos) continue;
-                if (((u32)r & 1) == qstrand) self = 1ULL << 43;  // MM_SEED_SELF (unused by chaining)
-            }
-            if (sp.no_dual && qr > tr) continue;
+    const u32 lane = lane_id();
+    const u64 w0 = mz_begin + ((u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+    if (w0 >= mz_end) return;
+    const u64 i = w0 + lane;
+    const bool in = i < mz_end;
+    const u32 n = in ? hn[i] : 0;
+    const u32 incl = wave_incl_scan_u32(n);
+    const u32 total = (u32)__builtin_amdgcn_readlane((i32)incl, 63);
+    if (total == 0) return;
+    const u32 rs = incl - n;                                     // first raw index of my minimizer
+    // per-minimizer fields, fetched by the lanes that expand its hits
+    u32 m_st = 0, m_q = 0, m_qpos = 0, m_flags = 0, m_ql = 0, m_qr = 0, m_rank = 0;
+    if (n) {
+        const u64 x = qx[i], y = qy[i];
+        m_q = (u32)(y >> 32); m_qpos = (u32)y >> 1;
+        m_flags = ((u32)y & 1) | ((u32)x & 0xff) << 8;          // strand | span << 8
+        m_ql = sp.q_len[m_q];
+        m_qr = sp.check_names ? sp.q_rank[m_q] : 0;
+        m_st = hs[i];
+        m_rank = (krank[i] - krank[qmz_off[m_q]]) & 0xFFFFFu;
+    }
+    u32 o = aoff[w0 - mz_begin];                                 // anchors written so far (wave-uniform)
+    o = (u32)__builtin_amdgcn_readfirstlane((i32)o);
+    for (u32 c0 = 0; c0 < total; c0 += 64) {
+        const u32 r = c0 + lane;
+        // largest lane l with rs[l] <= r (zero-length lists share their rs with the next one and lose)
+        u32 l = 0;
+#pragma unroll
+        for (u32 step = 32; step > 0; step >>= 1) {
+            const u32 v = (u32)__shfl((i32)rs, (int)(l + step), 64);
+            l = v <= r ? l + step : l;
         }
-        bool rev = ((u32)r & 1) != qstrand;
-        akey[o] = qpart | (u64)rid << kl.sh_rid() | (u64)(rev ? 1 : 0) << kl.sh_rev() | rpos;
-        aval[o] = rank | self | (u64)span << 32 | (rev ? yq_rev : qpos);
-        ++o;
+        const u32 j = r - (u32)__shfl((i32)rs, (int)l, 64);
+        const u32 st = (u32)__shfl((i32)m_st, (int)l, 64), q = (u32)__shfl((i32)m_q, (int)l, 64);
+        const u32 qpos = (u32)__shfl((i32)m_qpos, (int)l, 64), fl = (u32)__shfl((i32)m_flags, (int)l, 64);
+        const u32 ql = (u32)__shfl((i32)m_ql, (int)l, 64), qr = (u32)__shfl((i32)m_qr, (int)l, 64);
+        const u32 rk = (u32)__shfl((i32)m_rank, (int)l, 64);
+        bool keep = r < total;
+        u64 key = 0, val = 0;
+        if (keep) {
+            const u64 h = sp.pos[(u64)st + j];
+            const u32 rid = (u32)(h >> 32), rpos = (u32)h >> 1, qstrand = fl & 1, span = fl >> 8;
+            u64 self = 0;
+            if (sp.check_names) {
+                const u32 tr = sp.t_rank[rid];
+                if (qr == tr && sp.t_len[rid] == ql) {
+                    if (rpos == qpos) keep = false;
+                    if (((u32)h & 1) == qstrand) self = 1ULL << 43;  // MM_SEED_SELF (unused by chaining)
+                }
+                if (sp.no_dual && qr > tr) keep = false;
+            }
+            const bool rev = ((u32)h & 1) != qstrand;
+            const u32 yq_rev = ql - (qpos + 1 - span) - 1;
+            key = (u64)(q - q0) << kl.sh_q() | (u64)rid << kl.sh_rid() | (u64)(rev ? 1 : 0) << kl.sh_rev() | rpos;
+            val = (u64)rk << AVAL_RANK_SHIFT | self | (u64)span << 32 | (rev ? yq_rev : qpos);
+        }
+        const u64 km = __ballot(keep);
+        if (keep) {
+            const u32 d = o + (u32)__popcll(km & lanemask_lt());
+            akey[d] = key; aval[d] = val;
+        }
+        o += (u32)__popcll(km);
     }
 }
 

@@ -124,8 +124,8 @@ struct lrge_hip_index {
     int mid_occ = 0;
     u64 *d_pos = nullptr;       // [n_mz] y values grouped by key, ascending within a key
     u64 *d_skey = nullptr;      // [n_mz] sorted keys (kept for index_dump / tests)
-    u64 *d_ht = nullptr;        // open-addressing table of {key, start<<24 | min(count, 2^24-1)} pairs
-    u64 ht_mask = 0;
+    u64 *d_ht = nullptr;        // ordered open-addressing table of {key, start<<24 | min(count, 2^24-1)} pairs (k_index.h)
+    u64 ht_cap = 0;             // home slots are [0, ht_cap); slack slots follow
 };
 
 #define LRGE_SET_ERR(ctx, ...)                                  \

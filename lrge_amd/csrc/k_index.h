@@ -1,9 +1,13 @@
 // k_index.h -- K2 index build on top of the sorted (hash, y) stream, K2b occurrence threshold,
 // K3 lookup.  Restates mm2:index.c worker_post / mm_idx_get / mm_idx_cal_max_occ as:
-//   sorted keys -> run heads -> open-addressing table  hash -> (start, count)  into pos[].
-// (A bucket directory over the sorted distinct keys was tried instead of the table: minimizer hashes
-// are window minima, i.e. heavily skewed toward small values, which starves the top buckets and
-// crowds the bottom ones; the hash table is indifferent to the key distribution.)
+//   sorted keys -> run heads -> ORDERED open-addressing table  hash -> (start, count)  into pos[].
+// The minimizer stream is sorted by the BYTE-REVERSED hash (low byte most significant): minimizer
+// hashes are window minima, heavily skewed toward small values, but their low bytes are uniform.  A
+// key's home slot is  umulhi(bswap64(key), cap), monotone in that order, so inserting the distinct
+// keys in sorted order with linear probing has a closed form -- slot(r) = max(home(r), slot(r-1) + 1)
+// = r + prefix-max(home(r') - r') -- i.e. one max-scan and one streaming pass with nearly sequential
+// writes; no atomics, no random CAS traffic.  Lookups probe linearly from the home slot as usual (the
+// table does not wrap: it has slack slots behind `cap`, and the last one always stays empty).
 // The position list of a key is the y values in ascending order (the reference re-sorts every list
 // by y, and the sketch stream is already ascending in y, so a STABLE key sort yields that order).
 #pragma once
@@ -14,10 +18,7 @@
 #define HT_CNT_BITS 24
 #define HT_CNT_MAX ((1u << HT_CNT_BITS) - 1)
 
-__device__ __forceinline__ u64 ht_slot_hash(u64 key) {
-    // keys are already outputs of an invertible mixer; one multiply spreads the low bits
-    return (key * 0x9E3779B97F4A7C15ULL) >> 20;
-}
+__device__ __forceinline__ u64 ht_home(u64 key, u64 cap) { return __umul64hi(__builtin_bswap64(key), cap); }
 
 __global__ void k_run_heads(const u64 *__restrict__ skey, u64 n, u32 *__restrict__ head) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -34,52 +35,130 @@ __global__ void k_run_starts(const u32 *__restrict__ head, const u32 *__restrict
 }
 
 #define OCC_LDS_BINS 2048
-// per-run: insert into the table, histogram the run length (clamped to max_bin)
-// table entry = {key, start<<24 | count} in one 16-byte slot: insert and lookup touch one line
-__global__ __launch_bounds__(256) void k_table_insert(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
-                                                      u32 n_runs, u64 n, u64 *__restrict__ ht, u64 ht_mask,
-                                                      u32 *__restrict__ occ_hist, u32 max_bin) {
-    __shared__ u32 lh[OCC_LDS_BINS];
-    for (u32 i = threadIdx.x; i < OCC_LDS_BINS; i += blockDim.x) lh[i] = 0;
+#define PLACE_THREADS 256
+#define PLACE_ROWS 8
+#define PLACE_TILE (PLACE_THREADS * PLACE_ROWS)
+
+// d(r) = home(r) + (n_runs - r): slot(r) = prefix-max(d)(r) - (n_runs - r).  Needs cap + n_runs < 2^32.
+__device__ __forceinline__ u32 place_d(const u64 *__restrict__ skey, const u32 *__restrict__ run_start, u32 r, u32 n_runs, u64 cap) {
+    return (u32)ht_home(skey[run_start[r]], cap) + (n_runs - r);
+}
+
+__global__ __launch_bounds__(PLACE_THREADS) void k_place_reduce(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
+                                                                u32 n_runs, u64 cap, u32 *__restrict__ bmax) {
+    __shared__ u32 wm[PLACE_THREADS / 64];
+    u32 m = 0;
+    const u32 base = blockIdx.x * PLACE_TILE;
+#pragma unroll
+    for (int i = 0; i < PLACE_ROWS; ++i) {
+        const u32 r = base + i * PLACE_THREADS + threadIdx.x;
+        if (r < n_runs) { const u32 d = place_d(skey, run_start, r, n_runs, cap); m = d > m ? d : m; }
+    }
+    for (int d = 32; d > 0; d >>= 1) { const u32 o = (u32)__shfl_xor((i32)m, d, 64); m = o > m ? o : m; }
+    if (lane_id() == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    // grid-stride with a small grid: the histogram flush below hits the same few global addresses from
-    // every block, so the number of blocks (not of runs) sets that serialised cost
-    for (u64 rr = (u64)blockIdx.x * blockDim.x + threadIdx.x; rr < n_runs; rr += (u64)gridDim.x * blockDim.x) {
-        const u32 r = (u32)rr;
-        u32 st = run_start[r];
-        u64 en = (r + 1 < n_runs) ? run_start[r + 1] : n;
-        u32 cnt = (u32)(en - st);
-        u64 key = skey[st];
-        u64 slot = ht_slot_hash(key) & ht_mask;
-        for (;;) {
-            u64 prev = atomicCAS((unsigned long long *)&ht[2 * slot], (unsigned long long)HT_EMPTY, (unsigned long long)key);
-            if (prev == HT_EMPTY) break;  // keys are distinct per run, so no "already present" case
-            slot = (slot + 1) & ht_mask;
+    if (threadIdx.x == 0) {
+        u32 t = 0;
+        for (int w = 0; w < PLACE_THREADS / 64; ++w) t = wm[w] > t ? wm[w] : t;
+        bmax[blockIdx.x] = t;
+    }
+}
+
+// single block: in-place EXCLUSIVE max-scan of the block maxima (identity 0)
+__global__ __launch_bounds__(1024) void k_place_scan(u32 *data, u32 n) {
+    __shared__ u32 wm[16];
+    __shared__ u32 carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 base = 0; base < n; base += 1024) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = i < n ? data[i] : 0;
+        u32 inc = v;
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = (u32)__shfl_up((i32)inc, d, 64); if ((int)lane_id() >= d) inc = o > inc ? o : inc; }
+        if (lane_id() == 63) wm[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        u32 pre = carry_s;
+        for (u32 w = 0; w < (threadIdx.x >> 6); ++w) pre = wm[w] > pre ? wm[w] : pre;
+        u32 exc = (u32)__shfl_up((i32)inc, 1, 64);
+        exc = lane_id() == 0 ? 0 : exc;
+        if (i < n) data[i] = exc > pre ? exc : pre;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = inc > pre ? inc : pre;
+        __syncthreads();
+    }
+}
+
+// per run: its slot from the max-scan, the table entry {key, start<<24 | count} (one 16-byte slot: insert
+// and lookup touch one line), and the histogram of run lengths (clamped to max_bin) for mm_idx_cal_max_occ
+__global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
+                                                               u32 n_runs, u64 n, u64 cap, u64 n_slots, const u32 *__restrict__ bpre,
+                                                               u64 *__restrict__ ht, u32 *__restrict__ occ_hist, u32 max_bin,
+                                                               u32 *__restrict__ overflow) {
+    __shared__ u32 lh[OCC_LDS_BINS];
+    __shared__ u32 wm[PLACE_THREADS / 64];
+    __shared__ u32 carry_s;
+    for (u32 i = threadIdx.x; i < OCC_LDS_BINS; i += blockDim.x) lh[i] = 0;
+    const u32 w = threadIdx.x >> 6, lane = lane_id();
+    const u32 n_tiles = (n_runs + PLACE_TILE - 1) / PLACE_TILE;
+    // grid-stride over tiles with a small grid: the histogram flush at the end hits the same few global
+    // addresses from every block, so the number of blocks (not of runs) sets that serialised cost
+    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = bpre[tile];
+    __syncthreads();
+    const u32 base = tile * PLACE_TILE;
+    for (int row = 0; row < PLACE_ROWS; ++row) {
+        const u32 r = base + row * PLACE_THREADS + threadIdx.x;
+        const bool in = r < n_runs;
+        u32 st = 0, cnt = 0; u64 key = 0; u32 d = 0;
+        if (in) {
+            st = run_start[r];
+            const u64 en = (r + 1 < n_runs) ? run_start[r + 1] : n;
+            cnt = (u32)(en - st);
+            key = skey[st];
+            d = (u32)ht_home(key, cap) + (n_runs - r);
         }
-        ht[2 * slot + 1] = (u64)st << HT_CNT_BITS | (cnt < HT_CNT_MAX ? cnt : HT_CNT_MAX);
+        u32 inc = d;
+        for (int s = 1; s < 64; s <<= 1) { const u32 o = (u32)__shfl_up((i32)inc, s, 64); if ((int)lane >= s) inc = o > inc ? o : inc; }
+        if (lane == 63) wm[w] = inc;
+        __syncthreads();
+        u32 pre = carry_s;
+        for (u32 ww = 0; ww < w; ++ww) pre = wm[ww] > pre ? wm[ww] : pre;
+        const u32 m = inc > pre ? inc : pre;
+        __syncthreads();
+        if (threadIdx.x == PLACE_THREADS - 1) carry_s = m;
+        if (in) {
+            const u64 slot = (u64)m - (n_runs - r);
+            if (slot + 1 >= n_slots) *overflow = 1u;       // the last slot must stay empty
+            else {
+                ulonglong2 e; e.x = key; e.y = (u64)st << HT_CNT_BITS | (cnt < HT_CNT_MAX ? cnt : HT_CNT_MAX);
+                *(ulonglong2 *)(ht + 2 * slot) = e;
+            }
+        }
         const u32 hb = cnt < max_bin ? cnt : max_bin;
-        // most runs have length 1 or 2: count those per wave with a ballot instead of 64 conflicting
-        // LDS atomics on one address
-        const u64 m1 = __ballot(hb == 1), m2 = __ballot(hb == 2);
-        const u32 leader = (u32)__ffsll((unsigned long long)__ballot(true)) - 1;
-        if (lane_id() == leader) {
+        // most runs have length 1 or 2: count those per wave with a ballot instead of 64 conflicting LDS atomics
+        const u64 m1 = __ballot(in && hb == 1), m2 = __ballot(in && hb == 2);
+        if (lane == 0) {
             if (m1) atomicAdd(&lh[1], (u32)__popcll(m1));
             if (m2) atomicAdd(&lh[2], (u32)__popcll(m2));
         }
-        if (hb > 2) { if (hb < OCC_LDS_BINS) atomicAdd(&lh[hb], 1u); else atomicAdd(&occ_hist[hb], 1u); }
-        else if (hb == 0) atomicAdd(&lh[0], 1u);
+        if (in) {
+            if (hb > 2) { if (hb < OCC_LDS_BINS) atomicAdd(&lh[hb], 1u); else atomicAdd(&occ_hist[hb], 1u); }
+            else if (hb == 0) atomicAdd(&lh[0], 1u);
+        }
+        __syncthreads();
+    }
     }
     __syncthreads();
     for (u32 i = threadIdx.x; i < OCC_LDS_BINS && i <= max_bin; i += blockDim.x)
         if (lh[i]) atomicAdd(&occ_hist[i], lh[i]);
 }
 
-__device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 ht_mask, u64 key, u64 *start, u32 *cnt) {
-    u64 slot = ht_slot_hash(key) & ht_mask;
-    for (;;) {
+__device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u64 key, u64 *start, u32 *cnt) {
+    u64 slot = ht_home(key, cap);
+    for (;; ++slot) {
         const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
         if (e.x == key) { *start = e.y >> HT_CNT_BITS; *cnt = (u32)(e.y & HT_CNT_MAX); return true; }
         if (e.x == HT_EMPTY) return false;
-        slot = (slot + 1) & ht_mask;
     }
 }

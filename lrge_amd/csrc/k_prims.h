@@ -267,8 +267,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
 
 // Sorts (keys, vals) by bits [begin_bit, begin_bit + nbits) of the key (rounded up to whole bytes).  Ping-pongs between (k0,v0) and (k1,v1);
 // *res_k / *res_v point at the buffers holding the result.
+// reverse_digits: the LOWEST byte becomes the most significant digit (result ascending in the byte-reversed key).
 static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u64 *k1, u64 *v1, u64 n, int begin_bit,
-                            int nbits, u64 **res_k, u64 **res_v) {
+                            int nbits, u64 **res_k, u64 **res_v, bool reverse_digits = false) {
     *res_k = k0; *res_v = v0;
     if (n <= 1 || nbits <= 0) return LRGE_OK;
     if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
@@ -277,7 +278,7 @@ static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u6
     int passes = (nbits + 7) / 8;
     u64 *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     for (int p = 0; p < passes; ++p) {
-        int shift = begin_bit + p * 8;
+        int shift = begin_bit + (reverse_digits ? passes - 1 - p : p) * 8;
         hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);

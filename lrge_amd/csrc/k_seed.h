@@ -14,7 +14,7 @@ struct KeyLayout {      // composite anchor sort key: qlocal | rid | rev | rpos
 };
 
 struct SeedParams {
-    const u64 *ht; u64 ht_mask;
+    const u64 *ht; u64 ht_cap;
     const u64 *pos;            // index position lists
     const u32 *t_len, *t_rank; // indexed reads
     const u32 *q_len, *q_rank; // query reads
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, u64 
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_mz) return;
     u64 st = 0; u32 cnt = 0;
-    if (!ht_lookup(sp.ht, sp.ht_mask, qx[i] >> 8, &st, &cnt)) { st = 0; cnt = 0; }
+    if (!ht_lookup(sp.ht, sp.ht_cap, qx[i] >> 8, &st, &cnt)) { st = 0; cnt = 0; }
     hs[i] = (u32)st; hc[i] = cnt;
 }
 

@@ -279,7 +279,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         ALLOC_OR_FAIL(k1, sc, u64, M + 1);
         ALLOC_OR_FAIL(v1, sc, u64, M + 1);
         u64 *rk, *rv;
-        rc = radix_sort_pairs(ctx, sc, so.x, so.y, k1, v1, M, 0, 2 * P.k, &rk, &rv);
+        rc = radix_sort_pairs(ctx, sc, so.x, so.y, k1, v1, M, 0, 2 * P.k, &rk, &rv, /*reverse_digits=*/true);   // see k_index.h
         if (rc) return rc;
         // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
         skey = rk; spos = rv;
@@ -312,26 +312,48 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
             KCHK(ctx);
             sc.drop(head); sc.drop(runid); sc.drop(d_nr);
         }
-        u64 cap = 1024;
-        while (cap < 2 * (u64)n_runs) cap <<= 1;
-        ix->ht_mask = cap - 1;
+        u64 cap = 2 * (u64)n_runs;
+        if (cap < 1024) cap = 1024;
+        if (cap + n_runs >= (1ULL << 32)) { delete ix; LRGE_SET_ERR(ctx, "index limited to < 2^32/3 distinct minimizers (got %u)", n_runs); return LRGE_ERR_TOO_MANY; }
+        ix->ht_cap = cap;
         ix->n_keys = n_runs;
-        u64 *ht = sc.get<u64>(2 * cap);
-        u32 *d_occ = sc.get<u32>((size_t)max_bin + 1);
-        if (!ht || !d_occ) { delete ix; return LRGE_ERR_DEVICE; }
-        HIPCHK(ctx, hipMemsetAsync(ht, 0xFF, 2 * cap * 8, ctx->stream));   // key = HT_EMPTY
-        HIPCHK(ctx, hipMemsetAsync(d_occ, 0, ((size_t)max_bin + 1) * 4, ctx->stream));
-        if (n_runs) {
-            hipLaunchKernelGGL(k_table_insert, dim3((u32)std::min<u64>(div_up(n_runs, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
-                               skey, d_runstart, n_runs, M, ht, ix->ht_mask, d_occ, max_bin);
-            KCHK(ctx);
-        }
-        // the k-th smallest occurrence count almost always sits in the first few bins: fetch 16 KB of
-        // the histogram first, the whole 4 MB only if the prefix does not reach the k-th element
+        u32 *d_occ = sc.get<u32>((size_t)max_bin + 2);     // [max_bin + 1] = overflow flag
+        if (!d_occ) { delete ix; return LRGE_ERR_DEVICE; }
+        u64 *ht = nullptr;
         occ.assign((size_t)max_bin + 1, 0);
         const size_t head_bins = std::min<size_t>(4096, (size_t)max_bin + 1);
-        HIPCHK(ctx, hipMemcpyAsync(occ.data(), d_occ, head_bins * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        // slack behind cap: displaced keys at the very end of the table do not wrap.  n_runs / 16 is far more
+        // than linear probing at load 1/2 ever needs; if it were not, the second attempt (n_runs + 1) always fits.
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const u64 slack = attempt == 0 ? std::max<u64>((u64)n_runs / 16, 4096) : (u64)n_runs + 1;
+            const u64 n_slots = cap + slack;
+            ht = sc.get<u64>(2 * n_slots);
+            if (!ht) { delete ix; return LRGE_ERR_DEVICE; }
+            HIPCHK(ctx, hipMemsetAsync(ht, 0xFF, 2 * n_slots * 8, ctx->stream));   // key = HT_EMPTY
+            HIPCHK(ctx, hipMemsetAsync(d_occ, 0, ((size_t)max_bin + 2) * 4, ctx->stream));
+            if (n_runs) {
+                const u32 n_tiles = (u32)div_up(n_runs, PLACE_TILE);
+                u32 *bmax = sc.get<u32>((size_t)n_tiles + 1);
+                if (!bmax) { delete ix; return LRGE_ERR_DEVICE; }
+                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax);
+                KCHK(ctx);
+                hipLaunchKernelGGL(k_place_scan, dim3(1), dim3(1024), 0, ctx->stream, bmax, n_tiles);
+                KCHK(ctx);
+                hipLaunchKernelGGL(k_place_apply, dim3(std::min<u32>(n_tiles, (u32)ctx->n_cu * 8)), dim3(PLACE_THREADS), 0, ctx->stream,
+                                   skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1);
+                KCHK(ctx);
+                sc.drop(bmax);
+            }
+            // the k-th smallest occurrence count almost always sits in the first few bins: fetch 16 KB of
+            // the histogram first, the whole 4 MB only if the prefix does not reach the k-th element
+            u32 overflow = 0;
+            HIPCHK(ctx, hipMemcpyAsync(occ.data(), d_occ, head_bins * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(&overflow, d_occ + max_bin + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (!overflow) break;
+            sc.drop(ht); ht = nullptr;
+            if (attempt == 1) { delete ix; LRGE_SET_ERR(ctx, "index table placement overflowed%s", ""); return LRGE_ERR_DEVICE; }
+        }
         {
             const u32 kth = n_runs ? (u32)((1. - (double)P.mid_occ_frac) * (double)n_runs) : 0;
             u64 cum = 0;
@@ -390,8 +412,20 @@ extern "C" int lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, 
     *n_out = ix->n_mz;
     u64 m = ix->n_mz < cap ? ix->n_mz : cap;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
-    if (m && keys) HIPCHK(ctx, hipMemcpy(keys, ix->d_skey, m * 8, hipMemcpyDeviceToHost));
-    if (m && pos) HIPCHK(ctx, hipMemcpy(pos, ix->d_pos, m * 8, hipMemcpyDeviceToHost));
+    // the device keeps the stream ordered by the byte-reversed hash (k_index.h); the dump presents it in
+    // ascending hash order, lists ascending in y, i.e. the order mm_idx_get users see (debug / test entry point)
+    std::vector<u64> hk(ix->n_mz), hp(ix->n_mz);
+    if (ix->n_mz) {
+        HIPCHK(ctx, hipMemcpy(hk.data(), ix->d_skey, ix->n_mz * 8, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(hp.data(), ix->d_pos, ix->n_mz * 8, hipMemcpyDeviceToHost));
+    }
+    std::vector<u32> ord(ix->n_mz);
+    for (u64 i = 0; i < ix->n_mz; ++i) ord[i] = (u32)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return hk[a] < hk[b]; });
+    for (u64 i = 0; i < m; ++i) {
+        if (keys) keys[i] = hk[ord[i]];
+        if (pos) pos[i] = hp[ord[i]];
+    }
     return LRGE_OK;
 }
 
@@ -467,7 +501,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
 
     // ---- 2. lookup ----
     SeedParams sp;
-    sp.ht = ix->d_ht; sp.ht_mask = ix->ht_mask; sp.pos = ix->d_pos;
+    sp.ht = ix->d_ht; sp.ht_cap = ix->ht_cap; sp.pos = ix->d_pos;
     sp.t_len = T->d_len; sp.t_rank = T->d_rank; sp.q_len = Q->d_len; sp.q_rank = Q->d_rank;
     sp.mid_occ = ix->mid_occ;
     sp.check_names = (Q->has_rank && T->has_rank) ? 1 : 0;   // qname == NULL in minimap2 skips skip_seed entirely

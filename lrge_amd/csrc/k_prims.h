@@ -166,24 +166,36 @@ static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32
 #define RS_ITEMS 16
 #define RS_TILE (RS_THREADS * RS_ITEMS)
 
+// SEG: segmented sort.  The array is a sequence of independent segments (e.g. one per query) that must
+// each be sorted in place; every tile lies inside one segment and the histogram is laid out
+// [segment][digit][tile of the segment], so that ONE exclusive scan over it yields, per (tile, digit), the
+// global destination of that digit's run -- segments never mix and the segment id costs no sort pass.
+struct SegTile { u32 start, len, hbase, hstride; };   // hist index of digit d: hbase + d * hstride
+
+template <bool SEG>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
-                                                        u32 *__restrict__ hist) {
+                                                        u32 *__restrict__ hist, const SegTile *__restrict__ tiles) {
     __shared__ u32 h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    u64 base = (u64)blockIdx.x * RS_TILE + (u64)(threadIdx.x >> 6) * (RS_ITEMS * 64) + lane_id();
+    const u64 tile0 = SEG ? (u64)tiles[blockIdx.x].start : (u64)blockIdx.x * RS_TILE;
+    const u32 n_tile = SEG ? tiles[blockIdx.x].len : (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
+    const u32 l0 = (threadIdx.x >> 6) * (RS_ITEMS * 64) + lane_id();
 #pragma unroll 4
     for (int r = 0; r < RS_ITEMS; ++r) {
-        u64 i = base + (u64)r * 64;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1u);
+        const u32 l = l0 + (u32)r * 64;
+        if (l < n_tile) atomicAdd(&h[(keys[tile0 + l] >> shift) & 255], 1u);
     }
     __syncthreads();
-    hist[(u64)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+    const u64 hi = SEG ? (u64)tiles[blockIdx.x].hbase + (u64)threadIdx.x * tiles[blockIdx.x].hstride : (u64)threadIdx.x * nb + blockIdx.x;
+    hist[hi] = h[threadIdx.x];
 }
 
+template <bool SEG>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict__ keys_in, const u64 *__restrict__ vals_in,
                                                            u64 *__restrict__ keys_out, u64 *__restrict__ vals_out, u64 n,
-                                                           int shift, u32 nb, const u32 *__restrict__ hist_scanned) {
+                                                           int shift, u32 nb, const u32 *__restrict__ hist_scanned,
+                                                           const SegTile *__restrict__ tiles) {
     // 1. per-wave stable ranks (ballot digit matching + per-wave LDS counters)
     // 2. block-local destinations: the tile is first reordered through LDS so that each digit's
     //    items are contiguous, then written out as coalesced runs (one run per digit per tile)
@@ -194,16 +206,21 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     for (u32 i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    const u64 tile0 = (u64)blockIdx.x * RS_TILE;
-    const u64 base = tile0 + (u64)w * (RS_ITEMS * 64) + lane;
-    u64 k[RS_ITEMS];
+    const u64 tile0 = SEG ? (u64)tiles[blockIdx.x].start : (u64)blockIdx.x * RS_TILE;
+    const u32 n_tile = SEG ? tiles[blockIdx.x].len : (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
+    const u32 l0 = w * (RS_ITEMS * 64) + lane;           // tile-local index of my first item
+    const u64 base = tile0 + l0;
+    u64 k[RS_ITEMS], v[RS_ITEMS];
     u32 rank[RS_ITEMS];
     const u64 lt = lanemask_lt();
+    // all loads of the tile are issued up front: the values arrive while the keys are being ranked
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n_tile ? keys_in[base + (u64)r * 64] : ~0ULL;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) v[r] = l0 + (u32)r * 64 < n_tile ? vals_in[base + (u64)r * 64] : 0;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
-        u64 i = base + (u64)r * 64;
-        bool valid = i < n;
-        k[r] = valid ? keys_in[i] : ~0ULL;
+        bool valid = l0 + (u32)r * 64 < n_tile;
         u32 d = (u32)(k[r] >> shift) & 255;
         u64 m = __ballot(valid);
 #pragma unroll
@@ -229,20 +246,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         __syncthreads();
         u32 dstart = inc - tot;
         for (u32 ww = 0; ww < w; ++ww) dstart += wtot[ww];
-        gbase[d] = hist_scanned[(u64)d * nb + blockIdx.x] - dstart;
+        const u64 hi = SEG ? (u64)tiles[blockIdx.x].hbase + (u64)d * tiles[blockIdx.x].hstride : (u64)d * nb + blockIdx.x;
+        gbase[d] = hist_scanned[hi] - dstart;
         u32 run = dstart;
 #pragma unroll
         for (int ww = 0; ww < RS_WAVES; ++ww) { cnt[ww][d] = run; run += c[ww]; }
     }
     __syncthreads();
-    const u32 n_tile = (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
     u32 lpos[RS_ITEMS];
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
-        u64 i = base + (u64)r * 64;
         u32 d = (u32)(k[r] >> shift) & 255;
         lpos[r] = cnt[w][d] + rank[r];
-        if (i < n) stage[lpos[r]] = k[r];
+        if (l0 + (u32)r * 64 < n_tile) stage[lpos[r]] = k[r];
     }
     __syncthreads();
     u64 ko[RS_ITEMS];
@@ -254,8 +270,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
-        u64 i = base + (u64)r * 64;
-        if (i < n) stage[lpos[r]] = vals_in[i];
+        if (l0 + (u32)r * 64 < n_tile) stage[lpos[r]] = v[r];
     }
     __syncthreads();
 #pragma unroll
@@ -268,22 +283,27 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
 // Sorts (keys, vals) by bits [begin_bit, begin_bit + nbits) of the key (rounded up to whole bytes).  Ping-pongs between (k0,v0) and (k1,v1);
 // *res_k / *res_v point at the buffers holding the result.
 // reverse_digits: the LOWEST byte becomes the most significant digit (result ascending in the byte-reversed key).
+// d_tiles / n_tiles: segmented sort (see SegTile); every segment is sorted by the given bits, in place.
 static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u64 *k1, u64 *v1, u64 n, int begin_bit,
-                            int nbits, u64 **res_k, u64 **res_v, bool reverse_digits = false) {
+                            int nbits, u64 **res_k, u64 **res_v, bool reverse_digits = false,
+                            const SegTile *d_tiles = nullptr, u32 n_tiles = 0) {
     *res_k = k0; *res_v = v0;
     if (n <= 1 || nbits <= 0) return LRGE_OK;
     if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
-    u32 nb = (u32)div_up(n, RS_TILE);
+    u32 nb = d_tiles ? n_tiles : (u32)div_up(n, RS_TILE);
+    if (nb == 0) return LRGE_OK;
     ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * nb);
     int passes = (nbits + 7) / 8;
     u64 *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     for (int p = 0; p < passes; ++p) {
         int shift = begin_bit + (reverse_digits ? passes - 1 - p : p) * 8;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist);
+        if (d_tiles) hipLaunchKernelGGL(k_rs_hist<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, d_tiles);
+        else hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, d_tiles);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist);
+        if (d_tiles) hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist, d_tiles);
+        else hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist, d_tiles);
         KCHK(ctx);
         u64 *t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;

@@ -644,8 +644,29 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         }
         {
             StageTimer t(ctx, LRGE_T_ANCHOR_SORT);
-            rc = radix_sort_pairs(ctx, bsc, akey, aval, akey2, aval2, A, 0, (int)kl.total(), &skey, &sval);
+            // the expansion emits the anchors query by query, so only (target, strand, position) need sorting,
+            // inside every query's segment: the query bits cost no radix pass (SegTile, k_prims.h)
+            std::vector<SegTile> h_tiles;
+            {
+                u32 off = 0, tb = 0;
+                for (u32 q = q0; q < q1; ++q) {
+                    const u32 c = h_qtot[q], nt_q = (u32)div_up((u64)c, RS_TILE);
+                    for (u32 lt = 0; lt < nt_q; ++lt) {
+                        SegTile t; t.start = off + lt * RS_TILE; t.len = std::min<u32>(RS_TILE, c - lt * RS_TILE);
+                        t.hbase = 256u * tb + lt; t.hstride = nt_q;
+                        h_tiles.push_back(t);
+                    }
+                    off += c; tb += nt_q;
+                }
+            }
+            SegTile *d_tiles = (SegTile *)bsc.get<u32>(h_tiles.size() * 4 + 4);
+            if (!d_tiles) return LRGE_ERR_DEVICE;
+            HIPCHK(ctx, hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // h_tiles is pageable and goes out of scope
+            rc = radix_sort_pairs(ctx, bsc, akey, aval, akey2, aval2, A, 0, (int)(kl.bits_rpos + 1 + kl.bits_rid), &skey, &sval, false,
+                                  d_tiles, (u32)h_tiles.size());
             if (rc) return rc;
+            bsc.drop((u32 *)d_tiles);
             // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
             bsc.drop(skey == akey ? akey2 : akey);
             bsc.drop(sval == aval ? aval2 : aval);

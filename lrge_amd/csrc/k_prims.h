@@ -79,8 +79,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const u32 *in, u64
     __shared__ u32 wsum[SCAN_THREADS / 64];
     u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
     u32 s = 0;
+    if (base + SCAN_ITEMS <= n && ((uintptr_t)in & 15) == 0) {   // 4 x 16-byte loads instead of 16 dword loads
+        const uint4 *p = (const uint4 *)(in + base);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) s += in[base + i];
+        for (int i = 0; i < SCAN_ITEMS / 4; ++i) { const uint4 q = p[i]; s += q.x + q.y + q.z + q.w; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) s += in[base + i];
+    }
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
     if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -120,16 +126,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32 *in, u32 
     u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
     u32 v[SCAN_ITEMS];
     u32 s = 0;
+    const bool vec = base + SCAN_ITEMS <= n && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    if (vec) {
+        const uint4 *p = (const uint4 *)(in + base);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = base + i < n ? in[base + i] : 0; s += v[i]; }
+        for (int i = 0; i < SCAN_ITEMS / 4; ++i) { const uint4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) s += v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = base + i < n ? in[base + i] : 0; s += v[i]; }
+    }
     u32 inc = wave_incl_scan_u32(s);
     if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
     u32 off = block_offs[blockIdx.x];
     for (u32 w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
     off += inc - s;
+    if (vec) {
+        uint4 *po = (uint4 *)(out + base);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) out[base + i] = off; off += v[i]; }
+        for (int i = 0; i < SCAN_ITEMS / 4; ++i) {
+            uint4 q;
+            q.x = off; off += v[4 * i]; q.y = off; off += v[4 * i + 1]; q.z = off; off += v[4 * i + 2]; q.w = off; off += v[4 * i + 3];
+            po[i] = q;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) out[base + i] = off; off += v[i]; }
+    }
     if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total = off;
 }
 

@@ -41,6 +41,9 @@ struct LpgChainArgs {
 template <bool PENTAB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
     extern __shared__ i32 pen_tab[];
+    // this kernel's longest wavefronts are the critical path of the chain stage; k_chain_hw's wavefronts on
+    // the other stream share the SIMDs and should fill the gaps, not compete for issue slots
+    __builtin_amdgcn_s_setprio(3);
     const u32 li = blockIdx.x * 64 + threadIdx.x;
     const bool has = li < R.n_list;
     const u32 g = has ? R.list[li] : 0;
@@ -264,16 +267,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (has && bkey != 0) {
         const i32 zx = (i32)(u32)(bkey >> 32), top = (i32)(u32)bkey;
         i32 i = top, max_i = top, max_s = 0, depth = 0, cnt = 0;
-        u64 r = ld_u64_l2(grec + top);
-        for (;;) {
-            i = grec_p(r);
-            ++depth;
-            i32 s;
-            if (i < 0) s = zx;
-            else { r = ld_u64_l2(grec + i); s = zx - grec_f(r); }
-            if (s > max_s) { max_s = s; max_i = i; cnt = depth; }
-            else if (max_s - s > P.max_drop) break;
-            if (i < 0) break;
+        // A dependent load per hop would be the critical path of a long group.  Chains mostly step 1..3 anchors
+        // back, so each round trip fetches the 8 records ending at the current anchor and the lane then hops
+        // inside them without touching memory; all lanes of the wave refill in the same iteration.
+        bool done = false;
+        i32 cur = top;                                   // anchor whose record is needed next
+        while (!done) {
+            u64 blk[8];
+            const i32 lo = cur > 7 ? cur - 7 : 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) blk[t] = lo + t <= cur ? ld_u64_l2(grec + lo + t) : 0;
+            while (!done && cur >= lo) {
+                const i32 d = cur - lo;
+                u64 r = blk[0];
+#pragma unroll
+                for (int t = 1; t < 8; ++t) r = d == t ? blk[t] : r;
+                if (cur != top) {                        // (the record of `top` itself only supplies p)
+                    const i32 s = zx - grec_f(r);
+                    if (s > max_s) { max_s = s; max_i = cur; cnt = depth; }
+                    else if (max_s - s > P.max_drop) { done = true; break; }
+                }
+                i = grec_p(r);
+                ++depth;
+                if (i < 0) {                             // walked off the chain start: s = zx
+                    if (zx > max_s) { max_s = zx; max_i = -1; cnt = depth; }
+                    done = true;
+                }
+                cur = i;
+            }
         }
         const i32 sc = max_i == top ? 0 : max_s;
         const bool accepted = sc >= P.min_sc && cnt > 0 && cnt >= P.min_cnt;

@@ -117,7 +117,7 @@ def main():
 
     def step():
         ix = engine.Index(ctx, Td, 0)
-        tb = dict(ix.build_timings)
+        tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
         counts, has = ix.overlap_twoset(Qd)
         tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
         est = ctx.estimates(counts, qlens, float(avg_t), t.n, 100)
@@ -130,6 +130,8 @@ def main():
         else:
             est_all = est
         med = engine.median(est_all, True, 0.15, 0.65)
+        for k_ in ("rs_scatter_launches", "rs_scatter_items"):   # the index build sorts too
+            cn[k_] = cn.get(k_, 0) + cb_.get(k_, 0)
         return counts, est_all, med, tb, tm, cn, st
 
     for _ in range(a.warmup):
@@ -153,21 +155,41 @@ def main():
         K = a.steps
         ms_per_step = elapsed * 1e3 / K
         value = world * Qn * K / elapsed
-        # ---- roofline of the dominant kernel (k_chain_reg) against the HBM roof ----
-        # algorithmic bytes per launch = 16 B per anchor read (8 B key + 8 B value) + 4 B flag per group,
-        # the "16*H anchor in for chaining" term of B_q, restricted to what a launch covers.
-        launches = max(1, acc_cn.get("chain_launches", 0))
-        chain_ms = acc_tm.get("chain", 0.0)
-        alg_bytes = 16.0 * acc_cn.get("chain_anchors", 0) / launches
-        avg_launch_ms = chain_ms / launches
-        achieved = alg_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic = None
+        # ---- roofline of the dominant kernel against the HBM roof ----
+        # The kernel with the most time per step is k_chain_lpg (mg_lchain_dp + backtrack, 64 groups per
+        # wavefront).  Algorithmic bytes per launch = 16 B per anchor it chains (8 B key + 8 B value; SURVEY.md
+        # 8(d): the "16*H anchor in for chaining" term of B_q restricted to what the launch covers).  Its avg
+        # launch duration is measured live with a HIP event pair on the side stream the kernel runs on.
+        # It is an integer DP bound by VALU issue, not by memory, so frac is small by construction; the
+        # memory-bound kernel with the most time (k_rs_scatter, 32 B moved per item) is reported next to it.
+        pmc = {}
         pj = os.path.join(ROOT, "profiles", "chain_pmc.json")
         if os.path.exists(pj):
             try:
-                traffic = json.load(open(pj)).get("k_chain_reg_hbm_bytes_per_launch")
+                pmc = json.load(open(pj))
             except Exception:
-                traffic = None
+                pmc = {}
+
+        def roof(kernel, ms_total, launches, bytes_total, traffic_key):
+            launches = max(1, launches)
+            avg_ms = ms_total / launches
+            alg = bytes_total / launches
+            ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBPS, "traffic": pmc.get(traffic_key), "alg_bytes_per_launch": alg,
+                    "avg_launch_ms": avg_ms, "launches_per_step": launches / K}
+
+        mode = os.environ.get("LRGE_HIP_CHAIN", "")
+        if acc_cn.get("lpg_launches", 0):
+            r_dom = roof("k_chain_lpg", acc_tm.get("chain_lpg", 0.0), acc_cn["lpg_launches"], 16.0 * acc_cn.get("lpg_anchors", 0),
+                         "k_chain_lpg_hbm_bytes_per_launch")
+        else:   # a single-kernel mode was forced (LRGE_HIP_CHAIN=hw|reg|lds)
+            r_dom = roof("k_chain_" + (mode or "hw"), acc_tm.get("chain", 0.0), acc_cn.get("chain_launches", 0),
+                         16.0 * acc_cn.get("chain_anchors", 0), "k_chain_%s_hbm_bytes_per_launch" % (mode or "hw"))
+        r_stage = roof("chain stage: k_chain_hw beside k_chain_lpg (fork..join)", acc_tm.get("chain", 0.0),
+                       acc_cn.get("batches", 0), 16.0 * acc_cn.get("chain_anchors", 0), "chain_stage_hbm_bytes_per_step")
+        r_sc = roof("k_rs_scatter", acc_tm.get("rs_scatter", 0.0) + acc_tb.get("rs_scatter", 0.0), acc_cn.get("rs_scatter_launches", 0),
+                    32.0 * acc_cn.get("rs_scatter_items", 0), "k_rs_scatter_hbm_bytes_per_launch")
         # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
         L = float(q.lens().sum()); M = acc_cn.get("query_minimizers", 0) / K; H = acc_cn.get("anchors", 0) / K
         B_q = L / 4 + 32 * M + 8 * H + 32 * H + 4 * Qn
@@ -187,10 +209,8 @@ def main():
             "genome_size_abs_error": None if med[1] is None else abs(float(med[1]) - gsize),
             "estimate_q15_q65": [None if med[0] is None else float(med[0]), None if med[2] is None else float(med[2])],
             "mid_occ": st["mid_occ"],
-            "roofline": {"bound": "hbm", "kernel": os.environ.get("LRGE_HIP_CHAIN", "reg") == "reg" and "k_chain_reg" or "k_chain_lds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_launch_ms, "launches_per_step": launches / K,
-                         "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS},
+            "roofline": {**r_dom, "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS},
+            "roofline_other": [r_stage, r_sc],
             "stage_ms_per_step": {**{"index_" + k: v / K for k, v in acc_tb.items() if v and k != "total"},
                                   **{k: v / K for k, v in acc_tm.items() if v}},
             "work_per_step": {k: v / K for k, v in acc_cn.items()},

@@ -73,18 +73,23 @@ typedef struct {
                             corrections; with cnt (= n_match) and the query's avg_k it gives dv */
 } lrge_hip_chain;
 
-/* Stage timings of the last overlap/index call on a ctx, in milliseconds (HIP events on the
-   ctx stream).  Index into the array with LRGE_T_*. */
+/* Stage timings of the last overlap/index call on a ctx, in milliseconds (HIP event pairs recorded on the
+   stream each stage runs on).  Index into the array with LRGE_T_*.  LRGE_T_CHAIN spans the whole chain stage
+   (k_chain_hw beside k_chain_lpg, fork to join); LRGE_T_CHAIN_LPG is k_chain_lpg alone, on its side stream;
+   LRGE_T_RS_SCATTER sums every k_rs_scatter launch of the call (they also count inside the sort stages). */
 enum {
     LRGE_T_PACK = 0, LRGE_T_SKETCH, LRGE_T_INDEX_SORT, LRGE_T_INDEX_TABLE, LRGE_T_QFILTER,
-    LRGE_T_LOOKUP, LRGE_T_EXPAND, LRGE_T_ANCHOR_SORT, LRGE_T_GROUP, LRGE_T_CHAIN /* k_chain_lds launches */,
-    LRGE_T_CHAIN_GLB /* k_chain_glb launches */, LRGE_T_COUNT, LRGE_T_TOTAL, LRGE_T_N
+    LRGE_T_LOOKUP, LRGE_T_EXPAND, LRGE_T_ANCHOR_SORT, LRGE_T_GROUP, LRGE_T_CHAIN,
+    LRGE_T_CHAIN_GLB /* k_chain_glb launches (LRGE_HIP_CHAIN=lds|glb only) */, LRGE_T_COUNT, LRGE_T_TOTAL,
+    LRGE_T_CHAIN_LPG, LRGE_T_RS_SCATTER, LRGE_T_N
 };
 /* Work counters of the last overlap call (for the roofline's algorithmic bytes). */
 enum {
     LRGE_C_QUERY_BASES = 0, LRGE_C_QUERY_MINIMIZERS, LRGE_C_ANCHORS, LRGE_C_GROUPS,
-    LRGE_C_GROUPS_CHAINED, LRGE_C_CHAIN_LAUNCHES /* k_chain_lds */, LRGE_C_BATCHES,
-    LRGE_C_CHAIN_ANCHORS /* anchors read by k_chain_lds */, LRGE_C_CHAIN_GLB_LAUNCHES, LRGE_C_CHAIN_GLB_ANCHORS,
+    LRGE_C_GROUPS_CHAINED, LRGE_C_CHAIN_LAUNCHES, LRGE_C_BATCHES,
+    LRGE_C_CHAIN_ANCHORS /* anchors in chained groups */, LRGE_C_CHAIN_GLB_LAUNCHES, LRGE_C_CHAIN_GLB_ANCHORS,
+    LRGE_C_LPG_LAUNCHES, LRGE_C_LPG_ANCHORS /* of those, anchors chained by k_chain_lpg */,
+    LRGE_C_RS_SCATTER_LAUNCHES, LRGE_C_RS_SCATTER_ITEMS /* (key, value) pairs moved by k_rs_scatter */,
     LRGE_C_N
 };
 

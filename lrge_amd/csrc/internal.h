@@ -181,9 +181,10 @@ struct TimerRec { int slot; hipEvent_t a, b; };
 struct StageTimer {
     lrge_hip_ctx *ctx;
     int slot;
+    hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
     bool stopped = false;
-    StageTimer(lrge_hip_ctx *c, int s);
+    StageTimer(lrge_hip_ctx *c, int s, hipStream_t on = nullptr);
     void stop();
     ~StageTimer() { if (!stopped) stop(); }
 };
@@ -191,14 +192,14 @@ struct StageTimer {
 static inline u32 ceil_log2_u64(u64 v) { u32 b = 0; while (b < 64 && (1ULL << b) < v) ++b; return b; }
 static inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
 
-inline StageTimer::StageTimer(lrge_hip_ctx *c, int s) : ctx(c), slot(s) {
+inline StageTimer::StageTimer(lrge_hip_ctx *c, int s, hipStream_t on) : ctx(c), slot(s), st(on ? on : c->stream) {
     a = ctx->get_event(); b = ctx->get_event();
-    (void)hipEventRecord(a, ctx->stream);
+    (void)hipEventRecord(a, st);
 }
 inline void StageTimer::stop() {
     if (stopped) return;
     stopped = true;
-    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventRecord(b, st);
     ctx->timers.push_back(TimerRec{slot, a, b});
 }
 inline void lrge_hip_ctx::resolve_timers() {

@@ -346,21 +346,24 @@ __global__ __launch_bounds__(64) void k_chain_hw(HwChainArgs R, ChainParams P, G
 // n_out[0] = groups with n >= min_n, n_out[2] = those with n > big_n (n_out[1] is k_group_fill's cursor)
 __global__ void k_group_count(const u32 *__restrict__ gstart, u32 n_groups, u64 n_anchors, u32 min_n, u32 big_n,
                               u32 *__restrict__ n_out, unsigned long long *__restrict__ anchors_out) {
-    __shared__ u32 lc, lb; __shared__ unsigned long long la;
-    if (threadIdx.x == 0) { lc = 0; lb = 0; la = 0; }
+    __shared__ u32 lc, lb; __shared__ unsigned long long la, lab;
+    if (threadIdx.x == 0) { lc = 0; lb = 0; la = 0; lab = 0; }
     __syncthreads();
     const u64 c0 = (u64)blockIdx.x * GB_CHUNK;
-    u32 c = 0, b = 0; unsigned long long a = 0;
+    u32 c = 0, b = 0; unsigned long long a = 0, ab = 0;
     for (u64 gg = c0 + threadIdx.x; gg < c0 + GB_CHUNK && gg < n_groups; gg += blockDim.x) {
         const u32 g = (u32)gg;
         const u64 e = (g + 1 < n_groups) ? gstart[g + 1] : n_anchors;
         const u32 n = (u32)(e - gstart[g]);
-        if (n >= min_n) { ++c; a += n; if (n > big_n) ++b; }
+        if (n >= min_n) { ++c; a += n; if (n > big_n) { ++b; ab += n; } }
     }
     if (c) { atomicAdd(&lc, c); atomicAdd(&la, a); }
-    if (b) atomicAdd(&lb, b);
+    if (b) { atomicAdd(&lb, b); atomicAdd(&lab, ab); }
     __syncthreads();
-    if (threadIdx.x == 0 && lc) { atomicAdd(n_out, lc); atomicAdd(anchors_out, la); if (lb) atomicAdd(n_out + 2, lb); }
+    if (threadIdx.x == 0 && lc) {
+        atomicAdd(n_out, lc); atomicAdd(anchors_out, la);
+        if (lb) { atomicAdd(n_out + 2, lb); atomicAdd(anchors_out + 1, lab); }   // anchors_out[1]: anchors of the big groups
+    }
 }
 
 // keys = 65535 - min(n, 65535), so that an ascending 16-bit sort puts the largest groups first; vals = group id

@@ -23,6 +23,8 @@
 
 #define LPG_W 32
 #define LPG_B 16   // candidates per evaluate / resolve block
+#define LPG_CH 8   // anchors per input / output staging chunk
+#define LPG_RING_BYTES ((2 * (LPG_CH / 2) * 128 * 2 + LPG_CH * 64) * 8)
 #define LPG_MAX_N_DEFAULT 512
 
 struct LpgChainArgs {
@@ -40,7 +42,7 @@ struct LpgChainArgs {
 // LDS ([0, bw] + one "out of band" entry) with the very same f32 operations, and a candidate needs no f32 math.
 template <bool PENTAB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
-    extern __shared__ i32 pen_tab[];
+    extern __shared__ i32 pen_tab[];   // [bw + 2] when PENTAB, then the anchor / record staging ring (LPG_RING_BYTES)
     // this kernel's longest wavefronts are the critical path of the chain stage; k_chain_hw's wavefronts on
     // the other stream share the SIMDs and should fill the gaps, not compete for issue slots
     __builtin_amdgcn_s_setprio(3);
@@ -73,6 +75,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (threadIdx.x == 0) pen_tab[tabn] = 1 << 30;            // dd > bw: pushes s below NEG_BIG
         __syncthreads();
     }
+    // Anchor input / record output staging.  A lane walks its own group, so a plain per-step load touches 64
+    // different cache lines per instruction and each line is re-fetched for every anchor it holds (measured:
+    // 10x the algorithmic bytes).  Instead every lane streams its group in chunks of LPG_CH anchors: two 16-byte
+    // direct-to-LDS loads per array (global_load_lds_dwordx4, no VGPRs) one chunk ahead, and (f, p) records leave
+    // as one 32-byte run per lane and chunk.
+    //   ring_k / ring_v: [buffer 2][pair LPG_CH/2][lane 64][2]   ring_o: [row LPG_CH][lane 64]
+    u64 *ring_k = (u64 *)((char *)pen_tab + (PENTAB ? (((size_t)tabn + 1) * 4 + 15) / 16 * 16 : 0));
+    u64 *ring_v = ring_k + 2 * (LPG_CH / 2) * 128;
+    u64 *ring_o = ring_v + 2 * (LPG_CH / 2) * 128;
+    const u32 lane = threadIdx.x;
+    auto issue_chunk = [&](i32 a0, i32 buf) {            // anchors [a0, a0 + LPG_CH) -> buffer buf (reads <= 1 anchor past n)
+#pragma unroll
+        for (int pr = 0; pr < LPG_CH / 2; ++pr) {
+            if (a0 + 2 * pr < n) {
+                __builtin_amdgcn_global_load_lds(gk + a0 + 2 * pr, ring_k + (buf * (LPG_CH / 2) + pr) * 128, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gv + a0 + 2 * pr, ring_v + (buf * (LPG_CH / 2) + pr) * 128, 16, 0, 0);
+            }
+        }
+    };
+    issue_chunk(0, 0);
 
     // window: slot k <-> anchor i-1-k.  WO = one-hot of (j - p[j] - 1), 0 when there is no predecessor or it
     // lies >= 32 anchors back: shifted left by k+1 it is the mark that candidate k leaves on a later candidate.
@@ -83,13 +105,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int k = 0; k < LPG_W; ++k) { WX[k] = 0; WY[k] = INT32_MAX; WF[k] = 0; WS[k] = 0; WO[k] = 0; }
     i32 mi = -1, mi_x = 0, mi_y = 0, mi_f = 0, mi_sp = 0;
     u64 bkey = 0;                                   // best chain end: f << 32 | i  (f >= min_sc)
-    u64 nk = 0, nv = 0;
-    if (n > 0) { nk = gk[0]; nv = gv[0]; }
 
     for (i32 i = 0; i < n_max; ++i) {
         const bool alive = i < n;
-        const u64 ck = nk, cv = nv;
-        if (i + 1 < n) { nk = gk[i + 1]; nv = gv[i + 1]; }
+        const i32 r4 = i & (LPG_CH - 1), cb = (i / LPG_CH) & 1;
+        if (r4 == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk has landed (issued LPG_CH steps ago)
+            issue_chunk(i + LPG_CH, cb ^ 1);
+        }
+        const u32 ri = ((cb * (LPG_CH / 2) + (r4 >> 1)) * 64 + lane) * 2 + (r4 & 1);
+        const u64 ck = ring_k[ri], cv = ring_v[ri];
         const i32 xi = (i32)(ck & rmask), yi = (i32)(u32)cv, spi = (i32)((cv >> 32) & 0xff);
         const i32 navail = i < max_iter ? i : max_iter;         // candidates j in [i - navail, i - 1]
         const i32 kcap = navail < LPG_W ? navail : LPG_W;
@@ -245,9 +270,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         if (alive && (mi < 0 || (xi - mi_x <= maxdx && mi_f < max_f))) { mi = i; mi_x = xi; mi_y = yi; mi_f = max_f; mi_sp = spi; }
         if (alive) {
-            grec[i] = grec_make(max_f, max_j);
+            ring_o[r4 * 64 + lane] = grec_make(max_f, max_j);
             const u64 key = (u64)(u32)max_f << 32 | (u32)i;
             bkey = (max_f >= min_sc && key > bkey) ? key : bkey;
+        }
+        if (r4 == LPG_CH - 1) {
+            if (alive) {                                             // a full chunk: one 32-byte run per lane
+#pragma unroll
+                for (int t = 0; t < LPG_CH; t += 2) {
+                    ulonglong2 o; o.x = ring_o[t * 64 + lane]; o.y = ring_o[(t + 1) * 64 + lane];
+                    *(ulonglong2 *)(grec + i - (LPG_CH - 1) + t) = o;
+                }
+            }
+        } else if (__ballot(alive && i == n - 1)) {                 // a group ends inside its chunk
+            if (alive && i == n - 1)
+                for (i32 t = 0; t <= r4; ++t) grec[i - r4 + t] = ring_o[t * 64 + lane];
         }
         // shift the window, insert anchor i at slot 0
         const u32 reli = (u32)(i - 1 - max_j);                       // >= 32 (or "no predecessor"): no mark inside the window

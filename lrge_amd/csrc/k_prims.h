@@ -327,9 +327,15 @@ static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u6
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
         if (rc) return rc;
-        if (d_tiles) hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist, d_tiles);
-        else hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist, d_tiles);
-        KCHK(ctx);
+        {
+            StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+            if (d_tiles) hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist, d_tiles);
+            else hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist, d_tiles);
+            KCHK(ctx);
+            ts.stop();
+            ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
+            ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;
+        }
         u64 *t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
     }

@@ -259,6 +259,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
+    memset(ctx->counters, 0, sizeof(ctx->counters));
     StageTimer t_total(ctx, LRGE_T_TOTAL);
     Scratch sc(ctx);
     Preset P = make_preset(preset);
@@ -631,7 +632,8 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         {
             StageTimer t(ctx, LRGE_T_EXPAND);
             u32 *aoff = bsc.get<u32>(me - mb + 1);
-            akey = bsc.get<u64>(A); aval = bsc.get<u64>(A); akey2 = bsc.get<u64>(A); aval2 = bsc.get<u64>(A);
+            // (+8: k_chain_lpg streams anchors in 16-byte pairs and may read one element past the last group)
+            akey = bsc.get<u64>(A + 8); aval = bsc.get<u64>(A + 8); akey2 = bsc.get<u64>(A + 8); aval2 = bsc.get<u64>(A + 8);
             if (!aoff || !akey || !aval || !akey2 || !aval2) return LRGE_ERR_DEVICE;
             rc = scan_exclusive_u32(ctx, bsc, hv + mb, aoff, me - mb, nullptr);
             if (rc) return rc;
@@ -715,7 +717,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         u32 G = 0; u32 *gstart, *gflags, *bin_count = nullptr, *bin_list = nullptr, *hw_list = nullptr;
         u32 h_bins[N_BINS] = {0, 0, 0, 0, 0};
         unsigned long long h_bin_anchors[N_BINS] = {0, 0, 0, 0, 0};
-        u32 n_chained = 0; unsigned long long a_chained = 0;
+        u32 n_chained = 0; unsigned long long a_chained = 0, a_big = 0;
         {
             StageTimer t(ctx, LRGE_T_GROUP);
             u32 *head = bsc.get<u32>(A), *gid = bsc.get<u32>(A), *d_G = bsc.get<u32>(1);
@@ -735,15 +737,16 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             if (chain_mode == 0) {
                 // groups worth chaining, sorted by size (largest first) so that k_chain_hw pairs equals
                 u32 *d_cnt = bsc.get<u32>(4);
-                unsigned long long *d_anch = (unsigned long long *)bsc.get<u64>(1);
+                unsigned long long *d_anch = (unsigned long long *)bsc.get<u64>(2);
                 if (!d_cnt || !d_anch) return LRGE_ERR_DEVICE;
                 HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));
-                HIPCHK(ctx, hipMemsetAsync(d_anch, 0, 8, ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(d_anch, 0, 16, ctx->stream));
                 hipLaunchKernelGGL(k_group_count, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, lpg_max, d_cnt, d_anch);
                 KCHK(ctx);
                 HIPCHK(ctx, hipMemcpyAsync(&n_chained, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipMemcpyAsync(&n_big, d_cnt + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipMemcpyAsync(&a_chained, d_anch, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(&a_big, d_anch + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
                 if (n_chained) {
                     u64 *k0 = bsc.get<u64>(n_chained), *v0 = bsc.get<u64>(n_chained), *k1 = bsc.get<u64>(n_chained), *v1 = bsc.get<u64>(n_chained);
@@ -796,11 +799,16 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                         LpgChainArgs la;
                         la.akey = skey; la.aval = sval; la.gstart = gstart; la.n_groups = G; la.n_anchors = A;
                         la.list = hw_list + n_big; la.n_list = n_chained - n_big; la.grec = ha.grec; la.tmark = ha.tmark;
+                        StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
                         const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !getenv("LRGE_HIP_LPG_NOTAB");
-                        if (pentab) hipLaunchKernelGGL(k_chain_lpg<true>, dim3((la.n_list + 63) / 64), dim3(64), ((size_t)cp.bw + 2) * 4, both ? ctx->stream2 : ctx->stream, la, cp, go);
-                        else hipLaunchKernelGGL(k_chain_lpg<false>, dim3((la.n_list + 63) / 64), dim3(64), 0, both ? ctx->stream2 : ctx->stream, la, cp, go);
+                        if (pentab) hipLaunchKernelGGL(k_chain_lpg<true>, dim3((la.n_list + 63) / 64), dim3(64), (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES,
+                                                       both ? ctx->stream2 : ctx->stream, la, cp, go);
+                        else hipLaunchKernelGGL(k_chain_lpg<false>, dim3((la.n_list + 63) / 64), dim3(64), LPG_RING_BYTES, both ? ctx->stream2 : ctx->stream, la, cp, go);
                         KCHK(ctx);
+                        tl.stop();
                         ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+                        ctx->counters[LRGE_C_LPG_LAUNCHES] += 1;
+                        ctx->counters[LRGE_C_LPG_ANCHORS] += a_chained - a_big;
                     }
                     if (n_big) {
                         hipLaunchKernelGGL(k_chain_hw, dim3((n_big + 1) / 2), dim3(64), 0, ctx->stream, ha, cp, go);

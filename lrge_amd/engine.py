@@ -138,6 +138,7 @@ class Index:
         ctx._check(ctx._lib.lrge_hip_index_build(ctx.h, targets.h, preset, C.byref(h)))
         self.h = h
         self.build_timings = ctx.timings()
+        self.build_counters = ctx.counters()
 
     def free(self):
         if getattr(self, "h", None):

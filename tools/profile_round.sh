@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python $root/bench.py --no-cpu-baseline"
 timeout 600 python $root/bench.py --steps 5 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o s -- $B --steps 5 --warmup 1 > "$out/${tag}_stats.json" 2> "$out/${tag}_stats.err"
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU \
     --kernel-trace --output-format csv -d "$out/${tag}_sq" -o q -- $B --steps 1 --warmup 0 > /dev/null 2> "$out/${tag}_sq.err"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/${tag}_fetch" -o f -- $B --steps 1 --warmup 0 > /dev/null 2> "$out/${tag}_fetch.err"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/${tag}_write" -o w -- $B --steps 1 --warmup 0 > /dev/null 2> "$out/${tag}_write.err"

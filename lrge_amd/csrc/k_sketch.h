@@ -238,11 +238,34 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restri
     i32 s = (i32)(c - cm.chunk_start[r]) * SK_CHUNK;
     i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
     u32 o = offs[c];
+    // A lane's minimizers are consecutive in the output, but it produces one every ~3 steps: written one by
+    // one, every 32-byte sector reaches HBM as four partial writes (measured 4x the bytes).  The last <= 4 are
+    // kept in registers and leave as one sector-aligned 32-byte run per array whenever the output index
+    // reaches a multiple of 4; only the head and the tail of the lane's range are written singly.
+    u64 bx0 = 0, bx1 = 0, bx2 = 0, bx3 = 0, by0 = 0, by1 = 0, by2 = 0, by3 = 0;
+    u32 nb = 0;   // buffered entries: output indices [o - nb, o), newest in b?3
+    auto flush_tail = [&]() {
+        if (nb >= 3) { out_x[o - 3] = bx1; out_y[o - 3] = by1; }
+        if (nb >= 2) { out_x[o - 2] = bx2; out_y[o - 2] = by2; }
+        if (nb >= 1) { out_x[o - 1] = bx3; out_y[o - 1] = by3; }
+        nb = 0;
+    };
     sketch_chunk<K, W, HPC>(pack, nmask, woff[r], len, r, s, e, [&](u64 x, u64 y) {
-        out_x[o] = INDEX_KEYS ? (x >> 8) : x;  // the index keeps only the hash, queries keep hash<<8|span
-        out_y[o] = y;
-        ++o;
+        bx0 = bx1; bx1 = bx2; bx2 = bx3; bx3 = INDEX_KEYS ? (x >> 8) : x;  // the index keeps only the hash, queries keep hash<<8|span
+        by0 = by1; by1 = by2; by2 = by3; by3 = y;
+        ++o; ++nb;
+        if ((o & 3u) == 0) {
+            if (nb == 4) {
+                ulonglong2 a, b;
+                a.x = bx0; a.y = bx1; b.x = bx2; b.y = bx3;
+                *(ulonglong2 *)(out_x + o - 4) = a; *(ulonglong2 *)(out_x + o - 2) = b;
+                a.x = by0; a.y = by1; b.x = by2; b.y = by3;
+                *(ulonglong2 *)(out_y + o - 4) = a; *(ulonglong2 *)(out_y + o - 2) = b;
+                nb = 0;
+            } else flush_tail();
+        }
     });
+    flush_tail();
 }
 
 // per-read minimizer offsets from per-chunk offsets: mz_off[r] = offs[chunk_start[r]]

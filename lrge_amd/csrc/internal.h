@@ -112,7 +112,7 @@ struct lrge_hip_seqset {
     // host copies needed for planning
     std::vector<u64> h_woff;
     std::vector<u32> h_len;
-    std::vector<u32> h_rank;
+    std::vector<u32> h_rank, h_rank_sorted;
 };
 
 struct lrge_hip_index {

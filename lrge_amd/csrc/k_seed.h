@@ -176,6 +176,29 @@ __global__ void k_qocc_keys(const u64 *__restrict__ qx, const u64 *__restrict__ 
     v_idx[o] = (qy[i] >> 32) << 32 | (u32)i;  // value carries (query, original index); needs n < 2^32
 }
 
+// Conservative pre-check for K4a: the filter can only remove a value that occurs more than mid_occ times
+// inside one query.  One block per query counts its indexed minimizers into 8192 hashed LDS buckets; a
+// bucket count is an upper bound of the multiplicity of every value that falls into it, so when no bucket
+// of any query exceeds mid_occ the filter removes nothing and the exact (sort-based) pass is skipped.
+#define QOCC_BUCKETS 8192
+__global__ __launch_bounds__(256) void k_qocc_check(const u64 *__restrict__ qx, const u32 *__restrict__ hc,
+                                                    const u32 *__restrict__ qmz_off, u32 nq, int mid_occ, u32 *__restrict__ flag) {
+    __shared__ u32 cnt[QOCC_BUCKETS];
+    const u32 q = blockIdx.x;
+    if (q >= nq) return;
+    const u32 b = qmz_off[q], e = qmz_off[q + 1];
+    if ((i64)(e - b) <= (i64)mid_occ) return;                              // mv->n <= q_occ_max: filter off
+    for (u32 i = threadIdx.x; i < QOCC_BUCKETS; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    bool hit = false;
+    for (u32 i = b + threadIdx.x; i < e; i += blockDim.x) {
+        if (hc[i] == 0) continue;
+        const u32 h = (u32)(((qx[i] >> 8) * 0x9E3779B97F4A7C15ULL) >> 51);  // 13 bits
+        if ((i64)atomicAdd(&cnt[h], 1u) + 1 > (i64)mid_occ) hit = true;
+    }
+    if (hit) atomicOr(flag, 1u);
+}
+
 // One lane per element; run heads do the work (runs are short except for the pathological ones this
 // filter exists for).
 __global__ void k_qocc_mark(const u64 *__restrict__ sx, const u64 *__restrict__ sv, u64 n,

@@ -107,7 +107,8 @@ extern "C" int lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, cons
     if (name_rank) {
         s->has_rank = true;
         s->h_rank.assign(name_rank, name_rank + n);
-        std::vector<u32> tmp(s->h_rank);
+        s->h_rank_sorted = s->h_rank;
+        std::vector<u32> &tmp = s->h_rank_sorted;
         std::sort(tmp.begin(), tmp.end());
         for (u32 i = 1; i < n; ++i) if (tmp[i] == tmp[i - 1]) { s->dup_rank = true; break; }
     }
@@ -506,6 +507,17 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     sp.t_len = T->d_len; sp.t_rank = T->d_rank; sp.q_len = Q->d_len; sp.q_rank = Q->d_rank;
     sp.mid_occ = ix->mid_occ;
     sp.check_names = (Q->has_rank && T->has_rank) ? 1 : 0;   // qname == NULL in minimap2 skips skip_seed entirely
+    if (sp.check_names && job.dual) {
+        // with --dual=yes skip_seed only ever fires for a query that IS one of the indexed reads (same name, same
+        // length, same position).  Ranks are positions in the sorted union of names, so if no rank occurs in both
+        // sets (the two-set strategies) no hit can be skipped and the per-hit name checks are dropped altogether.
+        bool shared = false;
+        const std::vector<u32> &a = Q->h_rank_sorted, &b = T->h_rank_sorted;
+        for (size_t i = 0, j = 0; i < a.size() && j < b.size() && !shared;) {
+            if (a[i] == b[j]) shared = true; else if (a[i] < b[j]) ++i; else ++j;
+        }
+        if (!shared) sp.check_names = 0;
+    }
     sp.no_dual = job.dual ? 0 : 1;
     ALLOC_OR_FAIL(hs, sc, u32, Mq + 1); ALLOC_OR_FAIL(hc, sc, u32, Mq + 1);
     ALLOC_OR_FAIL(hn, sc, u32, Mq + 1); ALLOC_OR_FAIL(hv, sc, u32, Mq + 1); ALLOC_OR_FAIL(krank, sc, u32, Mq + 1);
@@ -527,6 +539,17 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         StageTimer t(ctx, LRGE_T_QFILTER);
         bool any = false;   // only queries with more minimizers than mid_occ can be affected
         for (u32 q = 0; q < nq && !any; ++q) any = (i64)(h_mzoff[q + 1] - h_mzoff[q]) > (i64)ix->mid_occ;
+        if (any && !getenv("LRGE_HIP_QOCC_EXACT")) {   // cheap conservative check first (k_qocc_check); the env knob forces the exact pass (tests)
+            ALLOC_OR_FAIL(d_qf, sc, u32, 1);
+            HIPCHK(ctx, hipMemsetAsync(d_qf, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_qocc_check, dim3(nq), dim3(256), 0, ctx->stream, so.x, hc, so.mz_off, nq, ix->mid_occ, d_qf);
+            KCHK(ctx);
+            u32 qf = 0;
+            HIPCHK(ctx, hipMemcpyAsync(&qf, d_qf, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            sc.drop(d_qf);
+            any = qf != 0;
+        }
         if (any) {
             ALLOC_OR_FAIL(flag, sc, u32, Mq); ALLOC_OR_FAIL(fpos, sc, u32, Mq); ALLOC_OR_FAIL(d_ns, sc, u32, 1);
             hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hc, Mq, flag);

@@ -238,6 +238,19 @@ def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, monkeypatch, kerne
     assert np.array_equal(counts, ecounts) and np.array_equal(has, ehas)
 
 
+def test_qocc_precheck_is_invisible(ctx, oracle, tiny_ont, monkeypatch):
+    """The conservative bucket pre-check (k_qocc_check) only decides whether the exact sort-based filter runs;
+    forcing the exact pass must not change anything."""
+    ds = tiny_ont
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, ds.q.seqs(), ds.q.names, ds.t.seqs(), ds.t.names, "ont")
+    ref, has = ixd.overlap_twoset(Qd)
+    monkeypatch.setenv("LRGE_HIP_QOCC_EXACT", "1")
+    exact, has2 = ixd.overlap_twoset(Qd)
+    assert np.array_equal(ref, exact) and np.array_equal(has, has2)
+    rc, ecounts, ehas = ixo.twoset_counts(Qo, threads=8)
+    assert np.array_equal(ref, ecounts) and np.array_equal(has, ehas)
+
+
 def test_query_occurrence_filter(ctx, oracle):
     """mm_seed_mz_flt in isolation: the query repeats a 60-mer 30 times; the targets cover that 60-mer
     only ~3x, so the index keeps it (count <= mid_occ) and only the QUERY-side filter (cnt > mid_occ and

@@ -195,11 +195,19 @@ static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32
 // each be sorted in place; every tile lies inside one segment and the histogram is laid out
 // [segment][digit][tile of the segment], so that ONE exclusive scan over it yields, per (tile, digit), the
 // global destination of that digit's run -- segments never mix and the segment id costs no sort pass.
-struct SegTile { u32 start, len, hbase, hstride; };   // hist index of digit d: hbase + d * hstride
+struct SegTile { u32 start, len, hbase, hstride, seg, pad; };   // hist index of digit d: hbase + d * hstride; seg = segment id
+
+// Packed anchors (count-only runs): one u64 = [self 1 | span 8 | qpos bits_qy | sort bits sb], sorted KEYS-ONLY on the
+// low sb bits; the last scatter pass unpacks every record into the (key, value) pair the chain kernels read
+// (key = segment << sh_q | sort bits, value = self << 43 | span << 32 | qpos) -- see k_seed.h for the layouts.
+struct UnpackParams { u32 sb, bits_qy, sh_q, dmask; };   // dmask: digit mask of the pass (the last digit may be narrower than 8 bits)
+#define RS_MODE_PAIRS 0
+#define RS_MODE_KEYS 1
+#define RS_MODE_UNPACK 2
 
 template <bool SEG>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
-                                                        u32 *__restrict__ hist, const SegTile *__restrict__ tiles) {
+                                                        u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255) {
     __shared__ u32 h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -209,18 +217,18 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
 #pragma unroll 4
     for (int r = 0; r < RS_ITEMS; ++r) {
         const u32 l = l0 + (u32)r * 64;
-        if (l < n_tile) atomicAdd(&h[(keys[tile0 + l] >> shift) & 255], 1u);
+        if (l < n_tile) atomicAdd(&h[(keys[tile0 + l] >> shift) & dmask], 1u);
     }
     __syncthreads();
     const u64 hi = SEG ? (u64)tiles[blockIdx.x].hbase + (u64)threadIdx.x * tiles[blockIdx.x].hstride : (u64)threadIdx.x * nb + blockIdx.x;
     hist[hi] = h[threadIdx.x];
 }
 
-template <bool SEG>
+template <bool SEG, int MODE>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict__ keys_in, const u64 *__restrict__ vals_in,
                                                            u64 *__restrict__ keys_out, u64 *__restrict__ vals_out, u64 n,
                                                            int shift, u32 nb, const u32 *__restrict__ hist_scanned,
-                                                           const SegTile *__restrict__ tiles) {
+                                                           const SegTile *__restrict__ tiles, UnpackParams up) {
     // 1. per-wave stable ranks (ballot digit matching + per-wave LDS counters)
     // 2. block-local destinations: the tile is first reordered through LDS so that each digit's
     //    items are contiguous, then written out as coalesced runs (one run per digit per tile)
@@ -229,6 +237,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     __shared__ u32 wtot[RS_WAVES];
     __shared__ u64 stage[RS_TILE];       // 32 KB: keys, then values
     const u32 w = threadIdx.x >> 6, lane = lane_id();
+    const u32 dmask = MODE == RS_MODE_PAIRS ? 255u : up.dmask;
     for (u32 i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const u64 tile0 = SEG ? (u64)tiles[blockIdx.x].start : (u64)blockIdx.x * RS_TILE;
@@ -241,12 +250,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     // all loads of the tile are issued up front: the values arrive while the keys are being ranked
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n_tile ? keys_in[base + (u64)r * 64] : ~0ULL;
+    if (MODE == RS_MODE_PAIRS) {
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) v[r] = l0 + (u32)r * 64 < n_tile ? vals_in[base + (u64)r * 64] : 0;
+        for (int r = 0; r < RS_ITEMS; ++r) v[r] = l0 + (u32)r * 64 < n_tile ? vals_in[base + (u64)r * 64] : 0;
+    }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         bool valid = l0 + (u32)r * 64 < n_tile;
-        u32 d = (u32)(k[r] >> shift) & 255;
+        u32 d = (u32)(k[r] >> shift) & dmask;
         u64 m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -281,17 +292,33 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     u32 lpos[RS_ITEMS];
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
-        u32 d = (u32)(k[r] >> shift) & 255;
+        u32 d = (u32)(k[r] >> shift) & dmask;
         lpos[r] = cnt[w][d] + rank[r];
         if (l0 + (u32)r * 64 < n_tile) stage[lpos[r]] = k[r];
     }
     __syncthreads();
     u64 ko[RS_ITEMS];
+    if (MODE == RS_MODE_UNPACK) {
+        const u64 seg = SEG ? (u64)tiles[blockIdx.x].seg << up.sh_q : 0;
+        const u64 smask = (1ULL << up.sb) - 1, qmask = (1ULL << up.bits_qy) - 1;
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {
+            u32 p = (u32)r * RS_THREADS + threadIdx.x;
+            if (p < n_tile) {
+                const u64 pk = stage[p];
+                const u64 o = (u64)gbase[(u32)(pk >> shift) & dmask] + p;
+                keys_out[o] = seg | (pk & smask);
+                vals_out[o] = ((pk >> (up.sb + up.bits_qy + 8)) & 1) << 43 | ((pk >> (up.sb + up.bits_qy)) & 0xff) << 32 | ((pk >> up.sb) & qmask);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         u32 p = (u32)r * RS_THREADS + threadIdx.x;
-        if (p < n_tile) { ko[r] = stage[p]; keys_out[gbase[(u32)(ko[r] >> shift) & 255] + p] = ko[r]; }
+        if (p < n_tile) { ko[r] = stage[p]; keys_out[gbase[(u32)(ko[r] >> shift) & dmask] + p] = ko[r]; }
     }
+    if (MODE == RS_MODE_KEYS) return;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
@@ -301,7 +328,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         u32 p = (u32)r * RS_THREADS + threadIdx.x;
-        if (p < n_tile) vals_out[gbase[(u32)(ko[r] >> shift) & 255] + p] = stage[p];
+        if (p < n_tile) vals_out[gbase[(u32)(ko[r] >> shift) & dmask] + p] = stage[p];
     }
 }
 
@@ -329,8 +356,8 @@ static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u6
         if (rc) return rc;
         {
             StageTimer ts(ctx, LRGE_T_RS_SCATTER);
-            if (d_tiles) hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist, d_tiles);
-            else hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist, d_tiles);
+            if (d_tiles) hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_PAIRS>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist, d_tiles, UnpackParams{0, 0, 0, 255});
+            else hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_PAIRS>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shift, nb, hist, d_tiles, UnpackParams{0, 0, 0, 255});
             KCHK(ctx);
             ts.stop();
             ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
@@ -341,5 +368,39 @@ static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u6
     }
     sc.drop(hist);
     *res_k = ki; *res_v = vi;
+    return LRGE_OK;
+}
+
+// Segmented keys-only sort of packed anchors on their low `nbits` bits (pk0/pk1 ping-pong); the last pass unpacks
+// into (out_k, out_v).  See UnpackParams.
+static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *pk1, u64 *out_k, u64 *out_v, u64 n, int nbits,
+                                 const SegTile *d_tiles, u32 n_tiles, UnpackParams up) {
+    if (n == 0 || n_tiles == 0) return LRGE_OK;
+    if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
+    const u32 nb = n_tiles;
+    ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * nb);
+    const int passes = nbits > 0 ? (nbits + 7) / 8 : 1;
+    u64 *ki = pk0, *ko = pk1;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * 8;
+        up.dmask = nbits - shift >= 8 ? 255u : (1u << (nbits - shift)) - 1u;   // bits above nbits are payload, not key
+        hipLaunchKernelGGL(k_rs_hist<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, d_tiles, up.dmask);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
+        if (rc) return rc;
+        {
+            StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+            if (p + 1 < passes)
+                hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, ko, (u64 *)nullptr, n, shift, nb, hist, d_tiles, up);
+            else
+                hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_UNPACK>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, out_k, out_v, n, shift, nb, hist, d_tiles, up);
+            KCHK(ctx);
+            ts.stop();
+            ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
+            ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;   // (bench prices an item at 32 B; these move 16 / 24 B)
+        }
+        u64 *t = ki; ki = ko; ko = t;
+    }
+    sc.drop(hist);
     return LRGE_OK;
 }

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
                                                 u64 mz_end, SeedParams sp, const u32 *__restrict__ hs,
                                                 const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
                                                 const u32 *__restrict__ krank, const u32 *__restrict__ qmz_off, u32 q0,
-                                                KeyLayout kl, u64 *__restrict__ akey, u64 *__restrict__ aval) {
+                                                KeyLayout kl, u64 *__restrict__ akey, u64 *__restrict__ aval, u32 packed_bits_qy) {
+    // packed_bits_qy != 0: count-only run, one packed u64 per anchor (UnpackParams in k_prims.h), aval unused
     const u32 lane = lane_id();
     const u64 w0 = mz_begin + ((u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
     if (w0 >= mz_end) return;
@@ -150,7 +151,11 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
         const u64 km = __ballot(keep);
         if (keep) {
             const u32 d = o + (u32)__popcll(km & lanemask_lt());
-            akey[d] = key; aval[d] = val;
+            if (packed_bits_qy) {
+                const u32 sb = kl.sh_q();
+                akey[d] = (key & ((1ULL << sb) - 1)) | (val & 0xFFFFFFFFULL) << sb | ((val >> 32) & 0xff) << (sb + packed_bits_qy) |
+                          ((val >> 43) & 1) << (sb + packed_bits_qy + 8);
+            } else { akey[d] = key; aval[d] = val; }
         }
         o += (u32)__popcll(km);
     }

@@ -652,6 +652,10 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         ctx->counters[LRGE_C_ANCHORS] += A;
         Scratch bsc(ctx);
         u64 *akey, *aval, *akey2, *aval2, *skey, *sval;
+        // count-only runs carry one packed u64 per anchor through the expansion and the sort (k_prims.h UnpackParams);
+        // chain records (PAF) need the seed rank as well and keep the (key, value) pairs
+        const u32 bits_qy = std::max<u32>(1, ceil_log2_u64((u64)Q->max_len + 1));
+        const bool packed = !d_chains && !job.dump_anchors && kl.sh_q() + bits_qy + 9 <= 64 && !env_u64("LRGE_HIP_NO_PACKED", 0);
         {
             StageTimer t(ctx, LRGE_T_EXPAND);
             u32 *aoff = bsc.get<u32>(me - mb + 1);
@@ -661,7 +665,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             rc = scan_exclusive_u32(ctx, bsc, hv + mb, aoff, me - mb, nullptr);
             if (rc) return rc;
             hipLaunchKernelGGL(k_expand, dim3((u32)div_up(me - mb, 256)), dim3(256), 0, ctx->stream, so.x, so.y, mb, me, sp, hs, hn, aoff,
-                               krank, so.mz_off, q0, kl, akey, aval);
+                               krank, so.mz_off, q0, kl, akey, aval, packed ? bits_qy : 0u);
             KCHK(ctx);
             // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
             bsc.drop(aoff);
@@ -678,23 +682,32 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                     const u32 c = h_qtot[q], nt_q = (u32)div_up((u64)c, RS_TILE);
                     for (u32 lt = 0; lt < nt_q; ++lt) {
                         SegTile t; t.start = off + lt * RS_TILE; t.len = std::min<u32>(RS_TILE, c - lt * RS_TILE);
-                        t.hbase = 256u * tb + lt; t.hstride = nt_q;
+                        t.hbase = 256u * tb + lt; t.hstride = nt_q; t.seg = q - q0; t.pad = 0;
                         h_tiles.push_back(t);
                     }
                     off += c; tb += nt_q;
                 }
             }
-            SegTile *d_tiles = (SegTile *)bsc.get<u32>(h_tiles.size() * 4 + 4);
+            SegTile *d_tiles = (SegTile *)bsc.get<u32>(h_tiles.size() * (sizeof(SegTile) / 4) + 4);
             if (!d_tiles) return LRGE_ERR_DEVICE;
             HIPCHK(ctx, hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // h_tiles is pageable and goes out of scope
-            rc = radix_sort_pairs(ctx, bsc, akey, aval, akey2, aval2, A, 0, (int)(kl.bits_rpos + 1 + kl.bits_rid), &skey, &sval, false,
-                                  d_tiles, (u32)h_tiles.size());
-            if (rc) return rc;
-            bsc.drop((u32 *)d_tiles);
-            // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
-            bsc.drop(skey == akey ? akey2 : akey);
-            bsc.drop(sval == aval ? aval2 : aval);
+            if (packed) {
+                UnpackParams up; up.sb = kl.sh_q(); up.bits_qy = bits_qy; up.sh_q = kl.sh_q(); up.dmask = 255;
+                rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up);
+                if (rc) return rc;
+                skey = aval; sval = aval2;
+                bsc.drop((u32 *)d_tiles);
+                bsc.drop(akey); bsc.drop(akey2);
+            } else {
+                rc = radix_sort_pairs(ctx, bsc, akey, aval, akey2, aval2, A, 0, (int)(kl.bits_rpos + 1 + kl.bits_rid), &skey, &sval, false,
+                                      d_tiles, (u32)h_tiles.size());
+                if (rc) return rc;
+                bsc.drop((u32 *)d_tiles);
+                // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
+                bsc.drop(skey == akey ? akey2 : akey);
+                bsc.drop(sval == aval ? aval2 : aval);
+            }
             t.stop();
         }
         if (job.dump_anchors) {

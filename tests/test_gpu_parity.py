@@ -238,6 +238,24 @@ def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, monkeypatch, kerne
     assert np.array_equal(counts, ecounts) and np.array_equal(has, ehas)
 
 
+@pytest.mark.parametrize("mode", ["twoset", "ava"])
+def test_packed_anchor_path_is_invisible(ctx, oracle, tiny_ont, monkeypatch, mode):
+    """Count-only runs sort packed 8-byte anchors (keys only) and unpack in the last radix pass; the
+    (key, value) pair path (LRGE_HIP_NO_PACKED=1, also what chain records use) must give the same counts."""
+    ds = tiny_ont
+    if mode == "twoset":
+        Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, ds.q.seqs(), ds.q.names, ds.t.seqs(), ds.t.names, "ont")
+        run = lambda: ixd.overlap_twoset(Qd)[0]
+    else:
+        Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, ds.t.seqs(), ds.t.names, ds.t.seqs(), ds.t.names, "ont", False)
+        run = lambda: ixd.overlap_ava()
+    a = run()
+    monkeypatch.setenv("LRGE_HIP_NO_PACKED", "1")
+    b = run()
+    assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert int(np.asarray(a).sum()) > 0
+
+
 def test_qocc_precheck_is_invisible(ctx, oracle, tiny_ont, monkeypatch):
     """The conservative bucket pre-check (k_qocc_check) only decides whether the exact sort-based filter runs;
     forcing the exact pass must not change anything."""

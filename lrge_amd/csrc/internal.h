@@ -125,6 +125,7 @@ struct lrge_hip_index {
     u64 *d_pos = nullptr;       // [n_mz] y values grouped by key, ascending within a key
     u64 *d_skey = nullptr;      // [n_mz] sorted keys (kept for index_dump / tests)
     u64 *d_ht = nullptr;        // ordered open-addressing table of {key, start<<24 | min(count, 2^24-1)} pairs (k_index.h)
+    u32 pk_pos1 = 0, pk_ybits = 0;   // packed entries (d_skey == d_pos): hash << pk_ybits | rid << pk_pos1 | (pos << 1 | strand)
     u64 ht_cap = 0;             // home slots are [0, ht_cap); slack slots follow
 };
 

@@ -20,10 +20,11 @@
 
 __device__ __forceinline__ u64 ht_home(u64 key, u64 cap) { return __umul64hi(__builtin_bswap64(key), cap); }
 
-__global__ void k_run_heads(const u64 *__restrict__ skey, u64 n, u32 *__restrict__ head) {
+// kshift: the stream holds packed entries, key = entry >> kshift (0 for plain keys)
+__global__ void k_run_heads(const u64 *__restrict__ skey, u64 n, u32 *__restrict__ head, u32 kshift) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    head[i] = (i == 0 || skey[i] != skey[i - 1]) ? 1u : 0u;
+    head[i] = (i == 0 || (skey[i] >> kshift) != (skey[i - 1] >> kshift)) ? 1u : 0u;
 }
 
 // run_start[run_id] = i for every head (run_id from the exclusive scan of head flags)
@@ -40,19 +41,19 @@ __global__ void k_run_starts(const u32 *__restrict__ head, const u32 *__restrict
 #define PLACE_TILE (PLACE_THREADS * PLACE_ROWS)
 
 // d(r) = home(r) + (n_runs - r): slot(r) = prefix-max(d)(r) - (n_runs - r).  Needs cap + n_runs < 2^32.
-__device__ __forceinline__ u32 place_d(const u64 *__restrict__ skey, const u32 *__restrict__ run_start, u32 r, u32 n_runs, u64 cap) {
-    return (u32)ht_home(skey[run_start[r]], cap) + (n_runs - r);
+__device__ __forceinline__ u32 place_d(const u64 *__restrict__ skey, const u32 *__restrict__ run_start, u32 r, u32 n_runs, u64 cap, u32 kshift) {
+    return (u32)ht_home(skey[run_start[r]] >> kshift, cap) + (n_runs - r);
 }
 
 __global__ __launch_bounds__(PLACE_THREADS) void k_place_reduce(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
-                                                                u32 n_runs, u64 cap, u32 *__restrict__ bmax) {
+                                                                u32 n_runs, u64 cap, u32 *__restrict__ bmax, u32 kshift) {
     __shared__ u32 wm[PLACE_THREADS / 64];
     u32 m = 0;
     const u32 base = blockIdx.x * PLACE_TILE;
 #pragma unroll
     for (int i = 0; i < PLACE_ROWS; ++i) {
         const u32 r = base + i * PLACE_THREADS + threadIdx.x;
-        if (r < n_runs) { const u32 d = place_d(skey, run_start, r, n_runs, cap); m = d > m ? d : m; }
+        if (r < n_runs) { const u32 d = place_d(skey, run_start, r, n_runs, cap, kshift); m = d > m ? d : m; }
     }
     for (int d = 32; d > 0; d >>= 1) { const u32 o = (u32)__shfl_xor((i32)m, d, 64); m = o > m ? o : m; }
     if (lane_id() == 0) wm[threadIdx.x >> 6] = m;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(1024) void k_place_scan(u32 *data, u32 n) {
 __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
                                                                u32 n_runs, u64 n, u64 cap, u64 n_slots, const u32 *__restrict__ bpre,
                                                                u64 *__restrict__ ht, u32 *__restrict__ occ_hist, u32 max_bin,
-                                                               u32 *__restrict__ overflow) {
+                                                               u32 *__restrict__ overflow, u32 kshift) {
     __shared__ u32 lh[OCC_LDS_BINS];
     __shared__ u32 wm[PLACE_THREADS / 64];
     __shared__ u32 carry_s;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
             st = run_start[r];
             const u64 en = (r + 1 < n_runs) ? run_start[r + 1] : n;
             cnt = (u32)(en - st);
-            key = skey[st];
+            key = skey[st] >> kshift;
             d = (u32)ht_home(key, cap) + (n_runs - r);
         }
         u32 inc = d;

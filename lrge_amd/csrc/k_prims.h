@@ -404,3 +404,37 @@ static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *
     sc.drop(hist);
     return LRGE_OK;
 }
+
+// Stable keys-only LSD sort on bits [begin_bit, begin_bit + nbits) (k0 / k1 ping-pong, *res = buffer holding the result).
+static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64 n, int begin_bit, int nbits, u64 **res,
+                           bool reverse_digits) {
+    *res = k0;
+    if (n <= 1 || nbits <= 0) return LRGE_OK;
+    if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
+    const u32 nb = (u32)div_up(n, RS_TILE);
+    ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * nb);
+    const int passes = (nbits + 7) / 8;
+    u64 *ki = k0, *ko = k1;
+    for (int p = 0; p < passes; ++p) {
+        const int d = reverse_digits ? passes - 1 - p : p;
+        const int shift = begin_bit + d * 8;
+        UnpackParams up{0, 0, 0, nbits - d * 8 >= 8 ? 255u : (1u << (nbits - d * 8)) - 1u};
+        hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, (const SegTile *)nullptr, up.dmask);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
+        if (rc) return rc;
+        {
+            StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+            hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_KEYS>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, ko, (u64 *)nullptr, n, shift, nb,
+                               hist, (const SegTile *)nullptr, up);
+            KCHK(ctx);
+            ts.stop();
+            ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
+            ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;
+        }
+        u64 *t = ki; ki = ko; ko = t;
+    }
+    sc.drop(hist);
+    *res = ki;
+    return LRGE_OK;
+}

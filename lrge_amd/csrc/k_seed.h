@@ -15,13 +15,22 @@ struct KeyLayout {      // composite anchor sort key: qlocal | rid | rev | rpos
 
 struct SeedParams {
     const u64 *ht; u64 ht_cap;
-    const u64 *pos;            // index position lists
+    const u64 *pos;            // index position lists (plain y values, or packed entries when pk_ybits != 0)
+    u32 pk_pos1, pk_ybits;     // packed index entry: hash << pk_ybits | rid << pk_pos1 | (pos << 1 | strand)
     const u32 *t_len, *t_rank; // indexed reads
     const u32 *q_len, *q_rank; // query reads
     int mid_occ;
     int check_names;           // both sets carry ranks
     int no_dual;               // MM_F_NO_DUAL (AVA)
 };
+
+// y value (rid << 32 | pos << 1 | strand) of index entry i
+__device__ __forceinline__ u64 index_y(const SeedParams &sp, u64 i) {
+    const u64 r = sp.pos[i];
+    if (sp.pk_ybits == 0) return r;
+    const u64 yb = r & ((1ULL << sp.pk_ybits) - 1);
+    return (yb >> sp.pk_pos1) << 32 | (yb & ((1ULL << sp.pk_pos1) - 1));
+}
 
 // K3: one lane per query minimizer: probe the index.  hs = list start, hc = raw list length (0 when
 // the hash is absent).  The mid_occ filter and skip_seed are applied by k_seed_counts, after the query
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(256) void k_seed_counts(const u64 *__restrict__ qy,
         const u32 qr = sp.q_rank[q], ql = sp.q_len[q];
         v = 0;
         for (u32 j = 0; j < n; ++j) {
-            const u64 r = sp.pos[st + j];
+            const u64 r = index_y(sp, st + j);
             const u32 rid = (u32)(r >> 32);
             const u32 tr = sp.t_rank[rid];
             bool skip = false;
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
         bool keep = r < total;
         u64 key = 0, val = 0;
         if (keep) {
-            const u64 h = sp.pos[(u64)st + j];
+            const u64 h = index_y(sp, (u64)st + j);
             const u32 rid = (u32)(h >> 32), rpos = (u32)h >> 1, qstrand = fl & 1, span = fl >> 8;
             u64 self = 0;
             if (sp.check_names) {

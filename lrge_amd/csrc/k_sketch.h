@@ -226,11 +226,13 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_count(const u64 *__restri
     counts[c] = n;
 }
 
-template <int K, int W, bool HPC, bool INDEX_KEYS>
+// PK (index only): one packed u64 per minimizer, hash << (pk_rid_bits + pk_pos1) | rid << pk_pos1 | (pos << 1 | strand),
+// written to out_x; out_y is not touched.  8 bytes per index entry instead of 16 through the sort and the lookups.
+template <int K, int W, bool HPC, bool INDEX_KEYS, bool PK>
 __global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
                                                             const u64 *__restrict__ woff, const u32 *__restrict__ lens,
                                                             ChunkMap cm, u32 n_chunks, const u32 *__restrict__ offs,
-                                                            u64 *__restrict__ out_x, u64 *__restrict__ out_y) {
+                                                            u64 *__restrict__ out_x, u64 *__restrict__ out_y, u32 pk_pos1, u32 pk_ybits) {
     u32 c = blockIdx.x * SK_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     u32 r = cm.find(c);
@@ -245,13 +247,15 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restri
     u64 bx0 = 0, bx1 = 0, bx2 = 0, bx3 = 0, by0 = 0, by1 = 0, by2 = 0, by3 = 0;
     u32 nb = 0;   // buffered entries: output indices [o - nb, o), newest in b?3
     auto flush_tail = [&]() {
-        if (nb >= 3) { out_x[o - 3] = bx1; out_y[o - 3] = by1; }
-        if (nb >= 2) { out_x[o - 2] = bx2; out_y[o - 2] = by2; }
-        if (nb >= 1) { out_x[o - 1] = bx3; out_y[o - 1] = by3; }
+        if (nb >= 3) { out_x[o - 3] = bx1; if (!PK) out_y[o - 3] = by1; }
+        if (nb >= 2) { out_x[o - 2] = bx2; if (!PK) out_y[o - 2] = by2; }
+        if (nb >= 1) { out_x[o - 1] = bx3; if (!PK) out_y[o - 1] = by3; }
         nb = 0;
     };
     sketch_chunk<K, W, HPC>(pack, nmask, woff[r], len, r, s, e, [&](u64 x, u64 y) {
-        bx0 = bx1; bx1 = bx2; bx2 = bx3; bx3 = INDEX_KEYS ? (x >> 8) : x;  // the index keeps only the hash, queries keep hash<<8|span
+        bx0 = bx1; bx1 = bx2; bx2 = bx3;
+        if (PK) bx3 = (x >> 8) << pk_ybits | (y >> 32) << pk_pos1 | (u64)(u32)y;
+        else bx3 = INDEX_KEYS ? (x >> 8) : x;  // the index keeps only the hash, queries keep hash<<8|span
         by0 = by1; by1 = by2; by2 = by3; by3 = y;
         ++o; ++nb;
         if ((o & 3u) == 0) {
@@ -259,8 +263,10 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restri
                 ulonglong2 a, b;
                 a.x = bx0; a.y = bx1; b.x = bx2; b.y = bx3;
                 *(ulonglong2 *)(out_x + o - 4) = a; *(ulonglong2 *)(out_x + o - 2) = b;
-                a.x = by0; a.y = by1; b.x = by2; b.y = by3;
-                *(ulonglong2 *)(out_y + o - 4) = a; *(ulonglong2 *)(out_y + o - 2) = b;
+                if (!PK) {
+                    a.x = by0; a.y = by1; b.x = by2; b.y = by3;
+                    *(ulonglong2 *)(out_y + o - 4) = a; *(ulonglong2 *)(out_y + o - 2) = b;
+                }
                 nb = 0;
             } else flush_tail();
         }

@@ -173,8 +173,9 @@ struct SketchOut {
     u64 n = 0;
 };
 
+// pk_ybits != 0 (index only): packed 8-byte entries in o->x, o->y stays null (k_sketch.h PK)
 template <int K, int W, bool HPC>
-static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o) {
+static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o, u32 pk_pos1, u32 pk_ybits) {
     std::vector<u32> cs((size_t)s->n + 1);
     u64 nc = 0;
     for (u32 i = 0; i < s->n; ++i) { cs[i] = (u32)nc; nc += (s->h_len[i] + SK_CHUNK - 1) / SK_CHUNK; }
@@ -201,14 +202,18 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
         HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, ctx->stream));
     }
     ALLOC_OR_FAIL(dx, sc, u64, (size_t)total + 1);
-    ALLOC_OR_FAIL(dy, sc, u64, (size_t)total + 1);
+    u64 *dy = nullptr;
+    if (!(index_keys && pk_ybits)) { dy = sc.get<u64>((size_t)total + 1); if (!dy) return LRGE_ERR_DEVICE; }
     if (n_chunks) {
-        if (index_keys)
-            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0,
-                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy);
+        if (index_keys && pk_ybits)
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, true>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0,
+                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, pk_pos1, pk_ybits);
+        else if (index_keys)
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, false>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0,
+                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, 0u, 0u);
         else
-            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0,
-                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy);
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false, false>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0,
+                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, 0u, 0u);
         KCHK(ctx);
     }
     hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, ctx->stream, d_cs, d_cnt, s->n,
@@ -220,10 +225,11 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     return LRGE_OK;
 }
 
-static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o) {
+static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o,
+                         u32 pk_pos1 = 0, u32 pk_ybits = 0) {
     StageTimer t(ctx, LRGE_T_SKETCH);
-    int rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o)
-                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o);
+    int rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits)
+                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits);
     t.stop();
     return rc;
 }
@@ -268,8 +274,15 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     // paths (no max_skip break -> candidates beyond the register window; tight max_iter clamp)
     P.max_skip = (int)env_u64("LRGE_HIP_DEBUG_MAX_SKIP", (u64)P.max_skip);
     P.max_iter = (int)env_u64("LRGE_HIP_DEBUG_MAX_ITER", (u64)P.max_iter);
+    // Index entries are packed into one u64 -- hash << ybits | rid << pos1 | (pos << 1 | strand) -- whenever that
+    // fits (2k + bits(rid) + bits(pos) + 1 <= 64: ava-ont always in practice, ava-pb for small read sets): half the
+    // bytes through the sort, the table build and the lookups, and 8 instead of 16 bytes per entry resident in HBM.
+    const u32 pk_pos1 = std::max<u32>(1, ceil_log2_u64((u64)targets->max_len + 1)) + 1;
+    const u32 pk_rid = std::max<u32>(1, ceil_log2_u64((u64)targets->n + 1));
+    const bool pk = 2 * (u32)P.k + pk_rid + pk_pos1 <= 64 && !env_u64("LRGE_HIP_NO_PACKED_INDEX", 0);
+    const u32 pk_ybits = pk ? pk_rid + pk_pos1 : 0;
     SketchOut so;
-    int rc = sketch_device(ctx, sc, targets, preset, true, &so);
+    int rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits);
     if (rc) return rc;
     sc.drop(so.mz_off);
     const u64 M = so.n;
@@ -279,14 +292,22 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     {
         StageTimer t(ctx, LRGE_T_INDEX_SORT);
         ALLOC_OR_FAIL(k1, sc, u64, M + 1);
-        ALLOC_OR_FAIL(v1, sc, u64, M + 1);
-        u64 *rk, *rv;
-        rc = radix_sort_pairs(ctx, sc, so.x, so.y, k1, v1, M, 0, 2 * P.k, &rk, &rv, /*reverse_digits=*/true);   // see k_index.h
-        if (rc) return rc;
-        // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
-        skey = rk; spos = rv;
-        sc.drop(rk == so.x ? k1 : so.x);
-        sc.drop(rv == so.y ? v1 : so.y);
+        if (pk) {
+            u64 *rk;
+            rc = radix_sort_keys(ctx, sc, so.x, k1, M, (int)pk_ybits, 2 * P.k, &rk, /*reverse_digits=*/true);   // see k_index.h
+            if (rc) return rc;
+            skey = rk; spos = rk;
+            sc.drop(rk == so.x ? k1 : so.x);
+        } else {
+            ALLOC_OR_FAIL(v1, sc, u64, M + 1);
+            u64 *rk, *rv;
+            rc = radix_sort_pairs(ctx, sc, so.x, so.y, k1, v1, M, 0, 2 * P.k, &rk, &rv, /*reverse_digits=*/true);   // see k_index.h
+            if (rc) return rc;
+            // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
+            skey = rk; spos = rv;
+            sc.drop(rk == so.x ? k1 : so.x);
+            sc.drop(rv == so.y ? v1 : so.y);
+        }
         t.stop();
     }
 
@@ -302,7 +323,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
             ALLOC_OR_FAIL(head, sc, u32, M);
             ALLOC_OR_FAIL(runid, sc, u32, M);
             ALLOC_OR_FAIL(d_nr, sc, u32, 1);
-            hipLaunchKernelGGL(k_run_heads, dim3((u32)div_up(M, 256)), dim3(256), 0, ctx->stream, skey, M, head);
+            hipLaunchKernelGGL(k_run_heads, dim3((u32)div_up(M, 256)), dim3(256), 0, ctx->stream, skey, M, head, pk_ybits);
             KCHK(ctx);
             rc = scan_exclusive_u32(ctx, sc, head, runid, M, d_nr);
             if (rc) { delete ix; return rc; }
@@ -337,12 +358,12 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
                 const u32 n_tiles = (u32)div_up(n_runs, PLACE_TILE);
                 u32 *bmax = sc.get<u32>((size_t)n_tiles + 1);
                 if (!bmax) { delete ix; return LRGE_ERR_DEVICE; }
-                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax);
+                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax, pk_ybits);
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_scan, dim3(1), dim3(1024), 0, ctx->stream, bmax, n_tiles);
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_apply, dim3(std::min<u32>(n_tiles, (u32)ctx->n_cu * 8)), dim3(PLACE_THREADS), 0, ctx->stream,
-                                   skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1);
+                                   skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1, pk_ybits);
                 KCHK(ctx);
                 sc.drop(bmax);
             }
@@ -384,7 +405,8 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         if (P.max_mid_occ > P.min_mid_occ && thres > P.max_mid_occ) thres = P.max_mid_occ;
         ix->mid_occ = thres;
     }
-    ix->d_pos = spos; ix->d_skey = skey; sc.keep(spos); sc.keep(skey);
+    ix->d_pos = spos; ix->d_skey = skey; sc.keep(spos); if (skey != spos) sc.keep(skey);
+    ix->pk_pos1 = pk ? pk_pos1 : 0; ix->pk_ybits = pk_ybits;
     t_total.stop();
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->resolve_timers();
@@ -394,7 +416,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
 
 extern "C" void lrge_hip_index_free(lrge_hip_index *ix) {
     if (!ix) return;
-    ix->ctx->pool.release(ix->d_pos); ix->ctx->pool.release(ix->d_skey);
+    ix->ctx->pool.release(ix->d_pos); if (ix->d_skey != ix->d_pos) ix->ctx->pool.release(ix->d_skey);
     ix->ctx->pool.release(ix->d_ht);
     delete ix;
 }
@@ -420,6 +442,13 @@ extern "C" int lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, 
     if (ix->n_mz) {
         HIPCHK(ctx, hipMemcpy(hk.data(), ix->d_skey, ix->n_mz * 8, hipMemcpyDeviceToHost));
         HIPCHK(ctx, hipMemcpy(hp.data(), ix->d_pos, ix->n_mz * 8, hipMemcpyDeviceToHost));
+    }
+    if (ix->pk_ybits) {   // packed entries -> (hash, y)
+        const u64 ym = (1ULL << ix->pk_ybits) - 1, pm = (1ULL << ix->pk_pos1) - 1;
+        for (u64 i = 0; i < ix->n_mz; ++i) {
+            const u64 e = hk[i], yb = e & ym;
+            hk[i] = e >> ix->pk_ybits; hp[i] = (yb >> ix->pk_pos1) << 32 | (yb & pm);
+        }
     }
     std::vector<u32> ord(ix->n_mz);
     for (u64 i = 0; i < ix->n_mz; ++i) ord[i] = (u32)i;
@@ -503,7 +532,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
 
     // ---- 2. lookup ----
     SeedParams sp;
-    sp.ht = ix->d_ht; sp.ht_cap = ix->ht_cap; sp.pos = ix->d_pos;
+    sp.ht = ix->d_ht; sp.ht_cap = ix->ht_cap; sp.pos = ix->d_pos; sp.pk_pos1 = ix->pk_pos1; sp.pk_ybits = ix->pk_ybits;
     sp.t_len = T->d_len; sp.t_rank = T->d_rank; sp.q_len = Q->d_len; sp.q_rank = Q->d_rank;
     sp.mid_occ = ix->mid_occ;
     sp.check_names = (Q->has_rank && T->has_rank) ? 1 : 0;   // qname == NULL in minimap2 skips skip_seed entirely

@@ -41,8 +41,12 @@ def test_sketch_parity(ctx, oracle, edge_set, preset):
     assert bad.size == 0, "first mismatch at %d: read %d" % (bad[0], int(ey[bad[0]] >> 32))
 
 
+@pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
-def test_index_parity(ctx, oracle, edge_set, preset):
+def test_index_parity(ctx, oracle, edge_set, preset, packed, monkeypatch):
+    """Both index layouts: packed 8-byte entries (the default when they fit) and (hash, y) pairs."""
+    if not packed:
+        monkeypatch.setenv("LRGE_HIP_NO_PACKED_INDEX", "1")
     qseqs, qnames, tseqs, tnames = edge_set
     Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset)
     st = ixd.stats()
@@ -253,6 +257,12 @@ def test_packed_anchor_path_is_invisible(ctx, oracle, tiny_ont, monkeypatch, mod
     monkeypatch.setenv("LRGE_HIP_NO_PACKED", "1")
     b = run()
     assert np.array_equal(np.asarray(a), np.asarray(b))
+    monkeypatch.setenv("LRGE_HIP_NO_PACKED_INDEX", "1")      # and the (hash, y) pair index
+    from lrge_amd import engine
+    ix2 = engine.Index(ctx, Td, PRESETS["ont"])
+    c = ix2.overlap_twoset(Qd)[0] if mode == "twoset" else ix2.overlap_ava()
+    ix2.free()
+    assert np.array_equal(np.asarray(a), np.asarray(c))
     assert int(np.asarray(a).sum()) > 0
 
 

@@ -109,6 +109,9 @@ struct lrge_hip_seqset {
     u64 *d_woff = nullptr;      // [n+1] word offset of each read
     u32 *d_len = nullptr;       // [n]
     u32 *d_rank = nullptr;      // [n]
+    u32 *d_cs = nullptr;        // [n+1] sketch chunk map: first 128-base chunk of each read
+    u64 n_chunks = 0;
+    std::vector<u32> h_cs;
     // host copies needed for planning
     std::vector<u64> h_woff;
     std::vector<u32> h_len;

@@ -123,6 +123,16 @@ extern "C" int lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, cons
     if ((e = hipMalloc((void **)&s->d_nmask, nw * 4)) != hipSuccess) return fail("hipMalloc nmask", e);
     if ((e = hipMalloc((void **)&s->d_woff, ((size_t)n + 1) * 8)) != hipSuccess) return fail("hipMalloc woff", e);
     if ((e = hipMalloc((void **)&s->d_len, (size_t)(n ? n : 1) * 4)) != hipSuccess) return fail("hipMalloc len", e);
+    {   // sketch chunk map (read -> first chunk), fixed for the life of the set
+        s->h_cs.resize((size_t)n + 1);
+        u64 nc = 0;
+        for (u32 i = 0; i < n; ++i) { s->h_cs[i] = (u32)nc; nc += (s->h_len[i] + SK_CHUNK - 1) / SK_CHUNK; }
+        s->n_chunks = nc;
+        s->h_cs[n] = (u32)nc;
+        if ((e = hipMalloc((void **)&s->d_cs, ((size_t)n + 1) * 4)) != hipSuccess) return fail("hipMalloc chunk map", e);
+        if (nc < (1ULL << 32) && (e = hipMemcpyAsync(s->d_cs, s->h_cs.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            return fail("copy chunk map", e);
+    }
     if ((e = hipMalloc((void **)&s->d_rank, (size_t)(n ? n : 1) * 4)) != hipSuccess) return fail("hipMalloc rank", e);
     if ((e = hipMemcpyAsync(s->d_woff, s->h_woff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("copy woff", e);
     if (n) {
@@ -159,7 +169,7 @@ extern "C" int lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, cons
 
 extern "C" void lrge_hip_seqset_free(lrge_hip_seqset *s) {
     if (!s) return;
-    (void)hipFree(s->d_pack); (void)hipFree(s->d_nmask); (void)hipFree(s->d_woff); (void)hipFree(s->d_len); (void)hipFree(s->d_rank);
+    (void)hipFree(s->d_pack); (void)hipFree(s->d_nmask); (void)hipFree(s->d_woff); (void)hipFree(s->d_len); (void)hipFree(s->d_rank); (void)hipFree(s->d_cs);
     delete s;
 }
 extern "C" uint32_t lrge_hip_seqset_size(const lrge_hip_seqset *s) { return s ? s->n : 0; }
@@ -176,18 +186,12 @@ struct SketchOut {
 // pk_ybits != 0 (index only): packed 8-byte entries in o->x, o->y stays null (k_sketch.h PK)
 template <int K, int W, bool HPC>
 static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o, u32 pk_pos1, u32 pk_ybits) {
-    std::vector<u32> cs((size_t)s->n + 1);
-    u64 nc = 0;
-    for (u32 i = 0; i < s->n; ++i) { cs[i] = (u32)nc; nc += (s->h_len[i] + SK_CHUNK - 1) / SK_CHUNK; }
-    cs[s->n] = (u32)nc;
-    if (nc >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
-    u32 n_chunks = (u32)nc;
-    ALLOC_OR_FAIL(d_cs, sc, u32, (size_t)s->n + 1);
+    if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
+    u32 n_chunks = (u32)s->n_chunks;
+    const u32 *d_cs = s->d_cs;           // chunk map, uploaded with the set
     ALLOC_OR_FAIL(d_cnt, sc, u32, (size_t)n_chunks + 1);
     ALLOC_OR_FAIL(d_total, sc, u32, 1);
     ALLOC_OR_FAIL(d_mzoff, sc, u32, (size_t)s->n + 1);
-    HIPCHK(ctx, hipMemcpyAsync(d_cs, cs.data(), ((size_t)s->n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // cs is a stack-lifetime host buffer
     ChunkMap cm{d_cs, s->n};
     u32 total = 0;
     if (n_chunks) {
@@ -220,7 +224,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                        n_chunks, d_total, d_mzoff);
     KCHK(ctx);
     // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
-    sc.drop(d_cs); sc.drop(d_cnt); sc.drop(d_total);
+    sc.drop(d_cnt); sc.drop(d_total);
     o->x = dx; o->y = dy; o->mz_off = d_mzoff; o->n = total;
     return LRGE_OK;
 }
@@ -667,6 +671,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         attr_set = true;
     }
 
+    std::vector<SegTile> h_tiles;   // per batch; lives until the batch's next host sync (the async H2D copy reads it)
     u32 q0 = job.dump_anchors ? job.dump_query : 0;
     const u32 q_end = job.dump_anchors ? job.dump_query + 1 : nq;
     while (q0 < q_end) {
@@ -704,7 +709,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             StageTimer t(ctx, LRGE_T_ANCHOR_SORT);
             // the expansion emits the anchors query by query, so only (target, strand, position) need sorting,
             // inside every query's segment: the query bits cost no radix pass (SegTile, k_prims.h)
-            std::vector<SegTile> h_tiles;
+            h_tiles.clear();
             {
                 u32 off = 0, tb = 0;
                 for (u32 q = q0; q < q1; ++q) {
@@ -720,7 +725,6 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             SegTile *d_tiles = (SegTile *)bsc.get<u32>(h_tiles.size() * (sizeof(SegTile) / 4) + 4);
             if (!d_tiles) return LRGE_ERR_DEVICE;
             HIPCHK(ctx, hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // h_tiles is pageable and goes out of scope
             if (packed) {
                 UnpackParams up; up.sb = kl.sh_q(); up.bits_qy = bits_qy; up.sh_q = kl.sh_q(); up.dmask = 255;
                 rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up);

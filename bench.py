@@ -130,7 +130,7 @@ def main():
         else:
             est_all = est
         med = engine.median(est_all, True, 0.15, 0.65)
-        for k_ in ("rs_scatter_launches", "rs_scatter_items"):   # the index build sorts too
+        for k_ in ("rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes"):   # the index build sorts too
             cn[k_] = cn.get(k_, 0) + cb_.get(k_, 0)
         return counts, est_all, med, tb, tm, cn, st
 
@@ -161,7 +161,7 @@ def main():
         # 8(d): the "16*H anchor in for chaining" term of B_q restricted to what the launch covers).  Its avg
         # launch duration is measured live with a HIP event pair on the side stream the kernel runs on.
         # It is an integer DP bound by VALU issue, not by memory, so frac is small by construction; the
-        # memory-bound kernel with the most time (k_rs_scatter, 32 B moved per item) is reported next to it.
+        # memory-bound kernel with the most time (k_rs_scatter: 32 B per (key, value) pair, 16 B per packed key, 24 B in the unpacking pass) is reported next to it.
         pmc = {}
         pj = os.path.join(ROOT, "profiles", "chain_pmc.json")
         if os.path.exists(pj):
@@ -189,7 +189,7 @@ def main():
         r_stage = roof("chain stage: k_chain_hw beside k_chain_lpg (fork..join)", acc_tm.get("chain", 0.0),
                        acc_cn.get("batches", 0), 16.0 * acc_cn.get("chain_anchors", 0), "chain_stage_hbm_bytes_per_step")
         r_sc = roof("k_rs_scatter", acc_tm.get("rs_scatter", 0.0) + acc_tb.get("rs_scatter", 0.0), acc_cn.get("rs_scatter_launches", 0),
-                    32.0 * acc_cn.get("rs_scatter_items", 0), "k_rs_scatter_hbm_bytes_per_launch")
+                    float(acc_cn.get("rs_scatter_bytes", 0)), "k_rs_scatter_hbm_bytes_per_launch")
         # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
         L = float(q.lens().sum()); M = acc_cn.get("query_minimizers", 0) / K; H = acc_cn.get("anchors", 0) / K
         B_q = L / 4 + 32 * M + 8 * H + 32 * H + 4 * Qn

@@ -89,7 +89,9 @@ enum {
     LRGE_C_GROUPS_CHAINED, LRGE_C_CHAIN_LAUNCHES, LRGE_C_BATCHES,
     LRGE_C_CHAIN_ANCHORS /* anchors in chained groups */, LRGE_C_CHAIN_GLB_LAUNCHES, LRGE_C_CHAIN_GLB_ANCHORS,
     LRGE_C_LPG_LAUNCHES, LRGE_C_LPG_ANCHORS /* of those, anchors chained by k_chain_lpg */,
-    LRGE_C_RS_SCATTER_LAUNCHES, LRGE_C_RS_SCATTER_ITEMS /* (key, value) pairs moved by k_rs_scatter */,
+    LRGE_C_RS_SCATTER_LAUNCHES, LRGE_C_RS_SCATTER_ITEMS /* items moved by k_rs_scatter */,
+    LRGE_C_RS_SCATTER_BYTES /* bytes those launches had to read + write: 32 per (key, value) pair, 16 per packed
+                               key, 24 in the unpacking pass */,
     LRGE_C_N
 };
 

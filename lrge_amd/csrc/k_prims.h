@@ -362,6 +362,7 @@ static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u6
             ts.stop();
             ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
             ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;
+            ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 32 * n;
         }
         u64 *t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
@@ -397,7 +398,8 @@ static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *
             KCHK(ctx);
             ts.stop();
             ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
-            ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;   // (bench prices an item at 32 B; these move 16 / 24 B)
+            ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;
+            ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (p + 1 < passes ? 16 : 24) * n;
         }
         u64 *t = ki; ki = ko; ko = t;
     }
@@ -431,6 +433,7 @@ static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64
             ts.stop();
             ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
             ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;
+            ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 16 * n;
         }
         u64 *t = ki; ki = ko; ko = t;
     }

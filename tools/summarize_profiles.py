@@ -63,15 +63,25 @@ out = {
 }
 # k_rs_scatter: both instantiations, averaged over all launches of the step
 tot, n = 0.0, 0
-for kern in ("k_rs_scatter<false>", "k_rs_scatter<true>"):
+for kern in fetch:
+    if not kern.startswith("k_rs_scatter"):
+        continue
     f = fetch.get(kern, {}).get("FETCH_SIZE"); w = write.get(kern, {}).get("WRITE_SIZE")
     if f and w:
         tot += f[1] * 1024 * 2.0 + w[1] * 1024 * 1.0; n += f[0]
 if n:
     out["k_rs_scatter_hbm_bytes_per_launch"] = tot / n
-hb = fetch.get("k_rs_hist<false>", {}).get("FETCH_SIZE")
-if hb:
-    out["calibration_k_rs_hist_false_fetch_KiB_per_launch"] = hb[1] / hb[0]
+# calibration of the x2 read correction: the largest k_rs_hist<false> launch of a step is the index sort's,
+# a pure stream of 8 B per index minimizer
+big = 0.0
+for r in csv.DictReader(open(os.path.join(G, tag + "_fetch", "f_counter_collection.csv"))):
+    if r["Kernel_Name"].startswith("void k_rs_hist<false>") and r["Counter_Name"] == "FETCH_SIZE":
+        big = max(big, float(r["Counter_Value"]))
+nmz = None
+for line in open(os.path.join(G, tag + "_bench.json")):
+    pass
+out["calibration"] = {"k_rs_hist_false_largest_launch_FETCH_SIZE_KiB": big,
+                      "note": "that launch reads 8 B x (index minimizers); FETCH_SIZE reports half of it on gfx950 (128-B requests tallied at 64 B)"}
 a, b = out["k_chain_lpg_hbm_bytes_per_launch"], out["k_chain_hw_hbm_bytes_per_launch"]
 out["chain_stage_hbm_bytes_per_step"] = (a or 0) + (b or 0) if (a or b) else None
 json.dump(out, open(os.path.join(P, "chain_pmc.json"), "w"), indent=1)

@@ -34,12 +34,13 @@ json.dump(under, open(os.path.join(P, rnd + "_bench_under_rocprof.json"), "w"), 
 
 for name, sub, pre in (("sq", "_sq", "q"), ("fetch", "_fetch", "f"), ("write", "_write", "w")):
     a = agg(os.path.join(G, tag + sub, pre + "_counter_collection.csv"))
-    with open(os.path.join(P, "%s_pmc_%s.csv" % (rnd, name)), "w") as f:
-        f.write("kernel,counter,dispatches,sum,per_dispatch\n")
+    with open(os.path.join(P, "%s_pmc_%s.csv" % (rnd, name)), "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["kernel", "counter", "dispatches", "sum", "per_dispatch"])
         for k in sorted(a):
             for c in sorted(a[k]):
                 n, v = a[k][c]
-                f.write("%s,%s,%d,%.6g,%.6g\n" % (k, c, n, v, v / n))
+                wr.writerow([k, c, n, "%.6g" % v, "%.6g" % (v / n)])
 
 fetch = agg(os.path.join(G, tag + "_fetch", "f_counter_collection.csv"))
 write = agg(os.path.join(G, tag + "_write", "w_counter_collection.csv"))

@@ -13,6 +13,8 @@
 #pragma once
 #include "k_chain_reg.h"
 
+#define HW_PRIO_N 1024
+
 struct HwChainArgs {
     const u64 *akey, *aval;
     const u32 *gstart;
@@ -163,6 +165,8 @@ __global__ __launch_bounds__(64) void k_chain_hw(HwChainArgs R, ChainParams P, G
     const u32 e0B = (gB + 1 < R.n_groups) ? RFL(R.gstart[gB + 1]) : (u32)R.n_anchors;
     const i32 nA = (i32)(e0A - s0A), nB = hasB ? (i32)(e0B - s0B) : 0;
     const i32 n_max = nA > nB ? nA : nB;
+    // the longest groups end last and set the stage time: their wavefronts get issue priority over the crowd
+    if (n_max >= HW_PRIO_N) __builtin_amdgcn_s_setprio(3);
     const u64 rmask = (1ULL << P.kl.bits_rpos) - 1;
     // per-lane view of "my" group
     const u32 s0 = h ? s0B : s0A;

@@ -143,7 +143,7 @@ def main():
         counts, est_all, med, tb, tm, cn, st = step()
         for k, v in tb.items(): acc_tb[k] = acc_tb.get(k, 0.0) + v
         for k, v in tm.items(): acc_tm[k] = acc_tm.get(k, 0.0) + v
-        for k, v in cn.items(): acc_cn[k] = acc_cn.get(k, 0) + v
+        for k, v in cn.items(): acc_cn[k] = v if k == "lpg_split" else acc_cn.get(k, 0) + v
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -213,7 +213,7 @@ def main():
             "roofline_other": [r_stage, r_sc],
             "stage_ms_per_step": {**{"index_" + k: v / K for k, v in acc_tb.items() if v and k != "total"},
                                   **{k: v / K for k, v in acc_tm.items() if v}},
-            "work_per_step": {k: v / K for k, v in acc_cn.items()},
+            "work_per_step": {k: (v if k == "lpg_split" else v / K) for k, v in acc_cn.items()},
         }
         if world == 1 and not a.no_cpu_baseline:
             cb, ccounts, cmid = cpu_baseline(q, t, a.cpu_seconds)

@@ -92,6 +92,7 @@ enum {
     LRGE_C_RS_SCATTER_LAUNCHES, LRGE_C_RS_SCATTER_ITEMS /* items moved by k_rs_scatter */,
     LRGE_C_RS_SCATTER_BYTES /* bytes those launches had to read + write: 32 per (key, value) pair, 16 per packed
                                key, 24 in the unpacking pass */,
+    LRGE_C_LPG_SPLIT /* group size above which the last batch used k_chain_hw instead of k_chain_lpg */,
     LRGE_C_N
 };
 

@@ -13,8 +13,6 @@
 #pragma once
 #include "k_chain_reg.h"
 
-#define HW_PRIO_N 1024
-
 struct HwChainArgs {
     const u64 *akey, *aval;
     const u32 *gstart;
@@ -165,8 +163,6 @@ __global__ __launch_bounds__(64) void k_chain_hw(HwChainArgs R, ChainParams P, G
     const u32 e0B = (gB + 1 < R.n_groups) ? RFL(R.gstart[gB + 1]) : (u32)R.n_anchors;
     const i32 nA = (i32)(e0A - s0A), nB = hasB ? (i32)(e0B - s0B) : 0;
     const i32 n_max = nA > nB ? nA : nB;
-    // the longest groups end last and set the stage time: their wavefronts get issue priority over the crowd
-    if (n_max >= HW_PRIO_N) __builtin_amdgcn_s_setprio(3);
     const u64 rmask = (1ULL << P.kl.bits_rpos) - 1;
     // per-lane view of "my" group
     const u32 s0 = h ? s0B : s0A;
@@ -347,27 +343,35 @@ __global__ __launch_bounds__(64) void k_chain_hw(HwChainArgs R, ChainParams P, G
 // ------------------------------------------------------------------------------------------
 // list of chained groups with their sizes (for the size sort that pairs groups for k_chain_hw)
 // ------------------------------------------------------------------------------------------
-// n_out[0] = groups with n >= min_n, n_out[2] = those with n > big_n (n_out[1] is k_group_fill's cursor)
-__global__ void k_group_count(const u32 *__restrict__ gstart, u32 n_groups, u64 n_anchors, u32 min_n, u32 big_n,
-                              u32 *__restrict__ n_out, unsigned long long *__restrict__ anchors_out) {
-    __shared__ u32 lc, lb; __shared__ unsigned long long la, lab;
-    if (threadIdx.x == 0) { lc = 0; lb = 0; la = 0; lab = 0; }
+// Size census of the groups worth chaining (n >= min_n): n_out[0] = how many, anchors_out[0] = their anchors, and a
+// histogram over size classes of GSZ_W anchors -- class c holds (c*GSZ_W, (c+1)*GSZ_W], the last class everything
+// above -- as counts hist_n[] and anchor sums hist_a[].  The host picks the k_chain_hw / k_chain_lpg split from it.
+// (n_out[1] is k_group_fill's cursor.)
+#define GSZ_W 64
+#define GSZ_BINS 257
+__device__ __forceinline__ u32 gsz_class(u32 n) { const u32 c = (n - 1) / GSZ_W; return c < GSZ_BINS - 1 ? c : GSZ_BINS - 1; }
+
+__global__ void k_group_count(const u32 *__restrict__ gstart, u32 n_groups, u64 n_anchors, u32 min_n,
+                              u32 *__restrict__ n_out, unsigned long long *__restrict__ anchors_out,
+                              u32 *__restrict__ hist_n, unsigned long long *__restrict__ hist_a) {
+    __shared__ u32 lc; __shared__ unsigned long long la;
+    __shared__ u32 hn[GSZ_BINS]; __shared__ unsigned long long ha[GSZ_BINS];
+    if (threadIdx.x == 0) { lc = 0; la = 0; }
+    for (u32 i = threadIdx.x; i < GSZ_BINS; i += blockDim.x) { hn[i] = 0; ha[i] = 0; }
     __syncthreads();
     const u64 c0 = (u64)blockIdx.x * GB_CHUNK;
-    u32 c = 0, b = 0; unsigned long long a = 0, ab = 0;
+    u32 c = 0; unsigned long long a = 0;
     for (u64 gg = c0 + threadIdx.x; gg < c0 + GB_CHUNK && gg < n_groups; gg += blockDim.x) {
         const u32 g = (u32)gg;
         const u64 e = (g + 1 < n_groups) ? gstart[g + 1] : n_anchors;
         const u32 n = (u32)(e - gstart[g]);
-        if (n >= min_n) { ++c; a += n; if (n > big_n) { ++b; ab += n; } }
+        if (n >= min_n && n > 0) { ++c; a += n; const u32 k = gsz_class(n); atomicAdd(&hn[k], 1u); atomicAdd(&ha[k], (unsigned long long)n); }
     }
     if (c) { atomicAdd(&lc, c); atomicAdd(&la, a); }
-    if (b) { atomicAdd(&lb, b); atomicAdd(&lab, ab); }
     __syncthreads();
-    if (threadIdx.x == 0 && lc) {
-        atomicAdd(n_out, lc); atomicAdd(anchors_out, la);
-        if (lb) { atomicAdd(n_out + 2, lb); atomicAdd(anchors_out + 1, lab); }   // anchors_out[1]: anchors of the big groups
-    }
+    if (threadIdx.x == 0 && lc) { atomicAdd(n_out, lc); atomicAdd(anchors_out, la); }
+    for (u32 i = threadIdx.x; i < GSZ_BINS; i += blockDim.x)
+        if (hn[i]) { atomicAdd(&hist_n[i], hn[i]); atomicAdd(&hist_a[i], ha[i]); }
 }
 
 // keys = 65535 - min(n, 65535), so that an ascending 16-bit sort puts the largest groups first; vals = group id

@@ -25,7 +25,7 @@
 #define LPG_B 16   // candidates per evaluate / resolve block
 #define LPG_CH 8   // anchors per input / output staging chunk
 #define LPG_RING_BYTES ((2 * (LPG_CH / 2) * 128 * 2 + LPG_CH * 64) * 8)
-#define LPG_MAX_N_DEFAULT 512
+#define LPG_MAX_AUTO 0xFFFFFFFEu   // split chosen per batch from the group-size census (lrge_hip.hip)
 
 struct LpgChainArgs {
     const u64 *akey, *aval;

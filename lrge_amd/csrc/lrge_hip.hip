@@ -650,7 +650,19 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     }
 
     // ---- 4. batches ----
-    const u64 batch_cap = env_u64("LRGE_HIP_BATCH_ANCHORS", 1ULL << 27);
+    // Anchors per batch.  Every batch pays the latency of its longest chain group once (the chain kernels are
+    // bound by it), so batches are as large as memory allows: ~64 B of scratch per anchor, at most half of the
+    // free HBM, at most 2^30 anchors (positions are 32-bit).
+    u64 batch_cap = 1ULL << 30;
+    {
+        size_t mfree = 0, mtotal = 0;
+        if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
+            const u64 by_mem = ((u64)mfree + ctx->pool.total) / 2 / 64;     // the pool's cached blocks are reusable too
+            if (by_mem < batch_cap) batch_cap = by_mem;
+        }
+        if (batch_cap < (1ULL << 20)) batch_cap = 1ULL << 20;
+    }
+    batch_cap = env_u64("LRGE_HIP_BATCH_ANCHORS", batch_cap);
     KeyLayout kl;
     kl.bits_rpos = std::max<u32>(1, ceil_log2_u64((u64)T->max_len + 1));
     kl.bits_rid = std::max<u32>(1, ceil_log2_u64((u64)nt));
@@ -776,13 +788,14 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         const int chain_mode = (cm && !strcmp(cm, "lds")) ? 1 : (cm && !strcmp(cm, "glb")) ? 2 : (cm && !strcmp(cm, "reg")) ? 3 : 0;
         // mode 0 splits the size-sorted group list: groups above lpg_max anchors go to k_chain_hw (short
         // latency per anchor), the rest to k_chain_lpg (64 groups per wavefront).  "hw" / "lpg" force one kernel.
-        u32 lpg_max = LPG_MAX_N_DEFAULT;
+        // The split is chosen per batch from the size census of the groups (see below); LRGE_HIP_LPG_MAX fixes it.
+        u32 lpg_max = LPG_MAX_AUTO;
         if (const char *e = getenv("LRGE_HIP_LPG_MAX")) lpg_max = (u32)strtoul(e, nullptr, 10);
         if (cm && !strcmp(cm, "hw")) lpg_max = 0;
         if (cm && !strcmp(cm, "lpg")) lpg_max = 0xFFFFFFFFu;
         if (lpg_max && (cp.want_all || d_chains) && !(cm && !strcmp(cm, "lpg"))) lpg_max = 0;   // records: wave-wide backtrack anyway
         if (cp.max_iter < LPG_W) lpg_max = 0;    // (debug knob only) k_chain_lpg assumes every window slot is a candidate
-        u32 n_big = 0;
+        u32 n_big = 0, lpg_split = 0;
         u32 G = 0; u32 *gstart, *gflags, *bin_count = nullptr, *bin_list = nullptr, *hw_list = nullptr;
         u32 h_bins[N_BINS] = {0, 0, 0, 0, 0};
         unsigned long long h_bin_anchors[N_BINS] = {0, 0, 0, 0, 0};
@@ -805,18 +818,58 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             bsc.drop(head); bsc.drop(gid); bsc.drop(d_G);
             if (chain_mode == 0) {
                 // groups worth chaining, sorted by size (largest first) so that k_chain_hw pairs equals
-                u32 *d_cnt = bsc.get<u32>(4);
-                unsigned long long *d_anch = (unsigned long long *)bsc.get<u64>(2);
+                u32 *d_cnt = bsc.get<u32>(4 + GSZ_BINS);
+                unsigned long long *d_anch = (unsigned long long *)bsc.get<u64>(2 + GSZ_BINS);
                 if (!d_cnt || !d_anch) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));
-                HIPCHK(ctx, hipMemsetAsync(d_anch, 0, 16, ctx->stream));
-                hipLaunchKernelGGL(k_group_count, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, lpg_max, d_cnt, d_anch);
+                HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, (4 + GSZ_BINS) * 4, ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(d_anch, 0, (2 + GSZ_BINS) * 8, ctx->stream));
+                hipLaunchKernelGGL(k_group_count, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, d_cnt, d_anch,
+                                   d_cnt + 4, d_anch + 2);
                 KCHK(ctx);
-                HIPCHK(ctx, hipMemcpyAsync(&n_chained, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipMemcpyAsync(&n_big, d_cnt + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipMemcpyAsync(&a_chained, d_anch, 8, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipMemcpyAsync(&a_big, d_anch + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+                u32 h_cnt[4 + GSZ_BINS]; unsigned long long h_anch[2 + GSZ_BINS];
+                HIPCHK(ctx, hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(h_anch, d_anch, sizeof(h_anch), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                n_chained = h_cnt[0]; a_chained = h_anch[0];
+                {
+                    // Split of the size-sorted list: groups above T anchors -> k_chain_hw (~0.55 us per anchor of latency,
+                    // ~93 VALU instructions per anchor), the rest -> k_chain_lpg (~4.4 us per anchor of the LONGEST group
+                    // of a wavefront, ~22 VALU per anchor).  Both run side by side; the stage takes about
+                    //   max(T * t_lpg, n_longest * t_hw, VALU work / issue rate of the chip)
+                    // and T (a multiple of GSZ_W) minimises that estimate.  Measured constants of this kernel pair.
+                    const u32 *hn = h_cnt + 4; const unsigned long long *ha = h_anch + 2;
+                    u32 T = lpg_max;
+                    if (lpg_max == LPG_MAX_AUTO) {
+                        const double t_lpg = 4.3e-6, t_hw = 0.55e-6, c_lpg = 22.0, c_hw = 93.0;
+                        const double rate = 0.8 * (double)ctx->n_cu * 4 * 2.1e9 / 4.0;   // wave64 VALU instructions per second, ~80 % reachable
+                        int top = -1;
+                        for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) top = b;
+                        double best = 1e30; T = 0;
+                        double a_le = 0;    // anchors in classes <= b
+                        for (int b = -1; b < GSZ_BINS - 1; ++b) {      // T = (b + 1) * GSZ_W: classes 0..b go to k_chain_lpg
+                            if (b >= 0) a_le += (double)ha[b];
+                            const double a_hw = (double)a_chained - a_le;
+                            const double crit_lpg = b >= 0 ? (double)std::min<int>(b + 1, top + 1) * GSZ_W * t_lpg : 0.0;
+                            const double crit_hw = a_hw > 0 ? (double)(top + 1) * GSZ_W * t_hw : 0.0;
+                            const double est = std::max(std::max(crit_lpg, crit_hw), (a_le * c_lpg + a_hw * c_hw) / rate);
+                            if (est < best - 1e-9) { best = est; T = (u32)(b + 1) * GSZ_W; }
+                            if (b >= top) break;
+                        }
+                    }
+                    // groups strictly above T: whole classes when T is a class edge, else (LRGE_HIP_LPG_MAX) count by class floor
+                    n_big = 0; a_big = 0;
+                    for (int b = 0; b < GSZ_BINS; ++b) {
+                        const bool above = (u64)b * GSZ_W >= (u64)T;    // class b = (b*W, (b+1)*W]
+                        if (above) { n_big += hn[b]; a_big += ha[b]; }
+                    }
+                    lpg_split = T;
+                    ctx->counters[LRGE_C_LPG_SPLIT] = lpg_split;
+                    if (getenv("LRGE_HIP_VERBOSE")) {
+                        int top = -1; for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) top = b;
+                        fprintf(stderr, "[lrge_hip] batch: %u groups chained, %llu anchors, largest class %d (<= %d anchors), split T=%u -> hw %u groups / %llu anchors\n",
+                                n_chained, a_chained, top, (top + 1) * GSZ_W, T, n_big, a_big);
+                    }
+                }
                 if (n_chained) {
                     u64 *k0 = bsc.get<u64>(n_chained), *v0 = bsc.get<u64>(n_chained), *k1 = bsc.get<u64>(n_chained), *v1 = bsc.get<u64>(n_chained);
                     hw_list = bsc.get<u32>(n_chained);

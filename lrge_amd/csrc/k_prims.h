@@ -441,3 +441,85 @@ static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64
     *res = ki;
     return LRGE_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Run heads of a sorted key stream, compacted: starts[r] = index of the first element of run r, where a run is a
+// maximal stretch of equal (key >> shift).  Two passes over the keys (count per tile, then fill) and nothing
+// else -- no flag / rank arrays of the stream's length.  Every thread owns HC_ITEMS consecutive keys (one full
+// 128-byte line), so its heads are consecutive in the output.
+// ------------------------------------------------------------------------------------------
+#define HC_THREADS 256
+#define HC_ITEMS 16
+#define HC_TILE (HC_THREADS * HC_ITEMS)
+
+__device__ __forceinline__ u32 hc_load_flags(const u64 *__restrict__ keys, u64 n, u32 shift, u64 base) {
+    // bit t set: element base + t starts a run
+    u32 f = 0;
+    if (base >= n) return 0;
+    u64 prev = base ? keys[base - 1] >> shift : 0;
+    const bool first = base == 0;
+    if (base + HC_ITEMS <= n) {
+        const ulonglong2 *p = (const ulonglong2 *)(keys + base);
+#pragma unroll
+        for (int t = 0; t < HC_ITEMS / 2; ++t) {
+            const ulonglong2 q = p[t];
+            const u64 a = q.x >> shift, b = q.y >> shift;
+            if (a != prev || (first && t == 0)) f |= 1u << (2 * t);
+            if (b != a) f |= 1u << (2 * t + 1);
+            prev = b;
+        }
+    } else {
+        for (int t = 0; t < HC_ITEMS && base + t < n; ++t) {
+            const u64 a = keys[base + t] >> shift;
+            if (a != prev || (first && t == 0)) f |= 1u << t;
+            prev = a;
+        }
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(HC_THREADS) void k_heads_count(const u64 *__restrict__ keys, u64 n, u32 shift, u32 *__restrict__ bcount) {
+    __shared__ u32 ws[HC_THREADS / 64];
+    const u64 base = (u64)blockIdx.x * HC_TILE + (u64)threadIdx.x * HC_ITEMS;
+    u32 c = (u32)__popc(hc_load_flags(keys, n, shift, base));
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if (lane_id() == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 t = 0; for (int w = 0; w < HC_THREADS / 64; ++w) t += ws[w]; bcount[blockIdx.x] = t; }
+}
+
+__global__ __launch_bounds__(HC_THREADS) void k_heads_fill(const u64 *__restrict__ keys, u64 n, u32 shift, const u32 *__restrict__ boff,
+                                                           u32 *__restrict__ starts) {
+    __shared__ u32 ws[HC_THREADS / 64];
+    const u64 base = (u64)blockIdx.x * HC_TILE + (u64)threadIdx.x * HC_ITEMS;
+    u32 f = hc_load_flags(keys, n, shift, base);
+    const u32 c = (u32)__popc(f);
+    const u32 inc = wave_incl_scan_u32(c);
+    if (lane_id() == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u32 o = boff[blockIdx.x] + inc - c;
+    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) o += ws[w];
+    while (f) { const u32 t = (u32)__ffs((int)f) - 1; f &= f - 1; starts[o++] = (u32)(base + t); }
+}
+
+// d_starts receives a pool block of n_heads + 1 entries (the extra one is not written); n < 2^32
+static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n, u32 shift, u32 **d_starts, u32 *n_heads) {
+    *d_starts = nullptr; *n_heads = 0;
+    if (n == 0) return LRGE_OK;
+    const u32 nb = (u32)div_up(n, HC_TILE);
+    ALLOC_OR_FAIL(bc, sc, u32, (size_t)nb + 1);
+    ALLOC_OR_FAIL(d_tot, sc, u32, 1);
+    hipLaunchKernelGGL(k_heads_count, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc);
+    KCHK(ctx);
+    int rc = scan_exclusive_u32(ctx, sc, bc, bc, nb, d_tot);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(n_heads, d_tot, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    u32 *st = sc.get<u32>((size_t)*n_heads + 1);
+    if (!st) return LRGE_ERR_DEVICE;
+    hipLaunchKernelGGL(k_heads_fill, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc, st);
+    KCHK(ctx);
+    sc.drop(bc); sc.drop(d_tot);
+    *d_starts = st;
+    return LRGE_OK;
+}

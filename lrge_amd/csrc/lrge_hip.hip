@@ -324,20 +324,8 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         StageTimer t(ctx, LRGE_T_INDEX_TABLE);
         u32 *d_runstart = nullptr;
         if (M) {
-            ALLOC_OR_FAIL(head, sc, u32, M);
-            ALLOC_OR_FAIL(runid, sc, u32, M);
-            ALLOC_OR_FAIL(d_nr, sc, u32, 1);
-            hipLaunchKernelGGL(k_run_heads, dim3((u32)div_up(M, 256)), dim3(256), 0, ctx->stream, skey, M, head, pk_ybits);
-            KCHK(ctx);
-            rc = scan_exclusive_u32(ctx, sc, head, runid, M, d_nr);
+            rc = compact_heads(ctx, sc, skey, M, pk_ybits, &d_runstart, &n_runs);    // runs of equal hash
             if (rc) { delete ix; return rc; }
-            HIPCHK(ctx, hipMemcpyAsync(&n_runs, d_nr, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            d_runstart = sc.get<u32>((size_t)n_runs + 1);
-            if (!d_runstart) { delete ix; return LRGE_ERR_DEVICE; }
-            hipLaunchKernelGGL(k_run_starts, dim3((u32)div_up(M, 256)), dim3(256), 0, ctx->stream, head, runid, M, d_runstart);
-            KCHK(ctx);
-            sc.drop(head); sc.drop(runid); sc.drop(d_nr);
         }
         u64 cap = 2 * (u64)n_runs;
         if (cap < 1024) cap = 1024;
@@ -802,20 +790,11 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         u32 n_chained = 0; unsigned long long a_chained = 0, a_big = 0;
         {
             StageTimer t(ctx, LRGE_T_GROUP);
-            u32 *head = bsc.get<u32>(A), *gid = bsc.get<u32>(A), *d_G = bsc.get<u32>(1);
-            if (!head || !gid || !d_G) return LRGE_ERR_DEVICE;
-            hipLaunchKernelGGL(k_group_heads, dim3((u32)div_up(A, 256)), dim3(256), 0, ctx->stream, skey, A, kl.bits_rpos, head);
-            KCHK(ctx);
-            rc = scan_exclusive_u32(ctx, bsc, head, gid, A, d_G);
+            rc = compact_heads(ctx, bsc, skey, A, kl.bits_rpos, &gstart, &G);       // runs of equal (query, target, strand)
             if (rc) return rc;
-            HIPCHK(ctx, hipMemcpyAsync(&G, d_G, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            gstart = bsc.get<u32>((size_t)G + 1); gflags = bsc.get<u32>((size_t)G + 1);
+            gflags = bsc.get<u32>((size_t)G + 1);
             if (!gstart || !gflags) return LRGE_ERR_DEVICE;
-            hipLaunchKernelGGL(k_run_starts, dim3((u32)div_up(A, 256)), dim3(256), 0, ctx->stream, head, gid, A, gstart);
-            KCHK(ctx);
             HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
-            bsc.drop(head); bsc.drop(gid); bsc.drop(d_G);
             if (chain_mode == 0) {
                 // groups worth chaining, sorted by size (largest first) so that k_chain_hw pairs equals
                 u32 *d_cnt = bsc.get<u32>(4 + GSZ_BINS);

@@ -51,10 +51,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("LRGE_HIP_LIB_AB") or LIB_PATH     # LRGE_HIP_LIB_AB: another build of the same library (tools/ab.sh)
+    if not os.path.exists(path):
         raise RuntimeError("liblrge_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
-                           "there is no CPU fallback" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+                           "there is no CPU fallback" % path)
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.lrge_hip_version.restype = C.c_char_p
     L.lrge_hip_last_error.restype = C.c_char_p

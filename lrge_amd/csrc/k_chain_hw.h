@@ -351,17 +351,18 @@ __global__ __launch_bounds__(64) void k_chain_hw(HwChainArgs R, ChainParams P, G
 #define GSZ_BINS 257
 __device__ __forceinline__ u32 gsz_class(u32 n) { const u32 c = (n - 1) / GSZ_W; return c < GSZ_BINS - 1 ? c : GSZ_BINS - 1; }
 
-__global__ void k_group_count(const u32 *__restrict__ gstart, u32 n_groups, u64 n_anchors, u32 min_n,
+// (the number of groups is read from device memory: the census is launched before the host knows it, grid-stride)
+__global__ void k_group_count(const u32 *__restrict__ gstart, const u32 *__restrict__ d_n_groups, u64 n_anchors, u32 min_n,
                               u32 *__restrict__ n_out, unsigned long long *__restrict__ anchors_out,
                               u32 *__restrict__ hist_n, unsigned long long *__restrict__ hist_a) {
     __shared__ u32 lc; __shared__ unsigned long long la;
     __shared__ u32 hn[GSZ_BINS]; __shared__ unsigned long long ha[GSZ_BINS];
+    const u32 n_groups = *d_n_groups;
     if (threadIdx.x == 0) { lc = 0; la = 0; }
     for (u32 i = threadIdx.x; i < GSZ_BINS; i += blockDim.x) { hn[i] = 0; ha[i] = 0; }
     __syncthreads();
-    const u64 c0 = (u64)blockIdx.x * GB_CHUNK;
     u32 c = 0; unsigned long long a = 0;
-    for (u64 gg = c0 + threadIdx.x; gg < c0 + GB_CHUNK && gg < n_groups; gg += blockDim.x) {
+    for (u64 gg = (u64)blockIdx.x * blockDim.x + threadIdx.x; gg < n_groups; gg += (u64)gridDim.x * blockDim.x) {
         const u32 g = (u32)gg;
         const u64 e = (g + 1 < n_groups) ? gstart[g + 1] : n_anchors;
         const u32 n = (u32)(e - gstart[g]);

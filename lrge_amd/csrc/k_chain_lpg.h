@@ -35,6 +35,7 @@ struct LpgChainArgs {
     u32 n_list;
     u64 *grec;         // [n_anchors]
     u32 *tmark;        // [n_anchors] zero-initialised
+    u32 prio;          // raise the wavefronts' issue priority (they run beside k_chain_hw)
 };
 
 // PENTAB: with chain_skip_scale == 0 (every preset lrge uses) comput_sc's penalty depends on dd alone --
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     extern __shared__ i32 pen_tab[];   // [bw + 2] when PENTAB, then the anchor / record staging ring (LPG_RING_BYTES)
     // this kernel's longest wavefronts are the critical path of the chain stage; k_chain_hw's wavefronts on
     // the other stream share the SIMDs and should fill the gaps, not compete for issue slots
-    __builtin_amdgcn_s_setprio(3);
+    if (R.prio) __builtin_amdgcn_s_setprio(3);
     const u32 li = blockIdx.x * 64 + threadIdx.x;
     const bool has = li < R.n_list;
     const u32 g = has ? R.list[li] : 0;

@@ -502,6 +502,22 @@ __global__ __launch_bounds__(HC_THREADS) void k_heads_fill(const u64 *__restrict
     while (f) { const u32 t = (u32)__ffs((int)f) - 1; f &= f - 1; starts[o++] = (u32)(base + t); }
 }
 
+// Same without the host round trip: starts must hold n + 1 entries (upper bound), *d_count (device) receives the
+// number of runs.  bc_out: scratch block the caller drops once the stream has passed.
+static int compact_heads_async(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n, u32 shift, u32 *starts, u32 *d_count) {
+    if (n == 0) { HIPCHK(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream)); return LRGE_OK; }
+    const u32 nb = (u32)div_up(n, HC_TILE);
+    ALLOC_OR_FAIL(bc, sc, u32, (size_t)nb + 1);
+    hipLaunchKernelGGL(k_heads_count, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc);
+    KCHK(ctx);
+    int rc = scan_exclusive_u32(ctx, sc, bc, bc, nb, d_count);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_heads_fill, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc, starts);
+    KCHK(ctx);
+    sc.drop(bc);   // (recycled in stream order)
+    return LRGE_OK;
+}
+
 // d_starts receives a pool block of n_heads + 1 entries (the extra one is not written); n < 2^32
 static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n, u32 shift, u32 **d_starts, u32 *n_heads) {
     *d_starts = nullptr; *n_heads = 0;

@@ -185,7 +185,8 @@ struct SketchOut {
 
 // pk_ybits != 0 (index only): packed 8-byte entries in o->x, o->y stays null (k_sketch.h PK)
 template <int K, int W, bool HPC>
-static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o, u32 pk_pos1, u32 pk_ybits) {
+static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o, u32 pk_pos1, u32 pk_ybits,
+                         std::vector<u32> *h_mzoff) {
     if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
     u32 n_chunks = (u32)s->n_chunks;
     const u32 *d_cs = s->d_cs;           // chunk map, uploaded with the set
@@ -200,11 +201,19 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, d_cnt, d_cnt, n_chunks, d_total);
         if (rc) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     } else {
         HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, ctx->stream));
     }
+    // per-read offsets follow from the chunk scan alone: they travel to the host with the total, in the one sync
+    hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, ctx->stream, d_cs, d_cnt, s->n,
+                       n_chunks, d_total, d_mzoff);
+    KCHK(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_mzoff) {
+        h_mzoff->resize((size_t)s->n + 1);
+        HIPCHK(ctx, hipMemcpyAsync(h_mzoff->data(), d_mzoff, ((size_t)s->n + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ALLOC_OR_FAIL(dx, sc, u64, (size_t)total + 1);
     u64 *dy = nullptr;
     if (!(index_keys && pk_ybits)) { dy = sc.get<u64>((size_t)total + 1); if (!dy) return LRGE_ERR_DEVICE; }
@@ -220,9 +229,6 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                                ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, 0u, 0u);
         KCHK(ctx);
     }
-    hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, ctx->stream, d_cs, d_cnt, s->n,
-                       n_chunks, d_total, d_mzoff);
-    KCHK(ctx);
     // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
     sc.drop(d_cnt); sc.drop(d_total);
     o->x = dx; o->y = dy; o->mz_off = d_mzoff; o->n = total;
@@ -230,10 +236,10 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
 }
 
 static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o,
-                         u32 pk_pos1 = 0, u32 pk_ybits = 0) {
+                         u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr) {
     StageTimer t(ctx, LRGE_T_SKETCH);
-    int rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits)
-                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits);
+    int rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff)
+                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff);
     t.stop();
     return rc;
 }
@@ -513,14 +519,12 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
 
     // ---- 1. sketch the queries ----
     SketchOut so;
-    int rc = sketch_device(ctx, sc, Q, ix->preset_id, false, &so);
+    std::vector<u32> h_mzoff;
+    int rc = sketch_device(ctx, sc, Q, ix->preset_id, false, &so, 0, 0, &h_mzoff);
     if (rc) return rc;
     const u64 Mq = so.n;
     ctx->counters[LRGE_C_QUERY_MINIMIZERS] = Mq;
     if (Mq >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "query set limited to < 2^32 minimizers"); return LRGE_ERR_TOO_MANY; }
-    std::vector<u32> h_mzoff((size_t)nq + 1);
-    HIPCHK(ctx, hipMemcpyAsync(h_mzoff.data(), so.mz_off, ((size_t)nq + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 
     // ---- 2. lookup ----
     SeedParams sp;
@@ -556,22 +560,10 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     // minimizers present in the index: every occurrence of a value x in one query gets the same lookup
     // result, so the per-query multiplicity of x is fully visible inside that subset, and absent values
     // contribute nothing whether removed or not.  A removed minimizer is marked absent (hc = 0).
-    if (Mq > 0 && P.q_occ_frac > 0.0f && ix->mid_occ > 0) {
+    // The exact filter (two radix sorts + a run-length mark) as a callable: it only runs when the conservative
+    // pre-check k_qocc_check cannot rule it out, or when LRGE_HIP_QOCC_EXACT forces it (tests).
+    auto run_exact_qocc = [&]() -> int {
         StageTimer t(ctx, LRGE_T_QFILTER);
-        bool any = false;   // only queries with more minimizers than mid_occ can be affected
-        for (u32 q = 0; q < nq && !any; ++q) any = (i64)(h_mzoff[q + 1] - h_mzoff[q]) > (i64)ix->mid_occ;
-        if (any && !getenv("LRGE_HIP_QOCC_EXACT")) {   // cheap conservative check first (k_qocc_check); the env knob forces the exact pass (tests)
-            ALLOC_OR_FAIL(d_qf, sc, u32, 1);
-            HIPCHK(ctx, hipMemsetAsync(d_qf, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(k_qocc_check, dim3(nq), dim3(256), 0, ctx->stream, so.x, hc, so.mz_off, nq, ix->mid_occ, d_qf);
-            KCHK(ctx);
-            u32 qf = 0;
-            HIPCHK(ctx, hipMemcpyAsync(&qf, d_qf, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            sc.drop(d_qf);
-            any = qf != 0;
-        }
-        if (any) {
             ALLOC_OR_FAIL(flag, sc, u32, Mq); ALLOC_OR_FAIL(fpos, sc, u32, Mq); ALLOC_OR_FAIL(d_ns, sc, u32, 1);
             hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hc, Mq, flag);
             KCHK(ctx);
@@ -599,10 +591,32 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                 sc.drop(ka); sc.drop(va); sc.drop(kb); sc.drop(vb);
             }
             sc.drop(flag); sc.drop(fpos); sc.drop(d_ns);
-        }
         t.stop();
+        return LRGE_OK;
+    };
+    bool qocc_possible = false;
+    if (Mq > 0 && P.q_occ_frac > 0.0f && ix->mid_occ > 0)   // only queries with more minimizers than mid_occ can be affected
+        for (u32 q = 0; q < nq && !qocc_possible; ++q) qocc_possible = (i64)(h_mzoff[q + 1] - h_mzoff[q]) > (i64)ix->mid_occ;
+    u32 *d_qf = nullptr; u32 qf = 0;
+    if (qocc_possible) {
+        if (getenv("LRGE_HIP_QOCC_EXACT")) { rc = run_exact_qocc(); if (rc) return rc; }
+        else {
+            // cheap conservative check; its verdict travels to the host with the next sync (no extra round trip)
+            StageTimer t(ctx, LRGE_T_QFILTER);
+            d_qf = sc.get<u32>(1);
+            if (!d_qf) return LRGE_ERR_DEVICE;
+            HIPCHK(ctx, hipMemsetAsync(d_qf, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_qocc_check, dim3(nq), dim3(256), 0, ctx->stream, so.x, hc, so.mz_off, nq, ix->mid_occ, d_qf);
+            KCHK(ctx);
+            t.stop();
+        }
     }
     if (job.paf_stats) {   // per-query seed statistics only (rl, avg_k ingredients)
+        if (d_qf) {
+            HIPCHK(ctx, hipMemcpyAsync(&qf, d_qf, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (qf) { rc = run_exact_qocc(); if (rc) return rc; }
+        }
         ALLOC_OR_FAIL(d_rl, sc, i32, (size_t)nq); ALLOC_OR_FAIL(d_ss, sc, u64, (size_t)nq); ALLOC_OR_FAIL(d_nk, sc, u32, (size_t)nq);
         hipLaunchKernelGGL(k_query_paf_stats, dim3((u32)div_up(nq, 64)), dim3(64), 0, ctx->stream, so.x, so.y, hc, so.mz_off, nq, ix->mid_occ,
                            d_rl, d_ss, d_nk);
@@ -615,7 +629,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         ctx->resolve_timers();
         return LRGE_OK;
     }
-    {
+    auto run_counts = [&]() -> int {
         StageTimer t(ctx, LRGE_T_LOOKUP);
         if (Mq) {
             hipLaunchKernelGGL(k_seed_counts, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.y, Mq, sp, hs, hc, hn, hv);
@@ -633,8 +647,17 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         hipLaunchKernelGGL(k_query_anchor_totals, dim3((u32)div_up(nq, 4)), dim3(256), 0, ctx->stream, hv, so.mz_off, nq, d_qtot);
         KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(h_qtot.data(), d_qtot, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (d_qf) HIPCHK(ctx, hipMemcpyAsync(&qf, d_qf, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         t.stop();
+        return LRGE_OK;
+    };
+    rc = run_counts();
+    if (rc) return rc;
+    if (d_qf && qf) {   // the pre-check could not rule the filter out: apply it, then count again
+        d_qf = nullptr;
+        rc = run_exact_qocc(); if (rc) return rc;
+        rc = run_counts(); if (rc) return rc;
     }
 
     // ---- 4. batches ----
@@ -790,11 +813,21 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         u32 n_chained = 0; unsigned long long a_chained = 0, a_big = 0;
         {
             StageTimer t(ctx, LRGE_T_GROUP);
-            rc = compact_heads(ctx, bsc, skey, A, kl.bits_rpos, &gstart, &G);       // runs of equal (query, target, strand)
-            if (rc) return rc;
-            gflags = bsc.get<u32>((size_t)G + 1);
-            if (!gstart || !gflags) return LRGE_ERR_DEVICE;
-            HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
+            u32 *d_G = bsc.get<u32>(1);
+            if (chain_mode == 0) {
+                // group starts into an upper-bound block (one entry per anchor): the group count stays on the device
+                // until it travels to the host together with the size census -- one round trip instead of two
+                gstart = bsc.get<u32>((size_t)A + 1);
+                if (!gstart || !d_G) return LRGE_ERR_DEVICE;
+                rc = compact_heads_async(ctx, bsc, skey, A, kl.bits_rpos, gstart, d_G);   // runs of equal (query, target, strand)
+                if (rc) return rc;
+            } else {
+                rc = compact_heads(ctx, bsc, skey, A, kl.bits_rpos, &gstart, &G);
+                if (rc) return rc;
+                gflags = bsc.get<u32>((size_t)G + 1);
+                if (!gstart || !gflags) return LRGE_ERR_DEVICE;
+                HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
+            }
             if (chain_mode == 0) {
                 // groups worth chaining, sorted by size (largest first) so that k_chain_hw pairs equals
                 u32 *d_cnt = bsc.get<u32>(4 + GSZ_BINS);
@@ -802,13 +835,17 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                 if (!d_cnt || !d_anch) return LRGE_ERR_DEVICE;
                 HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, (4 + GSZ_BINS) * 4, ctx->stream));
                 HIPCHK(ctx, hipMemsetAsync(d_anch, 0, (2 + GSZ_BINS) * 8, ctx->stream));
-                hipLaunchKernelGGL(k_group_count, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, d_cnt, d_anch,
-                                   d_cnt + 4, d_anch + 2);
+                hipLaunchKernelGGL(k_group_count, dim3((u32)std::min<u64>(div_up(A, 4096), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, gstart, d_G, A, min_n,
+                                   d_cnt, d_anch, d_cnt + 4, d_anch + 2);
                 KCHK(ctx);
                 u32 h_cnt[4 + GSZ_BINS]; unsigned long long h_anch[2 + GSZ_BINS];
+                HIPCHK(ctx, hipMemcpyAsync(&G, d_G, 4, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipMemcpyAsync(h_anch, d_anch, sizeof(h_anch), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                gflags = bsc.get<u32>((size_t)G + 1);
+                if (!gflags) return LRGE_ERR_DEVICE;
+                HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
                 n_chained = h_cnt[0]; a_chained = h_anch[0];
                 {
                     // Split of the size-sorted list: groups above T anchors -> k_chain_hw (~0.55 us per anchor of latency,
@@ -900,6 +937,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                         LpgChainArgs la;
                         la.akey = skey; la.aval = sval; la.gstart = gstart; la.n_groups = G; la.n_anchors = A;
                         la.list = hw_list + n_big; la.n_list = n_chained - n_big; la.grec = ha.grec; la.tmark = ha.tmark;
+                        la.prio = (u32)env_u64("LRGE_HIP_LPG_PRIO", 1);
                         StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
                         const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !getenv("LRGE_HIP_LPG_NOTAB");
                         if (pentab) hipLaunchKernelGGL(k_chain_lpg<true>, dim3((la.n_list + 63) / 64), dim3(64), (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES,

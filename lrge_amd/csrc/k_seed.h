@@ -45,31 +45,58 @@ __global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, u64 
 }
 
 // hn = list length of a KEPT seed (0 when absent, removed by mm_seed_mz_flt, or n > mid_occ -> flt),
-// hv = hits that survive skip_seed.
+// hv = hits that survive skip_seed.  Without name checks hv = hn.  With them (AVA, or sets that share reads) one
+// wavefront owns 64 consecutive minimizers and walks the concatenation of their hit lists 64 hits at a time, like
+// k_expand: the position-list reads are consecutive across the wave and every lane does useful work (one lane per
+// minimizer looping over its own list diverged on the list lengths and gathered 8 bytes per lane per step).
 __global__ __launch_bounds__(256) void k_seed_counts(const u64 *__restrict__ qy, u64 n_mz, SeedParams sp,
                                                      const u32 *__restrict__ hs, const u32 *__restrict__ hc,
                                                      u32 *__restrict__ hn, u32 *__restrict__ hv) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_mz) return;
-    const u32 c = hc[i];
+    __shared__ u32 kept[4][64];
+    const u32 lane = lane_id(), w = threadIdx.x >> 6;
+    const u64 w0 = ((u64)blockIdx.x * (blockDim.x >> 6) + w) * 64;
+    if (w0 >= n_mz) return;
+    const u64 i = w0 + lane;
+    const bool in = i < n_mz;
+    const u32 c = in ? hc[i] : 0;
     const u32 n = (c != 0 && (i64)c <= (i64)sp.mid_occ) ? c : 0;   // m[i].n > max_occ -> flt
-    u32 v = n;
-    if (n && sp.check_names) {
-        const u64 y = qy[i], st = hs[i];
-        const u32 q = (u32)(y >> 32), qpos = (u32)y >> 1;
-        const u32 qr = sp.q_rank[q], ql = sp.q_len[q];
-        v = 0;
-        for (u32 j = 0; j < n; ++j) {
-            const u64 r = index_y(sp, st + j);
-            const u32 rid = (u32)(r >> 32);
+    if (!sp.check_names) {
+        if (in) { hn[i] = n; hv[i] = n; }
+        return;
+    }
+    const u32 incl = wave_incl_scan_u32(n);
+    const u32 total = (u32)__builtin_amdgcn_readlane((i32)incl, 63);
+    const u32 rs = incl - n;
+    u32 m_st = 0, m_qpos = 0, m_ql = 0, m_qr = 0;
+    if (n) {
+        const u64 y = qy[i];
+        const u32 q = (u32)(y >> 32);
+        m_qpos = (u32)y >> 1; m_ql = sp.q_len[q]; m_qr = sp.q_rank[q]; m_st = hs[i];
+    }
+    kept[w][lane] = 0;
+    // (a wavefront only touches its own row: program order is enough, no barrier)
+    for (u32 c0 = 0; c0 < total; c0 += 64) {
+        const u32 r = c0 + lane;
+        u32 l = 0;
+#pragma unroll
+        for (u32 step = 32; step > 0; step >>= 1) {
+            const u32 v = (u32)__shfl((i32)rs, (int)(l + step), 64);
+            l = v <= r ? l + step : l;
+        }
+        const u32 j = r - (u32)__shfl((i32)rs, (int)l, 64);
+        const u32 st = (u32)__shfl((i32)m_st, (int)l, 64), qpos = (u32)__shfl((i32)m_qpos, (int)l, 64);
+        const u32 ql = (u32)__shfl((i32)m_ql, (int)l, 64), qr = (u32)__shfl((i32)m_qr, (int)l, 64);
+        if (r < total) {
+            const u64 h = index_y(sp, (u64)st + j);
+            const u32 rid = (u32)(h >> 32);
             const u32 tr = sp.t_rank[rid];
             bool skip = false;
-            if (qr == tr && sp.t_len[rid] == ql && ((u32)r >> 1) == qpos) skip = true;  // NO_DIAG, exact diagonal
+            if (qr == tr && sp.t_len[rid] == ql && ((u32)h >> 1) == qpos) skip = true;  // NO_DIAG, exact diagonal
             if (sp.no_dual && qr > tr) skip = true;                                     // NO_DUAL, cmp > 0
-            v += skip ? 0 : 1;
+            if (!skip) atomicAdd(&kept[w][l], 1u);
         }
     }
-    hn[i] = n; hv[i] = v;
+    if (in) { hn[i] = n; hv[i] = kept[w][lane]; }
 }
 
 // per-query sum of hv (one wave per query)

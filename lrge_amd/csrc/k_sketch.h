@@ -133,9 +133,13 @@ __device__ __forceinline__ void sketch_chunk(const u64 *pack, const u32 *nmask, 
     MinWindow<W> win; win.init();
     u64 kf = 0, kr = 0;
     int l = 0;
-    // HPC run-length queue of the last <=K runs (power-of-two ring)
-    u8 hq[HPC ? 32 : 1]; int hq_front = 0, hq_count = 0, kmer_span = 0;
-    (void)hq; (void)hq_front; (void)hq_count;
+    // HPC: lengths of the last K runs as a byte shift register in VGPRs (a ring indexed at run time would live
+    // in scratch memory); byte 0 = newest, byte K-1 = the run that leaves the k-mer at the next push, 0 while
+    // fewer than K runs are held
+    static_assert(K <= 24, "run-length shift register holds 24 runs");
+    u32 hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0, hq4 = 0, hq5 = 0;
+    int kmer_span = 0;
+    (void)hq0; (void)hq1; (void)hq2; (void)hq3; (void)hq4; (void)hq5;
 
     // ---- find the replay start h: HALO steps before the first owned step ----
     i32 h;
@@ -176,9 +180,14 @@ __device__ __forceinline__ void sketch_chunk(const u64 *pack, const u32 *nmask, 
                 while (i + run < len && rd.get(i + run) == c) ++run;
                 i += run - 1;  // i = last base of the run
                 int rl = run > 255 ? 255 : run;  // spans >= 256 invalidate the k-mer anyway
-                hq[(hq_count++ + hq_front) & 31] = (u8)rl;
-                kmer_span += rl;
-                if (hq_count > K) { kmer_span -= hq[hq_front]; hq_front = (hq_front + 1) & 31; --hq_count; }
+                {
+                    constexpr int OW = (K - 1) / 4, OB = ((K - 1) % 4) * 8;      // where byte K-1 sits
+                    const u32 ow = OW == 0 ? hq0 : OW == 1 ? hq1 : OW == 2 ? hq2 : OW == 3 ? hq3 : OW == 4 ? hq4 : hq5;
+                    const int oldest = (int)((ow >> OB) & 0xff);
+                    hq5 = hq5 << 8 | hq4 >> 24; hq4 = hq4 << 8 | hq3 >> 24; hq3 = hq3 << 8 | hq2 >> 24;
+                    hq2 = hq2 << 8 | hq1 >> 24; hq1 = hq1 << 8 | hq0 >> 24; hq0 = hq0 << 8 | (u32)rl;
+                    kmer_span += rl - oldest;
+                }
             } else kmer_span = l + 1 < K ? l + 1 : K;
             kf = (kf << 2 | c) & mask;
             kr = (kr >> 2) | (u64)(3 ^ c) << shift1;
@@ -189,7 +198,7 @@ __device__ __forceinline__ void sketch_chunk(const u64 *pack, const u32 *nmask, 
                 ix = mm_hash64(z ? kr : kf, mask) << 8 | (u64)kmer_span;
                 iy = (u64)rid << 32 | (u64)(u32)i << 1 | z;
             }
-        } else { l = 0; hq_count = hq_front = 0; kmer_span = 0; }
+        } else { l = 0; hq0 = hq1 = hq2 = hq3 = hq4 = hq5 = 0; kmer_span = 0; }
         const bool owned = step_start >= s;
         win.template step<K>(ix, iy, l, [&](u64 x, u64 y) { if (owned) emit(x, y); });
         ++i;

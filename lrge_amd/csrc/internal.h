@@ -85,6 +85,7 @@ struct lrge_hip_ctx {
     float ms[LRGE_T_N];
     u64 counters[LRGE_C_N];
     int n_cu = 256;
+    bool lsort_ok[3] = {false, false, false};   // which k_seg_sort_local variants this device can launch
     std::vector<struct TimerRec> timers;     // pending event pairs of the current call
     std::vector<hipEvent_t> event_pool;      // recycled events
     hipEvent_t get_event() {

@@ -195,7 +195,9 @@ static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32
 // each be sorted in place; every tile lies inside one segment and the histogram is laid out
 // [segment][digit][tile of the segment], so that ONE exclusive scan over it yields, per (tile, digit), the
 // global destination of that digit's run -- segments never mix and the segment id costs no sort pass.
-struct SegTile { u32 start, len, hbase, hstride, seg, pad; };   // hist index of digit d: hbase + d * hstride; seg = segment id
+// hist index of digit d: hbase + d * hstride; seg = segment id; delta = items in front of the segment that are NOT covered by
+// tiles of this sort (segments sorted elsewhere): the scanned histogram only counts tiled items
+struct SegTile { u32 start, len, hbase, hstride, seg, delta; };
 
 // Packed anchors (count-only runs): one u64 = [self 1 | span 8 | qpos bits_qy | sort bits sb], sorted KEYS-ONLY on the
 // low sb bits; the last scatter pass unpacks every record into the (key, value) pair the chain kernels read
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         u32 dstart = inc - tot;
         for (u32 ww = 0; ww < w; ++ww) dstart += wtot[ww];
         const u64 hi = SEG ? (u64)tiles[blockIdx.x].hbase + (u64)d * tiles[blockIdx.x].hstride : (u64)d * nb + blockIdx.x;
-        gbase[d] = hist_scanned[hi] - dstart;
+        gbase[d] = hist_scanned[hi] + (SEG ? tiles[blockIdx.x].delta : 0u) - dstart;
         u32 run = dstart;
 #pragma unroll
         for (int ww = 0; ww < RS_WAVES; ++ww) { cnt[ww][d] = run; run += c[ww]; }
@@ -538,4 +540,91 @@ static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n,
     sc.drop(bc); sc.drop(d_tot);
     *d_starts = st;
     return LRGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Segment-local sort of packed anchors: ONE workgroup sorts one whole segment (a query's anchors) inside LDS, all
+// radix passes, and writes the unpacked (key, value) pairs -- the data cross HBM once in (8 B) and once out (16 B)
+// instead of once per pass plus a histogram read per pass.  Same stable LSD passes, same ranking (ballot digit
+// matching + per-wave counters) as k_rs_scatter, so the resulting order is identical to the tiled global sort.
+// Segments above the variant's capacity stay on the global segmented sort.
+// ------------------------------------------------------------------------------------------
+struct SegDesc { u32 start, len, seg, pad; };
+#define LSORT_BYTES(THREADS, ITEMS) ((size_t)(THREADS) * (ITEMS) * 8 + (size_t)((THREADS) / 64) * 256 * 4 + 16)
+
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_seg_sort_local(const u64 *__restrict__ pk_in, u64 *__restrict__ out_k, u64 *__restrict__ out_v,
+                                                            const SegDesc *__restrict__ segs, UnpackParams up, int nbits) {
+    constexpr int WAVES = THREADS / 64, CAP = THREADS * ITEMS;
+    extern __shared__ u64 lsort_mem[];
+    u64 *stage = lsort_mem;                                   // [CAP]
+    u32 *cnt = (u32 *)(lsort_mem + CAP);                      // [WAVES][256]
+    u32 *wtot = cnt + WAVES * 256;                            // [4]: totals of the four 64-digit groups
+    const SegDesc sd = segs[blockIdx.x];
+    const u32 n = sd.len;
+    const u64 *src = pk_in + sd.start;
+    const u32 w = threadIdx.x >> 6, lane = lane_id();
+    const u32 l0 = w * (ITEMS * 64) + lane;
+    const u64 lt = lanemask_lt();
+    u64 k[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n ? src[l0 + (u32)r * 64] : ~0ULL;
+    const int passes = nbits > 0 ? (nbits + 7) / 8 : 1;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * 8;
+        const u32 dmask = nbits - shift >= 8 ? 255u : (1u << (nbits - shift)) - 1u;
+        for (u32 i = threadIdx.x; i < (u32)WAVES * 256; i += THREADS) cnt[i] = 0;
+        __syncthreads();
+        u32 rank[ITEMS];
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const u32 d = (u32)(k[r] >> shift) & dmask;
+            u64 m = ~0ULL;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const u64 bal = __ballot((d >> b) & 1);
+                m &= ((d >> b) & 1) ? bal : ~bal;
+            }
+            const u32 before = (u32)__popcll(m & lt);
+            const u32 leader = (u32)__ffsll((unsigned long long)m) - 1;
+            u32 old = 0;
+            if (lane == leader) { old = cnt[w * 256 + d]; cnt[w * 256 + d] = old + (u32)__popcll(m); }
+            old = __shfl(old, leader, 64);
+            rank[r] = old + before;
+        }
+        __syncthreads();
+        // digit totals -> exclusive scan over digits -> start of every (wave, digit) run (threads 0..255 = wavefronts 0..3)
+        u32 tot = 0, inc = 0;
+        if (threadIdx.x < 256) {
+            for (int ww = 0; ww < WAVES; ++ww) tot += cnt[ww * 256 + threadIdx.x];
+            inc = wave_incl_scan_u32(tot);
+            if (lane == 63) wtot[threadIdx.x >> 6] = inc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            u32 run = inc - tot;
+            for (u32 g = 0; g < (threadIdx.x >> 6); ++g) run += wtot[g];
+            for (int ww = 0; ww < WAVES; ++ww) { const u32 c = cnt[ww * 256 + threadIdx.x]; cnt[ww * 256 + threadIdx.x] = run; run += c; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const u32 d = (u32)(k[r] >> shift) & dmask;
+            stage[cnt[w * 256 + d] + rank[r]] = k[r];
+        }
+        __syncthreads();
+        if (p + 1 < passes) {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) k[r] = stage[l0 + (u32)r * 64];
+            __syncthreads();
+        }
+    }
+    // unpack and write, coalesced
+    const u64 seg = (u64)sd.seg << up.sh_q;
+    const u64 smask = (1ULL << up.sb) - 1, qmask = (1ULL << up.bits_qy) - 1;
+    for (u32 pp = threadIdx.x; pp < n; pp += THREADS) {
+        const u64 pk = stage[pp];
+        out_k[sd.start + pp] = seg | (pk & smask);
+        out_v[sd.start + pp] = ((pk >> (up.sb + up.bits_qy + 8)) & 1) << 43 | ((pk >> (up.sb + up.bits_qy)) & 0xff) << 32 | ((pk >> up.sb) & qmask);
+    }
 }

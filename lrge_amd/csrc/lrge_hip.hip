@@ -46,6 +46,13 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    // segment-local sort variants: the two larger ones need more than the default 64 KB of LDS per workgroup
+    ctx->lsort_ok[0] = true;
+    ctx->lsort_ok[1] = ctx->lsort_ok[0] && hipFuncSetAttribute((const void *)k_seg_sort_local<512, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                               (int)LSORT_BYTES(512, 16)) == hipSuccess;
+    ctx->lsort_ok[2] = ctx->lsort_ok[0] && hipFuncSetAttribute((const void *)k_seg_sort_local<1024, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                               (int)LSORT_BYTES(1024, 16)) == hipSuccess;
+    (void)hipGetLastError();
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
     memset(ctx->counters, 0, sizeof(ctx->counters));
@@ -695,6 +702,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     }
 
     std::vector<SegTile> h_tiles;   // per batch; lives until the batch's next host sync (the async H2D copy reads it)
+    std::vector<SegDesc> h_local[3];
     u32 q0 = job.dump_anchors ? job.dump_query : 0;
     const u32 q_end = job.dump_anchors ? job.dump_query + 1 : nq;
     while (q0 < q_end) {
@@ -733,13 +741,20 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             // the expansion emits the anchors query by query, so only (target, strand, position) need sorting,
             // inside every query's segment: the query bits cost no radix pass (SegTile, k_prims.h)
             h_tiles.clear();
+            for (auto &v : h_local) v.clear();
             {
-                u32 off = 0, tb = 0;
+                u32 off = 0, tb = 0, n_local = 0;
+                const bool local_ok = !getenv("LRGE_HIP_NO_LOCAL_SORT");
                 for (u32 q = q0; q < q1; ++q) {
-                    const u32 c = h_qtot[q], nt_q = (u32)div_up((u64)c, RS_TILE);
+                    const u32 c = h_qtot[q];
+                    if (packed && c) {   // segment-local sort classes (capacity 2048 / 8192 / 16384 anchors)
+                        const int cls = c <= 2048 ? 0 : c <= 8192 ? 1 : c <= 16384 ? 2 : 3;
+                        if (cls < 3 && local_ok && ctx->lsort_ok[cls]) { h_local[cls].push_back(SegDesc{off, c, q - q0, 0}); off += c; n_local += c; continue; }
+                    }
+                    const u32 nt_q = (u32)div_up((u64)c, RS_TILE);
                     for (u32 lt = 0; lt < nt_q; ++lt) {
                         SegTile t; t.start = off + lt * RS_TILE; t.len = std::min<u32>(RS_TILE, c - lt * RS_TILE);
-                        t.hbase = 256u * tb + lt; t.hstride = nt_q; t.seg = q - q0; t.pad = 0;
+                        t.hbase = 256u * tb + lt; t.hstride = nt_q; t.seg = q - q0; t.delta = n_local;
                         h_tiles.push_back(t);
                     }
                     off += c; tb += nt_q;
@@ -750,6 +765,29 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             HIPCHK(ctx, hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
             if (packed) {
                 UnpackParams up; up.sb = kl.sh_q(); up.bits_qy = bits_qy; up.sh_q = kl.sh_q(); up.dmask = 255;
+                // segments that fit a workgroup's LDS are sorted there in one kernel (k_seg_sort_local: 8 B in, 16 B out
+                // per anchor); only the larger ones take the tiled global passes
+                if (h_local[0].size()) {
+                    SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[0].size() * 4);
+                    if (!d) return LRGE_ERR_DEVICE;
+                    HIPCHK(ctx, hipMemcpyAsync(d, h_local[0].data(), h_local[0].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
+                    hipLaunchKernelGGL((k_seg_sort_local<256, 8>), dim3((u32)h_local[0].size()), dim3(256), LSORT_BYTES(256, 8), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
+                    KCHK(ctx);
+                }
+                if (h_local[1].size()) {
+                    SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[1].size() * 4);
+                    if (!d) return LRGE_ERR_DEVICE;
+                    HIPCHK(ctx, hipMemcpyAsync(d, h_local[1].data(), h_local[1].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
+                    hipLaunchKernelGGL((k_seg_sort_local<512, 16>), dim3((u32)h_local[1].size()), dim3(512), LSORT_BYTES(512, 16), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
+                    KCHK(ctx);
+                }
+                if (h_local[2].size()) {
+                    SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[2].size() * 4);
+                    if (!d) return LRGE_ERR_DEVICE;
+                    HIPCHK(ctx, hipMemcpyAsync(d, h_local[2].data(), h_local[2].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
+                    hipLaunchKernelGGL((k_seg_sort_local<1024, 16>), dim3((u32)h_local[2].size()), dim3(1024), LSORT_BYTES(1024, 16), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
+                    KCHK(ctx);
+                }
                 rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up);
                 if (rc) return rc;
                 skey = aval; sval = aval2;

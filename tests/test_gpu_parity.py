@@ -257,6 +257,12 @@ def test_packed_anchor_path_is_invisible(ctx, oracle, tiny_ont, monkeypatch, mod
     monkeypatch.setenv("LRGE_HIP_NO_PACKED", "1")
     b = run()
     assert np.array_equal(np.asarray(a), np.asarray(b))
+    monkeypatch.setenv("LRGE_HIP_NO_PACKED", "0")
+    monkeypatch.setenv("LRGE_HIP_NO_LOCAL_SORT", "1")        # packed anchors through the tiled global sort only
+    d = run()
+    assert np.array_equal(np.asarray(a), np.asarray(d))
+    monkeypatch.delenv("LRGE_HIP_NO_LOCAL_SORT")
+    monkeypatch.setenv("LRGE_HIP_NO_PACKED", "1")
     monkeypatch.setenv("LRGE_HIP_NO_PACKED_INDEX", "1")      # and the (hash, y) pair index
     from lrge_amd import engine
     ix2 = engine.Index(ctx, Td, PRESETS["ont"])

@@ -20,20 +20,7 @@
 
 __device__ __forceinline__ u64 ht_home(u64 key, u64 cap) { return __umul64hi(__builtin_bswap64(key), cap); }
 
-// kshift: the stream holds packed entries, key = entry >> kshift (0 for plain keys)
-__global__ void k_run_heads(const u64 *__restrict__ skey, u64 n, u32 *__restrict__ head, u32 kshift) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    head[i] = (i == 0 || (skey[i] >> kshift) != (skey[i - 1] >> kshift)) ? 1u : 0u;
-}
-
-// run_start[run_id] = i for every head (run_id from the exclusive scan of head flags)
-__global__ void k_run_starts(const u32 *__restrict__ head, const u32 *__restrict__ run_id, u64 n,
-                             u32 *__restrict__ run_start) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (head[i]) run_start[run_id[i]] = (u32)i;
-}
+// (run heads of the sorted stream: compact_heads() in k_prims.h; kshift = bits below the hash in a packed entry)
 
 #define OCC_LDS_BINS 2048
 #define PLACE_THREADS 256

@@ -376,8 +376,9 @@ static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u6
 
 // Segmented keys-only sort of packed anchors on their low `nbits` bits (pk0/pk1 ping-pong); the last pass unpacks
 // into (out_k, out_v).  See UnpackParams.
+// n_items = items covered by the tiles (for the byte counters).
 static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *pk1, u64 *out_k, u64 *out_v, u64 n, int nbits,
-                                 const SegTile *d_tiles, u32 n_tiles, UnpackParams up) {
+                                 const SegTile *d_tiles, u32 n_tiles, UnpackParams up, u64 n_items) {
     if (n == 0 || n_tiles == 0) return LRGE_OK;
     if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
     const u32 nb = n_tiles;
@@ -400,8 +401,8 @@ static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *
             KCHK(ctx);
             ts.stop();
             ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
-            ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;
-            ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (p + 1 < passes ? 16 : 24) * n;
+            ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n_items;
+            ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (p + 1 < passes ? 16 : 24) * n_items;
         }
         u64 *t = ki; ki = ko; ko = t;
     }

@@ -282,11 +282,7 @@ __global__ void k_query_paf_stats(const u64 *__restrict__ qx, const u64 *__restr
 // ------------------------------------------------------------------------------------------
 // groups on the sorted anchors: a group = one (query, target, strand)
 // ------------------------------------------------------------------------------------------
-__global__ void k_group_heads(const u64 *__restrict__ skey, u64 n, u32 bits_rpos, u32 *__restrict__ head) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    head[i] = (i == 0 || (skey[i] >> bits_rpos) != (skey[i - 1] >> bits_rpos)) ? 1u : 0u;
-}
+// (group boundaries: compact_heads() in k_prims.h on key >> bits_rpos)
 
 #define N_BINS 5
 #define GB_CHUNK 8192   // groups per block in k_group_bin

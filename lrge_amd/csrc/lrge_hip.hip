@@ -703,6 +703,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
 
     std::vector<SegTile> h_tiles;   // per batch; lives until the batch's next host sync (the async H2D copy reads it)
     std::vector<SegDesc> h_local[3];
+    u32 n_local_items = 0;         // anchors of the batch sorted by k_seg_sort_local
     u32 q0 = job.dump_anchors ? job.dump_query : 0;
     const u32 q_end = job.dump_anchors ? job.dump_query + 1 : nq;
     while (q0 < q_end) {
@@ -743,7 +744,8 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             h_tiles.clear();
             for (auto &v : h_local) v.clear();
             {
-                u32 off = 0, tb = 0, n_local = 0;
+                u32 off = 0, tb = 0, &n_local = n_local_items;
+                n_local = 0;
                 const bool local_ok = !getenv("LRGE_HIP_NO_LOCAL_SORT");
                 for (u32 q = q0; q < q1; ++q) {
                     const u32 c = h_qtot[q];
@@ -788,7 +790,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                     hipLaunchKernelGGL((k_seg_sort_local<1024, 16>), dim3((u32)h_local[2].size()), dim3(1024), LSORT_BYTES(1024, 16), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
                     KCHK(ctx);
                 }
-                rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up);
+                rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up, A - n_local_items);
                 if (rc) return rc;
                 skey = aval; sval = aval2;
                 bsc.drop((u32 *)d_tiles);

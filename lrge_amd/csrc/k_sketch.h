@@ -8,6 +8,7 @@
 // for the steps it owns.  The w-entry window lives in registers as a shift register (w is a
 // template constant, so every index is static), which replaces the scalar code's ring buffer.
 #pragma once
+#include <type_traits>
 #include "internal.h"
 #include "k_prims.h"
 
@@ -68,6 +69,19 @@ __device__ __forceinline__ u64 mm_hash64(u64 key, u64 mask) {  // mm2:sketch.c:h
     return key;
 }
 
+// the same mixer in 32-bit arithmetic: exact whenever the mask has <= 32 bits (every step is masked, so only the
+// low bits of each sum matter; k = 15 -> 30 bits)
+__device__ __forceinline__ u32 mm_hash32(u32 key, u32 mask) {
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
 struct BaseReader {  // sequential reader over the packed image of one read
     const u64 *pack; const u32 *nmask;
     u64 wbase; u64 w; u32 m; i32 cur_word;
@@ -80,40 +94,44 @@ struct BaseReader {  // sequential reader over the packed image of one read
     }
 };
 
-template <int W>
+// XT / YT: u64 for the general (x, y) pairs; u32 for the narrow form (non-HPC, 2k <= 32), where x is the bare hash
+// (the span is always k for a valid k-mer, so the order of hash<<8|span is the order of the hash) and y is
+// pos<<1|strand (the read id is constant inside a read)
+template <int W, typename XT = u64, typename YT = u64>
 struct MinWindow {  // shift-register form of mm_sketch's ring buffer + running minimum
-    u64 wx[W], wy[W];
-    u64 minx, miny;
+    static constexpr XT NONE = (XT)~(XT)0;
+    XT wx[W]; YT wy[W];
+    XT minx; YT miny;
     int mi;  // index of the current minimum inside the window (W-1 = newest), -1 = evicted
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int j = 0; j < W; ++j) { wx[j] = ~0ULL; wy[j] = ~0ULL; }
-        minx = miny = ~0ULL; mi = 0;
+        for (int j = 0; j < W; ++j) { wx[j] = NONE; wy[j] = (YT)~(YT)0; }
+        minx = NONE; miny = (YT)~(YT)0; mi = 0;
     }
     // One step of the scalar loop after `info` was computed.  l is the valid-base count AFTER this
     // step's increment.  emit(x,y) is called in exactly the scalar order.
     template <int K, typename Emit>
-    __device__ __forceinline__ void step(u64 ix, u64 iy, int l, Emit &&emit) {
+    __device__ __forceinline__ void step(XT ix, YT iy, int l, Emit &&emit) {
         const bool evicted = (mi == 0);
 #pragma unroll
         for (int j = 0; j + 1 < W; ++j) { wx[j] = wx[j + 1]; wy[j] = wy[j + 1]; }
         wx[W - 1] = ix; wy[W - 1] = iy;
         mi -= 1;
-        if (l == W + K - 1 && minx != ~0ULL) {  // first full window: flush identical minima
+        if (l == W + K - 1 && minx != NONE) {  // first full window: flush identical minima
 #pragma unroll
             for (int j = 0; j + 1 < W; ++j)
                 if (minx == wx[j] && wy[j] != miny) emit(wx[j], wy[j]);
         }
         if (ix <= minx) {
-            if (l >= W + K && minx != ~0ULL) emit(minx, miny);
+            if (l >= W + K && minx != NONE) emit(minx, miny);
             minx = ix; miny = iy; mi = W - 1;
         } else if (evicted) {
-            if (l >= W + K - 1 && minx != ~0ULL) emit(minx, miny);
-            minx = ~0ULL;
+            if (l >= W + K - 1 && minx != NONE) emit(minx, miny);
+            minx = NONE;
 #pragma unroll
             for (int j = 0; j < W; ++j)
                 if (minx >= wx[j]) { minx = wx[j]; miny = wy[j]; mi = j; }
-            if (l >= W + K - 1 && minx != ~0ULL) {
+            if (l >= W + K - 1 && minx != NONE) {
 #pragma unroll
                 for (int j = 0; j < W; ++j)
                     if (minx == wx[j] && miny != wy[j]) emit(wx[j], wy[j]);
@@ -129,9 +147,16 @@ __device__ __forceinline__ void sketch_chunk(const u64 *pack, const u32 *nmask, 
     constexpr u64 mask = (1ULL << (2 * K)) - 1;
     constexpr int shift1 = 2 * (K - 1);
     constexpr int HALO = W + K - 1;
+    constexpr bool NARROW = !HPC && 2 * K <= 32;
+    using XT = typename std::conditional<NARROW, u32, u64>::type;
     BaseReader rd; rd.init(pack, nmask, word_base);
-    MinWindow<W> win; win.init();
-    u64 kf = 0, kr = 0;
+    MinWindow<W, XT, XT> win; win.init();
+    XT kf = 0, kr = 0;
+    // narrow values -> the (x, y) pair the callers expect
+    auto emit_xy = [&](XT x, XT y) {
+        if (NARROW) emit((u64)x << 8 | (u64)K, (u64)rid << 32 | (u64)y);
+        else emit((u64)x, (u64)y);
+    };
     int l = 0;
     // HPC: lengths of the last K runs as a byte shift register in VGPRs (a ring indexed at run time would live
     // in scratch memory); byte 0 = newest, byte K-1 = the run that leaves the k-mer at the next push, 0 while
@@ -173,7 +198,7 @@ __device__ __forceinline__ void sketch_chunk(const u64 *pack, const u32 *nmask, 
         if (i >= e) break;  // steps starting at or beyond e belong to later chunks
         const i32 step_start = i;
         u32 c = rd.get(i);
-        u64 ix = ~0ULL, iy = ~0ULL;
+        XT ix = (XT)~(XT)0, iy = (XT)~(XT)0;
         if (c < 4) {
             if (HPC) {
                 i32 run = 1;
@@ -189,21 +214,21 @@ __device__ __forceinline__ void sketch_chunk(const u64 *pack, const u32 *nmask, 
                     kmer_span += rl - oldest;
                 }
             } else kmer_span = l + 1 < K ? l + 1 : K;
-            kf = (kf << 2 | c) & mask;
-            kr = (kr >> 2) | (u64)(3 ^ c) << shift1;
+            kf = (XT)((kf << 2 | c) & (XT)mask);
+            kr = (XT)((kr >> 2) | (XT)(3 ^ c) << shift1);
             // K is odd for both presets, so kf == kr (strand-symmetric k-mer) cannot happen
             const u32 z = kf < kr ? 0 : 1;
             ++l; if (l > W + K) l = W + K;  // only thresholds up to W+K are ever tested
             if (l >= K && kmer_span < 256) {
-                ix = mm_hash64(z ? kr : kf, mask) << 8 | (u64)kmer_span;
-                iy = (u64)rid << 32 | (u64)(u32)i << 1 | z;
+                if (NARROW) { ix = (XT)mm_hash32((u32)(z ? kr : kf), (u32)mask); iy = (XT)((u32)i << 1 | z); }   // (kmer_span == K here)
+                else { ix = (XT)(mm_hash64(z ? kr : kf, mask) << 8 | (u64)kmer_span); iy = (XT)((u64)rid << 32 | (u64)(u32)i << 1 | z); }
             }
         } else { l = 0; hq0 = hq1 = hq2 = hq3 = hq4 = hq5 = 0; kmer_span = 0; }
         const bool owned = step_start >= s;
-        win.template step<K>(ix, iy, l, [&](u64 x, u64 y) { if (owned) emit(x, y); });
+        win.template step<K>(ix, iy, l, [&](XT x, XT y) { if (owned) emit_xy(x, y); });
         ++i;
     }
-    if (e == len && win.minx != ~0ULL) emit(win.minx, win.miny);  // final flush by the last chunk
+    if (e == len && win.minx != win.NONE) emit_xy(win.minx, win.miny);  // final flush by the last chunk
 }
 
 // HPC clamps run lengths to 255 in the queue; a clamped run makes kmer_span >= 255+... only when

@@ -571,33 +571,33 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     // pre-check k_qocc_check cannot rule it out, or when LRGE_HIP_QOCC_EXACT forces it (tests).
     auto run_exact_qocc = [&]() -> int {
         StageTimer t(ctx, LRGE_T_QFILTER);
-            ALLOC_OR_FAIL(flag, sc, u32, Mq); ALLOC_OR_FAIL(fpos, sc, u32, Mq); ALLOC_OR_FAIL(d_ns, sc, u32, 1);
-            hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hc, Mq, flag);
+        ALLOC_OR_FAIL(flag, sc, u32, Mq); ALLOC_OR_FAIL(fpos, sc, u32, Mq); ALLOC_OR_FAIL(d_ns, sc, u32, 1);
+        hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hc, Mq, flag);
+        KCHK(ctx);
+        rc = scan_exclusive_u32(ctx, sc, flag, fpos, Mq, d_ns);
+        if (rc) return rc;
+        u32 Ms = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&Ms, d_ns, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (Ms > (u32)ix->mid_occ) {
+            ALLOC_OR_FAIL(ka, sc, u64, Ms); ALLOC_OR_FAIL(va, sc, u64, Ms);
+            ALLOC_OR_FAIL(kb, sc, u64, Ms); ALLOC_OR_FAIL(vb, sc, u64, Ms);
+            hipLaunchKernelGGL(k_qocc_keys, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, so.y, flag, fpos, Mq, ka, va);
             KCHK(ctx);
-            rc = scan_exclusive_u32(ctx, sc, flag, fpos, Mq, d_ns);
+            u64 *rk, *rv;
+            rc = radix_sort_pairs(ctx, sc, ka, va, kb, vb, Ms, 0, 2 * P.k + 8, &rk, &rv);   // by x
             if (rc) return rc;
-            u32 Ms = 0;
-            HIPCHK(ctx, hipMemcpyAsync(&Ms, d_ns, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            if (Ms > (u32)ix->mid_occ) {
-                ALLOC_OR_FAIL(ka, sc, u64, Ms); ALLOC_OR_FAIL(va, sc, u64, Ms);
-                ALLOC_OR_FAIL(kb, sc, u64, Ms); ALLOC_OR_FAIL(vb, sc, u64, Ms);
-                hipLaunchKernelGGL(k_qocc_keys, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, so.y, flag, fpos, Mq, ka, va);
-                KCHK(ctx);
-                u64 *rk, *rv;
-                rc = radix_sort_pairs(ctx, sc, ka, va, kb, vb, Ms, 0, 2 * P.k + 8, &rk, &rv);   // by x
-                if (rc) return rc;
-                u64 *ok = (rk == ka) ? kb : ka, *ov = (rv == va) ? vb : va;
-                u64 *rk2, *rv2;
-                // then (stable) by query id held in bits [32, 32+bits) of the value: swap roles
-                rc = radix_sort_pairs(ctx, sc, rv, rk, ov, ok, Ms, 32, (int)ceil_log2_u64((u64)nq + 1), &rk2, &rv2);
-                if (rc) return rc;
-                hipLaunchKernelGGL(k_qocc_mark, dim3((u32)div_up(Ms, 256)), dim3(256), 0, ctx->stream, rv2 /* x */, rk2 /* (q,idx) */,
-                                   (u64)Ms, so.mz_off, ix->mid_occ, P.q_occ_frac, hc);
-                KCHK(ctx);
-                sc.drop(ka); sc.drop(va); sc.drop(kb); sc.drop(vb);
-            }
-            sc.drop(flag); sc.drop(fpos); sc.drop(d_ns);
+            u64 *ok = (rk == ka) ? kb : ka, *ov = (rv == va) ? vb : va;
+            u64 *rk2, *rv2;
+            // then (stable) by query id held in bits [32, 32+bits) of the value: swap roles
+            rc = radix_sort_pairs(ctx, sc, rv, rk, ov, ok, Ms, 32, (int)ceil_log2_u64((u64)nq + 1), &rk2, &rv2);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_qocc_mark, dim3((u32)div_up(Ms, 256)), dim3(256), 0, ctx->stream, rv2 /* x */, rk2 /* (q,idx) */,
+                               (u64)Ms, so.mz_off, ix->mid_occ, P.q_occ_frac, hc);
+            KCHK(ctx);
+            sc.drop(ka); sc.drop(va); sc.drop(kb); sc.drop(vb);
+        }
+        sc.drop(flag); sc.drop(fpos); sc.drop(d_ns);
         t.stop();
         return LRGE_OK;
     };

@@ -140,8 +140,11 @@ int  lrge_hip_overlap_inverse(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
                               const lrge_hip_seqset *streamed, const lrge_hip_params *p,
                               uint32_t *counts);
 /*
- * All-vs-all (dual = no): `ix` must index `reads` itself.  counts[i] = symmetric overlap count
- * (ava.rs:271-306).  Duplicate identifiers: LRGE_ERR_DUPLICATE_ID.
+ * All-vs-all (dual = no): `reads` is the indexed set itself, or a SHARD of it (any subset, uploaded with name ranks
+ * taken over the whole set; multi-GPU runs give every rank one shard).  counts[] has one entry per INDEXED read:
+ * the symmetric overlap count (ava.rs:271-306) when `reads` is the whole set, this call's contribution to it
+ * when it is a shard -- the sum over a partition of the reads is the all-vs-all result (NO_DUAL lets exactly one
+ * read of every pair see it).  Duplicate identifiers: LRGE_ERR_DUPLICATE_ID.
  */
 int  lrge_hip_overlap_ava(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
                           const lrge_hip_seqset *reads, const lrge_hip_params *p,

@@ -482,6 +482,8 @@ struct CountParams {
     KeyLayout kl; u32 q0; int mode;
     const u32 *q_rank, *t_rank;   // may be null (then names are all distinct)
     int t_dup;                    // the indexed set holds repeated identifiers (forward mode only)
+    const u32 *q_map;             // all-vs-all over a SHARD of the reads: query index -> index of the same read in the
+                                  // indexed set (null: the query set is the indexed set itself)
 };
 
 __global__ void k_count(const u64 *__restrict__ skey, const u32 *__restrict__ gstart, const u32 *__restrict__ gflags,
@@ -518,7 +520,7 @@ __global__ void k_count(const u64 *__restrict__ skey, const u32 *__restrict__ gs
     else if (cp.mode == 1) atomicAdd(&counts[rid], 1u);
     else {
         if (cp.q_rank && cp.t_rank && cp.q_rank[q] == cp.t_rank[rid]) return;  // &rid == tname: self
-        atomicAdd(&counts[q], 1u);
+        atomicAdd(&counts[cp.q_map ? cp.q_map[q] : q], 1u);
         atomicAdd(&counts[rid], 1u);
     }
 }

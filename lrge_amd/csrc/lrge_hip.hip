@@ -500,6 +500,24 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     StageTimer t_total(ctx, LRGE_T_TOTAL);
     Scratch sc(ctx);
     const u32 n_out = job.mode == MODE_TWOSET ? nq : nt;
+    u32 *d_qmap = nullptr;
+    if (job.mode == MODE_AVA && Q != T) {
+        // a shard of the reads as queries: counts stay keyed by indexed read, so every query needs the index of the
+        // read with the same name (= the same rank) in the indexed set
+        std::vector<std::pair<u32, u32>> byrank(nt);
+        for (u32 i = 0; i < nt; ++i) byrank[i] = {T->h_rank[i], i};
+        std::sort(byrank.begin(), byrank.end());
+        std::vector<u32> qm(nq);
+        for (u32 q = 0; q < nq; ++q) {
+            auto it = std::lower_bound(byrank.begin(), byrank.end(), std::make_pair(Q->h_rank[q], 0u));
+            if (it == byrank.end() || it->first != Q->h_rank[q]) { LRGE_SET_ERR(ctx, "all-vs-all shard: read %u is not in the indexed set", q); return LRGE_ERR_INVALID; }
+            qm[q] = it->second;
+        }
+        d_qmap = sc.get<u32>((size_t)nq + 1);
+        if (!d_qmap) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemcpyAsync(d_qmap, qm.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // qm is a local
+    }
     ALLOC_OR_FAIL(d_counts, sc, u32, (size_t)n_out + 1);
     ALLOC_OR_FAIL(d_hasmap, sc, u32, (size_t)nq + 1);
     HIPCHK(ctx, hipMemsetAsync(d_counts, 0, ((size_t)n_out + 1) * 4, ctx->stream));
@@ -1064,6 +1082,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             CountParams cnp; cnp.kl = kl; cnp.q0 = q0; cnp.mode = job.mode;
             cnp.q_rank = Q->has_rank ? Q->d_rank : nullptr; cnp.t_rank = T->has_rank ? T->d_rank : nullptr;
             cnp.t_dup = T->dup_rank ? 1 : 0;
+            cnp.q_map = d_qmap;
             hipLaunchKernelGGL(k_count, dim3((u32)div_up(G, 256)), dim3(256), 0, ctx->stream, skey, gstart, gflags, G, cnp, d_counts, d_hasmap);
             KCHK(ctx);
             // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
@@ -1122,8 +1141,10 @@ extern "C" int lrge_hip_overlap_ava(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
                                     const lrge_hip_params *p, uint32_t *counts) {
     int rc = check_common(ctx, ix, reads);
     if (rc) return rc;
-    if (ix->seqs != reads) { LRGE_SET_ERR(ctx, "all-vs-all needs the index built over the same read set"); return LRGE_ERR_INVALID; }
-    if (reads->dup_rank) { LRGE_SET_ERR(ctx, "Duplicate read identifier"); return LRGE_ERR_DUPLICATE_ID; }
+    if (ix->seqs != reads && !(ix->seqs->has_rank && reads->has_rank)) {
+        LRGE_SET_ERR(ctx, "all-vs-all over a shard of the reads needs name ranks on both sets"); return LRGE_ERR_INVALID;
+    }
+    if (reads->dup_rank || ix->seqs->dup_rank) { LRGE_SET_ERR(ctx, "Duplicate read identifier"); return LRGE_ERR_DUPLICATE_ID; }
     OverlapJob job; job.mode = MODE_AVA; job.dual = 0;
     job.prm = p ? *p : lrge_hip_params{0, 0.2f};
     job.counts = counts;

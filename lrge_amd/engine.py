@@ -183,10 +183,13 @@ class Index:
                                                                counts.ctypes.data))
         return counts[:self.targets.n]
 
-    def overlap_ava(self, remove_internal=False, max_overhang_ratio=0.2):
+    def overlap_ava(self, remove_internal=False, max_overhang_ratio=0.2, shard=None):
+        """All-vs-all counts keyed by indexed read.  `shard`: a SeqSet holding a subset of the indexed reads (name
+        ranks over the whole set) -> this shard's contribution; the sum over a partition is the full result."""
         counts = np.zeros(max(self.targets.n, 1), dtype=np.uint32)
         p = self._params(remove_internal, max_overhang_ratio)
-        self.ctx._check(self.ctx._lib.lrge_hip_overlap_ava(self.ctx.h, self.h, self.targets.h, C.byref(p),
+        reads = self.targets if shard is None else shard
+        self.ctx._check(self.ctx._lib.lrge_hip_overlap_ava(self.ctx.h, self.h, reads.h, C.byref(p),
                                                            counts.ctypes.data))
         return counts[:self.targets.n]
 

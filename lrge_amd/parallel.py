@@ -80,3 +80,29 @@ def twoset_forward_sharded(overlap_fn, q_lens, rank, world):
     nm = torch.tensor([int(no_map)], dtype=torch.int64, device=dev)
     dist.all_reduce(nm, op=dist.ReduceOp.SUM)
     return allv, int(nm.item()), (lo, hi)
+
+
+def shard_by_rank_round_robin(name_ranks, rank, world):
+    """All-vs-all shards: reads dealt round-robin in NAME-RANK order (NO_DUAL lets the smaller-named read of a pair
+    carry it, so contiguous rank ranges would be unbalanced).  Returns this rank's read indices,
+    ascending (file order is kept inside a shard)."""
+    order = np.argsort(np.asarray(name_ranks), kind="stable")
+    return np.sort(order[rank::max(world, 1)])
+
+
+def ava_sharded(overlap_shard_fn, name_ranks, rank, world):
+    """All-vs-all over `world` GPUs.  `overlap_shard_fn(idx) -> u32[n_reads]`: counts keyed by indexed read that the
+    reads `idx`, used as queries against the replicated index, contribute (engine.Index.overlap_ava(shard=...)).
+    One all_reduce(sum) of the count vector closes the step; returns (counts of the whole job, idx)."""
+    idx = shard_by_rank_round_robin(name_ranks, rank, world)
+    part = np.asarray(overlap_shard_fn(idx), dtype=np.uint32)
+    return (allreduce_counts_u32(part) if world > 1 else part), idx
+
+
+def inverse_sharded(overlap_shard_fn, streamed_lens, rank, world):
+    """Inverse two-set (--use-min-ref): the index holds the query set (replicated), the streamed target reads are
+    sharded by bases.  `overlap_shard_fn(lo, hi) -> u32[n_indexed]`; one all_reduce(sum) closes the step."""
+    b = shard_by_bases(streamed_lens, world)
+    lo, hi = b[rank], b[rank + 1]
+    part = np.asarray(overlap_shard_fn(lo, hi), dtype=np.uint32)
+    return (allreduce_counts_u32(part) if world > 1 else part), (lo, hi)

@@ -272,6 +272,43 @@ def test_packed_anchor_path_is_invisible(ctx, oracle, tiny_ont, monkeypatch, mod
     assert int(np.asarray(a).sum()) > 0
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_ava_and_inverse_shards_sum_to_the_whole(ctx, oracle, tiny_ont, world):
+    """Multi-GPU decomposition on one GPU: the shards a world of `world` ranks would process, run one
+    after the other, must add up to the unsharded counts -- all-vs-all (reads dealt round-robin in name-rank
+    order, counts keyed by indexed read) and inverse two-set (streamed reads cut by bases)."""
+    from lrge_amd import engine, parallel
+    ds = tiny_ont
+    seqs, names = ds.t.seqs(), ds.t.names
+    ranks, _ = engine.name_ranks(names, names)
+    Td = _upload(ctx, seqs, ranks)
+    ix = engine.Index(ctx, Td, PRESETS["ont"])
+    full = ix.overlap_ava()
+    total = np.zeros_like(full)
+    seen = []
+    for r in range(world):
+        idx = parallel.shard_by_rank_round_robin(ranks, r, world)
+        seen += idx.tolist()
+        shard = _upload(ctx, [seqs[i] for i in idx], np.asarray(ranks)[idx])
+        total += ix.overlap_ava(shard=shard)
+    assert sorted(seen) == list(range(len(names)))
+    assert np.array_equal(total, full) and int(full.sum()) > 0
+    # inverse: index over the queries, targets streamed in shards
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Qd = _upload(ctx, ds.q.seqs(), qr)
+    ixq = engine.Index(ctx, Qd, PRESETS["ont"])
+    Tall = _upload(ctx, seqs, tr)
+    inv_full = ixq.overlap_inverse(Tall)
+    b = parallel.shard_by_bases(ds.t.lens(), world)
+    inv = np.zeros_like(inv_full)
+    for r in range(world):
+        lo, hi = b[r], b[r + 1]
+        if hi > lo:
+            inv += ixq.overlap_inverse(_upload(ctx, seqs[lo:hi], np.asarray(tr)[lo:hi]))
+    assert np.array_equal(inv, inv_full) and int(inv_full.sum()) > 0
+    ix.free(); ixq.free()
+
+
 def test_qocc_precheck_is_invisible(ctx, oracle, tiny_ont, monkeypatch):
     """The conservative bucket pre-check (k_qocc_check) only decides whether the exact sort-based filter runs;
     forcing the exact pass must not change anything."""

@@ -116,7 +116,11 @@ def _worker(rank, world, port, q):
         allv, no_map, (lo, hi) = parallel.twoset_forward_sharded(overlap_fn, lens, rank, world)
         counts = np.zeros(5, dtype=np.uint32); counts[rank] = 3; counts[4] = 1
         tot = parallel.allreduce_counts_u32(counts)
-        q.put((rank, allv.tolist(), no_map, lo, hi, tot.tolist()))
+        # all-vs-all / inverse drivers: the per-rank GPU call is stood in for by "one count per read of the shard"
+        ranks7 = np.array([4, 0, 6, 2, 5, 1, 3])
+        ava, idx = parallel.ava_sharded(lambda ix: np.bincount(ix, minlength=7), ranks7, rank, world)
+        inv, (ilo, ihi) = parallel.inverse_sharded(lambda a, b: np.bincount(np.arange(a, b) % 3, minlength=3), lens, rank, world)
+        q.put((rank, allv.tolist(), no_map, lo, hi, tot.tolist(), ava.tolist(), idx.tolist(), inv.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -132,9 +136,16 @@ def test_gloo_world2_gather_and_allreduce():
     for p in procs: p.join(timeout=60)
     full = ((np.arange(11, dtype=np.float32) + 0.5) * 1000).tolist()
     ranges = []
-    for rank, allv, no_map, lo, hi, tot in sorted(res):
+    shards = []
+    for rank, allv, no_map, lo, hi, tot, ava, idx, inv in sorted(res):
         assert allv == full                      # every rank ends with the whole vector, in query order
         assert no_map == 1
         assert tot == [3, 3, 0, 0, 2]
+        assert ava == [1] * 7                    # every read was a query on exactly one rank
+        assert inv == np.bincount(np.arange(11) % 3, minlength=3).tolist()
+        shards.append(idx)
         ranges.append((lo, hi))
+    assert sorted(shards[0] + shards[1]) == list(range(7))
+    # dealt in name-rank order: ranks 0,2,4,6 -> shard 0; 1,3,5 -> shard 1
+    assert shards[0] == sorted([1, 3, 0, 2]) and shards[1] == sorted([5, 6, 4])
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 11

@@ -21,6 +21,7 @@ struct HwChainArgs {
     u32 n_list;
     u64 *grec;         // [n_anchors]
     u32 *tmark;        // [n_anchors] zero-initialised
+    u32 prio;          // wavefront issue priority (0..3) while it runs beside k_chain_lpg
 };
 
 // inclusive max-scan inside each 32-lane half
@@ -163,6 +164,9 @@ __global__ __launch_bounds__(64) void k_chain_hw(HwChainArgs R, ChainParams P, G
     const u32 e0B = (gB + 1 < R.n_groups) ? RFL(R.gstart[gB + 1]) : (u32)R.n_anchors;
     const i32 nA = (i32)(e0A - s0A), nB = hasB ? (i32)(e0B - s0B) : 0;
     const i32 n_max = nA > nB ? nA : nB;
+    if (R.prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (R.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (R.prio == 1) __builtin_amdgcn_s_setprio(1);
     const u64 rmask = (1ULL << P.kl.bits_rpos) - 1;
     // per-lane view of "my" group
     const u32 s0 = h ? s0B : s0A;

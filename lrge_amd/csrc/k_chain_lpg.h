@@ -22,8 +22,12 @@
 #include "k_chain_hw.h"
 
 #define LPG_W 32
-#define LPG_B 16   // candidates per evaluate / resolve block
+#ifndef LPG_B
+#define LPG_B 8    // candidates per evaluate / resolve block
+#endif
+#ifndef LPG_CH
 #define LPG_CH 8   // anchors per input / output staging chunk
+#endif
 #define LPG_RING_BYTES ((2 * (LPG_CH / 2) * 128 * 2 + LPG_CH * 64) * 8)
 #define LPG_MAX_AUTO 0xFFFFFFFEu   // split chosen per batch from the group-size census (lrge_hip.hip)
 
@@ -46,7 +50,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     extern __shared__ i32 pen_tab[];   // [bw + 2] when PENTAB, then the anchor / record staging ring (LPG_RING_BYTES)
     // this kernel's longest wavefronts are the critical path of the chain stage; k_chain_hw's wavefronts on
     // the other stream share the SIMDs and should fill the gaps, not compete for issue slots
-    if (R.prio) __builtin_amdgcn_s_setprio(3);
+    if (R.prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (R.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (R.prio == 1) __builtin_amdgcn_s_setprio(1);
     const u32 li = blockIdx.x * 64 + threadIdx.x;
     const bool has = li < R.n_list;
     const u32 g = has ? R.list[li] : 0;

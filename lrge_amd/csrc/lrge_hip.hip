@@ -981,6 +981,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                     HwChainArgs ha;
                     ha.akey = skey; ha.aval = sval; ha.gstart = gstart; ha.n_groups = G; ha.n_anchors = A; ha.list = hw_list; ha.n_list = n_big;
                     ha.grec = bsc.get<u64>(A); ha.tmark = bsc.get<u32>(A);
+                    ha.prio = (u32)env_u64("LRGE_HIP_HW_PRIO", 0);
                     if (!ha.grec || !ha.tmark) return LRGE_ERR_DEVICE;
                     HIPCHK(ctx, hipMemsetAsync(ha.tmark, 0, A * 4, ctx->stream));
                     // the list is sorted by min(n, 65535) descending, so [0, n_big) are exactly the groups above lpg_max
@@ -995,7 +996,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
                         LpgChainArgs la;
                         la.akey = skey; la.aval = sval; la.gstart = gstart; la.n_groups = G; la.n_anchors = A;
                         la.list = hw_list + n_big; la.n_list = n_chained - n_big; la.grec = ha.grec; la.tmark = ha.tmark;
-                        la.prio = (u32)env_u64("LRGE_HIP_LPG_PRIO", 1);
+                        la.prio = (u32)env_u64("LRGE_HIP_LPG_PRIO", 3);
                         StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
                         const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !getenv("LRGE_HIP_LPG_NOTAB");
                         if (pentab) hipLaunchKernelGGL(k_chain_lpg<true>, dim3((la.n_list + 63) / 64), dim3(64), (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES,

@@ -485,22 +485,38 @@ struct OverlapJob {
 };
 
 
-static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *Q, OverlapJob &job) {
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    ctx->resolve_timers();
-    memset(ctx->ms, 0, sizeof(ctx->ms));
-    memset(ctx->counters, 0, sizeof(ctx->counters));
-    if (Q->has_empty && !job.dump_anchors) {  // aligner.rs:214-216 -> LrgeError::MapError aborts the run
-        LRGE_SET_ERR(ctx, "Error mapping read: Sequence is empty");
-        return LRGE_ERR_MAP;
-    }
-    const lrge_hip_seqset *T = ix->seqs;
-    const Preset &P = ix->P;
-    const u32 nq = Q->n, nt = T->n;
-    StageTimer t_total(ctx, LRGE_T_TOTAL);
-    Scratch sc(ctx);
-    const u32 n_out = job.mode == MODE_TWOSET ? nq : nt;
-    u32 *d_qmap = nullptr;
+// One overlap call = one OverlapRun: the state every stage shares lives here, the stages are its methods
+// (prepare -> seeds -> plan -> batch x N -> finish); a stage returns RUN_DONE when the call is complete early
+// (empty sets, statistics-only or anchor-dump runs).
+enum { RUN_DONE = 1 };
+
+struct OverlapRun {
+    lrge_hip_ctx *ctx; const lrge_hip_index *ix; const lrge_hip_seqset *Q; OverlapJob &job;
+    Scratch sc;
+    // outputs on the device
+    u32 n_out = 0; u32 *d_qmap = nullptr, *d_counts = nullptr, *d_hasmap = nullptr;
+    unsigned long long *d_nchains = nullptr; lrge_hip_chain *d_chains = nullptr;
+    // seeds: query minimizers, their index lookups, per-query anchor totals
+    SketchOut so; std::vector<u32> h_mzoff, h_qtot; u64 Mq = 0; SeedParams sp;
+    u32 *hs = nullptr, *hc = nullptr, *hn = nullptr, *hv = nullptr, *krank = nullptr;
+    // batch plan
+    u64 batch_cap = 0; KeyLayout kl; u32 max_bits_q = 0, min_n = 0; BinLimits bl; ChainParams cp;
+    std::vector<SegTile> h_tiles;   // per batch; lives until the batch's next host sync (the async H2D copy reads it)
+    std::vector<SegDesc> h_local[3];
+    u32 n_local_items = 0;         // anchors of the batch sorted by k_seg_sort_local
+
+    OverlapRun(lrge_hip_ctx *c, const lrge_hip_index *i, const lrge_hip_seqset *q, OverlapJob &j) : ctx(c), ix(i), Q(q), job(j), sc(c) {}
+    int prepare();                              // output buffers, shard map, empty-set shortcut
+    int seeds();                                // K1 sketch, K3 lookup, K4a query-occurrence filter, hit counts
+    int plan();                                 // batch size, key layout, chaining parameters
+    int batch(u32 q0, u32 q1, u64 A);           // K4 expand, sort, K5 groups, K6 chain, K7 count for queries [q0, q1)
+    int finish();                               // results to the host
+};
+
+int OverlapRun::prepare() {
+    const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
+    (void)T; (void)P; (void)nq; (void)nt;
+    n_out = job.mode == MODE_TWOSET ? nq : nt;
     if (job.mode == MODE_AVA && Q != T) {
         // a shard of the reads as queries: counts stay keyed by indexed read, so every query needs the index of the
         // read with the same name (= the same rank) in the indexed set
@@ -518,11 +534,10 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         HIPCHK(ctx, hipMemcpyAsync(d_qmap, qm.data(), (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // qm is a local
     }
-    ALLOC_OR_FAIL(d_counts, sc, u32, (size_t)n_out + 1);
-    ALLOC_OR_FAIL(d_hasmap, sc, u32, (size_t)nq + 1);
+    d_counts = sc.get<u32>((size_t)n_out + 1); d_hasmap = sc.get<u32>((size_t)nq + 1);
+    if (!d_counts || !d_hasmap) return LRGE_ERR_DEVICE;
     HIPCHK(ctx, hipMemsetAsync(d_counts, 0, ((size_t)n_out + 1) * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(d_hasmap, 0, ((size_t)nq + 1) * 4, ctx->stream));
-    unsigned long long *d_nchains = nullptr; lrge_hip_chain *d_chains = nullptr;
     if (job.n_chains) {
         d_nchains = (unsigned long long *)sc.get<u64>(1);
         d_chains = sc.get<lrge_hip_chain>(job.chain_cap ? job.chain_cap : 1);
@@ -536,23 +551,23 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         if (job.n_chains) *job.n_chains = 0;
         if (job.an) *job.an = 0;
         if (job.paf_stats) { memset(job.rep_len, 0, (size_t)nq * 4); memset(job.sum_span, 0, (size_t)nq * 8); memset(job.n_kept, 0, (size_t)nq * 4); }
-        t_total.stop();
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->resolve_timers();
-        return LRGE_OK;
+        return RUN_DONE;
     }
+    return LRGE_OK;
 
+}
+
+int OverlapRun::seeds() {
+    const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
+    (void)T; (void)P; (void)nq; (void)nt;
     // ---- 1. sketch the queries ----
-    SketchOut so;
-    std::vector<u32> h_mzoff;
     int rc = sketch_device(ctx, sc, Q, ix->preset_id, false, &so, 0, 0, &h_mzoff);
     if (rc) return rc;
-    const u64 Mq = so.n;
+    Mq = so.n;
     ctx->counters[LRGE_C_QUERY_MINIMIZERS] = Mq;
     if (Mq >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "query set limited to < 2^32 minimizers"); return LRGE_ERR_TOO_MANY; }
 
     // ---- 2. lookup ----
-    SeedParams sp;
     sp.ht = ix->d_ht; sp.ht_cap = ix->ht_cap; sp.pos = ix->d_pos; sp.pk_pos1 = ix->pk_pos1; sp.pk_ybits = ix->pk_ybits;
     sp.t_len = T->d_len; sp.t_rank = T->d_rank; sp.q_len = Q->d_len; sp.q_rank = Q->d_rank;
     sp.mid_occ = ix->mid_occ;
@@ -569,10 +584,10 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         if (!shared) sp.check_names = 0;
     }
     sp.no_dual = job.dual ? 0 : 1;
-    ALLOC_OR_FAIL(hs, sc, u32, Mq + 1); ALLOC_OR_FAIL(hc, sc, u32, Mq + 1);
-    ALLOC_OR_FAIL(hn, sc, u32, Mq + 1); ALLOC_OR_FAIL(hv, sc, u32, Mq + 1); ALLOC_OR_FAIL(krank, sc, u32, Mq + 1);
-    ALLOC_OR_FAIL(d_qtot, sc, u32, (size_t)nq + 1);
-    std::vector<u32> h_qtot((size_t)nq + 1, 0);
+    hs = sc.get<u32>(Mq + 1); hc = sc.get<u32>(Mq + 1); hn = sc.get<u32>(Mq + 1); hv = sc.get<u32>(Mq + 1); krank = sc.get<u32>(Mq + 1);
+    u32 *d_qtot = sc.get<u32>((size_t)nq + 1);
+    if (!hs || !hc || !hn || !hv || !krank || !d_qtot) return LRGE_ERR_DEVICE;
+    h_qtot.assign((size_t)nq + 1, 0);
     if (Mq) {
         StageTimer t(ctx, LRGE_T_LOOKUP);
         hipLaunchKernelGGL(k_lookup, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, Mq, sp, hs, hc);
@@ -649,10 +664,8 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         HIPCHK(ctx, hipMemcpyAsync(job.rep_len, d_rl, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(job.sum_span, d_ss, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(job.n_kept, d_nk, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-        t_total.stop();
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->resolve_timers();
-        return LRGE_OK;
+        return RUN_DONE;
     }
     auto run_counts = [&]() -> int {
         StageTimer t(ctx, LRGE_T_LOOKUP);
@@ -684,12 +697,17 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         rc = run_exact_qocc(); if (rc) return rc;
         rc = run_counts(); if (rc) return rc;
     }
+    return LRGE_OK;
+}
 
+int OverlapRun::plan() {
+    const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
+    (void)T; (void)P; (void)nq; (void)nt;
     // ---- 4. batches ----
     // Anchors per batch.  Every batch pays the latency of its longest chain group once (the chain kernels are
     // bound by it), so batches are as large as memory allows: ~64 B of scratch per anchor, at most half of the
     // free HBM, at most 2^30 anchors (positions are 32-bit).
-    u64 batch_cap = 1ULL << 30;
+    batch_cap = 1ULL << 30;
     {
         size_t mfree = 0, mtotal = 0;
         if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
@@ -699,13 +717,11 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         if (batch_cap < (1ULL << 20)) batch_cap = 1ULL << 20;
     }
     batch_cap = env_u64("LRGE_HIP_BATCH_ANCHORS", batch_cap);
-    KeyLayout kl;
     kl.bits_rpos = std::max<u32>(1, ceil_log2_u64((u64)T->max_len + 1));
     kl.bits_rid = std::max<u32>(1, ceil_log2_u64((u64)nt));
-    const u32 max_bits_q = 63 - (kl.bits_rpos + 1 + kl.bits_rid);
-    const u32 min_n = std::max<u32>((u32)P.min_cnt, (u32)div_up((u64)P.min_sc, P.hpc ? 255 : (u64)P.k));
-    BinLimits bl; bl.lim[0] = 64; bl.lim[1] = 256; bl.lim[2] = 1024; bl.lim[3] = 4096; bl.lim[4] = 0xFFFFFFFFu;
-    ChainParams cp;
+    max_bits_q = 63 - (kl.bits_rpos + 1 + kl.bits_rid);
+    min_n = std::max<u32>((u32)P.min_cnt, (u32)div_up((u64)P.min_sc, P.hpc ? 255 : (u64)P.k));
+    bl.lim[0] = 64; bl.lim[1] = 256; bl.lim[2] = 1024; bl.lim[3] = 4096; bl.lim[4] = 0xFFFFFFFFu;
     cp.max_dist_x = std::max(P.max_gap, P.bw); cp.max_dist_y = std::max(P.max_gap, P.bw);
     cp.bw = P.bw; cp.max_skip = P.max_skip; cp.max_iter = P.max_iter; cp.min_cnt = P.min_cnt; cp.min_sc = P.min_sc;
     cp.max_drop = P.bw; cp.pen_gap = P.pen_gap; cp.pen_skip = P.pen_skip;
@@ -718,379 +734,375 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_chain_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 18 + 64));
         attr_set = true;
     }
+    return LRGE_OK;
+}
 
-    std::vector<SegTile> h_tiles;   // per batch; lives until the batch's next host sync (the async H2D copy reads it)
-    std::vector<SegDesc> h_local[3];
-    u32 n_local_items = 0;         // anchors of the batch sorted by k_seg_sort_local
-    u32 q0 = job.dump_anchors ? job.dump_query : 0;
-    const u32 q_end = job.dump_anchors ? job.dump_query + 1 : nq;
-    while (q0 < q_end) {
-        u32 q1 = q0; u64 A = 0;
-        while (q1 < q_end && (q1 - q0) < (1u << std::min<u32>(max_bits_q, 24)) && (q1 == q0 || A + h_qtot[q1] <= batch_cap)) { A += h_qtot[q1]; ++q1; }
-        if (A >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "query %u alone yields %llu anchors (limit 2^32)", q0, (unsigned long long)A); return LRGE_ERR_TOO_MANY; }
-        ctx->counters[LRGE_C_BATCHES] += 1;
-        const u64 mb = h_mzoff[q0], me = h_mzoff[q1];
-        kl.bits_q = std::max<u32>(1, ceil_log2_u64((u64)(q1 - q0)));
-        cp.kl = kl; cp.q0 = q0;
-        if (A == 0 || me == mb) { q0 = q1; continue; }
-        ctx->counters[LRGE_C_ANCHORS] += A;
-        Scratch bsc(ctx);
-        u64 *akey, *aval, *akey2, *aval2, *skey, *sval;
-        // count-only runs carry one packed u64 per anchor through the expansion and the sort (k_prims.h UnpackParams);
-        // chain records (PAF) need the seed rank as well and keep the (key, value) pairs
-        const u32 bits_qy = std::max<u32>(1, ceil_log2_u64((u64)Q->max_len + 1));
-        const bool packed = !d_chains && !job.dump_anchors && kl.sh_q() + bits_qy + 9 <= 64 && !env_u64("LRGE_HIP_NO_PACKED", 0);
+int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
+    const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
+    (void)T; (void)P; (void)nq; (void)nt;
+    int rc = 0;
+    const u64 mb = h_mzoff[q0], me = h_mzoff[q1];
+    if (A == 0 || me == mb) return LRGE_OK;
+    ctx->counters[LRGE_C_ANCHORS] += A;
+    Scratch bsc(ctx);
+    u64 *akey, *aval, *akey2, *aval2, *skey, *sval;
+    // count-only runs carry one packed u64 per anchor through the expansion and the sort (k_prims.h UnpackParams);
+    // chain records (PAF) need the seed rank as well and keep the (key, value) pairs
+    const u32 bits_qy = std::max<u32>(1, ceil_log2_u64((u64)Q->max_len + 1));
+    const bool packed = !d_chains && !job.dump_anchors && kl.sh_q() + bits_qy + 9 <= 64 && !env_u64("LRGE_HIP_NO_PACKED", 0);
+    {
+        StageTimer t(ctx, LRGE_T_EXPAND);
+        u32 *aoff = bsc.get<u32>(me - mb + 1);
+        // (+8: k_chain_lpg streams anchors in 16-byte pairs and may read one element past the last group)
+        akey = bsc.get<u64>(A + 8); aval = bsc.get<u64>(A + 8); akey2 = bsc.get<u64>(A + 8); aval2 = bsc.get<u64>(A + 8);
+        if (!aoff || !akey || !aval || !akey2 || !aval2) return LRGE_ERR_DEVICE;
+        rc = scan_exclusive_u32(ctx, bsc, hv + mb, aoff, me - mb, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_expand, dim3((u32)div_up(me - mb, 256)), dim3(256), 0, ctx->stream, so.x, so.y, mb, me, sp, hs, hn, aoff,
+                           krank, so.mz_off, q0, kl, akey, aval, packed ? bits_qy : 0u);
+        KCHK(ctx);
+        // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
+        bsc.drop(aoff);
+        t.stop();
+    }
+    {
+        StageTimer t(ctx, LRGE_T_ANCHOR_SORT);
+        // the expansion emits the anchors query by query, so only (target, strand, position) need sorting,
+        // inside every query's segment: the query bits cost no radix pass (SegTile, k_prims.h)
+        h_tiles.clear();
+        for (auto &v : h_local) v.clear();
         {
-            StageTimer t(ctx, LRGE_T_EXPAND);
-            u32 *aoff = bsc.get<u32>(me - mb + 1);
-            // (+8: k_chain_lpg streams anchors in 16-byte pairs and may read one element past the last group)
-            akey = bsc.get<u64>(A + 8); aval = bsc.get<u64>(A + 8); akey2 = bsc.get<u64>(A + 8); aval2 = bsc.get<u64>(A + 8);
-            if (!aoff || !akey || !aval || !akey2 || !aval2) return LRGE_ERR_DEVICE;
-            rc = scan_exclusive_u32(ctx, bsc, hv + mb, aoff, me - mb, nullptr);
+            u32 off = 0, tb = 0, &n_local = n_local_items;
+            n_local = 0;
+            const bool local_ok = !getenv("LRGE_HIP_NO_LOCAL_SORT");
+            for (u32 q = q0; q < q1; ++q) {
+                const u32 c = h_qtot[q];
+                if (packed && c) {   // segment-local sort classes (capacity 2048 / 8192 / 16384 anchors)
+                    const int cls = c <= 2048 ? 0 : c <= 8192 ? 1 : c <= 16384 ? 2 : 3;
+                    if (cls < 3 && local_ok && ctx->lsort_ok[cls]) { h_local[cls].push_back(SegDesc{off, c, q - q0, 0}); off += c; n_local += c; continue; }
+                }
+                const u32 nt_q = (u32)div_up((u64)c, RS_TILE);
+                for (u32 lt = 0; lt < nt_q; ++lt) {
+                    SegTile t; t.start = off + lt * RS_TILE; t.len = std::min<u32>(RS_TILE, c - lt * RS_TILE);
+                    t.hbase = 256u * tb + lt; t.hstride = nt_q; t.seg = q - q0; t.delta = n_local;
+                    h_tiles.push_back(t);
+                }
+                off += c; tb += nt_q;
+            }
+        }
+        SegTile *d_tiles = (SegTile *)bsc.get<u32>(h_tiles.size() * (sizeof(SegTile) / 4) + 4);
+        if (!d_tiles) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
+        if (packed) {
+            UnpackParams up; up.sb = kl.sh_q(); up.bits_qy = bits_qy; up.sh_q = kl.sh_q(); up.dmask = 255;
+            // segments that fit a workgroup's LDS are sorted there in one kernel (k_seg_sort_local: 8 B in, 16 B out
+            // per anchor); only the larger ones take the tiled global passes
+            if (h_local[0].size()) {
+                SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[0].size() * 4);
+                if (!d) return LRGE_ERR_DEVICE;
+                HIPCHK(ctx, hipMemcpyAsync(d, h_local[0].data(), h_local[0].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL((k_seg_sort_local<256, 8>), dim3((u32)h_local[0].size()), dim3(256), LSORT_BYTES(256, 8), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
+                KCHK(ctx);
+            }
+            if (h_local[1].size()) {
+                SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[1].size() * 4);
+                if (!d) return LRGE_ERR_DEVICE;
+                HIPCHK(ctx, hipMemcpyAsync(d, h_local[1].data(), h_local[1].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL((k_seg_sort_local<512, 16>), dim3((u32)h_local[1].size()), dim3(512), LSORT_BYTES(512, 16), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
+                KCHK(ctx);
+            }
+            if (h_local[2].size()) {
+                SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[2].size() * 4);
+                if (!d) return LRGE_ERR_DEVICE;
+                HIPCHK(ctx, hipMemcpyAsync(d, h_local[2].data(), h_local[2].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL((k_seg_sort_local<1024, 16>), dim3((u32)h_local[2].size()), dim3(1024), LSORT_BYTES(1024, 16), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
+                KCHK(ctx);
+            }
+            rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up, A - n_local_items);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_expand, dim3((u32)div_up(me - mb, 256)), dim3(256), 0, ctx->stream, so.x, so.y, mb, me, sp, hs, hn, aoff,
-                               krank, so.mz_off, q0, kl, akey, aval, packed ? bits_qy : 0u);
-            KCHK(ctx);
+            skey = aval; sval = aval2;
+            bsc.drop((u32 *)d_tiles);
+            bsc.drop(akey); bsc.drop(akey2);
+        } else {
+            rc = radix_sort_pairs(ctx, bsc, akey, aval, akey2, aval2, A, 0, (int)(kl.bits_rpos + 1 + kl.bits_rid), &skey, &sval, false,
+                                  d_tiles, (u32)h_tiles.size());
+            if (rc) return rc;
+            bsc.drop((u32 *)d_tiles);
             // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
-            bsc.drop(aoff);
-            t.stop();
+            bsc.drop(skey == akey ? akey2 : akey);
+            bsc.drop(sval == aval ? aval2 : aval);
         }
-        {
-            StageTimer t(ctx, LRGE_T_ANCHOR_SORT);
-            // the expansion emits the anchors query by query, so only (target, strand, position) need sorting,
-            // inside every query's segment: the query bits cost no radix pass (SegTile, k_prims.h)
-            h_tiles.clear();
-            for (auto &v : h_local) v.clear();
-            {
-                u32 off = 0, tb = 0, &n_local = n_local_items;
-                n_local = 0;
-                const bool local_ok = !getenv("LRGE_HIP_NO_LOCAL_SORT");
-                for (u32 q = q0; q < q1; ++q) {
-                    const u32 c = h_qtot[q];
-                    if (packed && c) {   // segment-local sort classes (capacity 2048 / 8192 / 16384 anchors)
-                        const int cls = c <= 2048 ? 0 : c <= 8192 ? 1 : c <= 16384 ? 2 : 3;
-                        if (cls < 3 && local_ok && ctx->lsort_ok[cls]) { h_local[cls].push_back(SegDesc{off, c, q - q0, 0}); off += c; n_local += c; continue; }
-                    }
-                    const u32 nt_q = (u32)div_up((u64)c, RS_TILE);
-                    for (u32 lt = 0; lt < nt_q; ++lt) {
-                        SegTile t; t.start = off + lt * RS_TILE; t.len = std::min<u32>(RS_TILE, c - lt * RS_TILE);
-                        t.hbase = 256u * tb + lt; t.hstride = nt_q; t.seg = q - q0; t.delta = n_local;
-                        h_tiles.push_back(t);
-                    }
-                    off += c; tb += nt_q;
-                }
-            }
-            SegTile *d_tiles = (SegTile *)bsc.get<u32>(h_tiles.size() * (sizeof(SegTile) / 4) + 4);
-            if (!d_tiles) return LRGE_ERR_DEVICE;
-            HIPCHK(ctx, hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
-            if (packed) {
-                UnpackParams up; up.sb = kl.sh_q(); up.bits_qy = bits_qy; up.sh_q = kl.sh_q(); up.dmask = 255;
-                // segments that fit a workgroup's LDS are sorted there in one kernel (k_seg_sort_local: 8 B in, 16 B out
-                // per anchor); only the larger ones take the tiled global passes
-                if (h_local[0].size()) {
-                    SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[0].size() * 4);
-                    if (!d) return LRGE_ERR_DEVICE;
-                    HIPCHK(ctx, hipMemcpyAsync(d, h_local[0].data(), h_local[0].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
-                    hipLaunchKernelGGL((k_seg_sort_local<256, 8>), dim3((u32)h_local[0].size()), dim3(256), LSORT_BYTES(256, 8), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
-                    KCHK(ctx);
-                }
-                if (h_local[1].size()) {
-                    SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[1].size() * 4);
-                    if (!d) return LRGE_ERR_DEVICE;
-                    HIPCHK(ctx, hipMemcpyAsync(d, h_local[1].data(), h_local[1].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
-                    hipLaunchKernelGGL((k_seg_sort_local<512, 16>), dim3((u32)h_local[1].size()), dim3(512), LSORT_BYTES(512, 16), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
-                    KCHK(ctx);
-                }
-                if (h_local[2].size()) {
-                    SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[2].size() * 4);
-                    if (!d) return LRGE_ERR_DEVICE;
-                    HIPCHK(ctx, hipMemcpyAsync(d, h_local[2].data(), h_local[2].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
-                    hipLaunchKernelGGL((k_seg_sort_local<1024, 16>), dim3((u32)h_local[2].size()), dim3(1024), LSORT_BYTES(1024, 16), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
-                    KCHK(ctx);
-                }
-                rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up, A - n_local_items);
-                if (rc) return rc;
-                skey = aval; sval = aval2;
-                bsc.drop((u32 *)d_tiles);
-                bsc.drop(akey); bsc.drop(akey2);
-            } else {
-                rc = radix_sort_pairs(ctx, bsc, akey, aval, akey2, aval2, A, 0, (int)(kl.bits_rpos + 1 + kl.bits_rid), &skey, &sval, false,
-                                      d_tiles, (u32)h_tiles.size());
-                if (rc) return rc;
-                bsc.drop((u32 *)d_tiles);
-                // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
-                bsc.drop(skey == akey ? akey2 : akey);
-                bsc.drop(sval == aval ? aval2 : aval);
-            }
-            t.stop();
+        t.stop();
+    }
+    if (job.dump_anchors) {
+        *job.an = A;
+        u64 m = A < job.acap ? A : job.acap;
+        std::vector<u64> hk(m), hvv(m);
+        if (m) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
+            HIPCHK(ctx, hipMemcpy(hk.data(), skey, m * 8, hipMemcpyDeviceToHost));
+            HIPCHK(ctx, hipMemcpy(hvv.data(), sval, m * 8, hipMemcpyDeviceToHost));
         }
-        if (job.dump_anchors) {
-            *job.an = A;
-            u64 m = A < job.acap ? A : job.acap;
-            std::vector<u64> hk(m), hvv(m);
-            if (m) {
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
-                HIPCHK(ctx, hipMemcpy(hk.data(), skey, m * 8, hipMemcpyDeviceToHost));
-                HIPCHK(ctx, hipMemcpy(hvv.data(), sval, m * 8, hipMemcpyDeviceToHost));
-            }
-            const u64 rmask = (1ULL << kl.bits_rpos) - 1;
-            // back to minimap2's mm128 anchor encoding and array order: the device orders groups
-            // (target, strand) so that both strands of a pair are adjacent, minimap2 orders them
-            // (strand, target); a stable re-sort by x keeps the order inside every group.
-            std::vector<std::pair<u64, u64>> tmp(m);
-            for (u64 i = 0; i < m; ++i) {
-                u64 k = hk[i];
-                u64 rev = (k >> kl.sh_rev()) & 1, rid = (k >> kl.sh_rid()) & ((1ULL << kl.bits_rid) - 1);
-                tmp[i] = {rev << 63 | rid << 32 | (k & rmask), hvv[i] & AVAL_LOW_MASK};   // drop the seed rank
-            }
-            std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<u64, u64> &a, const std::pair<u64, u64> &b) { return a.first < b.first; });
-            for (u64 i = 0; i < m; ++i) { job.ax[i] = tmp[i].first; job.ay[i] = tmp[i].second; }
-            t_total.stop();
+        const u64 rmask = (1ULL << kl.bits_rpos) - 1;
+        // back to minimap2's mm128 anchor encoding and array order: the device orders groups
+        // (target, strand) so that both strands of a pair are adjacent, minimap2 orders them
+        // (strand, target); a stable re-sort by x keeps the order inside every group.
+        std::vector<std::pair<u64, u64>> tmp(m);
+        for (u64 i = 0; i < m; ++i) {
+            u64 k = hk[i];
+            u64 rev = (k >> kl.sh_rev()) & 1, rid = (k >> kl.sh_rid()) & ((1ULL << kl.bits_rid) - 1);
+            tmp[i] = {rev << 63 | rid << 32 | (k & rmask), hvv[i] & AVAL_LOW_MASK};   // drop the seed rank
+        }
+        std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<u64, u64> &a, const std::pair<u64, u64> &b) { return a.first < b.first; });
+        for (u64 i = 0; i < m; ++i) { job.ax[i] = tmp[i].first; job.ay[i] = tmp[i].second; }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return RUN_DONE;
+    }
+    // groups
+    // LRGE_HIP_CHAIN selects the chain kernel: default "hw" (two groups per wavefront), "reg" (one group
+    // per wavefront, register window), "lds" / "glb" (earlier forms, kept as on-device references)
+    const char *cm = getenv("LRGE_HIP_CHAIN");
+    const int chain_mode = (cm && !strcmp(cm, "lds")) ? 1 : (cm && !strcmp(cm, "glb")) ? 2 : (cm && !strcmp(cm, "reg")) ? 3 : 0;
+    // mode 0 splits the size-sorted group list: groups above lpg_max anchors go to k_chain_hw (short
+    // latency per anchor), the rest to k_chain_lpg (64 groups per wavefront).  "hw" / "lpg" force one kernel.
+    // The split is chosen per batch from the size census of the groups (see below); LRGE_HIP_LPG_MAX fixes it.
+    u32 lpg_max = LPG_MAX_AUTO;
+    if (const char *e = getenv("LRGE_HIP_LPG_MAX")) lpg_max = (u32)strtoul(e, nullptr, 10);
+    if (cm && !strcmp(cm, "hw")) lpg_max = 0;
+    if (cm && !strcmp(cm, "lpg")) lpg_max = 0xFFFFFFFFu;
+    if (lpg_max && (cp.want_all || d_chains) && !(cm && !strcmp(cm, "lpg"))) lpg_max = 0;   // records: wave-wide backtrack anyway
+    if (cp.max_iter < LPG_W) lpg_max = 0;    // (debug knob only) k_chain_lpg assumes every window slot is a candidate
+    u32 n_big = 0, lpg_split = 0;
+    u32 G = 0; u32 *gstart, *gflags, *bin_count = nullptr, *bin_list = nullptr, *hw_list = nullptr;
+    u32 h_bins[N_BINS] = {0, 0, 0, 0, 0};
+    unsigned long long h_bin_anchors[N_BINS] = {0, 0, 0, 0, 0};
+    u32 n_chained = 0; unsigned long long a_chained = 0, a_big = 0;
+    {
+        StageTimer t(ctx, LRGE_T_GROUP);
+        u32 *d_G = bsc.get<u32>(1);
+        if (chain_mode == 0) {
+            // group starts into an upper-bound block (one entry per anchor): the group count stays on the device
+            // until it travels to the host together with the size census -- one round trip instead of two
+            gstart = bsc.get<u32>((size_t)A + 1);
+            if (!gstart || !d_G) return LRGE_ERR_DEVICE;
+            rc = compact_heads_async(ctx, bsc, skey, A, kl.bits_rpos, gstart, d_G);   // runs of equal (query, target, strand)
+            if (rc) return rc;
+        } else {
+            rc = compact_heads(ctx, bsc, skey, A, kl.bits_rpos, &gstart, &G);
+            if (rc) return rc;
+            gflags = bsc.get<u32>((size_t)G + 1);
+            if (!gstart || !gflags) return LRGE_ERR_DEVICE;
+            HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
+        }
+        if (chain_mode == 0) {
+            // groups worth chaining, sorted by size (largest first) so that k_chain_hw pairs equals
+            u32 *d_cnt = bsc.get<u32>(4 + GSZ_BINS);
+            unsigned long long *d_anch = (unsigned long long *)bsc.get<u64>(2 + GSZ_BINS);
+            if (!d_cnt || !d_anch) return LRGE_ERR_DEVICE;
+            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, (4 + GSZ_BINS) * 4, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(d_anch, 0, (2 + GSZ_BINS) * 8, ctx->stream));
+            hipLaunchKernelGGL(k_group_count, dim3((u32)std::min<u64>(div_up(A, 4096), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, gstart, d_G, A, min_n,
+                               d_cnt, d_anch, d_cnt + 4, d_anch + 2);
+            KCHK(ctx);
+            u32 h_cnt[4 + GSZ_BINS]; unsigned long long h_anch[2 + GSZ_BINS];
+            HIPCHK(ctx, hipMemcpyAsync(&G, d_G, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_anch, d_anch, sizeof(h_anch), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            ctx->resolve_timers();
-            return LRGE_OK;
-        }
-        // groups
-        // LRGE_HIP_CHAIN selects the chain kernel: default "hw" (two groups per wavefront), "reg" (one group
-        // per wavefront, register window), "lds" / "glb" (earlier forms, kept as on-device references)
-        const char *cm = getenv("LRGE_HIP_CHAIN");
-        const int chain_mode = (cm && !strcmp(cm, "lds")) ? 1 : (cm && !strcmp(cm, "glb")) ? 2 : (cm && !strcmp(cm, "reg")) ? 3 : 0;
-        // mode 0 splits the size-sorted group list: groups above lpg_max anchors go to k_chain_hw (short
-        // latency per anchor), the rest to k_chain_lpg (64 groups per wavefront).  "hw" / "lpg" force one kernel.
-        // The split is chosen per batch from the size census of the groups (see below); LRGE_HIP_LPG_MAX fixes it.
-        u32 lpg_max = LPG_MAX_AUTO;
-        if (const char *e = getenv("LRGE_HIP_LPG_MAX")) lpg_max = (u32)strtoul(e, nullptr, 10);
-        if (cm && !strcmp(cm, "hw")) lpg_max = 0;
-        if (cm && !strcmp(cm, "lpg")) lpg_max = 0xFFFFFFFFu;
-        if (lpg_max && (cp.want_all || d_chains) && !(cm && !strcmp(cm, "lpg"))) lpg_max = 0;   // records: wave-wide backtrack anyway
-        if (cp.max_iter < LPG_W) lpg_max = 0;    // (debug knob only) k_chain_lpg assumes every window slot is a candidate
-        u32 n_big = 0, lpg_split = 0;
-        u32 G = 0; u32 *gstart, *gflags, *bin_count = nullptr, *bin_list = nullptr, *hw_list = nullptr;
-        u32 h_bins[N_BINS] = {0, 0, 0, 0, 0};
-        unsigned long long h_bin_anchors[N_BINS] = {0, 0, 0, 0, 0};
-        u32 n_chained = 0; unsigned long long a_chained = 0, a_big = 0;
-        {
-            StageTimer t(ctx, LRGE_T_GROUP);
-            u32 *d_G = bsc.get<u32>(1);
-            if (chain_mode == 0) {
-                // group starts into an upper-bound block (one entry per anchor): the group count stays on the device
-                // until it travels to the host together with the size census -- one round trip instead of two
-                gstart = bsc.get<u32>((size_t)A + 1);
-                if (!gstart || !d_G) return LRGE_ERR_DEVICE;
-                rc = compact_heads_async(ctx, bsc, skey, A, kl.bits_rpos, gstart, d_G);   // runs of equal (query, target, strand)
-                if (rc) return rc;
-            } else {
-                rc = compact_heads(ctx, bsc, skey, A, kl.bits_rpos, &gstart, &G);
-                if (rc) return rc;
-                gflags = bsc.get<u32>((size_t)G + 1);
-                if (!gstart || !gflags) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
+            gflags = bsc.get<u32>((size_t)G + 1);
+            if (!gflags) return LRGE_ERR_DEVICE;
+            HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
+            n_chained = h_cnt[0]; a_chained = h_anch[0];
+            {
+                // Split of the size-sorted list: groups above T anchors -> k_chain_hw (~0.55 us per anchor of latency,
+                // ~93 VALU instructions per anchor), the rest -> k_chain_lpg (~4.4 us per anchor of the LONGEST group
+                // of a wavefront, ~22 VALU per anchor).  Both run side by side; the stage takes about
+                //   max(T * t_lpg, n_longest * t_hw, VALU work / issue rate of the chip)
+                // and T (a multiple of GSZ_W) minimises that estimate.  Measured constants of this kernel pair.
+                const u32 *hn = h_cnt + 4; const unsigned long long *ha = h_anch + 2;
+                u32 T = lpg_max;
+                if (lpg_max == LPG_MAX_AUTO) {
+                    const double t_lpg = 4.3e-6, t_hw = 0.55e-6, c_lpg = 22.0, c_hw = 93.0;
+                    const double rate = 0.8 * (double)ctx->n_cu * 4 * 2.1e9 / 4.0;   // wave64 VALU instructions per second, ~80 % reachable
+                    int top = -1;
+                    for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) top = b;
+                    double best = 1e30; T = 0;
+                    double a_le = 0;    // anchors in classes <= b
+                    for (int b = -1; b < GSZ_BINS - 1; ++b) {      // T = (b + 1) * GSZ_W: classes 0..b go to k_chain_lpg
+                        if (b >= 0) a_le += (double)ha[b];
+                        const double a_hw = (double)a_chained - a_le;
+                        const double crit_lpg = b >= 0 ? (double)std::min<int>(b + 1, top + 1) * GSZ_W * t_lpg : 0.0;
+                        const double crit_hw = a_hw > 0 ? (double)(top + 1) * GSZ_W * t_hw : 0.0;
+                        const double est = std::max(std::max(crit_lpg, crit_hw), (a_le * c_lpg + a_hw * c_hw) / rate);
+                        if (est < best - 1e-9) { best = est; T = (u32)(b + 1) * GSZ_W; }
+                        if (b >= top) break;
+                    }
+                }
+                // groups strictly above T: whole classes when T is a class edge, else (LRGE_HIP_LPG_MAX) count by class floor
+                n_big = 0; a_big = 0;
+                for (int b = 0; b < GSZ_BINS; ++b) {
+                    const bool above = (u64)b * GSZ_W >= (u64)T;    // class b = (b*W, (b+1)*W]
+                    if (above) { n_big += hn[b]; a_big += ha[b]; }
+                }
+                lpg_split = T;
+                ctx->counters[LRGE_C_LPG_SPLIT] = lpg_split;
+                if (getenv("LRGE_HIP_VERBOSE")) {
+                    int top = -1; for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) top = b;
+                    fprintf(stderr, "[lrge_hip] batch: %u groups chained, %llu anchors, largest class %d (<= %d anchors), split T=%u -> hw %u groups / %llu anchors\n",
+                            n_chained, a_chained, top, (top + 1) * GSZ_W, T, n_big, a_big);
+                }
             }
-            if (chain_mode == 0) {
-                // groups worth chaining, sorted by size (largest first) so that k_chain_hw pairs equals
-                u32 *d_cnt = bsc.get<u32>(4 + GSZ_BINS);
-                unsigned long long *d_anch = (unsigned long long *)bsc.get<u64>(2 + GSZ_BINS);
-                if (!d_cnt || !d_anch) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, (4 + GSZ_BINS) * 4, ctx->stream));
-                HIPCHK(ctx, hipMemsetAsync(d_anch, 0, (2 + GSZ_BINS) * 8, ctx->stream));
-                hipLaunchKernelGGL(k_group_count, dim3((u32)std::min<u64>(div_up(A, 4096), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, gstart, d_G, A, min_n,
-                                   d_cnt, d_anch, d_cnt + 4, d_anch + 2);
+            if (n_chained) {
+                u64 *k0 = bsc.get<u64>(n_chained), *v0 = bsc.get<u64>(n_chained), *k1 = bsc.get<u64>(n_chained), *v1 = bsc.get<u64>(n_chained);
+                hw_list = bsc.get<u32>(n_chained);
+                if (!k0 || !v0 || !k1 || !v1 || !hw_list) return LRGE_ERR_DEVICE;
+                hipLaunchKernelGGL(k_group_fill, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, d_cnt + 1, k0, v0);
                 KCHK(ctx);
-                u32 h_cnt[4 + GSZ_BINS]; unsigned long long h_anch[2 + GSZ_BINS];
-                HIPCHK(ctx, hipMemcpyAsync(&G, d_G, 4, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipMemcpyAsync(h_anch, d_anch, sizeof(h_anch), hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-                gflags = bsc.get<u32>((size_t)G + 1);
-                if (!gflags) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
-                n_chained = h_cnt[0]; a_chained = h_anch[0];
-                {
-                    // Split of the size-sorted list: groups above T anchors -> k_chain_hw (~0.55 us per anchor of latency,
-                    // ~93 VALU instructions per anchor), the rest -> k_chain_lpg (~4.4 us per anchor of the LONGEST group
-                    // of a wavefront, ~22 VALU per anchor).  Both run side by side; the stage takes about
-                    //   max(T * t_lpg, n_longest * t_hw, VALU work / issue rate of the chip)
-                    // and T (a multiple of GSZ_W) minimises that estimate.  Measured constants of this kernel pair.
-                    const u32 *hn = h_cnt + 4; const unsigned long long *ha = h_anch + 2;
-                    u32 T = lpg_max;
-                    if (lpg_max == LPG_MAX_AUTO) {
-                        const double t_lpg = 4.3e-6, t_hw = 0.55e-6, c_lpg = 22.0, c_hw = 93.0;
-                        const double rate = 0.8 * (double)ctx->n_cu * 4 * 2.1e9 / 4.0;   // wave64 VALU instructions per second, ~80 % reachable
-                        int top = -1;
-                        for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) top = b;
-                        double best = 1e30; T = 0;
-                        double a_le = 0;    // anchors in classes <= b
-                        for (int b = -1; b < GSZ_BINS - 1; ++b) {      // T = (b + 1) * GSZ_W: classes 0..b go to k_chain_lpg
-                            if (b >= 0) a_le += (double)ha[b];
-                            const double a_hw = (double)a_chained - a_le;
-                            const double crit_lpg = b >= 0 ? (double)std::min<int>(b + 1, top + 1) * GSZ_W * t_lpg : 0.0;
-                            const double crit_hw = a_hw > 0 ? (double)(top + 1) * GSZ_W * t_hw : 0.0;
-                            const double est = std::max(std::max(crit_lpg, crit_hw), (a_le * c_lpg + a_hw * c_hw) / rate);
-                            if (est < best - 1e-9) { best = est; T = (u32)(b + 1) * GSZ_W; }
-                            if (b >= top) break;
-                        }
-                    }
-                    // groups strictly above T: whole classes when T is a class edge, else (LRGE_HIP_LPG_MAX) count by class floor
-                    n_big = 0; a_big = 0;
-                    for (int b = 0; b < GSZ_BINS; ++b) {
-                        const bool above = (u64)b * GSZ_W >= (u64)T;    // class b = (b*W, (b+1)*W]
-                        if (above) { n_big += hn[b]; a_big += ha[b]; }
-                    }
-                    lpg_split = T;
-                    ctx->counters[LRGE_C_LPG_SPLIT] = lpg_split;
-                    if (getenv("LRGE_HIP_VERBOSE")) {
-                        int top = -1; for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) top = b;
-                        fprintf(stderr, "[lrge_hip] batch: %u groups chained, %llu anchors, largest class %d (<= %d anchors), split T=%u -> hw %u groups / %llu anchors\n",
-                                n_chained, a_chained, top, (top + 1) * GSZ_W, T, n_big, a_big);
-                    }
-                }
-                if (n_chained) {
-                    u64 *k0 = bsc.get<u64>(n_chained), *v0 = bsc.get<u64>(n_chained), *k1 = bsc.get<u64>(n_chained), *v1 = bsc.get<u64>(n_chained);
-                    hw_list = bsc.get<u32>(n_chained);
-                    if (!k0 || !v0 || !k1 || !v1 || !hw_list) return LRGE_ERR_DEVICE;
-                    hipLaunchKernelGGL(k_group_fill, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, d_cnt + 1, k0, v0);
-                    KCHK(ctx);
-                    u64 *rk, *rv;
-                    rc = radix_sort_pairs(ctx, bsc, k0, v0, k1, v1, n_chained, 0, 16, &rk, &rv);   // keys: 65535 - min(n, 65535)
-                    if (rc) return rc;
-                    hipLaunchKernelGGL(k_vals_to_u32, dim3((u32)div_up(n_chained, 256)), dim3(256), 0, ctx->stream, rv, n_chained, hw_list);
-                    KCHK(ctx);
-                    bsc.drop(k0); bsc.drop(v0); bsc.drop(k1); bsc.drop(v1);
-                }
-                bsc.drop(d_cnt); bsc.drop(d_anch);
-            } else {
-                bin_count = bsc.get<u32>(N_BINS); bin_list = bsc.get<u32>((size_t)N_BINS * G + 1);
-                unsigned long long *bin_anchors = (unsigned long long *)bsc.get<u64>(N_BINS);
-                if (!bin_count || !bin_list || !bin_anchors) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemsetAsync(bin_anchors, 0, N_BINS * 8, ctx->stream));
-                HIPCHK(ctx, hipMemsetAsync(bin_count, 0, N_BINS * 4, ctx->stream));
-                hipLaunchKernelGGL(k_group_bin, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, bl, bin_count, bin_list, bin_anchors);
+                u64 *rk, *rv;
+                rc = radix_sort_pairs(ctx, bsc, k0, v0, k1, v1, n_chained, 0, 16, &rk, &rv);   // keys: 65535 - min(n, 65535)
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_vals_to_u32, dim3((u32)div_up(n_chained, 256)), dim3(256), 0, ctx->stream, rv, n_chained, hw_list);
                 KCHK(ctx);
-                HIPCHK(ctx, hipMemcpyAsync(h_bins, bin_count, N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipMemcpyAsync(h_bin_anchors, bin_anchors, N_BINS * 8, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                bsc.drop(k0); bsc.drop(v0); bsc.drop(k1); bsc.drop(v1);
             }
-            t.stop();
+            bsc.drop(d_cnt); bsc.drop(d_anch);
+        } else {
+            bin_count = bsc.get<u32>(N_BINS); bin_list = bsc.get<u32>((size_t)N_BINS * G + 1);
+            unsigned long long *bin_anchors = (unsigned long long *)bsc.get<u64>(N_BINS);
+            if (!bin_count || !bin_list || !bin_anchors) return LRGE_ERR_DEVICE;
+            HIPCHK(ctx, hipMemsetAsync(bin_anchors, 0, N_BINS * 8, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(bin_count, 0, N_BINS * 4, ctx->stream));
+            hipLaunchKernelGGL(k_group_bin, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, bl, bin_count, bin_list, bin_anchors);
+            KCHK(ctx);
+            HIPCHK(ctx, hipMemcpyAsync(h_bins, bin_count, N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_bin_anchors, bin_anchors, N_BINS * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
-        ctx->counters[LRGE_C_GROUPS] += G;
-        {
-            GroupOut go; go.flags = gflags; go.chains = d_chains; go.n_chains = d_nchains; go.chain_cap = job.chain_cap;
-            if (chain_mode == 0) {
-                if (n_chained) {
-                    StageTimer t(ctx, LRGE_T_CHAIN);
-                    HwChainArgs ha;
-                    ha.akey = skey; ha.aval = sval; ha.gstart = gstart; ha.n_groups = G; ha.n_anchors = A; ha.list = hw_list; ha.n_list = n_big;
-                    ha.grec = bsc.get<u64>(A); ha.tmark = bsc.get<u32>(A);
-                    ha.prio = (u32)env_u64("LRGE_HIP_HW_PRIO", 0);
-                    if (!ha.grec || !ha.tmark) return LRGE_ERR_DEVICE;
-                    HIPCHK(ctx, hipMemsetAsync(ha.tmark, 0, A * 4, ctx->stream));
-                    // the list is sorted by min(n, 65535) descending, so [0, n_big) are exactly the groups above lpg_max
-                    // the two kernels touch disjoint groups; k_chain_lpg goes to the side stream so that its long
-                    // wavefronts run beside k_chain_hw's (fork / join with events, no host sync)
-                    const bool both = n_big && n_chained > n_big;
-                    if (both) {
-                        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-                        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-                    }
-                    if (n_chained > n_big) {
-                        LpgChainArgs la;
-                        la.akey = skey; la.aval = sval; la.gstart = gstart; la.n_groups = G; la.n_anchors = A;
-                        la.list = hw_list + n_big; la.n_list = n_chained - n_big; la.grec = ha.grec; la.tmark = ha.tmark;
-                        la.prio = (u32)env_u64("LRGE_HIP_LPG_PRIO", 3);
-                        StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
-                        const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !getenv("LRGE_HIP_LPG_NOTAB");
-                        if (pentab) hipLaunchKernelGGL(k_chain_lpg<true>, dim3((la.n_list + 63) / 64), dim3(64), (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES,
-                                                       both ? ctx->stream2 : ctx->stream, la, cp, go);
-                        else hipLaunchKernelGGL(k_chain_lpg<false>, dim3((la.n_list + 63) / 64), dim3(64), LPG_RING_BYTES, both ? ctx->stream2 : ctx->stream, la, cp, go);
-                        KCHK(ctx);
-                        tl.stop();
-                        ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
-                        ctx->counters[LRGE_C_LPG_LAUNCHES] += 1;
-                        ctx->counters[LRGE_C_LPG_ANCHORS] += a_chained - a_big;
-                    }
-                    if (n_big) {
-                        hipLaunchKernelGGL(k_chain_hw, dim3((n_big + 1) / 2), dim3(64), 0, ctx->stream, ha, cp, go);
-                        KCHK(ctx);
-                        ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
-                    }
-                    if (both) {
-                        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-                        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-                    }
-                    t.stop();
-                    ctx->counters[LRGE_C_CHAIN_ANCHORS] += a_chained;
-                    ctx->counters[LRGE_C_GROUPS_CHAINED] += n_chained;
-                }
-            } else if (chain_mode == 3) {
-                // register-window kernel, one group per wavefront, every group size in one launch, largest bins first
-                u32 total_blocks = 0; u64 total_anch = 0;
-                RegChainArgs ra;
-                ra.akey = skey; ra.aval = sval; ra.gstart = gstart; ra.n_groups = G; ra.n_anchors = A; ra.list = bin_list;
-                for (int k = 0; k < N_BINS; ++k) {
-                    int b = N_BINS - 1 - k;
-                    ra.bin_first[k] = total_blocks; ra.bin_of[k] = (u32)b;
-                    total_blocks += h_bins[b]; total_anch += h_bin_anchors[b];
-                }
-                ra.n_blocks = total_blocks;
-                if (total_blocks) {
-                    StageTimer t(ctx, LRGE_T_CHAIN);
-                    ra.grec = bsc.get<u64>(A); ra.tmark = bsc.get<u32>(A);
-                    if (!ra.grec || !ra.tmark) return LRGE_ERR_DEVICE;
-                    HIPCHK(ctx, hipMemsetAsync(ra.tmark, 0, A * 4, ctx->stream));
-                    hipLaunchKernelGGL(k_chain_reg, dim3(total_blocks), dim3(64), 0, ctx->stream, ra, cp, go);
-                    KCHK(ctx);
-                    t.stop();
-                    ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
-                    ctx->counters[LRGE_C_CHAIN_ANCHORS] += total_anch;
-                    ctx->counters[LRGE_C_GROUPS_CHAINED] += total_blocks;
-                }
-            } else {
-                const int first_lds_bin = chain_mode == 2 ? -1 : N_BINS - 2;   // "glb": everything through the generic kernel
-                u32 n_glb = 0; u64 a_glb = 0;
-                for (int b = N_BINS - 1; b > first_lds_bin; --b) { n_glb += h_bins[b]; a_glb += h_bin_anchors[b]; }
-                if (n_glb) {
-                    StageTimer t(ctx, LRGE_T_CHAIN_GLB);
-                    i32 *gX = bsc.get<i32>(A), *gY = bsc.get<i32>(A), *gF = bsc.get<i32>(A), *gP = bsc.get<i32>(A), *gT = bsc.get<i32>(A);
-                    u8 *gS = bsc.get<u8>(A);
-                    if (!gX || !gY || !gF || !gP || !gT || !gS) return LRGE_ERR_DEVICE;
-                    for (int b = N_BINS - 1; b > first_lds_bin; --b) {
-                        if (!h_bins[b]) continue;
-                        hipLaunchKernelGGL(k_chain_glb, dim3(h_bins[b]), dim3(64), 0, ctx->stream, skey, sval, gstart, G, A,
-                                           bin_list + (u64)b * G, h_bins[b], gX, gY, gF, gP, gT, gS, cp, go);
-                        KCHK(ctx);
-                        ctx->counters[LRGE_C_CHAIN_GLB_LAUNCHES] += 1;
-                    }
-                    t.stop();
-                    ctx->counters[LRGE_C_CHAIN_GLB_ANCHORS] += a_glb;
-                    ctx->counters[LRGE_C_GROUPS_CHAINED] += n_glb;
-                }
+        t.stop();
+    }
+    ctx->counters[LRGE_C_GROUPS] += G;
+    {
+        GroupOut go; go.flags = gflags; go.chains = d_chains; go.n_chains = d_nchains; go.chain_cap = job.chain_cap;
+        if (chain_mode == 0) {
+            if (n_chained) {
                 StageTimer t(ctx, LRGE_T_CHAIN);
-                for (int b = first_lds_bin; b >= 0; --b) {
-                    if (!h_bins[b]) continue;
-                    u32 cap = bl.lim[b];
-                    hipLaunchKernelGGL(k_chain_lds, dim3(h_bins[b]), dim3(64), (size_t)cap * 18 + 64, ctx->stream, skey, sval, gstart, G, A,
-                                       bin_list + (u64)b * G, h_bins[b], cap, cp, go);
+                HwChainArgs ha;
+                ha.akey = skey; ha.aval = sval; ha.gstart = gstart; ha.n_groups = G; ha.n_anchors = A; ha.list = hw_list; ha.n_list = n_big;
+                ha.grec = bsc.get<u64>(A); ha.tmark = bsc.get<u32>(A);
+                ha.prio = (u32)env_u64("LRGE_HIP_HW_PRIO", 0);
+                if (!ha.grec || !ha.tmark) return LRGE_ERR_DEVICE;
+                HIPCHK(ctx, hipMemsetAsync(ha.tmark, 0, A * 4, ctx->stream));
+                // the list is sorted by min(n, 65535) descending, so [0, n_big) are exactly the groups above lpg_max
+                // the two kernels touch disjoint groups; k_chain_lpg goes to the side stream so that its long
+                // wavefronts run beside k_chain_hw's (fork / join with events, no host sync)
+                const bool both = n_big && n_chained > n_big;
+                if (both) {
+                    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                }
+                if (n_chained > n_big) {
+                    LpgChainArgs la;
+                    la.akey = skey; la.aval = sval; la.gstart = gstart; la.n_groups = G; la.n_anchors = A;
+                    la.list = hw_list + n_big; la.n_list = n_chained - n_big; la.grec = ha.grec; la.tmark = ha.tmark;
+                    la.prio = (u32)env_u64("LRGE_HIP_LPG_PRIO", 3);
+                    StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
+                    const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !getenv("LRGE_HIP_LPG_NOTAB");
+                    if (pentab) hipLaunchKernelGGL(k_chain_lpg<true>, dim3((la.n_list + 63) / 64), dim3(64), (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES,
+                                                   both ? ctx->stream2 : ctx->stream, la, cp, go);
+                    else hipLaunchKernelGGL(k_chain_lpg<false>, dim3((la.n_list + 63) / 64), dim3(64), LPG_RING_BYTES, both ? ctx->stream2 : ctx->stream, la, cp, go);
+                    KCHK(ctx);
+                    tl.stop();
+                    ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+                    ctx->counters[LRGE_C_LPG_LAUNCHES] += 1;
+                    ctx->counters[LRGE_C_LPG_ANCHORS] += a_chained - a_big;
+                }
+                if (n_big) {
+                    hipLaunchKernelGGL(k_chain_hw, dim3((n_big + 1) / 2), dim3(64), 0, ctx->stream, ha, cp, go);
                     KCHK(ctx);
                     ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
-                    ctx->counters[LRGE_C_CHAIN_ANCHORS] += h_bin_anchors[b];
-                    ctx->counters[LRGE_C_GROUPS_CHAINED] += h_bins[b];
+                }
+                if (both) {
+                    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
                 }
                 t.stop();
+                ctx->counters[LRGE_C_CHAIN_ANCHORS] += a_chained;
+                ctx->counters[LRGE_C_GROUPS_CHAINED] += n_chained;
             }
-        }
-        {
-            StageTimer t(ctx, LRGE_T_COUNT);
-            CountParams cnp; cnp.kl = kl; cnp.q0 = q0; cnp.mode = job.mode;
-            cnp.q_rank = Q->has_rank ? Q->d_rank : nullptr; cnp.t_rank = T->has_rank ? T->d_rank : nullptr;
-            cnp.t_dup = T->dup_rank ? 1 : 0;
-            cnp.q_map = d_qmap;
-            hipLaunchKernelGGL(k_count, dim3((u32)div_up(G, 256)), dim3(256), 0, ctx->stream, skey, gstart, gflags, G, cnp, d_counts, d_hasmap);
-            KCHK(ctx);
-            // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
+        } else if (chain_mode == 3) {
+            // register-window kernel, one group per wavefront, every group size in one launch, largest bins first
+            u32 total_blocks = 0; u64 total_anch = 0;
+            RegChainArgs ra;
+            ra.akey = skey; ra.aval = sval; ra.gstart = gstart; ra.n_groups = G; ra.n_anchors = A; ra.list = bin_list;
+            for (int k = 0; k < N_BINS; ++k) {
+                int b = N_BINS - 1 - k;
+                ra.bin_first[k] = total_blocks; ra.bin_of[k] = (u32)b;
+                total_blocks += h_bins[b]; total_anch += h_bin_anchors[b];
+            }
+            ra.n_blocks = total_blocks;
+            if (total_blocks) {
+                StageTimer t(ctx, LRGE_T_CHAIN);
+                ra.grec = bsc.get<u64>(A); ra.tmark = bsc.get<u32>(A);
+                if (!ra.grec || !ra.tmark) return LRGE_ERR_DEVICE;
+                HIPCHK(ctx, hipMemsetAsync(ra.tmark, 0, A * 4, ctx->stream));
+                hipLaunchKernelGGL(k_chain_reg, dim3(total_blocks), dim3(64), 0, ctx->stream, ra, cp, go);
+                KCHK(ctx);
+                t.stop();
+                ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+                ctx->counters[LRGE_C_CHAIN_ANCHORS] += total_anch;
+                ctx->counters[LRGE_C_GROUPS_CHAINED] += total_blocks;
+            }
+        } else {
+            const int first_lds_bin = chain_mode == 2 ? -1 : N_BINS - 2;   // "glb": everything through the generic kernel
+            u32 n_glb = 0; u64 a_glb = 0;
+            for (int b = N_BINS - 1; b > first_lds_bin; --b) { n_glb += h_bins[b]; a_glb += h_bin_anchors[b]; }
+            if (n_glb) {
+                StageTimer t(ctx, LRGE_T_CHAIN_GLB);
+                i32 *gX = bsc.get<i32>(A), *gY = bsc.get<i32>(A), *gF = bsc.get<i32>(A), *gP = bsc.get<i32>(A), *gT = bsc.get<i32>(A);
+                u8 *gS = bsc.get<u8>(A);
+                if (!gX || !gY || !gF || !gP || !gT || !gS) return LRGE_ERR_DEVICE;
+                for (int b = N_BINS - 1; b > first_lds_bin; --b) {
+                    if (!h_bins[b]) continue;
+                    hipLaunchKernelGGL(k_chain_glb, dim3(h_bins[b]), dim3(64), 0, ctx->stream, skey, sval, gstart, G, A,
+                                       bin_list + (u64)b * G, h_bins[b], gX, gY, gF, gP, gT, gS, cp, go);
+                    KCHK(ctx);
+                    ctx->counters[LRGE_C_CHAIN_GLB_LAUNCHES] += 1;
+                }
+                t.stop();
+                ctx->counters[LRGE_C_CHAIN_GLB_ANCHORS] += a_glb;
+                ctx->counters[LRGE_C_GROUPS_CHAINED] += n_glb;
+            }
+            StageTimer t(ctx, LRGE_T_CHAIN);
+            for (int b = first_lds_bin; b >= 0; --b) {
+                if (!h_bins[b]) continue;
+                u32 cap = bl.lim[b];
+                hipLaunchKernelGGL(k_chain_lds, dim3(h_bins[b]), dim3(64), (size_t)cap * 18 + 64, ctx->stream, skey, sval, gstart, G, A,
+                                   bin_list + (u64)b * G, h_bins[b], cap, cp, go);
+                KCHK(ctx);
+                ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+                ctx->counters[LRGE_C_CHAIN_ANCHORS] += h_bin_anchors[b];
+                ctx->counters[LRGE_C_GROUPS_CHAINED] += h_bins[b];
+            }
             t.stop();
         }
-        q0 = q1;
     }
+    {
+        StageTimer t(ctx, LRGE_T_COUNT);
+        CountParams cnp; cnp.kl = kl; cnp.q0 = q0; cnp.mode = job.mode;
+        cnp.q_rank = Q->has_rank ? Q->d_rank : nullptr; cnp.t_rank = T->has_rank ? T->d_rank : nullptr;
+        cnp.t_dup = T->dup_rank ? 1 : 0;
+        cnp.q_map = d_qmap;
+        hipLaunchKernelGGL(k_count, dim3((u32)div_up(G, 256)), dim3(256), 0, ctx->stream, skey, gstart, gflags, G, cnp, d_counts, d_hasmap);
+        KCHK(ctx);
+        // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
+        t.stop();
+    }
+    return LRGE_OK;
+}
+
+int OverlapRun::finish() {
+    const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
+    (void)T; (void)P; (void)nq; (void)nt;
     if (job.counts) HIPCHK(ctx, hipMemcpyAsync(job.counts, d_counts, (size_t)n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (job.has_map) HIPCHK(ctx, hipMemcpyAsync(job.has_map, d_hasmap, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1103,10 +1115,50 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         if (m && job.chains) HIPCHK(ctx, hipMemcpy(job.chains, d_chains, m * sizeof(lrge_hip_chain), hipMemcpyDeviceToHost));
     }
     if (job.an && job.dump_anchors) *job.an = 0;
-    t_total.stop();
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->resolve_timers();
     return LRGE_OK;
+}
+
+static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *Q, OverlapJob &job) {
+
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->resolve_timers();
+    memset(ctx->ms, 0, sizeof(ctx->ms));
+    memset(ctx->counters, 0, sizeof(ctx->counters));
+    if (Q->has_empty && !job.dump_anchors) {  // aligner.rs:214-216 -> LrgeError::MapError aborts the run
+        LRGE_SET_ERR(ctx, "Error mapping read: Sequence is empty");
+        return LRGE_ERR_MAP;
+    }
+    StageTimer t_total(ctx, LRGE_T_TOTAL);
+    OverlapRun R(ctx, ix, Q, job);
+    auto done = [&](int rc) -> int {            // common exit: total time, drain the stream, resolve the stage timers
+        if (rc == RUN_DONE) rc = LRGE_OK;
+        t_total.stop();
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        ctx->resolve_timers();
+        if (rc == LRGE_OK && e != hipSuccess) { LRGE_SET_ERR(ctx, "stream: %s", hipGetErrorString(e)); return LRGE_ERR_DEVICE; }
+        return rc;
+    };
+    int rc = R.prepare();
+    if (rc) return done(rc);
+    rc = R.seeds();
+    if (rc) return done(rc);
+    rc = R.plan();
+    if (rc) return done(rc);
+    const u32 nq = Q->n;
+    u32 q0 = job.dump_anchors ? job.dump_query : 0;
+    const u32 q_end = job.dump_anchors ? job.dump_query + 1 : nq;
+    while (q0 < q_end) {
+        u32 q1 = q0; u64 A = 0;
+        while (q1 < q_end && (q1 - q0) < (1u << std::min<u32>(R.max_bits_q, 24)) && (q1 == q0 || A + R.h_qtot[q1] <= R.batch_cap)) { A += R.h_qtot[q1]; ++q1; }
+        if (A >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "query %u alone yields %llu anchors (limit 2^32)", q0, (unsigned long long)A); return done(LRGE_ERR_TOO_MANY); }
+        ctx->counters[LRGE_C_BATCHES] += 1;
+        R.kl.bits_q = std::max<u32>(1, ceil_log2_u64((u64)(q1 - q0)));
+        R.cp.kl = R.kl; R.cp.q0 = q0;
+        rc = R.batch(q0, q1, A);
+        if (rc) return done(rc);
+        q0 = q1;
+    }
+    return done(R.finish());
 }
 
 static int check_common(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *q) {

@@ -485,6 +485,39 @@ struct OverlapJob {
 };
 
 
+// Split of the size-sorted group list between the two chain kernels, from the size census of k_group_count (hn / ha:
+// groups and anchors per class of GSZ_W anchors).  Groups above T anchors -> k_chain_hw (~0.55 us per anchor of latency,
+// ~93 VALU instructions per anchor), the rest -> k_chain_lpg (~4.3 us per anchor of the LONGEST group of a wavefront,
+// ~22 VALU per anchor).  Both run side by side; the stage takes about
+//   max(T * t_lpg, n_longest * t_hw, VALU work / issue rate of the chip)
+// and T (a multiple of GSZ_W) minimises that estimate -- measured constants of this kernel pair on MI355X.
+// `fixed` != LPG_MAX_AUTO pins T (LRGE_HIP_LPG_MAX / LRGE_HIP_CHAIN=hw|lpg).
+struct ChainSplit { u32 T, n_big; unsigned long long a_big; int top; };
+static ChainSplit choose_chain_split(const u32 *hn, const unsigned long long *ha, unsigned long long a_chained, u32 fixed, int n_cu) {
+    ChainSplit r; r.T = fixed; r.n_big = 0; r.a_big = 0; r.top = -1;
+    for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) r.top = b;
+    if (fixed == LPG_MAX_AUTO) {
+        const double t_lpg = 4.3e-6, t_hw = 0.55e-6, c_lpg = 22.0, c_hw = 93.0;
+        const double rate = 0.8 * (double)n_cu * 4 * 2.1e9 / 4.0;   // wave64 VALU instructions per second, ~80 % reachable
+        double best = 1e30, a_le = 0;    // a_le: anchors in classes <= b
+        r.T = 0;
+        for (int b = -1; b < GSZ_BINS - 1; ++b) {      // T = (b + 1) * GSZ_W: classes 0..b go to k_chain_lpg
+            if (b >= 0) a_le += (double)ha[b];
+            const double a_hw = (double)a_chained - a_le;
+            const double crit_lpg = b >= 0 ? (double)std::min<int>(b + 1, r.top + 1) * GSZ_W * t_lpg : 0.0;
+            const double crit_hw = a_hw > 0 ? (double)(r.top + 1) * GSZ_W * t_hw : 0.0;
+            const double est = std::max(std::max(crit_lpg, crit_hw), (a_le * c_lpg + a_hw * c_hw) / rate);
+            if (est < best - 1e-9) { best = est; r.T = (u32)(b + 1) * GSZ_W; }
+            if (b >= r.top) break;
+        }
+    }
+    // groups above T: whole classes (class b = (b*W, (b+1)*W]); a pinned T that is no class edge counts by class floor --
+    // any split point of the sorted list is valid, only the balance depends on it
+    for (int b = 0; b < GSZ_BINS; ++b)
+        if ((u64)b * GSZ_W >= (u64)r.T) { r.n_big += hn[b]; r.a_big += ha[b]; }
+    return r;
+}
+
 // One overlap call = one OverlapRun: the state every stage shares lives here, the stages are its methods
 // (prepare -> seeds -> plan -> batch x N -> finish); a stage returns RUN_DONE when the call is complete early
 // (empty sets, statistics-only or anchor-dump runs).
@@ -511,6 +544,10 @@ struct OverlapRun {
     int plan();                                 // batch size, key layout, chaining parameters
     int batch(u32 q0, u32 q1, u64 A);           // K4 expand, sort, K5 groups, K6 chain, K7 count for queries [q0, q1)
     int finish();                               // results to the host
+    void plan_anchor_sort(u32 q0, u32 q1, bool packed);          // which queries sort inside LDS, tiles for the rest
+    int dump_sorted_anchors(const u64 *skey, const u64 *sval, u64 A);   // lrge_hip_anchors_dump: one query's anchors, mm2 encoding
+    int launch_reference_chain(int chain_mode, Scratch &bsc, const u64 *skey, const u64 *sval, const u32 *gstart, u32 G, u64 A,
+                               const u32 *bin_list, const u32 *h_bins, const unsigned long long *h_bin_anchors, GroupOut go);
 };
 
 int OverlapRun::prepare() {
@@ -737,6 +774,120 @@ int OverlapRun::plan() {
     return LRGE_OK;
 }
 
+// The expansion emits the anchors query by query, so only (target, strand, position) need sorting, inside every
+// query's segment.  Packed (count-only) runs sort the segments that fit a workgroup's LDS there (k_seg_sort_local,
+// capacity classes 2048 / 8192 / 16384 anchors); everything else is cut into RS_TILE tiles for the segmented
+// global passes (SegTile, k_prims.h), whose scanned histogram is offset by the items sorted locally (delta).
+void OverlapRun::plan_anchor_sort(u32 q0, u32 q1, bool packed) {
+    h_tiles.clear();
+    for (auto &v : h_local) v.clear();
+    u32 off = 0, tb = 0, &n_local = n_local_items;
+    n_local = 0;
+    const bool local_ok = !getenv("LRGE_HIP_NO_LOCAL_SORT");
+    for (u32 q = q0; q < q1; ++q) {
+        const u32 c = h_qtot[q];
+        if (packed && c) {
+            const int cls = c <= 2048 ? 0 : c <= 8192 ? 1 : c <= 16384 ? 2 : 3;
+            if (cls < 3 && local_ok && ctx->lsort_ok[cls]) { h_local[cls].push_back(SegDesc{off, c, q - q0, 0}); off += c; n_local += c; continue; }
+        }
+        const u32 nt_q = (u32)div_up((u64)c, RS_TILE);
+        for (u32 lt = 0; lt < nt_q; ++lt) {
+            SegTile t; t.start = off + lt * RS_TILE; t.len = std::min<u32>(RS_TILE, c - lt * RS_TILE);
+            t.hbase = 256u * tb + lt; t.hstride = nt_q; t.seg = q - q0; t.delta = n_local;
+            h_tiles.push_back(t);
+        }
+        off += c; tb += nt_q;
+    }
+}
+
+int OverlapRun::dump_sorted_anchors(const u64 *skey, const u64 *sval, u64 A) {
+    *job.an = A;
+    u64 m = A < job.acap ? A : job.acap;
+    std::vector<u64> hk(m), hvv(m);
+    if (m) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
+        HIPCHK(ctx, hipMemcpy(hk.data(), skey, m * 8, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(hvv.data(), sval, m * 8, hipMemcpyDeviceToHost));
+    }
+    const u64 rmask = (1ULL << kl.bits_rpos) - 1;
+    // back to minimap2's mm128 anchor encoding and array order: the device orders groups
+    // (target, strand) so that both strands of a pair are adjacent, minimap2 orders them
+    // (strand, target); a stable re-sort by x keeps the order inside every group.
+    std::vector<std::pair<u64, u64>> tmp(m);
+    for (u64 i = 0; i < m; ++i) {
+        u64 k = hk[i];
+        u64 rev = (k >> kl.sh_rev()) & 1, rid = (k >> kl.sh_rid()) & ((1ULL << kl.bits_rid) - 1);
+        tmp[i] = {rev << 63 | rid << 32 | (k & rmask), hvv[i] & AVAL_LOW_MASK};   // drop the seed rank
+    }
+    std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<u64, u64> &a, const std::pair<u64, u64> &b) { return a.first < b.first; });
+    for (u64 i = 0; i < m; ++i) { job.ax[i] = tmp[i].first; job.ay[i] = tmp[i].second; }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RUN_DONE;
+}
+
+// LRGE_HIP_CHAIN=reg|lds|glb: the earlier one-group-per-wavefront chain kernels, kept as on-device references for the
+// parity tests (groups arrive in N_BINS size bins instead of the size-sorted list).
+int OverlapRun::launch_reference_chain(int chain_mode, Scratch &bsc, const u64 *skey, const u64 *sval, const u32 *gstart, u32 G, u64 A,
+                                       const u32 *bin_list, const u32 *h_bins, const unsigned long long *h_bin_anchors, GroupOut go) {
+    if (chain_mode == 3) {
+        // register-window kernel, one group per wavefront, every group size in one launch, largest bins first
+        u32 total_blocks = 0; u64 total_anch = 0;
+        RegChainArgs ra;
+        ra.akey = skey; ra.aval = sval; ra.gstart = gstart; ra.n_groups = G; ra.n_anchors = A; ra.list = bin_list;
+        for (int k = 0; k < N_BINS; ++k) {
+            int b = N_BINS - 1 - k;
+            ra.bin_first[k] = total_blocks; ra.bin_of[k] = (u32)b;
+            total_blocks += h_bins[b]; total_anch += h_bin_anchors[b];
+        }
+        ra.n_blocks = total_blocks;
+        if (total_blocks) {
+            StageTimer t(ctx, LRGE_T_CHAIN);
+            ra.grec = bsc.get<u64>(A); ra.tmark = bsc.get<u32>(A);
+            if (!ra.grec || !ra.tmark) return LRGE_ERR_DEVICE;
+            HIPCHK(ctx, hipMemsetAsync(ra.tmark, 0, A * 4, ctx->stream));
+            hipLaunchKernelGGL(k_chain_reg, dim3(total_blocks), dim3(64), 0, ctx->stream, ra, cp, go);
+            KCHK(ctx);
+            t.stop();
+            ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+            ctx->counters[LRGE_C_CHAIN_ANCHORS] += total_anch;
+            ctx->counters[LRGE_C_GROUPS_CHAINED] += total_blocks;
+        }
+    } else {
+        const int first_lds_bin = chain_mode == 2 ? -1 : N_BINS - 2;   // "glb": everything through the generic kernel
+        u32 n_glb = 0; u64 a_glb = 0;
+        for (int b = N_BINS - 1; b > first_lds_bin; --b) { n_glb += h_bins[b]; a_glb += h_bin_anchors[b]; }
+        if (n_glb) {
+            StageTimer t(ctx, LRGE_T_CHAIN_GLB);
+            i32 *gX = bsc.get<i32>(A), *gY = bsc.get<i32>(A), *gF = bsc.get<i32>(A), *gP = bsc.get<i32>(A), *gT = bsc.get<i32>(A);
+            u8 *gS = bsc.get<u8>(A);
+            if (!gX || !gY || !gF || !gP || !gT || !gS) return LRGE_ERR_DEVICE;
+            for (int b = N_BINS - 1; b > first_lds_bin; --b) {
+                if (!h_bins[b]) continue;
+                hipLaunchKernelGGL(k_chain_glb, dim3(h_bins[b]), dim3(64), 0, ctx->stream, skey, sval, gstart, G, A,
+                                   bin_list + (u64)b * G, h_bins[b], gX, gY, gF, gP, gT, gS, cp, go);
+                KCHK(ctx);
+                ctx->counters[LRGE_C_CHAIN_GLB_LAUNCHES] += 1;
+            }
+            t.stop();
+            ctx->counters[LRGE_C_CHAIN_GLB_ANCHORS] += a_glb;
+            ctx->counters[LRGE_C_GROUPS_CHAINED] += n_glb;
+        }
+        StageTimer t(ctx, LRGE_T_CHAIN);
+        for (int b = first_lds_bin; b >= 0; --b) {
+            if (!h_bins[b]) continue;
+            u32 cap = bl.lim[b];
+            hipLaunchKernelGGL(k_chain_lds, dim3(h_bins[b]), dim3(64), (size_t)cap * 18 + 64, ctx->stream, skey, sval, gstart, G, A,
+                               bin_list + (u64)b * G, h_bins[b], cap, cp, go);
+            KCHK(ctx);
+            ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
+            ctx->counters[LRGE_C_CHAIN_ANCHORS] += h_bin_anchors[b];
+            ctx->counters[LRGE_C_GROUPS_CHAINED] += h_bins[b];
+        }
+        t.stop();
+    }
+    return LRGE_OK;
+}
+
 int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
     const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
     (void)T; (void)P; (void)nq; (void)nt;
@@ -767,29 +918,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
     }
     {
         StageTimer t(ctx, LRGE_T_ANCHOR_SORT);
-        // the expansion emits the anchors query by query, so only (target, strand, position) need sorting,
-        // inside every query's segment: the query bits cost no radix pass (SegTile, k_prims.h)
-        h_tiles.clear();
-        for (auto &v : h_local) v.clear();
-        {
-            u32 off = 0, tb = 0, &n_local = n_local_items;
-            n_local = 0;
-            const bool local_ok = !getenv("LRGE_HIP_NO_LOCAL_SORT");
-            for (u32 q = q0; q < q1; ++q) {
-                const u32 c = h_qtot[q];
-                if (packed && c) {   // segment-local sort classes (capacity 2048 / 8192 / 16384 anchors)
-                    const int cls = c <= 2048 ? 0 : c <= 8192 ? 1 : c <= 16384 ? 2 : 3;
-                    if (cls < 3 && local_ok && ctx->lsort_ok[cls]) { h_local[cls].push_back(SegDesc{off, c, q - q0, 0}); off += c; n_local += c; continue; }
-                }
-                const u32 nt_q = (u32)div_up((u64)c, RS_TILE);
-                for (u32 lt = 0; lt < nt_q; ++lt) {
-                    SegTile t; t.start = off + lt * RS_TILE; t.len = std::min<u32>(RS_TILE, c - lt * RS_TILE);
-                    t.hbase = 256u * tb + lt; t.hstride = nt_q; t.seg = q - q0; t.delta = n_local;
-                    h_tiles.push_back(t);
-                }
-                off += c; tb += nt_q;
-            }
-        }
+        plan_anchor_sort(q0, q1, packed);
         SegTile *d_tiles = (SegTile *)bsc.get<u32>(h_tiles.size() * (sizeof(SegTile) / 4) + 4);
         if (!d_tiles) return LRGE_ERR_DEVICE;
         HIPCHK(ctx, hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
@@ -797,25 +926,16 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
             UnpackParams up; up.sb = kl.sh_q(); up.bits_qy = bits_qy; up.sh_q = kl.sh_q(); up.dmask = 255;
             // segments that fit a workgroup's LDS are sorted there in one kernel (k_seg_sort_local: 8 B in, 16 B out
             // per anchor); only the larger ones take the tiled global passes
-            if (h_local[0].size()) {
-                SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[0].size() * 4);
+            for (int cls = 0; cls < 3; ++cls) {
+                if (h_local[cls].empty()) continue;
+                SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[cls].size() * 4);
                 if (!d) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemcpyAsync(d, h_local[0].data(), h_local[0].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
-                hipLaunchKernelGGL((k_seg_sort_local<256, 8>), dim3((u32)h_local[0].size()), dim3(256), LSORT_BYTES(256, 8), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
-                KCHK(ctx);
-            }
-            if (h_local[1].size()) {
-                SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[1].size() * 4);
-                if (!d) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemcpyAsync(d, h_local[1].data(), h_local[1].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
-                hipLaunchKernelGGL((k_seg_sort_local<512, 16>), dim3((u32)h_local[1].size()), dim3(512), LSORT_BYTES(512, 16), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
-                KCHK(ctx);
-            }
-            if (h_local[2].size()) {
-                SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[2].size() * 4);
-                if (!d) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemcpyAsync(d, h_local[2].data(), h_local[2].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
-                hipLaunchKernelGGL((k_seg_sort_local<1024, 16>), dim3((u32)h_local[2].size()), dim3(1024), LSORT_BYTES(1024, 16), ctx->stream, akey, aval, aval2, d, up, (int)kl.sh_q());
+                HIPCHK(ctx, hipMemcpyAsync(d, h_local[cls].data(), h_local[cls].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
+                const dim3 grid((u32)h_local[cls].size());
+                const int nbits = (int)kl.sh_q();
+                if (cls == 0) hipLaunchKernelGGL((k_seg_sort_local<256, 8>), grid, dim3(256), LSORT_BYTES(256, 8), ctx->stream, akey, aval, aval2, d, up, nbits);
+                else if (cls == 1) hipLaunchKernelGGL((k_seg_sort_local<512, 16>), grid, dim3(512), LSORT_BYTES(512, 16), ctx->stream, akey, aval, aval2, d, up, nbits);
+                else hipLaunchKernelGGL((k_seg_sort_local<1024, 16>), grid, dim3(1024), LSORT_BYTES(1024, 16), ctx->stream, akey, aval, aval2, d, up, nbits);
                 KCHK(ctx);
             }
             rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up, A - n_local_items);
@@ -834,30 +954,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
         }
         t.stop();
     }
-    if (job.dump_anchors) {
-        *job.an = A;
-        u64 m = A < job.acap ? A : job.acap;
-        std::vector<u64> hk(m), hvv(m);
-        if (m) {
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
-            HIPCHK(ctx, hipMemcpy(hk.data(), skey, m * 8, hipMemcpyDeviceToHost));
-            HIPCHK(ctx, hipMemcpy(hvv.data(), sval, m * 8, hipMemcpyDeviceToHost));
-        }
-        const u64 rmask = (1ULL << kl.bits_rpos) - 1;
-        // back to minimap2's mm128 anchor encoding and array order: the device orders groups
-        // (target, strand) so that both strands of a pair are adjacent, minimap2 orders them
-        // (strand, target); a stable re-sort by x keeps the order inside every group.
-        std::vector<std::pair<u64, u64>> tmp(m);
-        for (u64 i = 0; i < m; ++i) {
-            u64 k = hk[i];
-            u64 rev = (k >> kl.sh_rev()) & 1, rid = (k >> kl.sh_rid()) & ((1ULL << kl.bits_rid) - 1);
-            tmp[i] = {rev << 63 | rid << 32 | (k & rmask), hvv[i] & AVAL_LOW_MASK};   // drop the seed rank
-        }
-        std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<u64, u64> &a, const std::pair<u64, u64> &b) { return a.first < b.first; });
-        for (u64 i = 0; i < m; ++i) { job.ax[i] = tmp[i].first; job.ay[i] = tmp[i].second; }
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        return RUN_DONE;
-    }
+    if (job.dump_anchors) return dump_sorted_anchors(skey, sval, A);
     // groups
     // LRGE_HIP_CHAIN selects the chain kernel: default "hw" (two groups per wavefront), "reg" (one group
     // per wavefront, register window), "lds" / "glb" (earlier forms, kept as on-device references)
@@ -914,43 +1011,12 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
             HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
             n_chained = h_cnt[0]; a_chained = h_anch[0];
             {
-                // Split of the size-sorted list: groups above T anchors -> k_chain_hw (~0.55 us per anchor of latency,
-                // ~93 VALU instructions per anchor), the rest -> k_chain_lpg (~4.4 us per anchor of the LONGEST group
-                // of a wavefront, ~22 VALU per anchor).  Both run side by side; the stage takes about
-                //   max(T * t_lpg, n_longest * t_hw, VALU work / issue rate of the chip)
-                // and T (a multiple of GSZ_W) minimises that estimate.  Measured constants of this kernel pair.
-                const u32 *hn = h_cnt + 4; const unsigned long long *ha = h_anch + 2;
-                u32 T = lpg_max;
-                if (lpg_max == LPG_MAX_AUTO) {
-                    const double t_lpg = 4.3e-6, t_hw = 0.55e-6, c_lpg = 22.0, c_hw = 93.0;
-                    const double rate = 0.8 * (double)ctx->n_cu * 4 * 2.1e9 / 4.0;   // wave64 VALU instructions per second, ~80 % reachable
-                    int top = -1;
-                    for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) top = b;
-                    double best = 1e30; T = 0;
-                    double a_le = 0;    // anchors in classes <= b
-                    for (int b = -1; b < GSZ_BINS - 1; ++b) {      // T = (b + 1) * GSZ_W: classes 0..b go to k_chain_lpg
-                        if (b >= 0) a_le += (double)ha[b];
-                        const double a_hw = (double)a_chained - a_le;
-                        const double crit_lpg = b >= 0 ? (double)std::min<int>(b + 1, top + 1) * GSZ_W * t_lpg : 0.0;
-                        const double crit_hw = a_hw > 0 ? (double)(top + 1) * GSZ_W * t_hw : 0.0;
-                        const double est = std::max(std::max(crit_lpg, crit_hw), (a_le * c_lpg + a_hw * c_hw) / rate);
-                        if (est < best - 1e-9) { best = est; T = (u32)(b + 1) * GSZ_W; }
-                        if (b >= top) break;
-                    }
-                }
-                // groups strictly above T: whole classes when T is a class edge, else (LRGE_HIP_LPG_MAX) count by class floor
-                n_big = 0; a_big = 0;
-                for (int b = 0; b < GSZ_BINS; ++b) {
-                    const bool above = (u64)b * GSZ_W >= (u64)T;    // class b = (b*W, (b+1)*W]
-                    if (above) { n_big += hn[b]; a_big += ha[b]; }
-                }
-                lpg_split = T;
+                const ChainSplit sp_ = choose_chain_split(h_cnt + 4, h_anch + 2, a_chained, lpg_max, ctx->n_cu);
+                n_big = sp_.n_big; a_big = sp_.a_big; lpg_split = sp_.T;
                 ctx->counters[LRGE_C_LPG_SPLIT] = lpg_split;
-                if (getenv("LRGE_HIP_VERBOSE")) {
-                    int top = -1; for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) top = b;
+                if (getenv("LRGE_HIP_VERBOSE"))
                     fprintf(stderr, "[lrge_hip] batch: %u groups chained, %llu anchors, largest class %d (<= %d anchors), split T=%u -> hw %u groups / %llu anchors\n",
-                            n_chained, a_chained, top, (top + 1) * GSZ_W, T, n_big, a_big);
-                }
+                            n_chained, a_chained, sp_.top, (sp_.top + 1) * GSZ_W, sp_.T, n_big, a_big);
             }
             if (n_chained) {
                 u64 *k0 = bsc.get<u64>(n_chained), *v0 = bsc.get<u64>(n_chained), *k1 = bsc.get<u64>(n_chained), *v1 = bsc.get<u64>(n_chained);
@@ -1029,61 +1095,9 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                 ctx->counters[LRGE_C_CHAIN_ANCHORS] += a_chained;
                 ctx->counters[LRGE_C_GROUPS_CHAINED] += n_chained;
             }
-        } else if (chain_mode == 3) {
-            // register-window kernel, one group per wavefront, every group size in one launch, largest bins first
-            u32 total_blocks = 0; u64 total_anch = 0;
-            RegChainArgs ra;
-            ra.akey = skey; ra.aval = sval; ra.gstart = gstart; ra.n_groups = G; ra.n_anchors = A; ra.list = bin_list;
-            for (int k = 0; k < N_BINS; ++k) {
-                int b = N_BINS - 1 - k;
-                ra.bin_first[k] = total_blocks; ra.bin_of[k] = (u32)b;
-                total_blocks += h_bins[b]; total_anch += h_bin_anchors[b];
-            }
-            ra.n_blocks = total_blocks;
-            if (total_blocks) {
-                StageTimer t(ctx, LRGE_T_CHAIN);
-                ra.grec = bsc.get<u64>(A); ra.tmark = bsc.get<u32>(A);
-                if (!ra.grec || !ra.tmark) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemsetAsync(ra.tmark, 0, A * 4, ctx->stream));
-                hipLaunchKernelGGL(k_chain_reg, dim3(total_blocks), dim3(64), 0, ctx->stream, ra, cp, go);
-                KCHK(ctx);
-                t.stop();
-                ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
-                ctx->counters[LRGE_C_CHAIN_ANCHORS] += total_anch;
-                ctx->counters[LRGE_C_GROUPS_CHAINED] += total_blocks;
-            }
         } else {
-            const int first_lds_bin = chain_mode == 2 ? -1 : N_BINS - 2;   // "glb": everything through the generic kernel
-            u32 n_glb = 0; u64 a_glb = 0;
-            for (int b = N_BINS - 1; b > first_lds_bin; --b) { n_glb += h_bins[b]; a_glb += h_bin_anchors[b]; }
-            if (n_glb) {
-                StageTimer t(ctx, LRGE_T_CHAIN_GLB);
-                i32 *gX = bsc.get<i32>(A), *gY = bsc.get<i32>(A), *gF = bsc.get<i32>(A), *gP = bsc.get<i32>(A), *gT = bsc.get<i32>(A);
-                u8 *gS = bsc.get<u8>(A);
-                if (!gX || !gY || !gF || !gP || !gT || !gS) return LRGE_ERR_DEVICE;
-                for (int b = N_BINS - 1; b > first_lds_bin; --b) {
-                    if (!h_bins[b]) continue;
-                    hipLaunchKernelGGL(k_chain_glb, dim3(h_bins[b]), dim3(64), 0, ctx->stream, skey, sval, gstart, G, A,
-                                       bin_list + (u64)b * G, h_bins[b], gX, gY, gF, gP, gT, gS, cp, go);
-                    KCHK(ctx);
-                    ctx->counters[LRGE_C_CHAIN_GLB_LAUNCHES] += 1;
-                }
-                t.stop();
-                ctx->counters[LRGE_C_CHAIN_GLB_ANCHORS] += a_glb;
-                ctx->counters[LRGE_C_GROUPS_CHAINED] += n_glb;
-            }
-            StageTimer t(ctx, LRGE_T_CHAIN);
-            for (int b = first_lds_bin; b >= 0; --b) {
-                if (!h_bins[b]) continue;
-                u32 cap = bl.lim[b];
-                hipLaunchKernelGGL(k_chain_lds, dim3(h_bins[b]), dim3(64), (size_t)cap * 18 + 64, ctx->stream, skey, sval, gstart, G, A,
-                                   bin_list + (u64)b * G, h_bins[b], cap, cp, go);
-                KCHK(ctx);
-                ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
-                ctx->counters[LRGE_C_CHAIN_ANCHORS] += h_bin_anchors[b];
-                ctx->counters[LRGE_C_GROUPS_CHAINED] += h_bins[b];
-            }
-            t.stop();
+            rc = launch_reference_chain(chain_mode, bsc, skey, sval, gstart, G, A, bin_list, h_bins, h_bin_anchors, go);
+            if (rc) return rc;
         }
     }
     {

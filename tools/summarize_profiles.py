@@ -58,6 +58,9 @@ def per_launch(kern):
 out = {
     "source": "tools/profile_round.sh %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0)" % tag,
     "fetch_correction": 2.0, "write_correction": 1.0,
+    "fetch_correction_note": "x2 is calibrated for wide coalesced streaming reads (k_rs_hist). k_chain_lpg reads 16 B per lane from 64 "
+                             "different lines per instruction; for that pattern the factor is uncalibrated, so its corrected figure is an "
+                             "upper bound (raw FETCH_SIZE + WRITE_SIZE: see *_pmc_fetch.csv / *_pmc_write.csv)",
     "k_chain_lpg_hbm_bytes_per_launch": per_launch("k_chain_lpg<true>"),
     "k_chain_hw_hbm_bytes_per_launch": per_launch("k_chain_hw"),
     "k_rs_scatter_hbm_bytes_per_launch": None,

@@ -30,8 +30,8 @@ HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2_bact_twoset")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the config (debug only; invalid as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

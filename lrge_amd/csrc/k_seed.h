@@ -229,12 +229,16 @@ __global__ __launch_bounds__(256) void k_qocc_check(const u64 *__restrict__ qx, 
     if (q >= nq) return;
     const u32 b = qmz_off[q], e = qmz_off[q + 1];
     if ((i64)(e - b) <= (i64)mid_occ) return;                              // mv->n <= q_occ_max: filter off
-    for (u32 i = threadIdx.x; i < QOCC_BUCKETS; i += blockDim.x) cnt[i] = 0;
+    // as many buckets as it takes to keep the load below 1/2 (a power of two, at most QOCC_BUCKETS): short queries
+    // do not pay for clearing 32 KB
+    u32 nbk = 256;
+    while (nbk < QOCC_BUCKETS && nbk < 2 * (e - b)) nbk <<= 1;
+    for (u32 i = threadIdx.x; i < nbk; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
     bool hit = false;
     for (u32 i = b + threadIdx.x; i < e; i += blockDim.x) {
         if (hc[i] == 0) continue;
-        const u32 h = (u32)(((qx[i] >> 8) * 0x9E3779B97F4A7C15ULL) >> 51);  // 13 bits
+        const u32 h = (u32)(((qx[i] >> 8) * 0x9E3779B97F4A7C15ULL) >> 51) & (nbk - 1);  // up to 13 bits
         if ((i64)atomicAdd(&cnt[h], 1u) + 1 > (i64)mid_occ) hit = true;
     }
     if (hit) atomicOr(flag, 1u);

@@ -926,20 +926,38 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
             UnpackParams up; up.sb = kl.sh_q(); up.bits_qy = bits_qy; up.sh_q = kl.sh_q(); up.dmask = 255;
             // segments that fit a workgroup's LDS are sorted there in one kernel (k_seg_sort_local: 8 B in, 16 B out
             // per anchor); only the larger ones take the tiled global passes
+            // the classes touch disjoint segments: the largest class runs on the side stream beside the others and the
+            // tiled passes (fork / join with events), so that its one-block-per-CU tail does not stand alone
+            const bool side = !h_local[2].empty() && (!h_local[1].empty() || !h_tiles.empty());
+            SegDesc *d_seg[3] = {nullptr, nullptr, nullptr};
             for (int cls = 0; cls < 3; ++cls) {
                 if (h_local[cls].empty()) continue;
-                SegDesc *d = (SegDesc *)bsc.get<u32>(h_local[cls].size() * 4);
-                if (!d) return LRGE_ERR_DEVICE;
-                HIPCHK(ctx, hipMemcpyAsync(d, h_local[cls].data(), h_local[cls].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
-                const dim3 grid((u32)h_local[cls].size());
-                const int nbits = (int)kl.sh_q();
-                if (cls == 0) hipLaunchKernelGGL((k_seg_sort_local<256, 8>), grid, dim3(256), LSORT_BYTES(256, 8), ctx->stream, akey, aval, aval2, d, up, nbits);
-                else if (cls == 1) hipLaunchKernelGGL((k_seg_sort_local<512, 16>), grid, dim3(512), LSORT_BYTES(512, 16), ctx->stream, akey, aval, aval2, d, up, nbits);
-                else hipLaunchKernelGGL((k_seg_sort_local<1024, 16>), grid, dim3(1024), LSORT_BYTES(1024, 16), ctx->stream, akey, aval, aval2, d, up, nbits);
+                d_seg[cls] = (SegDesc *)bsc.get<u32>(h_local[cls].size() * 4);
+                if (!d_seg[cls]) return LRGE_ERR_DEVICE;
+                HIPCHK(ctx, hipMemcpyAsync(d_seg[cls], h_local[cls].data(), h_local[cls].size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
+            }
+            if (side) {
+                HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            }
+            const int nbits = (int)kl.sh_q();
+            if (d_seg[2]) {
+                hipLaunchKernelGGL((k_seg_sort_local<1024, 16>), dim3((u32)h_local[2].size()), dim3(1024), LSORT_BYTES(1024, 16), side ? ctx->stream2 : ctx->stream,
+                                   akey, aval, aval2, d_seg[2], up, nbits);
+                KCHK(ctx);
+                if (side) HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            }
+            if (d_seg[1]) {
+                hipLaunchKernelGGL((k_seg_sort_local<512, 16>), dim3((u32)h_local[1].size()), dim3(512), LSORT_BYTES(512, 16), ctx->stream, akey, aval, aval2, d_seg[1], up, nbits);
+                KCHK(ctx);
+            }
+            if (d_seg[0]) {
+                hipLaunchKernelGGL((k_seg_sort_local<256, 8>), dim3((u32)h_local[0].size()), dim3(256), LSORT_BYTES(256, 8), ctx->stream, akey, aval, aval2, d_seg[0], up, nbits);
                 KCHK(ctx);
             }
             rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up, A - n_local_items);
             if (rc) return rc;
+            if (side) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             skey = aval; sval = aval2;
             bsc.drop((u32 *)d_tiles);
             bsc.drop(akey); bsc.drop(akey2);

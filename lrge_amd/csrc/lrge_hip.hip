@@ -674,22 +674,28 @@ int OverlapRun::seeds() {
     bool qocc_possible = false;
     if (Mq > 0 && P.q_occ_frac > 0.0f && ix->mid_occ > 0)   // only queries with more minimizers than mid_occ can be affected
         for (u32 q = 0; q < nq && !qocc_possible; ++q) qocc_possible = (i64)(h_mzoff[q + 1] - h_mzoff[q]) > (i64)ix->mid_occ;
-    u32 *d_qf = nullptr; u32 qf = 0;
+    u32 *d_qf = nullptr; u32 qf = 0; bool qf_on_side = false;
     if (qocc_possible) {
         if (getenv("LRGE_HIP_QOCC_EXACT")) { rc = run_exact_qocc(); if (rc) return rc; }
         else {
-            // cheap conservative check; its verdict travels to the host with the next sync (no extra round trip)
-            StageTimer t(ctx, LRGE_T_QFILTER);
+            // cheap conservative check, on the side stream beside the hit counting below (both only read the lookup
+            // results); its verdict travels to the host with the next sync (no extra round trip)
             d_qf = sc.get<u32>(1);
             if (!d_qf) return LRGE_ERR_DEVICE;
-            HIPCHK(ctx, hipMemsetAsync(d_qf, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(k_qocc_check, dim3(nq), dim3(256), 0, ctx->stream, so.x, hc, so.mz_off, nq, ix->mid_occ, d_qf);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            StageTimer t(ctx, LRGE_T_QFILTER, ctx->stream2);
+            HIPCHK(ctx, hipMemsetAsync(d_qf, 0, 4, ctx->stream2));
+            hipLaunchKernelGGL(k_qocc_check, dim3(nq), dim3(256), 0, ctx->stream2, so.x, hc, so.mz_off, nq, ix->mid_occ, d_qf);
             KCHK(ctx);
             t.stop();
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            qf_on_side = true;
         }
     }
     if (job.paf_stats) {   // per-query seed statistics only (rl, avg_k ingredients)
         if (d_qf) {
+            if (qf_on_side) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); qf_on_side = false; }
             HIPCHK(ctx, hipMemcpyAsync(&qf, d_qf, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             if (qf) { rc = run_exact_qocc(); if (rc) return rc; }
@@ -722,7 +728,10 @@ int OverlapRun::seeds() {
         hipLaunchKernelGGL(k_query_anchor_totals, dim3((u32)div_up(nq, 4)), dim3(256), 0, ctx->stream, hv, so.mz_off, nq, d_qtot);
         KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(h_qtot.data(), d_qtot, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (d_qf) HIPCHK(ctx, hipMemcpyAsync(&qf, d_qf, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (d_qf) {
+            if (qf_on_side) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); qf_on_side = false; }
+            HIPCHK(ctx, hipMemcpyAsync(&qf, d_qf, 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         t.stop();
         return LRGE_OK;

@@ -1,7 +1,10 @@
-"""Minimal read input for the host mirror: in-memory (names, seqs) or plain/gzip FASTA/FASTQ.
-The reference's full input layer (liblrge/src/io.rs: zstd/bz2/xz sniffing, BAM/CRAM/SAM) is host-side
-I/O outside the hot path."""
+"""Read input for the host mirror: in-memory (names, seqs) or FASTA/FASTQ files, plain or compressed.
+Compression is sniffed from the magic bytes like the reference does (liblrge/src/io.rs): gzip, bzip2 and xz
+through the Python standard library; zstd needs a module this image lacks and is reported as such.  BAM/CRAM/SAM
+(io.rs `alignment` feature) stay out: host-side I/O outside the hot path."""
+import bz2
 import gzip
+import lzma
 
 import numpy as np
 
@@ -14,9 +17,21 @@ def read_id(header: bytes) -> bytes:
     return header
 
 
+def _opener(path):
+    magic = open(path, "rb").read(6)
+    if magic[:2] == b"\x1f\x8b":
+        return gzip.open
+    if magic[:3] == b"BZh":
+        return bz2.open
+    if magic[:6] == b"\xfd7zXZ\x00":
+        return lzma.open
+    if magic[:4] == b"\x28\xb5\x2f\xfd":
+        raise ValueError("zstd-compressed input is not supported in this build (no zstd module): %r" % path)
+    return open
+
+
 def iter_records(path):
-    op = gzip.open if open(path, "rb").read(2) == b"\x1f\x8b" else open
-    with op(path, "rb") as fh:
+    with _opener(path)(path, "rb") as fh:
         first = fh.read(1)
         if not first:
             return

@@ -57,6 +57,22 @@ def _reads(n):
     return [b"r%d" % i for i in range(n)], [b"ACGT" * (5 + i % 3) for i in range(n)]
 
 
+def test_compressed_input_sniffing(tmp_path):
+    """gzip / bzip2 / xz are recognised by their magic bytes, whatever the file is called (io.rs)."""
+    import bz2, gzip, lzma
+    from lrge_amd import readio
+    fa = b">r1 desc\nACGT\nAC\n>r2\nGGTT\n"
+    for name, comp in (("a.dat", gzip.compress), ("b.dat", bz2.compress), ("c.dat", lzma.compress), ("d.dat", lambda x: x)):
+        p = tmp_path / name
+        p.write_bytes(comp(fa))
+        names, seqs = readio.load(str(p))
+        assert names == [b"r1", b"r2"] and seqs == [b"ACGTAC", b"GGTT"]
+    z = tmp_path / "e.zst"
+    z.write_bytes(b"\x28\xb5\x2f\xfd" + b"\x00" * 8)
+    with pytest.raises(ValueError):
+        readio.load(str(z))
+
+
 def test_twoset_split_guards():
     # twoset.rs:137-151: n <= Q -> TooFewReads; n < T+Q -> T = n - Q
     from lrge_amd import LrgeError

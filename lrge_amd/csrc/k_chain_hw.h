@@ -152,18 +152,25 @@ __device__ __noinline__ u32 backtrack_group(const u64 *gk, const u64 *gv, u64 *g
     return flags;
 }
 
-__global__ __launch_bounds__(64) void k_chain_hw(HwChainArgs R, ChainParams P, GroupOut out) {
-    const u32 ia = 2 * blockIdx.x, ib = ia + 1;
-    if (ia >= R.n_list) return;
+// one wavefront, the pair of groups list[ia], list[ia + 1]
+__device__ __forceinline__ void chain_hw_pair(const HwChainArgs &R, const ChainParams &P, const GroupOut &out, u32 ia, u32 n_list,
+                                              bool clear_tmark) {
+    const u32 ib = ia + 1;
+    if (ia >= n_list) return;
     const i32 lane = (i32)lane_id();
     const i32 h = lane >> 5, hl = lane & 31, hbase = lane & 32;
-    const bool hasB = ib < R.n_list;
+    const bool hasB = ib < n_list;
     const u32 gA = RFL(R.list[ia]), gB = hasB ? RFL(R.list[ib]) : gA;
     const u32 s0A = RFL(R.gstart[gA]), s0B = RFL(R.gstart[gB]);
     const u32 e0A = (gA + 1 < R.n_groups) ? RFL(R.gstart[gA + 1]) : (u32)R.n_anchors;
     const u32 e0B = (gB + 1 < R.n_groups) ? RFL(R.gstart[gB + 1]) : (u32)R.n_anchors;
     const i32 nA = (i32)(e0A - s0A), nB = hasB ? (i32)(e0B - s0B) : 0;
     const i32 n_max = nA > nB ? nA : nB;
+    if (clear_tmark) {   // groups another kernel gave up half way: its stamps must not be mistaken for ours
+        for (i32 t = lane; t < nA; t += 64) R.tmark[s0A + t] = 0;
+        for (i32 t = lane; t < nB; t += 64) R.tmark[s0B + t] = 0;
+        drain_stores();
+    }
     if (R.prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (R.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (R.prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -342,6 +349,17 @@ __global__ __launch_bounds__(64) void k_chain_hw(HwChainArgs R, ChainParams P, G
         const u32 flags = backtrack_group(R.akey + s0h, R.aval + s0h, R.grec + s0h, nh, rmask, qid, rid, rev, P, out);
         if (lane == 0) out.flags[g] = flags;
     }
+}
+
+__global__ __launch_bounds__(64) void k_chain_hw(HwChainArgs R, ChainParams P, GroupOut out) {
+    chain_hw_pair(R, P, out, 2 * blockIdx.x, R.n_list, false);
+}
+
+// the groups k_chain_lpg gave up (see LpgChainArgs): their number only exists on the device, so a fixed grid strides
+// over the list
+__global__ __launch_bounds__(64) void k_chain_hw_redo(HwChainArgs R, ChainParams P, GroupOut out, const u32 *__restrict__ d_n_list) {
+    const u32 n_list = RFL(*d_n_list);
+    for (u32 ia = 2 * blockIdx.x; ia < n_list; ia += 2 * gridDim.x) chain_hw_pair(R, P, out, ia, n_list, true);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -40,6 +40,11 @@ struct LpgChainArgs {
     u64 *grec;         // [n_anchors]
     u32 *tmark;        // [n_anchors] zero-initialised
     u32 prio;          // raise the wavefronts' issue priority (they run beside k_chain_hw)
+    // A lane's slow paths (candidates / rescans behind the 32-anchor window) walk HBM one element at a time: fine
+    // when rare, hopeless on repeat-rich groups where every anchor needs thousands of them.  A lane that has spent
+    // more than slow_budget such iterations on its group gives the group up: it is appended to redo_list and chained
+    // afterwards by k_chain_hw_redo, whose slow paths scan 64 candidates per step.
+    u32 *redo_list, *redo_count; u32 slow_budget;
 };
 
 // PENTAB: with chain_skip_scale == 0 (every preset lrge uses) comput_sc's penalty depends on dd alone --
@@ -113,8 +118,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     i32 mi = -1, mi_x = 0, mi_y = 0, mi_f = 0, mi_sp = 0;
     u64 bkey = 0;                                   // best chain end: f << 32 | i  (f >= min_sc)
 
+    u32 slow_iters = 0;
+    bool abandoned = false;
     for (i32 i = 0; i < n_max; ++i) {
-        const bool alive = i < n;
+        const bool alive = i < n && !abandoned;
         const i32 r4 = i & (LPG_CH - 1), cb = (i / LPG_CH) & 1;
         if (r4 == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk has landed (issued LPG_CH steps ago)
@@ -217,7 +224,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const bool cont = alive && !broke && more && n_reach == LPG_W;
         if (__ballot(cont)) {
             // rare: a lane's loop runs past its 32-anchor window; continue that lane's loop through HBM
-            if (cont) {
+            slow_iters += cont ? LPG_W : 0;
+            if (cont && slow_iters > R.slow_budget) abandoned = true;
+            else if (cont) {
                 const u32 stamp = (u32)i + 1;
                 // marks the window candidates left on anchors behind the window (all were valid and reached)
                 for (i32 k = 0; k < LPG_W; ++k) {
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 i32 j = i - 1 - LPG_W;
                 for (;; --j) {
                     if (j < lower) { end_j = j; break; }
+                    if (++slow_iters > R.slow_budget) { abandoned = true; break; }
                     const i32 xj = (i32)(gk[j] & rmask);
                     if (xi - xj > maxdx) { end_j = j; break; }
                     const u64 v = gv[j], r = ld_u64_l2(grec + j);
@@ -258,6 +268,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (more && xi - WX[LPG_W - 1] <= maxdx) {
                     drain_stores();
                     for (i32 j = i - 1 - LPG_W; j >= lower; --j) {
+                        if (++slow_iters > R.slow_budget) { abandoned = true; break; }
                         if (xi - (i32)(gk[j] & rmask) > maxdx) break;
                         const i32 f = grec_f(ld_u64_l2(grec + j));
                         if (f > bf) { bf = f; bj = j; }
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const bool need_records = out.chains != nullptr || P.remove_internal != 0;
     u32 flags = 0;
     bool fb = false;
-    if (has && bkey != 0) {
+    if (has && !abandoned && bkey != 0) {
         const i32 zx = (i32)(u32)(bkey >> 32), top = (i32)(u32)bkey;
         i32 i = top, max_i = top, max_s = 0, depth = 0, cnt = 0;
         // A dependent load per hop would be the critical path of a long group.  Chains mostly step 1..3 anchors
@@ -358,5 +369,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const u32 f = backtrack_group(R.akey + s0l, R.aval + s0l, R.grec + s0l, nl, rmask, qid, rid, rev, P, out);
         if ((i32)lane_id() == l) flags = f;
     }
-    if (has) out.flags[g] = flags;
+    if (has && !abandoned) out.flags[g] = flags;
+    if (abandoned) R.redo_list[atomicAdd(R.redo_count, 1u)] = g;
 }

@@ -1089,6 +1089,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                 // the two kernels touch disjoint groups; k_chain_lpg goes to the side stream so that its long
                 // wavefronts run beside k_chain_hw's (fork / join with events, no host sync)
                 const bool both = n_big && n_chained > n_big;
+                u32 *d_redo = nullptr, *redo_list = nullptr;
                 if (both) {
                     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
                     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -1098,6 +1099,11 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                     la.akey = skey; la.aval = sval; la.gstart = gstart; la.n_groups = G; la.n_anchors = A;
                     la.list = hw_list + n_big; la.n_list = n_chained - n_big; la.grec = ha.grec; la.tmark = ha.tmark;
                     la.prio = (u32)env_u64("LRGE_HIP_LPG_PRIO", 3);
+                    la.slow_budget = (u32)env_u64("LRGE_HIP_LPG_SLOW_BUDGET", 4096);
+                    la.redo_list = bsc.get<u32>((size_t)la.n_list + 1); la.redo_count = d_redo = bsc.get<u32>(1);
+                    if (!la.redo_list || !la.redo_count) return LRGE_ERR_DEVICE;
+                    redo_list = la.redo_list;
+                    HIPCHK(ctx, hipMemsetAsync(la.redo_count, 0, 4, both ? ctx->stream2 : ctx->stream));
                     StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
                     const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !getenv("LRGE_HIP_LPG_NOTAB");
                     if (pentab) hipLaunchKernelGGL(k_chain_lpg<true>, dim3((la.n_list + 63) / 64), dim3(64), (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES,
@@ -1117,6 +1123,12 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                 if (both) {
                     HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
                     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                }
+                if (d_redo) {   // groups k_chain_lpg gave up (slow-path budget): usually none, then this is an empty launch
+                    HwChainArgs hr = ha;
+                    hr.list = redo_list; hr.n_list = 0; hr.prio = 0;
+                    hipLaunchKernelGGL(k_chain_hw_redo, dim3((u32)ctx->n_cu * 2), dim3(64), 0, ctx->stream, hr, cp, go, d_redo);
+                    KCHK(ctx);
                 }
                 t.stop();
                 ctx->counters[LRGE_C_CHAIN_ANCHORS] += a_chained;

@@ -207,7 +207,7 @@ def test_batching_is_invisible(ctx, oracle, tiny_ont, monkeypatch):
     assert np.array_equal(ref, small)
 
 
-@pytest.mark.parametrize("kernel", ["hw", "lpg", "lpg_notab", "auto64", "reg", "lds", "glb"])
+@pytest.mark.parametrize("kernel", ["hw", "lpg", "lpg_notab", "lpg_redo", "auto64", "reg", "lds", "glb"])
 @pytest.mark.parametrize("max_skip,max_iter", [(25, 5000), (100000, 5000), (100000, 40), (3, 90)])
 def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, monkeypatch, kernel, max_skip, max_iter):
     """Every chain kernel (half-wave, lane-per-group, register-window, LDS, global) against the oracle, including the
@@ -217,6 +217,9 @@ def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, monkeypatch, kerne
     if kernel == "auto64":     # the default split (big groups -> k_chain_hw, the rest -> k_chain_lpg) at a low threshold
         monkeypatch.delenv("LRGE_HIP_CHAIN", raising=False)
         monkeypatch.setenv("LRGE_HIP_LPG_MAX", "64")
+    elif kernel == "lpg_redo":   # k_chain_lpg gives every group that touches a slow path to k_chain_hw_redo
+        monkeypatch.setenv("LRGE_HIP_CHAIN", "lpg")
+        monkeypatch.setenv("LRGE_HIP_LPG_SLOW_BUDGET", "0")
     elif kernel == "lpg_notab":  # k_chain_lpg with the f32 penalty computed per candidate instead of tabulated
         monkeypatch.setenv("LRGE_HIP_CHAIN", "lpg")
         monkeypatch.setenv("LRGE_HIP_LPG_NOTAB", "1")

@@ -59,7 +59,7 @@ CASE = st.fixed_dictionaries(dict(
     preset=st.sampled_from(["ont", "pb"]), internal=st.booleans()))
 
 
-def _check(ctx, oracle, c):
+def _check(ctx, oracle, c, skip=0, iters=0):
     from lrge_amd import engine
     from conftest import to_arrays
     rng = np.random.Generator(np.random.PCG64(c["seed"]))
@@ -78,6 +78,8 @@ def _check(ctx, oracle, c):
     ix = engine.Index(ctx, Td, preset)
     To, Qo = oracle.ReadSet(tseqs, tnames), oracle.ReadSet(qseqs, qnames)
     ixo = oracle.Index(To, oracle.make_opt(opreset, dual=True))
+    if skip: ixo.opt.max_chain_skip = skip
+    if iters: ixo.opt.max_chain_iter = iters
     st_ = ix.stats()
     assert (st_["n_minimizers"], st_["n_keys"], st_["mid_occ"]) == (ixo.n_minimizers, ixo.n_keys, ixo.mid_occ)
     # two-set forward
@@ -107,6 +109,8 @@ def _check(ctx, oracle, c):
     Ad = up(tseqs, ar)
     ixa = engine.Index(ctx, Ad, preset)
     ixoa = oracle.Index(To, oracle.make_opt(opreset, dual=False))
+    if skip: ixoa.opt.max_chain_skip = skip
+    if iters: ixoa.opt.max_chain_iter = iters
     ava = ixa.overlap_ava(remove_internal=F)
     rc, eava = ixoa.ava_counts(remove_internal=F, threads=4)
     assert np.array_equal(ava, eava), ("ava", c)
@@ -136,3 +140,32 @@ def test_property_cases_are_not_vacuous(ctx, oracle):
         total += int(ix.overlap_twoset(Qd)[0].sum())
         ix.free()
     assert total > 100
+
+
+@pytest.mark.parametrize("env", [
+    {"LRGE_HIP_CHAIN": "lpg", "LRGE_HIP_DEBUG_MAX_SKIP": "100000"},      # lane-per-group kernel, loops run past the window
+    {"LRGE_HIP_CHAIN": "hw", "LRGE_HIP_DEBUG_MAX_SKIP": "100000"},       # half-wave kernel, same
+    {"LRGE_HIP_CHAIN": "lpg", "LRGE_HIP_LPG_NOTAB": "1", "LRGE_HIP_DEBUG_MAX_ITER": "40"},
+    {"LRGE_HIP_CHAIN": "lpg", "LRGE_HIP_DEBUG_MAX_SKIP": "100000", "LRGE_HIP_LPG_SLOW_BUDGET": "0"},   # every slow-path group is redone by k_chain_hw_redo
+    {"LRGE_HIP_NO_PACKED": "1", "LRGE_HIP_NO_PACKED_INDEX": "1", "LRGE_HIP_QOCC_EXACT": "1", "LRGE_HIP_BATCH_ANCHORS": "3000"},
+], ids=["lpg-noskip", "hw-noskip", "lpg-notab-iter40", "lpg-redo", "unpacked-exact-batched"])
+def test_random_small_sets_forced_paths(ctx, oracle, env):
+    """The same random cases through the general / rarely taken device paths (the oracle gets the same overrides of
+    max_chain_skip / max_chain_iter)."""
+    import os
+
+    @settings(max_examples=10, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(CASE)
+    def run(c):
+        _check(ctx, oracle, c, skip=int(env.get("LRGE_HIP_DEBUG_MAX_SKIP", 0)), iters=int(env.get("LRGE_HIP_DEBUG_MAX_ITER", 0)))
+
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        run()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -1089,7 +1089,6 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                 // the two kernels touch disjoint groups; k_chain_lpg goes to the side stream so that its long
                 // wavefronts run beside k_chain_hw's (fork / join with events, no host sync)
                 const bool both = n_big && n_chained > n_big;
-                u32 *d_redo = nullptr, *redo_list = nullptr;
                 if (both) {
                     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
                     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -1099,10 +1098,11 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                     la.akey = skey; la.aval = sval; la.gstart = gstart; la.n_groups = G; la.n_anchors = A;
                     la.list = hw_list + n_big; la.n_list = n_chained - n_big; la.grec = ha.grec; la.tmark = ha.tmark;
                     la.prio = (u32)env_u64("LRGE_HIP_LPG_PRIO", 3);
-                    la.slow_budget = (u32)env_u64("LRGE_HIP_LPG_SLOW_BUDGET", 4096);
-                    la.redo_list = bsc.get<u32>((size_t)la.n_list + 1); la.redo_count = d_redo = bsc.get<u32>(1);
+                    // 1024: on clean input (C2) no group is given up -- redoing even one 500-anchor group costs 0.3 ms of
+                    // critical path; on a repeat-rich genome (synth c2_repeats) 64 would be ~1.7x faster still
+                    la.slow_budget = (u32)env_u64("LRGE_HIP_LPG_SLOW_BUDGET", 1024);
+                    la.redo_list = bsc.get<u32>((size_t)la.n_list + 1); la.redo_count = bsc.get<u32>(1);
                     if (!la.redo_list || !la.redo_count) return LRGE_ERR_DEVICE;
-                    redo_list = la.redo_list;
                     HIPCHK(ctx, hipMemsetAsync(la.redo_count, 0, 4, both ? ctx->stream2 : ctx->stream));
                     StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
                     const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !getenv("LRGE_HIP_LPG_NOTAB");
@@ -1114,6 +1114,21 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                     ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
                     ctx->counters[LRGE_C_LPG_LAUNCHES] += 1;
                     ctx->counters[LRGE_C_LPG_ANCHORS] += a_chained - a_big;
+                    {   // the groups k_chain_lpg gave up (slow-path budget), on the same stream right behind it -- beside
+                        // k_chain_hw's tail.  Usually none: then this is an empty launch.  Their number only exists on the
+                        // device: as many wavefronts as the chip holds stride the list.
+                        HwChainArgs hr = ha;
+                        hr.list = la.redo_list; hr.n_list = 0; hr.prio = 0;
+                        const u32 redo_grid = (u32)std::min<u64>(((u64)la.n_list + 1) / 2, (u64)ctx->n_cu * 32);
+                        hipLaunchKernelGGL(k_chain_hw_redo, dim3(std::max<u32>(redo_grid, 1)), dim3(64), 0, both ? ctx->stream2 : ctx->stream, hr, cp, go, la.redo_count);
+                        KCHK(ctx);
+                        if (getenv("LRGE_HIP_VERBOSE")) {
+                            u32 nr = 0;
+                            HIPCHK(ctx, hipMemcpyAsync(&nr, la.redo_count, 4, hipMemcpyDeviceToHost, both ? ctx->stream2 : ctx->stream));
+                            HIPCHK(ctx, hipStreamSynchronize(both ? ctx->stream2 : ctx->stream));
+                            fprintf(stderr, "[lrge_hip] k_chain_lpg handed %u of %u groups to k_chain_hw_redo\n", nr, la.n_list);
+                        }
+                    }
                 }
                 if (n_big) {
                     hipLaunchKernelGGL(k_chain_hw, dim3((n_big + 1) / 2), dim3(64), 0, ctx->stream, ha, cp, go);
@@ -1123,12 +1138,6 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                 if (both) {
                     HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
                     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-                }
-                if (d_redo) {   // groups k_chain_lpg gave up (slow-path budget): usually none, then this is an empty launch
-                    HwChainArgs hr = ha;
-                    hr.list = redo_list; hr.n_list = 0; hr.prio = 0;
-                    hipLaunchKernelGGL(k_chain_hw_redo, dim3((u32)ctx->n_cu * 2), dim3(64), 0, ctx->stream, hr, cp, go, d_redo);
-                    KCHK(ctx);
                 }
                 t.stop();
                 ctx->counters[LRGE_C_CHAIN_ANCHORS] += a_chained;

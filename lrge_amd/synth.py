@@ -54,9 +54,38 @@ PLATFORMS = {
 }
 
 
-def random_genome(size, seed):
+def random_genome(size, seed, repeats=0.0, tandem=0.0):
+    """Uniform random genome.  `repeats`: fraction of the genome overwritten with copies of 300-bp and 6-kb elements
+    at 1-3 % divergence (exercises mid_occ and wrong-locus chains); `tandem`: fraction made of
+    short tandem repeats (2-6 bp units, 200-2000 bp long: thousands of colliding seeds, the chaining worst case)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    return _ACGT[rng.integers(0, 4, size=size, dtype=np.uint8)]
+    g = _ACGT[rng.integers(0, 4, size=size, dtype=np.uint8)]
+    if repeats > 0:
+        budget = int(repeats * size)
+        fams = [(300, _ACGT[rng.integers(0, 4, size=300, dtype=np.uint8)]) for _ in range(8)] + \
+               [(6000, _ACGT[rng.integers(0, 4, size=6000, dtype=np.uint8)]) for _ in range(3)]
+        while budget > 0:
+            L, unit = fams[int(rng.integers(0, len(fams)))]
+            if L >= size:
+                break
+            copy = unit.copy()
+            div = rng.uniform(0.01, 0.03)
+            m = rng.random(L) < div
+            copy[m] = _ACGT[rng.integers(0, 4, size=int(m.sum()), dtype=np.uint8)]
+            p = int(rng.integers(0, size - L))
+            g[p:p + L] = copy
+            budget -= L
+    if tandem > 0:
+        budget = int(tandem * size)
+        while budget > 0:
+            ul = int(rng.integers(2, 7)); L = int(rng.integers(200, 2001))
+            if L >= size:
+                break
+            unit = _ACGT[rng.integers(0, 4, size=ul, dtype=np.uint8)]
+            p = int(rng.integers(0, size - L))
+            g[p:p + L] = np.tile(unit, L // ul + 1)[:L]
+            budget -= L
+    return g
 
 
 def _read_lengths(rng, n, p, gsize):
@@ -121,6 +150,8 @@ CONFIGS = {
     "c5_human_twoset": dict(genome=3_100_000_000, seed=31001, platform="hifi", mode="twoset", Q=100000, T=2000000),
     # C5 at one tenth of its size: same coverage (10x targets), fits the 2^32-entry limits of this round
     "c5_human_tenth": dict(genome=310_000_000, seed=31001, platform="hifi", mode="twoset", Q=10000, T=200000),
+    # C2 on a repeat-rich genome (15 % interspersed 300-bp / 6-kb families, 2 % short tandem repeats): robustness run
+    "c2_repeats": dict(genome=4_400_000, seed=4402, platform="ont", mode="twoset", Q=5000, T=10000, repeats=0.15, tandem=0.02),
     # reduced cases for tests / smoke
     "tiny_twoset": dict(genome=200_000, seed=77, platform="ont", mode="twoset", Q=60, T=300),
     "tiny_ava": dict(genome=100_000, seed=78, platform="ont", mode="ava", N=200),
@@ -132,7 +163,7 @@ def make_config(name, scale=1.0):
     """Return (genome_size, queries, targets) for twoset or (genome_size, reads, None) for ava."""
     c = CONFIGS[name]
     gsize = int(c["genome"] * scale)
-    genome = random_genome(gsize, c["seed"])
+    genome = random_genome(gsize, c["seed"], c.get("repeats", 0.0), c.get("tandem", 0.0))
     if c["mode"] == "twoset":
         q, t = max(1, int(c["Q"] * scale)), max(1, int(c["T"] * scale))
         reads = sample_reads(genome, q + t, c["platform"], seed=c["seed"] + 1)

@@ -21,6 +21,8 @@
  *   lrge_hip_overlap_ava       <- AvaStrategy::align_reads (ava.rs:165-366)
  *   lrge_hip_estimates         <- estimate::per_read_estimate (estimate.rs:142-157)
  *   lrge_hip_median            <- estimate::median + calculate_quantile (estimate.rs:80-132)
+ *   lrge_hip_unique_random_set <- unique_random_set (lib.rs:189-204): StdRng::seed_from_u64 +
+ *                                 rand::seq::index::sample (rand 0.9.4 / rand_chacha 0.9.0, Cargo.lock:1001-1029)
  *   lrge_hip_chains            <- the Vec<PafRecord> of Aligner::map (aligner.rs:244-291,
  *                                 minimap2/mapping.rs:10-54), batched
  */
@@ -171,6 +173,14 @@ int  lrge_hip_estimates(lrge_hip_ctx *ctx, const uint32_t *counts, const uint32_
    out = {lower, median, upper}, ok[i] = 1 if that slot is Some. */
 int  lrge_hip_median(const float *estimates, uint64_t n, int finite, int has_lower, float lower_q,
                      int has_upper, float upper_q, float out[3], int ok[3]);
+
+/* Host only: the k distinct indices in [0, n) that liblrge's sub-sampling draws (lib.rs:189-204), in the order
+   rand 0.9.4's index::sample returns them (split_into_hashsets, twoset.rs:632-652, takes the LAST target_num_reads
+   of them as targets).  has_seed = 0 seeds the generator from OS entropy.  Restated in include/lrge_rand.hpp.
+   LRGE_ERR_INVALID if k > n (the reference panics) or out is NULL with k > 0. */
+int  lrge_hip_unique_random_set(uint64_t k, uint32_t n, int has_seed, uint64_t seed, uint32_t *out);
+/* One ChaCha block of that generator (key = 8 LE words, 64-bit counter, stream 0): known-answer tests. */
+int  lrge_hip_chacha_block(const uint32_t key[8], uint64_t counter, int rounds, uint32_t out[16]);
 
 /* Stage-level introspection (parity tests, profiling). */
 int  lrge_hip_sketch_dump(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, int preset, uint64_t *x,

@@ -12,7 +12,6 @@
 #include <cstring>
 #include <numeric>
 #include <optional>
-#include <random>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -21,6 +20,7 @@
 #include <vector>
 
 #include "lrge_hip.h"
+#include "lrge_rand.hpp"
 
 namespace lrge {
 
@@ -102,17 +102,8 @@ inline std::vector<std::vector<uint32_t>> name_ranks(const std::vector<std::vect
     }
     return out;
 }
-// lib.rs:189-204.  NOTE: std::mt19937_64 + partial Fisher-Yates, not rand 0.9.4's ChaCha12 index::sample, so a
-// given seed selects a different (equally distributed) subset than the reference.
-inline std::vector<uint32_t> unique_random_set(size_t k, uint32_t n, std::optional<uint64_t> seed) {
-    if (k > n) throw std::invalid_argument("Cannot generate " + std::to_string(k) + " unique values from a range of 0 to " + std::to_string(n));
-    std::mt19937_64 rng(seed ? *seed : std::random_device{}());
-    std::vector<uint32_t> idx(n);
-    std::iota(idx.begin(), idx.end(), 0u);
-    for (size_t i = 0; i < k; ++i) { std::uniform_int_distribution<size_t> d(i, n - 1); std::swap(idx[i], idx[d(rng)]); }
-    idx.resize(k);
-    return idx;
-}
+// lib.rs:189-204: StdRng::seed_from_u64 + rand::seq::index::sample, restated in lrge_rand.hpp
+using ::lrge::unique_random_set;
 }  // namespace detail
 
 inline std::vector<std::string> paf_lines(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *qs, int dual,

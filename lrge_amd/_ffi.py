@@ -24,6 +24,7 @@ EXPORTS = [
     "lrge_hip_index_build", "lrge_hip_index_free", "lrge_hip_index_stats",
     "lrge_hip_overlap_twoset", "lrge_hip_overlap_inverse", "lrge_hip_overlap_ava", "lrge_hip_chains",
     "lrge_hip_estimates", "lrge_hip_median", "lrge_hip_paf_stats",
+    "lrge_hip_unique_random_set", "lrge_hip_chacha_block",
     "lrge_hip_sketch_dump", "lrge_hip_index_dump", "lrge_hip_anchors_dump",
     "lrge_hip_last_timings", "lrge_hip_last_counters", "lrge_hip_version",
 ]
@@ -81,6 +82,8 @@ def lib():
     L.lrge_hip_estimates.argtypes = [vp, vp, vp, C.c_uint32, C.c_float, C.c_uint64, C.c_uint32, vp]
     L.lrge_hip_median.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                                   C.POINTER(C.c_float * 3), C.POINTER(C.c_int * 3)]
+    L.lrge_hip_unique_random_set.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint64, vp]
+    L.lrge_hip_chacha_block.argtypes = [vp, C.c_uint64, C.c_int, vp]
     L.lrge_hip_sketch_dump.argtypes = [vp, vp, C.c_int, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.lrge_hip_index_dump.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.lrge_hip_anchors_dump.argtypes = [vp, vp, vp, C.c_int, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]

@@ -22,6 +22,7 @@ def _sources():
     for root, _, files in os.walk(CSRC):
         out += [os.path.join(root, f) for f in files]
     out.append(os.path.join(os.path.dirname(_HERE), "include", "lrge_hip.h"))
+    out.append(os.path.join(os.path.dirname(_HERE), "include", "lrge_rand.hpp"))
     return out
 
 
@@ -42,11 +43,12 @@ CLI_PATH = os.path.join(LIB_DIR, "lrge-hip")
 def build_cli(force=False):
     """The C++ host mirror (include/lrge_hip.hpp) + lrge-compatible driver, linked against liblrge_hip.so."""
     src = os.path.join(os.path.dirname(_HERE), "tools", "lrge_hip_cli.cpp")
-    hdr = os.path.join(os.path.dirname(_HERE), "include", "lrge_hip.hpp")
-    if not force and os.path.exists(CLI_PATH) and os.path.getmtime(CLI_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr),
-                                                                                    os.path.getmtime(LIB_PATH)):
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    hdrs = [os.path.join(inc, h) for h in ("lrge_hip.hpp", "lrge_hip.h", "lrge_rand.hpp", "lrge_io.hpp")]
+    if not force and os.path.exists(CLI_PATH) and os.path.getmtime(CLI_PATH) >= max([os.path.getmtime(src), os.path.getmtime(LIB_PATH)] +
+                                                                                    [os.path.getmtime(h) for h in hdrs]):
         return CLI_PATH
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI_PATH, src, "-L" + LIB_DIR, "-llrge_hip", "-lz",
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI_PATH, src, "-L" + LIB_DIR, "-llrge_hip", "-lz", "-ldl",
                            "-Wl,-rpath,$ORIGIN"])
     return CLI_PATH
 

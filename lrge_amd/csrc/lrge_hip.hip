@@ -14,6 +14,7 @@
 #include "k_chain_reg.h"
 #include "k_chain_hw.h"
 #include "k_chain_lpg.h"
+#include "../../include/lrge_rand.hpp"
 
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
 
@@ -1353,5 +1354,18 @@ extern "C" int lrge_hip_median(const float *estimates, uint64_t n, int finite, i
     ok[1] = quantile_f32(v, 0.5f, &out[1]);
     if (has_lower) ok[0] = quantile_f32(v, lower_q, &out[0]);
     if (has_upper) ok[2] = quantile_f32(v, upper_q, &out[2]);
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_unique_random_set(uint64_t k, uint32_t n, int has_seed, uint64_t seed, uint32_t *out) {
+    if (k > n || (k && !out)) return LRGE_ERR_INVALID;
+    std::vector<uint32_t> v = lrge::unique_random_set((size_t)k, n, has_seed ? std::optional<uint64_t>(seed) : std::nullopt);
+    std::copy(v.begin(), v.end(), out);
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_chacha_block(const uint32_t key[8], uint64_t counter, int rounds, uint32_t out[16]) {
+    if (!key || !out || rounds <= 0 || (rounds & 1)) return LRGE_ERR_INVALID;
+    lrge::rand09::chacha_block(key, counter, 0, rounds, out);
     return LRGE_OK;
 }

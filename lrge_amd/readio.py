@@ -1,12 +1,20 @@
-"""Read input for the host mirror: in-memory (names, seqs) or FASTA/FASTQ files, plain or compressed.
-Compression is sniffed from the magic bytes like the reference does (liblrge/src/io.rs): gzip, bzip2 and xz
-through the Python standard library; zstd needs a module this image lacks and is reported as such.  BAM/CRAM/SAM
-(io.rs `alignment` feature) stay out: host-side I/O outside the hot path."""
+"""Read input for the host mirror: in-memory (names, seqs) or files in the formats liblrge/src/io.rs accepts.
+Compression is sniffed from the magic bytes like the reference does (io.rs:36-63): gzip, bzip2 and xz through the
+Python standard library, zstd through the system's libzstd.so.1 (ctypes; no zstd module in this image).  The
+decompressed stream is sniffed again (io.rs:88-98): "BAM\\1" / "@HD" / "@SQ" / "@RG" -> unaligned BAM / SAM records
+(mapped records are refused with the reference's message), "CRAM" is recognised and refused, everything else is
+FASTA / FASTQ.  Host-side I/O outside the hot path."""
 import bz2
+import ctypes
 import gzip
+import io
 import lzma
+import struct
 
 import numpy as np
+
+MAPPED_MSG = "Mapped records are not supported. Only unaligned BAM/CRAM/SAM is allowed."
+_NT16 = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
 
 
 def read_id(header: bytes) -> bytes:
@@ -17,45 +25,200 @@ def read_id(header: bytes) -> bytes:
     return header
 
 
-def _opener(path):
-    magic = open(path, "rb").read(6)
+class _ZIn(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos", ctypes.c_size_t)]
+
+
+class _ZOut(ctypes.Structure):
+    _fields_ = [("dst", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos", ctypes.c_size_t)]
+
+
+def _libzstd():
+    try:
+        z = ctypes.CDLL("libzstd.so.1")
+    except OSError as e:
+        raise ValueError("zstd-compressed input needs libzstd.so.1: %s" % e)
+    z.ZSTD_createDStream.restype = ctypes.c_void_p
+    z.ZSTD_initDStream.argtypes = [ctypes.c_void_p]; z.ZSTD_initDStream.restype = ctypes.c_size_t
+    z.ZSTD_decompressStream.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ZOut), ctypes.POINTER(_ZIn)]
+    z.ZSTD_decompressStream.restype = ctypes.c_size_t
+    z.ZSTD_freeDStream.argtypes = [ctypes.c_void_p]
+    z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]; z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    return z
+
+
+def zstd_decompress(data: bytes) -> bytes:
+    z = _libzstd()
+    ds = z.ZSTD_createDStream()
+    if not ds or z.ZSTD_isError(z.ZSTD_initDStream(ds)):
+        raise ValueError("zstd: init failed")
+    src = ctypes.create_string_buffer(data, len(data))
+    buf = ctypes.create_string_buffer(1 << 20)
+    zin = _ZIn(ctypes.cast(src, ctypes.c_void_p), len(data), 0)
+    out, last = [], 0
+    try:
+        while zin.pos < zin.size or last:
+            zout = _ZOut(ctypes.cast(buf, ctypes.c_void_p), len(buf), 0)
+            before = zin.pos
+            last = z.ZSTD_decompressStream(ds, ctypes.byref(zout), ctypes.byref(zin))
+            if z.ZSTD_isError(last):
+                raise ValueError("zstd: corrupt input")
+            out.append(buf.raw[:zout.pos])
+            if zin.pos == before and zout.pos == 0:
+                if last:
+                    raise ValueError("zstd: unexpected end of file")
+                break
+    finally:
+        z.ZSTD_freeDStream(ds)
+    return b"".join(out)
+
+
+def zstd_compress(data: bytes, level=3) -> bytes:
+    """Only used to make test inputs."""
+    z = _libzstd()
+    cap = z.ZSTD_compressBound(len(data))
+    dst = ctypes.create_string_buffer(cap)
+    n = z.ZSTD_compress(dst, cap, data, len(data), level)
+    if z.ZSTD_isError(n):
+        raise ValueError("zstd: compression failed")
+    return dst.raw[:n]
+
+
+def _open_decompressed(path):
+    """io.rs:71-86: a binary stream of the decompressed file."""
+    with open(path, "rb") as fh:
+        magic = fh.read(5)
     if magic[:2] == b"\x1f\x8b":
-        return gzip.open
-    if magic[:3] == b"BZh":
-        return bz2.open
-    if magic[:6] == b"\xfd7zXZ\x00":
-        return lzma.open
+        return gzip.open(path, "rb")                      # multi-member, like MultiGzDecoder (BGZF included)
+    if magic[:2] == b"BZ":
+        return bz2.open(path, "rb")
+    if magic[:5] == b"\xfd7zXZ":
+        return lzma.open(path, "rb")
     if magic[:4] == b"\x28\xb5\x2f\xfd":
-        raise ValueError("zstd-compressed input is not supported in this build (no zstd module): %r" % path)
-    return open
+        with open(path, "rb") as fh:
+            return io.BytesIO(zstd_decompress(fh.read()))
+    return open(path, "rb")
+
+
+def _iter_fastx(fh, first):
+    if first == b">":
+        name, chunks = fh.readline().rstrip(b"\r\n"), []
+        for line in fh:
+            if line.startswith(b">"):
+                yield read_id(name), b"".join(chunks)
+                name, chunks = line[1:].rstrip(b"\r\n"), []
+            else:
+                chunks.append(line.rstrip(b"\r\n"))
+        yield read_id(name), b"".join(chunks)
+    elif first == b"@":
+        name = fh.readline().rstrip(b"\r\n")
+        while True:
+            seq = fh.readline().rstrip(b"\r\n")
+            plus, qual = fh.readline(), fh.readline()
+            if not plus.startswith(b"+") or not qual:
+                raise ValueError("truncated or malformed FASTQ record: %r" % name)
+            yield read_id(name), seq
+            hdr = fh.readline()
+            while hdr in (b"\n", b"\r\n"):
+                hdr = fh.readline()
+            if not hdr:
+                break
+            if not hdr.startswith(b"@"):
+                raise ValueError("malformed FASTQ record after %r" % name)
+            name = hdr[1:].rstrip(b"\r\n")
+    else:
+        raise ValueError("unrecognised sequence file")
+
+
+def _iter_sam(fh):
+    for line in fh:
+        line = line.rstrip(b"\r\n")
+        if not line or line.startswith(b"@"):
+            continue
+        f = line.split(b"\t", 11)
+        if len(f) < 11:
+            raise ValueError("invalid SAM record: fewer than 11 fields")
+        if not int(f[1]) & 4:
+            raise ValueError(MAPPED_MSG)
+        yield (b"" if f[0] == b"*" else f[0]), (b"" if f[9] == b"*" else f[9])
+
+
+def _iter_bam(fh):
+    data = fh.read()
+    l_text, = struct.unpack_from("<i", data, 4)
+    off = 8 + l_text
+    n_ref, = struct.unpack_from("<i", data, off); off += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", data, off); off += 4 + l_name + 4
+    while off < len(data):
+        block, = struct.unpack_from("<i", data, off); off += 4
+        if block < 32 or off + block > len(data):
+            raise ValueError("truncated or invalid BAM record")
+        l_read_name = data[off + 8]
+        n_cigar, flag, l_seq = struct.unpack_from("<HHi", data, off + 12)
+        if not flag & 4:
+            raise ValueError(MAPPED_MSG)
+        name = data[off + 32:off + 32 + max(l_read_name - 1, 0)]
+        s0 = off + 32 + l_read_name + 4 * n_cigar
+        packed = np.frombuffer(data, dtype=np.uint8, count=(l_seq + 1) // 2, offset=s0)
+        nib = np.empty(2 * len(packed), dtype=np.uint8)
+        nib[0::2] = packed >> 4
+        nib[1::2] = packed & 15
+        yield (b"" if name == b"*" else name), _NT16[nib[:l_seq]].tobytes()
+        off += block
 
 
 def iter_records(path):
-    with _opener(path)(path, "rb") as fh:
-        first = fh.read(1)
-        if not first:
+    """io.rs:154-184: (read id, sequence) per record."""
+    with _open_decompressed(path) as fh:
+        magic = fh.read(4)
+        rest = io.BufferedReader(_Chain(magic, fh)) if magic else None
+        if rest is None:
             return
-        if first == b">":
-            name, chunks = fh.readline().rstrip(b"\r\n"), []
-            for line in fh:
-                if line.startswith(b">"):
-                    yield read_id(name), b"".join(chunks)
-                    name, chunks = line[1:].rstrip(b"\r\n"), []
-                else:
-                    chunks.append(line.rstrip(b"\r\n"))
-            yield read_id(name), b"".join(chunks)
-        elif first == b"@":
-            name = fh.readline().rstrip(b"\r\n")
-            while True:
-                seq = fh.readline().rstrip(b"\r\n")
-                fh.readline(); fh.readline()
-                yield read_id(name), seq
-                hdr = fh.readline()
-                if not hdr:
-                    break
-                name = hdr[1:].rstrip(b"\r\n")
+        if magic == b"BAM\x01":
+            yield from _iter_bam(rest)
+        elif magic == b"CRAM":
+            raise ValueError("CRAM input is recognised but not supported by this build (convert with `samtools fastq`)")
+        elif magic[:3] in (b"@HD", b"@SQ", b"@RG"):
+            yield from _iter_sam(rest)
         else:
-            raise ValueError("unrecognised sequence file: %r" % path)
+            first = rest.read(1)
+            while first in (b"\n", b"\r"):
+                first = rest.read(1)
+            if not first:
+                return
+            yield from _iter_fastx(rest, first)
+
+
+class _Chain(io.RawIOBase):
+    """The sniffed bytes chained back in front of the stream (io.rs:100-102)."""
+
+    def __init__(self, head, tail):
+        self._head, self._tail = head, tail
+
+    def readable(self):
+        return True
+
+    def readinto(self, b):
+        if self._head:
+            n = min(len(b), len(self._head))
+            b[:n] = self._head[:n]
+            self._head = self._head[n:]
+            return n
+        data = self._tail.read(len(b))
+        b[:len(data)] = data
+        return len(data)
+
+
+def count_records(path):
+    """io.rs:123-152."""
+    n = sum(1 for _ in iter_records(path))
+    if n == 0:
+        raise ValueError("Is the file empty?")
+    return n
 
 
 def load(source):

@@ -16,13 +16,17 @@ PLATFORM_PRESET = {"ont": _ffi.PRESET_AVA_ONT, "nanopore": _ffi.PRESET_AVA_ONT,
 
 
 def unique_random_set(k, n, seed=None):
-    """lib.rs:189-204.  k distinct indices in [0, n).  NOTE: numpy PCG64, not rand 0.9.4's ChaCha12
-    `index::sample`, so a given --seed picks a different (equally distributed) subset than the
-    reference."""
+    """lib.rs:189-204.  k distinct indices in [0, n) in the order rand 0.9.4's `index::sample` returns them for
+    `StdRng::seed_from_u64(seed)` (OS entropy without a seed): `lrge_hip_unique_random_set`, restated in
+    include/lrge_rand.hpp."""
     if k > n:
         raise ValueError("Cannot generate %d unique values from a range of 0 to %d" % (k, n))
-    rng = np.random.Generator(np.random.PCG64(seed))
-    return rng.permutation(n)[:k].astype(np.uint32)
+    out = np.zeros(k, dtype=np.uint32)
+    rc = _ffi.lib().lrge_hip_unique_random_set(k, n, 0 if seed is None else 1, 0 if seed is None else int(seed) & (2**64 - 1),
+                                               out.ctypes.data)
+    if rc:
+        raise LrgeError("InvalidArgument", "unique_random_set failed (%d)" % rc)
+    return out
 
 
 def split_into_sets(indices, size_first):

@@ -1,0 +1,135 @@
+"""Input formats (liblrge/src/io.rs:35-184, lrge/tests/alignment.rs:5-67): FASTA / FASTQ / unaligned
+SAM / unaligned BAM, plain or gzip / bzip2 / xz / zstd, sniffed by magic bytes.  The Python mirror
+(lrge_amd/readio.py) and the C++ host side (include/lrge_io.hpp, through `lrge-hip --dump-records`, a host-only mode)
+must hand out the same (read id, sequence) records; mapped records are refused with the reference's message."""
+import bz2
+import gzip
+import lzma
+import os
+import subprocess
+
+import pytest
+
+from lrge_amd import build, readio
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RECORDS = [(b"read1", b"GATTACAGATTACA"), (b"r2", b"ACGTNNNNACGTacgt"), (b"third/1", b"T" * 300), (b"r4", b"C")]
+MAPPED = "Mapped records are not supported. Only unaligned BAM/CRAM/SAM is allowed."
+
+
+def _fasta():
+    return b"".join(b">%s some comment\tx\n%s\n%s\n" % (n, s[:7], s[7:]) if len(s) > 7 else b">%s\n%s\n" % (n, s) for n, s in RECORDS)
+
+
+def _fastq():
+    return b"".join(b"@%s desc\n%s\n+\n%s\n" % (n, s, b"!" * len(s)) for n, s in RECORDS)
+
+
+def _sam(mapped=False):
+    out = b"@HD\tVN:1.6\tSO:unsorted\n" + (b"@SQ\tSN:chr1\tLN:1000\n" if mapped else b"")
+    for i, (n, s) in enumerate(RECORDS):
+        if mapped and i == 0:
+            out += b"%s\t0\tchr1\t1\t0\t%dM\t*\t0\t0\t%s\t%s\n" % (n, len(s), s, b"!" * len(s))
+        else:
+            out += b"%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\tRG:Z:x\n" % (n, s, b"!" * len(s))
+    return out
+
+
+PLAIN = {"fa": _fasta, "fq": _fastq, "sam": _sam}
+COMPRESS = {"": lambda b: b, ".gz": gzip.compress, ".bz2": bz2.compress, ".xz": lzma.compress, ".zst": readio.zstd_compress}
+
+
+@pytest.fixture(scope="module")
+def cli():
+    build.build_lib()
+    return build.build_cli()
+
+
+def _dump(cli, path):
+    out = subprocess.run([cli, "--dump-records", str(path)], capture_output=True, timeout=60)
+    recs = [tuple(l.split(b"\t")) for l in out.stdout.split(b"\n") if l]
+    return out.returncode, recs, out.stderr.decode()
+
+
+@pytest.mark.parametrize("ext", sorted(COMPRESS))
+@pytest.mark.parametrize("kind", sorted(PLAIN))
+def test_every_format_yields_the_same_records(tmp_path, cli, kind, ext):
+    p = tmp_path / ("reads." + kind + ext + ".input")          # the extension plays no role: content is sniffed
+    p.write_bytes(COMPRESS[ext](PLAIN[kind]()))
+    expect = [(n, s) for n, s in RECORDS]
+    assert list(readio.iter_records(str(p))) == expect
+    assert readio.count_records(str(p)) == len(RECORDS)
+    rc, recs, err = _dump(cli, p)
+    assert rc == 0 and recs == expect, err
+
+
+def test_multi_member_gzip_and_crlf(tmp_path, cli):
+    fa = _fasta().replace(b"\n", b"\r\n")
+    half = len(fa) // 2
+    p = tmp_path / "multi.gz"
+    p.write_bytes(gzip.compress(fa[:half]) + gzip.compress(fa[half:]))
+    assert list(readio.iter_records(str(p))) == RECORDS
+    assert _dump(cli, p)[1] == RECORDS
+
+
+def test_toy_bam_matches_its_fasta_conversion(cli):
+    """lrge/tests/data/toy.bam (the reference's own test input, alignment.rs:52-67): 500 unaligned ONT reads."""
+    bam = list(readio.iter_records(os.path.join(GOLDEN, "toy.bam")))
+    fa = list(readio.iter_records(os.path.join(GOLDEN, "toy_reads.fa.gz")))
+    assert len(bam) == 500 and bam == fa
+    rc, recs, err = _dump(cli, os.path.join(GOLDEN, "toy.bam"))
+    assert rc == 0 and recs == fa and "500 records" in err
+
+
+@pytest.mark.parametrize("ext", ["", ".gz"])
+def test_mapped_records_are_refused(tmp_path, cli, ext):
+    """lrge/tests/alignment.rs:29-50."""
+    p = tmp_path / ("mapped.sam" + ext)
+    p.write_bytes(COMPRESS[ext](_sam(mapped=True)))
+    with pytest.raises(ValueError, match="Mapped records are not supported"):
+        list(readio.iter_records(str(p)))
+    rc, _, err = _dump(cli, p)
+    assert rc != 0 and MAPPED in err
+
+
+def test_mapped_bam_is_refused(tmp_path, cli):
+    import struct
+    name, seq = b"m1\0", b"\x12\x48"                                   # ACGT packed
+    rec = struct.pack("<iiBBHHHiiii", 0, 0, len(name), 0, 0, 0, 0, 4, -1, -1, 0) + name + seq + b"\xff" * 4
+    body = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", 1000) + \
+        struct.pack("<i", len(rec)) + rec
+    p = tmp_path / "mapped.bam"
+    p.write_bytes(gzip.compress(body))
+    with pytest.raises(ValueError, match="Mapped records are not supported"):
+        list(readio.iter_records(str(p)))
+    rc, _, err = _dump(cli, p)
+    assert rc != 0 and MAPPED in err
+    # the same record flagged unmapped is read: name without the NUL, 4-bit bases high nibble first
+    rec2 = rec[:14] + struct.pack("<H", 4) + rec[16:]
+    p.write_bytes(gzip.compress(body[:-len(rec)] + rec2))
+    assert list(readio.iter_records(str(p))) == [(b"m1", b"ACGT")]
+    assert _dump(cli, p)[1] == [(b"m1", b"ACGT")]
+
+
+def test_empty_cram_and_garbage(tmp_path, cli):
+    e = tmp_path / "empty.fa"
+    e.write_bytes(b"")
+    with pytest.raises(ValueError, match="Is the file empty"):
+        readio.count_records(str(e))
+    rc, _, err = _dump(cli, e)
+    assert rc != 0 and "Is the file empty?" in err
+    c = tmp_path / "x.cram"
+    c.write_bytes(b"CRAM\x03\x00" + b"\0" * 40)
+    with pytest.raises(ValueError, match="CRAM"):
+        list(readio.iter_records(str(c)))
+    assert _dump(cli, c)[0] != 0
+    g = tmp_path / "garbage"
+    g.write_bytes(b"hello world\n")
+    with pytest.raises(ValueError):
+        list(readio.iter_records(str(g)))
+    assert _dump(cli, g)[0] != 0
+    t = tmp_path / "trunc.gz"
+    t.write_bytes(gzip.compress(_fasta() * 50)[:-20])
+    with pytest.raises(Exception):
+        list(readio.iter_records(str(t)))
+    assert _dump(cli, t)[0] != 0

@@ -1,56 +1,24 @@
 // lrge_hip_cli.cpp -- flag-for-flag mirror of the `lrge` command line (lrge/src/cli.rs:9-87,
 // lrge/src/main.rs:32-123) driving the MI355X overlap engine through include/lrge_hip.hpp.
-// Input: plain or gzip FASTA/FASTQ (the reference's BAM/CRAM/zstd/bz2/xz readers are host I/O outside
-// the hot path: SURVEY.md 8f-4).  Like the reference CLI, -P is parsed but NOT forwarded to the
+// Input: FASTA / FASTQ / unaligned SAM / unaligned BAM, plain or gzip / bzip2 / xz / zstd compressed, sniffed by
+// magic bytes like liblrge/src/io.rs (include/lrge_io.hpp; CRAM is recognised and refused).  Like the reference CLI, -P is parsed but NOT forwarded to the
 // builders (lrge/src/main.rs:56-85), so the preset is always ava-ont; pass --honour-platform to
 // forward it (what the library API does).
-#include <zlib.h>
-
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 
 #include "../include/lrge_hip.hpp"
+#include "../include/lrge_io.hpp"
 
-static std::string read_id(const std::string &h) {   // io.rs:199-204
-    size_t i = 0;
-    while (i < h.size() && !(h[i] == ' ' || h[i] == '\t' || h[i] == '\n' || h[i] == '\r' || h[i] == '\v' || h[i] == '\f')) ++i;
-    return h.substr(0, i);
-}
-
-static bool gz_getline(gzFile f, std::string &out) {
-    out.clear();
-    char buf[1 << 16];
-    for (;;) {
-        if (!gzgets(f, buf, sizeof(buf))) return !out.empty();
-        out += buf;
-        if (!out.empty() && out.back() == '\n') { out.pop_back(); if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
-    }
-}
-
-static lrge::Reads load_fastx(const std::string &path) {
-    gzFile f = gzopen(path.c_str(), "rb");
-    if (!f) throw lrge::LrgeError(LRGE_ERR_IO, "cannot open " + path);
+static lrge::Reads load_reads(const std::string &path) {   // io.rs:154-184 via include/lrge_io.hpp
     lrge::Reads r;
-    std::string line, seq;
-    if (!gz_getline(f, line)) { gzclose(f); return r; }
-    if (line[0] == '>') {
-        std::string name = read_id(line.substr(1));
-        while (gz_getline(f, line)) {
-            if (!line.empty() && line[0] == '>') { r.names.push_back(name); r.seqs.push_back(seq); seq.clear(); name = read_id(line.substr(1)); }
-            else seq += line;
-        }
-        r.names.push_back(name); r.seqs.push_back(seq);
-    } else if (line[0] == '@') {
-        for (;;) {
-            std::string name = read_id(line.substr(1)), s, plus, qual;
-            if (!gz_getline(f, s) || !gz_getline(f, plus) || !gz_getline(f, qual)) { gzclose(f); throw lrge::LrgeError(LRGE_ERR_PARSE, "truncated FASTQ record"); }
-            r.names.push_back(name); r.seqs.push_back(s);
-            if (!gz_getline(f, line)) break;
-        }
-    } else { gzclose(f); throw lrge::LrgeError(LRGE_ERR_PARSE, "unrecognised sequence file"); }
-    gzclose(f);
+    try {
+        lrge::io::iter_records(path, [&](const std::string &name, const std::string &seq) { r.names.push_back(name); r.seqs.push_back(seq); });
+    } catch (const lrge::io::IoError &e) {
+        throw lrge::LrgeError(LRGE_ERR_IO, e.what());
+    }
     return r;
 }
 
@@ -60,7 +28,7 @@ int main(int argc, char **argv) {
     bool T_set = false, Q_set = false, filter = false, with_inf = false, precise = false, use_min_ref = false, honour_platform = false;
     float q1 = lrge::LOWER_QUANTILE, q3 = lrge::UPPER_QUANTILE, ratio = 0.2f;
     size_t threads = 1; std::optional<uint64_t> seed; int quiet = 0, verbose = 0, device = 0;
-    bool keep_temp = false; std::string temp_dir;
+    bool keep_temp = false, dump_records = false; std::string temp_dir;
     auto need = [&](int &i) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "error: missing value for %s\n", argv[i]); exit(2); } return argv[++i]; };
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -82,6 +50,7 @@ int main(int argc, char **argv) {
         else if (a == "--use-min-ref") use_min_ref = true;
         else if (a == "--honour-platform") honour_platform = true;
         else if (a == "--device") device = atoi(need(i));
+        else if (a == "--dump-records") dump_records = true;   // host-only: print "id<TAB>sequence" per record and exit (tests)
         else if (a == "-q" || a == "--quiet") ++quiet; else if (a == "-qq") quiet += 2; else if (a == "-qqq") quiet += 3;
         else if (a == "-v" || a == "--verbose") ++verbose; else if (a == "-vv") verbose += 2;
         else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); return 2; }
@@ -93,7 +62,13 @@ int main(int argc, char **argv) {
     if (quiet && verbose) { fprintf(stderr, "error: --quiet cannot be used with --verbose\n"); return 2; }
     const bool info = quiet == 0;
     try {
-        lrge::Reads reads = load_fastx(input);
+        if (dump_records) {
+            size_t n = lrge::io::count_records(input);
+            lrge::io::iter_records(input, [](const std::string &name, const std::string &seq) { printf("%s\t%s\n", name.c_str(), seq.c_str()); });
+            fprintf(stderr, "%zu records\n", n);
+            return 0;
+        }
+        lrge::Reads reads = load_reads(input);
         const lrge::Platform pf = (honour_platform && platform == "pb") ? lrge::Platform::PacBio : lrge::Platform::Nanopore;
         lrge::twoset::TwoSetStrategy ts(reads); lrge::ava::AvaStrategy as(reads);
         lrge::Estimate *st;
@@ -129,6 +104,9 @@ int main(int argc, char **argv) {
         if (precise) fprintf(out, "%.9g\n", (double)*r.estimate); else fprintf(out, "%.0f\n", (double)*r.estimate);
         if (out != stdout) fclose(out);
         if (info) fprintf(stderr, "[INFO] Done!\n");
+    } catch (const lrge::io::IoError &e) {
+        fprintf(stderr, "Error: Failed to generate estimate\n\nCaused by:\n    %s\n", e.what());
+        return 1;
     } catch (const lrge::LrgeError &e) {
         fprintf(stderr, "Error: Failed to generate estimate\n\nCaused by:\n    %s\n", e.what());
         return 1;

@@ -479,3 +479,46 @@ def test_cli_alignment_inputs_and_seeded_subsampling(ctx, oracle, tmp_path):
         assert out.returncode == 0 and np.float32(float(out.stdout.strip())) == med, (out.stdout, out.stderr)
         r = twoset.Builder().target_num_reads(T).query_num_reads(Q).seed(seed).build(bam).estimate(True, 0.15, 0.65)
         assert np.float32(r.estimate) == med and np.float32(r.lower) == lo and np.float32(r.upper) == hi
+
+
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_ultra_long_reads(ctx, oracle, preset):
+    """Reads of 100-600 kb (ultra-long ONT territory) on a genome with interspersed and tandem repeats: tens of
+    thousands of minimizers per read, query segments far beyond the LDS-resident sort classes, (target, strand) groups
+    with thousands of anchors, chains spanning hundreds of kilobases.  Counts, chains and all-vs-all counts must equal
+    the oracle's."""
+    from lrge_amd import engine, synth
+    genome = synth.random_genome(900_000, 515, repeats=0.05, tandem=0.01)
+    base = dict(synth.PLATFORMS["ont" if preset == "ont" else "hifi"])
+    synth.PLATFORMS["_ul"] = dict(base, kind="normal", mu=300_000.0, sigma=120_000.0, lo=100_000, hi=600_000)
+    try:
+        ul = synth.sample_reads(genome, 10, "_ul", seed=31, name_prefix="ul")
+    finally:
+        del synth.PLATFORMS["_ul"]
+    normal = synth.sample_reads(genome, 90, "ont" if preset == "ont" else "hifi", seed=33, name_prefix="n")
+    qseqs, qnames = ul.seqs()[:4] + normal.seqs()[:25], ul.names[:4] + normal.names[:25]
+    tseqs, tnames = ul.seqs()[4:] + normal.seqs()[25:], ul.names[4:] + normal.names[25:]
+    assert max(map(len, qseqs)) > 200_000
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset, dual=True)
+    for F in (False, True):
+        counts, has = ixd.overlap_twoset(Qd, remove_internal=F)
+        rc, ec, eh = ixo.twoset_counts(Qo, remove_internal=F, threads=8)
+        assert np.array_equal(counts, ec) and np.array_equal(has, eh)
+        assert int(ec.sum()) > (30 if F else 100)
+    cols = ["query", "target", "rev", "score", "cnt", "qs", "qe", "rs", "re", "mlen", "blen"]
+    got = _chain_rows(ixd.chains(Qd, dual=True), cols)
+    exp = _oracle_chains(ixo, qseqs, qnames)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    assert int((exp[:, 6] - exp[:, 5]).max()) > 100_000            # a chain over more than 100 kb of query
+    inv = ixd.overlap_inverse(Qd)
+    rc, einv = ixo.inverse_counts(Qo, threads=8)
+    assert np.array_equal(inv, einv)
+    ixd.free()
+    aseqs, anames = qseqs + tseqs, qnames + tnames
+    (ar,) = engine.name_ranks(anames)
+    Ad = _upload(ctx, aseqs, ar)
+    ixa = engine.Index(ctx, Ad, PRESETS[preset])
+    ixoa = oracle.Index(oracle.ReadSet(aseqs, anames), oracle.make_opt(oracle.PRESET_AVA_PB if preset == "pb" else oracle.PRESET_AVA_ONT, dual=False))
+    rc, eava = ixoa.ava_counts(threads=8)
+    assert np.array_equal(ixa.overlap_ava(), eava)
+    ixa.free()

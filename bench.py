@@ -190,6 +190,18 @@ def main():
                        acc_cn.get("batches", 0), 16.0 * acc_cn.get("chain_anchors", 0), "chain_stage_hbm_bytes_per_step")
         r_sc = roof("k_rs_scatter", acc_tm.get("rs_scatter", 0.0) + acc_tb.get("rs_scatter", 0.0), acc_cn.get("rs_scatter_launches", 0),
                     float(acc_cn.get("rs_scatter_bytes", 0)), "k_rs_scatter_hbm_bytes_per_launch")
+        # What actually bounds the chain stage: VALU issue.  A wave64 VALU instruction occupies its SIMD for 4 cycles
+        # (MI355X_MICROARCH.md); the instruction counts per launch come from the SQ counter pass in profiles/
+        # (SQ_INSTS_VALU, same command), the stage time is the live fork..join figure of this run.
+        issue = None
+        vi = [pmc.get("k_chain_lpg_valu_insts_per_launch"), pmc.get("k_chain_hw_valu_insts_per_launch")]
+        if all(vi) and acc_cn.get("batches", 0) and acc_tm.get("chain", 0.0) > 0:
+            n_simd, clk = 256 * 4, 2.4e9
+            issue_ms = sum(vi) * 4.0 / (n_simd * clk) * 1e3
+            stage_ms = acc_tm["chain"] / acc_cn["batches"]
+            issue = {"bound": "valu_issue", "valu_insts_per_step": sum(vi), "cycles_per_inst": 4, "simds": n_simd, "clock_ghz": 2.4,
+                     "issue_ms": issue_ms, "stage_ms": stage_ms, "frac": issue_ms / stage_ms,
+                     "note": "chain stage = k_chain_lpg + k_chain_hw side by side; integer DP, not a memory stream"}
         # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
         L = float(q.lens().sum()); M = acc_cn.get("query_minimizers", 0) / K; H = acc_cn.get("anchors", 0) / K
         B_q = L / 4 + 32 * M + 8 * H + 32 * H + 4 * Qn
@@ -211,6 +223,7 @@ def main():
             "mid_occ": st["mid_occ"],
             "roofline": {**r_dom, "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS},
             "roofline_other": [r_stage, r_sc],
+            "chain_stage_issue": issue,
             "stage_ms_per_step": {**{"index_" + k: v / K for k, v in acc_tb.items() if v and k != "total"},
                                   **{k: v / K for k, v in acc_tm.items() if v}},
             "work_per_step": {k: (v if k == "lpg_split" else v / K) for k, v in acc_cn.items()},

@@ -86,6 +86,11 @@ for line in open(os.path.join(G, tag + "_bench.json")):
     pass
 out["calibration"] = {"k_rs_hist_false_largest_launch_FETCH_SIZE_KiB": big,
                       "note": "that launch reads 8 B x (index minimizers); FETCH_SIZE reports half of it on gfx950 (128-B requests tallied at 64 B)"}
+# VALU issue of the chain stage (SQ pass): wave64 VALU instructions per launch; each occupies its SIMD for 4 cycles
+sq = agg(os.path.join(G, tag + "_sq", "q_counter_collection.csv"))
+for kern, key in (("k_chain_lpg<true>", "k_chain_lpg"), ("k_chain_hw", "k_chain_hw")):
+    v = sq.get(kern, {}).get("SQ_INSTS_VALU")
+    out[key + "_valu_insts_per_launch"] = v[1] / v[0] if v else None
 a, b = out["k_chain_lpg_hbm_bytes_per_launch"], out["k_chain_hw_hbm_bytes_per_launch"]
 out["chain_stage_hbm_bytes_per_step"] = (a or 0) + (b or 0) if (a or b) else None
 json.dump(out, open(os.path.join(P, "chain_pmc.json"), "w"), indent=1)

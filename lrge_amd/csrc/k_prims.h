@@ -207,14 +207,27 @@ struct UnpackParams { u32 sb, bits_qy, sh_q, dmask; };   // dmask: digit mask of
 #define RS_MODE_KEYS 1
 #define RS_MODE_UNPACK 2
 
+// Blocks are observed to be dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Tile t and
+// tile t + 1 of a pass write adjacent runs in every digit's region, so they should meet in ONE L2: XCD x takes the
+// x-th contiguous eighth of the tiles.  A bijection of [0, nb); placement is a speed matter only.
+__device__ __forceinline__ u32 xcd_tile(u32 b, u32 nb) {
+#ifdef RS_NO_XCD_MAP
+    (void)nb; return b;
+#else
+    const u32 per = nb >> 3, rem = nb & 7, x = b & 7;
+    return x * per + (x < rem ? x : rem) + (b >> 3);
+#endif
+}
+
 template <bool SEG>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
                                                         u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255) {
     __shared__ u32 h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const u64 tile0 = SEG ? (u64)tiles[blockIdx.x].start : (u64)blockIdx.x * RS_TILE;
-    const u32 n_tile = SEG ? tiles[blockIdx.x].len : (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
+    const u32 bid = xcd_tile(blockIdx.x, gridDim.x);
+    const u64 tile0 = SEG ? (u64)tiles[bid].start : (u64)bid * RS_TILE;
+    const u32 n_tile = SEG ? tiles[bid].len : (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
     const u32 l0 = (threadIdx.x >> 6) * (RS_ITEMS * 64) + lane_id();
 #pragma unroll 4
     for (int r = 0; r < RS_ITEMS; ++r) {
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
         if (l < n_tile) atomicAdd(&h[(keys[tile0 + l] >> shift) & dmask], 1u);
     }
     __syncthreads();
-    const u64 hi = SEG ? (u64)tiles[blockIdx.x].hbase + (u64)threadIdx.x * tiles[blockIdx.x].hstride : (u64)threadIdx.x * nb + blockIdx.x;
+    const u64 hi = SEG ? (u64)tiles[bid].hbase + (u64)threadIdx.x * tiles[bid].hstride : (u64)threadIdx.x * nb + bid;
     hist[hi] = h[threadIdx.x];
 }
 
@@ -239,11 +252,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     __shared__ u32 wtot[RS_WAVES];
     __shared__ u64 stage[RS_TILE];       // 32 KB: keys, then values
     const u32 w = threadIdx.x >> 6, lane = lane_id();
+    const u32 bid = xcd_tile(blockIdx.x, gridDim.x);
     const u32 dmask = MODE == RS_MODE_PAIRS ? 255u : up.dmask;
     for (u32 i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    const u64 tile0 = SEG ? (u64)tiles[blockIdx.x].start : (u64)blockIdx.x * RS_TILE;
-    const u32 n_tile = SEG ? tiles[blockIdx.x].len : (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
+    const u64 tile0 = SEG ? (u64)tiles[bid].start : (u64)bid * RS_TILE;
+    const u32 n_tile = SEG ? tiles[bid].len : (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
     const u32 l0 = w * (RS_ITEMS * 64) + lane;           // tile-local index of my first item
     const u64 base = tile0 + l0;
     u64 k[RS_ITEMS], v[RS_ITEMS];
@@ -284,8 +298,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         __syncthreads();
         u32 dstart = inc - tot;
         for (u32 ww = 0; ww < w; ++ww) dstart += wtot[ww];
-        const u64 hi = SEG ? (u64)tiles[blockIdx.x].hbase + (u64)d * tiles[blockIdx.x].hstride : (u64)d * nb + blockIdx.x;
-        gbase[d] = hist_scanned[hi] + (SEG ? tiles[blockIdx.x].delta : 0u) - dstart;
+        const u64 hi = SEG ? (u64)tiles[bid].hbase + (u64)d * tiles[bid].hstride : (u64)d * nb + bid;
+        gbase[d] = hist_scanned[hi] + (SEG ? tiles[bid].delta : 0u) - dstart;
         u32 run = dstart;
 #pragma unroll
         for (int ww = 0; ww < RS_WAVES; ++ww) { cnt[ww][d] = run; run += c[ww]; }
@@ -301,7 +315,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     __syncthreads();
     u64 ko[RS_ITEMS];
     if (MODE == RS_MODE_UNPACK) {
-        const u64 seg = SEG ? (u64)tiles[blockIdx.x].seg << up.sh_q : 0;
+        const u64 seg = SEG ? (u64)tiles[bid].seg << up.sh_q : 0;
         const u64 smask = (1ULL << up.sb) - 1, qmask = (1ULL << up.bits_qy) - 1;
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) {

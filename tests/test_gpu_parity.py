@@ -460,13 +460,17 @@ def test_cli_alignment_inputs_and_seeded_subsampling(ctx, oracle, tmp_path):
     assert out.returncode == 0, out.stderr                       # alignment.rs:52-67 asserts exactly this
     names, seqs = readio.load(bam)
 
-    def expect(T, Q, seed):
+    def expect(T, Q, seed, inverse=False, F=False):
         idx = rand09.unique_random_set(T + Q, len(names), seed)
         t, q = sorted(idx[Q:]), sorted(idx[:Q])                   # split_into_hashsets pops the targets off the end; file order
         To = oracle.ReadSet([seqs[i] for i in t], [names[i] for i in t])
         Qo = oracle.ReadSet([seqs[i] for i in q], [names[i] for i in q])
-        ixo = oracle.Index(To, oracle.make_opt(oracle.PRESET_AVA_ONT, dual=True))
-        rc, counts, has = ixo.twoset_counts(Qo, threads=4)
+        if inverse:                                               # --use-min-ref: index the queries, stream the targets
+            ixo = oracle.Index(Qo, oracle.make_opt(oracle.PRESET_AVA_ONT, dual=True))
+            rc, counts = ixo.inverse_counts(To, remove_internal=F, threads=4)
+        else:
+            ixo = oracle.Index(To, oracle.make_opt(oracle.PRESET_AVA_ONT, dual=True))
+            rc, counts, has = ixo.twoset_counts(Qo, remove_internal=F, threads=4)
         avg = np.float32(sum(len(seqs[i]) for i in t)) / np.float32(T)
         est = np.array([oracle.per_read_estimate(len(seqs[i]), float(avg), T, int(c), 100) for i, c in zip(q, counts)], dtype=np.float32)
         return oracle.median(est, True, 0.15, 0.65)
@@ -478,6 +482,15 @@ def test_cli_alignment_inputs_and_seeded_subsampling(ctx, oracle, tmp_path):
         out = subprocess.run([cli, bam, "-T", str(T), "-Q", str(Q), "-s", str(seed), "-f"], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and np.float32(float(out.stdout.strip())) == med, (out.stdout, out.stderr)
         r = twoset.Builder().target_num_reads(T).query_num_reads(Q).seed(seed).build(bam).estimate(True, 0.15, 0.65)
+        assert np.float32(r.estimate) == med and np.float32(r.lower) == lo and np.float32(r.upper) == hi
+    # --use-min-ref (twoset.rs:596-599: the query set is indexed when it holds fewer bases) and -F, through both mirrors
+    for T, Q, seed, inverse, F in ((300, 100, 9, True, False), (300, 100, 9, True, True), (200, 100, 42, False, True)):
+        lo, med, hi = expect(T, Q, seed, inverse, F)
+        args = [cli, bam, "-T", str(T), "-Q", str(Q), "-s", str(seed), "-f"] + (["--use-min-ref"] if inverse else []) + (["-F"] if F else [])
+        out = subprocess.run(args, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and np.float32(float(out.stdout.strip())) == med, (args, out.stdout, out.stderr)
+        r = twoset.Builder().target_num_reads(T).query_num_reads(Q).seed(seed).use_min_ref(inverse).remove_internal(F, 0.2).build(bam) \
+            .estimate(True, 0.15, 0.65)
         assert np.float32(r.estimate) == med and np.float32(r.lower) == lo and np.float32(r.upper) == hi
 
 

@@ -794,11 +794,12 @@ void OverlapRun::plan_anchor_sort(u32 q0, u32 q1, bool packed) {
     u32 off = 0, tb = 0, &n_local = n_local_items;
     n_local = 0;
     const bool local_ok = !getenv("LRGE_HIP_NO_LOCAL_SORT");
+    const int local_max = getenv("LRGE_HIP_LOCAL_SORT_MAX") ? atoi(getenv("LRGE_HIP_LOCAL_SORT_MAX")) : 2;   // largest class sorted in LDS
     for (u32 q = q0; q < q1; ++q) {
         const u32 c = h_qtot[q];
         if (packed && c) {
             const int cls = c <= 2048 ? 0 : c <= 8192 ? 1 : c <= 16384 ? 2 : 3;
-            if (cls < 3 && local_ok && ctx->lsort_ok[cls]) { h_local[cls].push_back(SegDesc{off, c, q - q0, 0}); off += c; n_local += c; continue; }
+            if (cls < 3 && cls <= local_max && local_ok && ctx->lsort_ok[cls]) { h_local[cls].push_back(SegDesc{off, c, q - q0, 0}); off += c; n_local += c; continue; }
         }
         const u32 nt_q = (u32)div_up((u64)c, RS_TILE);
         for (u32 lt = 0; lt < nt_q; ++lt) {

@@ -341,7 +341,11 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
             rc = compact_heads(ctx, sc, skey, M, pk_ybits, &d_runstart, &n_runs);    // runs of equal hash
             if (rc) { delete ix; return rc; }
         }
-        u64 cap = 2 * (u64)n_runs;
+#ifndef HT_CAP_NUM
+#define HT_CAP_NUM 2       // home slots per distinct key = HT_CAP_NUM / HT_CAP_DEN
+#define HT_CAP_DEN 1
+#endif
+        u64 cap = (u64)n_runs * HT_CAP_NUM / HT_CAP_DEN;
         if (cap < 1024) cap = 1024;
         if (cap + n_runs >= (1ULL << 32)) { delete ix; LRGE_SET_ERR(ctx, "index limited to < 2^32/3 distinct minimizers (got %u)", n_runs); return LRGE_ERR_TOO_MANY; }
         ix->ht_cap = cap;

@@ -142,11 +142,19 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
         if (lh[i]) atomicAdd(&occ_hist[i], lh[i]);
 }
 
+// The table is ORDERED: keys were placed in ascending byte-reversed order, each at its home slot or right behind its
+// predecessor, so a probe can stop at the first entry that is not smaller in that order -- an absent key (most query
+// minimizers of noisy reads) costs no more than a present one instead of a walk to the next empty slot.  An empty slot
+// (all ones) compares as the largest key.
 __device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u64 key, u64 *start, u32 *cnt) {
     u64 slot = ht_home(key, cap);
+    const u64 bk = __builtin_bswap64(key);
     for (;; ++slot) {
         const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
-        if (e.x == key) { *start = e.y >> HT_CNT_BITS; *cnt = (u32)(e.y & HT_CNT_MAX); return true; }
-        if (e.x == HT_EMPTY) return false;
+        if (__builtin_bswap64(e.x) >= bk) {
+            if (e.x != key) return false;
+            *start = e.y >> HT_CNT_BITS; *cnt = (u32)(e.y & HT_CNT_MAX);
+            return true;
+        }
     }
 }

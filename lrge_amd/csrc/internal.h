@@ -86,6 +86,26 @@ struct lrge_hip_ctx {
     u64 counters[LRGE_C_N];
     int n_cu = 256;
     bool lsort_ok[3] = {false, false, false};   // which k_seg_sort_local variants this device can launch
+    // Small device->host reads (totals, censuses, per-read vectors).  hipMemcpyAsync into pageable memory is a blocking
+    // staged copy, one round trip EACH; through this pinned area several reads queue up behind the kernels and cost
+    // one round trip at the following d2h_sync(), which also moves the bytes to where the caller wants them.
+    char *pin = nullptr; size_t pin_cap = 0, pin_used = 0;
+    struct PinItem { void *dst; size_t off, bytes; };
+    std::vector<PinItem> pin_items;
+    hipError_t d2h(void *dst, const void *src, size_t bytes, hipStream_t st) {
+        const size_t need = (bytes + 63) & ~(size_t)63;
+        if (!pin || pin_used + need > pin_cap) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);   // too large: direct
+        const hipError_t e = hipMemcpyAsync(pin + pin_used, src, bytes, hipMemcpyDeviceToHost, st);
+        pin_items.push_back(PinItem{dst, pin_used, bytes});
+        pin_used += need;
+        return e;
+    }
+    hipError_t d2h_sync(hipStream_t st) {
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e == hipSuccess) for (const PinItem &it : pin_items) memcpy(it.dst, pin + it.off, it.bytes);
+        pin_items.clear(); pin_used = 0;
+        return e;
+    }
     std::vector<struct TimerRec> timers;     // pending event pairs of the current call
     std::vector<hipEvent_t> event_pool;      // recycled events
     hipEvent_t get_event() {

@@ -47,6 +47,8 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (hipHostMalloc((void **)&ctx->pin, 1u << 20, hipHostMallocDefault) == hipSuccess) ctx->pin_cap = 1u << 20;
+    else { ctx->pin = nullptr; (void)hipGetLastError(); }       // reads fall back to pageable copies
     // segment-local sort variants: the two larger ones need more than the default 64 KB of LDS per workgroup
     ctx->lsort_ok[0] = true;
     ctx->lsort_ok[1] = ctx->lsort_ok[0] && hipFuncSetAttribute((const void *)k_seg_sort_local<512, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -68,6 +70,7 @@ extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
     ctx->resolve_timers();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->pool.destroy();
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join);
     (void)hipStreamDestroy(ctx->stream2);
@@ -96,6 +99,7 @@ extern "C" int lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, cons
     if (!ctx || !out || (n && (!bases || !offsets))) return LRGE_ERR_INVALID;
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
     lrge_hip_seqset *s = new lrge_hip_seqset();
     s->ctx = ctx; s->n = n;
     s->h_woff.resize((size_t)n + 1); s->h_len.resize(n ? n : 1);
@@ -216,12 +220,12 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, ctx->stream, d_cs, d_cnt, s->n,
                        n_chunks, d_total, d_mzoff);
     KCHK(ctx);
-    HIPCHK(ctx, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, ctx->d2h(&total, d_total, 4, ctx->stream));
     if (h_mzoff) {
         h_mzoff->resize((size_t)s->n + 1);
-        HIPCHK(ctx, hipMemcpyAsync(h_mzoff->data(), d_mzoff, ((size_t)s->n + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, ctx->d2h(h_mzoff->data(), d_mzoff, ((size_t)s->n + 1) * 4, ctx->stream));
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
     ALLOC_OR_FAIL(dx, sc, u64, (size_t)total + 1);
     u64 *dy = nullptr;
     if (!(index_keys && pk_ybits)) { dy = sc.get<u64>((size_t)total + 1); if (!dy) return LRGE_ERR_DEVICE; }
@@ -256,6 +260,7 @@ extern "C" int lrge_hip_sketch_dump(lrge_hip_ctx *ctx, const lrge_hip_seqset *s,
                                     uint64_t cap, uint64_t *n_out) {
     if (!ctx || !s || !n_out) return LRGE_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
     Scratch sc(ctx);
     SketchOut o;
     int rc = sketch_device(ctx, sc, s, preset, false, &o);
@@ -282,6 +287,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
     memset(ctx->counters, 0, sizeof(ctx->counters));
@@ -380,9 +386,9 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
             // the k-th smallest occurrence count almost always sits in the first few bins: fetch 16 KB of
             // the histogram first, the whole 4 MB only if the prefix does not reach the k-th element
             u32 overflow = 0;
-            HIPCHK(ctx, hipMemcpyAsync(occ.data(), d_occ, head_bins * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(&overflow, d_occ + max_bin + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, ctx->d2h(occ.data(), d_occ, head_bins * 4, ctx->stream));
+            HIPCHK(ctx, ctx->d2h(&overflow, d_occ + max_bin + 1, 4, ctx->stream));
+            HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
             if (!overflow) break;
             sc.drop(ht); ht = nullptr;
             if (attempt == 1) { delete ix; LRGE_SET_ERR(ctx, "index table placement overflowed%s", ""); return LRGE_ERR_DEVICE; }
@@ -443,6 +449,7 @@ extern "C" int lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, 
                                    uint64_t *n_out) {
     if (!ctx || !ix || !n_out) return LRGE_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
     *n_out = ix->n_mz;
     u64 m = ix->n_mz < cap ? ix->n_mz : cap;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
@@ -652,8 +659,8 @@ int OverlapRun::seeds() {
         rc = scan_exclusive_u32(ctx, sc, flag, fpos, Mq, d_ns);
         if (rc) return rc;
         u32 Ms = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&Ms, d_ns, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, ctx->d2h(&Ms, d_ns, 4, ctx->stream));
+        HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
         if (Ms > (u32)ix->mid_occ) {
             ALLOC_OR_FAIL(ka, sc, u64, Ms); ALLOC_OR_FAIL(va, sc, u64, Ms);
             ALLOC_OR_FAIL(kb, sc, u64, Ms); ALLOC_OR_FAIL(vb, sc, u64, Ms);
@@ -701,8 +708,8 @@ int OverlapRun::seeds() {
     if (job.paf_stats) {   // per-query seed statistics only (rl, avg_k ingredients)
         if (d_qf) {
             if (qf_on_side) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); qf_on_side = false; }
-            HIPCHK(ctx, hipMemcpyAsync(&qf, d_qf, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, ctx->d2h(&qf, d_qf, 4, ctx->stream));
+            HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
             if (qf) { rc = run_exact_qocc(); if (rc) return rc; }
         }
         ALLOC_OR_FAIL(d_rl, sc, i32, (size_t)nq); ALLOC_OR_FAIL(d_ss, sc, u64, (size_t)nq); ALLOC_OR_FAIL(d_nk, sc, u32, (size_t)nq);
@@ -732,12 +739,12 @@ int OverlapRun::seeds() {
         }
         hipLaunchKernelGGL(k_query_anchor_totals, dim3((u32)div_up(nq, 4)), dim3(256), 0, ctx->stream, hv, so.mz_off, nq, d_qtot);
         KCHK(ctx);
-        HIPCHK(ctx, hipMemcpyAsync(h_qtot.data(), d_qtot, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, ctx->d2h(h_qtot.data(), d_qtot, (size_t)nq * 4, ctx->stream));
         if (d_qf) {
             if (qf_on_side) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); qf_on_side = false; }
-            HIPCHK(ctx, hipMemcpyAsync(&qf, d_qf, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, ctx->d2h(&qf, d_qf, 4, ctx->stream));
         }
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
         t.stop();
         return LRGE_OK;
     };
@@ -1035,10 +1042,10 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                                d_cnt, d_anch, d_cnt + 4, d_anch + 2);
             KCHK(ctx);
             u32 h_cnt[4 + GSZ_BINS]; unsigned long long h_anch[2 + GSZ_BINS];
-            HIPCHK(ctx, hipMemcpyAsync(&G, d_G, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(h_anch, d_anch, sizeof(h_anch), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, ctx->d2h(&G, d_G, 4, ctx->stream));
+            HIPCHK(ctx, ctx->d2h(h_cnt, d_cnt, sizeof(h_cnt), ctx->stream));
+            HIPCHK(ctx, ctx->d2h(h_anch, d_anch, sizeof(h_anch), ctx->stream));
+            HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
             gflags = bsc.get<u32>((size_t)G + 1);
             if (!gflags) return LRGE_ERR_DEVICE;
             HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
@@ -1073,9 +1080,9 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
             HIPCHK(ctx, hipMemsetAsync(bin_count, 0, N_BINS * 4, ctx->stream));
             hipLaunchKernelGGL(k_group_bin, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, bl, bin_count, bin_list, bin_anchors);
             KCHK(ctx);
-            HIPCHK(ctx, hipMemcpyAsync(h_bins, bin_count, N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(h_bin_anchors, bin_anchors, N_BINS * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, ctx->d2h(h_bins, bin_count, N_BINS * 4, ctx->stream));
+            HIPCHK(ctx, ctx->d2h(h_bin_anchors, bin_anchors, N_BINS * 8, ctx->stream));
+            HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
         }
         t.stop();
     }
@@ -1172,9 +1179,9 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
 int OverlapRun::finish() {
     const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
     (void)T; (void)P; (void)nq; (void)nt;
-    if (job.counts) HIPCHK(ctx, hipMemcpyAsync(job.counts, d_counts, (size_t)n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (job.has_map) HIPCHK(ctx, hipMemcpyAsync(job.has_map, d_hasmap, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (job.counts) HIPCHK(ctx, ctx->d2h(job.counts, d_counts, (size_t)n_out * 4, ctx->stream));
+    if (job.has_map) HIPCHK(ctx, ctx->d2h(job.has_map, d_hasmap, (size_t)nq * 4, ctx->stream));
+    HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
     if (job.n_chains) {
         unsigned long long nchn = 0;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
@@ -1190,6 +1197,7 @@ int OverlapRun::finish() {
 static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *Q, OverlapJob &job) {
 
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
     memset(ctx->counters, 0, sizeof(ctx->counters));
@@ -1316,6 +1324,7 @@ extern "C" int lrge_hip_estimates(lrge_hip_ctx *ctx, const uint32_t *counts, con
     if (!ctx || (n && (!counts || !read_lens || !out))) return LRGE_ERR_INVALID;
     if (n == 0) return LRGE_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
     Scratch sc(ctx);
     ALLOC_OR_FAIL(dc, sc, u32, n); ALLOC_OR_FAIL(dl, sc, u32, n); ALLOC_OR_FAIL(d_out, sc, float, n);
     HIPCHK(ctx, hipMemcpyAsync(dc, counts, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1324,12 +1333,17 @@ extern "C" int lrge_hip_estimates(lrge_hip_ctx *ctx, const uint32_t *counts, con
     float nt = (float)n_target_reads, two_thr = 2.0f * (float)overlap_thresh;
     hipLaunchKernelGGL(k_estimate, dim3((u32)div_up(n, 256)), dim3(256), 0, ctx->stream, dc, dl, n, avg_target_len, nt, two_thr, d_out);
     KCHK(ctx);
-    HIPCHK(ctx, hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, ctx->d2h(out, d_out, (size_t)n * 4, ctx->stream));
+    HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
     return LRGE_OK;
 }
 
-// estimate.rs:80-132.  f32 arithmetic, no contraction (this TU is built with -ffp-contract=off).
+// estimate.rs:80-132.  f32 arithmetic, no contraction (this TU is built with -ffp-contract=off).  `d` must hold the
+// order statistics idx and idx + 1 at their sorted positions (the caller selects them; a full sort is not needed).
+static size_t quantile_index(size_t n, float q) {
+    volatile float pos = q * (float)(n - 1);
+    return (size_t)floorf(pos);
+}
 static bool quantile_f32(const std::vector<float> &d, float q, float *out) {
     if (d.empty()) return false;
     size_t n = d.size();
@@ -1355,7 +1369,21 @@ extern "C" int lrge_hip_median(const float *estimates, uint64_t n, int finite, i
     v.reserve(n);
     for (u64 i = 0; i < n; ++i) if (!finite || std::isfinite(estimates[i])) v.push_back(estimates[i]);
     if (v.empty()) return LRGE_OK;
-    std::sort(v.begin(), v.end());
+    // the reference sorts the whole vector (estimate.rs:90-95); only the (at most six) order statistics the three
+    // quantiles read are needed, and an order statistic does not depend on how ties are arranged: select them in
+    // ascending order, each inside the range the previous selection left unsorted
+    std::vector<size_t> need;
+    auto want = [&](float q) { const size_t i = quantile_index(v.size(), q); need.push_back(i); if (i + 1 < v.size()) need.push_back(i + 1); };
+    want(0.5f);
+    if (has_lower) want(lower_q);
+    if (has_upper) want(upper_q);
+    std::sort(need.begin(), need.end());
+    need.erase(std::unique(need.begin(), need.end()), need.end());
+    size_t from = 0;
+    for (size_t i : need) {
+        std::nth_element(v.begin() + from, v.begin() + i, v.end());
+        from = i + 1;
+    }
     ok[1] = quantile_f32(v, 0.5f, &out[1]);
     if (has_lower) ok[0] = quantile_f32(v, lower_q, &out[0]);
     if (has_upper) ok[2] = quantile_f32(v, upper_q, &out[2]);

@@ -174,6 +174,14 @@ int  lrge_hip_estimates(lrge_hip_ctx *ctx, const uint32_t *counts, const uint32_
 int  lrge_hip_median(const float *estimates, uint64_t n, int finite, int has_lower, float lower_q,
                      int has_upper, float upper_q, float out[3], int ok[3]);
 
+/* Optional hint, results unchanged: sketch `s` ahead of the overlap call that will stream it.  The request is picked up
+   by the NEXT lrge_hip_index_build on this context, which queues the set's sketch on a side stream right behind the
+   index's own sketch, so that this VALU-bound work runs beside the index's memory-bound sort and table passes (mm_map
+   sketches each query inside the call, mm2:map.c:mm_map_frag; here the set is known before the index exists).  The
+   next lrge_hip_overlap_* call that streams `s` against an index of the same preset consumes the result (once); any
+   other use simply sketches in line.  LRGE_HIP_NO_PRESKETCH=1 ignores the hint. */
+int  lrge_hip_seqset_presketch(lrge_hip_ctx *ctx, lrge_hip_seqset *s, int preset);
+
 /* Host only: the k distinct indices in [0, n) that liblrge's sub-sampling draws (lib.rs:189-204), in the order
    rand 0.9.4's index::sample returns them (split_into_hashsets, twoset.rs:632-652, takes the LAST target_num_reads
    of them as targets).  has_seed = 0 seeds the generator from OS entropy.  Restated in include/lrge_rand.hpp.

@@ -174,11 +174,13 @@ public:
         std::vector<uint32_t> counts(Q.lens.size()), has(Q.lens.size());
         uint32_t no_mapping = 0;
         if (use_min_ref && target_num_bases > query_num_bases) {
+            ctx.check(lrge_hip_seqset_presketch(ctx.h, T.h, preset));   // streamed set: sketched beside the index build
             detail::Index ix(ctx, Q, preset);
             ctx.check(lrge_hip_overlap_inverse(ctx.h, ix.h, T.h, &p, counts.data()));
             if (paf_sink) *paf_sink = paf_lines(ctx.h, ix.h, T.h, 1, tn, T.lens, qn, Q.lens);
             for (uint32_t c : counts) no_mapping += c == 0;                       // twoset.rs:545-569
         } else {
+            ctx.check(lrge_hip_seqset_presketch(ctx.h, Q.h, preset));
             detail::Index ix(ctx, T, preset);
             ctx.check(lrge_hip_overlap_twoset(ctx.h, ix.h, Q.h, &p, counts.data(), has.data()));
             if (paf_sink) *paf_sink = paf_lines(ctx.h, ix.h, Q.h, 1, qn, Q.lens, tn, T.lens);
@@ -253,7 +255,9 @@ public:
         auto ranks = detail::name_ranks({rn});
         detail::Ctx ctx(device);
         detail::SeqSet R(ctx, rs, ranks[0]);
-        detail::Index ix(ctx, R, platform == Platform::PacBio ? LRGE_PRESET_AVA_PB : LRGE_PRESET_AVA_ONT);
+        const int preset = platform == Platform::PacBio ? LRGE_PRESET_AVA_PB : LRGE_PRESET_AVA_ONT;
+        ctx.check(lrge_hip_seqset_presketch(ctx.h, R.h, preset));
+        detail::Index ix(ctx, R, preset);
         lrge_hip_params p{remove_internal ? 1 : 0, max_overhang_ratio};
         std::vector<uint32_t> counts(R.lens.size());
         ctx.check(lrge_hip_overlap_ava(ctx.h, ix.h, R.h, &p, counts.data()));

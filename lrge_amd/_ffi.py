@@ -20,7 +20,7 @@ C_NAMES = ["query_bases", "query_minimizers", "anchors", "groups", "groups_chain
 
 EXPORTS = [
     "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error",
-    "lrge_hip_seqset_upload", "lrge_hip_seqset_free", "lrge_hip_seqset_size",
+    "lrge_hip_seqset_upload", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch",
     "lrge_hip_index_build", "lrge_hip_index_free", "lrge_hip_index_stats",
     "lrge_hip_overlap_twoset", "lrge_hip_overlap_inverse", "lrge_hip_overlap_ava", "lrge_hip_chains",
     "lrge_hip_estimates", "lrge_hip_median", "lrge_hip_paf_stats",
@@ -70,6 +70,7 @@ def lib():
     L.lrge_hip_seqset_free.restype = None
     L.lrge_hip_seqset_size.argtypes = [vp]
     L.lrge_hip_seqset_size.restype = C.c_uint32
+    L.lrge_hip_seqset_presketch.argtypes = [vp, vp, C.c_int]
     L.lrge_hip_index_build.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
     L.lrge_hip_index_free.argtypes = [vp]
     L.lrge_hip_index_free.restype = None

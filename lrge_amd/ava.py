@@ -69,6 +69,7 @@ class AvaStrategy(Estimate):
             (ranks,) = engine.name_ranks(rn)
             R = ctx.upload(*readio.pack(rs), ranks)
             try:
+                R.presketch(preset)
                 ix = engine.Index(ctx, R, preset)
                 counts = ix.overlap_ava(self.remove_internal, self.max_overhang_ratio)
             except _ffi.LrgeHipError as e:

@@ -86,6 +86,7 @@ struct lrge_hip_ctx {
     u64 counters[LRGE_C_N];
     int n_cu = 256;
     bool lsort_ok[3] = {false, false, false};   // which k_seg_sort_local variants this device can launch
+    struct lrge_hip_seqset *presk_pending = nullptr; int presk_preset = -1;   // lrge_hip_seqset_presketch request
     // Small device->host reads (totals, censuses, per-read vectors).  hipMemcpyAsync into pageable memory is a blocking
     // staged copy, one round trip EACH; through this pinned area several reads queue up behind the kernels and cost
     // one round trip at the following d2h_sync(), which also moves the bytes to where the caller wants them.
@@ -115,8 +116,21 @@ struct lrge_hip_ctx {
     void resolve_timers();                   // call after the stream has been synchronised
 };
 
+struct Scratch;
+// A streamed read set sketched ahead of time on the side stream (lrge_hip_seqset_presketch): launched by the next
+// index build right behind its own sketch, so that this VALU-bound work runs beside the index's memory-bound sort and
+// table passes; consumed (once) by the next overlap call that streams the set against an index of the same preset.
+struct PreSketch {
+    int preset = -1;
+    u64 *x = nullptr, *y = nullptr;     // worst-case sized (one minimizer per base)
+    u32 *mz_off = nullptr, *d_total = nullptr;
+    Scratch *sc = nullptr;              // owns every allocation of the launch until the consumer is done with them
+    hipEvent_t ev_start = nullptr, ev_done = nullptr;
+};
+
 struct lrge_hip_seqset {
     lrge_hip_ctx *ctx;
+    PreSketch *presk = nullptr;
     u32 n = 0;
     u64 total_bases = 0;
     u64 n_words = 0;            // 32-base words in the packed image (reads start on a word)

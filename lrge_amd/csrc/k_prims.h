@@ -158,26 +158,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32 *in, u32 
     if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total = off;
 }
 
-// out may alias in.  d_total (device u32) receives the grand total (may be null).
-static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32 *out, u64 n, u32 *d_total) {
+// out may alias in.  d_total (device u32) receives the grand total (may be null).  `st`: stream (default ctx->stream);
+// `keep`: the block-sum scratch stays with `sc` instead of going back to the pool at once -- required when `st` is not
+// ctx->stream, because the pool recycles memory in the order of ctx->stream only.
+static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32 *out, u64 n, u32 *d_total, hipStream_t st = nullptr,
+                              bool keep = false) {
+    if (!st) st = ctx->stream;
     if (n == 0) {
-        if (d_total) HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, ctx->stream));
+        if (d_total) HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, st));
         return LRGE_OK;
     }
     u64 nb = div_up(n, SCAN_TILE);
     ALLOC_OR_FAIL(bs, sc, u32, nb + 1);
-    hipLaunchKernelGGL(k_scan_reduce, dim3((u32)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, n, bs);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((u32)nb), dim3(SCAN_THREADS), 0, st, in, n, bs);
     KCHK(ctx);
     if (nb <= 8192) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, bs, (u32)nb, (u32 *)nullptr);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, bs, (u32)nb, (u32 *)nullptr);
         KCHK(ctx);
     } else {
-        int rc = scan_exclusive_u32(ctx, sc, bs, bs, nb, nullptr);
+        int rc = scan_exclusive_u32(ctx, sc, bs, bs, nb, nullptr, st, keep);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_scan_apply, dim3((u32)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, bs, d_total);
+    hipLaunchKernelGGL(k_scan_apply, dim3((u32)nb), dim3(SCAN_THREADS), 0, st, in, out, n, bs, d_total);
     KCHK(ctx);
-    sc.drop(bs);
+    if (!keep) sc.drop(bs);
     return LRGE_OK;
 }
 

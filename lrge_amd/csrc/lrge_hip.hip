@@ -4,6 +4,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
+#include <set>
+#include <mutex>
 
 #include "internal.h"
 #include "k_prims.h"
@@ -17,6 +20,8 @@
 #include "../../include/lrge_rand.hpp"
 
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
+static std::mutex g_live_mu;
+static std::set<lrge_hip_ctx *> g_live_ctx;   // contexts that have not been destroyed
 
 extern "C" const char *lrge_hip_version(void) { return "lrge_hip 0.1.0 (gfx950)"; }
 
@@ -59,12 +64,14 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
     memset(ctx->counters, 0, sizeof(ctx->counters));
+    { std::lock_guard<std::mutex> g(g_live_mu); g_live_ctx.insert(ctx); }
     *out = ctx;
     return LRGE_OK;
 }
 
 extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
     if (!ctx) return;
+    { std::lock_guard<std::mutex> g(g_live_mu); g_live_ctx.erase(ctx); }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->resolve_timers();
@@ -179,8 +186,22 @@ extern "C" int lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, cons
     return LRGE_OK;
 }
 
+static void presketch_discard(lrge_hip_seqset *s) {
+    lrge_hip_ctx *ctx = s->ctx;
+    if (ctx->presk_pending == s) ctx->presk_pending = nullptr;
+    if (!s->presk) return;
+    (void)hipStreamSynchronize(ctx->stream2);          // its kernels may still be running
+    delete s->presk->sc;
+    ctx->event_pool.push_back(s->presk->ev_start); ctx->event_pool.push_back(s->presk->ev_done);
+    delete s->presk;
+    s->presk = nullptr;
+}
+
 extern "C" void lrge_hip_seqset_free(lrge_hip_seqset *s) {
     if (!s) return;
+    bool ctx_alive;
+    { std::lock_guard<std::mutex> g(g_live_mu); ctx_alive = g_live_ctx.count(s->ctx) != 0; }
+    if (ctx_alive) { (void)hipSetDevice(s->ctx->device); presketch_discard(s); }   // (a set that outlives its context only owns its own arrays)
     (void)hipFree(s->d_pack); (void)hipFree(s->d_nmask); (void)hipFree(s->d_woff); (void)hipFree(s->d_len); (void)hipFree(s->d_rank); (void)hipFree(s->d_cs);
     delete s;
 }
@@ -256,6 +277,79 @@ static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     return rc;
 }
 
+// ---- presketch: the streamed set's minimizers, computed on the side stream with no host round trip ----
+template <int K, int W, bool HPC>
+static int presketch_launch(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, PreSketch *p, hipStream_t st) {
+    if (s->n_chunks >= (1ULL << 32) || s->total_bases + 1 >= (1ULL << 32)) return LRGE_ERR_TOO_MANY;
+    Scratch &sc = *p->sc;
+    const u32 n_chunks = (u32)s->n_chunks;
+    ALLOC_OR_FAIL(d_cnt, sc, u32, (size_t)n_chunks + 1);
+    ALLOC_OR_FAIL(d_total, sc, u32, 1);
+    ALLOC_OR_FAIL(d_mzoff, sc, u32, (size_t)s->n + 1);
+    // the count is not known on the host when the write pass is queued: room for one minimizer per base
+    ALLOC_OR_FAIL(dx, sc, u64, (size_t)s->total_bases + 1);
+    ALLOC_OR_FAIL(dy, sc, u64, (size_t)s->total_bases + 1);
+    ChunkMap cm{s->d_cs, s->n};
+    if (n_chunks) {
+        hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0, st,
+                           s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, d_cnt, d_cnt, n_chunks, d_total, st, true);
+        if (rc) return rc;
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, st));
+    }
+    hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, st, s->d_cs, d_cnt, s->n, n_chunks, d_total,
+                       d_mzoff);
+    KCHK(ctx);
+    if (n_chunks) {
+        hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false, false>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0, st,
+                           s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, 0u, 0u);
+        KCHK(ctx);
+    }
+    p->x = dx; p->y = dy; p->mz_off = d_mzoff; p->d_total = d_total;
+    return LRGE_OK;
+}
+
+// Called by the index build right after its own sketch has been queued on ctx->stream.
+static int presketch_start_pending(lrge_hip_ctx *ctx) {
+    lrge_hip_seqset *s = ctx->presk_pending;
+    if (!s) return LRGE_OK;
+    ctx->presk_pending = nullptr;
+    if (s->presk) presketch_discard(s);
+    PreSketch *p = new PreSketch();
+    p->preset = ctx->presk_preset;
+    p->sc = new Scratch(ctx);
+    p->ev_start = ctx->get_event(); p->ev_done = ctx->get_event();
+    // behind the index sketch (both are VALU-bound; the point is to run beside the passes that follow it)
+    int rc = LRGE_OK;
+    hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+    if (e == hipSuccess) e = hipEventRecord(p->ev_start, ctx->stream2);
+    if (e == hipSuccess) {
+        rc = p->preset == LRGE_PRESET_AVA_PB ? presketch_launch<19, 5, true>(ctx, s, p, ctx->stream2)
+                                             : presketch_launch<15, 5, false>(ctx, s, p, ctx->stream2);
+        if (rc == LRGE_OK) e = hipEventRecord(p->ev_done, ctx->stream2);
+    }
+    if (e != hipSuccess || rc != LRGE_OK) {      // not fatal: the overlap call sketches the set itself
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipGetLastError();
+        delete p->sc;
+        ctx->event_pool.push_back(p->ev_start); ctx->event_pool.push_back(p->ev_done);
+        delete p;
+        return LRGE_OK;
+    }
+    s->presk = p;
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_seqset_presketch(lrge_hip_ctx *ctx, lrge_hip_seqset *s, int preset) {
+    if (!ctx || !s || s->ctx != ctx) return LRGE_ERR_INVALID;
+    if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
+    ctx->presk_pending = s; ctx->presk_preset = preset;
+    return LRGE_OK;
+}
+
 extern "C" int lrge_hip_sketch_dump(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, int preset, uint64_t *x, uint64_t *y,
                                     uint64_t cap, uint64_t *n_out) {
     if (!ctx || !s || !n_out) return LRGE_ERR_INVALID;
@@ -307,6 +401,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     const u32 pk_ybits = pk ? pk_rid + pk_pos1 : 0;
     SketchOut so;
     int rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits);
+    if (rc == LRGE_OK && !getenv("LRGE_HIP_NO_PRESKETCH")) rc = presketch_start_pending(ctx);
     if (rc) return rc;
     sc.drop(so.mz_off);
     const u64 M = so.n;
@@ -543,6 +638,7 @@ struct OverlapRun {
     unsigned long long *d_nchains = nullptr; lrge_hip_chain *d_chains = nullptr;
     // seeds: query minimizers, their index lookups, per-query anchor totals
     SketchOut so; std::vector<u32> h_mzoff, h_qtot; u64 Mq = 0; SeedParams sp;
+    std::unique_ptr<Scratch> presk_sc;   // memory of a consumed presketch (released with the run)
     u32 *hs = nullptr, *hc = nullptr, *hn = nullptr, *hv = nullptr, *krank = nullptr;
     // batch plan
     u64 batch_cap = 0; KeyLayout kl; u32 max_bits_q = 0, min_n = 0; BinLimits bl; ChainParams cp;
@@ -610,8 +706,26 @@ int OverlapRun::seeds() {
     const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
     (void)T; (void)P; (void)nq; (void)nt;
     // ---- 1. sketch the queries ----
-    int rc = sketch_device(ctx, sc, Q, ix->preset_id, false, &so, 0, 0, &h_mzoff);
-    if (rc) return rc;
+    int rc = LRGE_OK;
+    if (Q->presk && Q->presk->preset == ix->preset_id) {
+        // sketched ahead on the side stream (lrge_hip_seqset_presketch): wait for it on the device, fetch the count and
+        // the per-read offsets in the one round trip the in-line sketch pays too, and keep its memory until the call ends
+        PreSketch *p = Q->presk;
+        const_cast<lrge_hip_seqset *>(Q)->presk = nullptr;
+        presk_sc.reset(p->sc);
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, p->ev_done, 0));
+        u32 total = 0;
+        h_mzoff.resize((size_t)Q->n + 1);
+        HIPCHK(ctx, ctx->d2h(&total, p->d_total, 4, ctx->stream));
+        HIPCHK(ctx, ctx->d2h(h_mzoff.data(), p->mz_off, ((size_t)Q->n + 1) * 4, ctx->stream));
+        HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+        so.x = p->x; so.y = p->y; so.mz_off = p->mz_off; so.n = total;
+        ctx->timers.push_back(TimerRec{LRGE_T_SKETCH, p->ev_start, p->ev_done});   // both have completed; resolved with the call's timers
+        delete p;
+    } else {
+        rc = sketch_device(ctx, sc, Q, ix->preset_id, false, &so, 0, 0, &h_mzoff);
+        if (rc) return rc;
+    }
     Mq = so.n;
     ctx->counters[LRGE_C_QUERY_MINIMIZERS] = Mq;
     if (Mq >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "query set limited to < 2^32 minimizers"); return LRGE_ERR_TOO_MANY; }

@@ -119,6 +119,11 @@ class SeqSet:
         except Exception:
             pass
 
+    def presketch(self, preset):
+        """Hint (results unchanged): the next Index() built on this context sketches this set on a side stream beside its
+        own sort and table passes; the next overlap call that streams the set uses it (lrge_hip_seqset_presketch)."""
+        self.ctx._check(self.ctx._lib.lrge_hip_seqset_presketch(self.ctx.h, self.h, preset))
+
     def sketch(self, preset):
         n = C.c_uint64()
         self.ctx._check(self.ctx._lib.lrge_hip_sketch_dump(self.ctx.h, self.h, preset, None, None, 0, C.byref(n)))

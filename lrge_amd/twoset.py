@@ -113,11 +113,13 @@ class TwoSetStrategy(Estimate):
             T = ctx.upload(*readio.pack(ts), tr)
             try:
                 if self.use_min_ref and self.target_num_bases > self.query_num_bases:
+                    T.presketch(preset)                                   # streamed set: sketched beside the index build
                     ix = engine.Index(ctx, Q, preset)                     # index = query set
                     counts = ix.overlap_inverse(T, self.remove_internal, self.max_overhang_ratio)
                     no_mapping = int((counts == 0).sum())                 # twoset.rs:545-569
                     lens = Q.lens
                 else:
+                    Q.presketch(preset)
                     ix = engine.Index(ctx, T, preset)
                     counts, has = ix.overlap_twoset(Q, self.remove_internal, self.max_overhang_ratio)
                     no_mapping = int((has == 0).sum())                    # twoset.rs:303-309

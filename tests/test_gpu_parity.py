@@ -535,3 +535,57 @@ def test_ultra_long_reads(ctx, oracle, preset):
     rc, eava = ixoa.ava_counts(threads=8)
     assert np.array_equal(ixa.overlap_ava(), eava)
     ixa.free()
+
+
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_presketch_is_invisible(ctx, oracle, tiny_ont, tiny_hifi, preset, monkeypatch):
+    """lrge_hip_seqset_presketch is a scheduling hint: the streamed set is sketched on the side stream during the
+    index build and consumed by the next overlap call.  Same minimizers, hence the same counts / chains -- also when
+    the hint goes unused (another preset, a second call, a set freed with the result pending) or is switched off."""
+    from lrge_amd import engine
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Qd, Td = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
+    ix0 = engine.Index(ctx, Td, PRESETS[preset])
+    ref_counts, ref_has = ix0.overlap_twoset(Qd)
+    ref_chains = _chain_rows(ix0.chains(Qd, dual=True), ["query", "target", "rev", "score", "cnt", "qs", "qe", "rs", "re"])
+    ix0.free()
+    assert int(ref_counts.sum()) > 0
+    for variant in ("used", "twice", "other-preset", "off", "ava"):
+        if variant == "off":
+            monkeypatch.setenv("LRGE_HIP_NO_PRESKETCH", "1")
+        if variant == "ava":
+            Td.presketch(PRESETS[preset])                      # the indexed set itself is the streamed set
+            ix = engine.Index(ctx, Td, PRESETS[preset])
+            a = ix.overlap_ava()
+            ix.free()
+            ix = engine.Index(ctx, Td, PRESETS[preset])
+            assert np.array_equal(a, ix.overlap_ava())
+            ix.free()
+            continue
+        Qd.presketch(PRESETS["pb" if preset == "ont" else "ont"] if variant == "other-preset" else PRESETS[preset])
+        ix = engine.Index(ctx, Td, PRESETS[preset])
+        counts, has = ix.overlap_twoset(Qd)
+        assert np.array_equal(counts, ref_counts) and np.array_equal(has, ref_has), variant
+        if variant == "twice":                                  # consumed by the first call; the next ones sketch in line
+            counts, has = ix.overlap_twoset(Qd)
+            assert np.array_equal(counts, ref_counts)
+        got = _chain_rows(ix.chains(Qd, dual=True), ["query", "target", "rev", "score", "cnt", "qs", "qe", "rs", "re"])
+        assert np.array_equal(got, ref_chains), variant
+        ix.free()
+    monkeypatch.delenv("LRGE_HIP_NO_PRESKETCH", raising=False)
+    # a pending result that nobody consumes: freed with its set
+    Q2 = ctx.upload(ds.q.bases, ds.q.offsets, qr)
+    Q2.presketch(PRESETS[preset])
+    ix = engine.Index(ctx, Td, PRESETS[preset])
+    Q2.free()
+    counts, has = ix.overlap_twoset(Qd)
+    assert np.array_equal(counts, ref_counts)
+    ix.free()
+    # a request that no index build picks up before its set is freed
+    Q3 = ctx.upload(ds.q.bases, ds.q.offsets, qr)
+    Q3.presketch(PRESETS[preset])
+    Q3.free()
+    ix = engine.Index(ctx, Td, PRESETS[preset])
+    assert np.array_equal(ix.overlap_twoset(Qd)[0], ref_counts)
+    ix.free()

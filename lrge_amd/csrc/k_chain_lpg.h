@@ -51,7 +51,13 @@ struct LpgChainArgs {
 // PENTAB: with chain_skip_scale == 0 (every preset lrge uses) comput_sc's penalty depends on dd alone --
 // (i32)(pen_gap * dd + .5 * mg_log2(dd + 1)), and 0 for dd == 0 -- so it is tabulated once per wavefront in
 // LDS ([0, bw] + one "out of band" entry) with the very same f32 operations, and a candidate needs no f32 math.
-template <bool PENTAB>
+// FASTREACH (max_iter >= 64, i.e. always outside the tests): the number of window candidates in reach is not counted.
+// x is sorted, so all 32 are in reach iff the oldest one is, which is all the "continue behind the window" test needs;
+// and when the loop did not break, the exact end of the scanned range only feeds `mi < end_j`, which is false then:
+// at that point mi is in x-reach (the rescan above just made it so), every anchor in x-reach sits in the window in front
+// of end_j unless the window is exhausted, and an exhausted window with more candidates behind it takes the slow path,
+// which computes end_j itself.  Saves a compare, a select and an add per candidate and 32 live compare masks.
+template <bool PENTAB, bool FASTREACH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
     extern __shared__ i32 pen_tab[];   // [bw + 2] when PENTAB, then the anchor / record staging ring (LPG_RING_BYTES)
     // this kernel's longest wavefronts are the critical path of the chain stage; k_chain_hw's wavefronts on
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     i32 s = (spj < DG[b] ? spj : DG[b]) - PEN[b] + WF[k];
                     s = (u32)(dq - 1) < dqlim ? s : SC_NONE;
                     s = (u32)(dr - 1) < (u32)maxdx ? s : SC_NONE;      // 1 <= dr <= max_dist_x: in reach and dr != 0
-                    n_reach += dr <= maxdx ? 1 : 0;
+                    if (!FASTREACH) n_reach += dr <= maxdx ? 1 : 0;
                     S[b] = s;
                 }
             } else {
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     s = dd <= (u32)bw ? s : SC_NONE;
                     s = (u32)(dq - 1) < dqlim ? s : SC_NONE;
                     s = (u32)(dr - 1) < (u32)maxdx ? s : SC_NONE;
-                    n_reach += dr <= maxdx ? 1 : 0;
+                    if (!FASTREACH) n_reach += dr <= maxdx ? 1 : 0;
                     S[b] = s;
                 }
             }
@@ -221,8 +227,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // end of the loop: a break, the window start (x out of reach / max_iter), or more candidates behind the window
         const bool broke = end_b >= 0;
         n_reach = n_reach < kcap ? n_reach : kcap;               // empty slots may have counted as "in reach"
-        i32 end_j = broke ? end_b : i - 1 - n_reach;
-        const bool cont = alive && !broke && more && n_reach == LPG_W;
+        i32 end_j = broke ? end_b : (FASTREACH ? -1 : i - 1 - n_reach);
+        const bool cont = alive && !broke && more && (FASTREACH ? xi - WX[LPG_W - 1] <= maxdx : n_reach == LPG_W);   // (more: i > 32, the window is full)
         if (__ballot(cont)) {
             // rare: a lane's loop runs past its 32-anchor window; continue that lane's loop through HBM
             slow_iters += cont ? LPG_W : 0;

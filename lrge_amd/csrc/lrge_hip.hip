@@ -594,8 +594,8 @@ struct OverlapJob {
 
 // Split of the size-sorted group list between the two chain kernels, from the size census of k_group_count (hn / ha:
 // groups and anchors per class of GSZ_W anchors).  Groups above T anchors -> k_chain_hw (~0.55 us per anchor of latency,
-// ~93 VALU instructions per anchor), the rest -> k_chain_lpg (~4.3 us per anchor of the LONGEST group of a wavefront,
-// ~22 VALU per anchor).  Both run side by side; the stage takes about
+// ~93 VALU instructions per anchor), the rest -> k_chain_lpg (~4.1 us per anchor of the LONGEST group of a wavefront,
+// ~21 VALU per anchor).  Both run side by side; the stage takes about
 //   max(T * t_lpg, n_longest * t_hw, VALU work / issue rate of the chip)
 // and T (a multiple of GSZ_W) minimises that estimate -- measured constants of this kernel pair on MI355X.
 // `fixed` != LPG_MAX_AUTO pins T (LRGE_HIP_LPG_MAX / LRGE_HIP_CHAIN=hw|lpg).
@@ -604,7 +604,7 @@ static ChainSplit choose_chain_split(const u32 *hn, const unsigned long long *ha
     ChainSplit r; r.T = fixed; r.n_big = 0; r.a_big = 0; r.top = -1;
     for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) r.top = b;
     if (fixed == LPG_MAX_AUTO) {
-        const double t_lpg = 4.3e-6, t_hw = 0.55e-6, c_lpg = 22.0, c_hw = 93.0;
+        const double t_lpg = 4.1e-6, t_hw = 0.55e-6, c_lpg = 21.0, c_hw = 93.0;
         const double rate = 0.8 * (double)n_cu * 4 * 2.1e9 / 4.0;   // wave64 VALU instructions per second, ~80 % reachable
         double best = 1e30, a_le = 0;    // a_le: anchors in classes <= b
         r.T = 0;
@@ -1234,9 +1234,14 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                     HIPCHK(ctx, hipMemsetAsync(la.redo_count, 0, 4, both ? ctx->stream2 : ctx->stream));
                     StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
                     const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !getenv("LRGE_HIP_LPG_NOTAB");
-                    if (pentab) hipLaunchKernelGGL(k_chain_lpg<true>, dim3((la.n_list + 63) / 64), dim3(64), (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES,
-                                                   both ? ctx->stream2 : ctx->stream, la, cp, go);
-                    else hipLaunchKernelGGL(k_chain_lpg<false>, dim3((la.n_list + 63) / 64), dim3(64), LPG_RING_BYTES, both ? ctx->stream2 : ctx->stream, la, cp, go);
+                    const bool fastreach = cp.max_iter >= 64 && !getenv("LRGE_HIP_LPG_EXACT_REACH");
+                    const dim3 lgrid((la.n_list + 63) / 64);
+                    const size_t lds_tab = (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES;
+                    hipStream_t lst = both ? ctx->stream2 : ctx->stream;
+                    if (pentab && fastreach) hipLaunchKernelGGL((k_chain_lpg<true, true>), lgrid, dim3(64), lds_tab, lst, la, cp, go);
+                    else if (pentab) hipLaunchKernelGGL((k_chain_lpg<true, false>), lgrid, dim3(64), lds_tab, lst, la, cp, go);
+                    else if (fastreach) hipLaunchKernelGGL((k_chain_lpg<false, true>), lgrid, dim3(64), LPG_RING_BYTES, lst, la, cp, go);
+                    else hipLaunchKernelGGL((k_chain_lpg<false, false>), lgrid, dim3(64), LPG_RING_BYTES, lst, la, cp, go);
                     KCHK(ctx);
                     tl.stop();
                     ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;

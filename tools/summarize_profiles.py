@@ -61,7 +61,7 @@ out = {
     "fetch_correction_note": "x2 is calibrated for wide coalesced streaming reads (k_rs_hist). k_chain_lpg reads 16 B per lane from 64 "
                              "different lines per instruction; for that pattern the factor is uncalibrated, so its corrected figure is an "
                              "upper bound (raw FETCH_SIZE + WRITE_SIZE: see *_pmc_fetch.csv / *_pmc_write.csv)",
-    "k_chain_lpg_hbm_bytes_per_launch": per_launch("k_chain_lpg<true>"),
+    "k_chain_lpg_hbm_bytes_per_launch": per_launch(next((k for k in fetch if k.startswith("k_chain_lpg<")), "k_chain_lpg")),
     "k_chain_hw_hbm_bytes_per_launch": per_launch("k_chain_hw"),
     "k_rs_scatter_hbm_bytes_per_launch": None,
 }
@@ -88,7 +88,7 @@ out["calibration"] = {"k_rs_hist_false_largest_launch_FETCH_SIZE_KiB": big,
                       "note": "that launch reads 8 B x (index minimizers); FETCH_SIZE reports half of it on gfx950 (128-B requests tallied at 64 B)"}
 # VALU issue of the chain stage (SQ pass): wave64 VALU instructions per launch; each occupies its SIMD for 4 cycles
 sq = agg(os.path.join(G, tag + "_sq", "q_counter_collection.csv"))
-for kern, key in (("k_chain_lpg<true>", "k_chain_lpg"), ("k_chain_hw", "k_chain_hw")):
+for kern, key in ((next((k for k in sq if k.startswith("k_chain_lpg<")), "k_chain_lpg"), "k_chain_lpg"), ("k_chain_hw", "k_chain_hw")):
     v = sq.get(kern, {}).get("SQ_INSTS_VALU")
     out[key + "_valu_insts_per_launch"] = v[1] / v[0] if v else None
 a, b = out["k_chain_lpg_hbm_bytes_per_launch"], out["k_chain_hw_hbm_bytes_per_launch"]

@@ -3,6 +3,7 @@
 // computes fails with LRGE_ERR_DEVICE when no HIP device is usable.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdlib>
 #include <memory>
 #include <set>
@@ -33,6 +34,48 @@ extern "C" int lrge_hip_device_count(int *n) {
     return LRGE_OK;
 }
 
+// The two streams of a context must not share a hardware queue: the chain kernels (and the presketch, the largest
+// LDS sort class, the query-occurrence check) run side by side on them, and streams that the runtime multiplexes onto
+// one queue serialise.  That happens in processes that own other streams -- measured under torch.distributed + RCCL:
+// chain stage 2.3 -> 4.1 ms -- and neither a stream priority nor a creation order guarantees otherwise.  So the side
+// stream is chosen by measurement: two ~40 us spin kernels, one per stream, must finish in clearly less than the sum.
+__global__ void k_spin_ticks(long long ticks, u32 *sink) {
+    const long long t0 = wall_clock64();               // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) { }
+    if (sink && threadIdx.x == 1024) *sink = 1;         // (never true: keeps the loop observable)
+}
+static hipError_t pick_side_stream(lrge_hip_ctx *ctx) {
+    ctx->stream2 = nullptr;
+    if (getenv("LRGE_HIP_NO_STREAM_PROBE")) return hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    const long long ticks = 4000;                        // 40 us
+    auto run_pair = [&](hipStream_t a, hipStream_t b) -> double {
+        (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b);
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_spin_ticks, dim3(1), dim3(64), 0, a, ticks, (u32 *)nullptr);
+        if (b) hipLaunchKernelGGL(k_spin_ticks, dim3(1), dim3(64), 0, b, ticks, (u32 *)nullptr);
+        (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b);
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    };
+    (void)run_pair(ctx->stream, nullptr);                // warm-up: code object load, first launch
+    double single = 1e30;
+    for (int i = 0; i < 3; ++i) single = std::min(single, run_pair(ctx->stream, nullptr));
+    std::vector<hipStream_t> rejected;
+    hipError_t err = hipSuccess;
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        hipStream_t cand = nullptr;
+        if ((err = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking)) != hipSuccess) break;
+        (void)run_pair(ctx->stream, cand);
+        double both = 1e30;
+        for (int i = 0; i < 3; ++i) both = std::min(both, run_pair(ctx->stream, cand));
+        if (both < 1.5 * single || attempt == 11) { ctx->stream2 = cand; break; }   // concurrent (or nothing better to be had)
+        rejected.push_back(cand);                          // kept alive until the choice is made: it holds its queue slot
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    (void)hipGetLastError();
+    if (!ctx->stream2 && err == hipSuccess) err = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    return err;
+}
+
 extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     *out = nullptr;
     int c = 0;
@@ -43,7 +86,7 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     lrge_hip_ctx *ctx = new lrge_hip_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        pick_side_stream(ctx) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         g_last_error = "hipSetDevice/hipStreamCreate failed";

@@ -262,22 +262,17 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_count(const u64 *__restri
 
 // PK (index only): one packed u64 per minimizer, hash << (pk_rid_bits + pk_pos1) | rid << pk_pos1 | (pos << 1 | strand),
 // written to out_x; out_y is not touched.  8 bytes per index entry instead of 16 through the sort and the lookups.
+//
+// Writes chunk c's minimizers to out[o0 ...) and returns how many it found; only the first `cap` are stored.
+// A lane's minimizers are consecutive in the output, but it produces one every ~3 steps: written one by
+// one, every 32-byte sector reaches HBM as four partial writes (measured 4x the bytes).  The last <= 4 are
+// kept in registers and leave as one sector-aligned 32-byte run per array whenever the output index
+// reaches a multiple of 4; only the head and the tail of the lane's range are written singly.
 template <int K, int W, bool HPC, bool INDEX_KEYS, bool PK>
-__global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
-                                                            const u64 *__restrict__ woff, const u32 *__restrict__ lens,
-                                                            ChunkMap cm, u32 n_chunks, const u32 *__restrict__ offs,
-                                                            u64 *__restrict__ out_x, u64 *__restrict__ out_y, u32 pk_pos1, u32 pk_ybits) {
-    u32 c = blockIdx.x * SK_THREADS + threadIdx.x;
-    if (c >= n_chunks) return;
-    u32 r = cm.find(c);
-    i32 len = (i32)lens[r];
-    i32 s = (i32)(c - cm.chunk_start[r]) * SK_CHUNK;
-    i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
-    u32 o = offs[c];
-    // A lane's minimizers are consecutive in the output, but it produces one every ~3 steps: written one by
-    // one, every 32-byte sector reaches HBM as four partial writes (measured 4x the bytes).  The last <= 4 are
-    // kept in registers and leave as one sector-aligned 32-byte run per array whenever the output index
-    // reaches a multiple of 4; only the head and the tail of the lane's range are written singly.
+__device__ __forceinline__ u32 sketch_write_chunk(const u64 *__restrict__ pack, const u32 *__restrict__ nmask, u64 word_base, i32 len, u32 r,
+                                                  i32 s, i32 e, u32 o0, u32 cap, u64 *__restrict__ out_x, u64 *__restrict__ out_y,
+                                                  u32 pk_pos1, u32 pk_ybits) {
+    u32 o = o0, found = 0;
     u64 bx0 = 0, bx1 = 0, bx2 = 0, bx3 = 0, by0 = 0, by1 = 0, by2 = 0, by3 = 0;
     u32 nb = 0;   // buffered entries: output indices [o - nb, o), newest in b?3
     auto flush_tail = [&]() {
@@ -286,7 +281,8 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restri
         if (nb >= 1) { out_x[o - 1] = bx3; if (!PK) out_y[o - 1] = by3; }
         nb = 0;
     };
-    sketch_chunk<K, W, HPC>(pack, nmask, woff[r], len, r, s, e, [&](u64 x, u64 y) {
+    sketch_chunk<K, W, HPC>(pack, nmask, word_base, len, r, s, e, [&](u64 x, u64 y) {
+        if (found++ >= cap) return;                     // counted, not stored (the caller notices found > cap)
         bx0 = bx1; bx1 = bx2; bx2 = bx3;
         if (PK) bx3 = (x >> 8) << pk_ybits | (y >> 32) << pk_pos1 | (u64)(u32)y;
         else bx3 = INDEX_KEYS ? (x >> 8) : x;  // the index keeps only the hash, queries keep hash<<8|span
@@ -306,6 +302,77 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restri
         }
     });
     flush_tail();
+    return found;
+}
+
+// second pass of the two-pass form: offsets from the scanned counts of k_sketch_count
+template <int K, int W, bool HPC, bool INDEX_KEYS, bool PK>
+__global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
+                                                            const u64 *__restrict__ woff, const u32 *__restrict__ lens,
+                                                            ChunkMap cm, u32 n_chunks, const u32 *__restrict__ offs,
+                                                            u64 *__restrict__ out_x, u64 *__restrict__ out_y, u32 pk_pos1, u32 pk_ybits) {
+    u32 c = blockIdx.x * SK_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    u32 r = cm.find(c);
+    i32 len = (i32)lens[r];
+    i32 s = (i32)(c - cm.chunk_start[r]) * SK_CHUNK;
+    i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
+    (void)sketch_write_chunk<K, W, HPC, INDEX_KEYS, PK>(pack, nmask, woff[r], len, r, s, e, offs[c], 0xFFFFFFFFu, out_x, out_y, pk_pos1, pk_ybits);
+}
+
+// One-pass form: every chunk writes into its own slot of SK_CAP entries (tmp[c * SK_CAP ...)) and reports its count;
+// k_sketch_compact then closes the gaps.  The state machine -- the hash, the window -- runs once per base instead of
+// twice (count pass + write pass), at the price of one extra streaming copy of the minimizers.  A chunk with more than
+// SK_CAP minimizers (possible in principle: a step can emit up to w of them) raises *overflow and the caller falls
+// back to the two-pass form.
+#define SK_CAP (SK_CHUNK + 8)
+template <int K, int W, bool HPC, bool INDEX_KEYS, bool PK>
+__global__ __launch_bounds__(SK_THREADS) void k_sketch_direct(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
+                                                             const u64 *__restrict__ woff, const u32 *__restrict__ lens,
+                                                             ChunkMap cm, u32 n_chunks, u32 *__restrict__ counts, u32 *__restrict__ overflow,
+                                                             u64 *__restrict__ tmp_x, u64 *__restrict__ tmp_y, u32 pk_pos1, u32 pk_ybits,
+                                                             u32 cap /* <= SK_CAP; smaller only in tests */) {
+    u32 c = blockIdx.x * SK_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    u32 r = cm.find(c);
+    i32 len = (i32)lens[r];
+    i32 s = (i32)(c - cm.chunk_start[r]) * SK_CHUNK;
+    i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
+    const u64 base = (u64)c * SK_CAP;
+    const u32 found = sketch_write_chunk<K, W, HPC, INDEX_KEYS, PK>(pack, nmask, woff[r], len, r, s, e, 0u, cap, tmp_x + base,
+                                                                    PK ? tmp_y : tmp_y + base, pk_pos1, pk_ybits);
+    counts[c] = found;
+    if (found > cap) *overflow = 1u;
+}
+
+// One wavefront per 64 consecutive chunks: their minimizers form one contiguous output range, which the lanes walk 64
+// entries at a time (the chunk of an entry by a 6-step search through the 64 scanned counts), so the writes are
+// consecutive across the wave and the reads touch the fronts of two or three slots.
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void k_sketch_compact(const u64 *__restrict__ tmp_x, const u64 *__restrict__ tmp_y,
+                                                        const u32 *__restrict__ offs, const u32 *__restrict__ d_total, u32 n_chunks,
+                                                        u64 *__restrict__ out_x, u64 *__restrict__ out_y) {
+    __shared__ u32 so[4][65];
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 c0 = (blockIdx.x * 4 + w) * 64;
+    const u32 c = c0 + lane;
+    if (c0 < n_chunks) {
+        so[w][lane] = c < n_chunks ? offs[c] : *d_total;
+        if (lane == 63) so[w][64] = c0 + 64 < n_chunks ? offs[c0 + 64] : *d_total;
+    }
+    __syncthreads();
+    if (c0 >= n_chunks) return;
+    const u32 lo = so[w][0], hi = so[w][64];
+    for (u32 o = lo + lane; o < hi; o += 64) {
+        u32 j = 0;                                       // last chunk with offs <= o
+#pragma unroll
+        for (int st = 32; st > 0; st >>= 1) if (so[w][j + st] <= o) j += st;
+        const u32 within = o - so[w][j];
+        if (within >= SK_CAP) continue;                  // a chunk that overflowed its slot (the caller discards this output)
+        const u64 src = (u64)(c0 + j) * SK_CAP + within;
+        out_x[o] = tmp_x[src];
+        if (PAIRS) out_y[o] = tmp_y[src];
+    }
 }
 
 // per-read minimizer offsets from per-chunk offsets: mz_off[r] = offs[chunk_start[r]]

@@ -266,42 +266,78 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
     u32 n_chunks = (u32)s->n_chunks;
     const u32 *d_cs = s->d_cs;           // chunk map, uploaded with the set
+    const bool pk = index_keys && pk_ybits;
     ALLOC_OR_FAIL(d_cnt, sc, u32, (size_t)n_chunks + 1);
-    ALLOC_OR_FAIL(d_total, sc, u32, 1);
+    ALLOC_OR_FAIL(d_total, sc, u32, 2);  // [1] = overflow flag of the one-pass form
     ALLOC_OR_FAIL(d_mzoff, sc, u32, (size_t)s->n + 1);
     ChunkMap cm{d_cs, s->n};
-    u32 total = 0;
-    if (n_chunks) {
-        hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0, ctx->stream,
-                           s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt);
+    const dim3 sgrid((u32)div_up(n_chunks, SK_THREADS));
+    // One pass (k_sketch_direct into per-chunk slots, then k_sketch_compact) when the slots fit comfortably; the
+    // two-pass form (count, scan, write) otherwise, when a chunk overflows its slot, or on request.
+    const u64 slot_bytes = (u64)n_chunks * SK_CAP * 8 * (pk ? 1 : 2);
+    size_t mfree = (size_t)64 << 30, mtot = 0;
+    if (slot_bytes > ((u64)4 << 30)) (void)hipMemGetInfo(&mfree, &mtot);       // (small sets: no need to ask)
+    bool one_pass = n_chunks && !getenv("LRGE_HIP_SKETCH_TWO_PASS") && slot_bytes < ((u64)mfree + ctx->pool.total) / 4;
+    const char *cap_env = getenv("LRGE_HIP_DEBUG_SK_CAP");                      // tests: force the overflow fallback
+    const u32 sk_cap = cap_env ? (u32)std::min<u64>(strtoull(cap_env, nullptr, 10), SK_CAP) : (u32)SK_CAP;
+    u64 *tx = nullptr, *ty = nullptr;
+    if (one_pass) {
+        tx = sc.get<u64>((size_t)n_chunks * SK_CAP);
+        ty = pk ? nullptr : sc.get<u64>((size_t)n_chunks * SK_CAP);
+        if (!tx || (!pk && !ty)) { if (tx) sc.drop(tx); if (ty) sc.drop(ty); tx = ty = nullptr; one_pass = false; (void)hipGetLastError(); }
+    }
+    u32 tot_ovf[2] = {0, 0};
+    for (int pass = 0; pass < 2; ++pass) {       // second round only after a slot overflow
+        HIPCHK(ctx, hipMemsetAsync(d_total, 0, 8, ctx->stream));
+        if (n_chunks) {
+            if (one_pass) {
+                if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
+                                           s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap);
+                else if (index_keys) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
+                                                        s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap);
+                else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, false, false>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
+                                        s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap);
+            } else {
+                hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm,
+                                   n_chunks, d_cnt);
+            }
+            KCHK(ctx);
+            int rc = scan_exclusive_u32(ctx, sc, d_cnt, d_cnt, n_chunks, d_total);
+            if (rc) return rc;
+        }
+        // per-read offsets follow from the chunk scan alone: they travel to the host with the total, in the one sync
+        hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, ctx->stream, d_cs, d_cnt, s->n,
+                           n_chunks, d_total, d_mzoff);
         KCHK(ctx);
-        int rc = scan_exclusive_u32(ctx, sc, d_cnt, d_cnt, n_chunks, d_total);
-        if (rc) return rc;
-    } else {
-        HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, ctx->stream));
+        HIPCHK(ctx, ctx->d2h(tot_ovf, d_total, 8, ctx->stream));
+        if (h_mzoff) {
+            h_mzoff->resize((size_t)s->n + 1);
+            HIPCHK(ctx, ctx->d2h(h_mzoff->data(), d_mzoff, ((size_t)s->n + 1) * 4, ctx->stream));
+        }
+        HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+        if (!(one_pass && tot_ovf[1])) break;
+        one_pass = false;                        // a chunk held more than SK_CAP minimizers: redo in two passes
+        sc.drop(tx); if (ty) sc.drop(ty); tx = ty = nullptr;
     }
-    // per-read offsets follow from the chunk scan alone: they travel to the host with the total, in the one sync
-    hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, ctx->stream, d_cs, d_cnt, s->n,
-                       n_chunks, d_total, d_mzoff);
-    KCHK(ctx);
-    HIPCHK(ctx, ctx->d2h(&total, d_total, 4, ctx->stream));
-    if (h_mzoff) {
-        h_mzoff->resize((size_t)s->n + 1);
-        HIPCHK(ctx, ctx->d2h(h_mzoff->data(), d_mzoff, ((size_t)s->n + 1) * 4, ctx->stream));
-    }
-    HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+    const u32 total = tot_ovf[0];
     ALLOC_OR_FAIL(dx, sc, u64, (size_t)total + 1);
     u64 *dy = nullptr;
-    if (!(index_keys && pk_ybits)) { dy = sc.get<u64>((size_t)total + 1); if (!dy) return LRGE_ERR_DEVICE; }
-    if (n_chunks) {
-        if (index_keys && pk_ybits)
-            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, true>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0,
+    if (!pk) { dy = sc.get<u64>((size_t)total + 1); if (!dy) return LRGE_ERR_DEVICE; }
+    if (n_chunks && one_pass) {
+        const dim3 cgrid((u32)div_up(div_up(n_chunks, 64), 4));
+        if (pk) hipLaunchKernelGGL(k_sketch_compact<false>, cgrid, dim3(256), 0, ctx->stream, tx, ty, d_cnt, d_total, n_chunks, dx, dy);
+        else hipLaunchKernelGGL(k_sketch_compact<true>, cgrid, dim3(256), 0, ctx->stream, tx, ty, d_cnt, d_total, n_chunks, dx, dy);
+        KCHK(ctx);
+        sc.drop(tx); if (ty) sc.drop(ty);
+    } else if (n_chunks) {
+        if (pk)
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, true>), sgrid, dim3(SK_THREADS), 0,
                                ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, pk_pos1, pk_ybits);
         else if (index_keys)
-            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, false>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0,
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, false>), sgrid, dim3(SK_THREADS), 0,
                                ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, 0u, 0u);
         else
-            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false, false>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0,
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false, false>), sgrid, dim3(SK_THREADS), 0,
                                ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, 0u, 0u);
         KCHK(ctx);
     }
@@ -333,9 +369,12 @@ static int presketch_launch(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, PreSket
     ALLOC_OR_FAIL(dx, sc, u64, (size_t)s->total_bases + 1);
     ALLOC_OR_FAIL(dy, sc, u64, (size_t)s->total_bases + 1);
     ChunkMap cm{s->d_cs, s->n};
+    const dim3 sgrid((u32)div_up(n_chunks, SK_THREADS));
+    // Two passes here, not the one-pass form of sketch_launch: this runs beside the index's memory-bound sort passes, and
+    // a second VALU-bound pass overlaps with them where the one-pass form's streaming compaction competes (measured:
+    // the sort loses what the sketch gains).
     if (n_chunks) {
-        hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0, st,
-                           s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt);
+        hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), sgrid, dim3(SK_THREADS), 0, st, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, d_cnt, d_cnt, n_chunks, d_total, st, true);
         if (rc) return rc;
@@ -346,8 +385,8 @@ static int presketch_launch(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, PreSket
                        d_mzoff);
     KCHK(ctx);
     if (n_chunks) {
-        hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false, false>), dim3((u32)div_up(n_chunks, SK_THREADS)), dim3(SK_THREADS), 0, st,
-                           s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, 0u, 0u);
+        hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false, false>), sgrid, dim3(SK_THREADS), 0, st, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm,
+                           n_chunks, d_cnt, dx, dy, 0u, 0u);
         KCHK(ctx);
     }
     p->x = dx; p->y = dy; p->mz_off = d_mzoff; p->d_total = d_total;

@@ -27,8 +27,15 @@ def _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset, dual=True):
     return Qd, Td, ixd, Qo, To, ixo
 
 
+@pytest.mark.parametrize("form", ["one-pass", "two-pass", "overflow-fallback"])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
-def test_sketch_parity(ctx, oracle, edge_set, preset):
+def test_sketch_parity(ctx, oracle, edge_set, preset, form, monkeypatch):
+    # one-pass (per-chunk slots + compaction, the default), the two-pass form (count, scan, write), and the fallback from
+    # the first to the second when a chunk overflows its slot (forced here by a tiny slot capacity)
+    if form == "two-pass":
+        monkeypatch.setenv("LRGE_HIP_SKETCH_TWO_PASS", "1")
+    elif form == "overflow-fallback":
+        monkeypatch.setenv("LRGE_HIP_DEBUG_SK_CAP", "9")
     qseqs, qnames, tseqs, tnames = edge_set
     seqs = tseqs + [b"", b"A", b"ACGTTGCA" * 3]            # empty and tiny reads keep their rid
     S = _upload(ctx, seqs)

@@ -148,6 +148,11 @@ def main():
         for k, v in cn.items(): acc_cn[k] = v if k == "lpg_split" else acc_cn.get(k, 0) + v
     sync_all()
     elapsed = time.perf_counter() - t0
+    # one instrumented step AFTER the timed region: an event pair around every k_rs_scatter launch (timer level 2 costs
+    # ~2 % of a step in host work between launches, so the timed steps run at the default level)
+    ctx.set_timer_level(2)
+    _, _, _, tb2, tm2, cn2, _ = step()
+    ctx.set_timer_level(1)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -190,8 +195,10 @@ def main():
                          16.0 * acc_cn.get("chain_anchors", 0), "k_chain_%s_hbm_bytes_per_launch" % (mode or "hw"))
         r_stage = roof("chain stage: k_chain_hw beside k_chain_lpg (fork..join)", acc_tm.get("chain", 0.0),
                        acc_cn.get("batches", 0), 16.0 * acc_cn.get("chain_anchors", 0), "chain_stage_hbm_bytes_per_step")
-        r_sc = roof("k_rs_scatter", acc_tm.get("rs_scatter", 0.0) + acc_tb.get("rs_scatter", 0.0), acc_cn.get("rs_scatter_launches", 0),
-                    float(acc_cn.get("rs_scatter_bytes", 0)), "k_rs_scatter_hbm_bytes_per_launch")
+        r_sc = roof("k_rs_scatter", tm2.get("rs_scatter", 0.0) + tb2.get("rs_scatter", 0.0), cn2.get("rs_scatter_launches", 0),
+                    float(cn2.get("rs_scatter_bytes", 0)), "k_rs_scatter_hbm_bytes_per_launch")
+        r_sc["launches_per_step"] = float(cn2.get("rs_scatter_launches", 0))
+        r_sc["measured"] = "one instrumented step after the timed region (event pair around every launch)"
         # What actually bounds the chain stage: VALU issue.  A wave64 VALU instruction occupies its SIMD for 4 cycles
         # (MI355X_MICROARCH.md); the instruction counts per launch come from the SQ counter pass in profiles/
         # (SQ_INSTS_VALU, same command), the stage time is the live fork..join figure of this run.

@@ -198,6 +198,10 @@ int  lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, uint64_t *
 int  lrge_hip_anchors_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
                            const lrge_hip_seqset *queries, int dual, uint32_t query, uint64_t *x,
                            uint64_t *y, uint64_t cap, uint64_t *n_out);
+/* How much of a call is timed with HIP events: 0 = LRGE_T_TOTAL, LRGE_T_CHAIN, LRGE_T_CHAIN_LPG only; 1 (default) = every
+   stage; 2 = also a pair around every k_rs_scatter launch (LRGE_T_RS_SCATTER: ~14 more pairs per call, ~2 % of a C2
+   step in host work between launches).  Untimed slots read 0.  LRGE_HIP_TIMERS=<level> sets the initial level. */
+int  lrge_hip_set_timer_level(lrge_hip_ctx *ctx, int level);
 int  lrge_hip_last_timings(const lrge_hip_ctx *ctx, float ms[LRGE_T_N]);
 int  lrge_hip_last_counters(const lrge_hip_ctx *ctx, uint64_t c[LRGE_C_N]);
 const char *lrge_hip_version(void);

@@ -26,7 +26,7 @@ EXPORTS = [
     "lrge_hip_estimates", "lrge_hip_median", "lrge_hip_paf_stats",
     "lrge_hip_unique_random_set", "lrge_hip_chacha_block",
     "lrge_hip_sketch_dump", "lrge_hip_index_dump", "lrge_hip_anchors_dump",
-    "lrge_hip_last_timings", "lrge_hip_last_counters", "lrge_hip_version",
+    "lrge_hip_set_timer_level", "lrge_hip_last_timings", "lrge_hip_last_counters", "lrge_hip_version",
 ]
 
 
@@ -88,6 +88,7 @@ def lib():
     L.lrge_hip_sketch_dump.argtypes = [vp, vp, C.c_int, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.lrge_hip_index_dump.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.lrge_hip_anchors_dump.argtypes = [vp, vp, vp, C.c_int, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.lrge_hip_set_timer_level.argtypes = [vp, C.c_int]
     L.lrge_hip_last_timings.argtypes = [vp, C.POINTER(C.c_float * len(T_NAMES))]
     L.lrge_hip_last_counters.argtypes = [vp, C.POINTER(C.c_uint64 * len(C_NAMES))]
     _lib = L

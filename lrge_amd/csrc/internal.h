@@ -87,6 +87,7 @@ struct lrge_hip_ctx {
     int n_cu = 256;
     bool lsort_ok[3] = {false, false, false};   // which k_seg_sort_local variants this device can launch
     struct lrge_hip_seqset *presk_pending = nullptr; int presk_preset = -1;   // lrge_hip_seqset_presketch request
+    int timer_level = 1;                     // see StageTimer
     // Small device->host reads (totals, censuses, per-read vectors).  hipMemcpyAsync into pageable memory is a blocking
     // staged copy, one round trip EACH; through this pinned area several reads queue up behind the kernels and cost
     // one round trip at the following d2h_sync(), which also moves the bytes to where the caller wants them.
@@ -231,7 +232,14 @@ struct StageTimer {
 static inline u32 ceil_log2_u64(u64 v) { u32 b = 0; while (b < 64 && (1ULL << b) < v) ++b; return b; }
 static inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
 
+// Timer levels (lrge_hip_set_timer_level / LRGE_HIP_TIMERS): 0 = the call total and the chain stage only (what a
+// caller that just wants results should pay: two event records per timer are host work between launches), 1 = every
+// stage (default), 2 = also one pair around every k_rs_scatter launch.
+inline int timer_slot_level(int slot) {
+    return (slot == LRGE_T_TOTAL || slot == LRGE_T_CHAIN || slot == LRGE_T_CHAIN_LPG) ? 0 : slot == LRGE_T_RS_SCATTER ? 2 : 1;
+}
 inline StageTimer::StageTimer(lrge_hip_ctx *c, int s, hipStream_t on) : ctx(c), slot(s), st(on ? on : c->stream) {
+    if (timer_slot_level(s) > ctx->timer_level) { stopped = true; return; }     // not recorded
     a = ctx->get_event(); b = ctx->get_event();
     (void)hipEventRecord(a, st);
 }

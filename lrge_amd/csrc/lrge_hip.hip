@@ -107,6 +107,7 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
     memset(ctx->counters, 0, sizeof(ctx->counters));
+    if (getenv("LRGE_HIP_TIMERS")) ctx->timer_level = atoi(getenv("LRGE_HIP_TIMERS"));
     { std::lock_guard<std::mutex> g(g_live_mu); g_live_ctx.insert(ctx); }
     *out = ctx;
     return LRGE_OK;
@@ -129,6 +130,12 @@ extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
 }
 
 extern "C" const char *lrge_hip_last_error(const lrge_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int lrge_hip_set_timer_level(lrge_hip_ctx *ctx, int level) {
+    if (!ctx || level < 0 || level > 2) return LRGE_ERR_INVALID;
+    ctx->timer_level = level;
+    return LRGE_OK;
+}
 
 extern "C" int lrge_hip_last_timings(const lrge_hip_ctx *ctx, float ms[LRGE_T_N]) {
     if (!ctx) return LRGE_ERR_INVALID;

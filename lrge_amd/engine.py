@@ -58,6 +58,10 @@ class Context:
         except Exception:
             pass
 
+    def set_timer_level(self, level):
+        """0 = call total + chain stage only, 1 = every stage, 2 (default) = also every k_rs_scatter launch."""
+        self._check(self._lib.lrge_hip_set_timer_level(self.h, int(level)))
+
     def timings(self):
         a = (C.c_float * len(_ffi.T_NAMES))()
         self._lib.lrge_hip_last_timings(self.h, C.byref(a))

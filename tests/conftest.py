@@ -100,3 +100,28 @@ def to_arrays(seqs):
     np.cumsum(lens, out=offs[1:])
     b = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if int(offs[-1]) else np.zeros(0, dtype=np.uint8)
     return b, offs
+
+
+def write_unaligned_bam(path, names, seqs, bgzf_block=60000):
+    """A uBAM (flag 4, no references) holding the given reads: what `samtools import` / a basecaller writes.  Used to
+    rebuild the reference's toy.bam test input from its FASTA conversion (tests/golden/toy_reads.fa.gz) -- same reads,
+    same order -- instead of shipping the reference's file.  Compressed as a sequence of gzip members (BGZF-like)."""
+    import gzip
+    import struct
+    code = {c: i for i, c in enumerate(b"=ACMGRSVTWYHKDBN")}
+    text = b"@HD\tVN:1.6\tSO:unknown\n"
+    body = [b"BAM\x01", struct.pack("<i", len(text)), text, struct.pack("<i", 0)]
+    for n, s in zip(names, seqs):
+        up = s.upper()
+        nib = [code.get(c, 15) for c in up]
+        if len(nib) & 1:
+            nib.append(0)
+        packed = bytes((nib[i] << 4) | nib[i + 1] for i in range(0, len(nib), 2))
+        name = n + b"\0"
+        rec = struct.pack("<iiBBHHHiiii", -1, -1, len(name), 0, 4680, 0, 4, len(s), -1, -1, 0) + name + packed + b"\xff" * len(s)
+        body.append(struct.pack("<i", len(rec)) + rec)
+    raw = b"".join(body)
+    with open(path, "wb") as fh:
+        for i in range(0, len(raw), bgzf_block):
+            fh.write(gzip.compress(raw[i:i + bgzf_block], 6))
+        fh.write(gzip.compress(b""))

@@ -2,8 +2,6 @@
 """Regenerates the fixtures in this directory.  Run in the build container only (it reads the
 reference's test data file); the GPU box never runs this script.
 
-  toy.bam              byte-for-byte copy of /root/reference/lrge/tests/data/toy.bam (a data file of the reference's
-                       own integration test; input of the BAM reader tests and of the --seed 6 run)
   toy_reads.fa.gz      the 500 unaligned ONT reads of /root/reference/lrge/tests/data/toy.bam (data file
                        of the reference's own integration test, lrge/tests/alignment.rs:52-67; MIT),
                        converted BAM -> FASTA: read name up to the first whitespace, sequence as stored.
@@ -52,8 +50,6 @@ def read_bam(path):
 def main():
     import numpy as np
     from oracle import oracle as O
-    import shutil
-    shutil.copyfile(BAM, os.path.join(HERE, "toy.bam"))
     recs = read_bam(BAM)
     assert len(recs) == 500 and all(f & 4 for _, _, f in recs)
     with gzip.GzipFile(os.path.join(HERE, "toy_reads.fa.gz"), "wb", mtime=0) as fh:

@@ -462,7 +462,11 @@ def test_cli_alignment_inputs_and_seeded_subsampling(ctx, oracle, tmp_path):
                      b"READ2\t4\t*\t0\t0\t*\t*\t0\t0\tGATTACA\t!!!!!!!\n")
     out = subprocess.run([cli, str(msam), "-T", "1", "-Q", "1"], capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "Mapped records are not supported" in out.stderr, out.stderr
-    bam = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "toy.bam")
+    # the reference's toy.bam, rebuilt from its FASTA conversion (same reads, same order: the same indices are drawn)
+    from conftest import write_unaligned_bam
+    fa_names, fa_seqs = readio.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "toy_reads.fa.gz"))
+    bam = str(tmp_path / "toy.bam")
+    write_unaligned_bam(bam, fa_names, fa_seqs)
     out = subprocess.run([cli, bam, "-T", "10", "-Q", "5", "--seed", "6", "-f"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr                       # alignment.rs:52-67 asserts exactly this
     names, seqs = readio.load(bam)

@@ -72,12 +72,16 @@ def test_multi_member_gzip_and_crlf(tmp_path, cli):
     assert _dump(cli, p)[1] == RECORDS
 
 
-def test_toy_bam_matches_its_fasta_conversion(cli):
-    """lrge/tests/data/toy.bam (the reference's own test input, alignment.rs:52-67): 500 unaligned ONT reads."""
-    bam = list(readio.iter_records(os.path.join(GOLDEN, "toy.bam")))
+def test_toy_bam_matches_its_fasta_conversion(cli, tmp_path):
+    """The reads of lrge/tests/data/toy.bam (the reference's own test input, alignment.rs:52-67: 500 unaligned ONT reads),
+    shipped as their FASTA conversion and written back to uBAM here: both readers must return the same records."""
+    from conftest import write_unaligned_bam
     fa = list(readio.iter_records(os.path.join(GOLDEN, "toy_reads.fa.gz")))
+    bam_path = tmp_path / "toy.bam"
+    write_unaligned_bam(bam_path, [n for n, _ in fa], [s for _, s in fa])
+    bam = list(readio.iter_records(str(bam_path)))
     assert len(bam) == 500 and bam == fa
-    rc, recs, err = _dump(cli, os.path.join(GOLDEN, "toy.bam"))
+    rc, recs, err = _dump(cli, bam_path)
     assert rc == 0 and recs == fa and "500 records" in err
 
 

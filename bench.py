@@ -109,6 +109,12 @@ def main():
     qlens = q.lens()
     avg_t = np.float32(t.lens().sum()) / np.float32(t.n)
 
+    if use_dist:
+        pin_in = torch.empty(Qn, dtype=torch.float32).pin_memory()
+        pin_out = torch.empty(Qn * world, dtype=torch.float32).pin_memory()
+        d_mine = torch.empty(Qn, dtype=torch.float32, device="cuda")
+        d_all = torch.empty(Qn * world, dtype=torch.float32, device="cuda")
+
     def sync_all():
         torch.cuda.synchronize()
         if use_dist:
@@ -125,10 +131,12 @@ def main():
         est = ctx.estimates(counts, qlens, float(avg_t), t.n, 100)
         ix.free()
         if use_dist:    # the one collective of the path: per-read estimate vectors over RCCL/xGMI
-            mine = torch.from_numpy(est).cuda()
-            allv = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allv, mine)
-            est_all = torch.cat(allv).cpu().numpy()
+            pin_in.numpy()[:] = est                       # pinned staging: the copies queue up behind each other,
+            d_mine.copy_(pin_in, non_blocking=True)       # one host wait per step
+            dist.all_gather_into_tensor(d_all, d_mine)
+            pin_out.copy_(d_all, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            est_all = pin_out.numpy().copy()
         else:
             est_all = est
         med = engine.median(est_all, True, 0.15, 0.65)

@@ -600,3 +600,26 @@ def test_presketch_is_invisible(ctx, oracle, tiny_ont, tiny_hifi, preset, monkey
     ix = engine.Index(ctx, Td, PRESETS[preset])
     assert np.array_equal(ix.overlap_twoset(Qd)[0], ref_counts)
     ix.free()
+
+
+def test_repeated_steps_are_deterministic(ctx, tiny_ont):
+    """Sixty index-build + overlap steps on one context (pool memory recycled, the streamed set sketched on the side stream
+    in two of three): every step returns the very same counts.  A race between the two streams or a buffer recycled too
+    early would show up here as a flicker (the same loop ran 700 times on the C2 set without one)."""
+    from lrge_amd import engine
+    ds = tiny_ont
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Qd, Td = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
+    ref = {}
+    for it in range(60):
+        if it % 3 != 2:
+            Qd.presketch(0)
+        ix = engine.Index(ctx, Td, 0)
+        F = it % 5 == 4
+        counts, has = ix.overlap_twoset(Qd, remove_internal=F)
+        mid = ix.stats()["mid_occ"]
+        ix.free()
+        if F not in ref:
+            ref[F] = (counts.copy(), has.copy(), mid)
+        assert np.array_equal(counts, ref[F][0]) and np.array_equal(has, ref[F][1]) and mid == ref[F][2], it
+    assert int(ref[False][0].sum()) > 0

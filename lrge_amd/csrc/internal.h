@@ -132,6 +132,7 @@ struct PreSketch {
 struct lrge_hip_seqset {
     lrge_hip_ctx *ctx;
     PreSketch *presk = nullptr;
+    bool is_view = false;       // reads [r0, r1) of another set: shares its device arrays, owns only d_cs
     u32 n = 0;
     u64 total_bases = 0;
     u64 n_words = 0;            // 32-base words in the packed image (reads start on a word)
@@ -166,6 +167,13 @@ struct lrge_hip_index {
     u64 *d_ht = nullptr;        // ordered open-addressing table of {key, start<<24 | min(count, 2^24-1)} pairs (k_index.h)
     u32 pk_pos1 = 0, pk_ybits = 0;   // packed entries (d_skey == d_pos): hash << pk_ybits | rid << pk_pos1 | (pos << 1 | strand)
     u64 ht_cap = 0;             // home slots are [0, ht_cap); slack slots follow
+    u64 ht_slots = 0;           // ht_cap + slack
+    // A target set too large for one index (more than LRGE_HIP_PART_BASES bases: the 2^32-entry limits) is indexed in
+    // parts over views of the set.  The occurrence statistics are global (k_part_global_occ), so the parts together
+    // behave exactly like one index; a part's own d_* arrays are used as above, the container's are null.
+    std::vector<lrge_hip_index *> parts;
+    std::vector<lrge_hip_seqset *> part_sets;
+    std::vector<u32> part_r0;
 };
 
 #define LRGE_SET_ERR(ctx, ...)                                  \

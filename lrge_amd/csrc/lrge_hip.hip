@@ -252,6 +252,7 @@ extern "C" void lrge_hip_seqset_free(lrge_hip_seqset *s) {
     bool ctx_alive;
     { std::lock_guard<std::mutex> g(g_live_mu); ctx_alive = g_live_ctx.count(s->ctx) != 0; }
     if (ctx_alive) { (void)hipSetDevice(s->ctx->device); presketch_discard(s); }   // (a set that outlives its context only owns its own arrays)
+    if (s->is_view) { (void)hipFree(s->d_cs); delete s; return; }                   // a view owns its chunk map only
     (void)hipFree(s->d_pack); (void)hipFree(s->d_nmask); (void)hipFree(s->d_woff); (void)hipFree(s->d_len); (void)hipFree(s->d_rank); (void)hipFree(s->d_cs);
     delete s;
 }
@@ -465,9 +466,7 @@ static u64 env_u64(const char *name, u64 dflt) {
 // ------------------------------------------------------------------------------------------
 // index
 // ------------------------------------------------------------------------------------------
-extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_index **out) {
-    if (!ctx || !targets || !out) return LRGE_ERR_INVALID;
-    if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
+static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_index **out) {
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
@@ -535,7 +534,9 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
 #define HT_CAP_NUM 2       // home slots per distinct key = HT_CAP_NUM / HT_CAP_DEN
 #define HT_CAP_DEN 1
 #endif
-        u64 cap = (u64)n_runs * HT_CAP_NUM / HT_CAP_DEN;
+        // a part of a partitioned index (a target set of tens of gigabases) gets 1.25 instead of 2 slots per key: the
+        // tables of all parts are resident together and memory, not probe length (+15 % lookup time), is what binds there
+        u64 cap = targets->is_view ? (u64)n_runs * 5 / 4 : (u64)n_runs * HT_CAP_NUM / HT_CAP_DEN;
         if (cap < 1024) cap = 1024;
         if (cap + n_runs >= (1ULL << 32)) { delete ix; LRGE_SET_ERR(ctx, "index limited to < 2^32/3 distinct minimizers (got %u)", n_runs); return LRGE_ERR_TOO_MANY; }
         ix->ht_cap = cap;
@@ -550,6 +551,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         for (int attempt = 0; attempt < 2; ++attempt) {
             const u64 slack = attempt == 0 ? std::max<u64>((u64)n_runs / 16, 4096) : (u64)n_runs + 1;
             const u64 n_slots = cap + slack;
+            ix->ht_slots = n_slots;
             ht = sc.get<u64>(2 * n_slots);
             if (!ht) { delete ix; return LRGE_ERR_DEVICE; }
             HIPCHK(ctx, hipMemsetAsync(ht, 0xFF, 2 * n_slots * 8, ctx->stream));   // key = HT_EMPTY
@@ -614,8 +616,140 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     return LRGE_OK;
 }
 
+// Reads [r0, r1) of `s` as a set of its own: the packed image, the masks and the per-read arrays are shared (word offsets
+// are absolute), only the sketch chunk map is rebuilt so that chunk ids start at 0.
+static int seqset_view(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, u32 r0, u32 r1, lrge_hip_seqset **out) {
+    lrge_hip_seqset *v = new lrge_hip_seqset();
+    v->ctx = ctx; v->is_view = true; v->n = r1 - r0;
+    v->has_rank = s->has_rank; v->dup_rank = s->dup_rank;
+    v->d_pack = s->d_pack; v->d_nmask = s->d_nmask; v->d_woff = s->d_woff + r0; v->d_len = s->d_len + r0;
+    v->d_rank = s->d_rank ? s->d_rank + r0 : nullptr;
+    v->h_woff.assign(s->h_woff.begin() + r0, s->h_woff.begin() + r1 + 1);
+    v->h_len.assign(s->h_len.begin() + r0, s->h_len.begin() + r1);
+    if (v->h_len.empty()) v->h_len.push_back(0);
+    if (s->has_rank) {
+        v->h_rank.assign(s->h_rank.begin() + r0, s->h_rank.begin() + r1);
+        v->h_rank_sorted = v->h_rank;
+        std::sort(v->h_rank_sorted.begin(), v->h_rank_sorted.end());
+    }
+    v->h_cs.resize((size_t)v->n + 1);
+    for (u32 i = 0; i <= v->n; ++i) v->h_cs[i] = s->h_cs[r0 + i] - s->h_cs[r0];
+    v->n_chunks = v->h_cs[v->n];
+    for (u32 i = r0; i < r1; ++i) {
+        v->total_bases += s->h_len[i];
+        if (s->h_len[i] > v->max_len) v->max_len = s->h_len[i];
+        if (s->h_len[i] == 0) v->has_empty = true;
+    }
+    v->n_words = s->h_woff[r1] - s->h_woff[r0];
+    hipError_t e = hipMalloc((void **)&v->d_cs, ((size_t)v->n + 1) * 4);
+    if (e == hipSuccess) e = hipMemcpy(v->d_cs, v->h_cs.data(), ((size_t)v->n + 1) * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { LRGE_SET_ERR(ctx, "seqset view: %s", hipGetErrorString(e)); if (v->d_cs) (void)hipFree(v->d_cs); delete v; return LRGE_ERR_DEVICE; }
+    *out = v;
+    return LRGE_OK;
+}
+
+extern "C" void lrge_hip_index_free(lrge_hip_index *ix);
+
+// mm_idx_reader_read with batch_size = max (aligner.rs:112-122) makes ONE index whatever the size of the target file.
+// Here a target set above LRGE_HIP_PART_BASES bases (default 4e9: the 2^32-entry limits of one part) is indexed in parts
+// over views of the set; the occurrence statistics are then taken over all parts together (k_part_global_occ), mid_occ
+// from that global histogram, and a key that is too frequent globally is marked so in every part (k_part_drop) -- the
+// parts answer every lookup exactly as the one index would.
+extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_index **out) {
+    if (!ctx || !targets || !out) return LRGE_ERR_INVALID;
+    if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
+    *out = nullptr;
+    const u64 part_bases = env_u64("LRGE_HIP_PART_BASES", 4000000000ull);
+    if (targets->total_bases <= part_bases || targets->n < 2 || targets->is_view) return index_build_one(ctx, targets, preset, out);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // cut by reads, every part at most part_bases bases (a single longer read gets a part of its own)
+    std::vector<u32> cuts{0};
+    u64 acc = 0;
+    for (u32 r = 0; r < targets->n; ++r) {
+        if (acc && acc + targets->h_len[r] > part_bases) { cuts.push_back(r); acc = 0; }
+        acc += targets->h_len[r];
+    }
+    cuts.push_back(targets->n);
+    const int np = (int)cuts.size() - 1;
+    if (np > MAX_INDEX_PARTS) { LRGE_SET_ERR(ctx, "target set needs %d index parts (limit %d)", np, MAX_INDEX_PARTS); return LRGE_ERR_TOO_MANY; }
+    lrge_hip_index *top = new lrge_hip_index();
+    top->ctx = ctx; top->seqs = targets; top->preset_id = preset;
+    float ms_acc[LRGE_T_N]; u64 cn_acc[LRGE_C_N];
+    memset(ms_acc, 0, sizeof ms_acc); memset(cn_acc, 0, sizeof cn_acc);
+    auto fail = [&](int rc) { lrge_hip_index_free(top); return rc; };
+    for (int p = 0; p < np; ++p) {
+        lrge_hip_seqset *v = nullptr;
+        int rc = seqset_view(ctx, targets, cuts[p], cuts[p + 1], &v);
+        if (rc) return fail(rc);
+        top->part_sets.push_back(v); top->part_r0.push_back(cuts[p]);
+        lrge_hip_index *ixp = nullptr;
+        rc = index_build_one(ctx, v, preset, &ixp);
+        if (rc) return fail(rc);
+        top->parts.push_back(ixp);
+        top->n_mz += ixp->n_mz;
+        for (int i = 0; i < LRGE_T_N; ++i) ms_acc[i] += ctx->ms[i];
+        for (int i = 0; i < LRGE_C_N; ++i) cn_acc[i] += ctx->counters[i];
+    }
+    top->P = top->parts[0]->P;
+    // ---- global occurrence statistics ----
+    const Preset &P = top->P;
+    const u32 max_bin = (u32)P.max_mid_occ + 1;
+    Scratch sc(ctx);
+    ALLOC_OR_FAIL(d_hist, sc, u32, (size_t)max_bin + 1);
+    unsigned long long *d_nd = (unsigned long long *)sc.get<u64>(1);
+    if (!d_nd) return fail(LRGE_ERR_DEVICE);
+    HIPCHK(ctx, hipMemsetAsync(d_hist, 0, ((size_t)max_bin + 1) * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_nd, 0, 8, ctx->stream));
+    PartTables T; T.n = np;
+    for (int p = 0; p < np; ++p) { T.ht[p] = top->parts[p]->d_ht; T.cap[p] = top->parts[p]->ht_cap; }
+    std::vector<u32 *> gcount(np, nullptr);
+    for (int p = 0; p < np; ++p) {
+        const u64 ns = top->parts[p]->ht_slots;
+        gcount[p] = sc.get<u32>(ns + 1);
+        if (!gcount[p]) return fail(LRGE_ERR_DEVICE);
+        hipLaunchKernelGGL(k_part_global_occ, dim3((u32)div_up(ns, 256)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, T, p, gcount[p],
+                           d_hist, max_bin, d_nd);
+        KCHK(ctx);
+    }
+    std::vector<u32> occ((size_t)max_bin + 1);
+    unsigned long long n_distinct = 0;
+    HIPCHK(ctx, hipMemcpyAsync(occ.data(), d_hist, ((size_t)max_bin + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&n_distinct, d_nd, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    top->n_keys = n_distinct;
+    {   // mm_idx_cal_max_occ + mm_mapopt_update clamps, over the distinct keys of all parts (same arithmetic as index_build_one)
+        int thres;
+        if (n_distinct == 0) thres = INT32_MAX;
+        else {
+            const u64 kth = (u64)((1. - (double)P.mid_occ_frac) * (double)n_distinct);
+            u64 cum = 0; u32 v = max_bin;
+            for (u32 b = 0; b <= max_bin; ++b) { cum += occ[b]; if (cum > kth) { v = b; break; } }
+            thres = (int)v + 1;
+        }
+        if (thres < P.min_mid_occ) thres = P.min_mid_occ;
+        if (P.max_mid_occ > P.min_mid_occ && thres > P.max_mid_occ) thres = P.max_mid_occ;
+        top->mid_occ = thres;
+    }
+    for (int p = 0; p < np; ++p) {
+        const u64 ns = top->parts[p]->ht_slots;
+        hipLaunchKernelGGL(k_part_drop, dim3((u32)div_up(ns, 256)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, gcount[p], (u32)top->mid_occ);
+        KCHK(ctx);
+        top->parts[p]->mid_occ = top->mid_occ;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(ctx->ms, ms_acc, sizeof ms_acc); memcpy(ctx->counters, cn_acc, sizeof cn_acc);
+    *out = top;
+    return LRGE_OK;
+}
+
 extern "C" void lrge_hip_index_free(lrge_hip_index *ix) {
     if (!ix) return;
+    if (!ix->parts.empty() || !ix->part_sets.empty()) {
+        for (lrge_hip_index *p : ix->parts) lrge_hip_index_free(p);
+        for (lrge_hip_seqset *v : ix->part_sets) lrge_hip_seqset_free(v);
+        delete ix;
+        return;
+    }
     ix->ctx->pool.release(ix->d_pos); if (ix->d_skey != ix->d_pos) ix->ctx->pool.release(ix->d_skey);
     ix->ctx->pool.release(ix->d_ht);
     delete ix;
@@ -632,6 +766,7 @@ extern "C" int lrge_hip_index_stats(const lrge_hip_index *ix, uint64_t *n_minimi
 extern "C" int lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, uint64_t *keys, uint64_t *pos, uint64_t cap,
                                    uint64_t *n_out) {
     if (!ctx || !ix || !n_out) return LRGE_ERR_INVALID;
+    if (!ix->parts.empty()) { LRGE_SET_ERR(ctx, "index_dump: not implemented for a partitioned index"); return LRGE_ERR_TOO_MANY; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
     *n_out = ix->n_mz;
@@ -1446,22 +1581,45 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     return done(R.finish());
 }
 
-static int check_common(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *q) {
+static int check_common(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *q, bool parts_ok = false) {
     if (!ctx) return LRGE_ERR_INVALID;
     if (!ix) { LRGE_SET_ERR(ctx, "No index"); return LRGE_ERR_MAP; }   // aligner.rs:210-212
     if (!q) { LRGE_SET_ERR(ctx, "null read set"); return LRGE_ERR_INVALID; }
     if (ix->ctx != ctx || q->ctx != ctx) { LRGE_SET_ERR(ctx, "index / read set belong to another context"); return LRGE_ERR_INVALID; }
+    if (!ix->parts.empty() && !parts_ok) {
+        LRGE_SET_ERR(ctx, "the index is partitioned (%zu parts, target set above LRGE_HIP_PART_BASES): only lrge_hip_overlap_twoset is implemented for it", ix->parts.size());
+        return LRGE_ERR_TOO_MANY;
+    }
     return LRGE_OK;
 }
 
 extern "C" int lrge_hip_overlap_twoset(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries,
                                        const lrge_hip_params *p, uint32_t *counts, uint32_t *has_mapping) {
-    int rc = check_common(ctx, ix, queries);
+    int rc = check_common(ctx, ix, queries, /*parts_ok=*/true);
     if (rc) return rc;
     OverlapJob job; job.mode = MODE_TWOSET; job.dual = 1;
     job.prm = p ? *p : lrge_hip_params{0, 0.2f};
     job.counts = counts; job.has_map = has_mapping;
-    return run_overlap(ctx, ix, queries, job);
+    if (ix->parts.empty()) return run_overlap(ctx, ix, queries, job);
+    // partitioned index: the parts hold disjoint target reads, so a query's distinct-target count is the sum over the
+    // parts and it has a mapping if it has one in any part; every part sees the same queries and the global mid_occ
+    const u32 nq = queries->n;
+    std::vector<u32> c((size_t)nq + 1), h((size_t)nq + 1);
+    if (counts) std::fill(counts, counts + nq, 0u);
+    if (has_mapping) std::fill(has_mapping, has_mapping + nq, 0u);
+    float ms_acc[LRGE_T_N]; u64 cn_acc[LRGE_C_N];
+    memset(ms_acc, 0, sizeof ms_acc); memset(cn_acc, 0, sizeof cn_acc);
+    for (const lrge_hip_index *part : ix->parts) {
+        OverlapJob pj = job;
+        pj.counts = c.data(); pj.has_map = h.data();
+        rc = run_overlap(ctx, part, queries, pj);
+        if (rc) return rc;
+        for (u32 q = 0; q < nq; ++q) { if (counts) counts[q] += c[q]; if (has_mapping) has_mapping[q] |= h[q]; }
+        for (int i = 0; i < LRGE_T_N; ++i) ms_acc[i] += ctx->ms[i];
+        for (int i = 0; i < LRGE_C_N; ++i) cn_acc[i] = i == LRGE_C_LPG_SPLIT ? ctx->counters[i] : cn_acc[i] + ctx->counters[i];
+    }
+    memcpy(ctx->ms, ms_acc, sizeof ms_acc); memcpy(ctx->counters, cn_acc, sizeof cn_acc);
+    return LRGE_OK;
 }
 
 extern "C" int lrge_hip_overlap_inverse(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *streamed,

@@ -623,3 +623,49 @@ def test_repeated_steps_are_deterministic(ctx, tiny_ont):
             ref[F] = (counts.copy(), has.copy(), mid)
         assert np.array_equal(counts, ref[F][0]) and np.array_equal(has, ref[F][1]) and mid == ref[F][2], it
     assert int(ref[False][0].sum()) > 0
+
+
+@pytest.mark.parametrize("data,preset", [("tiny_ont", "ont"), ("tiny_hifi", "pb"), ("repeats", "ont")])
+def test_partitioned_index_is_exact(ctx, oracle, tiny_ont, tiny_hifi, data, preset, monkeypatch):
+    """A target set above LRGE_HIP_PART_BASES bases is indexed in parts (the 2^32-entry limits of one part; minimap2 is
+    given batch_size = max and always builds ONE index, aligner.rs:112-122).  With the occurrence statistics taken over
+    all parts the result must be that of the single index: same mid_occ, distinct-key and minimizer totals, the same
+    number of anchors and the same counts with and without -F -- forced here with parts of a few reads each.  The
+    repeat-rich set has a mid_occ above the floor of 10, i.e. one that the global histogram decides."""
+    from lrge_amd import engine, synth, _ffi
+    if data == "repeats":
+        g, q, t = synth.make_config("c2_repeats", 0.05)
+        ds = type("DS", (), {"q": q, "t": t})
+    else:
+        ds = tiny_ont if data == "tiny_ont" else tiny_hifi
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Qd, Td = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
+    ix = engine.Index(ctx, Td, PRESETS[preset])
+    ref_stats = ix.stats()
+    ref, ref_anchors = {}, {}
+    for F in (False, True):
+        ref[F] = ix.overlap_twoset(Qd, remove_internal=F)
+        ref_anchors[F] = ctx.counters()["anchors"]
+    ix.free()
+    assert int(ref[False][0].sum()) > 0
+    if data == "repeats":
+        assert ref_stats["mid_occ"] > 10
+    total = int(ds.t.lens().sum())
+    for n_parts in (2, 3, 7, 25):
+        monkeypatch.setenv("LRGE_HIP_PART_BASES", str(total // n_parts + 1))
+        Qd.presketch(PRESETS[preset])
+        ixp = engine.Index(ctx, Td, PRESETS[preset])
+        st = ixp.stats()
+        assert (st["n_minimizers"], st["n_keys"], st["mid_occ"]) == (ref_stats["n_minimizers"], ref_stats["n_keys"], ref_stats["mid_occ"]), n_parts
+        for F in (False, True):
+            counts, has = ixp.overlap_twoset(Qd, remove_internal=F)
+            assert ctx.counters()["anchors"] == ref_anchors[F], (n_parts, F)
+            assert np.array_equal(counts, ref[F][0]) and np.array_equal(has, ref[F][1]), (n_parts, F)
+        with pytest.raises(_ffi.LrgeHipError):                   # the other entry points say so instead of guessing
+            ixp.overlap_inverse(Qd)
+        ixp.free()
+    # the oracle agrees with the single index (and hence with the parts)
+    opt = oracle.make_opt(oracle.PRESET_AVA_PB if preset == "pb" else oracle.PRESET_AVA_ONT, dual=True)
+    ixo = oracle.Index(oracle.ReadSet(ds.t.seqs(), ds.t.names), opt)
+    rc, ec, eh = ixo.twoset_counts(oracle.ReadSet(ds.q.seqs(), ds.q.names), threads=8)
+    assert np.array_equal(ref[False][0], ec) and ixo.mid_occ == ref_stats["mid_occ"]

@@ -163,37 +163,45 @@ __device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u
 #define MAX_INDEX_PARTS 32
 struct PartTables { const u64 *ht[MAX_INDEX_PARTS]; u64 cap[MAX_INDEX_PARTS]; int n; };
 
-// One lane per slot of part `self`: the key's occurrence count summed over every part; each distinct key enters the
-// histogram once, in the lowest part that holds it.  gcount[slot] keeps the sum for k_part_drop.
+// One lane per slot of part `self` (grid-stride): the key's occurrence count summed over every part; each distinct key
+// enters the histogram once, in the lowest part that holds it.  gcount[slot] keeps the sum for k_part_drop.  The
+// histogram is gathered in LDS and flushed once per block from a small grid (k_place_apply's lesson: millions of
+// atomics on the same few dozen bins serialise at L2).
 __global__ __launch_bounds__(256) void k_part_global_occ(const u64 *__restrict__ ht, u64 n_slots, PartTables T, int self,
                                                          u32 *__restrict__ gcount, u32 *__restrict__ hist, u32 max_bin,
                                                          unsigned long long *__restrict__ n_distinct) {
-    const u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    bool first = false;
-    u32 total = 0;
-    if (slot < n_slots) {
-        const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
-        if (e.x != HT_EMPTY) {
-            u64 sum = e.y & HT_CNT_MAX;
-            first = true;
-            for (int o = 0; o < T.n; ++o) {
-                if (o == self) continue;
-                u64 st; u32 c;
-                if (ht_lookup(T.ht[o], T.cap[o], e.x, &st, &c)) { sum += c; if (o < self) first = false; }
+    __shared__ u32 lh[OCC_LDS_BINS];
+    __shared__ u32 l_first;
+    for (u32 i = threadIdx.x; i < OCC_LDS_BINS; i += blockDim.x) lh[i] = 0;
+    if (threadIdx.x == 0) l_first = 0;
+    __syncthreads();
+    const u64 rounds = (n_slots + (u64)gridDim.x * blockDim.x - 1) / ((u64)gridDim.x * blockDim.x);
+    for (u64 rd = 0; rd < rounds; ++rd) {
+        const u64 slot = (rd * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        bool first = false;
+        u32 total = 0;
+        if (slot < n_slots) {
+            const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
+            if (e.x != HT_EMPTY) {
+                u64 sum = e.y & HT_CNT_MAX;
+                first = true;
+                for (int o = 0; o < T.n; ++o) {
+                    if (o == self) continue;
+                    u64 st; u32 c;
+                    if (ht_lookup(T.ht[o], T.cap[o], e.x, &st, &c)) { sum += c; if (o < self) first = false; }
+                }
+                total = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sum;
+                gcount[slot] = total;
             }
-            total = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sum;
-            gcount[slot] = total;
         }
+        const u32 hb = total < max_bin ? total : max_bin;
+        const u64 mf = __ballot(first);
+        if (lane_id() == 0 && mf) atomicAdd(&l_first, (u32)__popcll(mf));
+        if (first) { if (hb < OCC_LDS_BINS) atomicAdd(&lh[hb], 1u); else atomicAdd(&hist[hb], 1u); }
     }
-    // counts of 1 and 2 are almost everything: one atomic per wavefront for those
-    const u32 hb = total < max_bin ? total : max_bin;
-    const u64 m1 = __ballot(first && hb == 1), m2 = __ballot(first && hb == 2), mf = __ballot(first);
-    if (lane_id() == 0) {
-        if (m1) atomicAdd(&hist[1], (u32)__popcll(m1));
-        if (m2) atomicAdd(&hist[2], (u32)__popcll(m2));
-        if (mf) atomicAdd(n_distinct, (unsigned long long)__popcll(mf));
-    }
-    if (first && hb != 1 && hb != 2) atomicAdd(&hist[hb], 1u);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < OCC_LDS_BINS && i <= max_bin; i += blockDim.x) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+    if (threadIdx.x == 0 && l_first) atomicAdd(n_distinct, (unsigned long long)l_first);
 }
 
 // A key whose GLOBAL count exceeds mid_occ must be dropped in every part: lift its local count above the threshold, which

@@ -692,6 +692,9 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     }
     top->P = top->parts[0]->P;
     // ---- global occurrence statistics ----
+    ctx->resolve_timers();
+    memset(ctx->ms, 0, sizeof(ctx->ms));
+    StageTimer t_glob(ctx, LRGE_T_INDEX_TABLE);
     const Preset &P = top->P;
     const u32 max_bin = (u32)P.max_mid_occ + 1;
     Scratch sc(ctx);
@@ -707,7 +710,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         const u64 ns = top->parts[p]->ht_slots;
         gcount[p] = sc.get<u32>(ns + 1);
         if (!gcount[p]) return fail(LRGE_ERR_DEVICE);
-        hipLaunchKernelGGL(k_part_global_occ, dim3((u32)div_up(ns, 256)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, T, p, gcount[p],
+        hipLaunchKernelGGL(k_part_global_occ, dim3((u32)std::min<u64>(div_up(ns, 256), (u64)ctx->n_cu * 16)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, T, p, gcount[p],
                            d_hist, max_bin, d_nd);
         KCHK(ctx);
     }
@@ -736,7 +739,10 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         KCHK(ctx);
         top->parts[p]->mid_occ = top->mid_occ;
     }
+    t_glob.stop();
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->resolve_timers();
+    ms_acc[LRGE_T_INDEX_TABLE] += ctx->ms[LRGE_T_INDEX_TABLE]; ms_acc[LRGE_T_TOTAL] += ctx->ms[LRGE_T_INDEX_TABLE];
     memcpy(ctx->ms, ms_acc, sizeof ms_acc); memcpy(ctx->counters, cn_acc, sizeof cn_acc);
     *out = top;
     return LRGE_OK;

@@ -164,11 +164,11 @@ __device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u
 struct PartTables { const u64 *ht[MAX_INDEX_PARTS]; u64 cap[MAX_INDEX_PARTS]; int n; };
 
 // One lane per slot of part `self` (grid-stride): the key's occurrence count summed over every part; each distinct key
-// enters the histogram once, in the lowest part that holds it.  gcount[slot] keeps the sum for k_part_drop.  The
+// enters the histogram once, in the lowest part that holds it.  The
 // histogram is gathered in LDS and flushed once per block from a small grid (k_place_apply's lesson: millions of
 // atomics on the same few dozen bins serialise at L2).
 __global__ __launch_bounds__(256) void k_part_global_occ(const u64 *__restrict__ ht, u64 n_slots, PartTables T, int self,
-                                                         u32 *__restrict__ gcount, u32 *__restrict__ hist, u32 max_bin,
+                                                         u32 *__restrict__ hist, u32 max_bin,
                                                          unsigned long long *__restrict__ n_distinct) {
     __shared__ u32 lh[OCC_LDS_BINS];
     __shared__ u32 l_first;
@@ -191,7 +191,6 @@ __global__ __launch_bounds__(256) void k_part_global_occ(const u64 *__restrict__
                     if (ht_lookup(T.ht[o], T.cap[o], e.x, &st, &c)) { sum += c; if (o < self) first = false; }
                 }
                 total = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sum;
-                gcount[slot] = total;
             }
         }
         const u32 hb = total < max_bin ? total : max_bin;
@@ -205,12 +204,21 @@ __global__ __launch_bounds__(256) void k_part_global_occ(const u64 *__restrict__
 }
 
 // A key whose GLOBAL count exceeds mid_occ must be dropped in every part: lift its local count above the threshold, which
-// is all k_lookup's consumers test (a dropped list is never expanded, so its true length is not needed any more).
-__global__ __launch_bounds__(256) void k_part_drop(u64 *__restrict__ ht, u64 n_slots, const u32 *__restrict__ gcount, u32 mid_occ) {
+// is all k_lookup's consumers test (a dropped list is never expanded, so its true length is not needed any more).  The
+// sum over the parts is taken again here rather than kept from k_part_global_occ: 4 bytes per slot of every part would
+// have to stay resident between the two kernels, and memory is what a partitioned index is short of.
+__global__ __launch_bounds__(256) void k_part_drop(u64 *__restrict__ ht, u64 n_slots, PartTables T, int self, u32 mid_occ) {
     const u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
     const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
     if (e.x == HT_EMPTY) return;
     const u32 local = (u32)(e.y & HT_CNT_MAX);
-    if (gcount[slot] > mid_occ && local <= mid_occ) ht[2 * slot + 1] = (e.y & ~(u64)HT_CNT_MAX) | (u64)(mid_occ + 1);
+    if (local > mid_occ) return;
+    u64 sum = local;
+    for (int o = 0; o < T.n && sum <= mid_occ; ++o) {
+        if (o == self) continue;
+        u64 st; u32 c;
+        if (ht_lookup(T.ht[o], T.cap[o], e.x, &st, &c)) sum += c;
+    }
+    if (sum > mid_occ) ht[2 * slot + 1] = (e.y & ~(u64)HT_CNT_MAX) | (u64)(mid_occ + 1);
 }

@@ -705,12 +705,9 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     HIPCHK(ctx, hipMemsetAsync(d_nd, 0, 8, ctx->stream));
     PartTables T; T.n = np;
     for (int p = 0; p < np; ++p) { T.ht[p] = top->parts[p]->d_ht; T.cap[p] = top->parts[p]->ht_cap; }
-    std::vector<u32 *> gcount(np, nullptr);
     for (int p = 0; p < np; ++p) {
         const u64 ns = top->parts[p]->ht_slots;
-        gcount[p] = sc.get<u32>(ns + 1);
-        if (!gcount[p]) return fail(LRGE_ERR_DEVICE);
-        hipLaunchKernelGGL(k_part_global_occ, dim3((u32)std::min<u64>(div_up(ns, 256), (u64)ctx->n_cu * 16)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, T, p, gcount[p],
+        hipLaunchKernelGGL(k_part_global_occ, dim3((u32)std::min<u64>(div_up(ns, 256), (u64)ctx->n_cu * 16)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, T, p,
                            d_hist, max_bin, d_nd);
         KCHK(ctx);
     }
@@ -735,7 +732,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     }
     for (int p = 0; p < np; ++p) {
         const u64 ns = top->parts[p]->ht_slots;
-        hipLaunchKernelGGL(k_part_drop, dim3((u32)div_up(ns, 256)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, gcount[p], (u32)top->mid_occ);
+        hipLaunchKernelGGL(k_part_drop, dim3((u32)div_up(ns, 256)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, T, p, (u32)top->mid_occ);
         KCHK(ctx);
         top->parts[p]->mid_occ = top->mid_occ;
     }

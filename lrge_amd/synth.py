@@ -141,6 +141,28 @@ def sample_reads(genome, n, platform="ont", seed=1, name_prefix="r", name_start=
     return ReadBatch(bases, offsets, names, starts, starts + lens, strands)
 
 
+def _block(args):
+    genome, nb, platform, seed, prefix, start, n_rate = args
+    return sample_reads(genome, nb, platform, seed=seed, name_prefix=prefix, name_start=start, n_rate=n_rate)
+
+
+def sample_reads_parallel(genome, n, platform="ont", seed=1, name_prefix="r", block=4096, procs=None):
+    """The same read model for sets of hundreds of thousands of reads: blocks of `block` reads drawn by worker processes,
+    block b with seed + 1000003 * b (so the set depends on (seed, block) but not on the number of processes)."""
+    import multiprocessing as mp
+    import os
+    jobs = [(genome, min(block, n - s0), platform, seed + 1000003 * (s0 // block), name_prefix, s0, 0.0) for s0 in range(0, n, block)]
+    procs = procs or min(len(jobs), max(1, (os.cpu_count() or 2) // 2), 64)
+    with mp.get_context("fork").Pool(procs) as pool:
+        parts = pool.map(_block, jobs, chunksize=1)
+    lens = np.concatenate([p.lens() for p in parts])
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    return ReadBatch(np.concatenate([p.bases for p in parts]), offsets, [nm for p in parts for nm in p.names],
+                     np.concatenate([p.starts for p in parts]), np.concatenate([p.ends for p in parts]),
+                     np.concatenate([p.strands for p in parts]))
+
+
 # The five BASELINE.json configs (SURVEY.md section 8d).  "twoset": first Q reads are queries, the
 # last T are targets (file order of Appendix C); "ava": all N reads.
 CONFIGS = {
@@ -150,6 +172,8 @@ CONFIGS = {
     "c5_human_twoset": dict(genome=3_100_000_000, seed=31001, platform="hifi", mode="twoset", Q=100000, T=2000000),
     # C5 at one tenth of its size: same coverage (10x targets), fits the 2^32-entry limits of this round
     "c5_human_tenth": dict(genome=310_000_000, seed=31001, platform="hifi", mode="twoset", Q=10000, T=200000),
+    # C5 at one quarter: 7.9 Gbases of targets -> a partitioned index (2 parts at the default limit); drawn in parallel blocks
+    "c5_human_quarter": dict(genome=775_000_000, seed=31001, platform="hifi", mode="twoset", Q=25000, T=500000, parallel=True),
     # C2 on a repeat-rich genome (15 % interspersed 300-bp / 6-kb families, 2 % short tandem repeats): robustness run
     "c2_repeats": dict(genome=4_400_000, seed=4402, platform="ont", mode="twoset", Q=5000, T=10000, repeats=0.15, tandem=0.02),
     # reduced cases for tests / smoke
@@ -166,7 +190,10 @@ def make_config(name, scale=1.0):
     genome = random_genome(gsize, c["seed"], c.get("repeats", 0.0), c.get("tandem", 0.0))
     if c["mode"] == "twoset":
         q, t = max(1, int(c["Q"] * scale)), max(1, int(c["T"] * scale))
-        reads = sample_reads(genome, q + t, c["platform"], seed=c["seed"] + 1)
+        if c.get("parallel"):
+            reads = sample_reads_parallel(genome, q + t, c["platform"], seed=c["seed"] + 1)
+        else:
+            reads = sample_reads(genome, q + t, c["platform"], seed=c["seed"] + 1)
         return gsize, reads.slice(0, q), reads.slice(q, q + t)
     n = max(2, int(c["N"] * scale))
     return gsize, sample_reads(genome, n, c["platform"], seed=c["seed"] + 1), None

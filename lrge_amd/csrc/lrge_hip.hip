@@ -24,6 +24,12 @@ static thread_local std::string g_last_error;  // failures that happen before a 
 static std::mutex g_live_mu;
 static std::set<lrge_hip_ctx *> g_live_ctx;   // contexts that have not been destroyed
 
+static u64 env_u64(const char *name, u64 dflt) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return strtoull(v, nullptr, 10);
+}
+
 extern "C" const char *lrge_hip_version(void) { return "lrge_hip 0.1.0 (gfx950)"; }
 
 extern "C" int lrge_hip_device_count(int *n) {
@@ -406,6 +412,7 @@ static int presketch_start_pending(lrge_hip_ctx *ctx) {
     lrge_hip_seqset *s = ctx->presk_pending;
     if (!s) return LRGE_OK;
     ctx->presk_pending = nullptr;
+    if (s->total_bases > env_u64("LRGE_HIP_STREAM_BASES", 4000000000ull)) return LRGE_OK;   // streamed in views: sketched per view
     if (s->presk) presketch_discard(s);
     PreSketch *p = new PreSketch();
     p->preset = ctx->presk_preset;
@@ -457,11 +464,6 @@ extern "C" int lrge_hip_sketch_dump(lrge_hip_ctx *ctx, const lrge_hip_seqset *s,
     return LRGE_OK;
 }
 
-static u64 env_u64(const char *name, u64 dflt) {
-    const char *v = getenv(name);
-    if (!v || !*v) return dflt;
-    return strtoull(v, nullptr, 10);
-}
 
 // ------------------------------------------------------------------------------------------
 // index
@@ -1596,6 +1598,55 @@ static int check_common(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_
     return LRGE_OK;
 }
 
+// A streamed set above LRGE_HIP_STREAM_BASES bases (default 4e9: < 2^32 minimizers per pass) goes through in views of
+// at most that many bases.  The streamed reads are independent of each other (twoset.rs:266-334, :485-565), so the passes
+// simply follow one another: per-read outputs land at the view's offset, per-indexed-read counts add up.
+static u64 stream_limit() { return env_u64("LRGE_HIP_STREAM_BASES", 4000000000ull); }
+static std::vector<u32> stream_cuts(const lrge_hip_seqset *s) {
+    std::vector<u32> cuts{0};
+    const u64 lim = stream_limit();
+    u64 acc = 0;
+    for (u32 r = 0; r < s->n; ++r) {
+        if (acc && acc + s->h_len[r] > lim) { cuts.push_back(r); acc = 0; }
+        acc += s->h_len[r];
+    }
+    cuts.push_back(s->n);
+    return cuts;
+}
+struct StageAcc {      // timings / counters of a call made of several passes
+    float ms[LRGE_T_N]; u64 cn[LRGE_C_N];
+    StageAcc() { memset(ms, 0, sizeof ms); memset(cn, 0, sizeof cn); }
+    void add(const lrge_hip_ctx *ctx) {
+        for (int i = 0; i < LRGE_T_N; ++i) ms[i] += ctx->ms[i];
+        for (int i = 0; i < LRGE_C_N; ++i) cn[i] = i == LRGE_C_LPG_SPLIT ? ctx->counters[i] : cn[i] + ctx->counters[i];
+    }
+    void store(lrge_hip_ctx *ctx) const { memcpy(ctx->ms, ms, sizeof ms); memcpy(ctx->counters, cn, sizeof cn); }
+};
+
+// two-set forward against one (unpartitioned) index, the queries in views if there are too many of them
+static int twoset_one_index(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries, const OverlapJob &job, StageAcc &acc) {
+    if (queries->total_bases <= stream_limit() || queries->n < 2) {
+        OverlapJob j = job;
+        int rc = run_overlap(ctx, ix, queries, j);
+        acc.add(ctx);
+        return rc;
+    }
+    const std::vector<u32> cuts = stream_cuts(queries);
+    for (size_t v = 0; v + 1 < cuts.size(); ++v) {
+        lrge_hip_seqset *view = nullptr;
+        int rc = seqset_view(ctx, queries, cuts[v], cuts[v + 1], &view);
+        if (rc) return rc;
+        OverlapJob j = job;
+        if (j.counts) j.counts += cuts[v];
+        if (j.has_map) j.has_map += cuts[v];
+        rc = run_overlap(ctx, ix, view, j);
+        acc.add(ctx);
+        lrge_hip_seqset_free(view);
+        if (rc) return rc;
+    }
+    return LRGE_OK;
+}
+
 extern "C" int lrge_hip_overlap_twoset(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries,
                                        const lrge_hip_params *p, uint32_t *counts, uint32_t *has_mapping) {
     int rc = check_common(ctx, ix, queries, /*parts_ok=*/true);
@@ -1603,25 +1654,26 @@ extern "C" int lrge_hip_overlap_twoset(lrge_hip_ctx *ctx, const lrge_hip_index *
     OverlapJob job; job.mode = MODE_TWOSET; job.dual = 1;
     job.prm = p ? *p : lrge_hip_params{0, 0.2f};
     job.counts = counts; job.has_map = has_mapping;
-    if (ix->parts.empty()) return run_overlap(ctx, ix, queries, job);
+    StageAcc acc;
+    if (ix->parts.empty()) {
+        rc = twoset_one_index(ctx, ix, queries, job, acc);
+        acc.store(ctx);
+        return rc;
+    }
     // partitioned index: the parts hold disjoint target reads, so a query's distinct-target count is the sum over the
     // parts and it has a mapping if it has one in any part; every part sees the same queries and the global mid_occ
     const u32 nq = queries->n;
     std::vector<u32> c((size_t)nq + 1), h((size_t)nq + 1);
     if (counts) std::fill(counts, counts + nq, 0u);
     if (has_mapping) std::fill(has_mapping, has_mapping + nq, 0u);
-    float ms_acc[LRGE_T_N]; u64 cn_acc[LRGE_C_N];
-    memset(ms_acc, 0, sizeof ms_acc); memset(cn_acc, 0, sizeof cn_acc);
     for (const lrge_hip_index *part : ix->parts) {
         OverlapJob pj = job;
         pj.counts = c.data(); pj.has_map = h.data();
-        rc = run_overlap(ctx, part, queries, pj);
+        rc = twoset_one_index(ctx, part, queries, pj, acc);
         if (rc) return rc;
         for (u32 q = 0; q < nq; ++q) { if (counts) counts[q] += c[q]; if (has_mapping) has_mapping[q] |= h[q]; }
-        for (int i = 0; i < LRGE_T_N; ++i) ms_acc[i] += ctx->ms[i];
-        for (int i = 0; i < LRGE_C_N; ++i) cn_acc[i] = i == LRGE_C_LPG_SPLIT ? ctx->counters[i] : cn_acc[i] + ctx->counters[i];
     }
-    memcpy(ctx->ms, ms_acc, sizeof ms_acc); memcpy(ctx->counters, cn_acc, sizeof cn_acc);
+    acc.store(ctx);
     return LRGE_OK;
 }
 
@@ -1633,7 +1685,27 @@ extern "C" int lrge_hip_overlap_inverse(lrge_hip_ctx *ctx, const lrge_hip_index 
     OverlapJob job; job.mode = MODE_INVERSE; job.dual = 1;
     job.prm = p ? *p : lrge_hip_params{0, 0.2f};
     job.counts = counts;
-    return run_overlap(ctx, ix, streamed, job);
+    if (streamed->total_bases <= stream_limit() || streamed->n < 2) return run_overlap(ctx, ix, streamed, job);
+    // the streamed (target) set in views: every streamed read adds one to the indexed reads it hits (twoset.rs:520-523)
+    const u32 n_ix = ix->seqs->n;
+    std::vector<u32> c((size_t)n_ix + 1);
+    if (counts) std::fill(counts, counts + n_ix, 0u);
+    StageAcc acc;
+    const std::vector<u32> cuts = stream_cuts(streamed);
+    for (size_t v = 0; v + 1 < cuts.size(); ++v) {
+        lrge_hip_seqset *view = nullptr;
+        rc = seqset_view(ctx, streamed, cuts[v], cuts[v + 1], &view);
+        if (rc) return rc;
+        OverlapJob j = job;
+        j.counts = c.data();
+        rc = run_overlap(ctx, ix, view, j);
+        acc.add(ctx);
+        lrge_hip_seqset_free(view);
+        if (rc) return rc;
+        if (counts) for (u32 i = 0; i < n_ix; ++i) counts[i] += c[i];
+    }
+    acc.store(ctx);
+    return LRGE_OK;
 }
 
 extern "C" int lrge_hip_overlap_ava(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *reads,

@@ -169,7 +169,7 @@ CONFIGS = {
     "c2_bact_twoset": dict(genome=4_400_000, seed=4401, platform="ont", mode="twoset", Q=5000, T=10000),
     "c3_yeast_ava": dict(genome=12_000_000, seed=1201, platform="ont", mode="ava", N=20000),
     "c4_dmel_twoset": dict(genome=143_000_000, seed=14301, platform="ont", mode="twoset", Q=50000, T=100000),
-    "c5_human_twoset": dict(genome=3_100_000_000, seed=31001, platform="hifi", mode="twoset", Q=100000, T=2000000),
+    "c5_human_twoset": dict(genome=3_100_000_000, seed=31001, platform="hifi", mode="twoset", Q=100000, T=2000000, parallel=True),
     # C5 at one tenth of its size: same coverage (10x targets), fits the 2^32-entry limits of this round
     "c5_human_tenth": dict(genome=310_000_000, seed=31001, platform="hifi", mode="twoset", Q=10000, T=200000),
     # C5 at one quarter: 7.9 Gbases of targets -> a partitioned index (2 parts at the default limit); drawn in parallel blocks

@@ -669,3 +669,41 @@ def test_partitioned_index_is_exact(ctx, oracle, tiny_ont, tiny_hifi, data, pres
     ixo = oracle.Index(oracle.ReadSet(ds.t.seqs(), ds.t.names), opt)
     rc, ec, eh = ixo.twoset_counts(oracle.ReadSet(ds.q.seqs(), ds.q.names), threads=8)
     assert np.array_equal(ref[False][0], ec) and ixo.mid_occ == ref_stats["mid_occ"]
+
+
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_streamed_set_in_views_is_exact(ctx, oracle, tiny_ont, tiny_hifi, preset, monkeypatch):
+    """A streamed set above LRGE_HIP_STREAM_BASES bases goes through in views (< 2^32 minimizers per pass): the queries of
+    a two-set run, the targets of an inverse (--use-min-ref) run.  Streamed reads are independent, so the result must not
+    change -- forced here with a few reads per view, alone and combined with a partitioned index."""
+    from lrge_amd import engine
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Qd, Td = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
+    ix = engine.Index(ctx, Td, PRESETS[preset])
+    ref = {F: ix.overlap_twoset(Qd, remove_internal=F) for F in (False, True)}
+    ix.free()
+    ixq = engine.Index(ctx, Qd, PRESETS[preset])                  # inverse: index = queries, targets streamed
+    ref_inv = {F: ixq.overlap_inverse(Td, remove_internal=F) for F in (False, True)}
+    assert int(ref[False][0].sum()) > 0 and int(ref_inv[False].sum()) > 0
+    qb, tb = int(ds.q.lens().sum()), int(ds.t.lens().sum())
+    for n_views in (2, 5, 13):
+        monkeypatch.setenv("LRGE_HIP_STREAM_BASES", str(tb // n_views + 1))
+        for F in (False, True):
+            assert np.array_equal(ixq.overlap_inverse(Td, remove_internal=F), ref_inv[F]), (n_views, F)
+        monkeypatch.setenv("LRGE_HIP_STREAM_BASES", str(qb // n_views + 1))
+        for part_bases in (None, tb // 3 + 1):
+            if part_bases:
+                monkeypatch.setenv("LRGE_HIP_PART_BASES", str(part_bases))
+            ixt = engine.Index(ctx, Td, PRESETS[preset])
+            for F in (False, True):
+                counts, has = ixt.overlap_twoset(Qd, remove_internal=F)
+                assert np.array_equal(counts, ref[F][0]) and np.array_equal(has, ref[F][1]), (n_views, part_bases, F)
+            ixt.free()
+            monkeypatch.delenv("LRGE_HIP_PART_BASES", raising=False)
+    ixq.free()
+    # the oracle agrees on the inverse counts
+    opt = oracle.make_opt(oracle.PRESET_AVA_PB if preset == "pb" else oracle.PRESET_AVA_ONT, dual=True)
+    ixo = oracle.Index(oracle.ReadSet(ds.q.seqs(), ds.q.names), opt)
+    rc, einv = ixo.inverse_counts(oracle.ReadSet(ds.t.seqs(), ds.t.names), threads=4)
+    assert np.array_equal(ref_inv[False], einv)

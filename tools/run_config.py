@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--preset", default=None, help="ont|pb (default: ont, like the reference CLI)")
     ap.add_argument("--check", type=int, default=32, help="reads spot-checked against the oracle (0 = none)")
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--inverse", action="store_true", help="--use-min-ref: index the query set, stream the targets (twoset.rs:596-599)")
     a = ap.parse_args()
     from lrge_amd import engine, synth
     cfg = synth.CONFIGS[a.config]
@@ -42,9 +43,17 @@ def main():
         best = None
         for _ in range(a.repeat):
             t1 = time.perf_counter()
-            ix = engine.Index(ctx, Td, preset)
-            tb = dict(ix.build_timings)
-            counts, has = ix.overlap_twoset(Qd)
+            if a.inverse:
+                Td.presketch(preset)
+                ix = engine.Index(ctx, Qd, preset)
+                tb = dict(ix.build_timings)
+                counts = ix.overlap_inverse(Td)
+                has = (counts > 0).astype(np.uint32)              # twoset.rs:545-569: no_mapping = indexed reads nobody hit
+            else:
+                Qd.presketch(preset)
+                ix = engine.Index(ctx, Td, preset)
+                tb = dict(ix.build_timings)
+                counts, has = ix.overlap_twoset(Qd)
             tm, cn, st = ctx.timings(), ctx.counters(), ix.stats()
             avg = np.float32(t.lens().sum()) / np.float32(t.n)
             est = ctx.estimates(counts, q.lens(), float(avg), t.n, 100)
@@ -56,16 +65,23 @@ def main():
         dt, tb, tm, cn, st, med, counts, has = best
         out.update(n_query=q.n, n_target=t.n, step_s=round(dt, 4), reads_per_s=round(q.n / dt, 1),
                    index_ms=round(tb["total"], 2), overlap_ms=round(tm["total"], 2),
-                   no_mapping=int((has == 0).sum()))
+                   no_mapping=int((has == 0).sum()), strategy="inverse (--use-min-ref)" if a.inverse else "forward")
         if a.check:
             from oracle import oracle as O
             opt = O.make_opt(O.PRESET_AVA_PB if preset else O.PRESET_AVA_ONT, dual=True)
             t1 = time.perf_counter()
-            ixo = O.Index(O.ReadSet(t.seqs(), t.names), opt)
-            sub = q.slice(0, min(a.check, q.n))
-            rc, ec, eh = ixo.twoset_counts(O.ReadSet(sub.seqs(), sub.names), threads=os.cpu_count())
-            out["oracle_check"] = {"reads": sub.n, "counts_equal": bool(np.array_equal(ec, counts[:sub.n])),
-                                   "mid_occ_equal": bool(ixo.mid_occ == st["mid_occ"]), "oracle_s": round(time.perf_counter() - t1, 1)}
+            if a.inverse:     # the whole target set has to stream through the oracle; the check is over the first `check` indexed reads
+                ixo = O.Index(O.ReadSet(q.seqs(), q.names), opt)
+                rc, einv = ixo.inverse_counts(O.ReadSet(t.seqs(), t.names), threads=os.cpu_count())
+                n = min(a.check, q.n)
+                out["oracle_check"] = {"reads": n, "counts_equal": bool(np.array_equal(einv[:n], counts[:n])), "all_equal": bool(np.array_equal(einv, counts)),
+                                       "mid_occ_equal": bool(ixo.mid_occ == st["mid_occ"]), "oracle_s": round(time.perf_counter() - t1, 1)}
+            else:
+                ixo = O.Index(O.ReadSet(t.seqs(), t.names), opt)
+                sub = q.slice(0, min(a.check, q.n))
+                rc, ec, eh = ixo.twoset_counts(O.ReadSet(sub.seqs(), sub.names), threads=os.cpu_count())
+                out["oracle_check"] = {"reads": sub.n, "counts_equal": bool(np.array_equal(ec, counts[:sub.n])),
+                                       "mid_occ_equal": bool(ixo.mid_occ == st["mid_occ"]), "oracle_s": round(time.perf_counter() - t1, 1)}
     else:
         reads = q
         t1 = time.perf_counter()

@@ -65,7 +65,10 @@ def main():
         dt, tb, tm, cn, st, med, counts, has = best
         out.update(n_query=q.n, n_target=t.n, step_s=round(dt, 4), reads_per_s=round(q.n / dt, 1),
                    index_ms=round(tb["total"], 2), overlap_ms=round(tm["total"], 2),
-                   no_mapping=int((has == 0).sum()), strategy="inverse (--use-min-ref)" if a.inverse else "forward")
+                   no_mapping=int((has == 0).sum()), strategy="inverse (--use-min-ref)" if a.inverse else "forward",
+                   mid_occ=st["mid_occ"], estimate=None if med[1] is None else float(med[1]),
+                   stage_ms={**{"index_" + k: round(v, 2) for k, v in tb.items() if v and k != "total"}, **{k: round(v, 2) for k, v in tm.items() if v}})
+        print("[run_config] device part done:", json.dumps(out), file=sys.stderr, flush=True)     # survives a slow / killed oracle check
         if a.check:
             from oracle import oracle as O
             opt = O.make_opt(O.PRESET_AVA_PB if preset else O.PRESET_AVA_ONT, dual=True)

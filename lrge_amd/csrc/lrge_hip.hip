@@ -609,7 +609,11 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         if (P.max_mid_occ > P.min_mid_occ && thres > P.max_mid_occ) thres = P.max_mid_occ;
         ix->mid_occ = thres;
     }
-    ix->d_pos = spos; ix->d_skey = skey; sc.keep(spos); if (skey != spos) sc.keep(skey);
+    // the sorted hashes of the (hash, y) pair layout are only read again by index_dump (tests); a part of a partitioned index
+    // cannot be dumped and is short of memory, so it gives them back (8 of its 16 bytes per minimizer)
+    ix->d_pos = spos; sc.keep(spos);
+    if (skey != spos && targets->is_view) { ix->d_skey = nullptr; }          // stays with `sc`: released at scope exit
+    else { ix->d_skey = skey; if (skey != spos) sc.keep(skey); }
     ix->pk_pos1 = pk ? pk_pos1 : 0; ix->pk_ybits = pk_ybits;
     t_total.stop();
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -755,7 +759,7 @@ extern "C" void lrge_hip_index_free(lrge_hip_index *ix) {
         delete ix;
         return;
     }
-    ix->ctx->pool.release(ix->d_pos); if (ix->d_skey != ix->d_pos) ix->ctx->pool.release(ix->d_skey);
+    ix->ctx->pool.release(ix->d_pos); if (ix->d_skey && ix->d_skey != ix->d_pos) ix->ctx->pool.release(ix->d_skey);
     ix->ctx->pool.release(ix->d_ht);
     delete ix;
 }

@@ -142,8 +142,15 @@ def sample_reads(genome, n, platform="ont", seed=1, name_prefix="r", name_start=
 
 
 def _block(args):
-    genome, nb, platform, seed, prefix, start, n_rate = args
-    return sample_reads(genome, nb, platform, seed=seed, name_prefix=prefix, name_start=start, n_rate=n_rate)
+    genome, nb, platform, seed, prefix, start, n_rate, spill = args
+    rb = sample_reads(genome, nb, platform, seed=seed, name_prefix=prefix, name_start=start, n_rate=n_rate)
+    if spill is None:
+        return rb
+    # large sets: hand the arrays over through tmpfs files instead of pickling gigabytes through the pool's pipes
+    path = "%s/blk_%010d" % (spill, start)
+    np.save(path + "_b.npy", rb.bases); np.save(path + "_o.npy", rb.offsets)
+    np.save(path + "_s.npy", np.stack([rb.starts, rb.ends, rb.strands.astype(np.int64)]))
+    return path, rb.names
 
 
 def sample_reads_parallel(genome, n, platform="ont", seed=1, name_prefix="r", block=4096, procs=None):
@@ -151,16 +158,31 @@ def sample_reads_parallel(genome, n, platform="ont", seed=1, name_prefix="r", bl
     block b with seed + 1000003 * b (so the set depends on (seed, block) but not on the number of processes)."""
     import multiprocessing as mp
     import os
-    jobs = [(genome, min(block, n - s0), platform, seed + 1000003 * (s0 // block), name_prefix, s0, 0.0) for s0 in range(0, n, block)]
-    procs = procs or min(len(jobs), max(1, (os.cpu_count() or 2) // 2), 64)
-    with mp.get_context("fork").Pool(procs) as pool:
-        parts = pool.map(_block, jobs, chunksize=1)
-    lens = np.concatenate([p.lens() for p in parts])
-    offsets = np.zeros(n + 1, dtype=np.uint64)
-    np.cumsum(lens, out=offsets[1:])
-    return ReadBatch(np.concatenate([p.bases for p in parts]), offsets, [nm for p in parts for nm in p.names],
-                     np.concatenate([p.starts for p in parts]), np.concatenate([p.ends for p in parts]),
-                     np.concatenate([p.strands for p in parts]))
+    import shutil
+    import tempfile
+    spill = tempfile.mkdtemp(prefix="lrge_synth_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        jobs = [(genome, min(block, n - s0), platform, seed + 1000003 * (s0 // block), name_prefix, s0, 0.0, spill) for s0 in range(0, n, block)]
+        procs = procs or min(len(jobs), max(1, (os.cpu_count() or 2) // 2), 96)
+        with mp.get_context("fork").Pool(procs) as pool:
+            res = pool.map(_block, jobs, chunksize=1)
+        offs = [np.load(p + "_o.npy") for p, _ in res]
+        lens = np.concatenate([np.diff(o).astype(np.int64) for o in offs])
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offsets[1:])
+        bases = np.empty(int(offsets[-1]), dtype=np.uint8)
+        pos = 0
+        meta = []
+        for (p, _), o in zip(res, offs):
+            b = np.load(p + "_b.npy")
+            bases[pos:pos + len(b)] = b
+            pos += len(b)
+            meta.append(np.load(p + "_s.npy"))
+        meta = np.concatenate(meta, axis=1)
+        names = [nm for _, nms in res for nm in nms]
+        return ReadBatch(bases, offsets, names, meta[0], meta[1], meta[2].astype(np.int8))
+    finally:
+        shutil.rmtree(spill, ignore_errors=True)
 
 
 # The five BASELINE.json configs (SURVEY.md section 8d).  "twoset": first Q reads are queries, the

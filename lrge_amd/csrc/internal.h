@@ -54,10 +54,11 @@ struct DevPool {
         void *p = nullptr;
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {  // drop the cache and retry once
+            (void)hipGetLastError();          // the failed attempt must not linger as the "last error" of a later launch check
             trim();
             e = hipMalloc(&p, bytes);
         }
-        if (e != hipSuccess) { *err = e; return nullptr; }
+        if (e != hipSuccess) { (void)hipGetLastError(); *err = e; return nullptr; }
         blks.push_back({p, bytes, true});
         total += bytes;
         return p;

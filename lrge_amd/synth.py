@@ -196,6 +196,7 @@ CONFIGS = {
     "c5_human_tenth": dict(genome=310_000_000, seed=31001, platform="hifi", mode="twoset", Q=10000, T=200000),
     # C5 at one quarter: 7.9 Gbases of targets -> a partitioned index (2 parts at the default limit); drawn in parallel blocks
     "c5_human_quarter": dict(genome=775_000_000, seed=31001, platform="hifi", mode="twoset", Q=25000, T=500000, parallel=True),
+    "c5_human_half": dict(genome=1_550_000_000, seed=31001, platform="hifi", mode="twoset", Q=50000, T=1000000, parallel=True),
     # C2 on a repeat-rich genome (15 % interspersed 300-bp / 6-kb families, 2 % short tandem repeats): robustness run
     "c2_repeats": dict(genome=4_400_000, seed=4402, platform="ont", mode="twoset", Q=5000, T=10000, repeats=0.15, tandem=0.02),
     # reduced cases for tests / smoke

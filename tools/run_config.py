@@ -32,6 +32,7 @@ def main():
     t0 = time.perf_counter()
     gsize, q, t = synth.make_config(a.config, a.scale)
     t_gen = time.perf_counter() - t0
+    print("[run_config] data generated in %.1f s" % t_gen, file=sys.stderr, flush=True)
     ctx = engine.Context(0)
     out = {"config": a.config, "scale": a.scale, "preset": "ava-pb" if preset else "ava-ont", "mode": cfg["mode"],
            "genome_size_true": gsize, "data_gen_s": round(t_gen, 1)}
@@ -40,6 +41,7 @@ def main():
         qr, tr = engine.name_ranks(q.names, t.names)
         Qd, Td = ctx.upload(q.bases, q.offsets, qr), ctx.upload(t.bases, t.offsets, tr)
         out["upload_s"] = round(time.perf_counter() - t1, 3)
+        print("[run_config] uploaded in %.1f s" % out["upload_s"], file=sys.stderr, flush=True)
         best = None
         for _ in range(a.repeat):
             t1 = time.perf_counter()

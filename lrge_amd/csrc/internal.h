@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -52,7 +53,11 @@ struct DevPool {
             if (!blks[i].used && blks[i].cap >= bytes && (best < 0 || blks[i].cap < blks[best].cap)) best = (int)i;
         if (best >= 0 && blks[best].cap <= bytes * 2 + (1 << 20)) { blks[best].used = true; return blks[best].p; }
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, bytes);
+        // test hook: every n-th miss asks for an impossible size first, i.e. takes the genuine failure + retry path
+        static const long fail_every = getenv("LRGE_HIP_DEBUG_ALLOC_FAIL_EVERY") ? atol(getenv("LRGE_HIP_DEBUG_ALLOC_FAIL_EVERY")) : 0;
+        static long misses = 0;
+        const bool sabotage = fail_every > 0 && (++misses % fail_every) == 0;
+        hipError_t e = hipMalloc(&p, sabotage ? ((size_t)1 << 60) : bytes);
         if (e != hipSuccess) {  // drop the cache and retry once
             (void)hipGetLastError();          // the failed attempt must not linger as the "last error" of a later launch check
             trim();

@@ -711,3 +711,36 @@ def test_streamed_set_in_views_is_exact(ctx, oracle, tiny_ont, tiny_hifi, preset
     ixo = oracle.Index(oracle.ReadSet(ds.q.seqs(), ds.q.names), opt)
     rc, einv = ixo.inverse_counts(oracle.ReadSet(ds.t.seqs(), ds.t.names), threads=4)
     assert np.array_equal(ref_inv[False], einv)
+
+
+def test_allocator_retry_leaves_no_stale_error(tiny_ont):
+    """Under memory pressure the pool's first hipMalloc fails, the cache is trimmed and the retry succeeds -- the failed
+    attempt must not surface later as the "last error" of a launch check (it did, at C5: the overlap call of a run whose
+    8-part index had been built stopped with "out of memory").  LRGE_HIP_DEBUG_ALLOC_FAIL_EVERY makes every third pool miss
+    take that path for real (an impossible request first); it is read once per process, so this runs in a child."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np
+from lrge_amd import engine, synth
+g, q, t = synth.make_config("tiny_twoset")
+ctx = engine.Context(0)
+qr, tr = engine.name_ranks(q.names, t.names)
+Qd, Td = ctx.upload(q.bases, q.offsets, qr), ctx.upload(t.bases, t.offsets, tr)
+out = []
+for it in range(4):
+    ix = engine.Index(ctx, Td, 0)
+    out.append(ix.overlap_twoset(Qd)[0].copy())
+    ix.free()
+assert all(np.array_equal(out[0], o) for o in out)
+print("SUM", int(out[0].sum()))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = []
+    for env_extra in ({}, {"LRGE_HIP_DEBUG_ALLOC_FAIL_EVERY": "3"}):
+        env = dict(os.environ, PYTHONPATH=root, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        sums.append([l for l in r.stdout.splitlines() if l.startswith("SUM")][0])
+    assert sums[0] == sums[1] and int(sums[0].split()[1]) > 0

@@ -102,6 +102,11 @@ int  lrge_hip_device_count(int *n);
 int  lrge_hip_ctx_create(int device, lrge_hip_ctx **out);
 void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx);
 const char *lrge_hip_last_error(const lrge_hip_ctx *ctx);
+/* Tuning / test options of a context (names and meanings: INTEGRATION.md section 6).  They are read from the environment
+   exactly once, when the context is created (LRGE_HIP_<NAME>=value), and can be changed here afterwards; value NULL clears
+   an option.  No entry point reads the environment per call.  The DEBUG_* options (fault injection, overrides of
+   minimap2's chaining heuristics for the parity tests) are accepted through this call only, never from the environment. */
+int  lrge_hip_ctx_set_option(lrge_hip_ctx *ctx, const char *name, const char *value);
 
 /*
  * Upload a read set and pack it 2-bit (+ ambiguity mask) in HBM.

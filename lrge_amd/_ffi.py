@@ -19,7 +19,7 @@ C_NAMES = ["query_bases", "query_minimizers", "anchors", "groups", "groups_chain
            "rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "lpg_split"]
 
 EXPORTS = [
-    "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error",
+    "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error", "lrge_hip_ctx_set_option",
     "lrge_hip_seqset_upload", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch",
     "lrge_hip_index_build", "lrge_hip_index_free", "lrge_hip_index_stats",
     "lrge_hip_overlap_twoset", "lrge_hip_overlap_inverse", "lrge_hip_overlap_ava", "lrge_hip_chains",
@@ -65,6 +65,7 @@ def lib():
     L.lrge_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.lrge_hip_ctx_destroy.argtypes = [vp]
     L.lrge_hip_ctx_destroy.restype = None
+    L.lrge_hip_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.lrge_hip_seqset_upload.argtypes = [vp, vp, vp, C.c_uint32, vp, C.POINTER(vp)]
     L.lrge_hip_seqset_free.argtypes = [vp]
     L.lrge_hip_seqset_free.restype = None

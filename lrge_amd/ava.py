@@ -63,8 +63,12 @@ class AvaStrategy(Estimate):
     # ava.rs:369-382 + :165-366
     def generate_estimates(self):
         rn, rs, sum_len = self.subsample_reads()
-        preset = PLATFORM_PRESET[self.platform]
+        try:
+            preset = PLATFORM_PRESET[self.platform]
+        except KeyError:
+            raise LrgeError("InvalidPlatform", self.platform)
         ctx = engine.Context(self.device)
+        R = ix = None
         try:
             (ranks,) = engine.name_ranks(rn)
             R = ctx.upload(*readio.pack(rs), ranks)
@@ -85,4 +89,7 @@ class AvaStrategy(Estimate):
                 log.info("%d (%.2f%%) read(s) did not overlap any other reads", no_mapping, 100.0 * no_mapping / self.num_reads)
             return est, no_mapping
         finally:
+            for h in (ix, R):             # handles go before their context
+                if h is not None:
+                    h.free()
             ctx.close()

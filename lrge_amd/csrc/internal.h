@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -45,6 +46,7 @@ struct DevPool {
     struct Blk { void *p; size_t cap; bool used; };
     std::vector<Blk> blks;
     size_t total = 0;
+    long fail_every = 0, misses = 0;
     void *alloc(size_t bytes, hipError_t *err) {
         if (bytes == 0) bytes = 256;
         bytes = (bytes + 255) & ~(size_t)255;
@@ -53,9 +55,8 @@ struct DevPool {
             if (!blks[i].used && blks[i].cap >= bytes && (best < 0 || blks[i].cap < blks[best].cap)) best = (int)i;
         if (best >= 0 && blks[best].cap <= bytes * 2 + (1 << 20)) { blks[best].used = true; return blks[best].p; }
         void *p = nullptr;
-        // test hook: every n-th miss asks for an impossible size first, i.e. takes the genuine failure + retry path
-        static const long fail_every = getenv("LRGE_HIP_DEBUG_ALLOC_FAIL_EVERY") ? atol(getenv("LRGE_HIP_DEBUG_ALLOC_FAIL_EVERY")) : 0;
-        static long misses = 0;
+        // test hook (option DEBUG_ALLOC_FAIL_EVERY, per context, set by lrge_hip_ctx_set_option only): every n-th miss asks
+        // for an impossible size first, i.e. takes the genuine failure + retry path
         const bool sabotage = fail_every > 0 && (++misses % fail_every) == 0;
         hipError_t e = hipMalloc(&p, sabotage ? ((size_t)1 << 60) : bytes);
         if (e != hipSuccess) {  // drop the cache and retry once
@@ -88,6 +89,10 @@ struct lrge_hip_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     DevPool pool;
+    // options: LRGE_HIP_<NAME> from the environment at creation, lrge_hip_ctx_set_option afterwards (never read per call)
+    std::map<std::string, std::string> opts;
+    const char *opt(const char *name) const { auto it = opts.find(name); return it == opts.end() ? nullptr : it->second.c_str(); }
+    u64 opt_u64(const char *name, u64 dflt) const { const char *v = opt(name); return (v && *v) ? strtoull(v, nullptr, 10) : dflt; }
     float ms[LRGE_T_N];
     u64 counters[LRGE_C_N];
     int n_cu = 256;

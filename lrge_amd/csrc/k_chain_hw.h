@@ -11,7 +11,7 @@
 // Everything rare (candidates beyond the 32-anchor window, long max_ii rescans) and the backtrack run
 // per half through the same out-of-line / wave-wide code k_chain_reg uses.
 #pragma once
-#include "k_chain_reg.h"
+#include "k_chain_common.h"
 
 struct HwChainArgs {
     const u64 *akey, *aval;

@@ -288,37 +288,4 @@ __global__ void k_query_paf_stats(const u64 *__restrict__ qx, const u64 *__restr
 // ------------------------------------------------------------------------------------------
 // (group boundaries: compact_heads() in k_prims.h on key >> bits_rpos)
 
-#define N_BINS 5
-#define GB_CHUNK 8192   // groups per block in k_group_bin
-struct BinLimits { u32 lim[N_BINS]; };  // bin b holds groups with n <= lim[b] (last = unbounded)
-
-__global__ void k_group_bin(const u32 *__restrict__ gstart, u32 n_groups, u64 n_anchors, u32 min_n, BinLimits bl,
-                            u32 *__restrict__ bin_count, u32 *__restrict__ bin_list /* [N_BINS][n_groups] */,
-                            unsigned long long *__restrict__ bin_anchors) {
-    // Each block owns a contiguous chunk of GB_CHUNK groups: count per bin in LDS, reserve the list
-    // slots with ONE global atomic per (block, bin) -- every block hits the same N_BINS addresses, so
-    // the block count sets the serialised cost -- then fill.  Order inside a bin is irrelevant.
-    __shared__ u32 lcnt[N_BINS], lbase[N_BINS], lfill[N_BINS];
-    __shared__ unsigned long long lanch[N_BINS];
-    if (threadIdx.x < N_BINS) { lcnt[threadIdx.x] = 0; lfill[threadIdx.x] = 0; lanch[threadIdx.x] = 0; }
-    __syncthreads();
-    const u64 c0 = (u64)blockIdx.x * GB_CHUNK;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (u64 gg = c0 + threadIdx.x; gg < c0 + GB_CHUNK && gg < n_groups; gg += blockDim.x) {
-            const u32 g = (u32)gg;
-            const u64 e = (g + 1 < n_groups) ? gstart[g + 1] : n_anchors;
-            const u32 n = (u32)(e - gstart[g]);
-            if (n < min_n) continue;
-            int b = N_BINS - 1;
-            for (int t = N_BINS - 2; t >= 0; --t) if (n <= bl.lim[t]) b = t;
-            if (pass == 0) { atomicAdd(&lcnt[b], 1u); atomicAdd(&lanch[b], (unsigned long long)n); }
-            else bin_list[(u64)b * n_groups + lbase[b] + atomicAdd(&lfill[b], 1u)] = g;
-        }
-        __syncthreads();
-        if (pass == 0 && threadIdx.x < N_BINS && lcnt[threadIdx.x]) {
-            lbase[threadIdx.x] = atomicAdd(&bin_count[threadIdx.x], lcnt[threadIdx.x]);
-            atomicAdd(&bin_anchors[threadIdx.x], lanch[threadIdx.x]);
-        }
-        __syncthreads();
-    }
-}
+#define GB_CHUNK 8192   // groups per block in k_group_fill

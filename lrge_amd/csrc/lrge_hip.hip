@@ -15,7 +15,7 @@
 #include "k_index.h"
 #include "k_seed.h"
 #include "k_chain.h"
-#include "k_chain_reg.h"
+#include "k_chain_common.h"
 #include "k_chain_hw.h"
 #include "k_chain_lpg.h"
 #include "../../include/lrge_rand.hpp"
@@ -24,10 +24,27 @@ static thread_local std::string g_last_error;  // failures that happen before a 
 static std::mutex g_live_mu;
 static std::set<lrge_hip_ctx *> g_live_ctx;   // contexts that have not been destroyed
 
-static u64 env_u64(const char *name, u64 dflt) {
-    const char *v = getenv(name);
-    if (!v || !*v) return dflt;
-    return strtoull(v, nullptr, 10);
+extern char **environ;
+
+// Tuning / test options of a context (internal.h: lrge_hip_ctx::opts).  Read from the environment ONCE, when the context
+// is created (LRGE_HIP_<NAME>=value; INTEGRATION.md section 6 lists them), and settable afterwards through
+// lrge_hip_ctx_set_option.  The DEBUG_* options change results or inject failures on purpose (parity tests drive rarely
+// taken paths with them): they are never read from the environment, only the explicit call sets them.
+static void load_env_options(lrge_hip_ctx *ctx) {
+    for (char **e = environ; e && *e; ++e) {
+        if (strncmp(*e, "LRGE_HIP_", 9) != 0 || strncmp(*e, "LRGE_HIP_DEBUG_", 15) == 0) continue;
+        const char *eq = strchr(*e, '=');
+        if (!eq) continue;
+        ctx->opts[std::string(*e + 9, (size_t)(eq - (*e + 9)))] = std::string(eq + 1);
+    }
+}
+
+extern "C" int lrge_hip_ctx_set_option(lrge_hip_ctx *ctx, const char *name, const char *value) {
+    if (!ctx || !name || !*name) return LRGE_ERR_INVALID;
+    if (value) ctx->opts[name] = value; else ctx->opts.erase(name);
+    if (!strcmp(name, "DEBUG_ALLOC_FAIL_EVERY")) { ctx->pool.fail_every = value ? atol(value) : 0; ctx->pool.misses = 0; }
+    if (!strcmp(name, "TIMERS") && value) ctx->timer_level = atoi(value);
+    return LRGE_OK;
 }
 
 extern "C" const char *lrge_hip_version(void) { return "lrge_hip 0.1.0 (gfx950)"; }
@@ -52,7 +69,7 @@ __global__ void k_spin_ticks(long long ticks, u32 *sink) {
 }
 static hipError_t pick_side_stream(lrge_hip_ctx *ctx) {
     ctx->stream2 = nullptr;
-    if (getenv("LRGE_HIP_NO_STREAM_PROBE")) return hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (ctx->opt("NO_STREAM_PROBE")) return hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     const long long ticks = 4000;                        // 40 us
     auto run_pair = [&](hipStream_t a, hipStream_t b) -> double {
         (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b);
@@ -91,6 +108,7 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     }
     lrge_hip_ctx *ctx = new lrge_hip_ctx();
     ctx->device = device;
+    load_env_options(ctx);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         pick_side_stream(ctx) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -113,7 +131,7 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
     memset(ctx->counters, 0, sizeof(ctx->counters));
-    if (getenv("LRGE_HIP_TIMERS")) ctx->timer_level = atoi(getenv("LRGE_HIP_TIMERS"));
+    if (ctx->opt("TIMERS")) ctx->timer_level = atoi(ctx->opt("TIMERS"));
     { std::lock_guard<std::mutex> g(g_live_mu); g_live_ctx.insert(ctx); }
     *out = ctx;
     return LRGE_OK;
@@ -291,8 +309,8 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     const u64 slot_bytes = (u64)n_chunks * SK_CAP * 8 * (pk ? 1 : 2);
     size_t mfree = (size_t)64 << 30, mtot = 0;
     if (slot_bytes > ((u64)4 << 30)) (void)hipMemGetInfo(&mfree, &mtot);       // (small sets: no need to ask)
-    bool one_pass = n_chunks && !getenv("LRGE_HIP_SKETCH_TWO_PASS") && slot_bytes < ((u64)mfree + ctx->pool.total) / 4;
-    const char *cap_env = getenv("LRGE_HIP_DEBUG_SK_CAP");                      // tests: force the overflow fallback
+    bool one_pass = n_chunks && !ctx->opt("SKETCH_TWO_PASS") && slot_bytes < ((u64)mfree + ctx->pool.total) / 4;
+    const char *cap_env = ctx->opt("DEBUG_SK_CAP");                      // tests: force the overflow fallback
     const u32 sk_cap = cap_env ? (u32)std::min<u64>(strtoull(cap_env, nullptr, 10), SK_CAP) : (u32)SK_CAP;
     u64 *tx = nullptr, *ty = nullptr;
     if (one_pass) {
@@ -412,7 +430,7 @@ static int presketch_start_pending(lrge_hip_ctx *ctx) {
     lrge_hip_seqset *s = ctx->presk_pending;
     if (!s) return LRGE_OK;
     ctx->presk_pending = nullptr;
-    if (s->total_bases > env_u64("LRGE_HIP_STREAM_BASES", 4000000000ull)) return LRGE_OK;   // streamed in views: sketched per view
+    if (s->total_bases > ctx->opt_u64("STREAM_BASES", 4000000000ull)) return LRGE_OK;   // streamed in views: sketched per view
     if (s->presk) presketch_discard(s);
     PreSketch *p = new PreSketch();
     p->preset = ctx->presk_preset;
@@ -468,6 +486,10 @@ extern "C" int lrge_hip_sketch_dump(lrge_hip_ctx *ctx, const lrge_hip_seqset *s,
 // ------------------------------------------------------------------------------------------
 // index
 // ------------------------------------------------------------------------------------------
+extern "C" void lrge_hip_index_free(lrge_hip_index *ix);
+struct IndexFree { void operator()(lrge_hip_index *ix) const { lrge_hip_index_free(ix); } };
+typedef std::unique_ptr<lrge_hip_index, IndexFree> IndexGuard;     // every early return releases what the index holds so far
+
 static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_index **out) {
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -480,18 +502,18 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     Preset P = make_preset(preset);
     // test-only overrides of two chaining heuristics, so that parity tests can drive the rarely taken
     // paths (no max_skip break -> candidates beyond the register window; tight max_iter clamp)
-    P.max_skip = (int)env_u64("LRGE_HIP_DEBUG_MAX_SKIP", (u64)P.max_skip);
-    P.max_iter = (int)env_u64("LRGE_HIP_DEBUG_MAX_ITER", (u64)P.max_iter);
+    P.max_skip = (int)ctx->opt_u64("DEBUG_MAX_SKIP", (u64)P.max_skip);
+    P.max_iter = (int)ctx->opt_u64("DEBUG_MAX_ITER", (u64)P.max_iter);
     // Index entries are packed into one u64 -- hash << ybits | rid << pos1 | (pos << 1 | strand) -- whenever that
     // fits (2k + bits(rid) + bits(pos) + 1 <= 64: ava-ont always in practice, ava-pb for small read sets): half the
     // bytes through the sort, the table build and the lookups, and 8 instead of 16 bytes per entry resident in HBM.
     const u32 pk_pos1 = std::max<u32>(1, ceil_log2_u64((u64)targets->max_len + 1)) + 1;
     const u32 pk_rid = std::max<u32>(1, ceil_log2_u64((u64)targets->n + 1));
-    const bool pk = 2 * (u32)P.k + pk_rid + pk_pos1 <= 64 && !env_u64("LRGE_HIP_NO_PACKED_INDEX", 0);
+    const bool pk = 2 * (u32)P.k + pk_rid + pk_pos1 <= 64 && !ctx->opt_u64("NO_PACKED_INDEX", 0);
     const u32 pk_ybits = pk ? pk_rid + pk_pos1 : 0;
     SketchOut so;
     int rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits);
-    if (rc == LRGE_OK && !getenv("LRGE_HIP_NO_PRESKETCH")) rc = presketch_start_pending(ctx);
+    if (rc == LRGE_OK && !ctx->opt("NO_PRESKETCH")) rc = presketch_start_pending(ctx);
     if (rc) return rc;
     sc.drop(so.mz_off);
     const u64 M = so.n;
@@ -521,6 +543,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     }
 
     lrge_hip_index *ix = new lrge_hip_index();
+    IndexGuard ix_guard(ix);
     ix->ctx = ctx; ix->seqs = targets; ix->preset_id = preset; ix->P = P; ix->n_mz = M;
     u32 n_runs = 0;
     const u32 max_bin = (u32)P.max_mid_occ + 1;
@@ -530,7 +553,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         u32 *d_runstart = nullptr;
         if (M) {
             rc = compact_heads(ctx, sc, skey, M, pk_ybits, &d_runstart, &n_runs);    // runs of equal hash
-            if (rc) { delete ix; return rc; }
+            if (rc) return rc;
         }
 #ifndef HT_CAP_NUM
 #define HT_CAP_NUM 2       // home slots per distinct key = HT_CAP_NUM / HT_CAP_DEN
@@ -540,11 +563,11 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         // tables of all parts are resident together and memory, not probe length (+15 % lookup time), is what binds there
         u64 cap = targets->is_view ? (u64)n_runs * 5 / 4 : (u64)n_runs * HT_CAP_NUM / HT_CAP_DEN;
         if (cap < 1024) cap = 1024;
-        if (cap + n_runs >= (1ULL << 32)) { delete ix; LRGE_SET_ERR(ctx, "index limited to < 2^32/3 distinct minimizers (got %u)", n_runs); return LRGE_ERR_TOO_MANY; }
+        if (cap + n_runs >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32/3 distinct minimizers (got %u)", n_runs); return LRGE_ERR_TOO_MANY; }
         ix->ht_cap = cap;
         ix->n_keys = n_runs;
         u32 *d_occ = sc.get<u32>((size_t)max_bin + 2);     // [max_bin + 1] = overflow flag
-        if (!d_occ) { delete ix; return LRGE_ERR_DEVICE; }
+        if (!d_occ) return LRGE_ERR_DEVICE;
         u64 *ht = nullptr;
         occ.assign((size_t)max_bin + 1, 0);
         const size_t head_bins = std::min<size_t>(4096, (size_t)max_bin + 1);
@@ -555,13 +578,13 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             const u64 n_slots = cap + slack;
             ix->ht_slots = n_slots;
             ht = sc.get<u64>(2 * n_slots);
-            if (!ht) { delete ix; return LRGE_ERR_DEVICE; }
+            if (!ht) return LRGE_ERR_DEVICE;
             HIPCHK(ctx, hipMemsetAsync(ht, 0xFF, 2 * n_slots * 8, ctx->stream));   // key = HT_EMPTY
             HIPCHK(ctx, hipMemsetAsync(d_occ, 0, ((size_t)max_bin + 2) * 4, ctx->stream));
             if (n_runs) {
                 const u32 n_tiles = (u32)div_up(n_runs, PLACE_TILE);
                 u32 *bmax = sc.get<u32>((size_t)n_tiles + 1);
-                if (!bmax) { delete ix; return LRGE_ERR_DEVICE; }
+                if (!bmax) return LRGE_ERR_DEVICE;
                 hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax, pk_ybits);
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_scan, dim3(1), dim3(1024), 0, ctx->stream, bmax, n_tiles);
@@ -579,7 +602,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
             if (!overflow) break;
             sc.drop(ht); ht = nullptr;
-            if (attempt == 1) { delete ix; LRGE_SET_ERR(ctx, "index table placement overflowed%s", ""); return LRGE_ERR_DEVICE; }
+            if (attempt == 1) { LRGE_SET_ERR(ctx, "index table placement overflowed%s", ""); return LRGE_ERR_DEVICE; }
         }
         {
             const u32 kth = n_runs ? (u32)((1. - (double)P.mid_occ_frac) * (double)n_runs) : 0;
@@ -618,7 +641,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     t_total.stop();
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->resolve_timers();
-    *out = ix;
+    *out = ix_guard.release();
     return LRGE_OK;
 }
 
@@ -654,8 +677,6 @@ static int seqset_view(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, u32 r0, u32 
     return LRGE_OK;
 }
 
-extern "C" void lrge_hip_index_free(lrge_hip_index *ix);
-
 // mm_idx_reader_read with batch_size = max (aligner.rs:112-122) makes ONE index whatever the size of the target file.
 // Here a target set above LRGE_HIP_PART_BASES bases (default 4e9: the 2^32-entry limits of one part) is indexed in parts
 // over views of the set; the occurrence statistics are then taken over all parts together (k_part_global_occ), mid_occ
@@ -665,7 +686,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     if (!ctx || !targets || !out) return LRGE_ERR_INVALID;
     if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
     *out = nullptr;
-    const u64 part_bases = env_u64("LRGE_HIP_PART_BASES", 4000000000ull);
+    const u64 part_bases = ctx->opt_u64("PART_BASES", 4000000000ull);
     if (targets->total_bases <= part_bases || targets->n < 2 || targets->is_view) return index_build_one(ctx, targets, preset, out);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // cut by reads, every part at most part_bases bases (a single longer read gets a part of its own)
@@ -679,18 +700,18 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     const int np = (int)cuts.size() - 1;
     if (np > MAX_INDEX_PARTS) { LRGE_SET_ERR(ctx, "target set needs %d index parts (limit %d)", np, MAX_INDEX_PARTS); return LRGE_ERR_TOO_MANY; }
     lrge_hip_index *top = new lrge_hip_index();
+    IndexGuard top_guard(top);
     top->ctx = ctx; top->seqs = targets; top->preset_id = preset;
     float ms_acc[LRGE_T_N]; u64 cn_acc[LRGE_C_N];
     memset(ms_acc, 0, sizeof ms_acc); memset(cn_acc, 0, sizeof cn_acc);
-    auto fail = [&](int rc) { lrge_hip_index_free(top); return rc; };
     for (int p = 0; p < np; ++p) {
         lrge_hip_seqset *v = nullptr;
         int rc = seqset_view(ctx, targets, cuts[p], cuts[p + 1], &v);
-        if (rc) return fail(rc);
+        if (rc) return rc;
         top->part_sets.push_back(v); top->part_r0.push_back(cuts[p]);
         lrge_hip_index *ixp = nullptr;
         rc = index_build_one(ctx, v, preset, &ixp);
-        if (rc) return fail(rc);
+        if (rc) return rc;
         top->parts.push_back(ixp);
         top->n_mz += ixp->n_mz;
         for (int i = 0; i < LRGE_T_N; ++i) ms_acc[i] += ctx->ms[i];
@@ -706,7 +727,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     Scratch sc(ctx);
     ALLOC_OR_FAIL(d_hist, sc, u32, (size_t)max_bin + 1);
     unsigned long long *d_nd = (unsigned long long *)sc.get<u64>(1);
-    if (!d_nd) return fail(LRGE_ERR_DEVICE);
+    if (!d_nd) return LRGE_ERR_DEVICE;
     HIPCHK(ctx, hipMemsetAsync(d_hist, 0, ((size_t)max_bin + 1) * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(d_nd, 0, 8, ctx->stream));
     PartTables T; T.n = np;
@@ -747,7 +768,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     ctx->resolve_timers();
     ms_acc[LRGE_T_INDEX_TABLE] += ctx->ms[LRGE_T_INDEX_TABLE]; ms_acc[LRGE_T_TOTAL] += ctx->ms[LRGE_T_INDEX_TABLE];
     memcpy(ctx->ms, ms_acc, sizeof ms_acc); memcpy(ctx->counters, cn_acc, sizeof cn_acc);
-    *out = top;
+    *out = top_guard.release();
     return LRGE_OK;
 }
 
@@ -759,8 +780,12 @@ extern "C" void lrge_hip_index_free(lrge_hip_index *ix) {
         delete ix;
         return;
     }
-    ix->ctx->pool.release(ix->d_pos); if (ix->d_skey && ix->d_skey != ix->d_pos) ix->ctx->pool.release(ix->d_skey);
-    ix->ctx->pool.release(ix->d_ht);
+    bool ctx_alive;
+    { std::lock_guard<std::mutex> g(g_live_mu); ctx_alive = g_live_ctx.count(ix->ctx) != 0; }
+    if (ctx_alive) {     // (a destroyed context has already freed its pool: an index that outlives it owns nothing)
+        ix->ctx->pool.release(ix->d_pos); if (ix->d_skey && ix->d_skey != ix->d_pos) ix->ctx->pool.release(ix->d_skey);
+        ix->ctx->pool.release(ix->d_ht);
+    }
     delete ix;
 }
 
@@ -874,7 +899,7 @@ struct OverlapRun {
     std::unique_ptr<Scratch> presk_sc;   // memory of a consumed presketch (released with the run)
     u32 *hs = nullptr, *hc = nullptr, *hn = nullptr, *hv = nullptr, *krank = nullptr;
     // batch plan
-    u64 batch_cap = 0; KeyLayout kl; u32 max_bits_q = 0, min_n = 0; BinLimits bl; ChainParams cp;
+    u64 batch_cap = 0; KeyLayout kl; u32 max_bits_q = 0, min_n = 0; ChainParams cp;
     std::vector<SegTile> h_tiles;   // per batch; lives until the batch's next host sync (the async H2D copy reads it)
     std::vector<SegDesc> h_local[3];
     u32 n_local_items = 0;         // anchors of the batch sorted by k_seg_sort_local
@@ -887,8 +912,6 @@ struct OverlapRun {
     int finish();                               // results to the host
     void plan_anchor_sort(u32 q0, u32 q1, bool packed);          // which queries sort inside LDS, tiles for the rest
     int dump_sorted_anchors(const u64 *skey, const u64 *sval, u64 A);   // lrge_hip_anchors_dump: one query's anchors, mm2 encoding
-    int launch_reference_chain(int chain_mode, Scratch &bsc, const u64 *skey, const u64 *sval, const u32 *gstart, u32 G, u64 A,
-                               const u32 *bin_list, const u32 *h_bins, const unsigned long long *h_bin_anchors, GroupOut go);
 };
 
 int OverlapRun::prepare() {
@@ -1035,7 +1058,7 @@ int OverlapRun::seeds() {
         for (u32 q = 0; q < nq && !qocc_possible; ++q) qocc_possible = (i64)(h_mzoff[q + 1] - h_mzoff[q]) > (i64)ix->mid_occ;
     u32 *d_qf = nullptr; u32 qf = 0; bool qf_on_side = false;
     if (qocc_possible) {
-        if (getenv("LRGE_HIP_QOCC_EXACT")) { rc = run_exact_qocc(); if (rc) return rc; }
+        if (ctx->opt("QOCC_EXACT")) { rc = run_exact_qocc(); if (rc) return rc; }
         else {
             // cheap conservative check, on the side stream beside the hit counting below (both only read the lookup
             // results); its verdict travels to the host with the next sync (no extra round trip)
@@ -1121,12 +1144,11 @@ int OverlapRun::plan() {
         }
         if (batch_cap < (1ULL << 20)) batch_cap = 1ULL << 20;
     }
-    batch_cap = env_u64("LRGE_HIP_BATCH_ANCHORS", batch_cap);
+    batch_cap = ctx->opt_u64("BATCH_ANCHORS", batch_cap);
     kl.bits_rpos = std::max<u32>(1, ceil_log2_u64((u64)T->max_len + 1));
     kl.bits_rid = std::max<u32>(1, ceil_log2_u64((u64)nt));
     max_bits_q = 63 - (kl.bits_rpos + 1 + kl.bits_rid);
     min_n = std::max<u32>((u32)P.min_cnt, (u32)div_up((u64)P.min_sc, P.hpc ? 255 : (u64)P.k));
-    bl.lim[0] = 64; bl.lim[1] = 256; bl.lim[2] = 1024; bl.lim[3] = 4096; bl.lim[4] = 0xFFFFFFFFu;
     cp.max_dist_x = std::max(P.max_gap, P.bw); cp.max_dist_y = std::max(P.max_gap, P.bw);
     cp.bw = P.bw; cp.max_skip = P.max_skip; cp.max_iter = P.max_iter; cp.min_cnt = P.min_cnt; cp.min_sc = P.min_sc;
     cp.max_drop = P.bw; cp.pen_gap = P.pen_gap; cp.pen_skip = P.pen_skip;
@@ -1134,11 +1156,6 @@ int OverlapRun::plan() {
     cp.max_overhang_ratio = job.prm.max_overhang_ratio;
     cp.want_all = (job.n_chains != nullptr || cp.remove_internal) ? 1 : 0;
     cp.q_len = Q->d_len; cp.t_len = T->d_len;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_chain_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 18 + 64));
-        attr_set = true;
-    }
     return LRGE_OK;
 }
 
@@ -1151,8 +1168,8 @@ void OverlapRun::plan_anchor_sort(u32 q0, u32 q1, bool packed) {
     for (auto &v : h_local) v.clear();
     u32 off = 0, tb = 0, &n_local = n_local_items;
     n_local = 0;
-    const bool local_ok = !getenv("LRGE_HIP_NO_LOCAL_SORT");
-    const int local_max = getenv("LRGE_HIP_LOCAL_SORT_MAX") ? atoi(getenv("LRGE_HIP_LOCAL_SORT_MAX")) : 2;   // largest class sorted in LDS
+    const bool local_ok = !ctx->opt("NO_LOCAL_SORT");
+    const int local_max = ctx->opt("LOCAL_SORT_MAX") ? atoi(ctx->opt("LOCAL_SORT_MAX")) : 2;   // largest class sorted in LDS
     for (u32 q = q0; q < q1; ++q) {
         const u32 c = h_qtot[q];
         if (packed && c) {
@@ -1194,69 +1211,6 @@ int OverlapRun::dump_sorted_anchors(const u64 *skey, const u64 *sval, u64 A) {
     return RUN_DONE;
 }
 
-// LRGE_HIP_CHAIN=reg|lds|glb: the earlier one-group-per-wavefront chain kernels, kept as on-device references for the
-// parity tests (groups arrive in N_BINS size bins instead of the size-sorted list).
-int OverlapRun::launch_reference_chain(int chain_mode, Scratch &bsc, const u64 *skey, const u64 *sval, const u32 *gstart, u32 G, u64 A,
-                                       const u32 *bin_list, const u32 *h_bins, const unsigned long long *h_bin_anchors, GroupOut go) {
-    if (chain_mode == 3) {
-        // register-window kernel, one group per wavefront, every group size in one launch, largest bins first
-        u32 total_blocks = 0; u64 total_anch = 0;
-        RegChainArgs ra;
-        ra.akey = skey; ra.aval = sval; ra.gstart = gstart; ra.n_groups = G; ra.n_anchors = A; ra.list = bin_list;
-        for (int k = 0; k < N_BINS; ++k) {
-            int b = N_BINS - 1 - k;
-            ra.bin_first[k] = total_blocks; ra.bin_of[k] = (u32)b;
-            total_blocks += h_bins[b]; total_anch += h_bin_anchors[b];
-        }
-        ra.n_blocks = total_blocks;
-        if (total_blocks) {
-            StageTimer t(ctx, LRGE_T_CHAIN);
-            ra.grec = bsc.get<u64>(A); ra.tmark = bsc.get<u32>(A);
-            if (!ra.grec || !ra.tmark) return LRGE_ERR_DEVICE;
-            HIPCHK(ctx, hipMemsetAsync(ra.tmark, 0, A * 4, ctx->stream));
-            hipLaunchKernelGGL(k_chain_reg, dim3(total_blocks), dim3(64), 0, ctx->stream, ra, cp, go);
-            KCHK(ctx);
-            t.stop();
-            ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
-            ctx->counters[LRGE_C_CHAIN_ANCHORS] += total_anch;
-            ctx->counters[LRGE_C_GROUPS_CHAINED] += total_blocks;
-        }
-    } else {
-        const int first_lds_bin = chain_mode == 2 ? -1 : N_BINS - 2;   // "glb": everything through the generic kernel
-        u32 n_glb = 0; u64 a_glb = 0;
-        for (int b = N_BINS - 1; b > first_lds_bin; --b) { n_glb += h_bins[b]; a_glb += h_bin_anchors[b]; }
-        if (n_glb) {
-            StageTimer t(ctx, LRGE_T_CHAIN_GLB);
-            i32 *gX = bsc.get<i32>(A), *gY = bsc.get<i32>(A), *gF = bsc.get<i32>(A), *gP = bsc.get<i32>(A), *gT = bsc.get<i32>(A);
-            u8 *gS = bsc.get<u8>(A);
-            if (!gX || !gY || !gF || !gP || !gT || !gS) return LRGE_ERR_DEVICE;
-            for (int b = N_BINS - 1; b > first_lds_bin; --b) {
-                if (!h_bins[b]) continue;
-                hipLaunchKernelGGL(k_chain_glb, dim3(h_bins[b]), dim3(64), 0, ctx->stream, skey, sval, gstart, G, A,
-                                   bin_list + (u64)b * G, h_bins[b], gX, gY, gF, gP, gT, gS, cp, go);
-                KCHK(ctx);
-                ctx->counters[LRGE_C_CHAIN_GLB_LAUNCHES] += 1;
-            }
-            t.stop();
-            ctx->counters[LRGE_C_CHAIN_GLB_ANCHORS] += a_glb;
-            ctx->counters[LRGE_C_GROUPS_CHAINED] += n_glb;
-        }
-        StageTimer t(ctx, LRGE_T_CHAIN);
-        for (int b = first_lds_bin; b >= 0; --b) {
-            if (!h_bins[b]) continue;
-            u32 cap = bl.lim[b];
-            hipLaunchKernelGGL(k_chain_lds, dim3(h_bins[b]), dim3(64), (size_t)cap * 18 + 64, ctx->stream, skey, sval, gstart, G, A,
-                               bin_list + (u64)b * G, h_bins[b], cap, cp, go);
-            KCHK(ctx);
-            ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;
-            ctx->counters[LRGE_C_CHAIN_ANCHORS] += h_bin_anchors[b];
-            ctx->counters[LRGE_C_GROUPS_CHAINED] += h_bins[b];
-        }
-        t.stop();
-    }
-    return LRGE_OK;
-}
-
 int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
     const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
     (void)T; (void)P; (void)nq; (void)nt;
@@ -1269,7 +1223,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
     // count-only runs carry one packed u64 per anchor through the expansion and the sort (k_prims.h UnpackParams);
     // chain records (PAF) need the seed rank as well and keep the (key, value) pairs
     const u32 bits_qy = std::max<u32>(1, ceil_log2_u64((u64)Q->max_len + 1));
-    const bool packed = !d_chains && !job.dump_anchors && kl.sh_q() + bits_qy + 9 <= 64 && !env_u64("LRGE_HIP_NO_PACKED", 0);
+    const bool packed = !d_chains && !job.dump_anchors && kl.sh_q() + bits_qy + 9 <= 64 && !ctx->opt_u64("NO_PACKED", 0);
     {
         StageTimer t(ctx, LRGE_T_EXPAND);
         u32 *aoff = bsc.get<u32>(me - mb + 1);
@@ -1342,43 +1296,31 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
         t.stop();
     }
     if (job.dump_anchors) return dump_sorted_anchors(skey, sval, A);
-    // groups
-    // LRGE_HIP_CHAIN selects the chain kernel: default "hw" (two groups per wavefront), "reg" (one group
-    // per wavefront, register window), "lds" / "glb" (earlier forms, kept as on-device references)
-    const char *cm = getenv("LRGE_HIP_CHAIN");
-    const int chain_mode = (cm && !strcmp(cm, "lds")) ? 1 : (cm && !strcmp(cm, "glb")) ? 2 : (cm && !strcmp(cm, "reg")) ? 3 : 0;
-    // mode 0 splits the size-sorted group list: groups above lpg_max anchors go to k_chain_hw (short
-    // latency per anchor), the rest to k_chain_lpg (64 groups per wavefront).  "hw" / "lpg" force one kernel.
-    // The split is chosen per batch from the size census of the groups (see below); LRGE_HIP_LPG_MAX fixes it.
+    // groups.  The size-sorted list of the groups worth chaining is split: groups above lpg_max anchors go to k_chain_hw
+    // (short latency per anchor), the rest to k_chain_lpg (64 groups per wavefront).  The split is chosen per batch from
+    // the size census of the groups (see below); option LPG_MAX pins it, CHAIN=hw|lpg forces one kernel.
+    const char *cm = ctx->opt("CHAIN");
     u32 lpg_max = LPG_MAX_AUTO;
-    if (const char *e = getenv("LRGE_HIP_LPG_MAX")) lpg_max = (u32)strtoul(e, nullptr, 10);
+    if (const char *e = ctx->opt("LPG_MAX")) lpg_max = (u32)strtoul(e, nullptr, 10);
     if (cm && !strcmp(cm, "hw")) lpg_max = 0;
     if (cm && !strcmp(cm, "lpg")) lpg_max = 0xFFFFFFFFu;
     if (lpg_max && (cp.want_all || d_chains) && !(cm && !strcmp(cm, "lpg"))) lpg_max = 0;   // records: wave-wide backtrack anyway
     if (cp.max_iter < LPG_W) lpg_max = 0;    // (debug knob only) k_chain_lpg assumes every window slot is a candidate
     u32 n_big = 0, lpg_split = 0;
-    u32 G = 0; u32 *gstart, *gflags, *bin_count = nullptr, *bin_list = nullptr, *hw_list = nullptr;
-    u32 h_bins[N_BINS] = {0, 0, 0, 0, 0};
-    unsigned long long h_bin_anchors[N_BINS] = {0, 0, 0, 0, 0};
+    u32 G = 0; u32 *gstart, *gflags, *hw_list = nullptr;
     u32 n_chained = 0; unsigned long long a_chained = 0, a_big = 0;
     {
         StageTimer t(ctx, LRGE_T_GROUP);
         u32 *d_G = bsc.get<u32>(1);
-        if (chain_mode == 0) {
+        {
             // group starts into an upper-bound block (one entry per anchor): the group count stays on the device
             // until it travels to the host together with the size census -- one round trip instead of two
             gstart = bsc.get<u32>((size_t)A + 1);
             if (!gstart || !d_G) return LRGE_ERR_DEVICE;
             rc = compact_heads_async(ctx, bsc, skey, A, kl.bits_rpos, gstart, d_G);   // runs of equal (query, target, strand)
             if (rc) return rc;
-        } else {
-            rc = compact_heads(ctx, bsc, skey, A, kl.bits_rpos, &gstart, &G);
-            if (rc) return rc;
-            gflags = bsc.get<u32>((size_t)G + 1);
-            if (!gstart || !gflags) return LRGE_ERR_DEVICE;
-            HIPCHK(ctx, hipMemsetAsync(gflags, 0, ((size_t)G + 1) * 4, ctx->stream));
         }
-        if (chain_mode == 0) {
+        {
             // groups worth chaining, sorted by size (largest first) so that k_chain_hw pairs equals
             u32 *d_cnt = bsc.get<u32>(4 + GSZ_BINS);
             unsigned long long *d_anch = (unsigned long long *)bsc.get<u64>(2 + GSZ_BINS);
@@ -1401,7 +1343,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                 const ChainSplit sp_ = choose_chain_split(h_cnt + 4, h_anch + 2, a_chained, lpg_max, ctx->n_cu);
                 n_big = sp_.n_big; a_big = sp_.a_big; lpg_split = sp_.T;
                 ctx->counters[LRGE_C_LPG_SPLIT] = lpg_split;
-                if (getenv("LRGE_HIP_VERBOSE"))
+                if (ctx->opt("VERBOSE"))
                     fprintf(stderr, "[lrge_hip] batch: %u groups chained, %llu anchors, largest class %d (<= %d anchors), split T=%u -> hw %u groups / %llu anchors\n",
                             n_chained, a_chained, sp_.top, (sp_.top + 1) * GSZ_W, sp_.T, n_big, a_big);
             }
@@ -1419,30 +1361,19 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                 bsc.drop(k0); bsc.drop(v0); bsc.drop(k1); bsc.drop(v1);
             }
             bsc.drop(d_cnt); bsc.drop(d_anch);
-        } else {
-            bin_count = bsc.get<u32>(N_BINS); bin_list = bsc.get<u32>((size_t)N_BINS * G + 1);
-            unsigned long long *bin_anchors = (unsigned long long *)bsc.get<u64>(N_BINS);
-            if (!bin_count || !bin_list || !bin_anchors) return LRGE_ERR_DEVICE;
-            HIPCHK(ctx, hipMemsetAsync(bin_anchors, 0, N_BINS * 8, ctx->stream));
-            HIPCHK(ctx, hipMemsetAsync(bin_count, 0, N_BINS * 4, ctx->stream));
-            hipLaunchKernelGGL(k_group_bin, dim3((u32)div_up(G, GB_CHUNK)), dim3(256), 0, ctx->stream, gstart, G, A, min_n, bl, bin_count, bin_list, bin_anchors);
-            KCHK(ctx);
-            HIPCHK(ctx, ctx->d2h(h_bins, bin_count, N_BINS * 4, ctx->stream));
-            HIPCHK(ctx, ctx->d2h(h_bin_anchors, bin_anchors, N_BINS * 8, ctx->stream));
-            HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
         }
         t.stop();
     }
     ctx->counters[LRGE_C_GROUPS] += G;
     {
         GroupOut go; go.flags = gflags; go.chains = d_chains; go.n_chains = d_nchains; go.chain_cap = job.chain_cap;
-        if (chain_mode == 0) {
+        {
             if (n_chained) {
                 StageTimer t(ctx, LRGE_T_CHAIN);
                 HwChainArgs ha;
                 ha.akey = skey; ha.aval = sval; ha.gstart = gstart; ha.n_groups = G; ha.n_anchors = A; ha.list = hw_list; ha.n_list = n_big;
                 ha.grec = bsc.get<u64>(A); ha.tmark = bsc.get<u32>(A);
-                ha.prio = (u32)env_u64("LRGE_HIP_HW_PRIO", 0);
+                ha.prio = (u32)ctx->opt_u64("HW_PRIO", 0);
                 if (!ha.grec || !ha.tmark) return LRGE_ERR_DEVICE;
                 HIPCHK(ctx, hipMemsetAsync(ha.tmark, 0, A * 4, ctx->stream));
                 // the list is sorted by min(n, 65535) descending, so [0, n_big) are exactly the groups above lpg_max
@@ -1457,17 +1388,17 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                     LpgChainArgs la;
                     la.akey = skey; la.aval = sval; la.gstart = gstart; la.n_groups = G; la.n_anchors = A;
                     la.list = hw_list + n_big; la.n_list = n_chained - n_big; la.grec = ha.grec; la.tmark = ha.tmark;
-                    la.prio = (u32)env_u64("LRGE_HIP_LPG_PRIO", 3);
+                    la.prio = (u32)ctx->opt_u64("LPG_PRIO", 3);
                     // 1024: on clean input (C2) no group is given up -- redoing even one 500-anchor group costs 0.3 ms of
                     // critical path; on a repeat-rich genome (synth c2_repeats) 64 would be ~1.7x faster still
-                    la.slow_budget = (u32)env_u64("LRGE_HIP_LPG_SLOW_BUDGET", 1024);
-                    la.slow_entries = (u32)env_u64("LRGE_HIP_LPG_SLOW_ENTRIES", 4);
+                    la.slow_budget = (u32)ctx->opt_u64("LPG_SLOW_BUDGET", 1024);
+                    la.slow_entries = (u32)ctx->opt_u64("LPG_SLOW_ENTRIES", 4);
                     la.redo_list = bsc.get<u32>((size_t)la.n_list + 1); la.redo_count = bsc.get<u32>(1);
                     if (!la.redo_list || !la.redo_count) return LRGE_ERR_DEVICE;
                     HIPCHK(ctx, hipMemsetAsync(la.redo_count, 0, 4, both ? ctx->stream2 : ctx->stream));
                     StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
-                    const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !getenv("LRGE_HIP_LPG_NOTAB");
-                    const bool fastreach = cp.max_iter >= 64 && !getenv("LRGE_HIP_LPG_EXACT_REACH");
+                    const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 12288 && !ctx->opt("LPG_NOTAB");
+                    const bool fastreach = cp.max_iter >= 64 && !ctx->opt("LPG_EXACT_REACH");
                     const dim3 lgrid((la.n_list + 63) / 64);
                     const size_t lds_tab = (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES;
                     hipStream_t lst = both ? ctx->stream2 : ctx->stream;
@@ -1488,7 +1419,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                         const u32 redo_grid = (u32)std::min<u64>(((u64)la.n_list + 1) / 2, (u64)ctx->n_cu * 32);
                         hipLaunchKernelGGL(k_chain_hw_redo, dim3(std::max<u32>(redo_grid, 1)), dim3(64), 0, both ? ctx->stream2 : ctx->stream, hr, cp, go, la.redo_count);
                         KCHK(ctx);
-                        if (getenv("LRGE_HIP_VERBOSE")) {
+                        if (ctx->opt("VERBOSE")) {
                             u32 nr = 0;
                             HIPCHK(ctx, hipMemcpyAsync(&nr, la.redo_count, 4, hipMemcpyDeviceToHost, both ? ctx->stream2 : ctx->stream));
                             HIPCHK(ctx, hipStreamSynchronize(both ? ctx->stream2 : ctx->stream));
@@ -1509,9 +1440,6 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                 ctx->counters[LRGE_C_CHAIN_ANCHORS] += a_chained;
                 ctx->counters[LRGE_C_GROUPS_CHAINED] += n_chained;
             }
-        } else {
-            rc = launch_reference_chain(chain_mode, bsc, skey, sval, gstart, G, A, bin_list, h_bins, h_bin_anchors, go);
-            if (rc) return rc;
         }
     }
     {
@@ -1605,10 +1533,10 @@ static int check_common(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_
 // A streamed set above LRGE_HIP_STREAM_BASES bases (default 4e9: < 2^32 minimizers per pass) goes through in views of
 // at most that many bases.  The streamed reads are independent of each other (twoset.rs:266-334, :485-565), so the passes
 // simply follow one another: per-read outputs land at the view's offset, per-indexed-read counts add up.
-static u64 stream_limit() { return env_u64("LRGE_HIP_STREAM_BASES", 4000000000ull); }
+static u64 stream_limit(const lrge_hip_ctx *ctx) { return ctx->opt_u64("STREAM_BASES", 4000000000ull); }
 static std::vector<u32> stream_cuts(const lrge_hip_seqset *s) {
     std::vector<u32> cuts{0};
-    const u64 lim = stream_limit();
+    const u64 lim = stream_limit(s->ctx);
     u64 acc = 0;
     for (u32 r = 0; r < s->n; ++r) {
         if (acc && acc + s->h_len[r] > lim) { cuts.push_back(r); acc = 0; }
@@ -1629,7 +1557,7 @@ struct StageAcc {      // timings / counters of a call made of several passes
 
 // two-set forward against one (unpartitioned) index, the queries in views if there are too many of them
 static int twoset_one_index(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries, const OverlapJob &job, StageAcc &acc) {
-    if (queries->total_bases <= stream_limit() || queries->n < 2) {
+    if (queries->total_bases <= stream_limit(ctx) || queries->n < 2) {
         OverlapJob j = job;
         int rc = run_overlap(ctx, ix, queries, j);
         acc.add(ctx);
@@ -1689,7 +1617,7 @@ extern "C" int lrge_hip_overlap_inverse(lrge_hip_ctx *ctx, const lrge_hip_index 
     OverlapJob job; job.mode = MODE_INVERSE; job.dual = 1;
     job.prm = p ? *p : lrge_hip_params{0, 0.2f};
     job.counts = counts;
-    if (streamed->total_bases <= stream_limit() || streamed->n < 2) return run_overlap(ctx, ix, streamed, job);
+    if (streamed->total_bases <= stream_limit(ctx) || streamed->n < 2) return run_overlap(ctx, ix, streamed, job);
     // the streamed (target) set in views: every streamed read adds one to the indexed reads it hits (twoset.rs:520-523)
     const u32 n_ix = ix->seqs->n;
     std::vector<u32> c((size_t)n_ix + 1);

@@ -58,6 +58,11 @@ class Context:
         except Exception:
             pass
 
+    def set_option(self, name, value):
+        """Tuning / test option of this context; value None clears it.  The same names are
+        read once from the environment (LRGE_HIP_<NAME>) when the context is created, except DEBUG_*."""
+        self._check(self._lib.lrge_hip_ctx_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
+
     def set_timer_level(self, level):
         """0 = call total + chain stage only, 1 = every stage, 2 (default) = also every k_rs_scatter launch."""
         self._check(self._lib.lrge_hip_set_timer_level(self.h, int(level)))
@@ -151,7 +156,8 @@ class Index:
 
     def free(self):
         if getattr(self, "h", None):
-            self.ctx._lib.lrge_hip_index_free(self.h)
+            if getattr(self.ctx, "h", None):      # a closed context has already released everything the index held
+                self.ctx._lib.lrge_hip_index_free(self.h)
             self.h = None
 
     def __del__(self):

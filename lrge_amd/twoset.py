@@ -107,6 +107,7 @@ class TwoSetStrategy(Estimate):
         except KeyError:
             raise LrgeError("InvalidPlatform", self.platform)
         ctx = engine.Context(self.device)
+        Q = T = ix = None
         try:
             qr, tr = engine.name_ranks(qn, tn)
             Q = ctx.upload(*readio.pack(qs), qr)
@@ -135,4 +136,7 @@ class TwoSetStrategy(Estimate):
                          100.0 * no_mapping / self.query_num_reads)
             return est, no_mapping
         finally:
+            for h in (ix, Q, T):          # handles go before their context (lrge_hip_index_free / _seqset_free)
+                if h is not None:
+                    h.free()
             ctx.close()

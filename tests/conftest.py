@@ -38,6 +38,28 @@ def ctx():
     c.close()
 
 
+class _Knobs:
+    """Options of the session context set for one test (lrge_hip_ctx_set_option) and cleared afterwards."""
+
+    def __init__(self, ctx):
+        self.ctx, self.touched = ctx, set()
+
+    def set(self, name, value):
+        self.ctx.set_option(name, str(value))
+        self.touched.add(name)
+
+    def unset(self, name):
+        self.ctx.set_option(name, None)
+
+
+@pytest.fixture
+def knobs(ctx):
+    k = _Knobs(ctx)
+    yield k
+    for name in k.touched:
+        ctx.set_option(name, None)
+
+
 # ------------------------------------------------------------------------------------------
 # shared small data sets (deterministic)
 # ------------------------------------------------------------------------------------------

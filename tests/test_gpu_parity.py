@@ -29,13 +29,13 @@ def _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset, dual=True):
 
 @pytest.mark.parametrize("form", ["one-pass", "two-pass", "overflow-fallback"])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
-def test_sketch_parity(ctx, oracle, edge_set, preset, form, monkeypatch):
+def test_sketch_parity(ctx, oracle, edge_set, preset, form, knobs):
     # one-pass (per-chunk slots + compaction, the default), the two-pass form (count, scan, write), and the fallback from
     # the first to the second when a chunk overflows its slot (forced here by a tiny slot capacity)
     if form == "two-pass":
-        monkeypatch.setenv("LRGE_HIP_SKETCH_TWO_PASS", "1")
+        knobs.set("SKETCH_TWO_PASS", "1")
     elif form == "overflow-fallback":
-        monkeypatch.setenv("LRGE_HIP_DEBUG_SK_CAP", "9")
+        knobs.set("DEBUG_SK_CAP", "9")
     qseqs, qnames, tseqs, tnames = edge_set
     seqs = tseqs + [b"", b"A", b"ACGTTGCA" * 3]            # empty and tiny reads keep their rid
     S = _upload(ctx, seqs)
@@ -50,10 +50,10 @@ def test_sketch_parity(ctx, oracle, edge_set, preset, form, monkeypatch):
 
 @pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
-def test_index_parity(ctx, oracle, edge_set, preset, packed, monkeypatch):
+def test_index_parity(ctx, oracle, edge_set, preset, packed, knobs):
     """Both index layouts: packed 8-byte entries (the default when they fit) and (hash, y) pairs."""
     if not packed:
-        monkeypatch.setenv("LRGE_HIP_NO_PACKED_INDEX", "1")
+        knobs.set("NO_PACKED_INDEX", "1")
     qseqs, qnames, tseqs, tnames = edge_set
     Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset)
     st = ixd.stats()
@@ -203,37 +203,37 @@ def test_error_paths(ctx, oracle):
     assert np.array_equal(got, exp) and np.array_equal(has, ehas)
 
 
-def test_batching_is_invisible(ctx, oracle, tiny_ont, monkeypatch):
+def test_batching_is_invisible(ctx, oracle, tiny_ont, knobs):
     """Forcing many small anchor batches must not change the counts."""
     ds = tiny_ont
     Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, ds.q.seqs(), ds.q.names, ds.t.seqs(), ds.t.names, "ont")
     ref, _ = ixd.overlap_twoset(Qd)
-    monkeypatch.setenv("LRGE_HIP_BATCH_ANCHORS", "20000")
+    knobs.set("BATCH_ANCHORS", "20000")
     small, _ = ixd.overlap_twoset(Qd)
     assert ctx.counters()["batches"] > 3
     assert np.array_equal(ref, small)
 
 
-@pytest.mark.parametrize("kernel", ["hw", "lpg", "lpg_notab", "lpg_redo", "auto64", "reg", "lds", "glb"])
+@pytest.mark.parametrize("kernel", ["hw", "lpg", "lpg_notab", "lpg_redo", "auto64"])
 @pytest.mark.parametrize("max_skip,max_iter", [(25, 5000), (100000, 5000), (100000, 40), (3, 90)])
-def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, monkeypatch, kernel, max_skip, max_iter):
-    """Every chain kernel (half-wave, lane-per-group, register-window, LDS, global) against the oracle, including the
+def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, knobs, kernel, max_skip, max_iter):
+    """Both chain kernels (half-wave, lane-per-group) and their forced variants against the oracle, including the
     paths the default heuristics almost never take: no max_skip break (the candidate loop walks the
     whole 5000-bp window, far past the 64 anchors held in registers) and a tight max_iter clamp.
     HiFi reads give dense anchor groups (hundreds of anchors inside one window)."""
     if kernel == "auto64":     # the default split (big groups -> k_chain_hw, the rest -> k_chain_lpg) at a low threshold
-        monkeypatch.delenv("LRGE_HIP_CHAIN", raising=False)
-        monkeypatch.setenv("LRGE_HIP_LPG_MAX", "64")
+        knobs.unset("CHAIN")
+        knobs.set("LPG_MAX", "64")
     elif kernel == "lpg_redo":   # k_chain_lpg gives every group that touches a slow path to k_chain_hw_redo
-        monkeypatch.setenv("LRGE_HIP_CHAIN", "lpg")
-        monkeypatch.setenv("LRGE_HIP_LPG_SLOW_BUDGET", "0")
+        knobs.set("CHAIN", "lpg")
+        knobs.set("LPG_SLOW_BUDGET", "0")
     elif kernel == "lpg_notab":  # k_chain_lpg with the f32 penalty computed per candidate instead of tabulated
-        monkeypatch.setenv("LRGE_HIP_CHAIN", "lpg")
-        monkeypatch.setenv("LRGE_HIP_LPG_NOTAB", "1")
+        knobs.set("CHAIN", "lpg")
+        knobs.set("LPG_NOTAB", "1")
     else:
-        monkeypatch.setenv("LRGE_HIP_CHAIN", kernel)
-    monkeypatch.setenv("LRGE_HIP_DEBUG_MAX_SKIP", str(max_skip))
-    monkeypatch.setenv("LRGE_HIP_DEBUG_MAX_ITER", str(max_iter))
+        knobs.set("CHAIN", kernel)
+    knobs.set("DEBUG_MAX_SKIP", str(max_skip))
+    knobs.set("DEBUG_MAX_ITER", str(max_iter))
     ds = tiny_hifi
     qseqs, tseqs = ds.q.seqs()[:8], ds.t.seqs()
     qnames = ds.q.names[:8]
@@ -253,7 +253,7 @@ def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, monkeypatch, kerne
 
 
 @pytest.mark.parametrize("mode", ["twoset", "ava"])
-def test_packed_anchor_path_is_invisible(ctx, oracle, tiny_ont, monkeypatch, mode):
+def test_packed_anchor_path_is_invisible(ctx, oracle, tiny_ont, knobs, mode):
     """Count-only runs sort packed 8-byte anchors (keys only) and unpack in the last radix pass; the
     (key, value) pair path (LRGE_HIP_NO_PACKED=1, also what chain records use) must give the same counts."""
     ds = tiny_ont
@@ -264,16 +264,16 @@ def test_packed_anchor_path_is_invisible(ctx, oracle, tiny_ont, monkeypatch, mod
         Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, ds.t.seqs(), ds.t.names, ds.t.seqs(), ds.t.names, "ont", False)
         run = lambda: ixd.overlap_ava()
     a = run()
-    monkeypatch.setenv("LRGE_HIP_NO_PACKED", "1")
+    knobs.set("NO_PACKED", "1")
     b = run()
     assert np.array_equal(np.asarray(a), np.asarray(b))
-    monkeypatch.setenv("LRGE_HIP_NO_PACKED", "0")
-    monkeypatch.setenv("LRGE_HIP_NO_LOCAL_SORT", "1")        # packed anchors through the tiled global sort only
+    knobs.set("NO_PACKED", "0")
+    knobs.set("NO_LOCAL_SORT", "1")        # packed anchors through the tiled global sort only
     d = run()
     assert np.array_equal(np.asarray(a), np.asarray(d))
-    monkeypatch.delenv("LRGE_HIP_NO_LOCAL_SORT")
-    monkeypatch.setenv("LRGE_HIP_NO_PACKED", "1")
-    monkeypatch.setenv("LRGE_HIP_NO_PACKED_INDEX", "1")      # and the (hash, y) pair index
+    knobs.unset("NO_LOCAL_SORT")
+    knobs.set("NO_PACKED", "1")
+    knobs.set("NO_PACKED_INDEX", "1")      # and the (hash, y) pair index
     from lrge_amd import engine
     ix2 = engine.Index(ctx, Td, PRESETS["ont"])
     c = ix2.overlap_twoset(Qd)[0] if mode == "twoset" else ix2.overlap_ava()
@@ -319,13 +319,13 @@ def test_ava_and_inverse_shards_sum_to_the_whole(ctx, oracle, tiny_ont, world):
     ix.free(); ixq.free()
 
 
-def test_qocc_precheck_is_invisible(ctx, oracle, tiny_ont, monkeypatch):
+def test_qocc_precheck_is_invisible(ctx, oracle, tiny_ont, knobs):
     """The conservative bucket pre-check (k_qocc_check) only decides whether the exact sort-based filter runs;
     forcing the exact pass must not change anything."""
     ds = tiny_ont
     Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, ds.q.seqs(), ds.q.names, ds.t.seqs(), ds.t.names, "ont")
     ref, has = ixd.overlap_twoset(Qd)
-    monkeypatch.setenv("LRGE_HIP_QOCC_EXACT", "1")
+    knobs.set("QOCC_EXACT", "1")
     exact, has2 = ixd.overlap_twoset(Qd)
     assert np.array_equal(ref, exact) and np.array_equal(has, has2)
     rc, ecounts, ehas = ixo.twoset_counts(Qo, threads=8)
@@ -549,7 +549,7 @@ def test_ultra_long_reads(ctx, oracle, preset):
 
 
 @pytest.mark.parametrize("preset", ["ont", "pb"])
-def test_presketch_is_invisible(ctx, oracle, tiny_ont, tiny_hifi, preset, monkeypatch):
+def test_presketch_is_invisible(ctx, oracle, tiny_ont, tiny_hifi, preset, knobs):
     """lrge_hip_seqset_presketch is a scheduling hint: the streamed set is sketched on the side stream during the
     index build and consumed by the next overlap call.  Same minimizers, hence the same counts / chains -- also when
     the hint goes unused (another preset, a second call, a set freed with the result pending) or is switched off."""
@@ -564,7 +564,7 @@ def test_presketch_is_invisible(ctx, oracle, tiny_ont, tiny_hifi, preset, monkey
     assert int(ref_counts.sum()) > 0
     for variant in ("used", "twice", "other-preset", "off", "ava"):
         if variant == "off":
-            monkeypatch.setenv("LRGE_HIP_NO_PRESKETCH", "1")
+            knobs.set("NO_PRESKETCH", "1")
         if variant == "ava":
             Td.presketch(PRESETS[preset])                      # the indexed set itself is the streamed set
             ix = engine.Index(ctx, Td, PRESETS[preset])
@@ -584,7 +584,7 @@ def test_presketch_is_invisible(ctx, oracle, tiny_ont, tiny_hifi, preset, monkey
         got = _chain_rows(ix.chains(Qd, dual=True), ["query", "target", "rev", "score", "cnt", "qs", "qe", "rs", "re"])
         assert np.array_equal(got, ref_chains), variant
         ix.free()
-    monkeypatch.delenv("LRGE_HIP_NO_PRESKETCH", raising=False)
+    knobs.unset("NO_PRESKETCH")
     # a pending result that nobody consumes: freed with its set
     Q2 = ctx.upload(ds.q.bases, ds.q.offsets, qr)
     Q2.presketch(PRESETS[preset])
@@ -626,7 +626,7 @@ def test_repeated_steps_are_deterministic(ctx, tiny_ont):
 
 
 @pytest.mark.parametrize("data,preset", [("tiny_ont", "ont"), ("tiny_hifi", "pb"), ("repeats", "ont")])
-def test_partitioned_index_is_exact(ctx, oracle, tiny_ont, tiny_hifi, data, preset, monkeypatch):
+def test_partitioned_index_is_exact(ctx, oracle, tiny_ont, tiny_hifi, data, preset, knobs):
     """A target set above LRGE_HIP_PART_BASES bases is indexed in parts (the 2^32-entry limits of one part; minimap2 is
     given batch_size = max and always builds ONE index, aligner.rs:112-122).  With the occurrence statistics taken over
     all parts the result must be that of the single index: same mid_occ, distinct-key and minimizer totals, the same
@@ -652,11 +652,11 @@ def test_partitioned_index_is_exact(ctx, oracle, tiny_ont, tiny_hifi, data, pres
         assert ref_stats["mid_occ"] > 10
     total = int(ds.t.lens().sum())
     for n_parts in (2, 3, 7, 25):
-        monkeypatch.setenv("LRGE_HIP_PART_BASES", str(total // n_parts + 1))
+        knobs.set("PART_BASES", str(total // n_parts + 1))
         if n_parts == 3:                                         # (hash, y) pair layout: a part then gives its sorted hashes back
-            monkeypatch.setenv("LRGE_HIP_NO_PACKED_INDEX", "1")
+            knobs.set("NO_PACKED_INDEX", "1")
         else:
-            monkeypatch.delenv("LRGE_HIP_NO_PACKED_INDEX", raising=False)
+            knobs.unset("NO_PACKED_INDEX")
         Qd.presketch(PRESETS[preset])
         ixp = engine.Index(ctx, Td, PRESETS[preset])
         st = ixp.stats()
@@ -676,7 +676,7 @@ def test_partitioned_index_is_exact(ctx, oracle, tiny_ont, tiny_hifi, data, pres
 
 
 @pytest.mark.parametrize("preset", ["ont", "pb"])
-def test_streamed_set_in_views_is_exact(ctx, oracle, tiny_ont, tiny_hifi, preset, monkeypatch):
+def test_streamed_set_in_views_is_exact(ctx, oracle, tiny_ont, tiny_hifi, preset, knobs):
     """A streamed set above LRGE_HIP_STREAM_BASES bases goes through in views (< 2^32 minimizers per pass): the queries of
     a two-set run, the targets of an inverse (--use-min-ref) run.  Streamed reads are independent, so the result must not
     change -- forced here with a few reads per view, alone and combined with a partitioned index."""
@@ -692,19 +692,19 @@ def test_streamed_set_in_views_is_exact(ctx, oracle, tiny_ont, tiny_hifi, preset
     assert int(ref[False][0].sum()) > 0 and int(ref_inv[False].sum()) > 0
     qb, tb = int(ds.q.lens().sum()), int(ds.t.lens().sum())
     for n_views in (2, 5, 13):
-        monkeypatch.setenv("LRGE_HIP_STREAM_BASES", str(tb // n_views + 1))
+        knobs.set("STREAM_BASES", str(tb // n_views + 1))
         for F in (False, True):
             assert np.array_equal(ixq.overlap_inverse(Td, remove_internal=F), ref_inv[F]), (n_views, F)
-        monkeypatch.setenv("LRGE_HIP_STREAM_BASES", str(qb // n_views + 1))
+        knobs.set("STREAM_BASES", str(qb // n_views + 1))
         for part_bases in (None, tb // 3 + 1):
             if part_bases:
-                monkeypatch.setenv("LRGE_HIP_PART_BASES", str(part_bases))
+                knobs.set("PART_BASES", str(part_bases))
             ixt = engine.Index(ctx, Td, PRESETS[preset])
             for F in (False, True):
                 counts, has = ixt.overlap_twoset(Qd, remove_internal=F)
                 assert np.array_equal(counts, ref[F][0]) and np.array_equal(has, ref[F][1]), (n_views, part_bases, F)
             ixt.free()
-            monkeypatch.delenv("LRGE_HIP_PART_BASES", raising=False)
+            knobs.unset("PART_BASES")
     ixq.free()
     # the oracle agrees on the inverse counts
     opt = oracle.make_opt(oracle.PRESET_AVA_PB if preset == "pb" else oracle.PRESET_AVA_ONT, dual=True)
@@ -716,8 +716,8 @@ def test_streamed_set_in_views_is_exact(ctx, oracle, tiny_ont, tiny_hifi, preset
 def test_allocator_retry_leaves_no_stale_error(tiny_ont):
     """Under memory pressure the pool's first hipMalloc fails, the cache is trimmed and the retry succeeds -- the failed
     attempt must not surface later as the "last error" of a launch check (it did, at C5: the overlap call of a run whose
-    8-part index had been built stopped with "out of memory").  LRGE_HIP_DEBUG_ALLOC_FAIL_EVERY makes every third pool miss
-    take that path for real (an impossible request first); it is read once per process, so this runs in a child."""
+    8-part index had been built stopped with "out of memory").  The option DEBUG_ALLOC_FAIL_EVERY (lrge_hip_ctx_set_option) makes every third
+    pool miss of that context take the path for real (an impossible request first); run in a child with a context of its own."""
     import os
     import subprocess
     import sys
@@ -725,7 +725,10 @@ def test_allocator_retry_leaves_no_stale_error(tiny_ont):
 import numpy as np
 from lrge_amd import engine, synth
 g, q, t = synth.make_config("tiny_twoset")
+import sys
 ctx = engine.Context(0)
+if len(sys.argv) > 1:
+    ctx.set_option("DEBUG_ALLOC_FAIL_EVERY", sys.argv[1])
 qr, tr = engine.name_ranks(q.names, t.names)
 Qd, Td = ctx.upload(q.bases, q.offsets, qr), ctx.upload(t.bases, t.offsets, tr)
 out = []
@@ -738,9 +741,9 @@ print("SUM", int(out[0].sum()))
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sums = []
-    for env_extra in ({}, {"LRGE_HIP_DEBUG_ALLOC_FAIL_EVERY": "3"}):
-        env = dict(os.environ, PYTHONPATH=root, **env_extra)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    for extra in ([], ["3"]):
+        env = dict(os.environ, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code] + extra, capture_output=True, text=True, timeout=300, env=env, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         sums.append([l for l in r.stdout.splitlines() if l.startswith("SUM")][0])
     assert sums[0] == sums[1] and int(sums[0].split()[1]) > 0

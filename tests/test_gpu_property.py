@@ -159,13 +159,11 @@ def test_random_small_sets_forced_paths(ctx, oracle, env):
     def run(c):
         _check(ctx, oracle, c, skip=int(env.get("LRGE_HIP_DEBUG_MAX_SKIP", 0)), iters=int(env.get("LRGE_HIP_DEBUG_MAX_ITER", 0)))
 
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    opts = {k[len("LRGE_HIP_"):]: v for k, v in env.items()}
+    for k, v in opts.items():
+        ctx.set_option(k, v)
     try:
         run()
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        for k in opts:
+            ctx.set_option(k, None)

@@ -82,8 +82,8 @@ typedef struct {
 enum {
     LRGE_T_PACK = 0, LRGE_T_SKETCH, LRGE_T_INDEX_SORT, LRGE_T_INDEX_TABLE, LRGE_T_QFILTER,
     LRGE_T_LOOKUP, LRGE_T_EXPAND, LRGE_T_ANCHOR_SORT, LRGE_T_GROUP, LRGE_T_CHAIN,
-    LRGE_T_CHAIN_GLB /* k_chain_glb launches (LRGE_HIP_CHAIN=lds|glb only) */, LRGE_T_COUNT, LRGE_T_TOTAL,
-    LRGE_T_CHAIN_LPG, LRGE_T_RS_SCATTER, LRGE_T_N
+    LRGE_T_CHAIN_GLB /* (unused: retired kernel) */, LRGE_T_COUNT, LRGE_T_TOTAL,
+    LRGE_T_CHAIN_LPG, LRGE_T_RS_SCATTER, LRGE_T_K_LOOKUP /* k_lookup alone (it also counts inside LRGE_T_LOOKUP) */, LRGE_T_N
 };
 /* Work counters of the last overlap call (for the roofline's algorithmic bytes). */
 enum {
@@ -95,6 +95,7 @@ enum {
     LRGE_C_RS_SCATTER_BYTES /* bytes those launches had to read + write: 32 per (key, value) pair, 16 per packed
                                key, 24 in the unpacking pass */,
     LRGE_C_LPG_SPLIT /* group size above which the last batch used k_chain_hw instead of k_chain_lpg */,
+    LRGE_C_LOOKUP_LAUNCHES /* k_lookup launches (one per pass over a streamed set / index part) */,
     LRGE_C_N
 };
 
@@ -119,6 +120,24 @@ int  lrge_hip_ctx_set_option(lrge_hip_ctx *ctx, const char *name, const char *va
  */
 int  lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, const uint64_t *offsets,
                             uint32_t n, const uint32_t *name_rank, lrge_hip_seqset **out);
+/*
+ * The same without waiting for the transfer: the copy and the 2-bit pack are queued on the context's copy stream and the
+ * call returns; every later call that consumes the set orders itself behind them on the device.  So a second set travels
+ * over PCIe while the first one is being indexed (the reference's producer thread / bounded channel, twoset.rs:216-241,
+ * does the same for its per-read stream).  `bases` may be
+ *   - pinned host memory (lrge_hip_host_alloc, hipHostMalloc/hipHostRegister): one DMA straight from the caller's buffer,
+ *     which must stay valid and unchanged until a call that consumes the set has returned or lrge_hip_seqset_wait(s);
+ *   - pageable host memory: staged through the context's pinned buffers (copied out before the call returns);
+ *   - device memory (reads already resident in HBM as ASCII): packed in place, no transfer.
+ * `offsets` and `name_rank` are copied before the call returns in every case.  lrge_hip_seqset_upload accepts the same
+ * three kinds of `bases`.
+ */
+int  lrge_hip_seqset_upload_async(lrge_hip_ctx *ctx, const char *bases, const uint64_t *offsets,
+                                  uint32_t n, const uint32_t *name_rank, lrge_hip_seqset **out);
+int  lrge_hip_seqset_wait(lrge_hip_seqset *s);          /* host-side wait for an async upload */
+/* Pinned host memory for read buffers (what the record reader of io.rs:186-249 would fill): DMA source without staging. */
+int  lrge_hip_host_alloc(size_t bytes, void **out);
+void lrge_hip_host_free(void *p);
 void lrge_hip_seqset_free(lrge_hip_seqset *s);
 uint32_t lrge_hip_seqset_size(const lrge_hip_seqset *s);
 

@@ -13,14 +13,15 @@ ERR_IO, ERR_PARSE, ERR_TOO_MANY, ERR_TOO_FEW, ERR_DEVICE, ERR_MAP, ERR_DUPLICATE
 PRESET_AVA_ONT, PRESET_AVA_PB = 0, 1
 
 T_NAMES = ["pack", "sketch", "index_sort", "index_table", "qfilter", "lookup", "expand", "anchor_sort", "group",
-           "chain", "chain_glb", "count", "total", "chain_lpg", "rs_scatter"]
+           "chain", "chain_glb", "count", "total", "chain_lpg", "rs_scatter", "k_lookup"]
 C_NAMES = ["query_bases", "query_minimizers", "anchors", "groups", "groups_chained", "chain_launches", "batches",
            "chain_anchors", "chain_glb_launches", "chain_glb_anchors", "lpg_launches", "lpg_anchors",
-           "rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "lpg_split"]
+           "rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "lpg_split", "lookup_launches"]
 
 EXPORTS = [
     "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error", "lrge_hip_ctx_set_option",
-    "lrge_hip_seqset_upload", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch",
+    "lrge_hip_seqset_upload", "lrge_hip_seqset_upload_async", "lrge_hip_seqset_wait", "lrge_hip_host_alloc",
+    "lrge_hip_host_free", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch",
     "lrge_hip_index_build", "lrge_hip_index_free", "lrge_hip_index_stats",
     "lrge_hip_overlap_twoset", "lrge_hip_overlap_inverse", "lrge_hip_overlap_ava", "lrge_hip_chains",
     "lrge_hip_estimates", "lrge_hip_median", "lrge_hip_paf_stats",
@@ -67,6 +68,11 @@ def lib():
     L.lrge_hip_ctx_destroy.restype = None
     L.lrge_hip_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.lrge_hip_seqset_upload.argtypes = [vp, vp, vp, C.c_uint32, vp, C.POINTER(vp)]
+    L.lrge_hip_seqset_upload_async.argtypes = [vp, vp, vp, C.c_uint32, vp, C.POINTER(vp)]
+    L.lrge_hip_seqset_wait.argtypes = [vp]
+    L.lrge_hip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.lrge_hip_host_free.argtypes = [vp]
+    L.lrge_hip_host_free.restype = None
     L.lrge_hip_seqset_free.argtypes = [vp]
     L.lrge_hip_seqset_free.restype = None
     L.lrge_hip_seqset_size.argtypes = [vp]

@@ -86,6 +86,12 @@ struct lrge_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;           // side stream: k_chain_lpg runs beside k_chain_hw (both are latency-, not throughput-bound)
+    // Upload path (lrge_hip_seqset_upload*): host -> device copies and the 2-bit pack run on their own stream, so that a
+    // set's transfer overlaps whatever the main stream does for another set (the queries travel while the target index
+    // is built).  A pageable source is staged through two pinned buffers filled by a few host threads.
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_gate = nullptr;            // main stream -> copy stream ordering at the start of an upload
+    char *stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; size_t stage_cap = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     DevPool pool;
@@ -159,6 +165,13 @@ struct lrge_hip_seqset {
     u32 *d_rank = nullptr;      // [n]
     u32 *d_cs = nullptr;        // [n+1] sketch chunk map: first 128-base chunk of each read
     u64 n_chunks = 0;
+    // upload in flight on ctx->copy_stream: consumers order themselves behind ev_ready (seqset_ready); the staging
+    // blocks below go back to the pool then
+    bool pooled = false;        // device arrays come from the context's pool (not hipMalloc)
+    bool pending = false;
+    hipEvent_t ev_ready = nullptr;
+    void *stg_ascii = nullptr, *stg_boff = nullptr, *stg_blk = nullptr;
+    std::vector<u64> h_boff; std::vector<u32> h_blk;
     std::vector<u32> h_cs;
     // host copies needed for planning
     std::vector<u64> h_woff;

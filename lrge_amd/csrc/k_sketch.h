@@ -18,39 +18,55 @@
 // ------------------------------------------------------------------------------------------
 // K0: one thread per 32-base word of the packed image
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 nt4_code(u8 c) {
-    // A/a=0 C/c=1 G/g=2 T/t/U/u=3 else 4 (mm2: seq_nt4_table)
-    u32 u = c & 0xDF;  // upper-case
-    u32 r = 4;
-    r = (u == 'A') ? 0 : r;
-    r = (u == 'C') ? 1 : r;
-    r = (u == 'G') ? 2 : r;
-    r = (u == 'T' || u == 'U') ? 3 : r;
-    // (c & 0xDF) maps a few non-letters onto letters ('!'..): only letters may match
-    bool is_alpha = (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
-    return is_alpha ? r : 4;
+// A/a=0 C/c=1 G/g=2 T/t/U/u=3 else 4 (mm2: seq_nt4_table).  For the five letters (either case) bits 1..2 of the ASCII code
+// are A 00, C 01, G 11, T/U 10, so the 2-bit code is b ^ (b >> 1) of those two bits; a byte is one of the letters iff
+// it lies in [0x40, 0x7f] and bit (c & 31) of {1, 3, 7, 20, 21} is set.
+__device__ __forceinline__ u32 nt4_code(u32 c) {
+    const u32 b = (c >> 1) & 3;
+    const bool letter = (c & 0xC0u) == 0x40u && ((0x0030008Au >> (c & 31)) & 1u);
+    return letter ? (b ^ (b >> 1)) : 4u;
 }
 
-__global__ __launch_bounds__(256) void k_pack(const u8 *__restrict__ ascii, const u64 *__restrict__ boff,
-                                              const u64 *__restrict__ woff, u32 n_reads, u64 n_words,
-                                              u64 *__restrict__ pack, u32 *__restrict__ nmask) {
-    u64 wid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+#define PACK_THREADS 256
+// One lane per 32-base word of the packed image.  `blk_read[b]` (computed on the host with the word offsets) is the read
+// that holds the first word of block b, so a lane finds its read with a short forward scan instead of a binary search;
+// a word's 32 source bytes are fetched as two (byte-aligned) 16-byte loads.
+__global__ __launch_bounds__(PACK_THREADS) void k_pack(const u8 *__restrict__ ascii, const u64 *__restrict__ boff,
+                                                       const u64 *__restrict__ woff, const u32 *__restrict__ blk_read, u32 n_reads,
+                                                       u64 n_words, u64 *__restrict__ pack, u32 *__restrict__ nmask) {
+    const u64 wid = (u64)blockIdx.x * PACK_THREADS + threadIdx.x;
     if (wid >= n_words) return;
-    // read r with woff[r] <= wid < woff[r+1]
-    u32 lo = 0, hi = n_reads;
-    while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (woff[mid] <= wid) lo = mid; else hi = mid; }
-    u32 r = lo;
-    u64 pos0 = (wid - woff[r]) * 32;
-    u64 len = boff[r + 1] - boff[r];
-    const u8 *src = ascii + boff[r] + pos0;
-    u64 w = 0; u32 m = 0;
-    u32 cnt = (u32)(len - pos0 < 32 ? len - pos0 : 32);
-    for (u32 i = 0; i < cnt; ++i) {
-        u32 c = nt4_code(src[i]);
-        w |= (u64)(c & 3) << (2 * i);
-        m |= (c >> 2) << i;
+    u32 r = blk_read[blockIdx.x];
+    while (r + 1 < n_reads && woff[r + 1] <= wid) ++r;          // (empty reads own no word and are stepped over)
+    const u64 pos0 = (wid - woff[r]) * 32;
+    const u64 b0 = boff[r], len = boff[r + 1] - b0;
+    const u8 *src = ascii + b0 + pos0;
+    const u32 cnt = (u32)(len - pos0 < 32 ? len - pos0 : 32);
+    u32 v[8];
+    if (cnt == 32) {
+        uint4 lo, hi;
+        __builtin_memcpy(&lo, src, 16); __builtin_memcpy(&hi, src + 16, 16);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    } else {                                                        // the last word of a read: never read past its end
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            u32 x = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const u32 i = 4 * j + t; if (i < cnt) x |= (u32)src[i] << (8 * t); }
+            v[j] = x;
+        }
     }
-    if (cnt < 32) m |= ~0u << cnt;  // padding past the end of the read is "ambiguous"
+    u64 w = 0; u32 m = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32 c = nt4_code((v[j] >> (8 * t)) & 0xffu);
+            w |= (u64)(c & 3) << (2 * (4 * j + t));
+            m |= (c >> 2) << (4 * j + t);
+        }
+    }
+    if (cnt < 32) { m |= ~0u << cnt; w &= (1ULL << (2 * cnt)) - 1; }   // padding past the end of the read is "ambiguous"
     pack[wid] = w;
     nmask[wid] = m;
 }

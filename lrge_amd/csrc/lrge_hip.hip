@@ -8,6 +8,7 @@
 #include <memory>
 #include <set>
 #include <mutex>
+#include <thread>
 
 #include "internal.h"
 #include "k_prims.h"
@@ -47,6 +48,7 @@ extern "C" int lrge_hip_ctx_set_option(lrge_hip_ctx *ctx, const char *name, cons
     return LRGE_OK;
 }
 
+extern "C" void lrge_hip_seqset_free(lrge_hip_seqset *s);
 extern "C" const char *lrge_hip_version(void) { return "lrge_hip 0.1.0 (gfx950)"; }
 
 extern "C" int lrge_hip_device_count(int *n) {
@@ -110,7 +112,8 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     ctx->device = device;
     load_env_options(ctx);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        pick_side_stream(ctx) != hipSuccess ||
+        pick_side_stream(ctx) != hipSuccess || hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_gate, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         g_last_error = "hipSetDevice/hipStreamCreate failed";
@@ -142,7 +145,10 @@ extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
     { std::lock_guard<std::mutex> g(g_live_mu); g_live_ctx.erase(ctx); }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->copy_stream);
     ctx->resolve_timers();
+    for (int b = 0; b < 2; ++b) { if (ctx->stage[b]) (void)hipHostFree(ctx->stage[b]); if (ctx->stage_ev[b]) (void)hipEventDestroy(ctx->stage_ev[b]); }
+    (void)hipEventDestroy(ctx->ev_gate); (void)hipStreamDestroy(ctx->copy_stream);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->pool.destroy();
     if (ctx->pin) (void)hipHostFree(ctx->pin);
@@ -175,28 +181,66 @@ extern "C" int lrge_hip_last_counters(const lrge_hip_ctx *ctx, uint64_t c[LRGE_C
 // ------------------------------------------------------------------------------------------
 // read sets
 // ------------------------------------------------------------------------------------------
-extern "C" int lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, const uint64_t *offsets, uint32_t n,
-                                      const uint32_t *name_rank, lrge_hip_seqset **out) {
+extern "C" int lrge_hip_host_alloc(size_t bytes, void **out) {
+    if (!out) return LRGE_ERR_INVALID;
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); g_last_error = hipGetErrorString(e); return LRGE_ERR_DEVICE; }
+    return LRGE_OK;
+}
+extern "C" void lrge_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// Every consumer of a set's device arrays calls this first: work queued on the main stream after it runs behind the
+// set's upload; the staging blocks of the upload return to the pool (recycled in main-stream order from here on).
+static int seqset_ready(lrge_hip_ctx *ctx, const lrge_hip_seqset *cs) {
+    lrge_hip_seqset *s = const_cast<lrge_hip_seqset *>(cs);
+    if (!s->pending) return LRGE_OK;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_ready, 0));
+    s->pending = false;
+    ctx->pool.release(s->stg_ascii); ctx->pool.release(s->stg_boff); ctx->pool.release(s->stg_blk);
+    s->stg_ascii = s->stg_boff = s->stg_blk = nullptr;
+    return LRGE_OK;
+}
+
+// pageable source -> pinned staging buffer with a few host threads (one thread moves ~10 GB/s, PCIe Gen5 x16 ~55)
+static void parallel_memcpy(char *dst, const char *src, size_t n) {
+    const size_t kMin = (size_t)4 << 20;
+    const unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, n / kMin));
+    if (nt <= 1) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n / nt + 63) & ~(size_t)63;
+    for (unsigned t = 1; t < nt; ++t) {
+        const size_t o = std::min(n, per * t), e = std::min(n, per * (t + 1));
+        if (e > o) th.emplace_back([=] { memcpy(dst + o, src + o, e - o); });
+    }
+    memcpy(dst, src, std::min(n, per));
+    for (auto &x : th) x.join();
+}
+
+static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64_t *offsets, uint32_t n, const uint32_t *name_rank,
+                              bool async, lrge_hip_seqset **out) {
     if (!ctx || !out || (n && (!bases || !offsets))) return LRGE_ERR_INVALID;
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
-    lrge_hip_seqset *s = new lrge_hip_seqset();
-    s->ctx = ctx; s->n = n;
-    s->h_woff.resize((size_t)n + 1); s->h_len.resize(n ? n : 1);
+    std::unique_ptr<lrge_hip_seqset, void (*)(lrge_hip_seqset *)> guard(new lrge_hip_seqset(), lrge_hip_seqset_free);
+    lrge_hip_seqset *s = guard.get();
+    s->ctx = ctx; s->n = n; s->pooled = true;
+    s->h_woff.resize((size_t)n + 1); s->h_len.resize(n ? n : 1); s->h_boff.resize((size_t)n + 1);
     u64 w = 0;
     for (u32 i = 0; i < n; ++i) {
         if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] >= (1ULL << 31)) {
-            LRGE_SET_ERR(ctx, "read %u: bad offsets or length >= 2^31", i); delete s; return LRGE_ERR_INVALID;
+            LRGE_SET_ERR(ctx, "read %u: bad offsets or length >= 2^31", i); return LRGE_ERR_INVALID;
         }
         u32 len = (u32)(offsets[i + 1] - offsets[i]);
-        s->h_woff[i] = w; s->h_len[i] = len;
+        s->h_woff[i] = w; s->h_len[i] = len; s->h_boff[i] = offsets[i] - offsets[0];
         w += (len + 31) / 32;
         if (len == 0) s->has_empty = true;
         if (len > s->max_len) s->max_len = len;
     }
     s->h_woff[n] = w; s->n_words = w;
     s->total_bases = n ? offsets[n] - offsets[0] : 0;
+    s->h_boff[n] = s->total_bases;
     if (name_rank) {
         s->has_rank = true;
         s->h_rank.assign(name_rank, name_rank + n);
@@ -205,58 +249,112 @@ extern "C" int lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, cons
         std::sort(tmp.begin(), tmp.end());
         for (u32 i = 1; i < n; ++i) if (tmp[i] == tmp[i - 1]) { s->dup_rank = true; break; }
     }
-    auto fail = [&](const char *what, hipError_t e) {
-        LRGE_SET_ERR(ctx, "seqset_upload: %s: %s", what, hipGetErrorString(e));
-        lrge_hip_seqset_free(s);
-        return LRGE_ERR_DEVICE;
-    };
-    hipError_t e;
-    size_t nw = (size_t)(w ? w : 1);
-    if ((e = hipMalloc((void **)&s->d_pack, nw * 8)) != hipSuccess) return fail("hipMalloc pack", e);
-    if ((e = hipMalloc((void **)&s->d_nmask, nw * 4)) != hipSuccess) return fail("hipMalloc nmask", e);
-    if ((e = hipMalloc((void **)&s->d_woff, ((size_t)n + 1) * 8)) != hipSuccess) return fail("hipMalloc woff", e);
-    if ((e = hipMalloc((void **)&s->d_len, (size_t)(n ? n : 1) * 4)) != hipSuccess) return fail("hipMalloc len", e);
     {   // sketch chunk map (read -> first chunk), fixed for the life of the set
         s->h_cs.resize((size_t)n + 1);
         u64 nc = 0;
         for (u32 i = 0; i < n; ++i) { s->h_cs[i] = (u32)nc; nc += (s->h_len[i] + SK_CHUNK - 1) / SK_CHUNK; }
         s->n_chunks = nc;
         s->h_cs[n] = (u32)nc;
-        if ((e = hipMalloc((void **)&s->d_cs, ((size_t)n + 1) * 4)) != hipSuccess) return fail("hipMalloc chunk map", e);
-        if (nc < (1ULL << 32) && (e = hipMemcpyAsync(s->d_cs, s->h_cs.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-            return fail("copy chunk map", e);
     }
-    if ((e = hipMalloc((void **)&s->d_rank, (size_t)(n ? n : 1) * 4)) != hipSuccess) return fail("hipMalloc rank", e);
-    if ((e = hipMemcpyAsync(s->d_woff, s->h_woff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("copy woff", e);
+    const u64 n_blk = div_up(w, PACK_THREADS);
+    {   // k_pack: read that holds the first word of every block
+        s->h_blk.resize((size_t)n_blk + 1);
+        u32 r = 0;
+        for (u64 b = 0; b < n_blk; ++b) {
+            const u64 w0 = b * PACK_THREADS;
+            while (r + 1 < n && s->h_woff[r + 1] <= w0) ++r;
+            s->h_blk[b] = r;
+        }
+    }
+    hipError_t e = hipSuccess;
+    auto alloc = [&](size_t bytes) -> void * { return ctx->pool.alloc(bytes, &e); };
+    const size_t nw = (size_t)(w ? w : 1);
+    s->d_pack = (u64 *)alloc(nw * 8); s->d_nmask = (u32 *)alloc(nw * 4);
+    s->d_woff = (u64 *)alloc(((size_t)n + 1) * 8); s->d_len = (u32 *)alloc((size_t)(n ? n : 1) * 4);
+    s->d_cs = (u32 *)alloc(((size_t)n + 1) * 4); s->d_rank = (u32 *)alloc((size_t)(n ? n : 1) * 4);
+    s->stg_boff = alloc(((size_t)n + 1) * 8); s->stg_blk = alloc((size_t)(n_blk + 1) * 4);
+    if (!s->d_pack || !s->d_nmask || !s->d_woff || !s->d_len || !s->d_cs || !s->d_rank || !s->stg_boff || !s->stg_blk) {
+        LRGE_SET_ERR(ctx, "seqset_upload: device allocation failed: %s", hipGetErrorString(e)); return LRGE_ERR_DEVICE;
+    }
+    // where do the bases live?  device memory (no copy at all), pinned host memory (one DMA), pageable host memory (staged)
+    const char *src = n ? bases + offsets[0] : nullptr;
+    int kind = 2;                                         // 0 device, 1 pinned host, 2 pageable host
+    if (src && s->total_bases) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, src) == hipSuccess) {
+            if (at.type == hipMemoryTypeDevice) kind = 0; else if (at.type == hipMemoryTypeHost) kind = 1;
+        } else (void)hipGetLastError();
+    }
+    const u8 *d_ascii = (const u8 *)src;
+    if (kind != 0 && s->total_bases) {
+        s->stg_ascii = alloc(s->total_bases);
+        if (!s->stg_ascii) { LRGE_SET_ERR(ctx, "seqset_upload: device allocation failed: %s", hipGetErrorString(e)); return LRGE_ERR_DEVICE; }
+        d_ascii = (const u8 *)s->stg_ascii;
+    }
+    if (!s->ev_ready) s->ev_ready = ctx->get_event();
+    hipStream_t cs = ctx->copy_stream;
+    // the blocks just taken from the pool may still be in use by work queued on the main stream
+    HIPCHK(ctx, hipEventRecord(ctx->ev_gate, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(cs, ctx->ev_gate, 0));
+    s->pending = true;                                     // (from here on seqset_free drains the copy stream first)
+    HIPCHK(ctx, hipMemcpyAsync(s->d_woff, s->h_woff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, cs));
+    HIPCHK(ctx, hipMemcpyAsync(s->stg_boff, s->h_boff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, cs));
+    HIPCHK(ctx, hipMemcpyAsync(s->stg_blk, s->h_blk.data(), (size_t)(n_blk + 1) * 4, hipMemcpyHostToDevice, cs));
+    if (s->n_chunks < (1ULL << 32)) HIPCHK(ctx, hipMemcpyAsync(s->d_cs, s->h_cs.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, cs));
     if (n) {
-        if ((e = hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("copy len", e);
-        if (name_rank && (e = hipMemcpyAsync(s->d_rank, name_rank, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("copy rank", e);
+        HIPCHK(ctx, hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, cs));
+        if (name_rank) HIPCHK(ctx, hipMemcpyAsync(s->d_rank, s->h_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, cs));
+    }
+    if (kind == 1) {
+        HIPCHK(ctx, hipMemcpyAsync(s->stg_ascii, src, s->total_bases, hipMemcpyHostToDevice, cs));
+    } else if (kind == 2 && s->total_bases) {
+        if (!ctx->stage[0]) {
+            const size_t cap = (size_t)64 << 20;
+            for (int b = 0; b < 2; ++b) {
+                HIPCHK(ctx, hipHostMalloc((void **)&ctx->stage[b], cap, hipHostMallocDefault));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_ev[b], hipEventDisableTiming));
+                HIPCHK(ctx, hipEventRecord(ctx->stage_ev[b], cs));
+            }
+            ctx->stage_cap = cap;
+        }
+        int b = 0;
+        for (u64 o = 0; o < s->total_bases; o += ctx->stage_cap, b ^= 1) {
+            const size_t len = (size_t)std::min<u64>(ctx->stage_cap, s->total_bases - o);
+            HIPCHK(ctx, hipEventSynchronize(ctx->stage_ev[b]));          // the DMA that last read this buffer
+            parallel_memcpy(ctx->stage[b], src + o, len);
+            HIPCHK(ctx, hipMemcpyAsync((char *)s->stg_ascii + o, ctx->stage[b], len, hipMemcpyHostToDevice, cs));
+            HIPCHK(ctx, hipEventRecord(ctx->stage_ev[b], cs));
+        }
     }
     if (w) {
-        // stage ASCII + byte offsets, pack on the device, drop the staging buffers
-        u8 *d_ascii = nullptr; u64 *d_boff = nullptr;
-        u64 nbytes = s->total_bases;
-        if ((e = hipMalloc((void **)&d_ascii, nbytes)) != hipSuccess) return fail("hipMalloc ascii", e);
-        if ((e = hipMalloc((void **)&d_boff, ((size_t)n + 1) * 8)) != hipSuccess) { (void)hipFree(d_ascii); return fail("hipMalloc boff", e); }
-        std::vector<u64> rel((size_t)n + 1);
-        for (u32 i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
-        e = hipMemcpyAsync(d_ascii, bases + offsets[0], nbytes, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_boff, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) {
-            StageTimer t(ctx, LRGE_T_PACK);
-            hipLaunchKernelGGL(k_pack, dim3((u32)div_up(w, 256)), dim3(256), 0, ctx->stream, d_ascii, d_boff, s->d_woff, n, w,
-                               s->d_pack, s->d_nmask);
-            e = hipGetLastError();
-            t.stop();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        ctx->resolve_timers();
-        (void)hipFree(d_ascii); (void)hipFree(d_boff);
-        if (e != hipSuccess) return fail("pack", e);
-    } else {
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail("sync", e);
+        // (timed only in the blocking form: a pending event pair would make the next call's timer resolution wait for
+        // this upload on the host)
+        std::unique_ptr<StageTimer> t(async ? nullptr : new StageTimer(ctx, LRGE_T_PACK, cs));
+        hipLaunchKernelGGL(k_pack, dim3((u32)n_blk), dim3(PACK_THREADS), 0, cs, d_ascii, (const u64 *)s->stg_boff, s->d_woff,
+                           (const u32 *)s->stg_blk, n, w, s->d_pack, s->d_nmask);
+        KCHK(ctx);
     }
-    *out = s;
+    HIPCHK(ctx, hipEventRecord(s->ev_ready, cs));
+    // async: the per-read arrays travel from the set's own host copies (they live as long as the set); only `bases`
+    // must stay valid, and only when it is pinned host memory (a pageable source has been copied out by now)
+    if (!async) { HIPCHK(ctx, hipStreamSynchronize(cs)); ctx->resolve_timers(); }
+    *out = guard.release();
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_seqset_upload(lrge_hip_ctx *ctx, const char *bases, const uint64_t *offsets, uint32_t n,
+                                      const uint32_t *name_rank, lrge_hip_seqset **out) {
+    return seqset_upload_impl(ctx, bases, offsets, n, name_rank, false, out);
+}
+extern "C" int lrge_hip_seqset_upload_async(lrge_hip_ctx *ctx, const char *bases, const uint64_t *offsets, uint32_t n,
+                                            const uint32_t *name_rank, lrge_hip_seqset **out) {
+    return seqset_upload_impl(ctx, bases, offsets, n, name_rank, true, out);
+}
+extern "C" int lrge_hip_seqset_wait(lrge_hip_seqset *s) {
+    if (!s) return LRGE_ERR_INVALID;
+    lrge_hip_ctx *ctx = s->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (s->pending) HIPCHK(ctx, hipEventSynchronize(s->ev_ready));
     return LRGE_OK;
 }
 
@@ -277,7 +375,18 @@ extern "C" void lrge_hip_seqset_free(lrge_hip_seqset *s) {
     { std::lock_guard<std::mutex> g(g_live_mu); ctx_alive = g_live_ctx.count(s->ctx) != 0; }
     if (ctx_alive) { (void)hipSetDevice(s->ctx->device); presketch_discard(s); }   // (a set that outlives its context only owns its own arrays)
     if (s->is_view) { (void)hipFree(s->d_cs); delete s; return; }                   // a view owns its chunk map only
-    (void)hipFree(s->d_pack); (void)hipFree(s->d_nmask); (void)hipFree(s->d_woff); (void)hipFree(s->d_len); (void)hipFree(s->d_rank); (void)hipFree(s->d_cs);
+    if (s->pooled) {
+        if (ctx_alive) {       // (a destroyed context has already freed its pool)
+            lrge_hip_ctx *ctx = s->ctx;
+            if (s->pending) (void)hipStreamSynchronize(ctx->copy_stream);          // an upload nobody consumed
+            DevPool &P = ctx->pool;
+            P.release(s->d_pack); P.release(s->d_nmask); P.release(s->d_woff); P.release(s->d_len); P.release(s->d_rank); P.release(s->d_cs);
+            P.release(s->stg_ascii); P.release(s->stg_boff); P.release(s->stg_blk);
+            if (s->ev_ready) ctx->event_pool.push_back(s->ev_ready);
+        }
+    } else {
+        (void)hipFree(s->d_pack); (void)hipFree(s->d_nmask); (void)hipFree(s->d_woff); (void)hipFree(s->d_len); (void)hipFree(s->d_rank); (void)hipFree(s->d_cs);
+    }
     delete s;
 }
 extern "C" uint32_t lrge_hip_seqset_size(const lrge_hip_seqset *s) { return s ? s->n : 0; }
@@ -381,8 +490,10 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
 
 static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o,
                          u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr) {
+    int rc = seqset_ready(ctx, s);
+    if (rc) return rc;
     StageTimer t(ctx, LRGE_T_SKETCH);
-    int rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff)
+    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff)
                                             : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff);
     t.stop();
     return rc;
@@ -432,6 +543,7 @@ static int presketch_start_pending(lrge_hip_ctx *ctx) {
     ctx->presk_pending = nullptr;
     if (s->total_bases > ctx->opt_u64("STREAM_BASES", 4000000000ull)) return LRGE_OK;   // streamed in views: sketched per view
     if (s->presk) presketch_discard(s);
+    if (seqset_ready(ctx, s) != LRGE_OK) return LRGE_OK;     // (the side stream is forked off the main stream below)
     PreSketch *p = new PreSketch();
     p->preset = ctx->presk_preset;
     p->sc = new Scratch(ctx);
@@ -648,6 +760,8 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
 // Reads [r0, r1) of `s` as a set of its own: the packed image, the masks and the per-read arrays are shared (word offsets
 // are absolute), only the sketch chunk map is rebuilt so that chunk ids start at 0.
 static int seqset_view(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, u32 r0, u32 r1, lrge_hip_seqset **out) {
+    int rrc = seqset_ready(ctx, s);
+    if (rrc) return rrc;
     lrge_hip_seqset *v = new lrge_hip_seqset();
     v->ctx = ctx; v->is_view = true; v->n = r1 - r0;
     v->has_rank = s->has_rank; v->dup_rank = s->dup_rank;
@@ -1008,10 +1122,11 @@ int OverlapRun::seeds() {
     if (!hs || !hc || !hn || !hv || !krank || !d_qtot) return LRGE_ERR_DEVICE;
     h_qtot.assign((size_t)nq + 1, 0);
     if (Mq) {
-        StageTimer t(ctx, LRGE_T_LOOKUP);
+        StageTimer t(ctx, LRGE_T_LOOKUP), tk(ctx, LRGE_T_K_LOOKUP);
         hipLaunchKernelGGL(k_lookup, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, Mq, sp, hs, hc);
         KCHK(ctx);
-        t.stop();
+        tk.stop(); t.stop();
+        ctx->counters[LRGE_C_LOOKUP_LAUNCHES] += 1;
     }
 
     // ---- 3. query occurrence filter (mm_seed_mz_flt) ----
@@ -1485,6 +1600,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         LRGE_SET_ERR(ctx, "Error mapping read: Sequence is empty");
         return LRGE_ERR_MAP;
     }
+    { int rrc = seqset_ready(ctx, Q); if (rrc) return rrc; rrc = seqset_ready(ctx, ix->seqs); if (rrc) return rrc; }
     StageTimer t_total(ctx, LRGE_T_TOTAL);
     OverlapRun R(ctx, ix, Q, job);
     auto done = [&](int rc) -> int {            // common exit: total time, drain the stream, resolve the stage timers

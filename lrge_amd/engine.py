@@ -77,8 +77,19 @@ class Context:
         self._lib.lrge_hip_last_counters(self.h, C.byref(a))
         return dict(zip(_ffi.C_NAMES, [int(x) for x in a]))
 
-    def upload(self, bases, offsets, ranks=None):
-        return SeqSet(self, bases, offsets, ranks)
+    def upload(self, bases, offsets, ranks=None, wait=True):
+        """Read set -> 2-bit packed in HBM.  `bases`: numpy uint8 (pageable or pinned host memory, see host_alloc) or an
+        int device pointer to ASCII already resident in HBM.  wait=False queues the transfer + pack on the copy stream
+        and returns (lrge_hip_seqset_upload_async): later calls order themselves behind it on the device."""
+        return SeqSet(self, bases, offsets, ranks, wait)
+
+    def host_alloc(self, nbytes):
+        """Pinned host buffer as a numpy uint8 array (lrge_hip_host_alloc): a DMA source without staging."""
+        p = C.c_void_p()
+        rc = self._lib.lrge_hip_host_alloc(int(nbytes), C.byref(p))
+        if rc != 0:
+            raise LrgeHipError(rc, self._lib.lrge_hip_last_error(None).decode())
+        return PinnedBuffer(self._lib, p, int(nbytes))
 
     def estimates(self, counts, read_lens, avg_target_len, n_target_reads, overlap_thresh=100):
         counts = np.ascontiguousarray(counts, dtype=np.uint32)
@@ -103,24 +114,54 @@ def median(estimates, finite=True, lower=None, upper=None):
     return tuple(np.float32(out[i]) if ok[i] else None for i in range(3))
 
 
+class PinnedBuffer:
+    """Pinned host memory owned by the library; `.array` is a numpy uint8 view of it."""
+
+    def __init__(self, lib, ptr, nbytes):
+        self._lib, self.ptr, self.nbytes = lib, ptr, nbytes
+        self.array = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(nbytes, 1),))[:nbytes]
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._lib.lrge_hip_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class SeqSet:
-    def __init__(self, ctx, bases, offsets, ranks=None):
+    def __init__(self, ctx, bases, offsets, ranks=None, wait=True):
         self.ctx = ctx
-        bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.n = offsets.size - 1
         self.lens = np.diff(offsets).astype(np.uint32)
+        if isinstance(bases, (int, np.integer)):          # device pointer to resident ASCII
+            ptr, self._src = int(bases), None
+        else:
+            if isinstance(bases, PinnedBuffer):
+                self._src, bases = bases, bases.array
+            bases = np.ascontiguousarray(bases, dtype=np.uint8)
+            ptr = bases.ctypes.data if bases.size else None
+            self._src = (getattr(self, "_src", None), bases)   # an async upload reads the source until the set is consumed
         r = None if ranks is None else np.ascontiguousarray(ranks, dtype=np.uint32)
         h = C.c_void_p()
-        ctx._check(ctx._lib.lrge_hip_seqset_upload(ctx.h, bases.ctypes.data if bases.size else None,
-                                                   offsets.ctypes.data, self.n,
-                                                   None if r is None else r.ctypes.data, C.byref(h)))
+        fn = ctx._lib.lrge_hip_seqset_upload if wait else ctx._lib.lrge_hip_seqset_upload_async
+        ctx._check(fn(ctx.h, ptr, offsets.ctypes.data, self.n, None if r is None else r.ctypes.data, C.byref(h)))
         self.h = h
+
+    def wait(self):
+        self.ctx._check(self.ctx._lib.lrge_hip_seqset_wait(self.h))
 
     def free(self):
         if getattr(self, "h", None):
-            self.ctx._lib.lrge_hip_seqset_free(self.h)
+            self.ctx._lib.lrge_hip_seqset_free(self.h)     # (drains a pending upload before the source may go)
             self.h = None
+        self._src = None
 
     def __del__(self):
         try:
@@ -146,10 +187,13 @@ class SeqSet:
 class Index:
     """AlignerWrapper::new(target_file, threads, preset, dual) -- aligner.rs:310-328."""
 
-    def __init__(self, ctx, targets, preset=_ffi.PRESET_AVA_ONT):
+    def __init__(self, ctx, targets, preset=_ffi.PRESET_AVA_ONT, streamed=None, comm=None):
         self.ctx, self.targets, self.preset = ctx, targets, preset
         h = C.c_void_p()
-        ctx._check(ctx._lib.lrge_hip_index_build(ctx.h, targets.h, preset, C.byref(h)))
+        if streamed is None and comm is None:
+            ctx._check(ctx._lib.lrge_hip_index_build(ctx.h, targets.h, preset, C.byref(h)))
+        else:
+            raise NotImplementedError("restricted / sharded index build")
         self.h = h
         self.build_timings = ctx.timings()
         self.build_counters = ctx.counters()

@@ -1,0 +1,198 @@
+"""GPU: the BASELINE.json configurations themselves against the CPU oracle, at their full sizes.
+
+  C2  4.4 Mbp ONT, two-set -Q 5000 -T 10000   every count, has_mapping, mid_occ, estimate / q15 / q65 (f32, 0 ulp)
+  C3  12 Mbp ONT, all-vs-all -n 20000          every count
+  C4  143 Mbp ONT, two-set -Q 50000 -T 100000  the first 1024 queries against the FULL target index, mid_occ;
+                                               all 50 000 counts through size-independent properties
+  C5/10  310 Mbp HiFi, -Q 10000 -T 200000      both presets (ava-pb = library semantics, ava-ont = what the reference CLI
+                                               runs), forward (first 256 queries) and inverse (--use-min-ref: every
+                                               indexed read, targets streamed) -- the full-size C5 needs ~25 minutes of
+                                               data generation and is run by tools/run_config.py (profiles/)
+
+Reference semantics: twoset.rs:286-317 (forward), ava.rs:271-306, twoset.rs:485-524 (inverse).  Each oracle run is
+repeated with sort_mode = SORT_MM2 (the emulation of ksort.h's unstable radix_sort_128x): the device implements the stable
+tie order, so this is where the two policies are compared on data with enough anchors for ties to occur.
+The oracle is the builder's restatement of minimap2 2.30 -- parity is unpinned against the real thing.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THREADS = os.cpu_count() or 8
+
+
+def _sets(ctx, q, t):
+    from lrge_amd import engine
+    qr, tr = engine.name_ranks(q.names, t.names)
+    return ctx.upload(q.bases, q.offsets, qr), ctx.upload(t.bases, t.offsets, tr)
+
+
+def _oracle_index(oracle, reads, preset, dual=True):
+    opt = oracle.make_opt(oracle.PRESET_AVA_PB if preset == 1 else oracle.PRESET_AVA_ONT, dual=dual)
+    return oracle.Index(oracle.ReadSet(reads.seqs(), reads.names), opt)
+
+
+def _both_policies(oracle, ixo, fn):
+    """fn() under the stable tie order and under the radix_sort_128x emulation."""
+    out = []
+    for mode in (oracle.SORT_STABLE, oracle.SORT_MM2):
+        ixo.opt.sort_mode = mode
+        out.append(fn())
+    ixo.opt.sort_mode = oracle.SORT_STABLE
+    return out
+
+
+def test_c2_full(ctx, oracle):
+    from lrge_amd import engine, synth
+    gsize, q, t = synth.make_config("c2_bact_twoset")
+    assert (q.n, t.n) == (5000, 10000)
+    Qd, Td = _sets(ctx, q, t)
+    Qd.presketch(0)
+    ix = engine.Index(ctx, Td, 0)
+    counts, has = ix.overlap_twoset(Qd)
+    st = ix.stats()
+    avg = np.float32(t.lens().sum()) / np.float32(t.n)
+    est = ctx.estimates(counts, q.lens(), float(avg), t.n, 100)
+    med = engine.median(est, True, 0.15, 0.65)
+    ix.free(); Qd.free(); Td.free()
+
+    ixo = _oracle_index(oracle, t, 0)
+    assert st["mid_occ"] == ixo.mid_occ and st["n_minimizers"] == ixo.n_minimizers and st["n_keys"] == ixo.n_keys
+    Qo = oracle.ReadSet(q.seqs(), q.names)
+    (rc, ec, eh), (rc2, ec2, eh2) = _both_policies(oracle, ixo, lambda: ixo.twoset_counts(Qo, threads=THREADS))
+    assert rc == 0 and rc2 == 0
+    assert np.array_equal(counts, ec) and np.array_equal(has, eh)
+    assert np.array_equal(ec, ec2) and np.array_equal(eh, eh2), "tie policies differ on %d reads" % int((ec != ec2).sum())
+    # estimates: f32, bit for bit (same counts -> same multiset; per_read_estimate is evaluated with one rounding per op)
+    eest = np.array([oracle.per_read_estimate(int(l), float(avg), t.n, int(c), 100) for l, c in zip(q.lens(), ec)], dtype=np.float32)
+    assert np.array_equal(est.view(np.uint32), eest.view(np.uint32))
+    emed = oracle.median(eest, True, 0.15, 0.65)
+    assert [np.float32(x).view(np.uint32) for x in med] == [np.float32(x).view(np.uint32) for x in emed]
+    assert abs(float(med[1]) - gsize) / gsize < 0.15          # 4.4 Mbp genome: the estimate lands near it
+
+
+def test_c3_full_ava(ctx, oracle):
+    from lrge_amd import engine, synth
+    gsize, reads, _ = synth.make_config("c3_yeast_ava")
+    assert reads.n == 20000
+    (ranks,) = engine.name_ranks(reads.names)
+    Rd = ctx.upload(reads.bases, reads.offsets, ranks)
+    Rd.presketch(0)
+    ix = engine.Index(ctx, Rd, 0)
+    counts = ix.overlap_ava()
+    st = ix.stats()
+    ix.free(); Rd.free()
+    ixo = _oracle_index(oracle, reads, 0, dual=False)
+    assert st["mid_occ"] == ixo.mid_occ
+    (rc, ec), (rc2, ec2) = _both_policies(oracle, ixo, lambda: ixo.ava_counts(threads=THREADS))
+    assert rc == 0 and rc2 == 0
+    assert np.array_equal(counts, ec)
+    assert np.array_equal(ec, ec2), "tie policies differ on %d reads" % int((ec != ec2).sum())
+    assert int(counts.sum()) % 2 == 0 and int(counts.sum()) > 100000     # symmetric counting: every pair adds two
+
+
+def test_c4_sampled_and_properties(ctx, oracle):
+    from lrge_amd import engine, synth
+    gsize, q, t = synth.make_config("c4_dmel_twoset")
+    assert (q.n, t.n) == (50000, 100000)
+    Qd, Td = _sets(ctx, q, t)
+    Qd.presketch(0)
+    ix = engine.Index(ctx, Td, 0)
+    counts, has = ix.overlap_twoset(Qd)
+    st = ix.stats()
+    # size-independent properties on all 50 000 queries
+    #  * streamed reads are independent: any sub-range of the queries gives the same counts for those reads
+    lo, hi = 20000, 23000
+    sub = q.slice(lo, hi)
+    qr, tr = engine.name_ranks(q.names, t.names)
+    Sd = ctx.upload(sub.bases, sub.offsets, qr[lo:hi])
+    c_sub, h_sub = ix.overlap_twoset(Sd)
+    assert np.array_equal(c_sub, counts[lo:hi]) and np.array_equal(h_sub, has[lo:hi])
+    #  * a count never exceeds the number of target reads that overlap the query's true interval by >= 1 base (no false
+    #    positives on a repeat-free random genome), and has_mapping <=> count > 0 without -F
+    assert np.array_equal(has > 0, counts > 0)
+    ts, te = np.sort(t.starts), np.sort(t.ends)
+    for i in range(0, q.n, 97):
+        # targets that start before the query's source interval ends, minus those that end before it starts
+        n_touch = int(np.searchsorted(ts, q.ends[i], side="left")) - int(np.searchsorted(te, q.starts[i], side="right"))
+        assert counts[i] <= max(n_touch, 0), (i, int(counts[i]), n_touch)
+    #  * idempotence: the same call again
+    c2, h2 = ix.overlap_twoset(Qd)
+    assert np.array_equal(c2, counts) and np.array_equal(h2, has)
+    ix.free(); Qd.free(); Td.free(); Sd.free()
+
+    n = 1024
+    ixo = _oracle_index(oracle, t, 0)
+    assert st["mid_occ"] == ixo.mid_occ and st["n_minimizers"] == ixo.n_minimizers and st["n_keys"] == ixo.n_keys
+    s = q.slice(0, n)
+    Qo = oracle.ReadSet(s.seqs(), s.names)
+    (rc, ec, eh), (rc2, ec2, eh2) = _both_policies(oracle, ixo, lambda: ixo.twoset_counts(Qo, threads=THREADS))
+    assert rc == 0 and rc2 == 0
+    assert np.array_equal(counts[:n], ec) and np.array_equal(has[:n], eh)
+    assert np.array_equal(ec, ec2), "tie policies differ on %d reads" % int((ec != ec2).sum())
+
+
+@pytest.fixture(scope="module")
+def c5_tenth():
+    from lrge_amd import synth
+    gsize, q, t = synth.make_config("c5_human_tenth")
+    assert (q.n, t.n) == (10000, 200000)
+    return gsize, q, t
+
+
+@pytest.mark.parametrize("preset", [1, 0], ids=["ava-pb", "ava-ont"])
+def test_c5_tenth_forward_and_inverse(ctx, oracle, c5_tenth, preset, knobs):
+    """Forward: the first 256 queries against the full 3-Gbase target index.  Inverse (--use-min-ref): the index holds the
+    queries, the targets are streamed -- for ava-pb all 200 000 of them (every indexed read's count is checked), for
+    ava-ont the first 40 000 (the oracle streams them at ~5 k reads/s).  The forward run is forced into 3 index parts and
+    2 streamed views with ava-pb, so the partitioned paths are exercised at scale."""
+    from lrge_amd import engine
+    gsize, q, t = c5_tenth
+    Qd, Td = _sets(ctx, q, t)
+    # ---- forward ----
+    if preset == 1:
+        knobs.set("PART_BASES", str(int(t.lens().sum()) // 3 + 1))
+        knobs.set("STREAM_BASES", str(int(q.lens().sum()) // 2 + 1))
+    Qd.presketch(preset)
+    ix = engine.Index(ctx, Td, preset)
+    counts, has = ix.overlap_twoset(Qd)
+    st = ix.stats()
+    ix.free()
+    knobs.unset("PART_BASES"); knobs.unset("STREAM_BASES")
+    ixo = _oracle_index(oracle, t, preset)
+    assert st["mid_occ"] == ixo.mid_occ and st["n_minimizers"] == ixo.n_minimizers and st["n_keys"] == ixo.n_keys
+    n = 256
+    s = q.slice(0, n)
+    Qo = oracle.ReadSet(s.seqs(), s.names)
+    (rc, ec, eh), (rc2, ec2, eh2) = _both_policies(oracle, ixo, lambda: ixo.twoset_counts(Qo, threads=THREADS))
+    assert rc == 0 and rc2 == 0
+    assert np.array_equal(counts[:n], ec) and np.array_equal(has[:n], eh)
+    assert np.array_equal(ec, ec2), "tie policies differ on %d reads" % int((ec != ec2).sum())
+    del ixo
+    # ---- inverse ----
+    n_stream = t.n if preset == 1 else 40000
+    ts = t if n_stream == t.n else t.slice(0, n_stream)
+    if n_stream == t.n:
+        Sd = Td
+    else:
+        qr, tr = engine.name_ranks(q.names, t.names)
+        Sd = ctx.upload(ts.bases, ts.offsets, tr[:n_stream])
+    Sd.presketch(preset)
+    ixq = engine.Index(ctx, Qd, preset)
+    inv = ixq.overlap_inverse(Sd)
+    stq = ixq.stats()
+    ixq.free()
+    ixo = _oracle_index(oracle, q, preset)
+    assert stq["mid_occ"] == ixo.mid_occ
+    To = oracle.ReadSet(ts.seqs(), ts.names)
+    (rc, einv), (rc2, einv2) = _both_policies(oracle, ixo, lambda: ixo.inverse_counts(To, threads=THREADS))
+    assert rc == 0 and rc2 == 0
+    assert np.array_equal(inv, einv)
+    assert np.array_equal(einv, einv2), "tie policies differ on %d reads" % int((einv != einv2).sum())
+    assert int(inv.sum()) > 1000
+    if Sd is not Td:
+        Sd.free()
+    Qd.free(); Td.free()

@@ -54,6 +54,7 @@ extern "C" {
 typedef struct lrge_hip_ctx    lrge_hip_ctx;
 typedef struct lrge_hip_seqset lrge_hip_seqset;
 typedef struct lrge_hip_index  lrge_hip_index;
+typedef struct lrge_hip_comm   lrge_hip_comm;
 
 /* Builder knobs that reach the hot path (twoset/builder.rs:41-185, ava/builder.rs:38-153). */
 typedef struct {
@@ -188,6 +189,33 @@ int  lrge_hip_chains(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip
    [qlen - qs > avg_k && tlen - re > avg_k]  (mm2:esterr.c).  Arrays have one entry per query. */
 int  lrge_hip_paf_stats(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries,
                         int32_t *rep_len, uint64_t *sum_span, uint32_t *n_kept);
+
+/*
+ * Multi-GPU: one context per GPU, every rank owns a range of the streamed reads end to end.  A
+ * communicator carries the two exchanges of the path -- a SUM all-reduce of small integer vectors (the global
+ * minimizer-occurrence histogram of lrge_hip_index_build_for; the per-indexed-read counts of the all-vs-all and inverse
+ * strategies, ava.rs:300-301, twoset.rs:520-523) and an all-gather of the per-read estimates (the `estimates` vector of
+ * twoset.rs:319-331).  Two transports:
+ *   lrge_hip_comm_create        RCCL over xGMI, one PROCESS per GPU: rank 0 calls lrge_hip_comm_unique_id and hands the
+ *                               128 bytes to the other ranks by whatever means the host has (a file, a socket, MPI,
+ *                               torch.distributed's store); every rank then calls lrge_hip_comm_create collectively.
+ *   lrge_hip_comm_create_local  the ranks are THREADS of one process (what a host that drives the GPUs from a thread
+ *                               pool wants): buffers meet in host memory behind a barrier.  All ranks share one group
+ *                               handle; collectives must be called by every rank, each from its own thread.
+ * Collectives are blocking and must be entered by all ranks in the same order.  Host-buffer forms below; the library
+ * itself uses the device forms inside lrge_hip_index_build_for.
+ */
+#define LRGE_HIP_COMM_ID_BYTES 128
+int  lrge_hip_comm_unique_id(void *id128);
+int  lrge_hip_comm_create(lrge_hip_ctx *ctx, int rank, int world, const void *id128, lrge_hip_comm **out);
+int  lrge_hip_comm_local_group_create(int world, void **group);
+void lrge_hip_comm_local_group_destroy(void *group);
+int  lrge_hip_comm_create_local(lrge_hip_ctx *ctx, int rank, void *group, lrge_hip_comm **out);
+void lrge_hip_comm_destroy(lrge_hip_comm *c);
+int  lrge_hip_comm_rank(const lrge_hip_comm *c);
+int  lrge_hip_comm_world(const lrge_hip_comm *c);
+int  lrge_hip_comm_allreduce_u32(lrge_hip_comm *c, uint32_t *inout, size_t n);                 /* in-place sum */
+int  lrge_hip_comm_allgather(lrge_hip_comm *c, const void *send, size_t bytes, void *recv);    /* recv: world * bytes */
 
 /* per_read_estimate over n reads on the device (f32, no contraction). out[i] = +inf if counts[i]==0 */
 int  lrge_hip_estimates(lrge_hip_ctx *ctx, const uint32_t *counts, const uint32_t *read_lens,

@@ -1,0 +1,158 @@
+// k_restrict.h -- the index of a multi-GPU run: restricted to the minimizers one rank's streamed reads carry, with
+// occurrence statistics that are still those of the WHOLE target set.
+//
+// mm_idx_gen indexes every target minimizer and mm_idx_cal_max_occ takes mid_occ from all distinct keys (mm2:index.c;
+// aligner.rs:144-197).  A rank that maps only its own range of the streamed reads asks mm_idx_get about the keys THOSE
+// reads carry and about no others, so its index only has to hold the entries of those keys -- complete lists, hence the
+// same answers -- provided mid_occ stays global.  Per rank:
+//   * a key set of the streamed reads' minimizers: a direct bitmap over the 2k-bit hash space when that fits (k = 15:
+//     2^30 bits = 128 MB, no false positives), else a blocked Bloom filter (3 bits inside one 64-bit word; a false positive
+//     only keeps entries nobody asks for);
+//   * one order-preserving pass over the target entries (two sweeps: count per tile, scan, write) that keeps the entries
+//     whose key is in the set, and beside them emits the bare hashes of the keys this rank OWNS (a 1/world share of the
+//     hash space) for the statistics;
+//   * the owned hashes are sorted and run-length counted into the occurrence histogram; one all-reduce (comm.h) of
+//     [distinct keys, minimizers, histogram] makes it the histogram of the whole target set, and mid_occ follows with the
+//     reference's arithmetic.
+#pragma once
+#include "internal.h"
+#include "k_prims.h"
+
+struct KeySet {
+    u64 *bits;          // n_words 64-bit words
+    u64 word_mask;      // n_words - 1 (power of two)
+    int direct;         // 1: bit index = hash itself (n_words * 64 >= 2^(2k))
+};
+
+__device__ __forceinline__ u64 ks_mix(u64 h) { h *= 0x9E3779B97F4A7C15ULL; return h ^ (h >> 29); }
+
+__device__ __forceinline__ void ks_locate(const KeySet &ks, u64 hash, u64 *word, u64 *mask) {
+    if (ks.direct) { *word = hash >> 6; *mask = 1ULL << (hash & 63); return; }
+    const u64 m = ks_mix(hash);
+    *word = (m >> 20) & ks.word_mask;
+    *mask = 1ULL << (m & 63) | 1ULL << ((m >> 6) & 63) | 1ULL << ((m >> 12) & 63);
+}
+__device__ __forceinline__ bool ks_test(const KeySet &ks, u64 hash) {
+    u64 w, m;
+    ks_locate(ks, hash, &w, &m);
+    return (ks.bits[w] & m) == m;
+}
+
+// one lane per streamed minimizer (x = hash << 8 | span)
+__global__ __launch_bounds__(256) void k_keyset_build(const u64 *__restrict__ qx, const u32 *__restrict__ d_n, KeySet ks) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *d_n) return;
+    u64 w, m;
+    ks_locate(ks, qx[i] >> 8, &w, &m);
+    atomicOr((unsigned long long *)&ks.bits[w], (unsigned long long)m);
+}
+
+// which rank owns a hash for the occurrence statistics
+__device__ __forceinline__ bool own_hash(u64 hash, u32 rank, u32 world) {
+    return world <= 1 || (u32)((ks_mix(hash) >> 32) % world) == rank;
+}
+
+#define RF_THREADS 256
+#define RF_ITEMS 8
+#define RF_TILE (RF_THREADS * RF_ITEMS)
+
+struct RestrictArgs {
+    const u64 *x; const u64 *y;     // entries: packed (y null, hash = x >> kshift) or (hash, y) pairs
+    u64 n; u32 kshift;
+    KeySet ks;
+    u32 rank, world;
+};
+
+// flags of a thread's RF_ITEMS consecutive entries: bit t = keep, bit 16 + t = owned
+__device__ __forceinline__ u32 rf_flags(const RestrictArgs &A, u64 base, u64 *xs) {
+    u32 f = 0;
+#pragma unroll
+    for (int t = 0; t < RF_ITEMS; ++t) {
+        const u64 i = base + t;
+        if (i < A.n) {
+            const u64 x = A.x[i];
+            xs[t] = x;
+            const u64 h = x >> A.kshift;
+            if (ks_test(A.ks, h)) f |= 1u << t;
+            if (own_hash(h, A.rank, A.world)) f |= 1u << (16 + t);
+        } else xs[t] = 0;
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(RF_THREADS) void k_restrict_count(RestrictArgs A, u32 *__restrict__ bc_keep, u32 *__restrict__ bc_own) {
+    __shared__ u32 wk[RF_THREADS / 64], wo[RF_THREADS / 64];
+    const u64 base = (u64)blockIdx.x * RF_TILE + (u64)threadIdx.x * RF_ITEMS;
+    u64 xs[RF_ITEMS];
+    const u32 f = rf_flags(A, base, xs);
+    u32 ck = (u32)__popc(f & 0xffffu), co = (u32)__popc(f >> 16);
+    for (int d = 32; d > 0; d >>= 1) { ck += __shfl_down(ck, d, 64); co += __shfl_down(co, d, 64); }
+    if (lane_id() == 0) { wk[threadIdx.x >> 6] = ck; wo[threadIdx.x >> 6] = co; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 a = 0, b = 0;
+        for (int w = 0; w < RF_THREADS / 64; ++w) { a += wk[w]; b += wo[w]; }
+        bc_keep[blockIdx.x] = a; bc_own[blockIdx.x] = b;
+    }
+}
+
+__global__ __launch_bounds__(RF_THREADS) void k_restrict_write(RestrictArgs A, const u32 *__restrict__ off_keep, const u32 *__restrict__ off_own,
+                                                               u64 *__restrict__ out_x, u64 *__restrict__ out_y, u64 *__restrict__ out_hash) {
+    __shared__ u32 wk[RF_THREADS / 64], wo[RF_THREADS / 64];
+    const u64 base = (u64)blockIdx.x * RF_TILE + (u64)threadIdx.x * RF_ITEMS;
+    u64 xs[RF_ITEMS];
+    const u32 f = rf_flags(A, base, xs);
+    const u32 ck = (u32)__popc(f & 0xffffu), co = (u32)__popc(f >> 16);
+    const u32 ik = wave_incl_scan_u32(ck), io = wave_incl_scan_u32(co);
+    if (lane_id() == 63) { wk[threadIdx.x >> 6] = ik; wo[threadIdx.x >> 6] = io; }
+    __syncthreads();
+    u32 ok = off_keep[blockIdx.x] + ik - ck, oo = off_own[blockIdx.x] + io - co;
+    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) { ok += wk[w]; oo += wo[w]; }
+#pragma unroll
+    for (int t = 0; t < RF_ITEMS; ++t) {
+        if (f & (1u << t)) { out_x[ok] = xs[t]; if (out_y) out_y[ok] = A.y[base + t]; ++ok; }
+        if (f & (1u << (16 + t))) out_hash[oo++] = xs[t] >> A.kshift;
+    }
+}
+
+// occurrence histogram of the runs of a sorted hash stream (run r = [start[r], start[r + 1])), gathered in LDS and
+// flushed once per block from a small grid (k_place_apply's lesson); *d_n_runs lives on the device
+#define OH_BINS 2048
+__global__ __launch_bounds__(256) void k_occ_hist_runs(const u32 *__restrict__ start, const u32 *__restrict__ d_n_runs, u64 n,
+                                                       u32 *__restrict__ hist, u32 max_bin) {
+    __shared__ u32 lh[OH_BINS];
+    for (u32 i = threadIdx.x; i < OH_BINS; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const u32 n_runs = *d_n_runs;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 r0 = (u64)blockIdx.x * blockDim.x; r0 < n_runs; r0 += stride) {
+        const u64 r = r0 + threadIdx.x;
+        const bool in = r < n_runs;
+        u32 hb = 0;
+        if (in) {
+            const u64 en = (r + 1 < n_runs) ? start[r + 1] : n;
+            const u64 c = en - start[r];
+            hb = c < max_bin ? (u32)c : max_bin;
+        }
+        // most runs have length 1 or 2: count those per wave with a ballot instead of 64 conflicting LDS atomics
+        const u64 m1 = __ballot(in && hb == 1), m2 = __ballot(in && hb == 2);
+        if (lane_id() == 0) {
+            if (m1) atomicAdd(&lh[1], (u32)__popcll(m1));
+            if (m2) atomicAdd(&lh[2], (u32)__popcll(m2));
+        }
+        if (in && hb != 1 && hb != 2) { if (hb < OH_BINS) atomicAdd(&lh[hb], 1u); else atomicAdd(&hist[hb], 1u); }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < OH_BINS && i <= max_bin; i += blockDim.x) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// [0] = distinct keys, [1] = minimizers, [2 ...) = the first `head` histogram bins, as u64 for the all-reduce
+__global__ void k_stats_pack(const u32 *__restrict__ d_n_runs, u64 n_mz, const u32 *__restrict__ hist, u32 head, u64 *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { out[0] = *d_n_runs; out[1] = n_mz; }
+    if (i < head) out[2 + i] = hist[i];
+}
+__global__ void k_u32_to_u64(const u32 *__restrict__ in, u64 n, u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}

@@ -19,6 +19,7 @@
 #include "k_chain_common.h"
 #include "k_chain_hw.h"
 #include "k_chain_lpg.h"
+#include "comm.h"
 #include "../../include/lrge_rand.hpp"
 
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
@@ -543,7 +544,6 @@ static int presketch_start_pending(lrge_hip_ctx *ctx) {
     ctx->presk_pending = nullptr;
     if (s->total_bases > ctx->opt_u64("STREAM_BASES", 4000000000ull)) return LRGE_OK;   // streamed in views: sketched per view
     if (s->presk) presketch_discard(s);
-    if (seqset_ready(ctx, s) != LRGE_OK) return LRGE_OK;     // (the side stream is forked off the main stream below)
     PreSketch *p = new PreSketch();
     p->preset = ctx->presk_preset;
     p->sc = new Scratch(ctx);
@@ -552,6 +552,9 @@ static int presketch_start_pending(lrge_hip_ctx *ctx) {
     int rc = LRGE_OK;
     hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+    // an upload of the set still in flight: only the side stream waits for it -- the main stream goes on with the index
+    // (its own seqset_ready comes with the overlap call, which also returns the staging blocks to the pool)
+    if (e == hipSuccess && s->pending) e = hipStreamWaitEvent(ctx->stream2, s->ev_ready, 0);
     if (e == hipSuccess) e = hipEventRecord(p->ev_start, ctx->stream2);
     if (e == hipSuccess) {
         rc = p->preset == LRGE_PRESET_AVA_PB ? presketch_launch<19, 5, true>(ctx, s, p, ctx->stream2)
@@ -1803,6 +1806,91 @@ extern "C" int lrge_hip_anchors_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix
     job.dump_anchors = true; job.dump_query = query; job.ax = x; job.ay = y; job.acap = (x && y) ? cap : 0; job.an = n_out;
     *n_out = 0;
     return run_overlap(ctx, ix, queries, job);
+}
+
+// ------------------------------------------------------------------------------------------
+// communicators (comm.h)
+// ------------------------------------------------------------------------------------------
+extern "C" int lrge_hip_comm_unique_id(void *id128) {
+    if (!id128) return LRGE_ERR_INVALID;
+    std::lock_guard<std::mutex> g(g_rccl_mu);
+    if (!g_rccl.load()) { g_last_error = g_rccl.err; return LRGE_ERR_DEVICE; }
+    lrge_ncclUniqueId id;
+    const int r = g_rccl.GetUniqueId(&id);
+    if (r != 0) { g_last_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return LRGE_ERR_DEVICE; }
+    memcpy(id128, id.internal, 128);
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_comm_create(lrge_hip_ctx *ctx, int rank, int world, const void *id128, lrge_hip_comm **out) {
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || !id128) return LRGE_ERR_INVALID;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    { std::lock_guard<std::mutex> g(g_rccl_mu); if (!g_rccl.load()) { LRGE_SET_ERR(ctx, "%s", g_rccl.err.c_str()); return LRGE_ERR_DEVICE; } }
+    lrge_ncclUniqueId id;
+    memcpy(id.internal, id128, 128);
+    std::unique_ptr<lrge_hip_comm> c(new lrge_hip_comm());
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    NCCLCHK(ctx, g_rccl.CommInitRank(&c->nccl, world, id, rank));
+    *out = c.release();
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_comm_local_group_create(int world, void **grp) {
+    if (!grp || world < 1) return LRGE_ERR_INVALID;
+    *grp = new LocalGroup(world);
+    return LRGE_OK;
+}
+extern "C" void lrge_hip_comm_local_group_destroy(void *grp) { delete (LocalGroup *)grp; }
+
+extern "C" int lrge_hip_comm_create_local(lrge_hip_ctx *ctx, int rank, void *grp, lrge_hip_comm **out) {
+    LocalGroup *g = (LocalGroup *)grp;
+    if (!ctx || !out || !g || rank < 0 || rank >= g->world) return LRGE_ERR_INVALID;
+    lrge_hip_comm *c = new lrge_hip_comm();
+    c->ctx = ctx; c->rank = rank; c->world = g->world; c->grp = g;
+    *out = c;
+    return LRGE_OK;
+}
+
+extern "C" void lrge_hip_comm_destroy(lrge_hip_comm *c) {
+    if (!c) return;
+    if (c->nccl) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); (void)g_rccl.CommDestroy(c->nccl); }
+    delete c;
+}
+extern "C" int lrge_hip_comm_rank(const lrge_hip_comm *c) { return c ? c->rank : -1; }
+extern "C" int lrge_hip_comm_world(const lrge_hip_comm *c) { return c ? c->world : 0; }
+
+// host-buffer forms of the two collectives that close a step
+extern "C" int lrge_hip_comm_allreduce_u32(lrge_hip_comm *c, uint32_t *inout, size_t n) {
+    if (!c || (n && !inout)) return LRGE_ERR_INVALID;
+    lrge_hip_ctx *ctx = c->ctx;
+    if (c->world == 1 || n == 0) return LRGE_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch sc(ctx);
+    ALLOC_OR_FAIL(d, sc, u32, n);
+    HIPCHK(ctx, hipMemcpyAsync(d, inout, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = comm_allreduce_sum(c, d, n, 4, ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(inout, d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_comm_allgather(lrge_hip_comm *c, const void *send, size_t bytes, void *recv) {
+    if (!c || (bytes && (!send || !recv))) return LRGE_ERR_INVALID;
+    lrge_hip_ctx *ctx = c->ctx;
+    if (bytes == 0) return LRGE_OK;
+    if (c->world == 1) { memcpy(recv, send, bytes); return LRGE_OK; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch sc(ctx);
+    ALLOC_OR_FAIL(ds, sc, char, bytes);
+    ALLOC_OR_FAIL(dr, sc, char, bytes * (size_t)c->world);
+    HIPCHK(ctx, hipMemcpyAsync(ds, send, bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = comm_allgather(c, ds, bytes, dr, ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(recv, dr, bytes * (size_t)c->world, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LRGE_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -84,7 +84,8 @@ enum {
     LRGE_T_PACK = 0, LRGE_T_SKETCH, LRGE_T_INDEX_SORT, LRGE_T_INDEX_TABLE, LRGE_T_QFILTER,
     LRGE_T_LOOKUP, LRGE_T_EXPAND, LRGE_T_ANCHOR_SORT, LRGE_T_GROUP, LRGE_T_CHAIN,
     LRGE_T_CHAIN_GLB /* (unused: retired kernel) */, LRGE_T_COUNT, LRGE_T_TOTAL,
-    LRGE_T_CHAIN_LPG, LRGE_T_RS_SCATTER, LRGE_T_K_LOOKUP /* k_lookup alone (it also counts inside LRGE_T_LOOKUP) */, LRGE_T_N
+    LRGE_T_CHAIN_LPG, LRGE_T_RS_SCATTER, LRGE_T_K_LOOKUP /* k_lookup alone (it also counts inside LRGE_T_LOOKUP) */,
+    LRGE_T_INDEX_RESTRICT /* lrge_hip_index_build_for: entry filter + global occurrence statistics */, LRGE_T_N
 };
 /* Work counters of the last overlap call (for the roofline's algorithmic bytes). */
 enum {
@@ -145,6 +146,21 @@ uint32_t lrge_hip_seqset_size(const lrge_hip_seqset *s);
 /* Build the minimizer index over `targets` with the given preset (also fixes mid_occ). */
 int  lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset,
                           lrge_hip_index **out);
+/*
+ * The index of a multi-GPU run (and optionally of a single GPU): built for ONE streamed set.  It holds the entries of the
+ * minimizers that occur in `streamed` -- complete position lists, so mm_idx_get answers every question that set can ask
+ * exactly as the full index would -- while mid_occ, n_keys and n_minimizers are those of the whole target set
+ * (mm_idx_cal_max_occ over all distinct keys).  Only `streamed` (or the library's own views of it) may be streamed against
+ * it: the other overlap calls fail with LRGE_ERR_INVALID.
+ *   comm == NULL  one GPU: the occurrence statistics are counted here.
+ *   comm != NULL  collective call: every rank passes the SAME target set and ITS OWN range of the streamed reads; each rank
+ *                 counts a 1/world share of the hash space and one small all-reduce completes the histogram.  No index
+ *                 data crosses the links.
+ * What it replaces: AlignerWrapper::new (aligner.rs:310-328) called once per process in a run sharded by query
+ * (twoset.rs:266-334).  streamed == NULL and comm == NULL is lrge_hip_index_build.
+ */
+int  lrge_hip_index_build_for(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset,
+                              lrge_hip_seqset *streamed, lrge_hip_comm *comm, lrge_hip_index **out);
 void lrge_hip_index_free(lrge_hip_index *ix);
 int  lrge_hip_index_stats(const lrge_hip_index *ix, uint64_t *n_minimizers, uint64_t *n_keys,
                           int32_t *mid_occ);

@@ -13,7 +13,7 @@ ERR_IO, ERR_PARSE, ERR_TOO_MANY, ERR_TOO_FEW, ERR_DEVICE, ERR_MAP, ERR_DUPLICATE
 PRESET_AVA_ONT, PRESET_AVA_PB = 0, 1
 
 T_NAMES = ["pack", "sketch", "index_sort", "index_table", "qfilter", "lookup", "expand", "anchor_sort", "group",
-           "chain", "chain_glb", "count", "total", "chain_lpg", "rs_scatter", "k_lookup"]
+           "chain", "chain_glb", "count", "total", "chain_lpg", "rs_scatter", "k_lookup", "index_restrict"]
 C_NAMES = ["query_bases", "query_minimizers", "anchors", "groups", "groups_chained", "chain_launches", "batches",
            "chain_anchors", "chain_glb_launches", "chain_glb_anchors", "lpg_launches", "lpg_anchors",
            "rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "lpg_split", "lookup_launches"]
@@ -22,7 +22,10 @@ EXPORTS = [
     "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error", "lrge_hip_ctx_set_option",
     "lrge_hip_seqset_upload", "lrge_hip_seqset_upload_async", "lrge_hip_seqset_wait", "lrge_hip_host_alloc",
     "lrge_hip_host_free", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch",
-    "lrge_hip_index_build", "lrge_hip_index_free", "lrge_hip_index_stats",
+    "lrge_hip_index_build", "lrge_hip_index_build_for", "lrge_hip_index_free",
+    "lrge_hip_comm_unique_id", "lrge_hip_comm_create", "lrge_hip_comm_local_group_create", "lrge_hip_comm_local_group_destroy",
+    "lrge_hip_comm_create_local", "lrge_hip_comm_destroy", "lrge_hip_comm_rank", "lrge_hip_comm_world",
+    "lrge_hip_comm_allreduce_u32", "lrge_hip_comm_allgather", "lrge_hip_index_stats",
     "lrge_hip_overlap_twoset", "lrge_hip_overlap_inverse", "lrge_hip_overlap_ava", "lrge_hip_chains",
     "lrge_hip_estimates", "lrge_hip_median", "lrge_hip_paf_stats",
     "lrge_hip_unique_random_set", "lrge_hip_chacha_block",
@@ -79,6 +82,19 @@ def lib():
     L.lrge_hip_seqset_size.restype = C.c_uint32
     L.lrge_hip_seqset_presketch.argtypes = [vp, vp, C.c_int]
     L.lrge_hip_index_build.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.lrge_hip_index_build_for.argtypes = [vp, vp, C.c_int, vp, vp, C.POINTER(vp)]
+    L.lrge_hip_comm_unique_id.argtypes = [vp]
+    L.lrge_hip_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.lrge_hip_comm_local_group_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.lrge_hip_comm_local_group_destroy.argtypes = [vp]
+    L.lrge_hip_comm_local_group_destroy.restype = None
+    L.lrge_hip_comm_create_local.argtypes = [vp, C.c_int, vp, C.POINTER(vp)]
+    L.lrge_hip_comm_destroy.argtypes = [vp]
+    L.lrge_hip_comm_destroy.restype = None
+    L.lrge_hip_comm_rank.argtypes = [vp]
+    L.lrge_hip_comm_world.argtypes = [vp]
+    L.lrge_hip_comm_allreduce_u32.argtypes = [vp, vp, C.c_size_t]
+    L.lrge_hip_comm_allgather.argtypes = [vp, vp, C.c_size_t, vp]
     L.lrge_hip_index_free.argtypes = [vp]
     L.lrge_hip_index_free.restype = None
     L.lrge_hip_index_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]

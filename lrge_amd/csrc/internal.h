@@ -150,6 +150,7 @@ struct lrge_hip_seqset {
     lrge_hip_ctx *ctx;
     PreSketch *presk = nullptr;
     bool is_view = false;       // reads [r0, r1) of another set: shares its device arrays, owns only d_cs
+    const lrge_hip_seqset *parent = nullptr;   // (of a view)
     u32 n = 0;
     u64 total_bases = 0;
     u64 n_words = 0;            // 32-base words in the packed image (reads start on a word)
@@ -195,6 +196,7 @@ struct lrge_hip_index {
     // A target set too large for one index (more than LRGE_HIP_PART_BASES bases: the 2^32-entry limits) is indexed in
     // parts over views of the set.  The occurrence statistics are global (k_part_global_occ), so the parts together
     // behave exactly like one index; a part's own d_* arrays are used as above, the container's are null.
+    const lrge_hip_seqset *restrict_set = nullptr;   // lrge_hip_index_build_for: the one set that may be streamed against this index
     std::vector<lrge_hip_index *> parts;
     std::vector<lrge_hip_seqset *> part_sets;
     std::vector<u32> part_r0;

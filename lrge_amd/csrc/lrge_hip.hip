@@ -20,6 +20,7 @@
 #include "k_chain_hw.h"
 #include "k_chain_lpg.h"
 #include "comm.h"
+#include "k_restrict.h"
 #include "../../include/lrge_rand.hpp"
 
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
@@ -605,7 +606,11 @@ extern "C" void lrge_hip_index_free(lrge_hip_index *ix);
 struct IndexFree { void operator()(lrge_hip_index *ix) const { lrge_hip_index_free(ix); } };
 typedef std::unique_ptr<lrge_hip_index, IndexFree> IndexGuard;     // every early return releases what the index holds so far
 
-static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_index **out) {
+// A restricted build (lrge_hip_index_build_for, k_restrict.h): the index holds the entries of the keys that occur in
+// `restrict_to`'s minimizers, its statistics (mid_occ, key and minimizer totals) are those of the whole target set.
+struct IndexBuildOpts { lrge_hip_seqset *restrict_to = nullptr; lrge_hip_comm *comm = nullptr; };
+
+static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_index **out, const IndexBuildOpts *ro = nullptr) {
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
@@ -627,12 +632,115 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     const bool pk = 2 * (u32)P.k + pk_rid + pk_pos1 <= 64 && !ctx->opt_u64("NO_PACKED_INDEX", 0);
     const u32 pk_ybits = pk ? pk_rid + pk_pos1 : 0;
     SketchOut so;
-    int rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits);
+    int rc = LRGE_OK;
+    KeySet ks{nullptr, 0, 0};
+    if (ro && ro->restrict_to) {
+        // the streamed set's sketch and the key set built from it go to the side stream FIRST, so that they run beside
+        // the target sketch below; the main stream meets them (ev_join) where the entries are filtered
+        lrge_hip_seqset *S = ro->restrict_to;
+        if (!S->presk || S->presk->preset != preset) {
+            ctx->presk_pending = S; ctx->presk_preset = preset;
+            rc = presketch_start_pending(ctx);
+            if (rc) return rc;
+        }
+        if (!S->presk) { LRGE_SET_ERR(ctx, "index_build_for: the streamed set is too large to restrict an index to (it is streamed in views)"); return LRGE_ERR_TOO_MANY; }
+        u64 n_words;
+        if (2 * P.k <= 33) { ks.direct = 1; n_words = std::max<u64>(1, (1ULL << (2 * P.k)) >> 6); }
+        else { n_words = 1ULL << 20; while (n_words < (1ULL << 31) && n_words * 64 < 8 * (S->total_bases + 1)) n_words <<= 1; }
+        ks.word_mask = n_words - 1;
+        ks.bits = sc.get<u64>(n_words);
+        if (!ks.bits) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemsetAsync(ks.bits, 0, n_words * 8, ctx->stream2));
+        hipLaunchKernelGGL(k_keyset_build, dim3((u32)div_up(S->total_bases + 1, 256)), dim3(256), 0, ctx->stream2, S->presk->x, S->presk->d_total, ks);
+        KCHK(ctx);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+    }
+    rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits);
     if (rc == LRGE_OK && !ctx->opt("NO_PRESKETCH")) rc = presketch_start_pending(ctx);
     if (rc) return rc;
     sc.drop(so.mz_off);
-    const u64 M = so.n;
+    u64 M = so.n;
     if (M >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32 minimizers (got %llu)", (unsigned long long)M); return LRGE_ERR_TOO_MANY; }
+
+    // ---- restricted build: keep the entries the streamed reads can ask for, count ALL keys for the statistics ----
+    bool have_global = false; u64 g_distinct = 0, g_mz = 0; int g_mid_occ = 0;
+    if (ro && ro->restrict_to) {
+        StageTimer t(ctx, LRGE_T_INDEX_RESTRICT);
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        RestrictArgs A;
+        A.x = so.x; A.y = pk ? nullptr : so.y; A.n = M; A.kshift = pk ? pk_ybits : 0; A.ks = ks;
+        A.rank = ro->comm ? (u32)ro->comm->rank : 0; A.world = ro->comm ? (u32)ro->comm->world : 1;
+        const u32 nb = (u32)div_up(M, RF_TILE);
+        ALLOC_OR_FAIL(bc_keep, sc, u32, (size_t)nb + 1); ALLOC_OR_FAIL(bc_own, sc, u32, (size_t)nb + 1); ALLOC_OR_FAIL(d_tot, sc, u32, 2);
+        u32 tot[2] = {0, 0};
+        if (nb) {
+            hipLaunchKernelGGL(k_restrict_count, dim3(nb), dim3(RF_THREADS), 0, ctx->stream, A, bc_keep, bc_own);
+            KCHK(ctx);
+            rc = scan_exclusive_u32(ctx, sc, bc_keep, bc_keep, nb, d_tot); if (rc) return rc;
+            rc = scan_exclusive_u32(ctx, sc, bc_own, bc_own, nb, d_tot + 1); if (rc) return rc;
+            HIPCHK(ctx, ctx->d2h(tot, d_tot, 8, ctx->stream));
+            HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+        }
+        const u64 Mk = tot[0], Ms = tot[1];
+        ALLOC_OR_FAIL(kx, sc, u64, Mk + 1);
+        u64 *ky = nullptr;
+        if (!pk) { ky = sc.get<u64>(Mk + 1); if (!ky) return LRGE_ERR_DEVICE; }
+        ALLOC_OR_FAIL(sh, sc, u64, Ms + 1);
+        if (nb) {
+            hipLaunchKernelGGL(k_restrict_write, dim3(nb), dim3(RF_THREADS), 0, ctx->stream, A, bc_keep, bc_own, kx, ky, sh);
+            KCHK(ctx);
+        }
+        sc.drop(so.x); if (so.y) sc.drop(so.y);
+        sc.drop(bc_keep); sc.drop(bc_own); sc.drop(d_tot);
+        so.x = kx; so.y = ky; M = Mk;
+        // occurrence statistics of the owned share of the hash space
+        const u32 max_bin_ = (u32)P.max_mid_occ + 1;
+        ALLOC_OR_FAIL(sh2, sc, u64, Ms + 1);
+        u64 *rs_ = nullptr;
+        rc = radix_sort_keys(ctx, sc, sh, sh2, Ms, 0, 2 * P.k, &rs_, false); if (rc) return rc;
+        ALLOC_OR_FAIL(starts, sc, u32, Ms + 2); ALLOC_OR_FAIL(d_nr, sc, u32, 1);
+        rc = compact_heads_async(ctx, sc, rs_, Ms, 0, starts, d_nr); if (rc) return rc;
+        ALLOC_OR_FAIL(d_hist, sc, u32, (size_t)max_bin_ + 2);
+        HIPCHK(ctx, hipMemsetAsync(d_hist, 0, ((size_t)max_bin_ + 2) * 4, ctx->stream));
+        if (Ms) {
+            hipLaunchKernelGGL(k_occ_hist_runs, dim3((u32)std::min<u64>(div_up(Ms, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, starts, d_nr, Ms, d_hist, max_bin_);
+            KCHK(ctx);
+        }
+        const u32 head = std::min<u32>(4096, max_bin_ + 1);
+        ALLOC_OR_FAIL(d_vec, sc, u64, (size_t)head + 2);
+        hipLaunchKernelGGL(k_stats_pack, dim3((u32)div_up(head, 256)), dim3(256), 0, ctx->stream, d_nr, Ms, d_hist, head, d_vec);
+        KCHK(ctx);
+        if (ro->comm) { rc = comm_allreduce_sum(ro->comm, d_vec, (size_t)head + 2, 8, ctx->stream); if (rc) return rc; }
+        std::vector<u64> hv((size_t)head + 2);
+        HIPCHK(ctx, hipMemcpyAsync(hv.data(), d_vec, hv.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        g_distinct = hv[0]; g_mz = hv[1];
+        // mm_idx_cal_max_occ + mm_mapopt_update clamps over the distinct keys of the whole target set (same arithmetic as below)
+        int thres = INT32_MAX;
+        if (g_distinct) {
+            const u64 kth = (u64)((1. - (double)P.mid_occ_frac) * (double)g_distinct);
+            u64 cum = 0; u32 v = max_bin_; bool found = false;
+            for (u32 b = 0; b < head; ++b) { cum += hv[2 + b]; if (cum > kth) { v = b; found = true; break; } }
+            if (!found && head < max_bin_ + 1) {      // the k-th count lies beyond the head bins: the whole histogram travels
+                ALLOC_OR_FAIL(d_full, sc, u64, (size_t)max_bin_ + 1);
+                hipLaunchKernelGGL(k_u32_to_u64, dim3((u32)div_up((u64)max_bin_ + 1, 256)), dim3(256), 0, ctx->stream, d_hist, (u64)max_bin_ + 1, d_full);
+                KCHK(ctx);
+                if (ro->comm) { rc = comm_allreduce_sum(ro->comm, d_full, (size_t)max_bin_ + 1, 8, ctx->stream); if (rc) return rc; }
+                std::vector<u64> full((size_t)max_bin_ + 1);
+                HIPCHK(ctx, hipMemcpyAsync(full.data(), d_full, full.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                cum = 0;
+                for (u32 b = 0; b <= max_bin_; ++b) { cum += full[b]; if (cum > kth) { v = b; break; } }
+                sc.drop(d_full);
+            }
+            thres = (int)v + 1;
+        }
+        if (thres < P.min_mid_occ) thres = P.min_mid_occ;
+        if (P.max_mid_occ > P.min_mid_occ && thres > P.max_mid_occ) thres = P.max_mid_occ;
+        g_mid_occ = thres; have_global = true;
+        sc.drop(sh); sc.drop(sh2); sc.drop(starts); sc.drop(d_nr); sc.drop(d_hist); sc.drop(d_vec); sc.drop(ks.bits);
+        t.stop();
+    }
 
     u64 *skey = so.x, *spos = so.y;
     {
@@ -747,6 +855,10 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         if (P.max_mid_occ > P.min_mid_occ && thres > P.max_mid_occ) thres = P.max_mid_occ;
         ix->mid_occ = thres;
     }
+    if (have_global) {      // restricted build: what mm_idx_stat / mm_idx_cal_max_occ report for the whole target set
+        ix->mid_occ = g_mid_occ; ix->n_keys = g_distinct; ix->n_mz = g_mz;
+        ix->restrict_set = ro->restrict_to;
+    }
     // the sorted hashes of the (hash, y) pair layout are only read again by index_dump (tests); a part of a partitioned index
     // cannot be dumped and is short of memory, so it gives them back (8 of its 16 bytes per minimizer)
     ix->d_pos = spos; sc.keep(spos);
@@ -766,7 +878,7 @@ static int seqset_view(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, u32 r0, u32 
     int rrc = seqset_ready(ctx, s);
     if (rrc) return rrc;
     lrge_hip_seqset *v = new lrge_hip_seqset();
-    v->ctx = ctx; v->is_view = true; v->n = r1 - r0;
+    v->ctx = ctx; v->is_view = true; v->n = r1 - r0; v->parent = s->parent ? s->parent : s;
     v->has_rank = s->has_rank; v->dup_rank = s->dup_rank;
     v->d_pack = s->d_pack; v->d_nmask = s->d_nmask; v->d_woff = s->d_woff + r0; v->d_len = s->d_len + r0;
     v->d_rank = s->d_rank ? s->d_rank + r0 : nullptr;
@@ -887,6 +999,22 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     memcpy(ctx->ms, ms_acc, sizeof ms_acc); memcpy(ctx->counters, cn_acc, sizeof cn_acc);
     *out = top_guard.release();
     return LRGE_OK;
+}
+
+extern "C" int lrge_hip_index_build_for(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_seqset *streamed,
+                                        lrge_hip_comm *comm, lrge_hip_index **out) {
+    if (!ctx || !targets || !out) return LRGE_ERR_INVALID;
+    if (!streamed && !comm) return lrge_hip_index_build(ctx, targets, preset, out);
+    if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
+    *out = nullptr;
+    if (!streamed) { LRGE_SET_ERR(ctx, "index_build_for: a communicator needs the streamed set of this rank"); return LRGE_ERR_INVALID; }
+    if (streamed->ctx != ctx || targets->ctx != ctx || (comm && comm->ctx != ctx)) { LRGE_SET_ERR(ctx, "index_build_for: sets / communicator belong to another context"); return LRGE_ERR_INVALID; }
+    if (targets->total_bases > ctx->opt_u64("PART_BASES", 4000000000ull)) {
+        LRGE_SET_ERR(ctx, "index_build_for: target sets above PART_BASES bases (a partitioned index) are not implemented for restricted builds");
+        return LRGE_ERR_TOO_MANY;
+    }
+    IndexBuildOpts ro; ro.restrict_to = streamed; ro.comm = comm;
+    return index_build_one(ctx, targets, preset, out, &ro);
 }
 
 extern "C" void lrge_hip_index_free(lrge_hip_index *ix) {
@@ -1642,6 +1770,10 @@ static int check_common(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_
     if (!ix) { LRGE_SET_ERR(ctx, "No index"); return LRGE_ERR_MAP; }   // aligner.rs:210-212
     if (!q) { LRGE_SET_ERR(ctx, "null read set"); return LRGE_ERR_INVALID; }
     if (ix->ctx != ctx || q->ctx != ctx) { LRGE_SET_ERR(ctx, "index / read set belong to another context"); return LRGE_ERR_INVALID; }
+    if (ix->restrict_set && q != ix->restrict_set && q->parent != ix->restrict_set) {
+        LRGE_SET_ERR(ctx, "this index was built for one streamed set (lrge_hip_index_build_for): only that set may be streamed against it");
+        return LRGE_ERR_INVALID;
+    }
     if (!ix->parts.empty() && !parts_ok) {
         LRGE_SET_ERR(ctx, "the index is partitioned (%zu parts, target set above LRGE_HIP_PART_BASES): only lrge_hip_overlap_twoset is implemented for it", ix->parts.size());
         return LRGE_ERR_TOO_MANY;

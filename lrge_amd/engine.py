@@ -190,10 +190,14 @@ class Index:
     def __init__(self, ctx, targets, preset=_ffi.PRESET_AVA_ONT, streamed=None, comm=None):
         self.ctx, self.targets, self.preset = ctx, targets, preset
         h = C.c_void_p()
+        # streamed / comm: an index built for ONE streamed set, occurrence statistics still over all targets; with a
+        # communicator every rank passes its own range of the streamed reads (lrge_hip_index_build_for)
+        self.streamed = streamed
         if streamed is None and comm is None:
             ctx._check(ctx._lib.lrge_hip_index_build(ctx.h, targets.h, preset, C.byref(h)))
         else:
-            raise NotImplementedError("restricted / sharded index build")
+            ctx._check(ctx._lib.lrge_hip_index_build_for(ctx.h, targets.h, preset, None if streamed is None else streamed.h,
+                                                         None if comm is None else comm.h, C.byref(h)))
         self.h = h
         self.build_timings = ctx.timings()
         self.build_counters = ctx.counters()

@@ -33,6 +33,88 @@ def shard_round_robin(n, rank, world):
     return np.arange(rank, n, world, dtype=np.int64)
 
 
+class _Comm:
+    """A communicator of the C ABI (lrge_hip_comm_*): the collectives run inside liblrge_hip.so."""
+
+    def __init__(self, ctx, h, rank, world):
+        self.ctx, self.h, self.rank, self.world = ctx, h, rank, world
+
+    def all_reduce_u32(self, counts):
+        """In-place-style SUM of per-rank partial count vectors (all-vs-all / inverse)."""
+        a = np.ascontiguousarray(counts, dtype=np.uint32).copy()
+        self.ctx._check(self.ctx._lib.lrge_hip_comm_allreduce_u32(self.h, a.ctypes.data, a.size))
+        return a
+
+    def all_gather_f32(self, local, max_len, lens):
+        """All-gather of the per-read estimate vectors; every rank knows every shard's length (the shards are cut from
+        read lengths all ranks hold), so one fixed-size gather of `max_len` floats per rank does it."""
+        import ctypes as C
+        send = np.full(max(max_len, 1), np.nan, dtype=np.float32)
+        send[:len(local)] = local
+        recv = np.empty(max(max_len, 1) * self.world, dtype=np.float32)
+        self.ctx._check(self.ctx._lib.lrge_hip_comm_allgather(self.h, send.ctypes.data, C.c_size_t(send.nbytes), recv.ctypes.data))
+        m = max(max_len, 1)
+        return np.concatenate([recv[r * m:r * m + lens[r]] for r in range(self.world)])
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx._lib.lrge_hip_comm_destroy(self.h)
+            self.h = None
+
+
+class RcclComm(_Comm):
+    """RCCL over xGMI, one process per GPU.  The 128-byte unique id travels through whatever the host has."""
+
+    @classmethod
+    def create(cls, ctx, rank, world, unique_id):
+        import ctypes as C
+        h = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        ctx._check(ctx._lib.lrge_hip_comm_create(ctx.h, rank, world, buf, C.byref(h)))
+        return cls(ctx, h, rank, world)
+
+    @staticmethod
+    def unique_id(ctx):
+        import ctypes as C
+        buf = (C.c_char * 128)()
+        rc = ctx._lib.lrge_hip_comm_unique_id(buf)
+        if rc != 0:
+            from ._ffi import LrgeHipError
+            raise LrgeHipError(rc, ctx._lib.lrge_hip_last_error(None).decode())
+        return bytes(buf)
+
+    @classmethod
+    def bootstrap(cls, ctx, rank, world, dist):
+        """Rank 0 draws the id; torch.distributed (any backend, used as a store only) hands it out."""
+        box = [cls.unique_id(ctx) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls.create(ctx, rank, world, box[0])
+
+
+class LocalGroup:
+    """The ranks are threads of this process (one context each); see lrge_hip_comm_create_local."""
+
+    def __init__(self, world):
+        import ctypes as C
+        from . import _ffi
+        self._lib, self.world = _ffi.lib(), world
+        self.h = C.c_void_p()
+        rc = self._lib.lrge_hip_comm_local_group_create(world, C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("local group: %d" % rc)
+
+    def comm(self, ctx, rank):
+        import ctypes as C
+        h = C.c_void_p()
+        ctx._check(self._lib.lrge_hip_comm_create_local(ctx.h, rank, self.h, C.byref(h)))
+        return _Comm(ctx, h, rank, self.world)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.lrge_hip_comm_local_group_destroy(self.h)
+            self.h = None
+
+
 def _dist():
     import torch.distributed as dist
     return dist

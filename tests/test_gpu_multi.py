@@ -1,0 +1,176 @@
+"""GPU: the multi-GPU mode on one device.
+
+  * lrge_hip_index_build_for on a single rank: an index restricted to the streamed set's minimizers answers exactly like the
+    full index and reports the full index's statistics (both entry layouts, direct bitmap and Bloom key sets);
+  * a whole world of ranks as THREADS of this process, one context each on the same GPU, joined by the library's local
+    communicator (lrge_hip_comm_create_local): every rank builds its restricted index collectively, maps its own range of
+    the queries, and the gathered estimates / reduced counts equal the single-GPU result;
+  * the RCCL transport with world size 1 (all a 1-GPU box can offer): unique id, communicator, both collectives and a
+    collective index build, in a child process.
+Reference semantics: twoset.rs:266-334 (queries are independent given the index), ava.rs:300-301 / twoset.rs:520-523
+(counts keyed by indexed read add up over the streamed reads).
+"""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PRESETS = {"ont": 0, "pb": 1}
+
+
+def _single(ctx, ds, preset, F=False):
+    from lrge_amd import engine
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Qd, Td = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
+    ix = engine.Index(ctx, Td, preset)
+    counts, has = ix.overlap_twoset(Qd, remove_internal=F)
+    st = ix.stats()
+    ix.free()
+    return Qd, Td, counts, has, st
+
+
+@pytest.mark.parametrize("layout", ["packed", "pairs"])
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_restricted_index_single_rank(ctx, tiny_ont, tiny_hifi, preset, layout, knobs):
+    from lrge_amd import _ffi, engine
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    if layout == "pairs":
+        knobs.set("NO_PACKED_INDEX", "1")
+    Qd, Td, counts, has, st = _single(ctx, ds, PRESETS[preset])
+    assert int(counts.sum()) > 0
+    for hint in (False, True):
+        if hint:
+            Qd.presketch(PRESETS[preset])          # an earlier hint is reused, not repeated
+        ix = engine.Index(ctx, Td, PRESETS[preset], streamed=Qd)
+        assert ix.stats() == st                    # mid_occ, distinct keys, minimizers of the WHOLE target set
+        for F in (False, True):
+            c, h = ix.overlap_twoset(Qd, remove_internal=F)
+            if not F:
+                assert np.array_equal(c, counts) and np.array_equal(h, has)
+        with pytest.raises(_ffi.LrgeHipError):     # built for Qd: nothing else may be streamed against it
+            ix.overlap_twoset(Td)
+        ix.free()
+    # the restricted index really is smaller: a streamed set of three reads keeps a fraction of the entries
+    sub = ds.q.slice(0, 3)
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Sd = ctx.upload(sub.bases, sub.offsets, qr[:3])
+    ix = engine.Index(ctx, Td, PRESETS[preset], streamed=Sd)
+    c3, h3 = ix.overlap_twoset(Sd)
+    assert np.array_equal(c3, counts[:3]) and np.array_equal(h3, has[:3]) and ix.stats() == st
+    ix.free()
+
+
+def _run_world(world, ds, preset, mode):
+    """Every rank in its own thread with its own context; returns the per-rank results."""
+    from lrge_amd import engine, parallel
+    grp = parallel.LocalGroup(world)
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    out, errs = [None] * world, []
+    bounds = parallel.shard_by_bases(ds.q.lens() if mode == "twoset" else ds.t.lens(), world)
+    avg_t = np.float32(ds.t.lens().sum()) / np.float32(ds.t.n)
+
+    def rank_main(r):
+        try:
+            c = engine.Context(0)
+            comm = grp.comm(c, r)
+            lo, hi = bounds[r], bounds[r + 1]
+            if mode == "twoset":       # forward: targets indexed (restricted per rank), this rank's queries streamed
+                Td = c.upload(ds.t.bases, ds.t.offsets, tr)
+                sub = ds.q.slice(lo, hi)
+                Qd = c.upload(sub.bases, sub.offsets, qr[lo:hi])
+                ix = engine.Index(c, Td, preset, streamed=Qd, comm=comm)
+                counts, has = ix.overlap_twoset(Qd)
+                est = c.estimates(counts, sub.lens(), float(avg_t), ds.t.n, 100)
+                lens = [bounds[i + 1] - bounds[i] for i in range(world)]
+                allest = comm.all_gather_f32(est, max(lens), lens)
+                out[r] = (counts, has, ix.stats(), allest)
+            else:                      # inverse: queries indexed (replicated, small), this rank's targets streamed
+                Qd = c.upload(ds.q.bases, ds.q.offsets, qr)
+                sub = ds.t.slice(lo, hi)
+                Sd = c.upload(sub.bases, sub.offsets, tr[lo:hi])
+                ix = engine.Index(c, Qd, preset, streamed=Sd, comm=comm)
+                part = ix.overlap_inverse(Sd)
+                out[r] = (comm.all_reduce_u32(part), ix.stats())
+            ix.free()
+            comm.close()
+            c.close()
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    grp.close()
+    assert not errs, errs
+    assert all(o is not None for o in out), "a rank did not finish"
+    return out, bounds
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_world_of_threads_forward(ctx, oracle, tiny_ont, tiny_hifi, preset, world):
+    from lrge_amd import engine
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    Qd, Td, counts, has, st = _single(ctx, ds, PRESETS[preset])
+    avg_t = np.float32(ds.t.lens().sum()) / np.float32(ds.t.n)
+    est = ctx.estimates(counts, ds.q.lens(), float(avg_t), ds.t.n, 100)
+    out, bounds = _run_world(world, ds, PRESETS[preset], "twoset")
+    for r, (c, h, s, allest) in enumerate(out):
+        assert s == st, (r, s, st)                                      # every rank reports the global statistics
+        assert np.array_equal(c, counts[bounds[r]:bounds[r + 1]]) and np.array_equal(h, has[bounds[r]:bounds[r + 1]])
+        assert np.array_equal(allest.view(np.uint32), est.view(np.uint32))   # the gathered vector, in query order, on every rank
+    # and the oracle agrees with the single-GPU run (hence with every rank)
+    opt = oracle.make_opt(oracle.PRESET_AVA_PB if preset == "pb" else oracle.PRESET_AVA_ONT, dual=True)
+    ixo = oracle.Index(oracle.ReadSet(ds.t.seqs(), ds.t.names), opt)
+    rc, ec, eh = ixo.twoset_counts(oracle.ReadSet(ds.q.seqs(), ds.q.names), threads=8)
+    assert np.array_equal(counts, ec) and ixo.mid_occ == st["mid_occ"]
+
+
+def test_world_of_threads_inverse(ctx, tiny_ont):
+    from lrge_amd import engine
+    ds = tiny_ont
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Qd, Td = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
+    ix = engine.Index(ctx, Qd, 0)
+    ref = ix.overlap_inverse(Td)
+    st = ix.stats()
+    ix.free()
+    out, _ = _run_world(3, ds, 0, "inverse")
+    for total, s in out:
+        assert np.array_equal(total, ref) and s == st
+
+
+def test_rccl_transport_world1():
+    """RCCL behind the C ABI on the one GPU of this box: unique id, communicator, all-reduce, all-gather and a collective
+    index build with world size 1 (in a child: RCCL keeps process-wide state)."""
+    code = r'''
+import numpy as np
+from lrge_amd import engine, parallel, synth
+ctx = engine.Context(0)
+uid = parallel.RcclComm.unique_id(ctx)
+assert len(uid) == 128 and any(uid)
+comm = parallel.RcclComm.create(ctx, 0, 1, uid)
+a = np.arange(1000, dtype=np.uint32)
+assert np.array_equal(comm.all_reduce_u32(a), a)
+e = np.linspace(0, 1, 37).astype(np.float32)
+assert np.array_equal(comm.all_gather_f32(e, 40, [37]), e)
+g, q, t = synth.make_config("tiny_twoset")
+qr, tr = engine.name_ranks(q.names, t.names)
+Qd, Td = ctx.upload(q.bases, q.offsets, qr), ctx.upload(t.bases, t.offsets, tr)
+ix0 = engine.Index(ctx, Td, 0); ref = ix0.overlap_twoset(Qd)[0]; st = ix0.stats(); ix0.free()
+ix = engine.Index(ctx, Td, 0, streamed=Qd, comm=comm)
+assert ix.stats() == st and np.array_equal(ix.overlap_twoset(Qd)[0], ref)
+ix.free(); comm.close(); ctx.close()
+print("RCCL-OK", int(ref.sum()))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])

@@ -46,6 +46,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--emulate-rank", default=None, metavar="R/N",
+                    help="timing emulation on ONE GPU of rank R of an N-rank strong-scaling run: this process maps rank R's query "
+                         "range against an index restricted to it and counts R's 1/N share of the occurrence statistics; nobody "
+                         "supplies the other shares, so mid_occ is incomplete and the RESULTS ARE INVALID -- the line is a "
+                         "projection input (DESIGN.md section 7), not a bench result")
     return ap.parse_args()
 
 
@@ -119,12 +124,18 @@ def main():
         comm = parallel.RcclComm.bootstrap(ctx, rank, world, dist)
 
     qr, tr = engine.name_ranks(q.names, t.names)
-    bounds = parallel.shard_by_bases(q.lens(), world)          # strong scaling: this rank's contiguous query range
-    lo, hi = bounds[rank], bounds[rank + 1]
-    qs = q if world == 1 else q.slice(lo, hi)
+    emu = None
+    if a.emulate_rank:
+        er, en = (int(x) for x in a.emulate_rank.split("/"))
+        assert world == 1 and 0 <= er < en
+        emu = (er, en)
+        ctx.set_option("DEBUG_OWN_SHARE", "%d,%d" % (en, er))
+    bounds = parallel.shard_by_bases(q.lens(), emu[1] if emu else world)   # strong scaling: this rank's contiguous query range
+    lo, hi = (bounds[emu[0]], bounds[emu[0] + 1]) if emu else (bounds[rank], bounds[rank + 1])
+    qs = q if (world == 1 and not emu) else q.slice(lo, hi)
     qs_rank = qr[lo:hi]
     avg_t = np.float32(t.lens().sum()) / np.float32(t.n)
-    max_shard = max(bounds[i + 1] - bounds[i] for i in range(world))
+    max_shard = max(bounds[i + 1] - bounds[i] for i in range(len(bounds) - 1))
 
     # the two homes of the ASCII reads: HBM (value) and pinned host memory (from_host)
     d_q = torch.from_numpy(qs.bases).cuda(); d_t = torch.from_numpy(t.bases).cuda()
@@ -144,7 +155,7 @@ def main():
         Qd = ctx.upload(src_q, qs.offsets, qs_rank, wait=False)    # travels / packs while the index is built
         if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
             Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
-        ix = engine.Index(ctx, Td, preset, streamed=Qd if world > 1 or os.environ.get("LRGE_BENCH_RESTRICT") else None, comm=comm)
+        ix = engine.Index(ctx, Td, preset, streamed=Qd if comm is not None or emu or os.environ.get("LRGE_BENCH_RESTRICT") else None, comm=comm)
         tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
         counts, has = ix.overlap_twoset(Qd)
         tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
@@ -188,7 +199,7 @@ def main():
     ctx.set_timer_level(1)
 
     from_host = None
-    if not a.no_from_host:
+    if not a.no_from_host and not emu:
         hq = ctx.host_alloc(max(qs.bases.size, 1)); ht = ctx.host_alloc(max(t.bases.size, 1))
         hq.array[:qs.bases.size] = qs.bases; ht.array[:t.bases.size] = t.bases
         k2 = max(3, a.steps // 2)
@@ -200,6 +211,14 @@ def main():
                      "counts_equal_resident_run": bool(np.array_equal(last2[0], counts))}
         hq.free(); ht.free()
 
+    if emu:
+        K = a.steps
+        print(json.dumps({"emulated_rank": "%d/%d" % emu, "INVALID_AS_RESULT": "one rank's share of the work on one GPU; mid_occ incomplete",
+                          "ms_per_step": elapsed * 1e3 / K, "query_reads_of_rank": qs.n, "config": a.config,
+                          "stage_ms_per_step": {**{"index_" + k: v / K for k, v in acc_tb.items() if v and k != "total"},
+                                                **{k: v / K for k, v in acc_tm.items() if v}}}))
+        ctx.close()
+        return
     if rank == 0:
         K = a.steps
         ms_per_step = elapsed * 1e3 / K

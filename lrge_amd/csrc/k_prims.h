@@ -358,7 +358,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
 // d_tiles / n_tiles: segmented sort (see SegTile); every segment is sorted by the given bits, in place.
 static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u64 *k1, u64 *v1, u64 n, int begin_bit,
                             int nbits, u64 **res_k, u64 **res_v, bool reverse_digits = false,
-                            const SegTile *d_tiles = nullptr, u32 n_tiles = 0) {
+                            const SegTile *d_tiles = nullptr, u32 n_tiles = 0, int pass_begin = 0, int pass_end = -1) {
+    // pass_begin / pass_end: only the LSD passes [pass_begin, pass_end) of the sort (a stable sort by digit each, so a
+    // caller may filter the stream between two of them: k_restrict.h)
     *res_k = k0; *res_v = v0;
     if (n <= 1 || nbits <= 0) return LRGE_OK;
     if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
@@ -367,7 +369,7 @@ static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u6
     ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * nb);
     int passes = (nbits + 7) / 8;
     u64 *ki = k0, *vi = v0, *ko = k1, *vo = v1;
-    for (int p = 0; p < passes; ++p) {
+    for (int p = pass_begin; p < (pass_end < 0 ? passes : std::min(pass_end, passes)); ++p) {
         int shift = begin_bit + (reverse_digits ? passes - 1 - p : p) * 8;
         if (d_tiles) hipLaunchKernelGGL(k_rs_hist<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, d_tiles);
         else hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, d_tiles);
@@ -430,7 +432,7 @@ static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *
 
 // Stable keys-only LSD sort on bits [begin_bit, begin_bit + nbits) (k0 / k1 ping-pong, *res = buffer holding the result).
 static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64 n, int begin_bit, int nbits, u64 **res,
-                           bool reverse_digits) {
+                           bool reverse_digits, int pass_begin = 0, int pass_end = -1) {
     *res = k0;
     if (n <= 1 || nbits <= 0) return LRGE_OK;
     if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
@@ -438,7 +440,7 @@ static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64
     ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * nb);
     const int passes = (nbits + 7) / 8;
     u64 *ki = k0, *ko = k1;
-    for (int p = 0; p < passes; ++p) {
+    for (int p = pass_begin; p < (pass_end < 0 ? passes : std::min(pass_end, passes)); ++p) {
         const int d = reverse_digits ? passes - 1 - p : p;
         const int shift = begin_bit + d * 8;
         UnpackParams up{0, 0, 0, nbits - d * 8 >= 8 ? 255u : (1u << (nbits - d * 8)) - 1u};

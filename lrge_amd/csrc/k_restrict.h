@@ -10,7 +10,9 @@
 //     only keeps entries nobody asks for);
 //   * one order-preserving pass over the target entries (two sweeps: count per tile, scan, write) that keeps the entries
 //     whose key is in the set, and beside them emits the bare hashes of the keys this rank OWNS (a 1/world share of the
-//     hash space) for the statistics;
+//     hash space) for the statistics.  It runs between the first and the second LSD pass of the index sort: the first
+//     pass groups the entries by the top digit of the hash and a key's bit lives in the slice of the set that belongs
+//     to its top digit, so a group's tests stay inside L2; the remaining passes only move what was kept;
 //   * the owned hashes are sorted and run-length counted into the occurrence histogram; one all-reduce (comm.h) of
 //     [distinct keys, minimizers, histogram] makes it the histogram of the whole target set, and mid_occ follows with the
 //     reference's arithmetic.
@@ -22,6 +24,8 @@ struct KeySet {
     u64 *bits;          // n_words 64-bit words
     u64 word_mask;      // n_words - 1 (power of two)
     int direct;         // 1: bit index = hash itself (n_words * 64 >= 2^(2k))
+    u32 top_shift;      // hash >> top_shift = the top digit of the hash (the first LSD pass of the index sort groups by it)
+    u32 low_bits;       // Bloom form: word = top digit << low_bits | low_bits bits of a mix of the hash
 };
 
 __device__ __forceinline__ u64 ks_mix(u64 h) { h *= 0x9E3779B97F4A7C15ULL; return h ^ (h >> 29); }
@@ -29,7 +33,7 @@ __device__ __forceinline__ u64 ks_mix(u64 h) { h *= 0x9E3779B97F4A7C15ULL; retur
 __device__ __forceinline__ void ks_locate(const KeySet &ks, u64 hash, u64 *word, u64 *mask) {
     if (ks.direct) { *word = hash >> 6; *mask = 1ULL << (hash & 63); return; }
     const u64 m = ks_mix(hash);
-    *word = (m >> 20) & ks.word_mask;
+    *word = ((hash >> ks.top_shift) << ks.low_bits | ((m >> 20) & ((1ULL << ks.low_bits) - 1))) & ks.word_mask;
     *mask = 1ULL << (m & 63) | 1ULL << ((m >> 6) & 63) | 1ULL << ((m >> 12) & 63);
 }
 __device__ __forceinline__ bool ks_test(const KeySet &ks, u64 hash) {

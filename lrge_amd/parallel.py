@@ -1,11 +1,13 @@
-"""Multi-GPU sharding of the overlap path: one process per GPU,
-`torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+"""Multi-GPU sharding of the overlap path: one context per GPU.
 
-The path shards by *streamed* read: queries in two-set forward mode, streamed targets in inverse
-mode, reads-as-queries in all-vs-all.  The index is replicated (built redundantly on every GPU, no
-data-path collective).  Exactly one collective closes the step:
-  * forward two-set: all_gather of the per-read f32 estimate vectors (ragged -> padded);
-  * all-vs-all / inverse: all_reduce(sum) of the u32 count vector keyed by indexed read.
+The path shards by *streamed* read: queries in two-set forward mode, streamed targets in inverse mode, reads-as-queries
+in all-vs-all.  Every rank owns its range end to end; its index holds the entries its own streamed reads can ask for
+(lrge_hip_index_build_for: no index data crosses the links, one small all-reduce makes mid_occ global).  One collective
+closes the step:
+  * forward two-set: all-gather of the per-read f32 estimate vectors;
+  * all-vs-all / inverse: all-reduce(sum) of the u32 count vector keyed by indexed read.
+Communicators: RcclComm (one process per GPU, RCCL through the C ABI), LocalGroup.comm (ranks = threads of one process),
+TorchComm (torch.distributed; "gloo" in the CPU tests), SoloComm.  The drivers below take any of them.
 """
 import numpy as np
 
@@ -115,53 +117,61 @@ class LocalGroup:
             self.h = None
 
 
-def _dist():
-    import torch.distributed as dist
-    return dist
+class TorchComm:
+    """The same two collectives over torch.distributed -- backend "gloo" in the CPU tests (world size 2, no GPU), "nccl"
+    (= RCCL) when a host prefers torch's communicator to the library's own.  Same interface as the C-ABI communicators."""
+
+    def __init__(self, dist=None):
+        import torch.distributed as _d
+        self.dist = dist or _d
+        self.rank, self.world = self.dist.get_rank(), self.dist.get_world_size()
+        self.dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+
+    def all_reduce_u32(self, counts):
+        import torch
+        t = torch.as_tensor(np.ascontiguousarray(counts).astype(np.int64)).to(self.dev)   # u32 travels as int64 (gloo / RCCL sum)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy().astype(np.uint32)
+
+    def all_gather_f32(self, local, max_len, lens):
+        import torch
+        m = max(max_len, 1)
+        pad = torch.full((m,), float("nan"), dtype=torch.float32, device=self.dev)
+        pad[:len(local)] = torch.as_tensor(np.ascontiguousarray(local, dtype=np.float32)).to(self.dev)
+        bufs = [torch.empty(m, dtype=torch.float32, device=self.dev) for _ in range(self.world)]
+        self.dist.all_gather(bufs, pad)
+        return np.concatenate([b[:n].cpu().numpy() for b, n in zip(bufs, lens)])
+
+    def close(self):
+        pass
 
 
-def gather_ragged_f32(local, device=None):
-    """all_gather of variable-length f32 vectors; returns the concatenation in rank order."""
-    import torch
-    dist = _dist()
-    world = dist.get_world_size()
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    loc = torch.as_tensor(np.ascontiguousarray(local, dtype=np.float32)).to(dev)
-    n_loc = torch.tensor([loc.numel()], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, n_loc)
-    sizes = [int(s.item()) for s in sizes]
-    m = max(sizes) if sizes else 0
-    pad = torch.full((m,), float("nan"), dtype=torch.float32, device=dev)
-    pad[:loc.numel()] = loc
-    bufs = [torch.empty(m, dtype=torch.float32, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    return np.concatenate([b[:s].cpu().numpy() for b, s in zip(bufs, sizes)]) if m else np.zeros(0, np.float32)
+class SoloComm:
+    """World of one: nothing to exchange."""
+    rank, world = 0, 1
+
+    def all_reduce_u32(self, counts):
+        return np.asarray(counts, dtype=np.uint32)
+
+    def all_gather_f32(self, local, max_len, lens):
+        return np.asarray(local, dtype=np.float32)
+
+    def close(self):
+        pass
 
 
-def allreduce_counts_u32(counts, device=None):
-    """Sum of per-rank partial count vectors (AVA / inverse).  u32 travels as int64 (gloo/RCCL sum)."""
-    import torch
-    dist = _dist()
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    t = torch.as_tensor(np.ascontiguousarray(counts).astype(np.int64)).to(dev)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.cpu().numpy().astype(np.uint32)
-
-
-def twoset_forward_sharded(overlap_fn, q_lens, rank, world):
-    """Run `overlap_fn(lo, hi) -> (estimates f32[hi-lo], no_mapping int)` on this rank's query range
-    and gather.  Returns (all estimates in query order, total no_mapping_count, (lo, hi))."""
-    import torch
-    dist = _dist()
-    b = shard_by_bases(q_lens, world)
-    lo, hi = b[rank], b[rank + 1]
+def twoset_forward_sharded(overlap_fn, q_lens, comm):
+    """Two-set forward over comm.world GPUs (STRONG scaling of one job): the queries are cut into contiguous ranges with equal
+    base counts, `overlap_fn(lo, hi) -> (estimates f32[hi-lo], no_mapping int)` runs this rank's range end to end (its
+    index restricted to its own queries: engine.Index(..., streamed=, comm=)), one all-gather of the estimate vectors
+    closes the step.  Returns (all estimates in query order, total no_mapping_count, (lo, hi))."""
+    b = shard_by_bases(q_lens, comm.world)
+    lo, hi = b[comm.rank], b[comm.rank + 1]
     est, no_map = overlap_fn(lo, hi)
-    allv = gather_ragged_f32(est)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    nm = torch.tensor([int(no_map)], dtype=torch.int64, device=dev)
-    dist.all_reduce(nm, op=dist.ReduceOp.SUM)
-    return allv, int(nm.item()), (lo, hi)
+    lens = [b[i + 1] - b[i] for i in range(comm.world)]
+    allv = comm.all_gather_f32(est, max(lens) if lens else 0, lens)
+    nm = comm.all_reduce_u32(np.array([int(no_map)], dtype=np.uint32))
+    return allv, int(nm[0]), (lo, hi)
 
 
 def shard_by_rank_round_robin(name_ranks, rank, world):
@@ -172,19 +182,20 @@ def shard_by_rank_round_robin(name_ranks, rank, world):
     return np.sort(order[rank::max(world, 1)])
 
 
-def ava_sharded(overlap_shard_fn, name_ranks, rank, world):
-    """All-vs-all over `world` GPUs.  `overlap_shard_fn(idx) -> u32[n_reads]`: counts keyed by indexed read that the
+def ava_sharded(overlap_shard_fn, name_ranks, comm):
+    """All-vs-all over comm.world GPUs.  `overlap_shard_fn(idx) -> u32[n_reads]`: counts keyed by indexed read that the
     reads `idx`, used as queries against the replicated index, contribute (engine.Index.overlap_ava(shard=...)).
     One all_reduce(sum) of the count vector closes the step; returns (counts of the whole job, idx)."""
-    idx = shard_by_rank_round_robin(name_ranks, rank, world)
+    idx = shard_by_rank_round_robin(name_ranks, comm.rank, comm.world)
     part = np.asarray(overlap_shard_fn(idx), dtype=np.uint32)
-    return (allreduce_counts_u32(part) if world > 1 else part), idx
+    return comm.all_reduce_u32(part), idx
 
 
-def inverse_sharded(overlap_shard_fn, streamed_lens, rank, world):
-    """Inverse two-set (--use-min-ref): the index holds the query set (replicated), the streamed target reads are
-    sharded by bases.  `overlap_shard_fn(lo, hi) -> u32[n_indexed]`; one all_reduce(sum) closes the step."""
-    b = shard_by_bases(streamed_lens, world)
-    lo, hi = b[rank], b[rank + 1]
+def inverse_sharded(overlap_shard_fn, streamed_lens, comm):
+    """Inverse two-set (--use-min-ref): the index holds the query set (small; replicated, or restricted to the rank's
+    streamed reads), the streamed target reads are cut by bases.  `overlap_shard_fn(lo, hi) -> u32[n_indexed]`; one
+    all_reduce(sum) closes the step."""
+    b = shard_by_bases(streamed_lens, comm.world)
+    lo, hi = b[comm.rank], b[comm.rank + 1]
     part = np.asarray(overlap_shard_fn(lo, hi), dtype=np.uint32)
-    return (allreduce_counts_u32(part) if world > 1 else part), (lo, hi)
+    return comm.all_reduce_u32(part), (lo, hi)

@@ -129,13 +129,15 @@ def _worker(rank, world, port, q):
 
         def overlap_fn(lo, hi):                       # stands in for the per-rank GPU call
             return full[lo:hi], int(rank == 0)
-        allv, no_map, (lo, hi) = parallel.twoset_forward_sharded(overlap_fn, lens, rank, world)
+        comm = parallel.TorchComm(dist)
+        assert (comm.rank, comm.world) == (rank, world)
+        allv, no_map, (lo, hi) = parallel.twoset_forward_sharded(overlap_fn, lens, comm)
         counts = np.zeros(5, dtype=np.uint32); counts[rank] = 3; counts[4] = 1
-        tot = parallel.allreduce_counts_u32(counts)
+        tot = comm.all_reduce_u32(counts)
         # all-vs-all / inverse drivers: the per-rank GPU call is stood in for by "one count per read of the shard"
         ranks7 = np.array([4, 0, 6, 2, 5, 1, 3])
-        ava, idx = parallel.ava_sharded(lambda ix: np.bincount(ix, minlength=7), ranks7, rank, world)
-        inv, (ilo, ihi) = parallel.inverse_sharded(lambda a, b: np.bincount(np.arange(a, b) % 3, minlength=3), lens, rank, world)
+        ava, idx = parallel.ava_sharded(lambda ix: np.bincount(ix, minlength=7), ranks7, comm)
+        inv, (ilo, ihi) = parallel.inverse_sharded(lambda a, b: np.bincount(np.arange(a, b) % 3, minlength=3), lens, comm)
         q.put((rank, allv.tolist(), no_map, lo, hi, tot.tolist(), ava.tolist(), idx.tolist(), inv.tolist()))
     finally:
         dist.destroy_process_group()

@@ -97,24 +97,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const u32 *in, u64
     }
 }
 
-// single block: in-place exclusive scan of up to any n (loops), writes total to *total
+// single block: in-place exclusive scan of up to any n, writes total to *total.  Every thread owns 8 consecutive items,
+// so the 8192 block sums of a 32 M-entry scan take ONE trip through memory and the block's barriers (one item per thread
+// and 8 trips cost 60-90 us per call, ~20 calls per step).
 __global__ __launch_bounds__(1024) void k_scan_small(u32 *data, u32 n, u32 *total) {
     __shared__ u32 wsum[16];
     __shared__ u32 carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (u32 base = 0; base < n; base += 1024) {
-        u32 i = base + threadIdx.x;
-        u32 v = i < n ? data[i] : 0;
-        u32 inc = wave_incl_scan_u32(v);
+    for (u32 base = 0; base < n; base += 8192) {
+        const u32 i0 = base + threadIdx.x * 8;
+        u32 v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = i0 + t < n ? data[i0 + t] : 0;
+        u32 s = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s += v[t];
+        const u32 inc = wave_incl_scan_u32(s);
         if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
         __syncthreads();
-        u32 woff = 0;
-        for (u32 w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
-        u32 carry = carry_s;
-        if (i < n) data[i] = carry + woff + inc - v;
+        u32 off = carry_s + inc - s;
+        for (u32 w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { if (i0 + t < n) data[i0 + t] = off; off += v[t]; }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        if (threadIdx.x == 1023) carry_s = off;
         __syncthreads();
     }
     if (threadIdx.x == 0 && total) *total = carry_s;

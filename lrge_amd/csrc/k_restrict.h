@@ -67,28 +67,33 @@ struct RestrictArgs {
     u32 rank, world;
 };
 
-// flags of a thread's RF_ITEMS consecutive entries: bit t = keep, bit 16 + t = owned
-__device__ __forceinline__ u32 rf_flags(const RestrictArgs &A, u64 base, u64 *xs) {
+// A tile = RF_ITEMS rows of RF_THREADS consecutive entries: lane t of a row reads entry tile_base + row * RF_THREADS + t,
+// so every load is one contiguous 512-byte run per wavefront, and (row, wave, lane) order is memory order -- the
+// compaction stays order-preserving with per-(row, wave) ballot counts instead of per-thread runs.
+// flags: bit row = keep, bit 16 + row = owned
+__device__ __forceinline__ u32 rf_flags(const RestrictArgs &A, u64 tile_base, u64 *xs) {
     u32 f = 0;
 #pragma unroll
-    for (int t = 0; t < RF_ITEMS; ++t) {
-        const u64 i = base + t;
+    for (int r = 0; r < RF_ITEMS; ++r) {
+        const u64 i = tile_base + (u64)r * RF_THREADS + threadIdx.x;
+        xs[r] = i < A.n ? A.x[i] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < RF_ITEMS; ++r) {
+        const u64 i = tile_base + (u64)r * RF_THREADS + threadIdx.x;
         if (i < A.n) {
-            const u64 x = A.x[i];
-            xs[t] = x;
-            const u64 h = x >> A.kshift;
-            if (ks_test(A.ks, h)) f |= 1u << t;
-            if (own_hash(h, A.rank, A.world)) f |= 1u << (16 + t);
-        } else xs[t] = 0;
+            const u64 h = xs[r] >> A.kshift;
+            if (ks_test(A.ks, h)) f |= 1u << r;
+            if (own_hash(h, A.rank, A.world)) f |= 1u << (16 + r);
+        }
     }
     return f;
 }
 
 __global__ __launch_bounds__(RF_THREADS) void k_restrict_count(RestrictArgs A, u32 *__restrict__ bc_keep, u32 *__restrict__ bc_own) {
     __shared__ u32 wk[RF_THREADS / 64], wo[RF_THREADS / 64];
-    const u64 base = (u64)blockIdx.x * RF_TILE + (u64)threadIdx.x * RF_ITEMS;
     u64 xs[RF_ITEMS];
-    const u32 f = rf_flags(A, base, xs);
+    const u32 f = rf_flags(A, (u64)blockIdx.x * RF_TILE, xs);
     u32 ck = (u32)__popc(f & 0xffffu), co = (u32)__popc(f >> 16);
     for (int d = 32; d > 0; d >>= 1) { ck += __shfl_down(ck, d, 64); co += __shfl_down(co, d, 64); }
     if (lane_id() == 0) { wk[threadIdx.x >> 6] = ck; wo[threadIdx.x >> 6] = co; }
@@ -102,20 +107,36 @@ __global__ __launch_bounds__(RF_THREADS) void k_restrict_count(RestrictArgs A, u
 
 __global__ __launch_bounds__(RF_THREADS) void k_restrict_write(RestrictArgs A, const u32 *__restrict__ off_keep, const u32 *__restrict__ off_own,
                                                                u64 *__restrict__ out_x, u64 *__restrict__ out_y, u64 *__restrict__ out_hash) {
-    __shared__ u32 wk[RF_THREADS / 64], wo[RF_THREADS / 64];
-    const u64 base = (u64)blockIdx.x * RF_TILE + (u64)threadIdx.x * RF_ITEMS;
+    __shared__ u32 ck[RF_ITEMS][RF_THREADS / 64], co[RF_ITEMS][RF_THREADS / 64];
+    const u64 tile_base = (u64)blockIdx.x * RF_TILE;
     u64 xs[RF_ITEMS];
-    const u32 f = rf_flags(A, base, xs);
-    const u32 ck = (u32)__popc(f & 0xffffu), co = (u32)__popc(f >> 16);
-    const u32 ik = wave_incl_scan_u32(ck), io = wave_incl_scan_u32(co);
-    if (lane_id() == 63) { wk[threadIdx.x >> 6] = ik; wo[threadIdx.x >> 6] = io; }
-    __syncthreads();
-    u32 ok = off_keep[blockIdx.x] + ik - ck, oo = off_own[blockIdx.x] + io - co;
-    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) { ok += wk[w]; oo += wo[w]; }
+    const u32 f = rf_flags(A, tile_base, xs);
+    const u32 w = threadIdx.x >> 6, lane = lane_id();
+    u32 pk[RF_ITEMS], po[RF_ITEMS];          // my rank inside my (row, wave)
 #pragma unroll
-    for (int t = 0; t < RF_ITEMS; ++t) {
-        if (f & (1u << t)) { out_x[ok] = xs[t]; if (out_y) out_y[ok] = A.y[base + t]; ++ok; }
-        if (f & (1u << (16 + t))) out_hash[oo++] = xs[t] >> A.kshift;
+    for (int r = 0; r < RF_ITEMS; ++r) {
+        const u64 bk = __ballot((f >> r) & 1u), bo = __ballot((f >> (16 + r)) & 1u);
+        pk[r] = (u32)__popcll(bk & lanemask_lt()); po[r] = (u32)__popcll(bo & lanemask_lt());
+        if (lane == 0) { ck[r][w] = (u32)__popcll(bk); co[r][w] = (u32)__popcll(bo); }
+    }
+    __syncthreads();
+    u32 ok = off_keep[blockIdx.x], oo = off_own[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < RF_ITEMS; ++r) {
+        u32 bk = 0, bo = 0, tk = 0, to = 0;   // before my wave in this row / the whole row
+#pragma unroll
+        for (u32 ww = 0; ww < RF_THREADS / 64; ++ww) {
+            const u32 a = ck[r][ww], b = co[r][ww];
+            if (ww < w) { bk += a; bo += b; }
+            tk += a; to += b;
+        }
+        if ((f >> r) & 1u) {
+            const u32 d = ok + bk + pk[r];
+            out_x[d] = xs[r];
+            if (out_y) out_y[d] = A.y[tile_base + (u64)r * RF_THREADS + threadIdx.x];
+        }
+        if ((f >> (16 + r)) & 1u) out_hash[oo + bo + po[r]] = xs[r] >> A.kshift;
+        ok += tk; oo += to;
     }
 }
 

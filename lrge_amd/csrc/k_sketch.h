@@ -28,47 +28,55 @@ __device__ __forceinline__ u32 nt4_code(u32 c) {
 }
 
 #define PACK_THREADS 256
-// One lane per 32-base word of the packed image.  `blk_read[b]` (computed on the host with the word offsets) is the read
-// that holds the first word of block b, so a lane finds its read with a short forward scan instead of a binary search;
-// a word's 32 source bytes are fetched as two (byte-aligned) 16-byte loads.
+#define PACK_WORDS (PACK_THREADS / 2)     // words per block
+// Two lanes per 32-base word of the packed image, 16 bases each: the lanes of a wavefront read consecutive 16-byte pieces
+// of the ASCII (one coalesced 1 KB run per load wherever a read continues), convert them to 32 bits + a 16-bit mask, and
+// the even lane writes the word after one exchange with its neighbour.  `blk_read[b]` (computed on the host with the
+// word offsets) is the read that holds the first word of block b, so a lane finds its read with a short forward scan
+// instead of a binary search.
 __global__ __launch_bounds__(PACK_THREADS) void k_pack(const u8 *__restrict__ ascii, const u64 *__restrict__ boff,
                                                        const u64 *__restrict__ woff, const u32 *__restrict__ blk_read, u32 n_reads,
                                                        u64 n_words, u64 *__restrict__ pack, u32 *__restrict__ nmask) {
-    const u64 wid = (u64)blockIdx.x * PACK_THREADS + threadIdx.x;
-    if (wid >= n_words) return;
-    u32 r = blk_read[blockIdx.x];
-    while (r + 1 < n_reads && woff[r + 1] <= wid) ++r;          // (empty reads own no word and are stepped over)
-    const u64 pos0 = (wid - woff[r]) * 32;
-    const u64 b0 = boff[r], len = boff[r + 1] - b0;
-    const u8 *src = ascii + b0 + pos0;
-    const u32 cnt = (u32)(len - pos0 < 32 ? len - pos0 : 32);
-    u32 v[8];
-    if (cnt == 32) {
-        uint4 lo, hi;
-        __builtin_memcpy(&lo, src, 16); __builtin_memcpy(&hi, src + 16, 16);
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-    } else {                                                        // the last word of a read: never read past its end
+    const u64 wid = (u64)blockIdx.x * PACK_WORDS + (threadIdx.x >> 1);
+    const u32 half = threadIdx.x & 1;
+    const bool in = wid < n_words;
+    u32 bits = 0, m = 0xffffu;
+    if (in) {
+        u32 r = blk_read[blockIdx.x];
+        while (r + 1 < n_reads && woff[r + 1] <= wid) ++r;          // (empty reads own no word and are stepped over)
+        const u64 pos0 = (wid - woff[r]) * 32 + 16 * half;
+        const u64 b0 = boff[r], len = boff[r + 1] - b0;
+        const u8 *src = ascii + b0 + pos0;
+        const u32 cnt = pos0 >= len ? 0u : (u32)(len - pos0 < 16 ? len - pos0 : 16);
+        u32 v[4] = {0, 0, 0, 0};
+        if (cnt == 16) {
+            uint4 q;
+            __builtin_memcpy(&q, src, 16);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {                                                        // the last word of a read: never read past its end
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            u32 x = 0;
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { const u32 i = 4 * j + t; if (i < cnt) x |= (u32)src[i] << (8 * t); }
-            v[j] = x;
+                for (int t = 0; t < 4; ++t) { const u32 i = 4 * j + t; if (i < cnt) v[j] |= (u32)src[i] << (8 * t); }
+            }
         }
-    }
-    u64 w = 0; u32 m = 0;
+        m = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const u32 c = nt4_code((v[j] >> (8 * t)) & 0xffu);
-            w |= (u64)(c & 3) << (2 * (4 * j + t));
-            m |= (c >> 2) << (4 * j + t);
+            for (int t = 0; t < 4; ++t) {
+                const u32 c = nt4_code((v[j] >> (8 * t)) & 0xffu);
+                bits |= (c & 3) << (2 * (4 * j + t));
+                m |= (c >> 2) << (4 * j + t);
+            }
         }
+        if (cnt < 16) { m |= 0xffffu & (~0u << cnt); bits &= cnt ? (~0u >> (32 - 2 * cnt)) : 0u; }   // padding past the end is "ambiguous"
     }
-    if (cnt < 32) { m |= ~0u << cnt; w &= (1ULL << (2 * cnt)) - 1; }   // padding past the end of the read is "ambiguous"
-    pack[wid] = w;
-    nmask[wid] = m;
+    const u32 obits = (u32)__shfl_xor((i32)bits, 1, 64), om = (u32)__shfl_xor((i32)m, 1, 64);
+    if (in && half == 0) {
+        pack[wid] = (u64)bits | (u64)obits << 32;
+        nmask[wid] = (m & 0xffffu) | om << 16;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

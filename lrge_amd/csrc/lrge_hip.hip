@@ -258,12 +258,12 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
         s->n_chunks = nc;
         s->h_cs[n] = (u32)nc;
     }
-    const u64 n_blk = div_up(w, PACK_THREADS);
+    const u64 n_blk = div_up(w, PACK_WORDS);
     {   // k_pack: read that holds the first word of every block
         s->h_blk.resize((size_t)n_blk + 1);
         u32 r = 0;
         for (u64 b = 0; b < n_blk; ++b) {
-            const u64 w0 = b * PACK_THREADS;
+            const u64 w0 = b * PACK_WORDS;
             while (r + 1 < n && s->h_woff[r + 1] <= w0) ++r;
             s->h_blk[b] = r;
         }

@@ -19,6 +19,7 @@
 #pragma once
 #include "internal.h"
 #include "k_prims.h"
+#include "k_sketch.h"
 
 struct KeySet {
     u64 *bits;          // n_words 64-bit words
@@ -53,7 +54,41 @@ __global__ __launch_bounds__(256) void k_keyset_build(const u64 *__restrict__ qx
 
 // which rank owns a hash for the occurrence statistics
 __device__ __forceinline__ bool own_hash(u64 hash, u32 rank, u32 world) {
-    return world <= 1 || (u32)((ks_mix(hash) >> 32) % world) == rank;
+    return world <= 1 || (u32)(((ks_mix(hash) >> 32) * (u64)world) >> 32) == rank;    // (multiply-shift: no integer division)
+}
+
+// The filter inside the sketch (the one-pass form of k_sketch.h): a minimizer is tested the moment mm_sketch's loop emits
+// it, so the entries nobody will ask for never reach memory -- the kernel is bound by its hash / window arithmetic, and the
+// scattered key-set probes ride along under it.  Kept entries go to the chunk's slot of tmp_x (tmp_y: the (hash, y) pair
+// layout), the bare hashes this rank owns to its slot of tmp_h; k_sketch_compact closes the gaps of each stream.
+template <int K, int W, bool HPC, bool PK>
+__global__ __launch_bounds__(SK_THREADS) void k_sketch_restrict(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
+                                                               const u64 *__restrict__ woff, const u32 *__restrict__ lens,
+                                                               ChunkMap cm, u32 n_chunks, u32 *__restrict__ cnt_keep, u32 *__restrict__ cnt_own,
+                                                               u32 *__restrict__ overflow, u64 *__restrict__ tmp_x, u64 *__restrict__ tmp_y,
+                                                               u64 *__restrict__ tmp_h, u32 pk_pos1, u32 pk_ybits, u32 cap, KeySet ks,
+                                                               u32 rank, u32 world) {
+    const u32 c = blockIdx.x * SK_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    const u32 r = cm.find(c);
+    const i32 len = (i32)lens[r];
+    const i32 s = (i32)(c - cm.chunk_start[r]) * SK_CHUNK;
+    const i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
+    const u64 base = (u64)c * SK_CAP;
+    u32 nk = 0, no = 0;
+    sketch_chunk<K, W, HPC>(pack, nmask, woff[r], len, r, s, e, [&](u64 x, u64 y) {
+        const u64 h = x >> 8;
+        if (ks_test(ks, h)) {
+            if (nk < cap) {
+                if (PK) tmp_x[base + nk] = h << pk_ybits | (y >> 32) << pk_pos1 | (u64)(u32)y;
+                else { tmp_x[base + nk] = h; tmp_y[base + nk] = y; }
+            }
+            ++nk;
+        }
+        if (own_hash(h, rank, world)) { if (no < cap) tmp_h[base + no] = h; ++no; }
+    });
+    cnt_keep[c] = nk; cnt_own[c] = no;
+    if (nk > cap || no > cap) *overflow = 1u;
 }
 
 #define RF_THREADS 256

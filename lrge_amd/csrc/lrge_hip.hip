@@ -606,6 +606,56 @@ extern "C" void lrge_hip_index_free(lrge_hip_index *ix);
 struct IndexFree { void operator()(lrge_hip_index *ix) const { lrge_hip_index_free(ix); } };
 typedef std::unique_ptr<lrge_hip_index, IndexFree> IndexGuard;     // every early return releases what the index holds so far
 
+// Restricted build, fast form: the key-set test inside the one-pass sketch (k_sketch_restrict).  *done = false when the
+// slots do not fit or a chunk overflowed its slot: the caller then takes the general form (full sketch, first sort pass,
+// filter sweeps).  On success o->x [, o->y] hold the kept entries (o->n of them), *hashes / *n_hashes the owned hashes.
+template <int K, int W, bool HPC>
+static int sketch_restrict_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool pk, u32 pk_pos1, u32 pk_ybits, KeySet ks,
+                                  u32 rank, u32 world, SketchOut *o, u64 **hashes, u64 *n_hashes, bool *done) {
+    *done = false;
+    if (s->n_chunks >= (1ULL << 32) || s->n_chunks == 0 || ctx->opt("SKETCH_TWO_PASS")) return LRGE_OK;
+    const u32 n_chunks = (u32)s->n_chunks;
+    const u64 slot_bytes = (u64)n_chunks * SK_CAP * 8 * (pk ? 2 : 3);
+    size_t mfree = (size_t)64 << 30, mtot = 0;
+    if (slot_bytes > ((u64)4 << 30)) (void)hipMemGetInfo(&mfree, &mtot);
+    if (slot_bytes >= ((u64)mfree + ctx->pool.total) / 4) return LRGE_OK;
+    const u32 sk_cap = ctx->opt("DEBUG_SK_CAP") ? (u32)std::min<u64>(ctx->opt_u64("DEBUG_SK_CAP", SK_CAP), SK_CAP) : (u32)SK_CAP;
+    u64 *tx = sc.get<u64>((size_t)n_chunks * SK_CAP), *ty = pk ? nullptr : sc.get<u64>((size_t)n_chunks * SK_CAP);
+    u64 *th = sc.get<u64>((size_t)n_chunks * SK_CAP);
+    auto drop_slots = [&]() { if (tx) sc.drop(tx); if (ty) sc.drop(ty); if (th) sc.drop(th); };
+    if (!tx || (!pk && !ty) || !th) { drop_slots(); (void)hipGetLastError(); return LRGE_OK; }
+    ALLOC_OR_FAIL(ck, sc, u32, (size_t)n_chunks + 1); ALLOC_OR_FAIL(co, sc, u32, (size_t)n_chunks + 1); ALLOC_OR_FAIL(d_tot, sc, u32, 3);
+    HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 12, ctx->stream));
+    ChunkMap cm{s->d_cs, s->n};
+    const dim3 sgrid((u32)div_up(n_chunks, SK_THREADS));
+    if (pk) hipLaunchKernelGGL((k_sketch_restrict<K, W, HPC, true>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm,
+                               n_chunks, ck, co, d_tot + 2, tx, ty, th, pk_pos1, pk_ybits, sk_cap, ks, rank, world);
+    else hipLaunchKernelGGL((k_sketch_restrict<K, W, HPC, false>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm,
+                            n_chunks, ck, co, d_tot + 2, tx, ty, th, 0u, 0u, sk_cap, ks, rank, world);
+    KCHK(ctx);
+    int rc = scan_exclusive_u32(ctx, sc, ck, ck, n_chunks, d_tot); if (rc) return rc;
+    rc = scan_exclusive_u32(ctx, sc, co, co, n_chunks, d_tot + 1); if (rc) return rc;
+    u32 tot[3] = {0, 0, 0};
+    HIPCHK(ctx, ctx->d2h(tot, d_tot, 12, ctx->stream));
+    HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+    if (tot[2]) { drop_slots(); sc.drop(ck); sc.drop(co); sc.drop(d_tot); return LRGE_OK; }    // a slot overflowed: general form
+    ALLOC_OR_FAIL(dx, sc, u64, (size_t)tot[0] + 1);
+    u64 *dy = nullptr;
+    if (!pk) { dy = sc.get<u64>((size_t)tot[0] + 1); if (!dy) return LRGE_ERR_DEVICE; }
+    ALLOC_OR_FAIL(dh, sc, u64, (size_t)tot[1] + 1);
+    const dim3 cgrid((u32)div_up(div_up(n_chunks, 64), 4));
+    if (pk) hipLaunchKernelGGL(k_sketch_compact<false>, cgrid, dim3(256), 0, ctx->stream, tx, ty, ck, d_tot, n_chunks, dx, dy);
+    else hipLaunchKernelGGL(k_sketch_compact<true>, cgrid, dim3(256), 0, ctx->stream, tx, ty, ck, d_tot, n_chunks, dx, dy);
+    KCHK(ctx);
+    hipLaunchKernelGGL(k_sketch_compact<false>, cgrid, dim3(256), 0, ctx->stream, th, (const u64 *)nullptr, co, d_tot + 1, n_chunks, dh, (u64 *)nullptr);
+    KCHK(ctx);
+    drop_slots(); sc.drop(ck); sc.drop(co); sc.drop(d_tot);
+    o->x = dx; o->y = dy; o->mz_off = nullptr; o->n = tot[0];
+    *hashes = dh; *n_hashes = tot[1];
+    *done = true;
+    return LRGE_OK;
+}
+
 // A restricted build (lrge_hip_index_build_for, k_restrict.h): the index holds the entries of the keys that occur in
 // `restrict_to`'s minimizers, its statistics (mid_occ, key and minimizer totals) are those of the whole target set.
 struct IndexBuildOpts { lrge_hip_seqset *restrict_to = nullptr; lrge_hip_comm *comm = nullptr; };
@@ -663,10 +713,37 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         KCHK(ctx);
         HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
     }
-    rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits);
-    if (rc == LRGE_OK && !ctx->opt("NO_PRESKETCH")) rc = presketch_start_pending(ctx);
-    if (rc) return rc;
-    sc.drop(so.mz_off);
+    // a restricted build counts its 1/world share of the hash space (the rest comes through the communicator)
+    u32 own_rank = 0, own_world = 1;
+    if (ro && ro->restrict_to) {
+        own_rank = ro->comm ? (u32)ro->comm->rank : 0; own_world = ro->comm ? (u32)ro->comm->world : 1;
+        if (!ro->comm && ctx->opt("DEBUG_OWN_SHARE")) {
+            // timing emulation of ONE rank of a world on a 1-GPU box ("world,rank"): this rank counts its share of the hash
+            // space and nobody supplies the rest, so the statistics (mid_occ) are incomplete and the results invalid
+            unsigned w_ = 1, r_ = 0;
+            if (sscanf(ctx->opt("DEBUG_OWN_SHARE"), "%u,%u", &w_, &r_) == 2 && w_ >= 1 && r_ < w_) { own_world = w_; own_rank = r_; }
+        }
+    }
+    bool fused = false; u64 *own_hashes = nullptr; u64 n_own = 0;
+    if (ro && ro->restrict_to && !ctx->opt("RESTRICT_SWEEPS")) {
+        // fast form: the key-set test inside the target sketch (needs the key set first: the main stream meets the side
+        // stream here instead of after the sketch)
+        rc = seqset_ready(ctx, targets);
+        if (rc) return rc;
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        StageTimer t(ctx, LRGE_T_SKETCH);
+        rc = (preset == LRGE_PRESET_AVA_PB)
+                 ? sketch_restrict_launch<19, 5, true>(ctx, sc, targets, pk, pk ? pk_pos1 : 0, pk_ybits, ks, own_rank, own_world, &so, &own_hashes, &n_own, &fused)
+                 : sketch_restrict_launch<15, 5, false>(ctx, sc, targets, pk, pk ? pk_pos1 : 0, pk_ybits, ks, own_rank, own_world, &so, &own_hashes, &n_own, &fused);
+        t.stop();
+        if (rc) return rc;
+    }
+    if (!fused) {
+        rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits);
+        if (rc == LRGE_OK && !ctx->opt("NO_PRESKETCH")) rc = presketch_start_pending(ctx);
+        if (rc) return rc;
+        sc.drop(so.mz_off);
+    }
     u64 M = so.n;
     if (M >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32 minimizers (got %llu)", (unsigned long long)M); return LRGE_ERR_TOO_MANY; }
 
@@ -674,7 +751,8 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     bool have_global = false; u64 g_distinct = 0, g_mz = 0; int g_mid_occ = 0;
     int pass_from = 0;      // LSD passes of the index sort already done
     if (ro && ro->restrict_to) {
-        {   // first pass of the index sort over ALL entries: groups them by the top digit of the hash (see the key set above)
+        u64 *sh = own_hashes; u64 Ms = n_own;
+        if (!fused) {   // general form: first pass of the index sort over ALL entries: groups them by the top digit of the hash (see the key set above)
             StageTimer t(ctx, LRGE_T_INDEX_SORT);
             ALLOC_OR_FAIL(k1, sc, u64, M + 1);
             if (pk) {
@@ -695,16 +773,11 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             t.stop();
         }
         StageTimer t(ctx, LRGE_T_INDEX_RESTRICT);
+        if (!fused) {
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         RestrictArgs A;
         A.x = so.x; A.y = pk ? nullptr : so.y; A.n = M; A.kshift = pk ? pk_ybits : 0; A.ks = ks;
-        A.rank = ro->comm ? (u32)ro->comm->rank : 0; A.world = ro->comm ? (u32)ro->comm->world : 1;
-        if (!ro->comm && ctx->opt("DEBUG_OWN_SHARE")) {
-            // timing emulation of ONE rank of a world on a 1-GPU box ("world,rank"): this rank counts its share of the hash
-            // space and nobody supplies the rest, so the statistics (mid_occ) are incomplete and the results invalid
-            unsigned w_ = 1, r_ = 0;
-            if (sscanf(ctx->opt("DEBUG_OWN_SHARE"), "%u,%u", &w_, &r_) == 2 && w_ >= 1 && r_ < w_) { A.world = w_; A.rank = r_; }
-        }
+        A.rank = own_rank; A.world = own_world;
         const u32 nb = (u32)div_up(M, RF_TILE);
         ALLOC_OR_FAIL(bc_keep, sc, u32, (size_t)nb + 1); ALLOC_OR_FAIL(bc_own, sc, u32, (size_t)nb + 1); ALLOC_OR_FAIL(d_tot, sc, u32, 2);
         u32 tot[2] = {0, 0};
@@ -716,11 +789,13 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             HIPCHK(ctx, ctx->d2h(tot, d_tot, 8, ctx->stream));
             HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
         }
-        const u64 Mk = tot[0], Ms = tot[1];
+        const u64 Mk = tot[0];
+        Ms = tot[1];
         ALLOC_OR_FAIL(kx, sc, u64, Mk + 1);
         u64 *ky = nullptr;
         if (!pk) { ky = sc.get<u64>(Mk + 1); if (!ky) return LRGE_ERR_DEVICE; }
-        ALLOC_OR_FAIL(sh, sc, u64, Ms + 1);
+        sh = sc.get<u64>(Ms + 1);
+        if (!sh) return LRGE_ERR_DEVICE;
         if (nb) {
             hipLaunchKernelGGL(k_restrict_write, dim3(nb), dim3(RF_THREADS), 0, ctx->stream, A, bc_keep, bc_own, kx, ky, sh);
             KCHK(ctx);
@@ -728,6 +803,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         sc.drop(so.x); if (so.y) sc.drop(so.y);
         sc.drop(bc_keep); sc.drop(bc_own); sc.drop(d_tot);
         so.x = kx; so.y = ky; M = Mk;
+        }
         // occurrence statistics of the owned share of the hash space
         const u32 max_bin_ = (u32)P.max_mid_occ + 1;
         ALLOC_OR_FAIL(sh2, sc, u64, Ms + 1);

@@ -34,13 +34,20 @@ def _single(ctx, ds, preset, F=False):
     return Qd, Td, counts, has, st
 
 
+@pytest.mark.parametrize("form", ["fused", "sweeps", "fused-overflow"])
 @pytest.mark.parametrize("layout", ["packed", "pairs"])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
-def test_restricted_index_single_rank(ctx, tiny_ont, tiny_hifi, preset, layout, knobs):
+def test_restricted_index_single_rank(ctx, tiny_ont, tiny_hifi, preset, layout, form, knobs):
+    """form: the key-set test inside the target sketch (default), the general form (full sketch, first sort pass, filter
+    sweeps: RESTRICT_SWEEPS), and the fall-back from the first to the second when a chunk overflows its slot."""
     from lrge_amd import _ffi, engine
     ds = tiny_ont if preset == "ont" else tiny_hifi
     if layout == "pairs":
         knobs.set("NO_PACKED_INDEX", "1")
+    if form == "sweeps":
+        knobs.set("RESTRICT_SWEEPS", "1")
+    elif form == "fused-overflow":
+        knobs.set("DEBUG_SK_CAP", "9")
     Qd, Td, counts, has, st = _single(ctx, ds, PRESETS[preset])
     assert int(counts.sum()) > 0
     for hint in (False, True):

@@ -725,7 +725,8 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         }
     }
     bool fused = false; u64 *own_hashes = nullptr; u64 n_own = 0;
-    if (ro && ro->restrict_to && !ctx->opt("RESTRICT_SWEEPS")) {
+    // (measured at C4: with a world of 2 the key set is so dense that the sweeps of the general form are the faster way)
+    if (ro && ro->restrict_to && !ctx->opt("RESTRICT_SWEEPS") && (own_world >= 4 || ctx->opt("RESTRICT_FUSED"))) {
         // fast form: the key-set test inside the target sketch (needs the key set first: the main stream meets the side
         // stream here instead of after the sketch)
         rc = seqset_ready(ctx, targets);

@@ -46,8 +46,10 @@ def test_restricted_index_single_rank(ctx, tiny_ont, tiny_hifi, preset, layout, 
         knobs.set("NO_PACKED_INDEX", "1")
     if form == "sweeps":
         knobs.set("RESTRICT_SWEEPS", "1")
-    elif form == "fused-overflow":
-        knobs.set("DEBUG_SK_CAP", "9")
+    else:
+        knobs.set("RESTRICT_FUSED", "1")           # (the default picks by world size)
+        if form == "fused-overflow":
+            knobs.set("DEBUG_SK_CAP", "9")
     Qd, Td, counts, has, st = _single(ctx, ds, PRESETS[preset])
     assert int(counts.sum()) > 0
     for hint in (False, True):

@@ -63,6 +63,7 @@ struct GroupOut {
     lrge_hip_chain *chains; // optional record sink
     unsigned long long *n_chains;
     u64 chain_cap;
+    u32 rid_base;           // partitioned index: first read of the part in the whole indexed set (records carry global ids)
 };
 
 #define RFL(v) __builtin_amdgcn_readfirstlane(v)
@@ -80,6 +81,8 @@ struct CountParams {
     int t_dup;                    // the indexed set holds repeated identifiers (forward mode only)
     const u32 *q_map;             // all-vs-all over a SHARD of the reads: query index -> index of the same read in the
                                   // indexed set (null: the query set is the indexed set itself)
+    u32 rid_base;                 // all-vs-all against one PART of a partitioned index: first read of the part in the whole
+                                  // indexed set (counts are keyed by the whole set)
 };
 
 __global__ void k_count(const u64 *__restrict__ skey, const u32 *__restrict__ gstart, const u32 *__restrict__ gflags,
@@ -117,7 +120,7 @@ __global__ void k_count(const u64 *__restrict__ skey, const u32 *__restrict__ gs
     else {
         if (cp.q_rank && cp.t_rank && cp.q_rank[q] == cp.t_rank[rid]) return;  // &rid == tname: self
         atomicAdd(&counts[cp.q_map ? cp.q_map[q] : q], 1u);
-        atomicAdd(&counts[rid], 1u);
+        atomicAdd(&counts[rid + cp.rid_base], 1u);
     }
 }
 

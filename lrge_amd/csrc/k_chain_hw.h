@@ -137,7 +137,7 @@ __device__ __noinline__ u32 backtrack_group(const u64 *gk, const u64 *gv, u64 *g
                 unsigned long long slot = atomicAdd(out.n_chains, 1ULL);
                 if (slot < out.chain_cap) {
                     lrge_hip_chain c;
-                    c.query = qid; c.target = rid; c.rev = (i32)rev; c.score = sc; c.cnt = cnt;
+                    c.query = qid; c.target = rid + out.rid_base; c.rev = (i32)rev; c.score = sc; c.cnt = cnt;
                     c.qs = qs; c.qe = qe; c.rs = rs; c.re = re; c.mlen = mlen; c.blen = blen;
                     {   // entries of minimap2's mini_pos[] spanned by the chain (kept-seed ranks ride in the anchor values)
                         const i32 r0 = (i32)(vf >> AVAL_RANK_SHIFT), r1 = (i32)(vt >> AVAL_RANK_SHIFT);

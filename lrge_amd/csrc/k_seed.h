@@ -261,6 +261,16 @@ __global__ void k_qocc_mark(const u64 *__restrict__ sx, const u64 *__restrict__ 
         for (u64 t = i; t < j; ++t) hc[(u32)sv[t]] = 0;
 }
 
+// Partitioned index: a query minimizer's occurrence count over all parts.  A key that is too frequent globally carries
+// mid_occ + 1 in every part that holds it (k_part_drop), all other local counts add up to the global one, so the clamped sum
+// tells kept (0 < n <= mid_occ) from repetitive (n > mid_occ) exactly as the one index would.
+__global__ void k_hc_accumulate(const u32 *__restrict__ hc, u64 n, u32 mid_occ, u32 *__restrict__ acc) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 s = (u64)acc[i] + hc[i];
+    acc[i] = s > mid_occ ? mid_occ + 1 : (u32)s;
+}
+
 // Per-query PAF statistics (mm2:seed.c mm_collect_matches, mm2:esterr.c mm_est_err): rep_len = length of
 // the query covered by filtered (n > mid_occ) seeds, sum_span / n_kept -> avg_k of the kept seeds.
 __global__ void k_query_paf_stats(const u64 *__restrict__ qx, const u64 *__restrict__ qy, const u32 *__restrict__ hc,

@@ -1204,6 +1204,10 @@ struct OverlapJob {
     bool dump_anchors = false; u32 dump_query = 0; u64 *ax = nullptr, *ay = nullptr; u64 acap = 0; u64 *an = nullptr;
     // per-query PAF statistics instead of chaining
     bool paf_stats = false; i32 *rep_len = nullptr; u64 *sum_span = nullptr; u32 *n_kept = nullptr;
+    // one part of a partitioned index (the entry points loop over the parts)
+    u32 rid_base = 0;                                   // first read of the part in the whole indexed set
+    const lrge_hip_seqset *indexed_top = nullptr;       // all-vs-all: the whole indexed set (counts are keyed by it)
+    u32 *d_hc_acc = nullptr; bool hc_last = true;       // paf_stats: occurrence counts accumulated over the parts (device)
 };
 
 
@@ -1274,12 +1278,14 @@ struct OverlapRun {
 int OverlapRun::prepare() {
     const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
     (void)T; (void)P; (void)nq; (void)nt;
-    n_out = job.mode == MODE_TWOSET ? nq : nt;
-    if (job.mode == MODE_AVA && Q != T) {
+    const lrge_hip_seqset *I = (job.mode == MODE_AVA && job.indexed_top) ? job.indexed_top : T;   // what the counts are keyed by
+    n_out = job.mode == MODE_TWOSET ? nq : (job.mode == MODE_AVA ? I->n : nt);
+    if (job.mode == MODE_AVA && Q != I) {
         // a shard of the reads as queries: counts stay keyed by indexed read, so every query needs the index of the
         // read with the same name (= the same rank) in the indexed set
-        std::vector<std::pair<u32, u32>> byrank(nt);
-        for (u32 i = 0; i < nt; ++i) byrank[i] = {T->h_rank[i], i};
+        const u32 ni = I->n;
+        std::vector<std::pair<u32, u32>> byrank(ni);
+        for (u32 i = 0; i < ni; ++i) byrank[i] = {I->h_rank[i], i};
         std::sort(byrank.begin(), byrank.end());
         std::vector<u32> qm(nq);
         for (u32 q = 0; q < nq; ++q) {
@@ -1440,8 +1446,14 @@ int OverlapRun::seeds() {
             HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
             if (qf) { rc = run_exact_qocc(); if (rc) return rc; }
         }
+        const u32 *hc_stats = hc;
+        if (job.d_hc_acc) {      // one part of a partitioned index: the statistics need the counts over all parts
+            if (Mq) { hipLaunchKernelGGL(k_hc_accumulate, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hc, Mq, (u32)ix->mid_occ, job.d_hc_acc); KCHK(ctx); }
+            if (!job.hc_last) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return RUN_DONE; }
+            hc_stats = job.d_hc_acc;
+        }
         ALLOC_OR_FAIL(d_rl, sc, i32, (size_t)nq); ALLOC_OR_FAIL(d_ss, sc, u64, (size_t)nq); ALLOC_OR_FAIL(d_nk, sc, u32, (size_t)nq);
-        hipLaunchKernelGGL(k_query_paf_stats, dim3((u32)div_up(nq, 64)), dim3(64), 0, ctx->stream, so.x, so.y, hc, so.mz_off, nq, ix->mid_occ,
+        hipLaunchKernelGGL(k_query_paf_stats, dim3((u32)div_up(nq, 64)), dim3(64), 0, ctx->stream, so.x, so.y, hc_stats, so.mz_off, nq, ix->mid_occ,
                            d_rl, d_ss, d_nk);
         KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(job.rep_len, d_rl, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1724,7 +1736,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
     }
     ctx->counters[LRGE_C_GROUPS] += G;
     {
-        GroupOut go; go.flags = gflags; go.chains = d_chains; go.n_chains = d_nchains; go.chain_cap = job.chain_cap;
+        GroupOut go; go.flags = gflags; go.chains = d_chains; go.n_chains = d_nchains; go.chain_cap = job.chain_cap; go.rid_base = job.rid_base;
         {
             if (n_chained) {
                 StageTimer t(ctx, LRGE_T_CHAIN);
@@ -1805,7 +1817,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
         CountParams cnp; cnp.kl = kl; cnp.q0 = q0; cnp.mode = job.mode;
         cnp.q_rank = Q->has_rank ? Q->d_rank : nullptr; cnp.t_rank = T->has_rank ? T->d_rank : nullptr;
         cnp.t_dup = T->dup_rank ? 1 : 0;
-        cnp.q_map = d_qmap;
+        cnp.q_map = d_qmap; cnp.rid_base = job.rid_base;
         hipLaunchKernelGGL(k_count, dim3((u32)div_up(G, 256)), dim3(256), 0, ctx->stream, skey, gstart, gflags, G, cnp, d_counts, d_hasmap);
         KCHK(ctx);
         // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
@@ -1887,7 +1899,7 @@ static int check_common(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_
         return LRGE_ERR_INVALID;
     }
     if (!ix->parts.empty() && !parts_ok) {
-        LRGE_SET_ERR(ctx, "the index is partitioned (%zu parts, target set above LRGE_HIP_PART_BASES): only lrge_hip_overlap_twoset is implemented for it", ix->parts.size());
+        LRGE_SET_ERR(ctx, "the index is partitioned (%zu parts, target set above PART_BASES bases): this entry point is not implemented for it", ix->parts.size());
         return LRGE_ERR_TOO_MANY;
     }
     return LRGE_OK;
@@ -1972,24 +1984,24 @@ extern "C" int lrge_hip_overlap_twoset(lrge_hip_ctx *ctx, const lrge_hip_index *
     return LRGE_OK;
 }
 
-extern "C" int lrge_hip_overlap_inverse(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *streamed,
-                                        const lrge_hip_params *p, uint32_t *counts) {
-    int rc = check_common(ctx, ix, streamed);
-    if (rc) return rc;
-    if (ix->seqs->dup_rank) { LRGE_SET_ERR(ctx, "Duplicate read identifier in the indexed set"); return LRGE_ERR_DUPLICATE_ID; }
-    OverlapJob job; job.mode = MODE_INVERSE; job.dual = 1;
-    job.prm = p ? *p : lrge_hip_params{0, 0.2f};
-    job.counts = counts;
-    if (streamed->total_bases <= stream_limit(ctx) || streamed->n < 2) return run_overlap(ctx, ix, streamed, job);
+// inverse against one (unpartitioned) index, the streamed set in views if it is too large; counts has ix->seqs->n entries
+static int inverse_one_index(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *streamed, const OverlapJob &job, uint32_t *counts,
+                             StageAcc &acc) {
+    if (streamed->total_bases <= stream_limit(ctx) || streamed->n < 2) {
+        OverlapJob j = job;
+        j.counts = counts;
+        int rc = run_overlap(ctx, ix, streamed, j);
+        acc.add(ctx);
+        return rc;
+    }
     // the streamed (target) set in views: every streamed read adds one to the indexed reads it hits (twoset.rs:520-523)
     const u32 n_ix = ix->seqs->n;
     std::vector<u32> c((size_t)n_ix + 1);
     if (counts) std::fill(counts, counts + n_ix, 0u);
-    StageAcc acc;
     const std::vector<u32> cuts = stream_cuts(streamed);
     for (size_t v = 0; v + 1 < cuts.size(); ++v) {
         lrge_hip_seqset *view = nullptr;
-        rc = seqset_view(ctx, streamed, cuts[v], cuts[v + 1], &view);
+        int rc = seqset_view(ctx, streamed, cuts[v], cuts[v + 1], &view);
         if (rc) return rc;
         OverlapJob j = job;
         j.counts = c.data();
@@ -1999,13 +2011,35 @@ extern "C" int lrge_hip_overlap_inverse(lrge_hip_ctx *ctx, const lrge_hip_index 
         if (rc) return rc;
         if (counts) for (u32 i = 0; i < n_ix; ++i) counts[i] += c[i];
     }
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_overlap_inverse(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *streamed,
+                                        const lrge_hip_params *p, uint32_t *counts) {
+    int rc = check_common(ctx, ix, streamed, /*parts_ok=*/true);
+    if (rc) return rc;
+    if (ix->seqs->dup_rank) { LRGE_SET_ERR(ctx, "Duplicate read identifier in the indexed set"); return LRGE_ERR_DUPLICATE_ID; }
+    OverlapJob job; job.mode = MODE_INVERSE; job.dual = 1;
+    job.prm = p ? *p : lrge_hip_params{0, 0.2f};
+    StageAcc acc;
+    if (ix->parts.empty()) {
+        rc = inverse_one_index(ctx, ix, streamed, job, counts, acc);
+        acc.store(ctx);
+        return rc;
+    }
+    // partitioned index: the parts hold disjoint indexed reads, every part sees all streamed reads and the global mid_occ --
+    // a part's counts are the counts of its reads
+    for (size_t pi = 0; pi < ix->parts.size(); ++pi) {
+        rc = inverse_one_index(ctx, ix->parts[pi], streamed, job, counts ? counts + ix->part_r0[pi] : nullptr, acc);
+        if (rc) return rc;
+    }
     acc.store(ctx);
     return LRGE_OK;
 }
 
 extern "C" int lrge_hip_overlap_ava(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *reads,
                                     const lrge_hip_params *p, uint32_t *counts) {
-    int rc = check_common(ctx, ix, reads);
+    int rc = check_common(ctx, ix, reads, /*parts_ok=*/true);
     if (rc) return rc;
     if (ix->seqs != reads && !(ix->seqs->has_rank && reads->has_rank)) {
         LRGE_SET_ERR(ctx, "all-vs-all over a shard of the reads needs name ranks on both sets"); return LRGE_ERR_INVALID;
@@ -2014,30 +2048,80 @@ extern "C" int lrge_hip_overlap_ava(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
     OverlapJob job; job.mode = MODE_AVA; job.dual = 0;
     job.prm = p ? *p : lrge_hip_params{0, 0.2f};
     job.counts = counts;
-    return run_overlap(ctx, ix, reads, job);
+    if (ix->parts.empty()) return run_overlap(ctx, ix, reads, job);
+    // partitioned index: every part sees all reads as queries; a pair is found in the part that holds its larger-named
+    // read (NO_DUAL), and both of its counts live in the one vector keyed by the whole set
+    if (!(ix->seqs->has_rank && reads->has_rank)) { LRGE_SET_ERR(ctx, "all-vs-all against a partitioned index needs name ranks"); return LRGE_ERR_INVALID; }
+    if (reads->total_bases > stream_limit(ctx)) { LRGE_SET_ERR(ctx, "all-vs-all: read sets above STREAM_BASES bases are not implemented"); return LRGE_ERR_TOO_MANY; }
+    const u32 n_all = ix->seqs->n;
+    std::vector<u32> c((size_t)n_all + 1);
+    if (counts) std::fill(counts, counts + n_all, 0u);
+    StageAcc acc;
+    for (size_t pi = 0; pi < ix->parts.size(); ++pi) {
+        OverlapJob j = job;
+        j.counts = c.data(); j.rid_base = ix->part_r0[pi]; j.indexed_top = ix->seqs;
+        rc = run_overlap(ctx, ix->parts[pi], reads, j);
+        acc.add(ctx);
+        if (rc) return rc;
+        if (counts) for (u32 i = 0; i < n_all; ++i) counts[i] += c[i];
+    }
+    acc.store(ctx);
+    return LRGE_OK;
 }
 
 extern "C" int lrge_hip_chains(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries, int dual,
                                lrge_hip_chain *out, uint64_t cap, uint64_t *n_out) {
-    int rc = check_common(ctx, ix, queries);
+    int rc = check_common(ctx, ix, queries, /*parts_ok=*/true);
     if (rc) return rc;
     if (!n_out) return LRGE_ERR_INVALID;
     OverlapJob job; job.mode = MODE_TWOSET; job.dual = dual ? 1 : 0;
     job.prm = lrge_hip_params{0, 0.2f};
-    job.chains = out; job.chain_cap = out ? cap : 0; job.n_chains = n_out;
-    return run_overlap(ctx, ix, queries, job);
+    if (ix->parts.empty()) {
+        job.chains = out; job.chain_cap = out ? cap : 0; job.n_chains = n_out;
+        return run_overlap(ctx, ix, queries, job);
+    }
+    // partitioned index: the chains of a query onto the reads of one part are found in that part; records carry the
+    // read's index in the whole set (rid_base)
+    u64 total = 0;
+    StageAcc acc;
+    for (size_t pi = 0; pi < ix->parts.size(); ++pi) {
+        OverlapJob j = job;
+        u64 n_part = 0;
+        const u64 room = (out && cap > total) ? cap - total : 0;
+        j.chains = room ? out + total : nullptr; j.chain_cap = room; j.n_chains = &n_part; j.rid_base = ix->part_r0[pi];
+        rc = run_overlap(ctx, ix->parts[pi], queries, j);
+        acc.add(ctx);
+        if (rc) return rc;
+        total += n_part;
+    }
+    acc.store(ctx);
+    *n_out = total;
+    return LRGE_OK;
 }
 
 extern "C" int lrge_hip_paf_stats(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries, int32_t *rep_len,
                                   uint64_t *sum_span, uint32_t *n_kept) {
-    int rc = check_common(ctx, ix, queries);
+    int rc = check_common(ctx, ix, queries, /*parts_ok=*/true);
     if (rc) return rc;
     if (!rep_len || !sum_span || !n_kept) return LRGE_ERR_INVALID;
     OverlapJob job; job.mode = MODE_TWOSET; job.dual = 1;
     job.prm = lrge_hip_params{0, 0.2f};
     job.paf_stats = true; job.rep_len = rep_len; job.sum_span = sum_span; job.n_kept = n_kept;
     if (queries->n == 0) return LRGE_OK;
-    return run_overlap(ctx, ix, queries, job);
+    if (ix->parts.empty()) return run_overlap(ctx, ix, queries, job);
+    // partitioned index: a seed is kept / repetitive by its occurrence count over ALL parts (k_hc_accumulate); the last
+    // part's pass turns the accumulated counts into rl / avg_k
+    if (queries->total_bases + 1 >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "paf_stats against a partitioned index: query set too large"); return LRGE_ERR_TOO_MANY; }
+    Scratch sc(ctx);
+    ALLOC_OR_FAIL(d_acc, sc, u32, (size_t)queries->total_bases + 1);      // (one minimizer per base at most)
+    HIPCHK(ctx, hipMemsetAsync(d_acc, 0, ((size_t)queries->total_bases + 1) * 4, ctx->stream));
+    for (size_t pi = 0; pi < ix->parts.size(); ++pi) {
+        OverlapJob j = job;
+        j.d_hc_acc = d_acc; j.hc_last = pi + 1 == ix->parts.size();
+        rc = run_overlap(ctx, ix->parts[pi], queries, j);
+        if (rc) return rc;
+    }
+    return LRGE_OK;
 }
 
 extern "C" int lrge_hip_anchors_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_hip_seqset *queries, int dual,

@@ -646,8 +646,12 @@ def test_partitioned_index_is_exact(ctx, oracle, tiny_ont, tiny_hifi, data, pres
     for F in (False, True):
         ref[F] = ix.overlap_twoset(Qd, remove_internal=F)
         ref_anchors[F] = ctx.counters()["anchors"]
+    ref_inv = ix.overlap_inverse(Qd)
+    ref_ava = ix.overlap_ava()
+    ref_chains = _chain_rows(ix.chains(Qd, dual=True), ["query", "target", "rev", "score", "cnt", "qs", "qe", "rs", "re", "mlen", "blen", "n_seeds"])
+    ref_paf = ix.paf_stats(Qd)
     ix.free()
-    assert int(ref[False][0].sum()) > 0
+    assert int(ref[False][0].sum()) > 0 and int(ref_inv.sum()) > 0 and int(ref_ava.sum()) > 0 and len(ref_chains) > 0
     if data == "repeats":
         assert ref_stats["mid_occ"] > 10
     total = int(ds.t.lens().sum())
@@ -665,8 +669,16 @@ def test_partitioned_index_is_exact(ctx, oracle, tiny_ont, tiny_hifi, data, pres
             counts, has = ixp.overlap_twoset(Qd, remove_internal=F)
             assert ctx.counters()["anchors"] == ref_anchors[F], (n_parts, F)
             assert np.array_equal(counts, ref[F][0]) and np.array_equal(has, ref[F][1]), (n_parts, F)
-        with pytest.raises(_ffi.LrgeHipError):                   # the other entry points say so instead of guessing
-            ixp.overlap_inverse(Qd)
+        # the other entry points against the parts: inverse counts (keyed by indexed read), all-vs-all over the indexed
+        # set itself (symmetric counts, both reads of a pair possibly in different parts), chain records with global
+        # target ids, and the per-query seed statistics (rl / avg_k: occurrence counts over all parts)
+        assert np.array_equal(ixp.overlap_inverse(Qd), ref_inv), n_parts
+        if n_parts in (2, 7):
+            assert np.array_equal(ixp.overlap_ava(), ref_ava), n_parts
+            got = _chain_rows(ixp.chains(Qd, dual=True), ["query", "target", "rev", "score", "cnt", "qs", "qe", "rs", "re", "mlen", "blen", "n_seeds"])
+            assert np.array_equal(got, ref_chains), n_parts
+            for a, b in zip(ixp.paf_stats(Qd), ref_paf):
+                assert np.array_equal(a, b), n_parts
         ixp.free()
     # the oracle agrees with the single index (and hence with the parts)
     opt = oracle.make_opt(oracle.PRESET_AVA_PB if preset == "pb" else oracle.PRESET_AVA_ONT, dual=True)

@@ -221,6 +221,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 n_skip = brk ? 0u : n_skip;
                 marks |= (valid ? WO[k] : 0u) << (k + 1);
             }
+            // every live lane's loop has stopped (max_skip break) -- in the long tail of the kernel, where a wavefront
+            // holds one or two unfinished groups, that is the usual case after 16 or 24 candidates: the remaining
+            // blocks would change nothing (min(S, lim) is invalid for all of them)
+            if (FASTREACH && kb + LPG_B < LPG_W && __ballot(lim == INT32_MAX) == 0) break;
         }
         i32 max_j = max_k < 0 ? -1 : i - 1 - max_k;
         const i32 end_b = end_k < 0 ? -1 : i - 1 - end_k;

@@ -125,10 +125,12 @@ __device__ __forceinline__ u32 rf_flags(const RestrictArgs &A, u64 tile_base, u6
     return f;
 }
 
-__global__ __launch_bounds__(RF_THREADS) void k_restrict_count(RestrictArgs A, u32 *__restrict__ bc_keep, u32 *__restrict__ bc_own) {
+__global__ __launch_bounds__(RF_THREADS) void k_restrict_count(RestrictArgs A, u32 *__restrict__ bc_keep, u32 *__restrict__ bc_own,
+                                                               u32 *__restrict__ flags) {
     __shared__ u32 wk[RF_THREADS / 64], wo[RF_THREADS / 64];
     u64 xs[RF_ITEMS];
     const u32 f = rf_flags(A, (u64)blockIdx.x * RF_TILE, xs);
+    flags[(u64)blockIdx.x * RF_THREADS + threadIdx.x] = f;      // the write sweep does not probe the key set again
     u32 ck = (u32)__popc(f & 0xffffu), co = (u32)__popc(f >> 16);
     for (int d = 32; d > 0; d >>= 1) { ck += __shfl_down(ck, d, 64); co += __shfl_down(co, d, 64); }
     if (lane_id() == 0) { wk[threadIdx.x >> 6] = ck; wo[threadIdx.x >> 6] = co; }
@@ -141,11 +143,17 @@ __global__ __launch_bounds__(RF_THREADS) void k_restrict_count(RestrictArgs A, u
 }
 
 __global__ __launch_bounds__(RF_THREADS) void k_restrict_write(RestrictArgs A, const u32 *__restrict__ off_keep, const u32 *__restrict__ off_own,
-                                                               u64 *__restrict__ out_x, u64 *__restrict__ out_y, u64 *__restrict__ out_hash) {
+                                                               const u32 *__restrict__ flags, u64 *__restrict__ out_x, u64 *__restrict__ out_y,
+                                                               u64 *__restrict__ out_hash) {
     __shared__ u32 ck[RF_ITEMS][RF_THREADS / 64], co[RF_ITEMS][RF_THREADS / 64];
     const u64 tile_base = (u64)blockIdx.x * RF_TILE;
     u64 xs[RF_ITEMS];
-    const u32 f = rf_flags(A, tile_base, xs);
+    const u32 f = flags[(u64)blockIdx.x * RF_THREADS + threadIdx.x];
+#pragma unroll
+    for (int r = 0; r < RF_ITEMS; ++r) {
+        const u64 i = tile_base + (u64)r * RF_THREADS + threadIdx.x;
+        xs[r] = i < A.n ? A.x[i] : 0;
+    }
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     u32 pk[RF_ITEMS], po[RF_ITEMS];          // my rank inside my (row, wave)
 #pragma unroll

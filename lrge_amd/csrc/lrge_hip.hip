@@ -781,9 +781,10 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         A.rank = own_rank; A.world = own_world;
         const u32 nb = (u32)div_up(M, RF_TILE);
         ALLOC_OR_FAIL(bc_keep, sc, u32, (size_t)nb + 1); ALLOC_OR_FAIL(bc_own, sc, u32, (size_t)nb + 1); ALLOC_OR_FAIL(d_tot, sc, u32, 2);
+        ALLOC_OR_FAIL(d_flags, sc, u32, (size_t)nb * RF_THREADS + 1);
         u32 tot[2] = {0, 0};
         if (nb) {
-            hipLaunchKernelGGL(k_restrict_count, dim3(nb), dim3(RF_THREADS), 0, ctx->stream, A, bc_keep, bc_own);
+            hipLaunchKernelGGL(k_restrict_count, dim3(nb), dim3(RF_THREADS), 0, ctx->stream, A, bc_keep, bc_own, d_flags);
             KCHK(ctx);
             rc = scan_exclusive_u32(ctx, sc, bc_keep, bc_keep, nb, d_tot); if (rc) return rc;
             rc = scan_exclusive_u32(ctx, sc, bc_own, bc_own, nb, d_tot + 1); if (rc) return rc;
@@ -798,11 +799,11 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         sh = sc.get<u64>(Ms + 1);
         if (!sh) return LRGE_ERR_DEVICE;
         if (nb) {
-            hipLaunchKernelGGL(k_restrict_write, dim3(nb), dim3(RF_THREADS), 0, ctx->stream, A, bc_keep, bc_own, kx, ky, sh);
+            hipLaunchKernelGGL(k_restrict_write, dim3(nb), dim3(RF_THREADS), 0, ctx->stream, A, bc_keep, bc_own, d_flags, kx, ky, sh);
             KCHK(ctx);
         }
         sc.drop(so.x); if (so.y) sc.drop(so.y);
-        sc.drop(bc_keep); sc.drop(bc_own); sc.drop(d_tot);
+        sc.drop(bc_keep); sc.drop(bc_own); sc.drop(d_tot); sc.drop(d_flags);
         so.x = kx; so.y = ky; M = Mk;
         }
         // occurrence statistics of the owned share of the hash space

@@ -227,6 +227,9 @@ def load(source):
         names, seqs = [], []
         for n, s in iter_records(source):
             names.append(n); seqs.append(s)
+        if not names:                                   # count_records, io.rs:140-145
+            from .estimate import LrgeError
+            raise LrgeError("IoError", "Is the file empty?")
         return names, seqs
     if hasattr(source, "seqs"):
         return list(source.names), source.seqs()

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <cmath>
 #include <iostream>
 
 #include "../include/lrge_hip.hpp"
@@ -19,7 +20,34 @@ static lrge::Reads load_reads(const std::string &path) {   // io.rs:154-184 via 
     } catch (const lrge::io::IoError &e) {
         throw lrge::LrgeError(LRGE_ERR_IO, e.what());
     }
+    if (r.names.empty()) throw lrge::LrgeError(LRGE_ERR_IO, "IO error: Is the file empty?");   // count_records, io.rs:140-145
     return r;
+}
+
+// Rust's `{}` for an f32 (main.rs:107): the shortest decimal digits that read back as the same f32, written positionally
+// (never with an exponent).
+static std::string display_f32(float v) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    char buf[64];
+    int prec = 0;
+    for (; prec < 9; ++prec) {
+        snprintf(buf, sizeof buf, "%.*e", prec, (double)v);
+        if (strtof(buf, nullptr) == v) break;
+    }
+    snprintf(buf, sizeof buf, "%.*e", prec, (double)v);
+    std::string m(buf);
+    const size_t epos = m.find('e');
+    const int ex = atoi(m.c_str() + epos + 1);
+    std::string digits; bool neg = false;
+    for (size_t i = 0; i < epos; ++i) { if (m[i] == '-') neg = true; else if (m[i] != '.') digits += m[i]; }
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();      // 1.50e3 -> "15", exponent 3
+    std::string out;
+    if (ex >= 0) {
+        if ((int)digits.size() <= ex + 1) out = digits + std::string((size_t)(ex + 1 - (int)digits.size()), '0');
+        else out = digits.substr(0, (size_t)ex + 1) + "." + digits.substr((size_t)ex + 1);
+    } else out = "0." + std::string((size_t)(-ex - 1), '0') + digits;
+    return (neg ? "-" : "") + out;
 }
 
 int main(int argc, char **argv) {
@@ -101,7 +129,7 @@ int main(int argc, char **argv) {
         }
         FILE *out = output == "-" ? stdout : fopen(output.c_str(), "w");
         if (!out) { fprintf(stderr, "Error: Failed to create output file\n"); return 1; }
-        if (precise) fprintf(out, "%.9g\n", (double)*r.estimate); else fprintf(out, "%.0f\n", (double)*r.estimate);
+        if (precise) fprintf(out, "%s\n", display_f32(*r.estimate).c_str()); else fprintf(out, "%.0f\n", (double)*r.estimate);
         if (out != stdout) fclose(out);
         if (info) fprintf(stderr, "[INFO] Done!\n");
     } catch (const lrge::io::IoError &e) {

@@ -114,14 +114,29 @@ def main():
     Qn, Tn = q.n, t.n
 
     ctx = engine.Context(local_rank)
-    comm = None
+    comm, transport = None, None
     if use_dist:
         # torch.distributed only bootstraps (TCP store over gloo): the data-path collectives are the library's own RCCL
         # communicator behind the C ABI (lrge_hip_comm_*), created from a unique id that rank 0 hands out
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        comm = parallel.RcclComm.bootstrap(ctx, rank, world, dist)
+        transport = "rccl"
+        try:
+            if os.environ.get("LRGE_BENCH_TRANSPORT") == "host":
+                raise RuntimeError("host transport requested")
+            comm = parallel.RcclComm.bootstrap(ctx, rank, world, dist)
+        except Exception as e:      # noqa: BLE001 -- the collectives then travel over gloo on host buffers (say so in the line)
+            transport = "host (gloo) -- RCCL communicator not created: %s" % str(e)[:200]
+            comm = None
+        # every rank must agree on the transport
+        flag = torch.tensor([1 if comm is not None else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+                transport = "host (gloo) -- another rank could not create its RCCL communicator"
+            comm = parallel.HostComm(ctx, dist)
 
     qr, tr = engine.name_ranks(q.names, t.names)
     emu = None
@@ -130,15 +145,24 @@ def main():
         assert world == 1 and 0 <= er < en
         emu = (er, en)
         ctx.set_option("DEBUG_OWN_SHARE", "%d,%d" % (en, er))
-    bounds = parallel.shard_by_bases(q.lens(), emu[1] if emu else world)   # strong scaling: this rank's contiguous query range
-    lo, hi = (bounds[emu[0]], bounds[emu[0] + 1]) if emu else (bounds[rank], bounds[rank + 1])
-    qs = q if (world == 1 and not emu) else q.slice(lo, hi)
-    qs_rank = qr[lo:hi]
+    n_shards = emu[1] if emu else world
+    my = emu[0] if emu else rank
+    # strong scaling: the STREAMED set is cut into contiguous ranges with equal base counts -- the queries in the forward
+    # strategy (twoset.rs:266-334), the targets with --inverse (--use-min-ref, twoset.rs:485-565)
+    bounds = parallel.shard_by_bases(t.lens() if a.inverse else q.lens(), n_shards)
+    lo, hi = bounds[my], bounds[my + 1]
+    if a.inverse:
+        qs, qs_rank = q, qr                                      # indexed set: every rank holds all of it
+        ts, ts_rank = (t, tr) if n_shards == 1 else (t.slice(lo, hi), tr[lo:hi])
+    else:
+        qs, qs_rank = (q, qr) if n_shards == 1 else (q.slice(lo, hi), qr[lo:hi])
+        ts, ts_rank = t, tr
     avg_t = np.float32(t.lens().sum()) / np.float32(t.n)
-    max_shard = max(bounds[i + 1] - bounds[i] for i in range(len(bounds) - 1))
+    shard_lens = [bounds[i + 1] - bounds[i] for i in range(n_shards)]
+    max_shard = max(shard_lens)
 
     # the two homes of the ASCII reads: HBM (value) and pinned host memory (from_host)
-    d_q = torch.from_numpy(qs.bases).cuda(); d_t = torch.from_numpy(t.bases).cuda()
+    d_q = torch.from_numpy(qs.bases).cuda(); d_t = torch.from_numpy(ts.bases).cuda()
     torch.cuda.synchronize()
 
     def sync_all():
@@ -149,22 +173,35 @@ def main():
 
     def step(src_q, src_t):
         """src_*: int device pointer (ASCII resident in HBM) or PinnedBuffer (ASCII in pinned host memory)."""
-        if a.inverse:      # index = this rank's ... the whole query set; the streamed targets are what is sharded
-            raise SystemExit("--inverse: use tools/run_config.py (bench.py times the forward strategy)")
-        Td = ctx.upload(src_t, t.offsets, tr, wait=False)          # K0 pack (and PCIe, from the host) on the copy stream
-        Qd = ctx.upload(src_q, qs.offsets, qs_rank, wait=False)    # travels / packs while the index is built
-        if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
-            Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
-        ix = engine.Index(ctx, Td, preset, streamed=Qd if comm is not None or emu or os.environ.get("LRGE_BENCH_RESTRICT") else None, comm=comm)
-        tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
-        counts, has = ix.overlap_twoset(Qd)
-        tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
-        est = ctx.estimates(counts, qs.lens(), float(avg_t), t.n, 100)
-        ix.free(); Qd.free(); Td.free()
-        if comm is not None:    # the one collective that closes the step: per-read estimate vectors over RCCL/xGMI
-            est_all = comm.all_gather_f32(est, max_shard, [bounds[i + 1] - bounds[i] for i in range(world)])
+        if a.inverse:
+            # index = the query set (small), the streamed targets of this rank travel / pack while it is built
+            Qd = ctx.upload(src_q, qs.offsets, qs_rank, wait=False)
+            Td = ctx.upload(src_t, ts.offsets, ts_rank, wait=False)
+            if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
+                Td.presketch(preset)
+            ix = engine.Index(ctx, Qd, preset)
+            tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
+            counts = ix.overlap_inverse(Td)
+            tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
+            ix.free(); Qd.free(); Td.free()
+            if comm is not None:    # the one collective that closes the step: count vector keyed by indexed read (twoset.rs:520-523)
+                counts = comm.all_reduce_u32(counts)
+            est_all = ctx.estimates(counts, q.lens(), float(avg_t), t.n, 100)
         else:
-            est_all = est
+            Td = ctx.upload(src_t, ts.offsets, ts_rank, wait=False)      # K0 pack (and PCIe, from the host) on the copy stream
+            Qd = ctx.upload(src_q, qs.offsets, qs_rank, wait=False)      # travels / packs while the index is built
+            if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
+                Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
+            ix = engine.Index(ctx, Td, preset, streamed=Qd if comm is not None or emu or os.environ.get("LRGE_BENCH_RESTRICT") else None, comm=comm)
+            tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
+            counts, has = ix.overlap_twoset(Qd)
+            tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
+            est = ctx.estimates(counts, qs.lens(), float(avg_t), t.n, 100)
+            ix.free(); Qd.free(); Td.free()
+            if comm is not None:    # the one collective that closes the step: per-read estimate vectors over RCCL/xGMI
+                est_all = comm.all_gather_f32(est, max_shard, shard_lens)
+            else:
+                est_all = est
         med = engine.median(est_all, True, 0.15, 0.65)
         for k_ in ("rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes"):   # the index build sorts too
             cn[k_] = cn.get(k_, 0) + cb_.get(k_, 0)
@@ -200,14 +237,14 @@ def main():
 
     from_host = None
     if not a.no_from_host and not emu:
-        hq = ctx.host_alloc(max(qs.bases.size, 1)); ht = ctx.host_alloc(max(t.bases.size, 1))
-        hq.array[:qs.bases.size] = qs.bases; ht.array[:t.bases.size] = t.bases
+        hq = ctx.host_alloc(max(qs.bases.size, 1)); ht = ctx.host_alloc(max(ts.bases.size, 1))
+        hq.array[:qs.bases.size] = qs.bases; ht.array[:ts.bases.size] = ts.bases
         k2 = max(3, a.steps // 2)
         e2, _, _, _, last2 = timed(hq, ht, 1, k2)
         from_host = {"ms_per_step": e2 * 1e3 / k2, "value": Qn * k2 / e2, "unit": "reads/s", "steps": k2,
                      "what": "same step with the ASCII reads in pinned host memory when the clock starts: %.2f GB over PCIe "
                              "inside the timed region, on the copy stream (queries travel while the target index is built)"
-                             % ((qs.bases.size + t.bases.size) / 1e9),
+                             % ((qs.bases.size + ts.bases.size) / 1e9),
                      "counts_equal_resident_run": bool(np.array_equal(last2[0], counts))}
         hq.free(); ht.free()
 
@@ -251,9 +288,10 @@ def main():
                     float(cn2.get("rs_scatter_bytes", 0)) * K, "bytes each launch has to read + write (32 / pair, 16 / packed key, 24 unpacking)")
         r_sc["measured"] = "one instrumented step after the timed region (event pair around every launch)"
         # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
-        L = float(q.lens().sum()); M = acc_cn.get("query_minimizers", 0) / K; H = acc_cn.get("anchors", 0) / K
+        # (streamed set: the queries, or the targets with --inverse; for N > 1 rank 0's counters times the world size)
+        L = float((t if a.inverse else q).lens().sum()); M = world * acc_cn.get("query_minimizers", 0) / K; H = world * acc_cn.get("anchors", 0) / K
         B_q = L / 4 + 32 * M + 8 * H + 32 * H + 4 * Qn
-        B_idx = float(t.lens().sum()) / 4 + 16 * st["n_minimizers"]
+        B_idx = float((q if a.inverse else t).lens().sum()) / 4 + 16 * st["n_minimizers"]
         e2e_gbps = (B_q + B_idx) / (ms_per_step * 1e-3) / 1e9
         r_dom = cands[0] if cands else r_sc
         out = {
@@ -261,12 +299,15 @@ def main():
             "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 keys / i32 chain scores / f32 gap penalty", "data": "synthetic",
-            "config": {"workload": "%s: %.1f Mbp genome, %s reads, two-set forward -Q %d -T %d, preset %s, dual=yes; ASCII reads "
+            "config": {"workload": "%s: %.1f Mbp genome, %s reads, two-set %s -Q %d -T %d, preset %s, dual=yes; ASCII reads "
                                    "resident in HBM, 2-bit pack inside the step"
-                                   % (a.config, gsize / 1e6, cfg["platform"], Qn, Tn, "ava-pb" if preset else "ava-ont"),
+                                   % (a.config, gsize / 1e6, cfg["platform"], "--use-min-ref (index = queries, targets streamed)" if a.inverse else "forward",
+                                      Qn, Tn, "ava-pb" if preset else "ava-ont"),
                        "query_reads": Qn, "target_reads": Tn,
-                       "parallelism": "one job, queries cut into %d ranges by bases; index %s" %
-                                      (world, "restricted to each rank's query minimizers, global occurrence statistics by one all-reduce" if world > 1 else "over all targets"),
+                       "parallelism": ("one job, streamed targets cut into %d ranges by bases; query index replicated; counts all-reduced" % world) if a.inverse else
+                                      ("one job, queries cut into %d ranges by bases; index %s" %
+                                       (world, "restricted to each rank's query minimizers, global occurrence statistics by one all-reduce" if world > 1 else "over all targets")),
+                       "collectives": transport if use_dist else None,
                        "scale": a.scale, "data_gen_s": round(t_gen, 1)},
             "from_host": from_host,
             "genome_size_true": gsize,
@@ -280,7 +321,7 @@ def main():
                                   **{k: v / K for k, v in acc_tm.items() if v}},
             "work_per_step": {k: (v if k == "lpg_split" else v / K) for k, v in acc_cn.items()},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.inverse:   # (the CPU leg times the forward strategy)
             cb, ccounts, cmid = cpu_baseline(q, t, a.cpu_seconds, preset)
             out["cpu_baseline"] = cb
             out["gpu_vs_cpu_port"] = value / cb["value"]

@@ -227,6 +227,13 @@ int  lrge_hip_comm_create(lrge_hip_ctx *ctx, int rank, int world, const void *id
 int  lrge_hip_comm_local_group_create(int world, void **group);
 void lrge_hip_comm_local_group_destroy(void *group);
 int  lrge_hip_comm_create_local(lrge_hip_ctx *ctx, int rank, void *group, lrge_hip_comm **out);
+/*   lrge_hip_comm_create_host   the host's own collectives (MPI, gloo, ...): the library stages its small vectors through host
+ *                               memory and calls back.  allreduce: in-place SUM of n elements of elem_bytes (4: u32, 8: u64);
+ *                               allgather: recv holds world * bytes; both return 0 on success. */
+typedef int (*lrge_hip_host_allreduce_fn)(void *user, void *inout, size_t n, int elem_bytes);
+typedef int (*lrge_hip_host_allgather_fn)(void *user, const void *send, size_t bytes, void *recv);
+int  lrge_hip_comm_create_host(lrge_hip_ctx *ctx, int rank, int world, lrge_hip_host_allreduce_fn allreduce,
+                               lrge_hip_host_allgather_fn allgather, void *user, lrge_hip_comm **out);
 void lrge_hip_comm_destroy(lrge_hip_comm *c);
 int  lrge_hip_comm_rank(const lrge_hip_comm *c);
 int  lrge_hip_comm_world(const lrge_hip_comm *c);

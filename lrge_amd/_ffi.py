@@ -24,7 +24,7 @@ EXPORTS = [
     "lrge_hip_host_free", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch",
     "lrge_hip_index_build", "lrge_hip_index_build_for", "lrge_hip_index_free",
     "lrge_hip_comm_unique_id", "lrge_hip_comm_create", "lrge_hip_comm_local_group_create", "lrge_hip_comm_local_group_destroy",
-    "lrge_hip_comm_create_local", "lrge_hip_comm_destroy", "lrge_hip_comm_rank", "lrge_hip_comm_world",
+    "lrge_hip_comm_create_local", "lrge_hip_comm_create_host", "lrge_hip_comm_destroy", "lrge_hip_comm_rank", "lrge_hip_comm_world",
     "lrge_hip_comm_allreduce_u32", "lrge_hip_comm_allgather", "lrge_hip_index_stats",
     "lrge_hip_overlap_twoset", "lrge_hip_overlap_inverse", "lrge_hip_overlap_ava", "lrge_hip_chains",
     "lrge_hip_estimates", "lrge_hip_median", "lrge_hip_paf_stats",
@@ -89,6 +89,7 @@ def lib():
     L.lrge_hip_comm_local_group_destroy.argtypes = [vp]
     L.lrge_hip_comm_local_group_destroy.restype = None
     L.lrge_hip_comm_create_local.argtypes = [vp, C.c_int, vp, C.POINTER(vp)]
+    L.lrge_hip_comm_create_host.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.POINTER(vp)]
     L.lrge_hip_comm_destroy.argtypes = [vp]
     L.lrge_hip_comm_destroy.restype = None
     L.lrge_hip_comm_rank.argtypes = [vp]

@@ -70,7 +70,9 @@ struct lrge_hip_comm {
     int rank = 0, world = 1;
     lrge_ncclComm_t nccl = nullptr;      // RCCL transport
     LocalGroup *grp = nullptr;           // local transport
-    std::vector<char> hbuf;              // host staging of the local transport
+    // host transport: the caller's own collectives (MPI, gloo, ...) on host buffers; the library stages through the host
+    lrge_hip_host_allreduce_fn cb_allreduce = nullptr; lrge_hip_host_allgather_fn cb_allgather = nullptr; void *cb_user = nullptr;
+    std::vector<char> hbuf;              // host staging of the local / host transports
 };
 
 #define NCCLCHK(ctx, call)                                                                                          \
@@ -93,6 +95,12 @@ static int comm_allreduce_sum(lrge_hip_comm *c, void *dbuf, size_t n, int esz, h
     c->hbuf.resize(n * (size_t)esz);
     HIPCHK(ctx, hipMemcpyAsync(c->hbuf.data(), dbuf, n * (size_t)esz, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    if (c->cb_allreduce) {
+        if (c->cb_allreduce(c->cb_user, c->hbuf.data(), n, esz) != 0) { LRGE_SET_ERR(ctx, "host communicator: all-reduce callback failed"); return LRGE_ERR_DEVICE; }
+        HIPCHK(ctx, hipMemcpyAsync(dbuf, c->hbuf.data(), n * (size_t)esz, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        return LRGE_OK;
+    }
     LocalGroup *g = c->grp;
     g->slot[(size_t)c->rank] = c->hbuf.data();
     g->barrier();
@@ -116,6 +124,13 @@ static int comm_allgather(lrge_hip_comm *c, const void *dsend, size_t bytes, voi
     c->hbuf.resize(bytes);
     HIPCHK(ctx, hipMemcpyAsync(c->hbuf.data(), dsend, bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    if (c->cb_allgather) {
+        std::vector<char> all(bytes * (size_t)c->world);
+        if (c->cb_allgather(c->cb_user, c->hbuf.data(), bytes, all.data()) != 0) { LRGE_SET_ERR(ctx, "host communicator: all-gather callback failed"); return LRGE_ERR_DEVICE; }
+        HIPCHK(ctx, hipMemcpyAsync(drecv, all.data(), all.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        return LRGE_OK;
+    }
     LocalGroup *g = c->grp;
     g->slot[(size_t)c->rank] = c->hbuf.data();
     g->barrier();

@@ -2181,6 +2181,15 @@ extern "C" int lrge_hip_comm_create_local(lrge_hip_ctx *ctx, int rank, void *grp
     return LRGE_OK;
 }
 
+extern "C" int lrge_hip_comm_create_host(lrge_hip_ctx *ctx, int rank, int world, lrge_hip_host_allreduce_fn allreduce,
+                                         lrge_hip_host_allgather_fn allgather, void *user, lrge_hip_comm **out) {
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || !allreduce || !allgather) return LRGE_ERR_INVALID;
+    lrge_hip_comm *c = new lrge_hip_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->cb_allreduce = allreduce; c->cb_allgather = allgather; c->cb_user = user;
+    *out = c;
+    return LRGE_OK;
+}
+
 extern "C" void lrge_hip_comm_destroy(lrge_hip_comm *c) {
     if (!c) return;
     if (c->nccl) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); (void)g_rccl.CommDestroy(c->nccl); }

@@ -93,6 +93,45 @@ class RcclComm(_Comm):
         return cls.create(ctx, rank, world, box[0])
 
 
+class HostComm(_Comm):
+    """The library's collectives carried by torch.distributed on HOST buffers (gloo works wherever TCP does): the
+    fall-back transport of bench.py should RCCL fail to come up, and what a host with its own MPI would plug in."""
+
+    def __init__(self, ctx, dist):
+        import ctypes as C
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+        def allreduce(_user, buf, n, esz):
+            try:
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint64 if esz == 8 else C.c_uint32)), shape=(n,))
+                t = torch.from_numpy(a.astype(np.int64))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                a[:] = t.numpy().astype(a.dtype)
+                return 0
+            except Exception:      # noqa: BLE001 -- reported through the return code
+                return 1
+
+        def allgather(_user, send, nbytes, recv):
+            try:
+                s_ = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                r_ = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+                bufs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(bufs, torch.from_numpy(s_.copy()))
+                r_[:] = np.concatenate([b.numpy() for b in bufs])
+                return 0
+            except Exception:      # noqa: BLE001
+                return 1
+
+        self._ar, self._ag = AR(allreduce), AG(allgather)      # keep the trampolines alive
+        h = C.c_void_p()
+        ctx._check(ctx._lib.lrge_hip_comm_create_host(ctx.h, rank, world, C.cast(self._ar, C.c_void_p), C.cast(self._ag, C.c_void_p),
+                                                      None, C.byref(h)))
+        super().__init__(ctx, h, rank, world)
+
+
 class LocalGroup:
     """The ranks are threads of this process (one context each); see lrge_hip_comm_create_local."""
 

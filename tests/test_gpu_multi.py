@@ -156,6 +156,63 @@ def test_world_of_threads_inverse(ctx, tiny_ont):
         assert np.array_equal(total, ref) and s == st
 
 
+def _proc_rank(rank, world, port, q):
+    """One PROCESS per rank, both on GPU 0, joined by torch.distributed/gloo through the library's host transport."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from lrge_amd import engine, parallel, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g, qs, ts = synth.make_config("tiny_twoset")
+        qr, tr = engine.name_ranks(qs.names, ts.names)
+        ctx = engine.Context(0)
+        comm = parallel.HostComm(ctx, dist)
+
+        def overlap_fn(lo, hi):
+            sub = qs.slice(lo, hi)
+            Td = ctx.upload(ts.bases, ts.offsets, tr)
+            Qd = ctx.upload(sub.bases, sub.offsets, qr[lo:hi])
+            ix = engine.Index(ctx, Td, 0, streamed=Qd, comm=comm)       # collective: all-reduce of the occurrence statistics
+            counts, has = ix.overlap_twoset(Qd)
+            st = ix.stats()
+            avg = np.float32(ts.lens().sum()) / np.float32(ts.n)
+            est = ctx.estimates(counts, sub.lens(), float(avg), ts.n, 100)
+            ix.free()
+            overlap_fn.out = (counts, st)
+            return est, int((has == 0).sum())
+        allv, no_map, (lo, hi) = parallel.twoset_forward_sharded(overlap_fn, qs.lens(), comm)
+        q.put((rank, lo, hi, overlap_fn.out[0].tolist(), overlap_fn.out[1], allv.view(np.uint32).tolist(), no_map))
+        comm.close(); ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_host_transport(ctx, tiny_ont):
+    """World of two PROCESSES (both on this box's one GPU): the sharded forward job through lrge_amd.parallel with the
+    library's host transport carried by gloo -- the same code path bench.py --gpus N takes, with RCCL swapped for TCP."""
+    import socket
+    import torch.multiprocessing as mp
+    from lrge_amd import engine
+    ds = tiny_ont
+    Qd, Td, counts, has, st = _single(ctx, ds, 0)
+    avg_t = np.float32(ds.t.lens().sum()) / np.float32(ds.t.n)
+    est = ctx.estimates(counts, ds.q.lens(), float(avg_t), ds.t.n, 100)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_proc_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == ds.q.n
+    for rank, lo, hi, c, s_, allv, no_map in res:
+        assert c == counts[lo:hi].tolist() and s_ == st
+        assert allv == est.view(np.uint32).tolist()
+        assert no_map == int((has == 0).sum())
+
+
 def test_rccl_transport_world1():
     """RCCL behind the C ABI on the one GPU of this box: unique id, communicator, all-reduce, all-gather and a collective
     index build with world size 1 (in a child: RCCL keeps process-wide state)."""

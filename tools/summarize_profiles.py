@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn one tools/profile_round.sh run (gpurun_out/<tag>_*) into the tracked files under profiles/:
    <round>_bench.json, <round>_kernel_stats.csv, <round>_pmc_sq.csv, <round>_pmc_fetch.csv, <round>_pmc_write.csv
-   and chain_pmc.json (HBM bytes per launch for the kernels bench.py's roofline block names).
+   and <round>_hbm_traffic.json (corrected HBM bytes and VALU instructions per launch of every kernel).
    usage: tools/summarize_profiles.py <tag> <round-prefix>      e.g.  r1k r01"""
 import collections
 import csv
@@ -44,54 +44,36 @@ for name, sub, pre in (("sq", "_sq", "q"), ("fetch", "_fetch", "f"), ("write", "
 
 fetch = agg(os.path.join(G, tag + "_fetch", "f_counter_collection.csv"))
 write = agg(os.path.join(G, tag + "_write", "w_counter_collection.csv"))
+sq = agg(os.path.join(G, tag + "_sq", "q_counter_collection.csv"))
 
-
-def per_launch(kern):
-    # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, HBM
-    # section; calibrated here on k_rs_hist, a pure 8 B/key stream): reads x2, writes x1
+# HBM bytes per launch of every kernel: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies 128-B read requests at 64 B
+# (MI355X_MICROARCH.md, HBM section): reads x2, writes x1.  The x2 is calibrated for wide coalesced streaming reads only
+# (checked below on k_rs_hist, a pure 8 B/key stream); for gather patterns (k_lookup: one 16-byte slot per random line,
+# k_chain_lpg: 16 B per lane from 64 lines) it is uncalibrated and the corrected figure is an upper bound -- the raw counters
+# are in <round>_pmc_fetch.csv / _pmc_write.csv.
+per = {}
+for kern in sorted(set(fetch) | set(write)):
     f = fetch.get(kern, {}).get("FETCH_SIZE"); w = write.get(kern, {}).get("WRITE_SIZE")
     if not f or not w:
-        return None
-    return (f[1] / f[0]) * 1024 * 2.0 + (w[1] / w[0]) * 1024 * 1.0
-
-
-out = {
-    "source": "tools/profile_round.sh %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0)" % tag,
-    "fetch_correction": 2.0, "write_correction": 1.0,
-    "fetch_correction_note": "x2 is calibrated for wide coalesced streaming reads (k_rs_hist). k_chain_lpg reads 16 B per lane from 64 "
-                             "different lines per instruction; for that pattern the factor is uncalibrated, so its corrected figure is an "
-                             "upper bound (raw FETCH_SIZE + WRITE_SIZE: see *_pmc_fetch.csv / *_pmc_write.csv)",
-    "k_chain_lpg_hbm_bytes_per_launch": per_launch(next((k for k in fetch if k.startswith("k_chain_lpg<")), "k_chain_lpg")),
-    "k_chain_hw_hbm_bytes_per_launch": per_launch("k_chain_hw"),
-    "k_rs_scatter_hbm_bytes_per_launch": None,
-}
-# k_rs_scatter: both instantiations, averaged over all launches of the step
-tot, n = 0.0, 0
-for kern in fetch:
-    if not kern.startswith("k_rs_scatter"):
         continue
-    f = fetch.get(kern, {}).get("FETCH_SIZE"); w = write.get(kern, {}).get("WRITE_SIZE")
-    if f and w:
-        tot += f[1] * 1024 * 2.0 + w[1] * 1024 * 1.0; n += f[0]
-if n:
-    out["k_rs_scatter_hbm_bytes_per_launch"] = tot / n
-# calibration of the x2 read correction: the largest k_rs_hist<false> launch of a step is the index sort's,
-# a pure stream of 8 B per index minimizer
+    v = sq.get(kern, {}).get("SQ_INSTS_VALU")
+    per[kern] = {"launches_in_pass": f[0], "fetch_raw_bytes_per_launch": f[1] / f[0] * 1024, "write_raw_bytes_per_launch": w[1] / w[0] * 1024,
+                 "hbm_bytes_per_launch_corrected": f[1] / f[0] * 1024 * 2.0 + w[1] / w[0] * 1024,
+                 "valu_insts_per_launch": v[1] / v[0] if v else None}
 big = 0.0
 for r in csv.DictReader(open(os.path.join(G, tag + "_fetch", "f_counter_collection.csv"))):
     if r["Kernel_Name"].startswith("void k_rs_hist<false>") and r["Counter_Name"] == "FETCH_SIZE":
         big = max(big, float(r["Counter_Value"]))
-nmz = None
-for line in open(os.path.join(G, tag + "_bench.json")):
-    pass
-out["calibration"] = {"k_rs_hist_false_largest_launch_FETCH_SIZE_KiB": big,
-                      "note": "that launch reads 8 B x (index minimizers); FETCH_SIZE reports half of it on gfx950 (128-B requests tallied at 64 B)"}
-# VALU issue of the chain stage (SQ pass): wave64 VALU instructions per launch; each occupies its SIMD for 4 cycles
-sq = agg(os.path.join(G, tag + "_sq", "q_counter_collection.csv"))
-for kern, key in ((next((k for k in sq if k.startswith("k_chain_lpg<")), "k_chain_lpg"), "k_chain_lpg"), ("k_chain_hw", "k_chain_hw")):
-    v = sq.get(kern, {}).get("SQ_INSTS_VALU")
-    out[key + "_valu_insts_per_launch"] = v[1] / v[0] if v else None
-a, b = out["k_chain_lpg_hbm_bytes_per_launch"], out["k_chain_hw_hbm_bytes_per_launch"]
-out["chain_stage_hbm_bytes_per_step"] = (a or 0) + (b or 0) if (a or b) else None
-json.dump(out, open(os.path.join(P, "chain_pmc.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
+out = {
+    "source": "tools/profile_round.sh %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes, bench.py --steps 1 --warmup 0; "
+              "the pass also holds the instrumented step, so per-launch figures average 2 steps' launches)" % tag,
+    "workload": bench.get("config", {}).get("workload"),
+    "fetch_correction": 2.0, "write_correction": 1.0,
+    "calibration": {"k_rs_hist_false_largest_launch_FETCH_SIZE_KiB": big, "index_minimizers": bench.get("work_per_step", {}).get("rs_scatter_items"),
+                    "note": "the largest k_rs_hist<false> launch reads 8 B x (index minimizers); FETCH_SIZE reports half of it on gfx950 "
+                            "(128-B requests tallied at 64 B)"},
+    "valu_issue_note": "a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md:52-53)",
+    "kernels": per,
+}
+json.dump(out, open(os.path.join(P, rnd + "_hbm_traffic.json"), "w"), indent=1)
+print(json.dumps({k: v["hbm_bytes_per_launch_corrected"] for k, v in per.items()}, indent=1))

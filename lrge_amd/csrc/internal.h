@@ -73,6 +73,14 @@ struct DevPool {
         if (!p) return;
         for (auto &b : blks) if (b.p == p) { b.used = false; return; }
     }
+    // give a block back to the device right away (a multi-gigabyte staging buffer nobody will ask for again: kept in the
+    // cache it would stand in the way of everything else until an allocation fails)
+    void free_now(void *p) {
+        if (!p) return;
+        for (size_t i = 0; i < blks.size(); ++i)
+            if (blks[i].p == p) { (void)hipFree(p); total -= blks[i].cap; blks.erase(blks.begin() + i); return; }
+    }
+    size_t cap_of(void *p) const { for (auto &b : blks) if (b.p == p) return b.cap; return 0; }
     void trim() {
         std::vector<Blk> keep;
         for (auto &b : blks) { if (b.used) keep.push_back(b); else { (void)hipFree(b.p); total -= b.cap; } }

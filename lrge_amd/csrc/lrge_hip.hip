@@ -199,7 +199,11 @@ static int seqset_ready(lrge_hip_ctx *ctx, const lrge_hip_seqset *cs) {
     if (!s->pending) return LRGE_OK;
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_ready, 0));
     s->pending = false;
-    ctx->pool.release(s->stg_ascii); ctx->pool.release(s->stg_boff); ctx->pool.release(s->stg_blk);
+    if (ctx->pool.cap_of(s->stg_ascii) > ((size_t)4 << 30)) {      // tens of gigabases of ASCII: not worth caching
+        (void)hipStreamSynchronize(ctx->copy_stream);                // (the pack that read it has run; hipFree would wait anyway)
+        ctx->pool.free_now(s->stg_ascii);
+    } else ctx->pool.release(s->stg_ascii);
+    ctx->pool.release(s->stg_boff); ctx->pool.release(s->stg_blk);
     s->stg_ascii = s->stg_boff = s->stg_blk = nullptr;
     return LRGE_OK;
 }

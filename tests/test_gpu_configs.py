@@ -147,15 +147,15 @@ def c5_tenth():
 def test_c5_tenth_forward_and_inverse(ctx, oracle, c5_tenth, preset, knobs):
     """Forward: the first 256 queries against the full 3-Gbase target index.  Inverse (--use-min-ref): the index holds the
     queries, the targets are streamed -- for ava-pb all 200 000 of them (every indexed read's count is checked), for
-    ava-ont the first 40 000 (the oracle streams them at ~5 k reads/s).  The forward run is forced into 3 index parts and
-    2 streamed views with ava-pb, so the partitioned paths are exercised at scale."""
+    ava-ont the first 40 000 (the oracle streams them at ~5 k reads/s).  The forward run is forced into 8 index parts and
+    3 streamed views with ava-pb (what full-size C5 needs on one GPU), so the partitioned paths are exercised at scale."""
     from lrge_amd import engine
     gsize, q, t = c5_tenth
     Qd, Td = _sets(ctx, q, t)
     # ---- forward ----
     if preset == 1:
-        knobs.set("PART_BASES", str(int(t.lens().sum()) // 3 + 1))
-        knobs.set("STREAM_BASES", str(int(q.lens().sum()) // 2 + 1))
+        knobs.set("PART_BASES", str(int(t.lens().sum()) // 8 + 1))      # 8 index parts, as full-size C5 needs
+        knobs.set("STREAM_BASES", str(int(q.lens().sum()) // 3 + 1))    # and the queries in 3 views
     Qd.presketch(preset)
     ix = engine.Index(ctx, Td, preset)
     counts, has = ix.overlap_twoset(Qd)

@@ -271,6 +271,14 @@ __global__ void k_hc_accumulate(const u32 *__restrict__ hc, u64 n, u32 mid_occ, 
     acc[i] = s > mid_occ ? mid_occ + 1 : (u32)s;
 }
 
+// kept seeds by their occurrence count over all parts (see k_hc_accumulate): 0 < n <= mid_occ
+__global__ void k_flag_kept(const u32 *__restrict__ g, u64 n, u32 mid_occ, u32 *__restrict__ flag) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 c = g[i];
+    flag[i] = (c != 0 && c <= mid_occ) ? 1u : 0u;
+}
+
 // Per-query PAF statistics (mm2:seed.c mm_collect_matches, mm2:esterr.c mm_est_err): rep_len = length of
 // the query covered by filtered (n > mid_occ) seeds, sum_span / n_kept -> avg_k of the kept seeds.
 __global__ void k_query_paf_stats(const u64 *__restrict__ qx, const u64 *__restrict__ qy, const u32 *__restrict__ hc,

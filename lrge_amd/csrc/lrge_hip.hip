@@ -1213,6 +1213,8 @@ struct OverlapJob {
     u32 rid_base = 0;                                   // first read of the part in the whole indexed set
     const lrge_hip_seqset *indexed_top = nullptr;       // all-vs-all: the whole indexed set (counts are keyed by it)
     u32 *d_hc_acc = nullptr; bool hc_last = true;       // paf_stats: occurrence counts accumulated over the parts (device)
+    const u32 *d_hc_global = nullptr;                   // chain records: those counts, complete (a seed's rank among the KEPT seeds
+                                                        // of its query -- n_seeds / dv -- counts seeds kept in ANY part)
 };
 
 
@@ -1474,7 +1476,8 @@ int OverlapRun::seeds() {
             KCHK(ctx);
             // rank of every kept seed inside its query (= its index in minimap2's mini_pos[])
             ALLOC_OR_FAIL(kflag, sc, u32, Mq);
-            hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hn, Mq, kflag);
+            if (job.d_hc_global) hipLaunchKernelGGL(k_flag_kept, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, job.d_hc_global, Mq, (u32)ix->mid_occ, kflag);
+            else hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hn, Mq, kflag);
             KCHK(ctx);
             rc = scan_exclusive_u32(ctx, sc, kflag, krank, Mq, krank + Mq);
             if (rc) return rc;
@@ -2086,11 +2089,23 @@ extern "C" int lrge_hip_chains(lrge_hip_ctx *ctx, const lrge_hip_index *ix, cons
         return run_overlap(ctx, ix, queries, job);
     }
     // partitioned index: the chains of a query onto the reads of one part are found in that part; records carry the
-    // read's index in the whole set (rid_base)
+    // read's index in the whole set (rid_base).  n_seeds spans the query's KEPT seeds, and kept is a property of the
+    // whole index: a first sweep over the parts sums every query minimizer's occurrence count (k_hc_accumulate)
+    if (queries->total_bases + 1 >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "chains against a partitioned index: query set too large"); return LRGE_ERR_TOO_MANY; }
+    Scratch sc(ctx);
+    ALLOC_OR_FAIL(d_acc, sc, u32, (size_t)queries->total_bases + 1);
+    HIPCHK(ctx, hipMemsetAsync(d_acc, 0, ((size_t)queries->total_bases + 1) * 4, ctx->stream));
+    for (size_t pi = 0; pi < ix->parts.size(); ++pi) {
+        OverlapJob j = job;
+        j.paf_stats = true; j.d_hc_acc = d_acc; j.hc_last = false;      // (accumulate only)
+        rc = run_overlap(ctx, ix->parts[pi], queries, j);
+        if (rc) return rc;
+    }
     u64 total = 0;
     StageAcc acc;
     for (size_t pi = 0; pi < ix->parts.size(); ++pi) {
         OverlapJob j = job;
+        j.d_hc_global = d_acc;
         u64 n_part = 0;
         const u64 room = (out && cap > total) ? cap - total : 0;
         j.chains = room ? out + total : nullptr; j.chain_cap = room; j.n_chains = &n_part; j.rid_base = ix->part_r0[pi];

@@ -1230,8 +1230,12 @@ static ChainSplit choose_chain_split(const u32 *hn, const unsigned long long *ha
     ChainSplit r; r.T = fixed; r.n_big = 0; r.a_big = 0; r.top = -1;
     for (int b = 0; b < GSZ_BINS; ++b) if (hn[b]) r.top = b;
     if (fixed == LPG_MAX_AUTO) {
+        // measured constants of this kernel pair on MI355X.  `rate` is the wave64 VALU instruction rate the chip sustains for
+        // k_chain_lpg at its residency (1.25 wavefronts per SIMD, bounded by LDS) -- 422 G/s measured at C4; a shape with four
+        // wavefronts per workgroup and twice the residency was measured too (round 2): every step took 1.4x as long and the
+        // stage was slower or equal on C2, C4 and C5/10 alike, because the stage is bound by T * t_lpg, not by throughput
         const double t_lpg = 4.1e-6, t_hw = 0.55e-6, c_lpg = 21.0, c_hw = 93.0;
-        const double rate = 0.8 * (double)n_cu * 4 * 2.1e9 / 4.0;   // wave64 VALU instructions per second, ~80 % reachable
+        const double rate = 0.8 * (double)n_cu * 4 * 2.1e9 / 4.0;
         double best = 1e30, a_le = 0;    // a_le: anchors in classes <= b
         r.T = 0;
         for (int b = -1; b < GSZ_BINS - 1; ++b) {      // T = (b + 1) * GSZ_W: classes 0..b go to k_chain_lpg
@@ -1775,16 +1779,15 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                     if (!la.redo_list || !la.redo_count) return LRGE_ERR_DEVICE;
                     HIPCHK(ctx, hipMemsetAsync(la.redo_count, 0, 4, both ? ctx->stream2 : ctx->stream));
                     StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
-                    const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 4096 && !ctx->opt("LPG_NOTAB");
+                    const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 8192 && !ctx->opt("LPG_NOTAB");
                     const bool fastreach = cp.max_iter >= 64 && !ctx->opt("LPG_EXACT_REACH");
-                    const dim3 lgrid((la.n_list + 64 * LPG_WAVES - 1) / (64 * LPG_WAVES)), lblock(64 * LPG_WAVES);
-                    const size_t lds_ring = (size_t)LPG_WAVES * LPG_RING_BYTES;
-                    const size_t lds_tab = (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + lds_ring;
+                    const dim3 lgrid((la.n_list + 63) / 64);
+                    const size_t lds_tab = (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES;
                     hipStream_t lst = both ? ctx->stream2 : ctx->stream;
-                    if (pentab && fastreach) hipLaunchKernelGGL((k_chain_lpg<true, true>), lgrid, lblock, lds_tab, lst, la, cp, go);
-                    else if (pentab) hipLaunchKernelGGL((k_chain_lpg<true, false>), lgrid, lblock, lds_tab, lst, la, cp, go);
-                    else if (fastreach) hipLaunchKernelGGL((k_chain_lpg<false, true>), lgrid, lblock, lds_ring, lst, la, cp, go);
-                    else hipLaunchKernelGGL((k_chain_lpg<false, false>), lgrid, lblock, lds_ring, lst, la, cp, go);
+                    if (pentab && fastreach) hipLaunchKernelGGL((k_chain_lpg<true, true>), lgrid, dim3(64), lds_tab, lst, la, cp, go);
+                    else if (pentab) hipLaunchKernelGGL((k_chain_lpg<true, false>), lgrid, dim3(64), lds_tab, lst, la, cp, go);
+                    else if (fastreach) hipLaunchKernelGGL((k_chain_lpg<false, true>), lgrid, dim3(64), LPG_RING_BYTES, lst, la, cp, go);
+                    else hipLaunchKernelGGL((k_chain_lpg<false, false>), lgrid, dim3(64), LPG_RING_BYTES, lst, la, cp, go);
                     KCHK(ctx);
                     tl.stop();
                     ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;

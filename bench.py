@@ -101,6 +101,8 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
+    if os.environ.get("LRGE_BENCH_SHARE_GPU") == "1":     # tests on a 1-GPU box: all ranks of a world on the devices there are
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("LRGE_BENCH_FORCE_DIST") == "1"   # the switch lets a 1-GPU box exercise RCCL
     preset = 1 if a.preset == "pb" else 0

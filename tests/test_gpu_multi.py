@@ -240,3 +240,24 @@ print("RCCL-OK", int(ref.sum()))
     env = dict(os.environ, PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_bench_world2_on_one_gpu():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with both ranks
+    on this box's one GPU and the collectives on the host transport (RCCL refuses two ranks on one device): the strong-
+    scaling split, the collective index build and the all-gather must reproduce the one-GPU estimate bit for bit."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, LRGE_BENCH_SHARE_GPU="1", LRGE_BENCH_TRANSPORT="host")
+    common = ["--config", "c2_bact_twoset", "--scale", "0.2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-from-host"]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    two = json.loads([l for l in r2.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "host" in two["config"]["collectives"]
+    for k in ("genome_size_estimate", "estimate_q15_q65", "mid_occ"):
+        assert one[k] == two[k], (k, one[k], two[k])

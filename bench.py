@@ -116,7 +116,7 @@ def main():
     Qn, Tn = q.n, t.n
 
     ctx = engine.Context(local_rank)
-    comm, transport = None, None
+    comm, transport, rccl_thread = None, None, None
     if use_dist:
         # torch.distributed only bootstraps (TCP store over gloo): the data-path collectives are the library's own RCCL
         # communicator behind the C ABI (lrge_hip_comm_*), created from a unique id that rank 0 hands out
@@ -124,13 +124,26 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         transport = "rccl"
-        try:
-            if os.environ.get("LRGE_BENCH_TRANSPORT") == "host":
-                raise RuntimeError("host transport requested")
-            comm = parallel.RcclComm.bootstrap(ctx, rank, world, dist)
-        except Exception as e:      # noqa: BLE001 -- the collectives then travel over gloo on host buffers (say so in the line)
-            transport = "host (gloo) -- RCCL communicator not created: %s" % str(e)[:200]
-            comm = None
+        if os.environ.get("LRGE_BENCH_TRANSPORT") == "host":
+            transport = "host (gloo) -- requested"
+        else:
+            # ncclCommInitRank blocks until every rank has joined; a mis-set network interface would hang it for good, so the
+            # bootstrap runs in a helper thread with a deadline -- past it the collectives travel over gloo on host buffers
+            # (and the line says so)
+            import threading
+            box = {}
+
+            def _boot():
+                try:
+                    box["comm"] = parallel.RcclComm.bootstrap(ctx, rank, world, dist)
+                except Exception as e:      # noqa: BLE001
+                    box["err"] = e
+            rccl_thread = threading.Thread(target=_boot, daemon=True)
+            rccl_thread.start()
+            rccl_thread.join(timeout=float(os.environ.get("LRGE_BENCH_RCCL_TIMEOUT", "240")))
+            comm = box.get("comm")
+            if comm is None:
+                transport = "host (gloo) -- RCCL communicator not created: %s" % (str(box.get("err"))[:200] if "err" in box else "timed out")
         # every rank must agree on the transport
         flag = torch.tensor([1 if comm is not None else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -333,6 +346,9 @@ def main():
         print(json.dumps(out))
     if comm is not None:
         comm.close()
+    if rccl_thread is not None and rccl_thread.is_alive():     # a communicator bootstrap that never returned: leave without joining it
+        sys.stdout.flush()
+        os._exit(0)
     if use_dist:
         dist.destroy_process_group()
     ctx.close()

@@ -88,8 +88,15 @@ class RcclComm(_Comm):
     @classmethod
     def bootstrap(cls, ctx, rank, world, dist):
         """Rank 0 draws the id; torch.distributed (any backend, used as a store only) hands it out."""
-        box = [cls.unique_id(ctx) if rank == 0 else None]
+        box, err = [None], None
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id(ctx)
+            except Exception as e:      # noqa: BLE001 -- the other ranks must not be left waiting in the broadcast
+                err = e
         dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise RuntimeError("rank 0 could not draw a RCCL unique id" + (": %s" % err if err else ""))
         return cls.create(ctx, rank, world, box[0])
 
 

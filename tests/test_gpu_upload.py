@@ -32,7 +32,9 @@ class _DevBuf:
 
     def __init__(self, host):
         import ctypes as C
-        self.hip = C.CDLL("libamdhip64.so")
+        # the copy liblrge_hip.so is linked against (already mapped), not the one bundled with torch
+        paths = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l and "/torch/" not in l})
+        self.hip = C.CDLL(paths[0] if paths else "libamdhip64.so")
         self.ptr = C.c_void_p()
         assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(max(host.size, 1))) == 0
         assert self.hip.hipMemcpy(self.ptr, C.c_void_p(host.ctypes.data), C.c_size_t(host.size), 1) == 0   # hipMemcpyHostToDevice

@@ -185,7 +185,7 @@ struct lrge_hip_seqset {
     // host copies needed for planning
     std::vector<u64> h_woff;
     std::vector<u32> h_len;
-    std::vector<u32> h_rank, h_rank_sorted;
+    std::vector<u32> h_rank;
 };
 
 struct lrge_hip_index {

@@ -2342,11 +2342,18 @@ extern "C" int lrge_hip_median(const float *estimates, uint64_t n, int finite, i
     if (has_upper) want(upper_q);
     std::sort(need.begin(), need.end());
     need.erase(std::unique(need.begin(), need.end()), need.end());
-    size_t from = 0;
-    for (size_t i : need) {
-        std::nth_element(v.begin() + from, v.begin() + i, v.end());
-        from = i + 1;
-    }
+    // select the middle one of the needed order statistics first, then the rest inside the halves it leaves: every later
+    // selection works on a fraction of the vector (one pass over all of it + the halves, instead of a suffix per statistic)
+    struct Sel {
+        static void run(std::vector<float> &v, const std::vector<size_t> &need, size_t a, size_t b, size_t lo, size_t hi) {
+            if (a >= b) return;
+            const size_t m = (a + b) / 2, i = need[m];
+            std::nth_element(v.begin() + lo, v.begin() + i, v.begin() + hi);
+            run(v, need, a, m, lo, i);
+            run(v, need, m + 1, b, i + 1, hi);
+        }
+    };
+    Sel::run(v, need, 0, need.size(), 0, v.size());
     ok[1] = quantile_f32(v, 0.5f, &out[1]);
     if (has_lower) ok[0] = quantile_f32(v, lower_q, &out[0]);
     if (has_upper) ok[2] = quantile_f32(v, upper_q, &out[2]);

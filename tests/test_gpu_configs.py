@@ -1,6 +1,7 @@
 """GPU: the BASELINE.json configurations themselves against the CPU oracle, at their full sizes.
 
-  C2  4.4 Mbp ONT, two-set -Q 5000 -T 10000   every count, has_mapping, mid_occ, estimate / q15 / q65 (f32, 0 ulp)
+  C2  4.4 Mbp ONT, two-set -Q 5000 -T 10000   every count, has_mapping, mid_occ, estimate / q15 / q65 (f32, 0 ulp); again with -F;
+                                               every PafRecord of the first 300 queries as PAF lines
   C3  12 Mbp ONT, all-vs-all -n 20000          every count
   C4  143 Mbp ONT, two-set -Q 50000 -T 100000  the first 1024 queries against the FULL target index, mid_occ;
                                                all 50 000 counts through size-independent properties
@@ -72,6 +73,46 @@ def test_c2_full(ctx, oracle):
     emed = oracle.median(eest, True, 0.15, 0.65)
     assert [np.float32(x).view(np.uint32) for x in med] == [np.float32(x).view(np.uint32) for x in emed]
     assert abs(float(med[1]) - gsize) / gsize < 0.15          # 4.4 Mbp genome: the estimate lands near it
+
+
+def test_c2_filter_internal_and_paf_records(ctx, oracle):
+    """C2 again with -F (mapping.rs:59-77 through twoset.rs:295-299) on all 5 000 queries, and every PafRecord field of the
+    first 300 queries (aligner.rs:244-291: coordinates, cm, s1, mlen / blen, dv, rl) as the multiset of PAF lines."""
+    from lrge_amd import engine, paf, synth
+    gsize, q, t = synth.make_config("c2_bact_twoset")
+    Qd, Td = _sets(ctx, q, t)
+    ix = engine.Index(ctx, Td, 0)
+    counts_f, has_f = ix.overlap_twoset(Qd, remove_internal=True, max_overhang_ratio=0.2)
+    counts_p, _ = ix.overlap_twoset(Qd)
+    n = 300
+    sub = q.slice(0, n)
+    qr, tr = engine.name_ranks(q.names, t.names)
+    Sd = ctx.upload(sub.bases, sub.offsets, qr[:n])
+    chains = ix.chains(Sd, dual=True)
+    rl, ss, nk = ix.paf_stats(Sd)
+    ix.free(); Sd.free(); Qd.free(); Td.free()
+    ixo = _oracle_index(oracle, t, 0)
+    Qo = oracle.ReadSet(q.seqs(), q.names)
+    (rc, ec, eh), (rc2, ec2, eh2) = _both_policies(oracle, ixo, lambda: ixo.twoset_counts(Qo, remove_internal=True, ratio=0.2, threads=THREADS))
+    assert rc == 0 and rc2 == 0
+    assert np.array_equal(counts_f, ec) and np.array_equal(has_f, eh)
+    assert np.array_equal(ec, ec2)
+    assert int((counts_f != counts_p).sum()) > 100            # the filter does drop overlaps on this data
+    qlens, tlens = [int(x) for x in sub.lens()], [int(x) for x in t.lens()]
+    got = sorted(paf.paf_lines(chains, sub.names, qlens, t.names, tlens, rl, ss, nk))
+    exp = []
+    seqs = sub.seqs()
+    for qi in range(n):
+        for r in ixo.map(seqs[qi], sub.names[qi]):
+            ti = int(r["rid"])
+            exp.append("\t".join([sub.names[qi].decode(), str(qlens[qi]), str(r["qs"]), str(r["qe"]), "-" if r["rev"] else "+",
+                                  t.names[ti].decode(), str(tlens[ti]), str(r["rs"]), str(r["re"]), str(r["mlen"]), str(r["blen"]), "0",
+                                  "tp:A:S", "cm:i:%d" % r["cnt"], "s1:i:%d" % r["score"], "dv:f:" + paf.format_dv(r["dv"]),
+                                  "rl:i:%d" % r["rep_len"]]))
+    exp.sort()
+    assert len(exp) > 5000 and len(got) == len(exp)
+    bad = [i for i, (a, b) in enumerate(zip(got, exp)) if a != b]
+    assert not bad, "first differing PAF line:\n%s\n%s" % (got[bad[0]], exp[bad[0]])
 
 
 def test_c3_full_ava(ctx, oracle):

@@ -100,6 +100,10 @@ struct lrge_hip_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_gate = nullptr;            // main stream -> copy stream ordering at the start of an upload
     char *stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; size_t stage_cap = 0;
+    // pinned arena for the per-read arrays of an upload (offsets, lengths, ranks, chunk and block maps): they are laid out
+    // in it back to back and travel as ONE transfer (six copies from pageable vectors cost ~0.1 ms each of host time in
+    // front of every index build).  Bump allocation; rewound when no upload is in flight.
+    char *meta_pin = nullptr; size_t meta_cap = 0, meta_used = 0; int meta_inflight = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     DevPool pool;
@@ -180,6 +184,8 @@ struct lrge_hip_seqset {
     bool pending = false;
     hipEvent_t ev_ready = nullptr;
     void *stg_ascii = nullptr, *stg_boff = nullptr, *stg_blk = nullptr;
+    void *d_meta = nullptr;     // pooled sets: ONE device block behind d_woff, d_len, d_rank, d_cs, stg_boff, stg_blk
+    bool meta_arena = false;    // the upload's per-read arrays sit in the context's pinned arena until the set is ready
     std::vector<u64> h_boff; std::vector<u32> h_blk;
     std::vector<u32> h_cs;
     // host copies needed for planning

@@ -154,6 +154,7 @@ extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->pool.destroy();
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->meta_pin) (void)hipHostFree(ctx->meta_pin);
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join);
     (void)hipStreamDestroy(ctx->stream2);
@@ -233,12 +234,12 @@ static int seqset_ready(lrge_hip_ctx *ctx, const lrge_hip_seqset *cs) {
     if (!s->pending) return LRGE_OK;
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_ready, 0));
     s->pending = false;
+    if (s->meta_arena) { s->meta_arena = false; if (--ctx->meta_inflight == 0) ctx->meta_used = 0; }
     if (ctx->pool.cap_of(s->stg_ascii) > ((size_t)4 << 30)) {      // tens of gigabases of ASCII: not worth caching
         (void)hipStreamSynchronize(ctx->copy_stream);                // (the pack that read it has run; hipFree would wait anyway)
         ctx->pool.free_now(s->stg_ascii);
     } else ctx->pool.release(s->stg_ascii);
-    ctx->pool.release(s->stg_boff); ctx->pool.release(s->stg_blk);
-    s->stg_ascii = s->stg_boff = s->stg_blk = nullptr;
+    s->stg_ascii = nullptr;       // (stg_boff / stg_blk live inside the set's meta block)
     return LRGE_OK;
 }
 
@@ -307,12 +308,18 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
     auto alloc = [&](size_t bytes) -> void * { return ctx->pool.alloc(bytes, &e); };
     const size_t nw = (size_t)(w ? w : 1);
     s->d_pack = (u64 *)alloc(nw * 8); s->d_nmask = (u32 *)alloc(nw * 4);
-    s->d_woff = (u64 *)alloc(((size_t)n + 1) * 8); s->d_len = (u32 *)alloc((size_t)(n ? n : 1) * 4);
-    s->d_cs = (u32 *)alloc(((size_t)n + 1) * 4); s->d_rank = (u32 *)alloc((size_t)(n ? n : 1) * 4);
-    s->stg_boff = alloc(((size_t)n + 1) * 8); s->stg_blk = alloc((size_t)(n_blk + 1) * 4);
-    if (!s->d_pack || !s->d_nmask || !s->d_woff || !s->d_len || !s->d_cs || !s->d_rank || !s->stg_boff || !s->stg_blk) {
+    // the per-read arrays: one device block, one host image, one transfer
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_woff = 0, o_boff = o_woff + al(((size_t)n + 1) * 8), o_blk = o_boff + al(((size_t)n + 1) * 8);
+    const size_t o_cs = o_blk + al((size_t)(n_blk + 1) * 4), o_len = o_cs + al(((size_t)n + 1) * 4);
+    const size_t o_rank = o_len + al((size_t)(n ? n : 1) * 4), meta_bytes = o_rank + al((size_t)(n ? n : 1) * 4);
+    s->d_meta = alloc(meta_bytes);
+    if (!s->d_pack || !s->d_nmask || !s->d_meta) {
         LRGE_SET_ERR(ctx, "seqset_upload: device allocation failed: %s", hipGetErrorString(e)); return LRGE_ERR_DEVICE;
     }
+    char *dm = (char *)s->d_meta;
+    s->d_woff = (u64 *)(dm + o_woff); s->stg_boff = dm + o_boff; s->stg_blk = dm + o_blk;
+    s->d_cs = (u32 *)(dm + o_cs); s->d_len = (u32 *)(dm + o_len); s->d_rank = (u32 *)(dm + o_rank);
     // where do the bases live?  device memory (no copy at all), pinned host memory (one DMA), pageable host memory (staged)
     const char *src = n ? bases + offsets[0] : nullptr;
     int kind = 2;                                         // 0 device, 1 pinned host, 2 pageable host
@@ -334,13 +341,26 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
     HIPCHK(ctx, hipEventRecord(ctx->ev_gate, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(cs, ctx->ev_gate, 0));
     s->pending = true;                                     // (from here on seqset_free drains the copy stream first)
-    HIPCHK(ctx, hipMemcpyAsync(s->d_woff, s->h_woff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, cs));
-    HIPCHK(ctx, hipMemcpyAsync(s->stg_boff, s->h_boff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, cs));
-    HIPCHK(ctx, hipMemcpyAsync(s->stg_blk, s->h_blk.data(), (size_t)(n_blk + 1) * 4, hipMemcpyHostToDevice, cs));
-    if (s->n_chunks < (1ULL << 32)) HIPCHK(ctx, hipMemcpyAsync(s->d_cs, s->h_cs.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, cs));
-    if (n) {
-        HIPCHK(ctx, hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, cs));
-        if (name_rank) HIPCHK(ctx, hipMemcpyAsync(s->d_rank, s->h_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, cs));
+    {
+        if (!ctx->meta_pin && hipHostMalloc((void **)&ctx->meta_pin, (size_t)32 << 20, hipHostMallocDefault) == hipSuccess) ctx->meta_cap = (size_t)32 << 20;
+        else if (!ctx->meta_pin) (void)hipGetLastError();
+        char *hm = nullptr;
+        if (ctx->meta_pin && ctx->meta_used + meta_bytes <= ctx->meta_cap) {
+            hm = ctx->meta_pin + ctx->meta_used; ctx->meta_used += meta_bytes; ++ctx->meta_inflight; s->meta_arena = true;
+        }
+        auto put = [&](size_t off, const void *src_, size_t bytes) -> hipError_t {
+            if (hm) { memcpy(hm + off, src_, bytes); return hipSuccess; }
+            return hipMemcpyAsync(dm + off, src_, bytes, hipMemcpyHostToDevice, cs);       // (arena full: piecewise, from the set's own vectors)
+        };
+        HIPCHK(ctx, put(o_woff, s->h_woff.data(), ((size_t)n + 1) * 8));
+        HIPCHK(ctx, put(o_boff, s->h_boff.data(), ((size_t)n + 1) * 8));
+        HIPCHK(ctx, put(o_blk, s->h_blk.data(), (size_t)(n_blk + 1) * 4));
+        if (s->n_chunks < (1ULL << 32)) HIPCHK(ctx, put(o_cs, s->h_cs.data(), ((size_t)n + 1) * 4));
+        if (n) {
+            HIPCHK(ctx, put(o_len, s->h_len.data(), (size_t)n * 4));
+            if (name_rank) HIPCHK(ctx, put(o_rank, s->h_rank.data(), (size_t)n * 4));
+        }
+        if (hm) HIPCHK(ctx, hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, cs));
     }
     if (kind == 1) {
         HIPCHK(ctx, hipMemcpyAsync(s->stg_ascii, src, s->total_bases, hipMemcpyHostToDevice, cs));
@@ -417,8 +437,8 @@ extern "C" void lrge_hip_seqset_free(lrge_hip_seqset *s) {
             lrge_hip_ctx *ctx = s->ctx;
             if (s->pending) (void)hipStreamSynchronize(ctx->copy_stream);          // an upload nobody consumed
             DevPool &P = ctx->pool;
-            P.release(s->d_pack); P.release(s->d_nmask); P.release(s->d_woff); P.release(s->d_len); P.release(s->d_rank); P.release(s->d_cs);
-            P.release(s->stg_ascii); P.release(s->stg_boff); P.release(s->stg_blk);
+            if (s->meta_arena && --ctx->meta_inflight == 0) ctx->meta_used = 0;
+            P.release(s->d_pack); P.release(s->d_nmask); P.release(s->d_meta); P.release(s->stg_ascii);
             if (s->ev_ready) ctx->event_pool.push_back(s->ev_ready);
         }
     } else {

@@ -262,6 +262,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
                               bool async, lrge_hip_seqset **out) {
     if (!ctx || !out || (n && (!bases || !offsets))) return LRGE_ERR_INVALID;
     *out = nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
     std::unique_ptr<lrge_hip_seqset, void (*)(lrge_hip_seqset *)> guard(new lrge_hip_seqset(), lrge_hip_seqset_free);
@@ -395,6 +396,8 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
     // async: the per-read arrays travel from the set's own host copies (they live as long as the set); only `bases`
     // must stay valid, and only when it is pinned host memory (a pageable source has been copied out by now)
     if (!async) { HIPCHK(ctx, hipStreamSynchronize(cs)); ctx->resolve_timers(); }
+    if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] upload of %u reads: %.3f ms of host time\n", n,
+                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     *out = guard.release();
     return LRGE_OK;
 }

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
         m_ql = sp.q_len[m_q];
         m_qr = sp.check_names ? sp.q_rank[m_q] : 0;
         m_st = hs[i];
-        m_rank = (krank[i] - krank[qmz_off[m_q]]) & 0xFFFFFu;
+        if (krank) m_rank = (krank[i] - krank[qmz_off[m_q]]) & 0xFFFFFu;    // (null: count-only run, the packed anchor has no rank field)
     }
     u32 o = aoff[w0 - mz_begin];                                 // anchors written so far (wave-uniform)
     o = (u32)__builtin_amdgcn_readfirstlane((i32)o);

@@ -1318,6 +1318,7 @@ struct OverlapRun {
     // outputs on the device
     u32 n_out = 0; u32 *d_qmap = nullptr, *d_counts = nullptr, *d_hasmap = nullptr;
     unsigned long long *d_nchains = nullptr; lrge_hip_chain *d_chains = nullptr;
+    bool need_rank = true;      // seed ranks (krank) are wanted by this run's anchors
     // seeds: query minimizers, their index lookups, per-query anchor totals
     SketchOut so; std::vector<u32> h_mzoff, h_qtot; u64 Mq = 0; SeedParams sp;
     std::unique_ptr<Scratch> presk_sc;   // memory of a consumed presketch (released with the run)
@@ -1526,14 +1527,20 @@ int OverlapRun::seeds() {
         if (Mq) {
             hipLaunchKernelGGL(k_seed_counts, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.y, Mq, sp, hs, hc, hn, hv);
             KCHK(ctx);
-            // rank of every kept seed inside its query (= its index in minimap2's mini_pos[])
-            ALLOC_OR_FAIL(kflag, sc, u32, Mq);
-            if (job.d_hc_global) hipLaunchKernelGGL(k_flag_kept, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, job.d_hc_global, Mq, (u32)ix->mid_occ, kflag);
-            else hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hn, Mq, kflag);
-            KCHK(ctx);
-            rc = scan_exclusive_u32(ctx, sc, kflag, krank, Mq, krank + Mq);
-            if (rc) return rc;
-            sc.drop(kflag);
+            // rank of every kept seed inside its query (= its index in minimap2's mini_pos[]): only chain records carry it
+            // (mm_est_err's dv); a count-only run packs its anchors without it (OverlapRun::batch) and skips the flag + scan
+            const u32 bits_rpos_ = std::max<u32>(1, ceil_log2_u64((u64)T->max_len + 1)), bits_rid_ = std::max<u32>(1, ceil_log2_u64((u64)T->n));
+            const u32 bits_qy_ = std::max<u32>(1, ceil_log2_u64((u64)Q->max_len + 1));
+            need_rank = d_chains || job.dump_anchors || bits_rpos_ + 1 + bits_rid_ + bits_qy_ + 9 > 64 || ctx->opt_u64("NO_PACKED", 0);
+            if (need_rank) {
+                ALLOC_OR_FAIL(kflag, sc, u32, Mq);
+                if (job.d_hc_global) hipLaunchKernelGGL(k_flag_kept, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, job.d_hc_global, Mq, (u32)ix->mid_occ, kflag);
+                else hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hn, Mq, kflag);
+                KCHK(ctx);
+                rc = scan_exclusive_u32(ctx, sc, kflag, krank, Mq, krank + Mq);
+                if (rc) return rc;
+                sc.drop(kflag);
+            }
         } else {
             HIPCHK(ctx, hipMemsetAsync(krank, 0, 4, ctx->stream));
         }
@@ -1663,7 +1670,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
         rc = scan_exclusive_u32(ctx, bsc, hv + mb, aoff, me - mb, nullptr);
         if (rc) return rc;
         hipLaunchKernelGGL(k_expand, dim3((u32)div_up(me - mb, 256)), dim3(256), 0, ctx->stream, so.x, so.y, mb, me, sp, hs, hn, aoff,
-                           krank, so.mz_off, q0, kl, akey, aval, packed ? bits_qy : 0u);
+                           need_rank ? krank : (const u32 *)nullptr, so.mz_off, q0, kl, akey, aval, packed ? bits_qy : 0u);
         KCHK(ctx);
         // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
         bsc.drop(aoff);

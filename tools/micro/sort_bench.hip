@@ -1,0 +1,89 @@
+// sort_bench.hip -- the index sort (radix_sort_keys of csrc/k_prims.h) alone: correctness against std::stable_sort on a small
+// input, order + permutation checks and timing at index scale.  Development harness, not part of the product or the tests.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/micro/_bin/sort_bench tools/micro/sort_bench.hip && tools/micro/_bin/sort_bench [n]
+#include "../../lrge_amd/csrc/k_prims.h"
+
+#include <algorithm>
+#include <chrono>
+#include <random>
+
+static u64 order_key(u64 k, int begin_bit, int nbits) {      // the key the reversed-digit LSD sort orders by
+    const int passes = (nbits + 7) / 8;
+    u64 f = 0;
+    for (int d = 0; d < passes; ++d) {
+        const int w = nbits - d * 8 >= 8 ? 8 : nbits - d * 8;
+        f = (f << w) | ((k >> (begin_bit + d * 8)) & ((1ULL << w) - 1));
+    }
+    return f;
+}
+
+__global__ void k_fill(u64 *k, u64 n, int ybits, int hbits, u64 seed) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 x = (i + seed) * 0x9E3779B97F4A7C15ULL; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+    // a third of the keys repeat (real minimizers), so that stability matters
+    if ((x & 3) == 0) x = (x >> 8) % 1000003;
+    k[i] = ((x & ((1ULL << hbits) - 1)) << ybits) | i;        // payload = original position: stable <=> ascending inside a key
+}
+__global__ void k_check(const u64 *k, u64 n, int ybits, int hbits, unsigned long long *bad, unsigned long long *sum) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    atomicAdd(sum, (unsigned long long)(k[i] * 0x9E3779B97F4A7C15ULL >> 40));
+    if (i == 0) return;
+    const int passes = (hbits + 7) / 8;
+    u64 fa = 0, fb = 0;
+    for (int d = 0; d < passes; ++d) {
+        const int w = hbits - d * 8 >= 8 ? 8 : hbits - d * 8;
+        fa = (fa << w) | ((k[i - 1] >> (ybits + d * 8)) & ((1ULL << w) - 1));
+        fb = (fb << w) | ((k[i] >> (ybits + d * 8)) & ((1ULL << w) - 1));
+    }
+    const u64 ya = k[i - 1] & ((1ULL << ybits) - 1), yb = k[i] & ((1ULL << ybits) - 1);
+    if (fa > fb || (fa == fb && ya >= yb)) atomicAdd(bad, 1ULL);
+}
+
+int main(int argc, char **argv) {
+    const u64 n_big = argc > 1 ? strtoull(argv[1], nullptr, 10) : 242000000ULL;
+    const int ybits = 34, hbits = argc > 2 ? atoi(argv[2]) : 30;
+    lrge_hip_ctx ctx; memset(ctx.ms, 0, sizeof ctx.ms); memset(ctx.counters, 0, sizeof ctx.counters);
+    ctx.timer_level = 0;
+    if (hipStreamCreate(&ctx.stream) != hipSuccess) { fprintf(stderr, "no device\n"); return 2; }
+    int rc_all = 0;
+    for (u64 n : {(u64)1, (u64)4095, (u64)4096, (u64)4097, (u64)1000003, n_big}) {
+        Scratch sc(&ctx);
+        u64 *k0 = sc.get<u64>(n), *k1 = sc.get<u64>(n);
+        unsigned long long *d_chk = sc.get<unsigned long long>(4);
+        if (!k0 || !k1 || !d_chk) { fprintf(stderr, "alloc failed\n"); return 2; }
+        hipLaunchKernelGGL(k_fill, dim3((u32)div_up(n, 256)), dim3(256), 0, ctx.stream, k0, n, ybits, hbits, 12345ULL);
+        (void)hipMemsetAsync(d_chk, 0, 32, ctx.stream);
+        hipLaunchKernelGGL(k_check, dim3((u32)div_up(n, 256)), dim3(256), 0, ctx.stream, k0, n, ybits, hbits, d_chk, d_chk + 1);
+        std::vector<u64> h_in;
+        if (n <= 2000000) { h_in.resize(n); (void)hipMemcpy(h_in.data(), k0, n * 8, hipMemcpyDeviceToHost); }
+        u64 *res = nullptr;
+        float best = 1e9f;
+        const int reps = n > 2000000 ? 4 : 1;
+        for (int r = 0; r < reps; ++r) {
+            if (r) hipLaunchKernelGGL(k_fill, dim3((u32)div_up(n, 256)), dim3(256), 0, ctx.stream, k0, n, ybits, hbits, 12345ULL);
+            hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, ctx.stream);
+            const int rc = radix_sort_keys(&ctx, sc, k0, k1, n, ybits, hbits, &res, /*reverse_digits=*/true);
+            (void)hipEventRecord(b, ctx.stream);
+            if (rc || hipStreamSynchronize(ctx.stream) != hipSuccess) { fprintf(stderr, "sort failed: %s / %s\n", ctx.err.c_str(), hipGetErrorString(hipGetLastError())); return 1; }
+            float ms = 0; (void)hipEventElapsedTime(&ms, a, b); best = std::min(best, ms);
+            if (res != k0 && r + 1 < reps) {}      // (refilled into k0 every round)
+        }
+        hipLaunchKernelGGL(k_check, dim3((u32)div_up(n, 256)), dim3(256), 0, ctx.stream, res, n, ybits, hbits, d_chk + 2, d_chk + 3);
+        unsigned long long h[4];
+        (void)hipMemcpy(h, d_chk, 32, hipMemcpyDeviceToHost);
+        bool ok = h[2] == 0 && h[1] == h[3];
+        if (!h_in.empty()) {
+            std::stable_sort(h_in.begin(), h_in.end(), [&](u64 a, u64 b) { return order_key(a, ybits, hbits) < order_key(b, ybits, hbits); });
+            std::vector<u64> h_out(n); (void)hipMemcpy(h_out.data(), res, n * 8, hipMemcpyDeviceToHost);
+            ok = ok && h_out == h_in;
+        }
+        printf("n = %llu: %s  (order violations %llu, checksum %s)  %.3f ms  %.2f G keys/s\n", (unsigned long long)n, ok ? "ok" : "WRONG", h[2],
+               h[1] == h[3] ? "equal" : "DIFFERENT", best, n / best * 1e-6);
+        if (!ok) rc_all = 1;
+    }
+    ctx.pool.destroy();
+    return rc_all;
+}

@@ -268,43 +268,34 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
     std::unique_ptr<lrge_hip_seqset, void (*)(lrge_hip_seqset *)> guard(new lrge_hip_seqset(), lrge_hip_seqset_free);
     lrge_hip_seqset *s = guard.get();
     s->ctx = ctx; s->n = n; s->pooled = true;
-    s->h_woff.resize((size_t)n + 1); s->h_len.resize(n ? n : 1); s->h_boff.resize((size_t)n + 1);
-    u64 w = 0;
-    for (u32 i = 0; i < n; ++i) {
-        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] >= (1ULL << 31)) {
-            LRGE_SET_ERR(ctx, "read %u: bad offsets or length >= 2^31", i); return LRGE_ERR_INVALID;
+    // one pass over the offsets: word offsets, lengths, sketch chunk map (read -> first chunk, fixed for the life of the set)
+    s->h_woff.resize((size_t)n + 1); s->h_len.resize(n ? n : 1); s->h_cs.resize((size_t)n + 1);
+    u64 w = 0, nc = 0;
+    {
+        u64 *hw = s->h_woff.data(); u32 *hl = s->h_len.data(), *hc = s->h_cs.data();
+        u32 max_len = 0; bool has_empty = false;
+        for (u32 i = 0; i < n; ++i) {
+            const u64 d = offsets[i + 1] - offsets[i];
+            if (offsets[i + 1] < offsets[i] || d >= (1ULL << 31)) {
+                LRGE_SET_ERR(ctx, "read %u: bad offsets or length >= 2^31", i); return LRGE_ERR_INVALID;
+            }
+            const u32 len = (u32)d;
+            hw[i] = w; hl[i] = len; hc[i] = (u32)nc;
+            w += (len + 31) / 32; nc += (len + SK_CHUNK - 1) / SK_CHUNK;
+            has_empty |= len == 0;
+            max_len = len > max_len ? len : max_len;
         }
-        u32 len = (u32)(offsets[i + 1] - offsets[i]);
-        s->h_woff[i] = w; s->h_len[i] = len; s->h_boff[i] = offsets[i] - offsets[0];
-        w += (len + 31) / 32;
-        if (len == 0) s->has_empty = true;
-        if (len > s->max_len) s->max_len = len;
+        hw[n] = w; hc[n] = (u32)nc;
+        s->max_len = max_len; s->has_empty = has_empty;
     }
-    s->h_woff[n] = w; s->n_words = w;
+    s->n_words = w; s->n_chunks = nc;
     s->total_bases = n ? offsets[n] - offsets[0] : 0;
-    s->h_boff[n] = s->total_bases;
     if (name_rank) {
         s->has_rank = true;
         s->h_rank.assign(name_rank, name_rank + n);
         s->dup_rank = ranks_have_duplicate(s->h_rank);
     }
-    {   // sketch chunk map (read -> first chunk), fixed for the life of the set
-        s->h_cs.resize((size_t)n + 1);
-        u64 nc = 0;
-        for (u32 i = 0; i < n; ++i) { s->h_cs[i] = (u32)nc; nc += (s->h_len[i] + SK_CHUNK - 1) / SK_CHUNK; }
-        s->n_chunks = nc;
-        s->h_cs[n] = (u32)nc;
-    }
     const u64 n_blk = div_up(w, PACK_WORDS);
-    {   // k_pack: read that holds the first word of every block
-        s->h_blk.resize((size_t)n_blk + 1);
-        u32 r = 0;
-        for (u64 b = 0; b < n_blk; ++b) {
-            const u64 w0 = b * PACK_WORDS;
-            while (r + 1 < n && s->h_woff[r + 1] <= w0) ++r;
-            s->h_blk[b] = r;
-        }
-    }
     hipError_t e = hipSuccess;
     auto alloc = [&](size_t bytes) -> void * { return ctx->pool.alloc(bytes, &e); };
     const size_t nw = (size_t)(w ? w : 1);
@@ -354,8 +345,27 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
             return hipMemcpyAsync(dm + off, src_, bytes, hipMemcpyHostToDevice, cs);       // (arena full: piecewise, from the set's own vectors)
         };
         HIPCHK(ctx, put(o_woff, s->h_woff.data(), ((size_t)n + 1) * 8));
-        HIPCHK(ctx, put(o_boff, s->h_boff.data(), ((size_t)n + 1) * 8));
-        HIPCHK(ctx, put(o_blk, s->h_blk.data(), (size_t)(n_blk + 1) * 4));
+        {   // k_pack's two maps exist for the upload only: base offset of every read relative to the first, and the read that
+            // holds the first word of every block -- produced where they travel from (the arena; the set's own vectors when
+            // it is full, because an asynchronous copy reads them after this call has returned)
+            u64 *boff; u32 *blk;
+            if (hm) { boff = (u64 *)(hm + o_boff); blk = (u32 *)(hm + o_blk); }
+            else { s->h_boff.resize((size_t)n + 1); s->h_blk.resize((size_t)n_blk + 1); boff = s->h_boff.data(); blk = s->h_blk.data(); }
+            const u64 o0 = n ? offsets[0] : 0;
+            for (u32 i = 0; i <= n; ++i) boff[i] = n ? offsets[i] - o0 : 0;
+            const u64 *hw = s->h_woff.data();
+            u32 r = 0;
+            for (u64 bq = 0; bq < n_blk; ++bq) {
+                const u64 w0 = bq * PACK_WORDS;
+                while (r + 1 < n && hw[r + 1] <= w0) ++r;
+                blk[bq] = r;
+            }
+            blk[n_blk] = 0;
+            if (!hm) {
+                HIPCHK(ctx, put(o_boff, boff, ((size_t)n + 1) * 8));
+                HIPCHK(ctx, put(o_blk, blk, (size_t)(n_blk + 1) * 4));
+            }
+        }
         if (s->n_chunks < (1ULL << 32)) HIPCHK(ctx, put(o_cs, s->h_cs.data(), ((size_t)n + 1) * 4));
         if (n) {
             HIPCHK(ctx, put(o_len, s->h_len.data(), (size_t)n * 4));
@@ -2360,11 +2370,24 @@ extern "C" int lrge_hip_median(const float *estimates, uint64_t n, int finite, i
         return LRGE_ERR_INVALID;                           // "Quantile must be between 0.0 and 1.0"
     std::vector<float> v;
     v.reserve(n);
-    for (u64 i = 0; i < n; ++i) if (!finite || std::isfinite(estimates[i])) v.push_back(estimates[i]);
+    // kept values, and on the way a histogram over the top bits of their patterns: for non-negative floats the bit pattern
+    // orders like the value, so the bin that holds an order statistic is known after one pass
+    constexpr int kShift = 17, kBins = 1 << (31 - kShift);
+    std::vector<u32> hist((size_t)kBins + 1, 0);
+    bool radix_ok = true;
+    v.resize(n);
+    size_t nv = 0;
+    for (u64 i = 0; i < n; ++i) {
+        const float e = estimates[i];
+        u32 b; memcpy(&b, &e, 4);
+        if (finite && (b & 0x7F800000u) == 0x7F800000u) continue;      // infinity or NaN
+        if ((b >> 31) || e != e) radix_ok = false; else ++hist[b >> kShift];
+        v[nv++] = e;
+    }
+    v.resize(nv);
     if (v.empty()) return LRGE_OK;
     // the reference sorts the whole vector (estimate.rs:90-95); only the (at most six) order statistics the three
-    // quantiles read are needed, and an order statistic does not depend on how ties are arranged: select them in
-    // ascending order, each inside the range the previous selection left unsorted
+    // quantiles read are needed, and an order statistic does not depend on how ties are arranged
     std::vector<size_t> need;
     auto want = [&](float q) { const size_t i = quantile_index(v.size(), q); need.push_back(i); if (i + 1 < v.size()) need.push_back(i + 1); };
     want(0.5f);
@@ -2372,18 +2395,50 @@ extern "C" int lrge_hip_median(const float *estimates, uint64_t n, int finite, i
     if (has_upper) want(upper_q);
     std::sort(need.begin(), need.end());
     need.erase(std::unique(need.begin(), need.end()), need.end());
-    // select the middle one of the needed order statistics first, then the rest inside the halves it leaves: every later
-    // selection works on a fraction of the vector (one pass over all of it + the halves, instead of a suffix per statistic)
-    struct Sel {
-        static void run(std::vector<float> &v, const std::vector<size_t> &need, size_t a, size_t b, size_t lo, size_t hi) {
-            if (a >= b) return;
-            const size_t m = (a + b) / 2, i = need[m];
-            std::nth_element(v.begin() + lo, v.begin() + i, v.begin() + hi);
-            run(v, need, a, m, lo, i);
-            run(v, need, m + 1, b, i + 1, hi);
+    if (radix_ok) {
+        // gather the (few) bins that hold a needed rank, select inside them, and put each statistic at its index of `v`
+        // (quantile_f32 below reads v[idx] and v[idx + 1] only)
+        std::vector<u32> cum((size_t)kBins + 1, 0);
+        for (int b = 0; b < kBins; ++b) cum[(size_t)b + 1] = cum[b] + hist[b];
+        std::vector<int> bin_of(need.size());
+        std::vector<int> bins;
+        for (size_t k = 0; k < need.size(); ++k) {
+            const int b = (int)(std::upper_bound(cum.begin(), cum.end(), (u32)need[k]) - cum.begin()) - 1;
+            bin_of[k] = b;
+            if (bins.empty() || bins.back() != b) bins.push_back(b);       // (need is ascending, so are the bins)
         }
-    };
-    Sel::run(v, need, 0, need.size(), 0, v.size());
+        std::vector<std::vector<float>> members(bins.size());
+        for (size_t t = 0; t < bins.size(); ++t) members[t].reserve(hist[bins[t]]);
+        std::vector<int8_t> slot_of((size_t)kBins, (int8_t)-1);      // (16 K bins: ~200 of 50 000 clustered estimates per bin)
+        for (size_t t = 0; t < bins.size(); ++t) slot_of[bins[t]] = (int8_t)t;
+        for (const float e : v) {
+            u32 b; memcpy(&b, &e, 4);
+            const int t = slot_of[b >> kShift];
+            if (t >= 0) members[(size_t)t].push_back(e);
+        }
+        std::vector<float> stat(need.size());
+        for (size_t k = 0; k < need.size(); ++k) {
+            const size_t t = (size_t)(std::find(bins.begin(), bins.end(), bin_of[k]) - bins.begin());
+            std::vector<float> &m = members[t];
+            const size_t r = need[k] - cum[bin_of[k]];
+            std::nth_element(m.begin(), m.begin() + r, m.end());
+            stat[k] = m[r];
+        }
+        for (size_t k = 0; k < need.size(); ++k) v[need[k]] = stat[k];
+    } else {
+        // negative values or NaNs (finite == 0): comparison-based selection.  The middle one of the needed order statistics
+        // first, then the rest inside the halves it leaves: every later selection works on a fraction of the vector
+        struct Sel {
+            static void run(std::vector<float> &v, const std::vector<size_t> &need, size_t a, size_t b, size_t lo, size_t hi) {
+                if (a >= b) return;
+                const size_t m = (a + b) / 2, i = need[m];
+                std::nth_element(v.begin() + lo, v.begin() + i, v.begin() + hi);
+                run(v, need, a, m, lo, i);
+                run(v, need, m + 1, b, i + 1, hi);
+            }
+        };
+        Sel::run(v, need, 0, need.size(), 0, v.size());
+    }
     ok[1] = quantile_f32(v, 0.5f, &out[1]);
     if (has_lower) ok[0] = quantile_f32(v, lower_q, &out[0]);
     if (has_upper) ok[2] = quantile_f32(v, upper_q, &out[2]);

@@ -53,6 +53,28 @@ def test_host_median_matches_reference_kats():
         engine.median(np.ones(3, dtype=np.float32), True, None, 0.5)   # reference panics (estimate.rs:109)
 
 
+def test_host_median_selection_equals_a_full_sort(oracle):
+    """lrge_hip_median selects the order statistics it needs (bin histogram over the float patterns + selection inside the
+    bins; comparison-based selection when negative values are present) where the reference sorts everything
+    (estimate.rs:90-95): same result bit for bit, on ties, clusters, infinities, zeros and negatives."""
+    from lrge_amd import engine
+    rng = np.random.Generator(np.random.PCG64(11))
+    cases = []
+    for n in (1, 2, 3, 7, 64, 1000, 50_000):
+        cases.append(rng.lognormal(18.0, 0.6, n).astype(np.float32))                      # what genome-size estimates look like
+        cases.append(np.round(rng.lognormal(3.0, 0.3, n)).astype(np.float32))             # heavy ties
+        c = rng.lognormal(18.0, 0.6, n).astype(np.float32); c[rng.random(n) < 0.3] = np.inf; cases.append(c)
+        cases.append(np.full(n, 4.25, dtype=np.float32))                                  # one value
+        c = rng.normal(0.0, 5.0, n).astype(np.float32); c[rng.random(n) < 0.1] = 0.0; cases.append(c)   # negatives, zeros
+    for v in cases:
+        for finite in (True, False):
+            for lo, hi in ((0.15, 0.65), (0.0, 1.0), (None, None), (0.5, None)):
+                got, exp = engine.median(v, finite, lo, hi), oracle.median(v, finite, lo, hi)
+                # (inf * 0 in the interpolation gives NaN in the reference too: compare patterns, not values)
+                bits = lambda t: tuple(None if x is None else np.float32(x).view(np.uint32) & (0xFFFFFFFF if x == x else 0x7F800000) for x in t)
+                assert bits(got) == bits(exp), (v.size, finite, lo, hi, got, exp)
+
+
 def test_name_ranks_follow_strcmp():
     from lrge_amd import engine
     a, b = engine.name_ranks([b"r2", b"r10", b"R1"], [b"r10", b"a"])

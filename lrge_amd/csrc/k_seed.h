@@ -35,13 +35,17 @@ __device__ __forceinline__ u64 index_y(const SeedParams &sp, u64 i) {
 // K3: one lane per query minimizer: probe the index.  hs = list start, hc = raw list length (0 when
 // the hash is absent).  The mid_occ filter and skip_seed are applied by k_seed_counts, after the query
 // occurrence filter had its say.
+// hn (may be null): the kept list length k_seed_counts would derive from hc -- written here when no name checks are needed
+// (two-set runs without shared reads), so that the common path, in which mm_seed_mz_flt removes nothing, needs no second
+// pass over the 10^8 counters.
 __global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, u64 n_mz, SeedParams sp,
-                                                u32 *__restrict__ hs, u32 *__restrict__ hc) {
+                                                u32 *__restrict__ hs, u32 *__restrict__ hc, u32 *__restrict__ hn) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_mz) return;
     u64 st = 0; u32 cnt = 0;
     if (!ht_lookup(sp.ht, sp.ht_cap, qx[i] >> 8, &st, &cnt)) { st = 0; cnt = 0; }
     hs[i] = (u32)st; hc[i] = cnt;
+    if (hn) hn[i] = (cnt != 0 && (i64)cnt <= (i64)sp.mid_occ) ? cnt : 0;   // m[i].n > max_occ -> flt (as in k_seed_counts)
 }
 
 // hn = list length of a KEPT seed (0 when absent, removed by mm_seed_mz_flt, or n > mid_occ -> flt),

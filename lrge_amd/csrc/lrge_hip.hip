@@ -1436,13 +1436,16 @@ int OverlapRun::seeds() {
         if (!shared) sp.check_names = 0;
     }
     sp.no_dual = job.dual ? 0 : 1;
-    hs = sc.get<u32>(Mq + 1); hc = sc.get<u32>(Mq + 1); hn = sc.get<u32>(Mq + 1); hv = sc.get<u32>(Mq + 1); krank = sc.get<u32>(Mq + 1);
+    // without name checks every kept hit survives skip_seed: hv IS hn, and k_lookup fills it (k_seed_counts only runs again
+    // if the exact query occurrence filter had to change hc)
+    const bool counts_in_lookup = !sp.check_names;
+    hs = sc.get<u32>(Mq + 1); hc = sc.get<u32>(Mq + 1); hn = sc.get<u32>(Mq + 1); hv = counts_in_lookup ? hn : sc.get<u32>(Mq + 1); krank = sc.get<u32>(Mq + 1);
     u32 *d_qtot = sc.get<u32>((size_t)nq + 1);
     if (!hs || !hc || !hn || !hv || !krank || !d_qtot) return LRGE_ERR_DEVICE;
     h_qtot.assign((size_t)nq + 1, 0);
     if (Mq) {
         StageTimer t(ctx, LRGE_T_LOOKUP), tk(ctx, LRGE_T_K_LOOKUP);
-        hipLaunchKernelGGL(k_lookup, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, Mq, sp, hs, hc);
+        hipLaunchKernelGGL(k_lookup, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.x, Mq, sp, hs, hc, counts_in_lookup ? hn : (u32 *)nullptr);
         KCHK(ctx);
         tk.stop(); t.stop();
         ctx->counters[LRGE_C_LOOKUP_LAUNCHES] += 1;
@@ -1488,11 +1491,12 @@ int OverlapRun::seeds() {
         return LRGE_OK;
     };
     bool qocc_possible = false;
+    bool hc_changed = false;       // by run_exact_qocc: k_lookup's own kept counts are stale then
     if (Mq > 0 && P.q_occ_frac > 0.0f && ix->mid_occ > 0)   // only queries with more minimizers than mid_occ can be affected
         for (u32 q = 0; q < nq && !qocc_possible; ++q) qocc_possible = (i64)(h_mzoff[q + 1] - h_mzoff[q]) > (i64)ix->mid_occ;
     u32 *d_qf = nullptr; u32 qf = 0; bool qf_on_side = false;
     if (qocc_possible) {
-        if (ctx->opt("QOCC_EXACT")) { rc = run_exact_qocc(); if (rc) return rc; }
+        if (ctx->opt("QOCC_EXACT")) { rc = run_exact_qocc(); if (rc) return rc; hc_changed = true; }
         else {
             // cheap conservative check, on the side stream beside the hit counting below (both only read the lookup
             // results); its verdict travels to the host with the next sync (no extra round trip)
@@ -1535,8 +1539,10 @@ int OverlapRun::seeds() {
     auto run_counts = [&]() -> int {
         StageTimer t(ctx, LRGE_T_LOOKUP);
         if (Mq) {
-            hipLaunchKernelGGL(k_seed_counts, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.y, Mq, sp, hs, hc, hn, hv);
-            KCHK(ctx);
+            if (!counts_in_lookup || hc_changed) {
+                hipLaunchKernelGGL(k_seed_counts, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, so.y, Mq, sp, hs, hc, hn, hv);
+                KCHK(ctx);
+            }
             // rank of every kept seed inside its query (= its index in minimap2's mini_pos[]): only chain records carry it
             // (mm_est_err's dv); a count-only run packs its anchors without it (OverlapRun::batch) and skips the flag + scan
             const u32 bits_rpos_ = std::max<u32>(1, ceil_log2_u64((u64)T->max_len + 1)), bits_rid_ = std::max<u32>(1, ceil_log2_u64((u64)T->n));
@@ -1570,6 +1576,7 @@ int OverlapRun::seeds() {
     if (d_qf && qf) {   // the pre-check could not rule the filter out: apply it, then count again
         d_qf = nullptr;
         rc = run_exact_qocc(); if (rc) return rc;
+        hc_changed = true;
         rc = run_counts(); if (rc) return rc;
     }
     return LRGE_OK;

@@ -197,9 +197,13 @@ static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32
 //   item(tile, w, r, lane) = tile*RS_TILE + w*RS_ITEMS*64 + r*64 + lane
 // so that per-wave running digit counters give a stable rank.
 // ------------------------------------------------------------------------------------------
+#ifndef RS_THREADS
 #define RS_THREADS 256
+#endif
 #define RS_WAVES (RS_THREADS / 64)
+#ifndef RS_ITEMS
 #define RS_ITEMS 16
+#endif
 #define RS_TILE (RS_THREADS * RS_ITEMS)
 
 // SEG: segmented sort.  The array is a sequence of independent segments (e.g. one per query) that must

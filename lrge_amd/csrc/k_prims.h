@@ -2,12 +2,28 @@
 // written for gfx950: 64-lane wavefronts, ballot-based digit matching, LDS counters.
 #pragma once
 #include "internal.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // wave helpers
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ULL << lane_id()) - 1ULL; }
+
+// Lanes of the wavefront that hold the same digit as this lane ("match any"; gfx9 has no instruction for it).  Per digit bit:
+// the sign-extended bit (v_bfe_i32), its ballot (one v_cmp), and acc |= ballot ^ bit on each half of the mask (one v_bitop3
+// each) -- 4 instructions; the plain `m &= bit ? bal : ~bal` compiled to 10.  acc collects the lanes that DIFFER in some bit;
+// the class is what is left of the lanes under consideration.  NB: the number of bits is a compile-time or wavefront-uniform
+// value.
+__device__ __forceinline__ void wave_match_bit(u32 d, int b, u32 &acc_lo, u32 &acc_hi) {
+    const u32 nb = (u32)__builtin_amdgcn_sbfe((i32)d, (u32)b, 1u);      // 0 or ~0
+    const u64 bal = __ballot(nb != 0);
+    acc_lo = __builtin_amdgcn_bitop3_b32(acc_lo, (u32)bal, nb, 0xF6);        // a | (b ^ c)
+    acc_hi = __builtin_amdgcn_bitop3_b32(acc_hi, (u32)(bal >> 32), nb, 0xF6);
+}
+// before = same-digit lanes below this one, total = same-digit lanes: the stable rank ingredients of one row of 64 items
+__device__ __forceinline__ u32 wave_match_before(u32 m_lo, u32 m_hi) { return __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u)); }
+__device__ __forceinline__ u32 wave_match_total(u32 m_lo, u32 m_hi) { return (u32)__popc(m_lo) + (u32)__popc(m_hi); }
 
 __device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
 #pragma unroll
@@ -279,7 +295,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     const u64 base = tile0 + l0;
     u64 k[RS_ITEMS], v[RS_ITEMS];
     u32 rank[RS_ITEMS];
-    const u64 lt = lanemask_lt();
     // all loads of the tile are issued up front: the values arrive while the keys are being ranked
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n_tile ? keys_in[base + (u64)r * 64] : ~0ULL;
@@ -289,21 +304,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
-        bool valid = l0 + (u32)r * 64 < n_tile;
-        u32 d = (u32)(k[r] >> shift) & dmask;
-        u64 m = __ballot(valid);
+        const bool valid = l0 + (u32)r * 64 < n_tile;
+        const u32 d = (u32)(k[r] >> shift) & dmask;
+        const u64 mv = __ballot(valid);
+        u32 a_lo = 0, a_hi = 0;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            u64 bal = __ballot((d >> b) & 1);
-            m &= ((d >> b) & 1) ? bal : ~bal;
-        }
-        u32 before = (u32)__popcll(m & lt);
-        u32 leader = (u32)__ffsll((unsigned long long)m) - 1;
-        u32 old = 0;
-        // one returning LDS add per (row, digit present): the 16 rows' counter updates queue up in the LDS pipeline instead of
-        // forming a read -> wait -> write chain per row (same wavefront, in-order LDS: row r + 1 sees row r's add)
-        if (valid && lane == leader) old = atomicAdd(&cnt[w][d], (u32)__popcll(m));
-        old = __shfl(old, valid ? leader : lane, 64);
+        for (int b = 0; b < 8; ++b) wave_match_bit(d, b, a_lo, a_hi);
+        const u32 m_lo = (u32)mv & ~a_lo, m_hi = (u32)(mv >> 32) & ~a_hi;
+        const u32 before = wave_match_before(m_lo, m_hi);
+        // every lane of a digit class reads the class counter (one broadcast LDS read), the lowest lane of the class -- the one
+        // with nobody before it -- moves it on: no leader search, no cross-lane shuffle.  Same wavefront, in-order LDS: row
+        // r + 1 reads what row r wrote.
+        const u32 old = cnt[w][d];
+        if (valid && before == 0) cnt[w][d] = old + wave_match_total(m_lo, m_hi);
         rank[r] = old + before;
     }
     __syncthreads();
@@ -586,73 +599,75 @@ static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n,
 // Segments above the variant's capacity stay on the global segmented sort.
 // ------------------------------------------------------------------------------------------
 struct SegDesc { u32 start, len, seg, pad; };
-#define LSORT_BYTES(THREADS, ITEMS) ((size_t)(THREADS) * (ITEMS) * 8 + (size_t)((THREADS) / 64) * 256 * 4 + 16)
+// DB = digit bits of a pass.  9-bit digits (the 512- and 1024-thread variants: one digit per thread in the scan step) sort the
+// 34 key bits of the headline workload in 4 passes instead of 5; their counters are 16-bit (a count is at most CAP <= 16384)
+// so that the LDS footprint, hence the residency, stays that of the 8-bit form.
+#ifndef LSORT_DB
+#define LSORT_DB 9      // digit bits of the 512- and 1024-thread variants
+#endif
+#define LSORT_BYTES(THREADS, ITEMS, DB) ((size_t)(THREADS) * (ITEMS) * 8 + (size_t)((THREADS) / 64) * (1 << (DB)) * ((DB) > 8 ? 2 : 4) + 64)
 
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, int DB>
 __global__ __launch_bounds__(THREADS) void k_seg_sort_local(const u64 *__restrict__ pk_in, u64 *__restrict__ out_k, u64 *__restrict__ out_v,
                                                             const SegDesc *__restrict__ segs, UnpackParams up, int nbits) {
-    constexpr int WAVES = THREADS / 64, CAP = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64, CAP = THREADS * ITEMS, NDIG = 1 << DB;
+    static_assert(THREADS >= NDIG, "one thread per digit in the scan step");
+    typedef typename std::conditional<(DB > 8), u16, u32>::type CT;
     extern __shared__ u64 lsort_mem[];
     u64 *stage = lsort_mem;                                   // [CAP]
-    u32 *cnt = (u32 *)(lsort_mem + CAP);                      // [WAVES][256]
-    u32 *wtot = cnt + WAVES * 256;                            // [4]: totals of the four 64-digit groups
+    u32 *wtot = (u32 *)(lsort_mem + CAP);                     // [NDIG / 64]: totals of the 64-digit groups
+    CT *cnt = (CT *)(wtot + 16);                              // [WAVES][NDIG]
     const SegDesc sd = segs[blockIdx.x];
     const u32 n = sd.len;
     const u64 *src = pk_in + sd.start;
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     const u32 l0 = w * (ITEMS * 64) + lane;
-    const u64 lt = lanemask_lt();
     u64 k[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n ? src[l0 + (u32)r * 64] : ~0ULL;
-    // the key bits are dealt evenly over the passes (34 bits: 7,7,7,7,6 instead of 8,8,8,8,2): a digit bit costs one ballot per
-    // row whether the pass needs it or not, and any stable LSD split gives the same order
-    const int passes = nbits > 0 ? (nbits + 7) / 8 : 1;
+    // the key bits are dealt evenly over the passes (34 bits in 8-bit digits: 7,7,7,7,6 instead of 8,8,8,8,2): a digit bit costs
+    // one ballot per row whether the pass needs it or not, and any stable LSD split gives the same order
+    const int passes = nbits > 0 ? (nbits + DB - 1) / DB : 1;
     const int bpp = nbits > 0 ? (nbits + passes - 1) / passes : 1;
     for (int p = 0; p < passes; ++p) {
         const int shift = p * bpp;
         const int nbp = nbits - shift >= bpp ? bpp : (nbits > shift ? nbits - shift : 1);
         const u32 dmask = (1u << nbp) - 1u;
-        for (u32 i = threadIdx.x; i < (u32)WAVES * 256; i += THREADS) cnt[i] = 0;
+        for (u32 i = threadIdx.x; i < (u32)WAVES * NDIG; i += THREADS) cnt[i] = 0;
         __syncthreads();
         u32 rank[ITEMS];
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const u32 d = (u32)(k[r] >> shift) & dmask;
-            u64 m = ~0ULL;
+            u32 a_lo = 0, a_hi = 0;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                if (b < nbp) {                                  // (wavefront-uniform)
-                    const u64 bal = __ballot((d >> b) & 1);
-                    m &= ((d >> b) & 1) ? bal : ~bal;
-                }
-            }
-            const u32 before = (u32)__popcll(m & lt);
-            const u32 leader = (u32)__ffsll((unsigned long long)m) - 1;
-            u32 old = 0;
-            if (lane == leader) old = atomicAdd(&cnt[w * 256 + d], (u32)__popcll(m));   // see k_rs_scatter
-            old = __shfl(old, leader, 64);
+            for (int b = 0; b < DB; ++b)
+                if (b < nbp) wave_match_bit(d, b, a_lo, a_hi);   // (wavefront-uniform)
+            const u32 m_lo = ~a_lo, m_hi = ~a_hi;
+            const u32 before = wave_match_before(m_lo, m_hi);
+            const u32 old = cnt[w * NDIG + d];                  // see k_rs_scatter
+            if (before == 0) cnt[w * NDIG + d] = (CT)(old + wave_match_total(m_lo, m_hi));
             rank[r] = old + before;
         }
         __syncthreads();
-        // digit totals -> exclusive scan over digits -> start of every (wave, digit) run (threads 0..255 = wavefronts 0..3)
+        // digit totals -> exclusive scan over digits -> start of every (wave, digit) run (thread t < NDIG = digit t)
         u32 tot = 0, inc = 0;
-        if (threadIdx.x < 256) {
-            for (int ww = 0; ww < WAVES; ++ww) tot += cnt[ww * 256 + threadIdx.x];
+        if (threadIdx.x < NDIG) {
+            for (int ww = 0; ww < WAVES; ++ww) tot += cnt[ww * NDIG + threadIdx.x];
             inc = wave_incl_scan_u32(tot);
             if (lane == 63) wtot[threadIdx.x >> 6] = inc;
         }
         __syncthreads();
-        if (threadIdx.x < 256) {
+        if (threadIdx.x < NDIG) {
             u32 run = inc - tot;
             for (u32 g = 0; g < (threadIdx.x >> 6); ++g) run += wtot[g];
-            for (int ww = 0; ww < WAVES; ++ww) { const u32 c = cnt[ww * 256 + threadIdx.x]; cnt[ww * 256 + threadIdx.x] = run; run += c; }
+            for (int ww = 0; ww < WAVES; ++ww) { const u32 c = cnt[ww * NDIG + threadIdx.x]; cnt[ww * NDIG + threadIdx.x] = (CT)run; run += c; }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const u32 d = (u32)(k[r] >> shift) & dmask;
-            stage[cnt[w * 256 + d] + rank[r]] = k[r];
+            stage[cnt[w * NDIG + d] + rank[r]] = k[r];
         }
         __syncthreads();
         if (p + 1 < passes) {

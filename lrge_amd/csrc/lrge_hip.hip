@@ -128,10 +128,10 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     else { ctx->pin = nullptr; (void)hipGetLastError(); }       // reads fall back to pageable copies
     // segment-local sort variants: the two larger ones need more than the default 64 KB of LDS per workgroup
     ctx->lsort_ok[0] = true;
-    ctx->lsort_ok[1] = ctx->lsort_ok[0] && hipFuncSetAttribute((const void *)k_seg_sort_local<512, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                               (int)LSORT_BYTES(512, 16)) == hipSuccess;
-    ctx->lsort_ok[2] = ctx->lsort_ok[0] && hipFuncSetAttribute((const void *)k_seg_sort_local<1024, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                               (int)LSORT_BYTES(1024, 16)) == hipSuccess;
+    ctx->lsort_ok[1] = ctx->lsort_ok[0] && hipFuncSetAttribute((const void *)k_seg_sort_local<512, 16, LSORT_DB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                               (int)LSORT_BYTES(512, 16, LSORT_DB)) == hipSuccess;
+    ctx->lsort_ok[2] = ctx->lsort_ok[0] && hipFuncSetAttribute((const void *)k_seg_sort_local<1024, 16, LSORT_DB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                               (int)LSORT_BYTES(1024, 16, LSORT_DB)) == hipSuccess;
     (void)hipGetLastError();
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
@@ -1719,17 +1719,17 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
             }
             const int nbits = (int)kl.sh_q();
             if (d_seg[2]) {
-                hipLaunchKernelGGL((k_seg_sort_local<1024, 16>), dim3((u32)h_local[2].size()), dim3(1024), LSORT_BYTES(1024, 16), side ? ctx->stream2 : ctx->stream,
+                hipLaunchKernelGGL((k_seg_sort_local<1024, 16, LSORT_DB>), dim3((u32)h_local[2].size()), dim3(1024), LSORT_BYTES(1024, 16, LSORT_DB), side ? ctx->stream2 : ctx->stream,
                                    akey, aval, aval2, d_seg[2], up, nbits);
                 KCHK(ctx);
                 if (side) HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
             }
             if (d_seg[1]) {
-                hipLaunchKernelGGL((k_seg_sort_local<512, 16>), dim3((u32)h_local[1].size()), dim3(512), LSORT_BYTES(512, 16), ctx->stream, akey, aval, aval2, d_seg[1], up, nbits);
+                hipLaunchKernelGGL((k_seg_sort_local<512, 16, LSORT_DB>), dim3((u32)h_local[1].size()), dim3(512), LSORT_BYTES(512, 16, LSORT_DB), ctx->stream, akey, aval, aval2, d_seg[1], up, nbits);
                 KCHK(ctx);
             }
             if (d_seg[0]) {
-                hipLaunchKernelGGL((k_seg_sort_local<256, 8>), dim3((u32)h_local[0].size()), dim3(256), LSORT_BYTES(256, 8), ctx->stream, akey, aval, aval2, d_seg[0], up, nbits);
+                hipLaunchKernelGGL((k_seg_sort_local<256, 8, 8>), dim3((u32)h_local[0].size()), dim3(256), LSORT_BYTES(256, 8, 8), ctx->stream, akey, aval, aval2, d_seg[0], up, nbits);
                 KCHK(ctx);
             }
             rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up, A - n_local_items);

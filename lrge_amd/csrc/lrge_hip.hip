@@ -1705,7 +1705,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
             // per anchor); only the larger ones take the tiled global passes
             // the classes touch disjoint segments: the largest class runs on the side stream beside the others and the
             // tiled passes (fork / join with events), so that its one-block-per-CU tail does not stand alone
-            const bool side = !h_local[2].empty() && (!h_local[1].empty() || !h_tiles.empty());
+            const bool side = !h_local[2].empty() && (!h_local[1].empty() || !h_tiles.empty()) && !ctx->opt("LSORT_SERIAL");
             SegDesc *d_seg[3] = {nullptr, nullptr, nullptr};
             for (int cls = 0; cls < 3; ++cls) {
                 if (h_local[cls].empty()) continue;

@@ -2,9 +2,9 @@
 //
 // k_chain_hw resolves the order-dependent state of mg_lchain_dp's predecessor loop with cross-lane
 // scans; that costs ~195 VALU instructions per step of two anchors, of which comput_sc is ~35 -- the
-// kernel is bound by VALU issue (4 cycles per wave64 instruction), not by memory.  Here every LANE owns
+// kernel is bound by VALU issue and per-step latency, not by memory.  Here every LANE owns
 // one (query, target, strand) group and runs the plain sequential loop over its candidates, so the
-// scans disappear: a candidate costs ~60 lane-operations and one wave instruction serves 64 groups.
+// scans disappear: a candidate costs ~34 lane-operations and one wave instruction serves 64 groups.
 //   * the last 32 anchors of each lane's group live in VGPR arrays (fully unrolled loops, static
 //     indices), shifted by one slot per step;
 //   * the t[] marks of the sequential loop become a 32-bit register mask (a mark is only ever read
@@ -15,7 +15,8 @@
 //   * backtrack: every lane tracks its best chain end during the DP and walks that one chain; when the
 //     first chain is accepted and no records are wanted that settles the group's flags, otherwise the
 //     group falls back to the wave-wide backtrack_group().
-// A step takes ~2000 instructions regardless of the group size, so the latency per anchor is ~10x
+// A step takes ~1400 instructions regardless of the group size (4.1 us: ~7 cycles per instruction of
+// one wavefront, measured issue costs in tools/micro/valu_rate.hip), so the latency per anchor is ~8x
 // that of k_chain_hw: groups above LPG_MAX_N anchors stay on k_chain_hw (the host splits the sorted
 // list), everything else -- ~90 % of the anchors of the headline workload -- runs here.
 #pragma once

@@ -146,11 +146,14 @@ struct MinWindow {  // shift-register form of mm_sketch's ring buffer + running 
             for (int j = 0; j + 1 < W; ++j)
                 if (minx == wx[j] && wy[j] != miny) emit(wx[j], wy[j]);
         }
-        if (ix <= minx) {
-            if (l >= W + K && minx != NONE) emit(minx, miny);
+        // "the old minimum leaves": one emission site for both ways it happens (a new element that is not larger, or the
+        // minimum falling out of the window) -- the lanes of a wavefront take both in the same step all the time, and
+        // every site carries the whole output-buffer code
+        const bool le = ix <= minx;
+        if (minx != NONE && ((le && l >= W + K) || (!le && evicted && l >= W + K - 1))) emit(minx, miny);
+        if (le) {
             minx = ix; miny = iy; mi = W - 1;
         } else if (evicted) {
-            if (l >= W + K - 1 && minx != NONE) emit(minx, miny);
             minx = NONE;
 #pragma unroll
             for (int j = 0; j < W; ++j)

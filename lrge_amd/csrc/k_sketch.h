@@ -142,9 +142,15 @@ struct MinWindow {  // shift-register form of mm_sketch's ring buffer + running 
         wx[W - 1] = ix; wy[W - 1] = iy;
         mi -= 1;
         if (l == W + K - 1 && minx != NONE) {  // first full window: flush identical minima
+            // (identical minima = the same k-mer twice inside w positions: rare, so ONE branch guards the per-slot ones)
+            bool any = false;
 #pragma unroll
-            for (int j = 0; j + 1 < W; ++j)
-                if (minx == wx[j] && wy[j] != miny) emit(wx[j], wy[j]);
+            for (int j = 0; j + 1 < W; ++j) any |= minx == wx[j] && wy[j] != miny;
+            if (any) {
+#pragma unroll
+                for (int j = 0; j + 1 < W; ++j)
+                    if (minx == wx[j] && wy[j] != miny) emit(wx[j], wy[j]);
+            }
         }
         // "the old minimum leaves": one emission site for both ways it happens (a new element that is not larger, or the
         // minimum falling out of the window) -- the lanes of a wavefront take both in the same step all the time, and
@@ -159,9 +165,14 @@ struct MinWindow {  // shift-register form of mm_sketch's ring buffer + running 
             for (int j = 0; j < W; ++j)
                 if (minx >= wx[j]) { minx = wx[j]; miny = wy[j]; mi = j; }
             if (l >= W + K - 1 && minx != NONE) {
+                bool any = false;
 #pragma unroll
-                for (int j = 0; j < W; ++j)
-                    if (minx == wx[j] && miny != wy[j]) emit(wx[j], wy[j]);
+                for (int j = 0; j < W; ++j) any |= minx == wx[j] && miny != wy[j];
+                if (any) {
+#pragma unroll
+                    for (int j = 0; j < W; ++j)
+                        if (minx == wx[j] && miny != wy[j]) emit(wx[j], wy[j]);
+                }
             }
         }
     }

@@ -1438,7 +1438,7 @@ int OverlapRun::seeds() {
     sp.no_dual = job.dual ? 0 : 1;
     // without name checks every kept hit survives skip_seed: hv IS hn, and k_lookup fills it (k_seed_counts only runs again
     // if the exact query occurrence filter had to change hc)
-    const bool counts_in_lookup = !sp.check_names;
+    const bool counts_in_lookup = !sp.check_names && !ctx->opt("COUNTS_AFTER_LOOKUP");   // (option: the separate pass, for A/B runs)
     hs = sc.get<u32>(Mq + 1); hc = sc.get<u32>(Mq + 1); hn = sc.get<u32>(Mq + 1); hv = counts_in_lookup ? hn : sc.get<u32>(Mq + 1); krank = sc.get<u32>(Mq + 1);
     u32 *d_qtot = sc.get<u32>((size_t)nq + 1);
     if (!hs || !hc || !hn || !hv || !krank || !d_qtot) return LRGE_ERR_DEVICE;

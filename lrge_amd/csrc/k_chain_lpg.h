@@ -29,7 +29,10 @@
 #ifndef LPG_CH
 #define LPG_CH 8   // anchors per input / output staging chunk
 #endif
-#define LPG_RING_BYTES ((2 * (LPG_CH / 2) * 128 * 2 + LPG_CH * 64) * 8)
+#ifndef LPG_WAVES
+#define LPG_WAVES 1   // wavefronts per workgroup (they share the penalty table; every wavefront has its own ring)
+#endif
+#define LPG_RING_BYTES ((2 * (LPG_CH / 2) * 128 * 2 + LPG_CH * 64) * 8)      // per wavefront
 #define LPG_MAX_AUTO 0xFFFFFFFEu   // split chosen per batch from the group-size census (lrge_hip.hip)
 
 struct LpgChainArgs {
@@ -59,14 +62,14 @@ struct LpgChainArgs {
 // of end_j unless the window is exhausted, and an exhausted window with more candidates behind it takes the slow path,
 // which computes end_j itself.  Saves a compare, a select and an add per candidate and 32 live compare masks.
 template <bool PENTAB, bool FASTREACH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
+__global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
     extern __shared__ i32 pen_tab[];   // [bw + 2] when PENTAB, then the anchor / record staging ring (LPG_RING_BYTES)
     // this kernel's longest wavefronts are the critical path of the chain stage; k_chain_hw's wavefronts on
     // the other stream share the SIMDs and should fill the gaps, not compete for issue slots
     if (R.prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (R.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (R.prio == 1) __builtin_amdgcn_s_setprio(1);
-    const u32 li = blockIdx.x * 64 + threadIdx.x;
+    const u32 li = blockIdx.x * (64 * LPG_WAVES) + threadIdx.x;
     const bool has = li < R.n_list;
     const u32 g = has ? R.list[li] : 0;
     const u32 s0 = has ? R.gstart[g] : 0;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
     const u32 tabn = (u32)bw + 1;
     if (PENTAB) {
-        for (u32 d = threadIdx.x; d < tabn; d += 64) {
+        for (u32 d = threadIdx.x; d < tabn; d += 64 * LPG_WAVES) {
             const float lin_pen = pen_gap * (float)(i32)d + pen_skip * 0.0f;
             float log_pen = mg_log2_dev((float)(i32)(d + 1));
             log_pen = d >= 1 ? log_pen : 0.0f;
@@ -101,10 +104,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // direct-to-LDS loads per array (global_load_lds_dwordx4, no VGPRs) one chunk ahead, and (f, p) records leave
     // as one 32-byte run per lane and chunk.
     //   ring_k / ring_v: [buffer 2][pair LPG_CH/2][lane 64][2]   ring_o: [row LPG_CH][lane 64]
-    u64 *ring_k = (u64 *)((char *)pen_tab + (PENTAB ? (((size_t)tabn + 1) * 4 + 15) / 16 * 16 : 0));
+    u64 *ring_k = (u64 *)((char *)pen_tab + (PENTAB ? (((size_t)tabn + 1) * 4 + 15) / 16 * 16 : 0) + (size_t)(threadIdx.x >> 6) * LPG_RING_BYTES);
     u64 *ring_v = ring_k + 2 * (LPG_CH / 2) * 128;
     u64 *ring_o = ring_v + 2 * (LPG_CH / 2) * 128;
-    const u32 lane = threadIdx.x;
+    const u32 lane = threadIdx.x & 63;
     auto issue_chunk = [&](i32 a0, i32 buf) {            // anchors [a0, a0 + LPG_CH) -> buffer buf (reads <= 1 anchor past n)
 #pragma unroll
         for (int pr = 0; pr < LPG_CH / 2; ++pr) {

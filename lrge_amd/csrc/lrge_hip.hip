@@ -1853,13 +1853,14 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                     StageTimer tl(ctx, LRGE_T_CHAIN_LPG, both ? ctx->stream2 : ctx->stream);
                     const bool pentab = cp.pen_skip == 0.0f && cp.bw >= 0 && cp.bw + 2 <= 8192 && !ctx->opt("LPG_NOTAB");
                     const bool fastreach = cp.max_iter >= 64 && !ctx->opt("LPG_EXACT_REACH");
-                    const dim3 lgrid((la.n_list + 63) / 64);
-                    const size_t lds_tab = (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + LPG_RING_BYTES;
+                    const dim3 lgrid((la.n_list + 64 * LPG_WAVES - 1) / (64 * LPG_WAVES)), lblock(64 * LPG_WAVES);
+                    const size_t lds_ring = (size_t)LPG_WAVES * LPG_RING_BYTES;
+                    const size_t lds_tab = (((size_t)cp.bw + 2) * 4 + 15) / 16 * 16 + lds_ring;
                     hipStream_t lst = both ? ctx->stream2 : ctx->stream;
-                    if (pentab && fastreach) hipLaunchKernelGGL((k_chain_lpg<true, true>), lgrid, dim3(64), lds_tab, lst, la, cp, go);
-                    else if (pentab) hipLaunchKernelGGL((k_chain_lpg<true, false>), lgrid, dim3(64), lds_tab, lst, la, cp, go);
-                    else if (fastreach) hipLaunchKernelGGL((k_chain_lpg<false, true>), lgrid, dim3(64), LPG_RING_BYTES, lst, la, cp, go);
-                    else hipLaunchKernelGGL((k_chain_lpg<false, false>), lgrid, dim3(64), LPG_RING_BYTES, lst, la, cp, go);
+                    if (pentab && fastreach) hipLaunchKernelGGL((k_chain_lpg<true, true>), lgrid, lblock, lds_tab, lst, la, cp, go);
+                    else if (pentab) hipLaunchKernelGGL((k_chain_lpg<true, false>), lgrid, lblock, lds_tab, lst, la, cp, go);
+                    else if (fastreach) hipLaunchKernelGGL((k_chain_lpg<false, true>), lgrid, lblock, lds_ring, lst, la, cp, go);
+                    else hipLaunchKernelGGL((k_chain_lpg<false, false>), lgrid, lblock, lds_ring, lst, la, cp, go);
                     KCHK(ctx);
                     tl.stop();
                     ctx->counters[LRGE_C_CHAIN_LAUNCHES] += 1;

@@ -2288,7 +2288,13 @@ extern "C" int lrge_hip_comm_create_host(lrge_hip_ctx *ctx, int rank, int world,
 
 extern "C" void lrge_hip_comm_destroy(lrge_hip_comm *c) {
     if (!c) return;
-    if (c->nccl) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); (void)g_rccl.CommDestroy(c->nccl); }
+    if (c->nccl) {
+        // (a communicator that outlives its context -- as lrge_hip_index_free / _seqset_free tolerate too -- must not touch it)
+        bool ctx_alive;
+        { std::lock_guard<std::mutex> g(g_live_mu); ctx_alive = g_live_ctx.count(c->ctx) != 0; }
+        if (ctx_alive) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); }
+        (void)g_rccl.CommDestroy(c->nccl);
+    }
     delete c;
 }
 extern "C" int lrge_hip_comm_rank(const lrge_hip_comm *c) { return c ? c->rank : -1; }

@@ -104,6 +104,7 @@ struct lrge_hip_ctx {
     // in it back to back and travel as ONE transfer (six copies from pageable vectors cost ~0.1 ms each of host time in
     // front of every index build).  Bump allocation; rewound when no upload is in flight.
     char *meta_pin = nullptr; size_t meta_cap = 0, meta_used = 0; int meta_inflight = 0;
+    hipEvent_t ev_meta = nullptr;            // behind the last transfer out of the arena: waited for before a rewound arena is written again
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     DevPool pool;

@@ -154,6 +154,7 @@ extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->pool.destroy();
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->ev_meta) (void)hipEventDestroy(ctx->ev_meta);
     if (ctx->meta_pin) (void)hipHostFree(ctx->meta_pin);
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join);
@@ -338,6 +339,10 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
         else if (!ctx->meta_pin) (void)hipGetLastError();
         char *hm = nullptr;
         if (ctx->meta_pin && ctx->meta_used + meta_bytes <= ctx->meta_cap) {
+            // a rewound arena: every consumer of the earlier uploads has ordered itself behind them on the DEVICE
+            // (seqset_ready); the host must not overwrite the bytes before the last transfer has actually read them
+            // (it almost always has: ~2 us)
+            if (ctx->meta_used == 0 && ctx->ev_meta) HIPCHK(ctx, hipEventSynchronize(ctx->ev_meta));
             hm = ctx->meta_pin + ctx->meta_used; ctx->meta_used += meta_bytes; ++ctx->meta_inflight; s->meta_arena = true;
         }
         auto put = [&](size_t off, const void *src_, size_t bytes) -> hipError_t {
@@ -371,7 +376,11 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
             HIPCHK(ctx, put(o_len, s->h_len.data(), (size_t)n * 4));
             if (name_rank) HIPCHK(ctx, put(o_rank, s->h_rank.data(), (size_t)n * 4));
         }
-        if (hm) HIPCHK(ctx, hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, cs));
+        if (hm) {
+            HIPCHK(ctx, hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, cs));
+            if (!ctx->ev_meta) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_meta, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_meta, cs));
+        }
     }
     if (kind == 1) {
         HIPCHK(ctx, hipMemcpyAsync(s->stg_ascii, src, s->total_bases, hipMemcpyHostToDevice, cs));

@@ -542,15 +542,21 @@ __global__ __launch_bounds__(HC_THREADS) void k_heads_count(const u64 *__restric
 __global__ __launch_bounds__(HC_THREADS) void k_heads_fill(const u64 *__restrict__ keys, u64 n, u32 shift, const u32 *__restrict__ boff,
                                                            u32 *__restrict__ starts) {
     __shared__ u32 ws[HC_THREADS / 64];
+    __shared__ u32 tile[HC_TILE];            // the block's heads, in order: they leave as one coalesced run
     const u64 base = (u64)blockIdx.x * HC_TILE + (u64)threadIdx.x * HC_ITEMS;
     u32 f = hc_load_flags(keys, n, shift, base);
     const u32 c = (u32)__popc(f);
     const u32 inc = wave_incl_scan_u32(c);
     if (lane_id() == 63) ws[threadIdx.x >> 6] = inc;
     __syncthreads();
-    u32 o = boff[blockIdx.x] + inc - c;
-    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) o += ws[w];
-    while (f) { const u32 t = (u32)__ffs((int)f) - 1; f &= f - 1; starts[o++] = (u32)(base + t); }
+    u32 o = inc - c, total = 0;
+    for (u32 w = 0; w < HC_THREADS / 64; ++w) { if (w < (threadIdx.x >> 6)) o += ws[w]; total += ws[w]; }
+    // (a thread's heads are consecutive, but written one by one per thread every store instruction of the wavefront
+    // touched 64 different lines)
+    while (f) { const u32 t = (u32)__ffs((int)f) - 1; f &= f - 1; tile[o++] = (u32)(base + t); }
+    __syncthreads();
+    const u32 g0 = boff[blockIdx.x];
+    for (u32 i = threadIdx.x; i < total; i += HC_THREADS) starts[g0 + i] = tile[i];
 }
 
 // Same without the host round trip: starts must hold n + 1 entries (upper bound), *d_count (device) receives the

@@ -529,22 +529,26 @@ __device__ __forceinline__ u32 hc_load_flags(const u64 *__restrict__ keys, u64 n
     return f;
 }
 
-__global__ __launch_bounds__(HC_THREADS) void k_heads_count(const u64 *__restrict__ keys, u64 n, u32 shift, u32 *__restrict__ bcount) {
+// flags: the 16 head bits of every thread's line, kept for k_heads_fill (2 bytes instead of re-reading 128 bytes of keys)
+__global__ __launch_bounds__(HC_THREADS) void k_heads_count(const u64 *__restrict__ keys, u64 n, u32 shift, u32 *__restrict__ bcount,
+                                                            u16 *__restrict__ flags) {
     __shared__ u32 ws[HC_THREADS / 64];
     const u64 base = (u64)blockIdx.x * HC_TILE + (u64)threadIdx.x * HC_ITEMS;
-    u32 c = (u32)__popc(hc_load_flags(keys, n, shift, base));
+    const u32 f = hc_load_flags(keys, n, shift, base);
+    flags[(u64)blockIdx.x * HC_THREADS + threadIdx.x] = (u16)f;
+    u32 c = (u32)__popc(f);
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
     if (lane_id() == 0) ws[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) { u32 t = 0; for (int w = 0; w < HC_THREADS / 64; ++w) t += ws[w]; bcount[blockIdx.x] = t; }
 }
 
-__global__ __launch_bounds__(HC_THREADS) void k_heads_fill(const u64 *__restrict__ keys, u64 n, u32 shift, const u32 *__restrict__ boff,
+__global__ __launch_bounds__(HC_THREADS) void k_heads_fill(const u16 *__restrict__ flags, const u32 *__restrict__ boff,
                                                            u32 *__restrict__ starts) {
     __shared__ u32 ws[HC_THREADS / 64];
     __shared__ u32 tile[HC_TILE];            // the block's heads, in order: they leave as one coalesced run
     const u64 base = (u64)blockIdx.x * HC_TILE + (u64)threadIdx.x * HC_ITEMS;
-    u32 f = hc_load_flags(keys, n, shift, base);
+    u32 f = flags[(u64)blockIdx.x * HC_THREADS + threadIdx.x];
     const u32 c = (u32)__popc(f);
     const u32 inc = wave_incl_scan_u32(c);
     if (lane_id() == 63) ws[threadIdx.x >> 6] = inc;
@@ -565,13 +569,14 @@ static int compact_heads_async(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, 
     if (n == 0) { HIPCHK(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream)); return LRGE_OK; }
     const u32 nb = (u32)div_up(n, HC_TILE);
     ALLOC_OR_FAIL(bc, sc, u32, (size_t)nb + 1);
-    hipLaunchKernelGGL(k_heads_count, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc);
+    ALLOC_OR_FAIL(fl, sc, u16, (size_t)nb * HC_THREADS);
+    hipLaunchKernelGGL(k_heads_count, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc, fl);
     KCHK(ctx);
     int rc = scan_exclusive_u32(ctx, sc, bc, bc, nb, d_count);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_heads_fill, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc, starts);
+    hipLaunchKernelGGL(k_heads_fill, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, fl, bc, starts);
     KCHK(ctx);
-    sc.drop(bc);   // (recycled in stream order)
+    sc.drop(bc); sc.drop(fl);   // (recycled in stream order)
     return LRGE_OK;
 }
 
@@ -582,7 +587,8 @@ static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n,
     const u32 nb = (u32)div_up(n, HC_TILE);
     ALLOC_OR_FAIL(bc, sc, u32, (size_t)nb + 1);
     ALLOC_OR_FAIL(d_tot, sc, u32, 1);
-    hipLaunchKernelGGL(k_heads_count, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc);
+    ALLOC_OR_FAIL(fl, sc, u16, (size_t)nb * HC_THREADS);
+    hipLaunchKernelGGL(k_heads_count, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc, fl);
     KCHK(ctx);
     int rc = scan_exclusive_u32(ctx, sc, bc, bc, nb, d_tot);
     if (rc) return rc;
@@ -590,9 +596,9 @@ static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n,
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     u32 *st = sc.get<u32>((size_t)*n_heads + 1);
     if (!st) return LRGE_ERR_DEVICE;
-    hipLaunchKernelGGL(k_heads_fill, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc, st);
+    hipLaunchKernelGGL(k_heads_fill, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, fl, bc, st);
     KCHK(ctx);
-    sc.drop(bc); sc.drop(d_tot);
+    sc.drop(bc); sc.drop(d_tot); sc.drop(fl);
     *d_starts = st;
     return LRGE_OK;
 }

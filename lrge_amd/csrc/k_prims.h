@@ -113,31 +113,51 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const u32 *in, u64
     }
 }
 
-// single block: in-place exclusive scan of up to any n, writes total to *total.  Every thread owns 8 consecutive items,
-// so the 8192 block sums of a 32 M-entry scan take ONE trip through memory and the block's barriers (one item per thread
-// and 8 trips cost 60-90 us per call, ~20 calls per step).
-__global__ __launch_bounds__(1024) void k_scan_small(u32 *data, u32 n, u32 *total) {
-    __shared__ u32 wsum[16];
+// single block: in-place exclusive scan of up to any n, writes total to *total.  Every thread owns SS_ITEMS consecutive items,
+// so the <= 8192 block sums of a 32 M-entry scan take ONE trip through memory and the block's barriers.  256 threads, not
+// 1024: this kernel runs ~16 times per step between kernels of the same stream while OTHER streams fill the chip (the
+// query sketch beside the index sort, the chain kernels beside each other); a 16-wavefront workgroup then waited for a CU
+// with four free slots on every SIMD -- 94 us on average, 1.2 ms at worst, for 10 us of work -- where four wavefronts fit anywhere.
+#define SS_THREADS 256
+#define SS_ITEMS 32
+__global__ __launch_bounds__(SS_THREADS) void k_scan_small(u32 *data, u32 n, u32 *total) {
+    __shared__ u32 wsum[SS_THREADS / 64];
     __shared__ u32 carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (u32 base = 0; base < n; base += 8192) {
-        const u32 i0 = base + threadIdx.x * 8;
-        u32 v[8];
+    for (u32 base = 0; base < n; base += SS_THREADS * SS_ITEMS) {
+        const u32 i0 = base + threadIdx.x * SS_ITEMS;
+        u32 v[SS_ITEMS];
+        if (i0 + SS_ITEMS <= n) {
+            const uint4 *p = (const uint4 *)(data + i0);      // (i0 is a multiple of 32: 16-byte aligned with the block)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = i0 + t < n ? data[i0 + t] : 0;
+            for (int t = 0; t < SS_ITEMS / 4; ++t) { const uint4 q = p[t]; v[4 * t] = q.x; v[4 * t + 1] = q.y; v[4 * t + 2] = q.z; v[4 * t + 3] = q.w; }
+        } else {
+#pragma unroll
+            for (int t = 0; t < SS_ITEMS; ++t) v[t] = i0 + t < n ? data[i0 + t] : 0;
+        }
         u32 s = 0;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) s += v[t];
+        for (int t = 0; t < SS_ITEMS; ++t) s += v[t];
         const u32 inc = wave_incl_scan_u32(s);
         if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
         __syncthreads();
         u32 off = carry_s + inc - s;
         for (u32 w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
+        if (i0 + SS_ITEMS <= n) {
+            uint4 *p = (uint4 *)(data + i0);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { if (i0 + t < n) data[i0 + t] = off; off += v[t]; }
+            for (int t = 0; t < SS_ITEMS / 4; ++t) {
+                uint4 q;
+                q.x = off; off += v[4 * t]; q.y = off; off += v[4 * t + 1]; q.z = off; off += v[4 * t + 2]; q.w = off; off += v[4 * t + 3];
+                p[t] = q;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < SS_ITEMS; ++t) { if (i0 + t < n) data[i0 + t] = off; off += v[t]; }
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = off;
+        if (threadIdx.x == SS_THREADS - 1) carry_s = off;
         __syncthreads();
     }
     if (threadIdx.x == 0 && total) *total = carry_s;
@@ -196,7 +216,7 @@ static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32
     hipLaunchKernelGGL(k_scan_reduce, dim3((u32)nb), dim3(SCAN_THREADS), 0, st, in, n, bs);
     KCHK(ctx);
     if (nb <= 8192) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, bs, (u32)nb, (u32 *)nullptr);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SS_THREADS), 0, st, bs, (u32)nb, (u32 *)nullptr);
         KCHK(ctx);
     } else {
         int rc = scan_exclusive_u32(ctx, sc, bs, bs, nb, nullptr, st, keep);

@@ -207,6 +207,7 @@ struct lrge_hip_index {
     u64 *d_ht = nullptr;        // ordered open-addressing table of {key, start<<24 | min(count, 2^24-1)} pairs (k_index.h)
     u32 pk_pos1 = 0, pk_ybits = 0;   // packed entries (d_skey == d_pos): hash << pk_ybits | rid << pk_pos1 | (pos << 1 | strand)
     u64 ht_cap = 0;             // home slots are [0, ht_cap); slack slots follow
+    u32 ht_fix = 0;             // how ht_home() stretches the partial top byte of the hash (k_index.h); fixed at build time
     u64 ht_slots = 0;           // ht_cap + slack
     // A target set too large for one index (more than LRGE_HIP_PART_BASES bases: the 2^32-entry limits) is indexed in
     // parts over views of the set.  The occurrence statistics are global (k_part_global_occ), so the parts together

@@ -18,7 +18,26 @@
 #define HT_CNT_BITS 24
 #define HT_CNT_MAX ((1u << HT_CNT_BITS) - 1)
 
-__device__ __forceinline__ u64 ht_home(u64 key, u64 cap) { return __umul64hi(__builtin_bswap64(key), cap); }
+// Home slot = position of the key in the byte-reversed order, scaled to [0, cap).  A hash of B = 2k bits fills its top byte only
+// partly (k = 15: 6 of 8 bits; k = 19 likewise), and byte-reversed that byte sits in the MIDDLE of the 64-bit value: left as it
+// is, the keys of every (b0, b1, b2) prefix would all fall into the first quarter of that prefix's slot range -- runs of ~11
+// occupied slots followed by ~11 empty ones at load 1/2, ~5 slots and ~1.8 sectors per probe instead of ~1.5 and ~1.15
+// (measured: 117 bytes fetched per probe; tools/micro/random_access.hip reaches 52 G single-sector probes per second on the same
+// 6 GB).  `fix` = position of that byte in the reversed value | its missing bits << 8 (ht_fix_of): the partial byte is
+// stretched to a full one, which keeps the order (it is the least significant digit of it) and makes the homes uniform.
+__host__ __device__ __forceinline__ u32 ht_fix_of(int k) {
+    const int B = 2 * k, part = B % 8;
+    if (part == 0) return 0;
+    const int nb = (B + 7) / 8;                       // bytes of the hash; the partial one is byte nb - 1 -> bits [64 - 8 nb, +8)
+    return (u32)(64 - 8 * nb) | (u32)(8 - part) << 8;
+}
+__device__ __forceinline__ u64 ht_home(u64 key, u64 cap, u32 fix) {
+    u64 bs = __builtin_bswap64(key);
+    const u32 pos = fix & 0xff, tsh = fix >> 8;
+    const u64 pb = bs & (0xFFull << pos);
+    bs = (bs ^ pb) | (pb << tsh);                      // (tsh == 0: unchanged)
+    return __umul64hi(bs, cap);
+}
 
 // (run heads of the sorted stream: compact_heads() in k_prims.h; kshift = bits below the hash in a packed entry)
 
@@ -28,19 +47,19 @@ __device__ __forceinline__ u64 ht_home(u64 key, u64 cap) { return __umul64hi(__b
 #define PLACE_TILE (PLACE_THREADS * PLACE_ROWS)
 
 // d(r) = home(r) + (n_runs - r): slot(r) = prefix-max(d)(r) - (n_runs - r).  Needs cap + n_runs < 2^32.
-__device__ __forceinline__ u32 place_d(const u64 *__restrict__ skey, const u32 *__restrict__ run_start, u32 r, u32 n_runs, u64 cap, u32 kshift) {
-    return (u32)ht_home(skey[run_start[r]] >> kshift, cap) + (n_runs - r);
+__device__ __forceinline__ u32 place_d(const u64 *__restrict__ skey, const u32 *__restrict__ run_start, u32 r, u32 n_runs, u64 cap, u32 kshift, u32 fix) {
+    return (u32)ht_home(skey[run_start[r]] >> kshift, cap, fix) + (n_runs - r);
 }
 
 __global__ __launch_bounds__(PLACE_THREADS) void k_place_reduce(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
-                                                                u32 n_runs, u64 cap, u32 *__restrict__ bmax, u32 kshift) {
+                                                                u32 n_runs, u64 cap, u32 *__restrict__ bmax, u32 kshift, u32 fix) {
     __shared__ u32 wm[PLACE_THREADS / 64];
     u32 m = 0;
     const u32 base = blockIdx.x * PLACE_TILE;
 #pragma unroll
     for (int i = 0; i < PLACE_ROWS; ++i) {
         const u32 r = base + i * PLACE_THREADS + threadIdx.x;
-        if (r < n_runs) { const u32 d = place_d(skey, run_start, r, n_runs, cap, kshift); m = d > m ? d : m; }
+        if (r < n_runs) { const u32 d = place_d(skey, run_start, r, n_runs, cap, kshift, fix); m = d > m ? d : m; }
     }
     for (int d = 32; d > 0; d >>= 1) { const u32 o = (u32)__shfl_xor((i32)m, d, 64); m = o > m ? o : m; }
     if (lane_id() == 0) wm[threadIdx.x >> 6] = m;
@@ -81,7 +100,7 @@ __global__ __launch_bounds__(1024) void k_place_scan(u32 *data, u32 n) {
 __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
                                                                u32 n_runs, u64 n, u64 cap, u64 n_slots, const u32 *__restrict__ bpre,
                                                                u64 *__restrict__ ht, u32 *__restrict__ occ_hist, u32 max_bin,
-                                                               u32 *__restrict__ overflow, u32 kshift) {
+                                                               u32 *__restrict__ overflow, u32 kshift, u32 fix) {
     __shared__ u32 lh[OCC_LDS_BINS];
     __shared__ u32 wm[PLACE_THREADS / 64];
     __shared__ u32 carry_s;
@@ -104,7 +123,7 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
             const u64 en = (r + 1 < n_runs) ? run_start[r + 1] : n;
             cnt = (u32)(en - st);
             key = skey[st] >> kshift;
-            d = (u32)ht_home(key, cap) + (n_runs - r);
+            d = (u32)ht_home(key, cap, fix) + (n_runs - r);
         }
         u32 inc = d;
         for (int s = 1; s < 64; s <<= 1) { const u32 o = (u32)__shfl_up((i32)inc, s, 64); if ((int)lane >= s) inc = o > inc ? o : inc; }
@@ -146,8 +165,8 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
 // predecessor, so a probe can stop at the first entry that is not smaller in that order -- an absent key (most query
 // minimizers of noisy reads) costs no more than a present one instead of a walk to the next empty slot.  An empty slot
 // (all ones) compares as the largest key.
-__device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u64 key, u64 *start, u32 *cnt) {
-    u64 slot = ht_home(key, cap);
+__device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u32 fix, u64 key, u64 *start, u32 *cnt) {
+    u64 slot = ht_home(key, cap, fix);
     const u64 bk = __builtin_bswap64(key);
     for (;; ++slot) {
         const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
@@ -161,7 +180,7 @@ __device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u
 
 // ---- partitioned index: occurrence statistics over all parts (mm_idx_cal_max_occ sees ONE index) ----
 #define MAX_INDEX_PARTS 32
-struct PartTables { const u64 *ht[MAX_INDEX_PARTS]; u64 cap[MAX_INDEX_PARTS]; int n; };
+struct PartTables { const u64 *ht[MAX_INDEX_PARTS]; u64 cap[MAX_INDEX_PARTS]; int n; u32 fix; };
 
 // One lane per slot of part `self` (grid-stride): the key's occurrence count summed over every part; each distinct key
 // enters the histogram once, in the lowest part that holds it.  The
@@ -188,7 +207,7 @@ __global__ __launch_bounds__(256) void k_part_global_occ(const u64 *__restrict__
                 for (int o = 0; o < T.n; ++o) {
                     if (o == self) continue;
                     u64 st; u32 c;
-                    if (ht_lookup(T.ht[o], T.cap[o], e.x, &st, &c)) { sum += c; if (o < self) first = false; }
+                    if (ht_lookup(T.ht[o], T.cap[o], T.fix, e.x, &st, &c)) { sum += c; if (o < self) first = false; }
                 }
                 total = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sum;
             }
@@ -218,7 +237,7 @@ __global__ __launch_bounds__(256) void k_part_drop(u64 *__restrict__ ht, u64 n_s
     for (int o = 0; o < T.n && sum <= mid_occ; ++o) {
         if (o == self) continue;
         u64 st; u32 c;
-        if (ht_lookup(T.ht[o], T.cap[o], e.x, &st, &c)) sum += c;
+        if (ht_lookup(T.ht[o], T.cap[o], T.fix, e.x, &st, &c)) sum += c;
     }
     if (sum > mid_occ) ht[2 * slot + 1] = (e.y & ~(u64)HT_CNT_MAX) | (u64)(mid_occ + 1);
 }

@@ -14,7 +14,7 @@ struct KeyLayout {      // composite anchor sort key: qlocal | rid | rev | rpos
 };
 
 struct SeedParams {
-    const u64 *ht; u64 ht_cap;
+    const u64 *ht; u64 ht_cap; u32 ht_fix;   // (ht_fix: see ht_home)
     const u64 *pos;            // index position lists (plain y values, or packed entries when pk_ybits != 0)
     u32 pk_pos1, pk_ybits;     // packed index entry: hash << pk_ybits | rid << pk_pos1 | (pos << 1 | strand)
     const u32 *t_len, *t_rank; // indexed reads
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, u64 
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_mz) return;
     u64 st = 0; u32 cnt = 0;
-    if (!ht_lookup(sp.ht, sp.ht_cap, qx[i] >> 8, &st, &cnt)) { st = 0; cnt = 0; }
+    if (!ht_lookup(sp.ht, sp.ht_cap, sp.ht_fix, qx[i] >> 8, &st, &cnt)) { st = 0; cnt = 0; }
     hs[i] = (u32)st; hc[i] = cnt;
     if (hn) hn[i] = (cnt != 0 && (i64)cnt <= (i64)sp.mid_occ) ? cnt : 0;   // m[i].n > max_occ -> flt (as in k_seed_counts)
 }

@@ -963,6 +963,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     std::vector<u32> occ;
     {
         StageTimer t(ctx, LRGE_T_INDEX_TABLE);
+        const u32 ht_fix = ctx->opt("HT_NO_FIX") ? 0u : ht_fix_of(P.k);     // (option HT_NO_FIX: the clustered homes of rounds 1-2, for A/B runs)
         u32 *d_runstart = nullptr;
         if (M) {
             rc = compact_heads(ctx, sc, skey, M, pk_ybits, &d_runstart, &n_runs);    // runs of equal hash
@@ -977,7 +978,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         u64 cap = targets->is_view ? (u64)n_runs * 5 / 4 : (u64)n_runs * HT_CAP_NUM / HT_CAP_DEN;
         if (cap < 1024) cap = 1024;
         if (cap + n_runs >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32/3 distinct minimizers (got %u)", n_runs); return LRGE_ERR_TOO_MANY; }
-        ix->ht_cap = cap;
+        ix->ht_cap = cap; ix->ht_fix = ht_fix;
         ix->n_keys = n_runs;
         u32 *d_occ = sc.get<u32>((size_t)max_bin + 2);     // [max_bin + 1] = overflow flag
         if (!d_occ) return LRGE_ERR_DEVICE;
@@ -998,12 +999,12 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
                 const u32 n_tiles = (u32)div_up(n_runs, PLACE_TILE);
                 u32 *bmax = sc.get<u32>((size_t)n_tiles + 1);
                 if (!bmax) return LRGE_ERR_DEVICE;
-                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax, pk_ybits);
+                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax, pk_ybits, ht_fix);
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_scan, dim3(1), dim3(1024), 0, ctx->stream, bmax, n_tiles);
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_apply, dim3(std::min<u32>(n_tiles, (u32)ctx->n_cu * 8)), dim3(PLACE_THREADS), 0, ctx->stream,
-                                   skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1, pk_ybits);
+                                   skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1, pk_ybits, ht_fix);
                 KCHK(ctx);
                 sc.drop(bmax);
             }
@@ -1147,7 +1148,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     if (!d_nd) return LRGE_ERR_DEVICE;
     HIPCHK(ctx, hipMemsetAsync(d_hist, 0, ((size_t)max_bin + 1) * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(d_nd, 0, 8, ctx->stream));
-    PartTables T; T.n = np;
+    PartTables T; T.n = np; T.fix = top->parts[0]->ht_fix;
     for (int p = 0; p < np; ++p) { T.ht[p] = top->parts[p]->d_ht; T.cap[p] = top->parts[p]->ht_cap; }
     for (int p = 0; p < np; ++p) {
         const u64 ns = top->parts[p]->ht_slots;
@@ -1433,7 +1434,7 @@ int OverlapRun::seeds() {
     if (Mq >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "query set limited to < 2^32 minimizers"); return LRGE_ERR_TOO_MANY; }
 
     // ---- 2. lookup ----
-    sp.ht = ix->d_ht; sp.ht_cap = ix->ht_cap; sp.pos = ix->d_pos; sp.pk_pos1 = ix->pk_pos1; sp.pk_ybits = ix->pk_ybits;
+    sp.ht = ix->d_ht; sp.ht_cap = ix->ht_cap; sp.ht_fix = ix->ht_fix; sp.pos = ix->d_pos; sp.pk_pos1 = ix->pk_pos1; sp.pk_ybits = ix->pk_ybits;
     sp.t_len = T->d_len; sp.t_rank = T->d_rank; sp.q_len = Q->d_len; sp.q_rank = Q->d_rank;
     sp.mid_occ = ix->mid_occ;
     sp.check_names = (Q->has_rank && T->has_rank) ? 1 : 0;   // qname == NULL in minimap2 skips skip_seed entirely

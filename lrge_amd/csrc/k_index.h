@@ -170,6 +170,11 @@ __device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u
     const u64 bk = __builtin_bswap64(key);
     for (;; ++slot) {
         const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
+#ifndef HT_LAZY_VALUE
+        // keep the slot ONE 16-byte load: left alone the compiler fetches the key first and the value only on a match --
+        // a second dependent trip to the cache for every present key
+        asm volatile("" : : "v"((u32)e.y), "v"((u32)(e.y >> 32)));
+#endif
         if (__builtin_bswap64(e.x) >= bk) {
             if (e.x != key) return false;
             *start = e.y >> HT_CNT_BITS; *cnt = (u32)(e.y & HT_CNT_MAX);

@@ -137,7 +137,12 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
     if (w0 >= mz_end) return;
     const u64 i = w0 + lane;
     const bool in = i < mz_end;
+    // the per-minimizer streams are read for every lane, kept seed or not, TOGETHER with the counts: a third of the seeds are
+    // kept, so every line of them is fetched anyway, and loads that wait for hn[] cost the wavefront one more trip to memory
+    // (this kernel is bound by the length of its chain of dependent loads, not by bytes)
     const u32 n = in ? hn[i] : 0;
+    const u64 x = in ? qx[i] : 0, y = in ? qy[i] : 0;
+    const u32 st_i = in ? hs[i] : 0;
     const u32 incl = wave_incl_scan_u32(n);
     const u32 total = (u32)__builtin_amdgcn_readlane((i32)incl, 63);
     if (total == 0) return;
@@ -145,12 +150,11 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
     // per-minimizer fields, fetched by the lanes that expand its hits
     u32 m_st = 0, m_q = 0, m_qpos = 0, m_flags = 0, m_ql = 0, m_qr = 0, m_rank = 0;
     if (n) {
-        const u64 x = qx[i], y = qy[i];
         m_q = (u32)(y >> 32); m_qpos = (u32)y >> 1;
         m_flags = ((u32)y & 1) | ((u32)x & 0xff) << 8;          // strand | span << 8
         m_ql = sp.q_len[m_q];
         m_qr = sp.check_names ? sp.q_rank[m_q] : 0;
-        m_st = hs[i];
+        m_st = st_i;
         if (krank) m_rank = (krank[i] - krank[qmz_off[m_q]]) & 0xFFFFFu;    // (null: count-only run, the packed anchor has no rank field)
     }
     u32 o = aoff[w0 - mz_begin];                                 // anchors written so far (wave-uniform)

@@ -3,7 +3,7 @@
 //   sorted keys -> run heads -> ORDERED open-addressing table  hash -> (start, count)  into pos[].
 // The minimizer stream is sorted by the BYTE-REVERSED hash (low byte most significant): minimizer
 // hashes are window minima, heavily skewed toward small values, but their low bytes are uniform.  A
-// key's home slot is  umulhi(bswap64(key), cap), monotone in that order, so inserting the distinct
+// key's home slot is  umulhi(bswap64(key), cap) (with the partial top byte stretched: ht_home), monotone in that order, so inserting the distinct
 // keys in sorted order with linear probing has a closed form -- slot(r) = max(home(r), slot(r-1) + 1)
 // = r + prefix-max(home(r') - r') -- i.e. one max-scan and one streaming pass with nearly sequential
 // writes; no atomics, no random CAS traffic.  Lookups probe linearly from the home slot as usual (the

@@ -45,6 +45,7 @@ __device__ __forceinline__ u64 ht_home(u64 key, u64 cap, u32 fix) {
 #define PLACE_THREADS 256
 #define PLACE_ROWS 8
 #define PLACE_TILE (PLACE_THREADS * PLACE_ROWS)
+#define PLACE_COMP 384      // slots a wavefront composes in LDS (64 runs at load 1/2 span ~128)
 
 // d(r) = home(r) + (n_runs - r): slot(r) = prefix-max(d)(r) - (n_runs - r).  Needs cap + n_runs < 2^32.
 __device__ __forceinline__ u32 place_d(const u64 *__restrict__ skey, const u32 *__restrict__ run_start, u32 r, u32 n_runs, u64 cap, u32 kshift, u32 fix) {
@@ -100,7 +101,13 @@ __global__ __launch_bounds__(1024) void k_place_scan(u32 *data, u32 n) {
 __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
                                                                u32 n_runs, u64 n, u64 cap, u64 n_slots, const u32 *__restrict__ bpre,
                                                                u64 *__restrict__ ht, u32 *__restrict__ occ_hist, u32 max_bin,
-                                                               u32 *__restrict__ overflow, u32 kshift, u32 fix) {
+                                                               u32 *__restrict__ overflow, u32 kshift, u32 fix, u32 *__restrict__ last_slot) {
+    // last_slot != null: the table has NOT been cleared.  The runs of a wavefront occupy increasing slots, and the slot of the
+    // run in front of the wavefront's first one is known from the same max-scan: every wavefront owns the contiguous slot
+    // range (slot of the run before its first, slot of its last], composes it in LDS -- empty slots and entries -- and writes
+    // it as whole lines.  The table is written once (6 GB at C4) instead of cleared and then written into with 16-byte
+    // stores; *last_slot receives the slot of the last run (k_fill_tail clears what lies behind it).
+    __shared__ ulonglong2 comp[PLACE_THREADS / 64][PLACE_COMP];
     __shared__ u32 lh[OCC_LDS_BINS];
     __shared__ u32 wm[PLACE_THREADS / 64];
     __shared__ u32 carry_s;
@@ -134,12 +141,32 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
         const u32 m = inc > pre ? inc : pre;
         __syncthreads();
         if (threadIdx.x == PLACE_THREADS - 1) carry_s = m;
-        if (in) {
-            const u64 slot = (u64)m - (n_runs - r);
-            if (slot + 1 >= n_slots) *overflow = 1u;       // the last slot must stay empty
-            else {
-                ulonglong2 e; e.x = key; e.y = (u64)st << HT_CNT_BITS | (cnt < HT_CNT_MAX ? cnt : HT_CNT_MAX);
-                *(ulonglong2 *)(ht + 2 * slot) = e;
+        const u64 slot = in ? (u64)m - (n_runs - r) : 0;
+        ulonglong2 e; e.x = key; e.y = (u64)st << HT_CNT_BITS | (cnt < HT_CNT_MAX ? cnt : HT_CNT_MAX);
+        if (in && slot + 1 >= n_slots) *overflow = 1u;      // the last slot must stay empty
+        if (!last_slot) {
+            if (in && slot + 1 < n_slots) *(ulonglong2 *)(ht + 2 * slot) = e;
+        } else {
+            // first slot this lane is responsible for: one behind the slot of run r - 1 (m of the lane before; `pre` for lane 0)
+            u32 m_prev = (u32)__shfl_up((i32)m, 1, 64);
+            m_prev = lane == 0 ? pre : m_prev;
+            const u64 fill0 = (in && r > 0) ? (u64)m_prev - (n_runs - (r - 1)) + 1 : 0;
+            const u64 vmask = __ballot(in);
+            if (vmask) {
+                const int nv = (int)__popcll(vmask);                           // valid lanes are a prefix
+                const u64 F = (u64)__shfl((i32)(u32)fill0, 0, 64) | (u64)(u32)__shfl((i32)(u32)(fill0 >> 32), 0, 64) << 32;
+                const u64 L = (u64)(u32)__shfl((i32)(u32)slot, nv - 1, 64) | (u64)(u32)__shfl((i32)(u32)(slot >> 32), nv - 1, 64) << 32;
+                const u64 R = L - F + 1;
+                ulonglong2 empty; empty.x = HT_EMPTY; empty.y = HT_EMPTY;
+                if (R <= PLACE_COMP) {
+                    for (u32 i = lane; i < (u32)R; i += 64) comp[w][i] = empty;
+                    if (in) comp[w][(u32)(slot - F)] = e;
+                    for (u32 i = lane; i < (u32)R; i += 64) if (F + i < n_slots) *(ulonglong2 *)(ht + 2 * (F + i)) = comp[w][i];
+                } else if (in) {                                              // a sparse stretch: every lane clears its own gap
+                    for (u64 q = fill0; q < slot; ++q) if (q < n_slots) *(ulonglong2 *)(ht + 2 * q) = empty;
+                    if (slot < n_slots) *(ulonglong2 *)(ht + 2 * slot) = e;
+                }
+                if (in && r == n_runs - 1) *last_slot = (u32)(slot < n_slots ? slot : n_slots - 1);
             }
         }
         const u32 hb = cnt < max_bin ? cnt : max_bin;
@@ -159,6 +186,13 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
     __syncthreads();
     for (u32 i = threadIdx.x; i < OCC_LDS_BINS && i <= max_bin; i += blockDim.x)
         if (lh[i]) atomicAdd(&occ_hist[i], lh[i]);
+}
+
+// clears the slots behind the last run (slack + whatever the homes left free at the end); *last_slot from k_place_apply
+__global__ __launch_bounds__(256) void k_fill_tail(u64 *__restrict__ ht, u64 n_slots, const u32 *__restrict__ last_slot) {
+    ulonglong2 empty; empty.x = HT_EMPTY; empty.y = HT_EMPTY;
+    for (u64 q = (u64)*last_slot + 1 + (u64)blockIdx.x * blockDim.x + threadIdx.x; q < n_slots; q += (u64)gridDim.x * blockDim.x)
+        *(ulonglong2 *)(ht + 2 * q) = empty;
 }
 
 // The table is ORDERED: keys were placed in ascending byte-reversed order, each at its home slot or right behind its

@@ -993,7 +993,10 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             ix->ht_slots = n_slots;
             ht = sc.get<u64>(2 * n_slots);
             if (!ht) return LRGE_ERR_DEVICE;
-            HIPCHK(ctx, hipMemsetAsync(ht, 0xFF, 2 * n_slots * 8, ctx->stream));   // key = HT_EMPTY
+            // the placement kernel writes every slot itself (entries and empty ones) unless told otherwise (option HT_MEMSET: clear
+            // first, then 16-byte entry stores -- the form of rounds 1-2, for A/B runs)
+            const bool fused_fill = n_runs != 0 && !ctx->opt("HT_MEMSET");
+            if (!fused_fill) HIPCHK(ctx, hipMemsetAsync(ht, 0xFF, 2 * n_slots * 8, ctx->stream));   // key = HT_EMPTY
             HIPCHK(ctx, hipMemsetAsync(d_occ, 0, ((size_t)max_bin + 2) * 4, ctx->stream));
             if (n_runs) {
                 const u32 n_tiles = (u32)div_up(n_runs, PLACE_TILE);
@@ -1004,8 +1007,13 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
                 hipLaunchKernelGGL(k_place_scan, dim3(1), dim3(1024), 0, ctx->stream, bmax, n_tiles);
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_apply, dim3(std::min<u32>(n_tiles, (u32)ctx->n_cu * 8)), dim3(PLACE_THREADS), 0, ctx->stream,
-                                   skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1, pk_ybits, ht_fix);
+                                   skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1, pk_ybits, ht_fix,
+                                   fused_fill ? bmax + n_tiles : (u32 *)nullptr);
                 KCHK(ctx);
+                if (fused_fill) {
+                    hipLaunchKernelGGL(k_fill_tail, dim3((u32)std::min<u64>(div_up(n_slots - cap / 2, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, ht, n_slots, bmax + n_tiles);
+                    KCHK(ctx);
+                }
                 sc.drop(bmax);
             }
             // the k-th smallest occurrence count almost always sits in the first few bins: fetch 16 KB of

@@ -229,7 +229,9 @@ __global__ void k_qocc_keys(const u64 *__restrict__ qx, const u64 *__restrict__ 
 // inside one query.  One block per query counts its indexed minimizers into 8192 hashed LDS buckets; a
 // bucket count is an upper bound of the multiplicity of every value that falls into it, so when no bucket
 // of any query exceeds mid_occ the filter removes nothing and the exact (sort-based) pass is skipped.
+#ifndef QOCC_BUCKETS
 #define QOCC_BUCKETS 8192
+#endif
 __global__ __launch_bounds__(256) void k_qocc_check(const u64 *__restrict__ qx, const u32 *__restrict__ hc,
                                                     const u32 *__restrict__ qmz_off, u32 nq, int mid_occ, u32 *__restrict__ flag) {
     __shared__ u32 cnt[QOCC_BUCKETS];
@@ -249,7 +251,15 @@ __global__ __launch_bounds__(256) void k_qocc_check(const u64 *__restrict__ qx, 
         const u32 h = (u32)(((qx[i] >> 8) * 0x9E3779B97F4A7C15ULL) >> 51) & (nbk - 1);  // up to 13 bits
         if ((i64)atomicAdd(&cnt[h], 1u) + 1 > (i64)mid_occ) hit = true;
     }
-    if (hit) atomicOr(flag, 1u);
+    if (hit) { atomicOr(flag, 1u); flag[1 + q] = 1u; }      // flag[0]: any query; flag[1 + q]: this one (benign same-value race)
+}
+
+// flag = present in the index AND the minimizer's query is one the pre-check could not clear (qsel[1 + q]; null = every query):
+// the exact pass then sorts the minimizers of those queries only -- a false alarm on one very long read (its buckets fill up)
+// costs microseconds, not a sort of every query's minimizers
+__global__ void k_flag_present_sel(const u32 *__restrict__ hc, const u64 *__restrict__ qy, const u32 *__restrict__ qsel, u64 n, u32 *__restrict__ flag) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (hc[i] != 0 && (!qsel || qsel[1 + (u32)(qy[i] >> 32)] != 0)) ? 1u : 0u;
 }
 
 // One lane per element; run heads do the work (runs are short except for the pathological ones this

@@ -1476,10 +1476,11 @@ int OverlapRun::seeds() {
     // contribute nothing whether removed or not.  A removed minimizer is marked absent (hc = 0).
     // The exact filter (two radix sorts + a run-length mark) as a callable: it only runs when the conservative
     // pre-check k_qocc_check cannot rule it out, or when LRGE_HIP_QOCC_EXACT forces it (tests).
+    const u32 *d_qsel = nullptr;      // per-query verdicts of the pre-check (null: the exact pass takes every query)
     auto run_exact_qocc = [&]() -> int {
         StageTimer t(ctx, LRGE_T_QFILTER);
         ALLOC_OR_FAIL(flag, sc, u32, Mq); ALLOC_OR_FAIL(fpos, sc, u32, Mq); ALLOC_OR_FAIL(d_ns, sc, u32, 1);
-        hipLaunchKernelGGL(k_flag_nonzero, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hc, Mq, flag);
+        hipLaunchKernelGGL(k_flag_present_sel, dim3((u32)div_up(Mq, 256)), dim3(256), 0, ctx->stream, hc, so.y, d_qsel, Mq, flag);
         KCHK(ctx);
         rc = scan_exclusive_u32(ctx, sc, flag, fpos, Mq, d_ns);
         if (rc) return rc;
@@ -1518,12 +1519,13 @@ int OverlapRun::seeds() {
         else {
             // cheap conservative check, on the side stream beside the hit counting below (both only read the lookup
             // results); its verdict travels to the host with the next sync (no extra round trip)
-            d_qf = sc.get<u32>(1);
+            d_qf = sc.get<u32>((size_t)nq + 1);     // [0] any query, [1 + q] query q
             if (!d_qf) return LRGE_ERR_DEVICE;
+            d_qsel = d_qf;
             HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
             StageTimer t(ctx, LRGE_T_QFILTER, ctx->stream2);
-            HIPCHK(ctx, hipMemsetAsync(d_qf, 0, 4, ctx->stream2));
+            HIPCHK(ctx, hipMemsetAsync(d_qf, 0, ((size_t)nq + 1) * 4, ctx->stream2));
             hipLaunchKernelGGL(k_qocc_check, dim3(nq), dim3(256), 0, ctx->stream2, so.x, hc, so.mz_off, nq, ix->mid_occ, d_qf);
             KCHK(ctx);
             t.stop();

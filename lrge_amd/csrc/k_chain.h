@@ -85,10 +85,13 @@ struct CountParams {
                                   // indexed set (counts are keyed by the whole set)
 };
 
+// list / n_list: the groups that were chained (all others carry no flags: one lane per CHAINED group instead of one per
+// group -- 0.5 M of 109 M at C4)
 __global__ void k_count(const u64 *__restrict__ skey, const u32 *__restrict__ gstart, const u32 *__restrict__ gflags,
-                        u32 n_groups, CountParams cp, u32 *__restrict__ counts, u32 *__restrict__ has_map) {
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_groups) return;
+                        const u32 *__restrict__ list, u32 n_list, CountParams cp, u32 *__restrict__ counts, u32 *__restrict__ has_map) {
+    const u32 li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_list) return;
+    const u32 g = list[li];
     u32 fl = gflags[g];
     if (!fl) return;
     u64 k = skey[gstart[g]];

@@ -1923,8 +1923,10 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
         cnp.q_rank = Q->has_rank ? Q->d_rank : nullptr; cnp.t_rank = T->has_rank ? T->d_rank : nullptr;
         cnp.t_dup = T->dup_rank ? 1 : 0;
         cnp.q_map = d_qmap; cnp.rid_base = job.rid_base;
-        hipLaunchKernelGGL(k_count, dim3((u32)div_up(G, 256)), dim3(256), 0, ctx->stream, skey, gstart, gflags, G, cnp, d_counts, d_hasmap);
-        KCHK(ctx);
+        if (n_chained) {
+            hipLaunchKernelGGL(k_count, dim3((u32)div_up(n_chained, 256)), dim3(256), 0, ctx->stream, skey, gstart, gflags, hw_list, n_chained, cnp, d_counts, d_hasmap);
+            KCHK(ctx);
+        }
         // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
         t.stop();
     }

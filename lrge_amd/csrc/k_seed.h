@@ -103,6 +103,13 @@ __global__ __launch_bounds__(256) void k_seed_counts(const u64 *__restrict__ qy,
     if (in) { hn[i] = n; hv[i] = kept[w][lane]; }
 }
 
+// per-query anchor totals from the scanned hit counts (aoff has n_mz + 1 entries; differences are exact modulo 2^32, and a
+// query's total is far below that)
+__global__ void k_query_totals_from_scan(const u32 *__restrict__ aoff, const u32 *__restrict__ qmz_off, u32 nq, u32 *__restrict__ totals) {
+    const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) totals[q] = aoff[qmz_off[q + 1]] - aoff[qmz_off[q]];
+}
+
 // per-query sum of hv (one wave per query)
 __global__ __launch_bounds__(256) void k_query_anchor_totals(const u32 *__restrict__ hv, const u32 *__restrict__ qmz_off,
                                                              u32 nq, u32 *__restrict__ totals) {
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
         m_st = st_i;
         if (krank) m_rank = (krank[i] - krank[qmz_off[m_q]]) & 0xFFFFFu;    // (null: count-only run, the packed anchor has no rank field)
     }
-    u32 o = aoff[w0 - mz_begin];                                 // anchors written so far (wave-uniform)
+    u32 o = aoff[w0] - aoff[mz_begin];                           // anchors written so far (wave-uniform); aoff: scan over ALL query minimizers
     o = (u32)__builtin_amdgcn_readfirstlane((i32)o);
     for (u32 c0 = 0; c0 < total; c0 += 64) {
         const u32 r = c0 + lane;

@@ -1350,7 +1350,7 @@ struct OverlapRun {
     // seeds: query minimizers, their index lookups, per-query anchor totals
     SketchOut so; std::vector<u32> h_mzoff, h_qtot; u64 Mq = 0; SeedParams sp;
     std::unique_ptr<Scratch> presk_sc;   // memory of a consumed presketch (released with the run)
-    u32 *hs = nullptr, *hc = nullptr, *hn = nullptr, *hv = nullptr, *krank = nullptr;
+    u32 *hs = nullptr, *hc = nullptr, *hn = nullptr, *hv = nullptr, *krank = nullptr, *aoff_all = nullptr;
     // batch plan
     u64 batch_cap = 0; KeyLayout kl; u32 max_bits_q = 0, min_n = 0; ChainParams cp;
     std::vector<SegTile> h_tiles;   // per batch; lives until the batch's next host sync (the async H2D copy reads it)
@@ -1459,7 +1459,8 @@ int OverlapRun::seeds() {
     const bool counts_in_lookup = !sp.check_names && !ctx->opt("COUNTS_AFTER_LOOKUP");   // (option: the separate pass, for A/B runs)
     hs = sc.get<u32>(Mq + 1); hc = sc.get<u32>(Mq + 1); hn = sc.get<u32>(Mq + 1); hv = counts_in_lookup ? hn : sc.get<u32>(Mq + 1); krank = sc.get<u32>(Mq + 1);
     u32 *d_qtot = sc.get<u32>((size_t)nq + 1);
-    if (!hs || !hc || !hn || !hv || !krank || !d_qtot) return LRGE_ERR_DEVICE;
+    aoff_all = sc.get<u32>(Mq + 1);
+    if (!hs || !hc || !hn || !hv || !krank || !d_qtot || !aoff_all) return LRGE_ERR_DEVICE;
     h_qtot.assign((size_t)nq + 1, 0);
     if (Mq) {
         StageTimer t(ctx, LRGE_T_LOOKUP), tk(ctx, LRGE_T_K_LOOKUP);
@@ -1580,7 +1581,14 @@ int OverlapRun::seeds() {
         } else {
             HIPCHK(ctx, hipMemsetAsync(krank, 0, 4, ctx->stream));
         }
-        hipLaunchKernelGGL(k_query_anchor_totals, dim3((u32)div_up(nq, 4)), dim3(256), 0, ctx->stream, hv, so.mz_off, nq, d_qtot);
+        // ONE scan of the surviving-hit counts over all query minimizers: the per-query totals are differences of it, and every
+        // batch's k_expand reads its output offsets from it (relative to the batch's first minimizer; all modulo 2^32, so a job
+        // with more than 2^32 anchors is fine as long as a batch -- at most 2^30 -- and a query stay below)
+        if (Mq) {
+            rc = scan_exclusive_u32(ctx, sc, hv, aoff_all, Mq, aoff_all + Mq);
+            if (rc) return rc;
+        } else HIPCHK(ctx, hipMemsetAsync(aoff_all, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_query_totals_from_scan, dim3((u32)div_up(nq, 256)), dim3(256), 0, ctx->stream, aoff_all, so.mz_off, nq, d_qtot);
         KCHK(ctx);
         HIPCHK(ctx, ctx->d2h(h_qtot.data(), d_qtot, (size_t)nq * 4, ctx->stream));
         if (d_qf) {
@@ -1700,17 +1708,14 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
     const bool packed = !d_chains && !job.dump_anchors && kl.sh_q() + bits_qy + 9 <= 64 && !ctx->opt_u64("NO_PACKED", 0);
     {
         StageTimer t(ctx, LRGE_T_EXPAND);
-        u32 *aoff = bsc.get<u32>(me - mb + 1);
+        const u32 *aoff = aoff_all;
         // (+8: k_chain_lpg streams anchors in 16-byte pairs and may read one element past the last group)
         akey = bsc.get<u64>(A + 8); aval = bsc.get<u64>(A + 8); akey2 = bsc.get<u64>(A + 8); aval2 = bsc.get<u64>(A + 8);
         if (!aoff || !akey || !aval || !akey2 || !aval2) return LRGE_ERR_DEVICE;
-        rc = scan_exclusive_u32(ctx, bsc, hv + mb, aoff, me - mb, nullptr);
-        if (rc) return rc;
         hipLaunchKernelGGL(k_expand, dim3((u32)div_up(me - mb, 256)), dim3(256), 0, ctx->stream, so.x, so.y, mb, me, sp, hs, hn, aoff,
                            need_rank ? krank : (const u32 *)nullptr, so.mz_off, q0, kl, akey, aval, packed ? bits_qy : 0u);
         KCHK(ctx);
         // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
-        bsc.drop(aoff);
         t.stop();
     }
     {

@@ -54,7 +54,33 @@ template <int MODE> static void run2(const char *name, uint64_t mb) {
     (void)hipFree(tab); (void)hipFree(qx); (void)hipFree(o1); (void)hipFree(o2); (void)hipFree(o3);
 }
 
+// k_expand's gather: consecutive lanes read consecutive 8-byte entries of short lists (G entries each) at random places
+template <int G>
+__global__ __launch_bounds__(256) void k_lists(const unsigned long long *__restrict__ tab, uint64_t n_entries, uint64_t n, unsigned long long *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t list = i / G, j = i % G;
+    uint64_t x = (list + 7) * 0x9E3779B97F4A7C15ULL; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+    const unsigned long long v = tab[__umul64hi(x, n_entries - G) + j];
+    if (v == 0x1234567ULL) atomicAdd(out, v);
+}
+template <int G> static void run_lists() {
+    const uint64_t n = 211ULL << 20, bytes = 1940ULL << 20;
+    unsigned long long *tab, *d_out; (void)hipMalloc(&tab, bytes); (void)hipMemset(tab, 0xAB, bytes); (void)hipMalloc(&d_out, 8);
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    float best = 1e9f;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL(k_lists<G>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, tab, bytes / 8, n, d_out);
+        (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+        float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    printf("lists of %d entries, 211 M entries gathered from 1.9 GB: %7.3f ms = %5.1f G lists/s\n", G, best, (n / G) / best * 1e-6);
+    (void)hipFree(tab); (void)hipFree(d_out);
+}
+
 int main() {
+    run_lists<1>(); run_lists<2>(); run_lists<5>(); run_lists<13>();
     run2<0>("one 8-byte load per thread", 6144);
     run2<1>("+ key stream read", 6144);
     run2<2>("+ linear continuation + value fetch", 6144);

@@ -98,6 +98,8 @@ enum {
                                key, 24 in the unpacking pass */,
     LRGE_C_LPG_SPLIT /* group size above which the last batch used k_chain_hw instead of k_chain_lpg */,
     LRGE_C_LOOKUP_LAUNCHES /* k_lookup launches (one per pass over a streamed set / index part) */,
+    LRGE_C_TABLE_DISP_SUM /* last index build: sum over the distinct keys of their distance from the home slot in the ordered
+                             table; divided by the number of keys it is ~0.5 at load 1/2 when the home slots are uniform */,
     LRGE_C_N
 };
 

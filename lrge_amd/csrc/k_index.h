@@ -113,6 +113,7 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
     __shared__ u32 carry_s;
     for (u32 i = threadIdx.x; i < OCC_LDS_BINS; i += blockDim.x) lh[i] = 0;
     const u32 w = threadIdx.x >> 6, lane = lane_id();
+    u32 disp_sum = 0;      // (per lane: at most a few thousand runs x small displacements)
     const u32 n_tiles = (n_runs + PLACE_TILE - 1) / PLACE_TILE;
     // grid-stride over tiles with a small grid: the histogram flush at the end hits the same few global
     // addresses from every block, so the number of blocks (not of runs) sets that serialised cost
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
         __syncthreads();
         if (threadIdx.x == PLACE_THREADS - 1) carry_s = m;
         const u64 slot = in ? (u64)m - (n_runs - r) : 0;
+        if (in) disp_sum += (u32)(slot - (u64)(d - (n_runs - r)));      // slot - home
         ulonglong2 e; e.x = key; e.y = (u64)st << HT_CNT_BITS | (cnt < HT_CNT_MAX ? cnt : HT_CNT_MAX);
         if (in && slot + 1 >= n_slots) *overflow = 1u;      // the last slot must stay empty
         if (!last_slot) {
@@ -186,6 +188,9 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
     __syncthreads();
     for (u32 i = threadIdx.x; i < OCC_LDS_BINS && i <= max_bin; i += blockDim.x)
         if (lh[i]) atomicAdd(&occ_hist[i], lh[i]);
+    // total displacement (slot - home) of the block's runs -> the two words at occ_hist[max_bin + 2] (LRGE_C_TABLE_DISP_SUM)
+    for (int s2 = 32; s2 > 0; s2 >>= 1) disp_sum += (u32)__shfl_xor((i32)disp_sum, s2, 64);
+    if (lane == 0 && disp_sum) atomicAdd((unsigned long long *)(occ_hist + max_bin + 2 + ((max_bin + 2) & 1)), (unsigned long long)disp_sum);
 }
 
 // clears the slots behind the last run (slack + whatever the homes left free at the end); *last_slot from k_place_apply

@@ -985,7 +985,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         if (cap + n_runs >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32/3 distinct minimizers (got %u)", n_runs); return LRGE_ERR_TOO_MANY; }
         ix->ht_cap = cap; ix->ht_fix = ht_fix;
         ix->n_keys = n_runs;
-        u32 *d_occ = sc.get<u32>((size_t)max_bin + 2);     // [max_bin + 1] = overflow flag
+        u32 *d_occ = sc.get<u32>((size_t)max_bin + 5);     // [max_bin + 1] = overflow flag, then (8-byte aligned) the u64 sum of displacements
         if (!d_occ) return LRGE_ERR_DEVICE;
         u64 *ht = nullptr;
         occ.assign((size_t)max_bin + 1, 0);
@@ -1002,7 +1002,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             // first, then 16-byte entry stores -- the form of rounds 1-2, for A/B runs)
             const bool fused_fill = n_runs != 0 && !ctx->opt("HT_MEMSET");
             if (!fused_fill) HIPCHK(ctx, hipMemsetAsync(ht, 0xFF, 2 * n_slots * 8, ctx->stream));   // key = HT_EMPTY
-            HIPCHK(ctx, hipMemsetAsync(d_occ, 0, ((size_t)max_bin + 2) * 4, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(d_occ, 0, ((size_t)max_bin + 5) * 4, ctx->stream));
             if (n_runs) {
                 const u32 n_tiles = (u32)div_up(n_runs, PLACE_TILE);
                 u32 *bmax = sc.get<u32>((size_t)n_tiles + 1);
@@ -1023,10 +1023,12 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             }
             // the k-th smallest occurrence count almost always sits in the first few bins: fetch 16 KB of
             // the histogram first, the whole 4 MB only if the prefix does not reach the k-th element
-            u32 overflow = 0;
+            u32 overflow = 0; u64 disp_sum = 0;
             HIPCHK(ctx, ctx->d2h(occ.data(), d_occ, head_bins * 4, ctx->stream));
             HIPCHK(ctx, ctx->d2h(&overflow, d_occ + max_bin + 1, 4, ctx->stream));
+            HIPCHK(ctx, ctx->d2h(&disp_sum, d_occ + max_bin + 2 + ((max_bin + 2) & 1), 8, ctx->stream));
             HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+            ctx->counters[LRGE_C_TABLE_DISP_SUM] = disp_sum;
             if (!overflow) break;
             sc.drop(ht); ht = nullptr;
             if (attempt == 1) { LRGE_SET_ERR(ctx, "index table placement overflowed%s", ""); return LRGE_ERR_DEVICE; }

@@ -31,11 +31,27 @@ __host__ __device__ __forceinline__ u32 ht_fix_of(int k) {
     const int nb = (B + 7) / 8;                       // bytes of the hash; the partial one is byte nb - 1 -> bits [64 - 8 nb, +8)
     return (u32)(64 - 8 * nb) | (u32)(8 - part) << 8;
 }
+// + the exponent of the distribution correction of the partial byte (0: linear stretch only)
+__host__ __device__ __forceinline__ u32 ht_fix_with_power(int k, u32 pw) { const u32 f = ht_fix_of(k); return f ? f | pw << 16 : 0u; }
 __device__ __forceinline__ u64 ht_home(u64 key, u64 cap, u32 fix) {
     u64 bs = __builtin_bswap64(key);
-    const u32 pos = fix & 0xff, tsh = fix >> 8;
+    const u32 pos = fix & 0xff, tsh = (fix >> 8) & 0xff, pw = fix >> 16;
     const u64 pb = bs & (0xFFull << pos);
-    bs = (bs ^ pb) | (pb << tsh);                      // (tsh == 0: unchanged)
+    u64 nb = pb << tsh;                                // (tsh == 0: unchanged)
+    if (pw) {
+        // The partial byte holds the TOP bits of the hash, and minimizer hashes are window minima: P(h > x) ~ (1 - x)^w, three
+        // quarters of them lie in the first quarter of the range.  Any monotone map of that byte keeps the table's order, so it
+        // is sent through the distribution function 1 - (1 - t)^pw, which spreads the keys of a stretch evenly over it.
+        const u32 bits = 8 - tsh, v = (u32)(pb >> pos);                // v in [0, 2^bits)
+        const u32 u = (1u << bits) - v;                                  // 1 .. 2^bits
+        u64 p = u;
+        for (u32 e = 1; e < pw; ++e) p *= u;                             // u^pw <= 2^(bits * pw) <= 2^48
+        const u32 sh = bits * pw - 8;
+        u32 f = 256u - (u32)(p >> sh);                                   // 256 * (1 - (u / 2^bits)^pw), 0 .. 256
+        f = f > 255u ? 255u : f;
+        nb = (u64)f << pos;
+    }
+    bs = (bs ^ pb) | nb;
     return __umul64hi(bs, cap);
 }
 

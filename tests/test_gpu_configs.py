@@ -144,9 +144,10 @@ def test_c4_sampled_and_properties(ctx, oracle):
     ix = engine.Index(ctx, Td, 0)
     # regression guard for the ordered table (k_index.h, ht_home): the 30-bit hash leaves the top byte partly empty, and
     # byte-reversed that byte sits in the middle of the home-slot key -- unless it is stretched to a full byte the keys of every
-    # 22-slot stretch crowd into its first quarter (mean displacement 3.1 slots instead of 1.05 at this size, 117 instead of 77
-    # bytes fetched per probe).  Results never depend on it; only a table of this size shows it.
-    assert ix.build_counters["table_disp_sum"] < 1.5 * ix.stats()["n_keys"]
+    # 22-slot stretch crowd into its first quarter (mean displacement 3.1 slots; 1.05 with the byte stretched; 0.30 with the byte
+    # also sent through the distribution function of a window minimum, the default).  Results never depend on it; only a table
+    # of this size shows it.
+    assert ix.build_counters["table_disp_sum"] < 0.6 * ix.stats()["n_keys"]
     counts, has = ix.overlap_twoset(Qd)
     st = ix.stats()
     # size-independent properties on all 50 000 queries

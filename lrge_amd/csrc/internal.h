@@ -81,6 +81,9 @@ struct DevPool {
             if (blks[i].p == p) { (void)hipFree(p); total -= blks[i].cap; blks.erase(blks.begin() + i); return; }
     }
     size_t cap_of(void *p) const { for (auto &b : blks) if (b.p == p) return b.cap; return 0; }
+    // bytes the pool holds but nobody uses: what an allocation can get back (by reuse, or by trim() + hipMalloc) on top of
+    // the device's free memory.  `total` also counts the blocks in use -- a resident 150 GB index is not available memory
+    size_t idle() const { size_t n = 0; for (auto &b : blks) if (!b.used) n += b.cap; return n; }
     void trim() {
         std::vector<Blk> keep;
         for (auto &b : blks) { if (b.used) keep.push_back(b); else { (void)hipFree(b.p); total -= b.cap; } }
@@ -200,7 +203,8 @@ struct lrge_hip_index {
     const lrge_hip_seqset *seqs;
     int preset_id;
     Preset P;
-    u64 n_mz = 0, n_keys = 0;
+    u64 n_mz = 0, n_keys = 0;   // what lrge_hip_index_stats reports (a restricted build: those of the WHOLE target set)
+    u64 n_entries = 0;          // entries resident in d_pos / d_skey (a restricted build holds fewer than n_mz)
     int mid_occ = 0;
     u64 *d_pos = nullptr;       // [n_mz] y values grouped by key, ascending within a key
     u64 *d_skey = nullptr;      // [n_mz] sorted keys (kept for index_dump / tests)

@@ -497,7 +497,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     const u64 slot_bytes = (u64)n_chunks * SK_CAP * 8 * (pk ? 1 : 2);
     size_t mfree = (size_t)64 << 30, mtot = 0;
     if (slot_bytes > ((u64)4 << 30)) (void)hipMemGetInfo(&mfree, &mtot);       // (small sets: no need to ask)
-    bool one_pass = n_chunks && !ctx->opt("SKETCH_TWO_PASS") && slot_bytes < ((u64)mfree + ctx->pool.total) / 4;
+    bool one_pass = n_chunks && !ctx->opt("SKETCH_TWO_PASS") && slot_bytes < ((u64)mfree + ctx->pool.idle()) / 4;
     const char *cap_env = ctx->opt("DEBUG_SK_CAP");                      // tests: force the overflow fallback
     const u32 sk_cap = cap_env ? (u32)std::min<u64>(strtoull(cap_env, nullptr, 10), SK_CAP) : (u32)SK_CAP;
     u64 *tx = nullptr, *ty = nullptr;
@@ -700,7 +700,7 @@ static int sketch_restrict_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip
     const u64 slot_bytes = (u64)n_chunks * SK_CAP * 8 * (pk ? 2 : 3);
     size_t mfree = (size_t)64 << 30, mtot = 0;
     if (slot_bytes > ((u64)4 << 30)) (void)hipMemGetInfo(&mfree, &mtot);
-    if (slot_bytes >= ((u64)mfree + ctx->pool.total) / 4) return LRGE_OK;
+    if (slot_bytes >= ((u64)mfree + ctx->pool.idle()) / 4) return LRGE_OK;
     const u32 sk_cap = ctx->opt("DEBUG_SK_CAP") ? (u32)std::min<u64>(ctx->opt_u64("DEBUG_SK_CAP", SK_CAP), SK_CAP) : (u32)SK_CAP;
     u64 *tx = sc.get<u64>((size_t)n_chunks * SK_CAP), *ty = pk ? nullptr : sc.get<u64>((size_t)n_chunks * SK_CAP);
     u64 *th = sc.get<u64>((size_t)n_chunks * SK_CAP);
@@ -962,7 +962,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
 
     lrge_hip_index *ix = new lrge_hip_index();
     IndexGuard ix_guard(ix);
-    ix->ctx = ctx; ix->seqs = targets; ix->preset_id = preset; ix->P = P; ix->n_mz = M;
+    ix->ctx = ctx; ix->seqs = targets; ix->preset_id = preset; ix->P = P; ix->n_mz = M; ix->n_entries = M;
     u32 n_runs = 0;
     const u32 max_bin = (u32)P.max_mid_occ + 1;
     std::vector<u32> occ;
@@ -1252,25 +1252,25 @@ extern "C" int lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, 
     if (!ix->parts.empty()) { LRGE_SET_ERR(ctx, "index_dump: not implemented for a partitioned index"); return LRGE_ERR_TOO_MANY; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
-    *n_out = ix->n_mz;
-    u64 m = ix->n_mz < cap ? ix->n_mz : cap;
+    *n_out = ix->n_entries;
+    u64 m = ix->n_entries < cap ? ix->n_entries : cap;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
     // the device keeps the stream ordered by the byte-reversed hash (k_index.h); the dump presents it in
     // ascending hash order, lists ascending in y, i.e. the order mm_idx_get users see (debug / test entry point)
-    std::vector<u64> hk(ix->n_mz), hp(ix->n_mz);
-    if (ix->n_mz) {
-        HIPCHK(ctx, hipMemcpy(hk.data(), ix->d_skey, ix->n_mz * 8, hipMemcpyDeviceToHost));
-        HIPCHK(ctx, hipMemcpy(hp.data(), ix->d_pos, ix->n_mz * 8, hipMemcpyDeviceToHost));
+    std::vector<u64> hk(ix->n_entries), hp(ix->n_entries);
+    if (ix->n_entries) {
+        HIPCHK(ctx, hipMemcpy(hk.data(), ix->d_skey, ix->n_entries * 8, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(hp.data(), ix->d_pos, ix->n_entries * 8, hipMemcpyDeviceToHost));
     }
     if (ix->pk_ybits) {   // packed entries -> (hash, y)
         const u64 ym = (1ULL << ix->pk_ybits) - 1, pm = (1ULL << ix->pk_pos1) - 1;
-        for (u64 i = 0; i < ix->n_mz; ++i) {
+        for (u64 i = 0; i < ix->n_entries; ++i) {
             const u64 e = hk[i], yb = e & ym;
             hk[i] = e >> ix->pk_ybits; hp[i] = (yb >> ix->pk_pos1) << 32 | (yb & pm);
         }
     }
-    std::vector<u32> ord(ix->n_mz);
-    for (u64 i = 0; i < ix->n_mz; ++i) ord[i] = (u32)i;
+    std::vector<u32> ord(ix->n_entries);
+    for (u64 i = 0; i < ix->n_entries; ++i) ord[i] = (u32)i;
     std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return hk[a] < hk[b]; });
     for (u64 i = 0; i < m; ++i) {
         if (keys) keys[i] = hk[ord[i]];
@@ -1628,7 +1628,7 @@ int OverlapRun::plan() {
     {
         size_t mfree = 0, mtotal = 0;
         if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
-            const u64 by_mem = ((u64)mfree + ctx->pool.total) / 2 / 64;     // the pool's cached blocks are reusable too
+            const u64 by_mem = ((u64)mfree + ctx->pool.idle()) / 2 / 64;     // the pool's idle blocks are reusable too (not the ones in use: a resident index)
             if (by_mem < batch_cap) batch_cap = by_mem;
         }
         if (batch_cap < (1ULL << 20)) batch_cap = 1ULL << 20;

@@ -5,7 +5,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <string>
 #include <vector>
@@ -41,55 +44,121 @@ inline Preset make_preset(int preset) {
     return p;
 }
 
-// Caching device allocator: blocks are reused across calls, freed when the ctx dies.
+// Device memory of a context: an arena allocator (the role of minimap2's kalloc / ThreadLocalBuffer, thread_buf.rs:7-42).
+// hipMalloc costs ~25 ms per GB on this platform (measured: 321 GB of requests = 9.4 s of a 10.3 s H. sapiens-scale index
+// build when every odd-sized request went to the runtime), and hipFree synchronises the device.  So memory is taken from
+// the runtime in a few large SEGMENTS that grow geometrically, and requests are served from them by best fit with
+// splitting; released blocks coalesce with their free neighbours.  Nothing goes back to the runtime before the context
+// dies, except under memory pressure (trim(): wholly idle segments).  A released block is reusable at once: every user
+// is ordered on the context's streams (internal.h: Scratch; side streams are joined with events before a block is
+// released).
 struct DevPool {
-    struct Blk { void *p; size_t cap; bool used; };
-    std::vector<Blk> blks;
-    size_t total = 0;
+    struct Blk { size_t size; bool used; int seg; };
+    std::map<char *, Blk> blks;                         // every block of every segment, by address
+    std::multimap<size_t, char *> free_by_size;         // the free ones, for best fit
+    struct Seg { char *base; size_t size; };
+    std::vector<Seg> segs;
+    size_t total = 0;                                   // bytes held from the runtime (all segments)
+    size_t in_use = 0;
     long fail_every = 0, misses = 0;
+    // bookkeeping for option VERBOSE: what the device allocator itself cost
+    double ms_malloc = 0, ms_free = 0; u64 n_malloc = 0, n_free = 0, n_trim = 0, bytes_malloc = 0;
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    static constexpr size_t kAlign = 256, kMinSeg = (size_t)64 << 20, kSplitMin = (size_t)64 << 10;
+
+    void unfree(std::map<char *, Blk>::iterator it) {
+        auto r = free_by_size.equal_range(it->second.size);
+        for (auto f = r.first; f != r.second; ++f) if (f->second == it->first) { free_by_size.erase(f); return; }
+    }
+    void *take(std::map<char *, Blk>::iterator it, size_t bytes) {
+        unfree(it);
+        const size_t rest = it->second.size - bytes;
+        if (rest >= kSplitMin) {
+            it->second.size = bytes;
+            char *q = it->first + bytes;
+            blks[q] = Blk{rest, false, it->second.seg};
+            free_by_size.emplace(rest, q);
+        }
+        it->second.used = true;
+        in_use += it->second.size;
+        return it->first;
+    }
     void *alloc(size_t bytes, hipError_t *err) {
-        if (bytes == 0) bytes = 256;
-        bytes = (bytes + 255) & ~(size_t)255;
-        int best = -1;
-        for (size_t i = 0; i < blks.size(); ++i)
-            if (!blks[i].used && blks[i].cap >= bytes && (best < 0 || blks[i].cap < blks[best].cap)) best = (int)i;
-        if (best >= 0 && blks[best].cap <= bytes * 2 + (1 << 20)) { blks[best].used = true; return blks[best].p; }
-        void *p = nullptr;
+        if (bytes == 0) bytes = kAlign;
+        bytes = (bytes + kAlign - 1) & ~(kAlign - 1);
+        auto f = free_by_size.lower_bound(bytes);
+        if (f != free_by_size.end()) return take(blks.find(f->second), bytes);
+        // a new segment: at least what is held already (geometric growth -> few, large segments that split well), never
+        // less than the request; if the runtime cannot give that much, exactly the request, after returning idle segments
         // test hook (option DEBUG_ALLOC_FAIL_EVERY, per context, set by lrge_hip_ctx_set_option only): every n-th miss asks
         // for an impossible size first, i.e. takes the genuine failure + retry path
         const bool sabotage = fail_every > 0 && (++misses % fail_every) == 0;
-        hipError_t e = hipMalloc(&p, sabotage ? ((size_t)1 << 60) : bytes);
-        if (e != hipSuccess) {  // drop the cache and retry once
+        size_t want = std::max(bytes, std::max(kMinSeg, std::min(total, (size_t)32 << 30)));
+        want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        void *p = nullptr;
+        const double t0 = now_ms();
+        hipError_t e = hipMalloc(&p, sabotage ? ((size_t)1 << 60) : want);
+        if (e != hipSuccess && !sabotage && want > bytes) {      // not that much left: exactly the request
+            (void)hipGetLastError(); want = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) {  // give idle segments back and retry once
             (void)hipGetLastError();          // the failed attempt must not linger as the "last error" of a later launch check
             trim();
-            e = hipMalloc(&p, bytes);
+            e = hipMalloc(&p, want);
         }
+        ms_malloc += now_ms() - t0; ++n_malloc;
         if (e != hipSuccess) { (void)hipGetLastError(); *err = e; return nullptr; }
-        blks.push_back({p, bytes, true});
-        total += bytes;
-        return p;
+        bytes_malloc += want;
+        segs.push_back(Seg{(char *)p, want});
+        total += want;
+        auto it = blks.emplace((char *)p, Blk{want, false, (int)segs.size() - 1}).first;
+        free_by_size.emplace(want, (char *)p);
+        return take(it, bytes);
     }
     void release(void *p) {
         if (!p) return;
-        for (auto &b : blks) if (b.p == p) { b.used = false; return; }
+        auto it = blks.find((char *)p);
+        if (it == blks.end() || !it->second.used) return;
+        it->second.used = false;
+        in_use -= it->second.size;
+        // coalesce with the free neighbours of the same segment
+        auto nx = std::next(it);
+        if (nx != blks.end() && !nx->second.used && nx->second.seg == it->second.seg && nx->first == it->first + it->second.size) {
+            unfree(nx); it->second.size += nx->second.size; blks.erase(nx);
+        }
+        if (it != blks.begin()) {
+            auto pv = std::prev(it);
+            if (!pv->second.used && pv->second.seg == it->second.seg && pv->first + pv->second.size == it->first) {
+                unfree(pv); pv->second.size += it->second.size; blks.erase(it); it = pv;
+            }
+        }
+        free_by_size.emplace(it->second.size, it->first);
     }
-    // give a block back to the device right away (a multi-gigabyte staging buffer nobody will ask for again: kept in the
-    // cache it would stand in the way of everything else until an allocation fails)
-    void free_now(void *p) {
-        if (!p) return;
-        for (size_t i = 0; i < blks.size(); ++i)
-            if (blks[i].p == p) { (void)hipFree(p); total -= blks[i].cap; blks.erase(blks.begin() + i); return; }
-    }
-    size_t cap_of(void *p) const { for (auto &b : blks) if (b.p == p) return b.cap; return 0; }
-    // bytes the pool holds but nobody uses: what an allocation can get back (by reuse, or by trim() + hipMalloc) on top of
-    // the device's free memory.  `total` also counts the blocks in use -- a resident 150 GB index is not available memory
-    size_t idle() const { size_t n = 0; for (auto &b : blks) if (!b.used) n += b.cap; return n; }
+    // (round 2 gave multi-gigabyte staging blocks back to the runtime at once; inside an arena a released block serves any
+    // later request, so this is release())
+    void free_now(void *p) { release(p); }
+    size_t cap_of(void *p) const { auto it = blks.find((char *)p); return it == blks.end() ? 0 : it->second.size; }
+    // bytes held but not in use: what requests can be served from without asking the runtime (fragmentation aside).
+    // `total` also counts the blocks in use -- a resident 150 GB index is not available memory
+    size_t idle() const { return total - in_use; }
+    // wholly idle segments go back to the runtime (memory pressure only: hipFree synchronises the device)
     void trim() {
-        std::vector<Blk> keep;
-        for (auto &b : blks) { if (b.used) keep.push_back(b); else { (void)hipFree(b.p); total -= b.cap; } }
-        blks.swap(keep);
+        const double t0 = now_ms(); ++n_trim;
+        for (size_t si = 0; si < segs.size(); ++si) {
+            if (!segs[si].base) continue;
+            auto it = blks.find(segs[si].base);
+            if (it == blks.end() || it->second.used || it->second.size != segs[si].size) continue;
+            unfree(it); blks.erase(it);
+            (void)hipFree(segs[si].base); ++n_free;
+            total -= segs[si].size;
+            segs[si].base = nullptr; segs[si].size = 0;
+        }
+        ms_free += now_ms() - t0;
     }
-    void destroy() { for (auto &b : blks) (void)hipFree(b.p); blks.clear(); total = 0; }
+    void destroy() {
+        for (auto &sg : segs) if (sg.base) (void)hipFree(sg.base);
+        segs.clear(); blks.clear(); free_by_size.clear(); total = 0; in_use = 0;
+    }
 };
 
 struct TimerRec;

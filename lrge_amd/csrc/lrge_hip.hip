@@ -142,8 +142,18 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
     return LRGE_OK;
 }
 
+static void pool_report(lrge_hip_ctx *ctx, const char *where) {
+    if (!ctx->opt("VERBOSE")) return;
+    const DevPool &P = ctx->pool;
+    size_t n_seg = 0; for (const auto &sg : P.segs) n_seg += sg.base != nullptr;
+    fprintf(stderr, "[lrge_hip] pool at %s: %zu blocks in %zu segments, %.1f GB held (%.1f idle); so far %llu hipMalloc (%.1f GB, %.0f ms), %llu trims freeing %llu segments (%.0f ms)\n",
+            where, P.blks.size(), n_seg, P.total / 1073741824.0, P.idle() / 1073741824.0, (unsigned long long)P.n_malloc, P.bytes_malloc / 1073741824.0, P.ms_malloc,
+            (unsigned long long)P.n_trim, (unsigned long long)P.n_free, P.ms_free);
+}
+
 extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
     if (!ctx) return;
+    pool_report(ctx, "ctx_destroy");
     { std::lock_guard<std::mutex> g(g_live_mu); g_live_ctx.erase(ctx); }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -236,10 +246,7 @@ static int seqset_ready(lrge_hip_ctx *ctx, const lrge_hip_seqset *cs) {
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_ready, 0));
     s->pending = false;
     if (s->meta_arena) { s->meta_arena = false; if (--ctx->meta_inflight == 0) ctx->meta_used = 0; }
-    if (ctx->pool.cap_of(s->stg_ascii) > ((size_t)4 << 30)) {      // tens of gigabases of ASCII: not worth caching
-        (void)hipStreamSynchronize(ctx->copy_stream);                // (the pack that read it has run; hipFree would wait anyway)
-        ctx->pool.free_now(s->stg_ascii);
-    } else ctx->pool.release(s->stg_ascii);
+    ctx->pool.release(s->stg_ascii);      // (an arena block: whatever its size, it serves any later request)
     s->stg_ascii = nullptr;       // (stg_boff / stg_blk live inside the set's meta block)
     return LRGE_OK;
 }
@@ -1074,6 +1081,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     t_total.stop();
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->resolve_timers();
+    pool_report(ctx, "index_build_one");
     *out = ix_guard.release();
     return LRGE_OK;
 }
@@ -1982,6 +1990,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         t_total.stop();
         const hipError_t e = hipStreamSynchronize(ctx->stream);
         ctx->resolve_timers();
+        pool_report(ctx, "run_overlap");
         if (rc == LRGE_OK && e != hipSuccess) { LRGE_SET_ERR(ctx, "stream: %s", hipGetErrorString(e)); return LRGE_ERR_DEVICE; }
         return rc;
     };

@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--preset", default="ont", choices=["ont", "pb"])
     ap.add_argument("--inverse", action="store_true", help="--use-min-ref: index the queries, stream the targets")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the config (debug only; invalid as a result)")
+    ap.add_argument("--generator", default="auto", choices=["auto", "pcg", "cb"],
+                    help="pcg: lrge_amd.synth (sequential numpy generator, host); cb: lrge_amd.synth_cb (counter-based, reads written "
+                         "straight into HBM by the device twin -- what makes c5_human_twoset, 31.5 Gbases, a bench workload); "
+                         "auto = cb for c5_human_twoset, pcg otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -88,6 +92,40 @@ def cpu_baseline(q, t, budget_s, preset):
         (np.concatenate(counts) if counts else np.zeros(0, np.uint32)), ix.mid_occ
 
 
+def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
+    """The same leg for a job whose target set the host cannot index inside a bench run (H. sapiens-scale: 30 Gbases):
+    the oracle indexes 1/F of the target reads (host twin of the generator) and maps query reads against that index
+    for ~budget seconds.  Pro-rated to the whole job as  time = F x index time + F x map time per read x reads  --
+    the seed hits, anchors and chains of a query grow with the number of target reads, its own sketch (a small part)
+    does not, so this slightly overstates the CPU's time per read and is labelled as what it is: a sample."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    F = 40
+    nt = max(1000, Tn // F)
+    opt = O.make_opt(O.PRESET_AVA_PB if preset else O.PRESET_AVA_ONT, dual=True)
+    t = spec.host_reads(first=Qn, n=nt)
+    t0 = time.perf_counter()
+    ix = O.Index(O.ReadSet(t.seqs(), t.names), opt)
+    t_index = time.perf_counter() - t0
+    done, t_map, chunk = 0, 0.0, max(64, 8 * cores)
+    while done < Qn and t_map < budget_s:
+        hi = min(Qn, done + chunk)
+        sub = spec.host_reads(first=done, n=hi - done)
+        Q = O.ReadSet(sub.seqs(), sub.names)
+        t1 = time.perf_counter()
+        rc, c, _ = ix.twoset_counts(Q, threads=cores)
+        t_map += time.perf_counter() - t1
+        assert rc == 0
+        done = hi
+    scale = Tn / nt
+    t_job = scale * t_index + scale * (t_map / done) * Qn
+    return dict(value=Qn / t_job, unit="reads/s", cores=cores, kind="port",
+                sample="SAMPLE of the job: oracle index over %d of the %d target reads (%.1f s), %d query reads mapped against it on %d "
+                       "threads (%.1f s); pro-rated x%.1f in the target dimension (index time and per-read map time both scale with "
+                       "the number of target reads) and to all %d queries" % (nt, Tn, t_index, done, cores, t_map, scale, Qn),
+                index_s_sample=t_index, map_s_sample=t_map, reads_mapped=done)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -108,12 +146,24 @@ def main():
     preset = 1 if a.preset == "pb" else 0
 
     # ---- synthetic inputs (untimed; every rank draws the same seeded job) ----
-    cfg = synth.CONFIGS[a.config]
-    assert cfg["mode"] == "twoset", "bench.py times the two-set path"
+    gen = a.generator if a.generator != "auto" else ("cb" if a.config == "c5_human_twoset" else "pcg")
     t_gen = time.perf_counter()
-    gsize, q, t = synth.make_config(a.config, a.scale)
+    if gen == "cb":
+        from lrge_amd import synth_cb
+        spec, Qn, Tn = synth_cb.spec_of(a.config, a.scale)
+        cfg = dict(synth_cb.CONFIGS[a.config], mode="twoset")
+        gsize = spec.gsize
+        q = t = None
+        # emitted lengths of every read (one counting pass of the device twin; the bases themselves follow below, per rank)
+        all_lens = spec.emitted_lens(0, Qn + Tn, local_rank)
+        q_lens, t_lens = all_lens[:Qn].astype(np.int64), all_lens[Qn:].astype(np.int64)
+    else:
+        cfg = synth.CONFIGS[a.config]
+        assert cfg["mode"] == "twoset", "bench.py times the two-set path"
+        gsize, q, t = synth.make_config(a.config, a.scale)
+        Qn, Tn = q.n, t.n
+        q_lens, t_lens = q.lens(), t.lens()
     t_gen = time.perf_counter() - t_gen
-    Qn, Tn = q.n, t.n
 
     ctx = engine.Context(local_rank)
     comm, transport, rccl_thread = None, None, None
@@ -153,7 +203,6 @@ def main():
                 transport = "host (gloo) -- another rank could not create its RCCL communicator"
             comm = parallel.HostComm(ctx, dist)
 
-    qr, tr = engine.name_ranks(q.names, t.names)
     emu = None
     if a.emulate_rank:
         er, en = (int(x) for x in a.emulate_rank.split("/"))
@@ -164,20 +213,33 @@ def main():
     my = emu[0] if emu else rank
     # strong scaling: the STREAMED set is cut into contiguous ranges with equal base counts -- the queries in the forward
     # strategy (twoset.rs:266-334), the targets with --inverse (--use-min-ref, twoset.rs:485-565)
-    bounds = parallel.shard_by_bases(t.lens() if a.inverse else q.lens(), n_shards)
+    bounds = parallel.shard_by_bases(t_lens if a.inverse else q_lens, n_shards)
     lo, hi = bounds[my], bounds[my + 1]
-    if a.inverse:
-        qs, qs_rank = q, qr                                      # indexed set: every rank holds all of it
-        ts, ts_rank = (t, tr) if n_shards == 1 else (t.slice(lo, hi), tr[lo:hi])
-    else:
-        qs, qs_rank = (q, qr) if n_shards == 1 else (q.slice(lo, hi), qr[lo:hi])
-        ts, ts_rank = t, tr
-    avg_t = np.float32(t.lens().sum()) / np.float32(t.n)
+    q_rng = (0, Qn) if (a.inverse or n_shards == 1) else (lo, hi)       # this rank's reads of each set
+    t_rng = (lo, hi) if (a.inverse and n_shards > 1) else (0, Tn)
+    avg_t = np.float32(t_lens.sum()) / np.float32(Tn)
     shard_lens = [bounds[i + 1] - bounds[i] for i in range(n_shards)]
     max_shard = max(shard_lens)
 
-    # the two homes of the ASCII reads: HBM (value) and pinned host memory (from_host)
-    d_q = torch.from_numpy(qs.bases).cuda(); d_t = torch.from_numpy(ts.bases).cuda()
+    class Src:
+        """One read set of this rank's job: offsets, name ranks, and where its ASCII bases live (HBM; host on request)."""
+
+    qs, ts = Src(), Src()
+    if gen == "cb":
+        # names are r%08d of the read index, so the index is the lexicographic rank over the union of both sets
+        for S, (r0, r1), first in ((qs, q_rng, 0), (ts, t_rng, Qn)):
+            S.dev = spec.device_reads(first + r0, r1 - r0, local_rank)      # ASCII straight into HBM
+            S.n, S.offsets, S.rank, S.nbytes, S.ptr = r1 - r0, S.dev.offsets, S.dev.name_ranks(), S.dev.total_bases, S.dev.ptr
+            S.host = S.dev.to_host
+    else:
+        qr, tr = engine.name_ranks(q.names, t.names)
+        for S, R, rk, (r0, r1) in ((qs, q, qr, q_rng), (ts, t, tr, t_rng)):
+            sub = R if (r0, r1) == (0, R.n) else R.slice(r0, r1)
+            S.n, S.offsets, S.rank, S.nbytes = sub.n, sub.offsets, rk[r0:r1], sub.bases.size
+            S.tensor = torch.from_numpy(sub.bases).cuda()               # the ASCII reads resident in HBM (value)
+            S.ptr = S.tensor.data_ptr()
+            S.host = (lambda sub=sub: sub.bases)
+    qs_lens = q_lens[q_rng[0]:q_rng[1]]
     torch.cuda.synchronize()
 
     def sync_all():
@@ -190,8 +252,8 @@ def main():
         """src_*: int device pointer (ASCII resident in HBM) or PinnedBuffer (ASCII in pinned host memory)."""
         if a.inverse:
             # index = the query set (small), the streamed targets of this rank travel / pack while it is built
-            Qd = ctx.upload(src_q, qs.offsets, qs_rank, wait=False)
-            Td = ctx.upload(src_t, ts.offsets, ts_rank, wait=False)
+            Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)
+            Td = ctx.upload(src_t, ts.offsets, ts.rank, wait=False)
             if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
                 Td.presketch(preset)
             ix = engine.Index(ctx, Qd, preset)
@@ -201,17 +263,17 @@ def main():
             ix.free(); Qd.free(); Td.free()
             if comm is not None:    # the one collective that closes the step: count vector keyed by indexed read (twoset.rs:520-523)
                 counts = comm.all_reduce_u32(counts)
-            est_all = ctx.estimates(counts, q.lens(), float(avg_t), t.n, 100)
+            est_all = ctx.estimates(counts, q_lens, float(avg_t), Tn, 100)
         else:
-            Td = ctx.upload(src_t, ts.offsets, ts_rank, wait=False)      # K0 pack (and PCIe, from the host) on the copy stream
-            Qd = ctx.upload(src_q, qs.offsets, qs_rank, wait=False)      # travels / packs while the index is built
+            Td = ctx.upload(src_t, ts.offsets, ts.rank, wait=False)      # K0 pack (and PCIe, from the host) on the copy stream
+            Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)      # travels / packs while the index is built
             if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
                 Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
             ix = engine.Index(ctx, Td, preset, streamed=Qd if comm is not None or emu or os.environ.get("LRGE_BENCH_RESTRICT") else None, comm=comm)
             tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
             counts, has = ix.overlap_twoset(Qd)
             tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
-            est = ctx.estimates(counts, qs.lens(), float(avg_t), t.n, 100)
+            est = ctx.estimates(counts, qs_lens, float(avg_t), Tn, 100)
             ix.free(); Qd.free(); Td.free()
             if comm is not None:    # the one collective that closes the step: per-read estimate vectors over RCCL/xGMI
                 est_all = comm.all_gather_f32(est, max_shard, shard_lens)
@@ -242,24 +304,26 @@ def main():
             elapsed = float(tt.item())
         return elapsed, acc_tb, acc_tm, acc_cn, last
 
-    elapsed, acc_tb, acc_tm, acc_cn, last = timed(d_q.data_ptr(), d_t.data_ptr(), a.warmup, a.steps)
+    elapsed, acc_tb, acc_tm, acc_cn, last = timed(qs.ptr, ts.ptr, a.warmup, a.steps)
     counts, est_all, med, _, _, _, st = last
     # one instrumented step AFTER the timed region: an event pair around every k_rs_scatter launch (timer level 2 costs
     # host work between launches, so the timed steps run at the default level)
     ctx.set_timer_level(2)
-    _, _, _, tb2, tm2, cn2, _ = step(d_q.data_ptr(), d_t.data_ptr())
+    _, _, _, tb2, tm2, cn2, _ = step(qs.ptr, ts.ptr)
     ctx.set_timer_level(1)
 
     from_host = None
     if not a.no_from_host and not emu:
-        hq = ctx.host_alloc(max(qs.bases.size, 1)); ht = ctx.host_alloc(max(ts.bases.size, 1))
-        hq.array[:qs.bases.size] = qs.bases; ht.array[:ts.bases.size] = ts.bases
+        hq = ctx.host_alloc(max(qs.nbytes, 1)); ht = ctx.host_alloc(max(ts.nbytes, 1))
+        hq.array[:qs.nbytes] = qs.host(); ht.array[:ts.nbytes] = ts.host()
+        if gen == "cb":       # the resident copies have done their part: their room goes to the staging blocks of the uploads
+            qs.dev.free(); ts.dev.free()
         k2 = max(3, a.steps // 2)
         e2, _, _, _, last2 = timed(hq, ht, 1, k2)
         from_host = {"ms_per_step": e2 * 1e3 / k2, "value": Qn * k2 / e2, "unit": "reads/s", "steps": k2,
                      "what": "same step with the ASCII reads in pinned host memory when the clock starts: %.2f GB over PCIe "
                              "inside the timed region, on the copy stream (queries travel while the target index is built)"
-                             % ((qs.bases.size + ts.bases.size) / 1e9),
+                             % ((qs.nbytes + ts.nbytes) / 1e9),
                      "counts_equal_resident_run": bool(np.array_equal(last2[0], counts))}
         hq.free(); ht.free()
 
@@ -304,9 +368,9 @@ def main():
         r_sc["measured"] = "one instrumented step after the timed region (event pair around every launch)"
         # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
         # (streamed set: the queries, or the targets with --inverse; for N > 1 rank 0's counters times the world size)
-        L = float((t if a.inverse else q).lens().sum()); M = world * acc_cn.get("query_minimizers", 0) / K; H = world * acc_cn.get("anchors", 0) / K
+        L = float((t_lens if a.inverse else q_lens).sum()); M = world * acc_cn.get("query_minimizers", 0) / K; H = world * acc_cn.get("anchors", 0) / K
         B_q = L / 4 + 32 * M + 8 * H + 32 * H + 4 * Qn
-        B_idx = float((q if a.inverse else t).lens().sum()) / 4 + 16 * st["n_minimizers"]
+        B_idx = float((q_lens if a.inverse else t_lens).sum()) / 4 + 16 * st["n_minimizers"]
         e2e_gbps = (B_q + B_idx) / (ms_per_step * 1e-3) / 1e9
         r_dom = cands[0] if cands else r_sc
         out = {
@@ -337,12 +401,20 @@ def main():
             "work_per_step": {k: (v if k == "lpg_split" else v / K) for k, v in acc_cn.items()},
         }
         if world == 1 and not a.no_cpu_baseline and not a.inverse:   # (the CPU leg times the forward strategy)
-            cb, ccounts, cmid = cpu_baseline(q, t, a.cpu_seconds, preset)
-            out["cpu_baseline"] = cb
-            out["gpu_vs_cpu_port"] = value / cb["value"]
-            n = len(ccounts)
-            out["parity_vs_oracle_sample"] = {"reads": n, "counts_equal": bool(np.array_equal(ccounts, counts[:n])),
-                                              "mid_occ_equal": bool(cmid == st["mid_occ"])}
+            if gen == "cb" and Tn > 400000:
+                cb = cpu_baseline_sampled(spec, Qn, Tn, a.cpu_seconds, preset)
+                out["cpu_baseline"] = cb
+                out["gpu_vs_cpu_port"] = value / cb["value"]
+                out["parity_vs_oracle_sample"] = None      # (no full-size oracle index inside a bench run: tests/test_gpu_configs.py::test_c5_full)
+            else:
+                if gen == "cb":
+                    q, t = spec.host_reads(first=0, n=Qn), spec.host_reads(first=Qn, n=Tn)
+                cb, ccounts, cmid = cpu_baseline(q, t, a.cpu_seconds, preset)
+                out["cpu_baseline"] = cb
+                out["gpu_vs_cpu_port"] = value / cb["value"]
+                n = len(ccounts)
+                out["parity_vs_oracle_sample"] = {"reads": n, "counts_equal": bool(np.array_equal(ccounts, counts[:n])),
+                                                  "mid_occ_equal": bool(cmid == st["mid_occ"])}
         print(json.dumps(out))
     if comm is not None:
         comm.close()

@@ -128,6 +128,14 @@ class Spec:
         return out
 
     # ---- device twin ----
+    def emitted_lens(self, first, n, device=0):
+        """Emitted length of reads [first, first + n) (the counting pass of the device twin alone)."""
+        ol = np.empty(n, np.uint32)
+        rc = _hip().cb_hip_count(device, C.byref(self.params), _vp(self.lentab), C.c_uint64(first), C.c_uint64(n), _vp(ol))
+        if rc:
+            raise RuntimeError("cb_hip_count: HIP error %d" % rc)
+        return ol
+
     def device_reads(self, first, n, device=0):
         """Reads [first, first + n) written into HBM.  Returns a DeviceReads (device pointer + host offsets / truth)."""
         L = _hip()

@@ -367,17 +367,31 @@ lo_index_t *lo_index_build(const char *bases, const uint64_t *offs, uint32_t n,
     ix->n_mz = (uint64_t)v.n; ix->mz = v.a;
     hy = (hy_t *)malloc((ix->n_mz ? ix->n_mz : 1) * sizeof(hy_t));
     {   /* sort by (hash, y): bucket on the top 12 hash bits (buckets concatenate into the global order),
-           then sort the buckets in parallel */
+           then sort the buckets in parallel.  The scatter is parallel too: (hash, y) is a total order on the entries of
+           one index (y = rid << 32 | pos << 1 | strand is unique), so where an entry lands inside its bucket before the
+           sort does not matter */
         const int shift = 2 * opt->k > 12 ? 2 * opt->k - 12 : 0;
         uint64_t *bstart = (uint64_t *)calloc(4097 + 1, 8), *fill;
-        int64_t b;
-        for (i = 0; i < ix->n_mz; ++i) ++bstart[((v.a[i].x >> 8) >> shift) + 1];
+        int64_t b, ii;
+#pragma omp parallel
+        {
+            uint64_t *loc = (uint64_t *)calloc(4096, 8);
+            int64_t t;
+#pragma omp for schedule(static) nowait
+            for (t = 0; t < (int64_t)ix->n_mz; ++t) ++loc[(v.a[t].x >> 8) >> shift];
+#pragma omp critical
+            for (t = 0; t < 4096; ++t) bstart[t + 1] += loc[t];
+            free(loc);
+        }
         for (i = 0; i < 4096; ++i) bstart[i + 1] += bstart[i];
         fill = (uint64_t *)malloc(4097 * 8);
         memcpy(fill, bstart, 4097 * 8);
-        for (i = 0; i < ix->n_mz; ++i) {
-            uint64_t h = v.a[i].x >> 8, d = fill[h >> shift]++;
-            hy[d].h = h; hy[d].y = v.a[i].y;
+#pragma omp parallel for schedule(static)
+        for (ii = 0; ii < (int64_t)ix->n_mz; ++ii) {
+            uint64_t h = v.a[ii].x >> 8, d;
+#pragma omp atomic capture
+            d = fill[h >> shift]++;
+            hy[d].h = h; hy[d].y = v.a[ii].y;
         }
         free(fill);
 #pragma omp parallel for schedule(dynamic, 8)
@@ -385,17 +399,34 @@ lo_index_t *lo_index_build(const char *bases, const uint64_t *offs, uint32_t n,
             if (bstart[b + 1] > bstart[b]) qsort(hy + bstart[b], bstart[b + 1] - bstart[b], sizeof(hy_t), cmp_hy);
         free(bstart);
     }
-    for (i = 0, j = 0; i < ix->n_mz; ++i)
-        if (i == 0 || hy[i].h != hy[i - 1].h) ++j;
-    ix->n_keys = j;
-    ix->key = (uint64_t *)malloc((j ? j : 1) * 8);
-    ix->off = (uint64_t *)malloc((j + 1) * 8);
-    ix->pos = (uint64_t *)malloc((ix->n_mz ? ix->n_mz : 1) * 8);
-    for (i = 0, j = 0; i < ix->n_mz; ++i) {
-        if (i == 0 || hy[i].h != hy[i - 1].h) { ix->key[j] = hy[i].h; ix->off[j] = i; ++j; }
-        ix->pos[i] = hy[i].y;
+    {   /* run heads -> key[], off[], pos[]: the heads are counted per block, the blocks' counts scanned, the arrays filled in parallel */
+        const int64_t nblk = 1024;
+        const uint64_t per = (ix->n_mz + (uint64_t)nblk - 1) / (uint64_t)nblk;
+        uint64_t *bh = (uint64_t *)calloc((size_t)nblk + 1, 8);
+        int64_t bb;
+#pragma omp parallel for schedule(static)
+        for (bb = 0; bb < nblk; ++bb) {
+            uint64_t lo = (uint64_t)bb * per, hi = lo + per < ix->n_mz ? lo + per : ix->n_mz, t, c = 0;
+            for (t = lo; t < hi; ++t) c += (t == 0 || hy[t].h != hy[t - 1].h);
+            bh[bb + 1] = c;
+        }
+        for (bb = 0; bb < nblk; ++bb) bh[bb + 1] += bh[bb];
+        j = bh[nblk];
+        ix->n_keys = j;
+        ix->key = (uint64_t *)malloc((j ? j : 1) * 8);
+        ix->off = (uint64_t *)malloc((j + 1) * 8);
+        ix->pos = (uint64_t *)malloc((ix->n_mz ? ix->n_mz : 1) * 8);
+#pragma omp parallel for schedule(static)
+        for (bb = 0; bb < nblk; ++bb) {
+            uint64_t lo = (uint64_t)bb * per, hi = lo + per < ix->n_mz ? lo + per : ix->n_mz, t, jj = bh[bb];
+            for (t = lo; t < hi; ++t) {
+                if (t == 0 || hy[t].h != hy[t - 1].h) { ix->key[jj] = hy[t].h; ix->off[jj] = t; ++jj; }
+                ix->pos[t] = hy[t].y;
+            }
+        }
+        ix->off[j] = ix->n_mz;
+        free(bh);
     }
-    ix->off[j] = ix->n_mz;
     free(hy);
 
     /* mm_mapopt_update: only when mid_occ was not given */
@@ -423,6 +454,116 @@ uint64_t lo_index_dump_minimizers(const lo_index_t *ix, lo_mm128_t *out, uint64_
     uint64_t n = ix->n_mz < cap ? ix->n_mz : cap;
     if (out) memcpy(out, ix->mz, n * sizeof(lo_mm128_t));
     return ix->n_mz;
+}
+
+static int cmp_u64(const void *pa, const void *pb);
+/* ------------------------------------------------------------------------------------------ */
+/* Index statistics of a target set too large to index here in one piece (H. sapiens-scale: 30 Gbases): the reads go  */
+/* through mm_sketch chunk by chunk, only the minimizer hashes are kept, and n_minimizers, n_keys and mid_occ follow   */
+/* with the arithmetic of calc_mid_occ above (the k-th smallest occurrence count over the distinct keys).              */
+/* ------------------------------------------------------------------------------------------ */
+struct lo_kstat { lo_opt_t opt; uint64_t *keys; uint64_t n, m; };
+
+lo_kstat_t *lo_kstat_new(const lo_opt_t *opt)
+{
+    lo_kstat_t *s = (lo_kstat_t *)calloc(1, sizeof(*s));
+    s->opt = *opt;
+    return s;
+}
+void lo_kstat_free(lo_kstat_t *s) { if (s) { free(s->keys); free(s); } }
+
+int lo_kstat_add(lo_kstat_t *s, const char *bases, const uint64_t *offs, uint32_t n, int threads)
+{
+    vec128_t *per = (vec128_t *)calloc(n ? n : 1, sizeof(vec128_t));
+    uint64_t *start = (uint64_t *)malloc(((size_t)n + 1) * 8), tot = 0;
+    int64_t r;
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (r = 0; r < (int64_t)n; ++r)
+        if (offs[r + 1] > offs[r])
+            sketch_into(bases + offs[r], (int32_t)(offs[r + 1] - offs[r]), s->opt.w, s->opt.k, (uint32_t)r, s->opt.is_hpc, &per[r]);
+    for (r = 0; r < (int64_t)n; ++r) { start[r] = tot; tot += (uint64_t)per[r].n; }
+    if (s->n + tot > s->m) {
+        s->m = (s->n + tot) * 5 / 4 + 1024;
+        s->keys = (uint64_t *)realloc(s->keys, s->m * 8);
+        if (!s->keys) return -1;
+    }
+#pragma omp parallel for schedule(dynamic, 16)
+    for (r = 0; r < (int64_t)n; ++r) {
+        int64_t t;
+        for (t = 0; t < per[r].n; ++t) s->keys[s->n + start[r] + (uint64_t)t] = per[r].a[t].x >> 8;
+        free(per[r].a);
+    }
+    s->n += tot;
+    free(per); free(start);
+    return 0;
+}
+
+int lo_kstat_finish(lo_kstat_t *s, int threads, uint64_t *n_mz, uint64_t *n_keys, int32_t *mid_occ)
+{
+    enum { NB = 4096, HB = 1 << 20 };
+    const int shift = 2 * s->opt.k > 12 ? 2 * s->opt.k - 12 : 0;
+    uint64_t *bstart = (uint64_t *)calloc(NB + 2, 8), *fill, *srt, *hist, nk = 0, i;
+    int64_t b, ii;
+    int32_t thres;
+    if (threads > 0) omp_set_num_threads(threads);
+    srt = (uint64_t *)malloc((s->n ? s->n : 1) * 8);
+    hist = (uint64_t *)calloc(HB + 1, 8);
+    if (!srt || !hist) return -1;
+#pragma omp parallel
+    {
+        uint64_t *loc = (uint64_t *)calloc(NB, 8);
+        int64_t t;
+#pragma omp for schedule(static) nowait
+        for (t = 0; t < (int64_t)s->n; ++t) ++loc[s->keys[t] >> shift];
+#pragma omp critical
+        for (t = 0; t < NB; ++t) bstart[t + 1] += loc[t];
+        free(loc);
+    }
+    for (i = 0; i < NB; ++i) bstart[i + 1] += bstart[i];
+    fill = (uint64_t *)malloc((NB + 1) * 8);
+    memcpy(fill, bstart, (NB + 1) * 8);
+#pragma omp parallel for schedule(static)
+    for (ii = 0; ii < (int64_t)s->n; ++ii) {
+        uint64_t d;
+#pragma omp atomic capture
+        d = fill[s->keys[ii] >> shift]++;
+        srt[d] = s->keys[ii];
+    }
+    free(fill);
+#pragma omp parallel
+    {
+        uint64_t *lh = (uint64_t *)calloc(HB + 1, 8), lk = 0;
+        int64_t t;
+#pragma omp for schedule(dynamic, 8) nowait
+        for (b = 0; b < NB; ++b) {
+            uint64_t lo = bstart[b], hi = bstart[b + 1], p, run = 0;
+            if (hi <= lo) continue;
+            qsort(srt + lo, hi - lo, 8, cmp_u64);
+            for (p = lo; p < hi; ++p) {
+                ++run;
+                if (p + 1 == hi || srt[p + 1] != srt[p]) { ++lk; ++lh[run < HB ? run : HB]; run = 0; }
+            }
+        }
+#pragma omp critical
+        { nk += lk; for (t = 0; t <= HB; ++t) hist[t] += lh[t]; }
+        free(lh);
+    }
+    free(srt); free(bstart);
+    /* calc_mid_occ: the k-th smallest count (0-based k = (1 - f) n) + 1, then the clamps of mm_mapopt_update */
+    if (s->opt.mid_occ_frac <= 0.f || nk == 0) thres = INT32_MAX;
+    else {
+        const uint64_t kth = (uint64_t)((1. - (double)s->opt.mid_occ_frac) * (double)nk);
+        uint64_t cum = 0, c;
+        thres = -1;
+        for (c = 0; c <= HB; ++c) { cum += hist[c]; if (cum > kth) { thres = (int32_t)c + 1; break; } }
+        if (thres < 0 || thres > HB) { free(hist); return -2; }      /* the k-th count lies in the overflow bin */
+    }
+    free(hist);
+    if (thres < s->opt.min_mid_occ) thres = s->opt.min_mid_occ;
+    if (s->opt.max_mid_occ > s->opt.min_mid_occ && thres > s->opt.max_mid_occ) thres = s->opt.max_mid_occ;
+    *n_mz = s->n; *n_keys = nk; *mid_occ = thres;
+    return 0;
 }
 
 int32_t lo_index_get(const lo_index_t *ix, uint64_t minier, const uint64_t **list)

@@ -82,6 +82,14 @@ int32_t  lo_index_get(const lo_index_t *ix, uint64_t minier, const uint64_t **li
 /* dump all minimizers in sketch order (rid-major) -- for stage-level parity tests */
 uint64_t lo_index_dump_minimizers(const lo_index_t *ix, lo_mm128_t *out, uint64_t cap);
 
+/* n_minimizers / n_keys / mid_occ of a target set sketched chunk by chunk (sets too large to index here in one piece);
+   same arithmetic as lo_index_build's.  finish: 0, -1 out of memory, -2 the k-th count exceeds the histogram */
+typedef struct lo_kstat lo_kstat_t;
+lo_kstat_t *lo_kstat_new(const lo_opt_t *opt);
+int  lo_kstat_add(lo_kstat_t *s, const char *bases, const uint64_t *offs, uint32_t n, int threads);
+int  lo_kstat_finish(lo_kstat_t *s, int threads, uint64_t *n_mz, uint64_t *n_keys, int32_t *mid_occ);
+void lo_kstat_free(lo_kstat_t *s);
+
 /* stage outputs for one query: sorted anchors (after collect_seed_hits) */
 int64_t lo_anchors(const lo_index_t *ix, const lo_opt_t *opt, const char *seq, int32_t qlen,
                    const char *qname, lo_mm128_t *out, int64_t cap);

@@ -97,6 +97,11 @@ def lib():
         L.lo_inverse_skip.restype = C.c_int
         L.lo_inverse_skip.argtypes = [C.c_int32] * 3 + [C.c_int] + [C.c_int32] * 3 + [C.c_float]
         L.lo_sort128x.argtypes = [vp, C.c_int64, C.c_int]
+        L.lo_kstat_new.restype = vp
+        L.lo_kstat_new.argtypes = [C.POINTER(Opt)]
+        L.lo_kstat_add.argtypes = [vp, vp, vp, C.c_uint32, C.c_int]
+        L.lo_kstat_finish.argtypes = [vp, C.c_int, u64p, u64p, C.POINTER(C.c_int32)]
+        L.lo_kstat_free.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -216,6 +221,31 @@ class Index:
                                  rs.n, C.cast(rs._cnames, C.c_void_p), int(remove_internal), ratio, threads,
                                  counts.ctypes.data)
         return rc, counts[:rs.n]
+
+
+class KeyStats:
+    """n_minimizers / n_keys / mid_occ of a target set fed chunk by chunk (lo_kstat_*): what Index() reports for the
+    whole set, for sets too large to index on the host in one piece."""
+
+    def __init__(self, opt):
+        self.h = lib().lo_kstat_new(C.byref(opt))
+
+    def add(self, bases, offsets, threads=0):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        rc = lib().lo_kstat_add(self.h, bases.ctypes.data if bases.size else None, offsets.ctypes.data, offsets.size - 1, threads)
+        assert rc == 0, rc
+
+    def finish(self, threads=0):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_int32()
+        rc = lib().lo_kstat_finish(self.h, threads, C.byref(a), C.byref(b), C.byref(c))
+        assert rc == 0, rc
+        return dict(n_minimizers=a.value, n_keys=b.value, mid_occ=c.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lo_kstat_free(self.h)
+            self.h = None
 
 
 def per_read_estimate(read_len, avg_target_len, n_target_reads, n_ovlaps, thr):

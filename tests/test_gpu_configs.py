@@ -5,6 +5,9 @@
   C3  12 Mbp ONT, all-vs-all -n 20000          every count
   C4  143 Mbp ONT, two-set -Q 50000 -T 100000  the first 1024 queries against the FULL target index, mid_occ;
                                                all 50 000 counts through size-independent properties
+  C5  3.1 Gbp HiFi, -Q 100000 -T 2000000       FULL SIZE (test_c5_full: counter-based generator, reads written into HBM): inverse
+                                               against the oracle on a 20 000-target range + additivity over all targets; forward:
+                                               index statistics against the oracle fixture + size-independent properties
   C5/10  310 Mbp HiFi, -Q 10000 -T 200000      both presets (ava-pb = library semantics, ava-ont = what the reference CLI
                                                runs), forward (first 256 queries) and inverse (--use-min-ref: every
                                                indexed read, targets streamed) -- the full-size C5 needs ~25 minutes of
@@ -254,3 +257,111 @@ def test_c5_tenth_forward_and_inverse(ctx, oracle, c5_tenth, preset, knobs):
     if Sd is not Td:
         Sd.free()
     Qd.free(); Td.free()
+
+
+def test_c5_full(ctx, oracle):
+    """BASELINE configs[4] at FULL size on one GPU: H. sapiens-scale HiFi, -Q 100 000 -T 2 000 000 (31.5 Gbases), preset
+    ava-pb.  The reads are written straight into HBM by the device twin of the counter-based generator
+    (lrge_amd/synth_cb.py; the host twin feeds the oracle the very same reads, tests/test_synth_cb.py).
+
+    inverse (--use-min-ref, twoset.rs:370-584, what the reference itself picks at this size):
+      * a range of 20 000 streamed targets against the oracle's index of all 100 000 queries: every count, mid_occ,
+        n_keys, n_minimizers;
+      * all 2 000 000 targets through the additivity of the strategy (twoset.rs:520-523: every streamed read adds one to
+        the reads it hits): counts(all) = counts(before the range) + counts(range) + counts(after the range).
+    forward (one index whatever the target size, aligner.rs:111-120 -- here 8 parts with global occurrence statistics):
+      * n_minimizers / n_keys / mid_occ of the 8-part index against the oracle's (tests/golden/c5_full_index_stats.json,
+        made by tests/golden/make_c5_fixture.py from the host twin's reads);
+      * size-independent properties on all 100 000 queries: sub-range independence, no count above the number of truly
+        overlapping targets, sensitivity, idempotence, and agreement with the (oracle-anchored) inverse counts.
+    """
+    import json
+    from lrge_amd import engine, synth_cb
+    spec, Q, T = synth_cb.spec_of("c5_human_twoset")
+    assert (Q, T) == (100000, 2000000)
+    preset = 1
+    dq, dt = spec.device_reads(0, Q), spec.device_reads(Q, T)
+    assert dq.total_bases + dt.total_bases > 31_000_000_000
+    for dr, first in ((dq, 0), (dt, Q)):                         # the twins agree on this very set (both ends of each set)
+        for lo in (0, dr.n - 300):
+            h = spec.host_reads(first=first + lo, n=300)
+            assert np.array_equal(h.bases, dr.to_host(lo, lo + 300))
+    Qd = ctx.upload(dq.ptr, dq.offsets, dq.name_ranks())
+    Td = ctx.upload(dt.ptr, dt.offsets, dt.name_ranks())
+    qlens = dq.lens()
+    q_start, q_end = dq.starts, dq.ends
+    t_start, t_end = dt.starts, dt.ends
+    dq.free(); dt.free()
+
+    # ---- inverse ----
+    ixq = engine.Index(ctx, Qd, preset)
+    stq = ixq.stats()
+    inv_all = ixq.overlap_inverse(Td)
+    n_s = 20000
+    lo = (T - n_s) // 2
+    parts = []
+    for a, b in ((0, lo), (lo, lo + n_s), (lo + n_s, T)):
+        d = spec.device_reads(Q + a, b - a)
+        Sd = ctx.upload(d.ptr, d.offsets, d.name_ranks())
+        d.free()
+        parts.append(ixq.overlap_inverse(Sd))
+        Sd.free()
+    ixq.free()
+    assert np.array_equal(inv_all, parts[0] + parts[1] + parts[2])
+    hq = spec.host_reads(first=0, n=Q)
+    ixo = _oracle_index(oracle, hq, preset)
+    assert stq["mid_occ"] == ixo.mid_occ and stq["n_minimizers"] == ixo.n_minimizers and stq["n_keys"] == ixo.n_keys
+    ht = spec.host_reads(first=Q + lo, n=n_s)
+    rc, einv = ixo.inverse_counts(oracle.ReadSet(ht.seqs(), ht.names), threads=THREADS)
+    assert rc == 0
+    assert np.array_equal(parts[1], einv)
+    assert int(einv.sum()) > 10000
+    del ixo, hq, ht
+
+    # ---- forward ----
+    ix = engine.Index(ctx, Td, preset)
+    st = ix.stats()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "c5_full_index_stats.json")) as f:
+        fx = json.load(f)
+    import zlib
+    chk = spec.host_reads(idx=[0, Q - 1, Q, Q + T // 2, Q + T - 1])
+    assert fx["reads_crc32"] == "%08x" % (zlib.crc32(chk.bases.tobytes()) & 0xFFFFFFFF), "fixture made with another generator"
+    assert {k: st[k] for k in ("n_minimizers", "n_keys", "mid_occ")} == {k: fx["ava-pb"][k] for k in ("n_minimizers", "n_keys", "mid_occ")}
+    assert st["n_minimizers"] > 2**32          # more than one index part can hold
+    counts, has = ix.overlap_twoset(Qd)
+    #  * sub-range independence
+    a, b = 40000, 42000
+    d = spec.device_reads(a, b - a)
+    Sd = ctx.upload(d.ptr, d.offsets, d.name_ranks())
+    d.free()
+    c_sub, h_sub = ix.overlap_twoset(Sd)
+    Sd.free()
+    assert np.array_equal(c_sub, counts[a:b]) and np.array_equal(h_sub, has[a:b])
+    #  * no count above the number of targets whose source interval touches the query's; has_mapping <=> count > 0
+    assert np.array_equal(has > 0, counts > 0)
+    ts, te = np.sort(t_start), np.sort(t_end)
+    n_touch = np.searchsorted(ts, q_end, side="left") - np.searchsorted(te, q_start, side="right")
+    assert (counts <= np.maximum(n_touch, 0)).all()
+    #  * sensitivity: of the targets overlapping a query's source interval by >= 2 kb, more than 95 % are found (HiFi)
+    order = np.argsort(t_start, kind="stable")
+    ts_s, te_s = t_start[order], t_end[order]
+    found = true_long = 0
+    for i in range(0, Q, 199):
+        x = int(np.searchsorted(ts_s, q_start[i] - 30000, side="left")); y = int(np.searchsorted(ts_s, q_end[i], side="left"))
+        ov = np.minimum(te_s[x:y], q_end[i]) - np.maximum(ts_s[x:y], q_start[i])
+        n_long = int((ov >= 2000).sum())
+        true_long += n_long; found += min(int(counts[i]), n_long)
+    assert true_long > 3000 and found > 0.95 * true_long, (found, true_long)
+    #  * the two strategies count the same overlaps from the two sides (different indexes, different mid_occ: not identical,
+    #    but the inverse counts are anchored to the oracle above)
+    diff = np.abs(counts.astype(np.int64) - inv_all.astype(np.int64))
+    assert (diff <= 2).mean() > 0.97 and abs(int(counts.sum()) - int(inv_all.sum())) < 0.01 * int(inv_all.sum()), ((diff <= 2).mean(), int(counts.sum()), int(inv_all.sum()))
+    #  * idempotence
+    c2, h2 = ix.overlap_twoset(Qd)
+    assert np.array_equal(c2, counts) and np.array_equal(h2, has)
+    #  * the estimate lands on the genome size
+    avg = np.float32(np.diff(dt.offsets).sum()) / np.float32(T)
+    est = ctx.estimates(counts, qlens, float(avg), T, 100)
+    med = engine.median(est, True, 0.15, 0.65)
+    assert abs(float(med[1]) - spec.gsize) < 0.03 * spec.gsize
+    ix.free(); Qd.free(); Td.free()

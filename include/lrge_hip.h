@@ -163,6 +163,25 @@ int  lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int
  */
 int  lrge_hip_index_build_for(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset,
                               lrge_hip_seqset *streamed, lrge_hip_comm *comm, lrge_hip_index **out);
+/*
+ * The same index with the TARGET SKETCH sharded as well: a collective call in which every rank passes
+ * ITS OWN contiguous share of the target reads -- reads [shard_first, shard_first + size(target_shard)) of the whole target
+ * set, whose lengths and name ranks every rank knows (all_target_lens / all_target_ranks, n_targets entries; ranks may be
+ * NULL) -- and its own range of the streamed reads.  Rank r sketches only its share; three exchanges complete the picture:
+ * an all-gather of the ranks' key sets (Bloom filters), a variable-size all-to-all that sends every entry to the ranks whose
+ * streamed reads carry its key (complete position lists wherever they are asked for), and one that sends every hash to the
+ * rank that owns it for the occurrence statistics (one small all-reduce then fixes mid_occ, n_keys, n_minimizers globally).
+ * The result answers the rank's streamed set exactly as the one index over all targets would.  The shares must be handed out
+ * in rank order (rank 0 holds the first reads) so that position lists keep the order of the one index.
+ * Replaces: AlignerWrapper::new (aligner.rs:310-328) in a run sharded by query (twoset.rs:266-334), with mm_idx_gen's
+ * pipeline (mm2:index.c) itself spread over the ranks.
+ */
+int  lrge_hip_index_build_sharded(lrge_hip_ctx *ctx, const uint32_t *all_target_lens, const uint32_t *all_target_ranks,
+                                  uint32_t n_targets, const lrge_hip_seqset *target_shard, uint32_t shard_first, int preset,
+                                  lrge_hip_seqset *streamed, lrge_hip_comm *comm, lrge_hip_index **out);
+/* Exchange volumes of the last lrge_hip_index_build_sharded on this context: {key-set bytes contributed, entries sketched here,
+   entries sent to other ranks, entries received from other ranks, hashes sent, hashes received, bytes per entry, entries kept}. */
+int  lrge_hip_last_shard_stats(const lrge_hip_ctx *ctx, uint64_t out[8]);
 void lrge_hip_index_free(lrge_hip_index *ix);
 int  lrge_hip_index_stats(const lrge_hip_index *ix, uint64_t *n_minimizers, uint64_t *n_keys,
                           int32_t *mid_occ);
@@ -241,6 +260,22 @@ int  lrge_hip_comm_rank(const lrge_hip_comm *c);
 int  lrge_hip_comm_world(const lrge_hip_comm *c);
 int  lrge_hip_comm_allreduce_u32(lrge_hip_comm *c, uint32_t *inout, size_t n);                 /* in-place sum */
 int  lrge_hip_comm_allgather(lrge_hip_comm *c, const void *send, size_t bytes, void *recv);    /* recv: world * bytes */
+/* Variable-size all-to-all: this rank sends elements [send_off[d], send_off[d + 1]) of `send` to rank d and finds rank s's
+   share at element recv_off[s] of `recv` (world + 1 prefix sums each, in elements of elem_bytes bytes; the receive counts are
+   the other ranks' send counts -- exchange them with lrge_hip_comm_allgather first).  RCCL: one send / receive pair per
+   peer in a group (point-to-point over xGMI); local groups copy device to device; host callbacks fall back to an all-gather.
+   The exchange lrge_hip_index_build_sharded runs on device buffers. */
+int  lrge_hip_comm_alltoallv(lrge_hip_comm *c, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off,
+                             size_t elem_bytes);
+/* Ranks RCCL itself counts in this communicator (ncclCommCount); 0 for the local / host transports. */
+int  lrge_hip_comm_rccl_ranks(const lrge_hip_comm *c, int *n);
+/* Timing emulation of a world on ONE GPU (local groups only): with serialize on, the ranks of the group take turns -- a rank
+   computes between lrge_hip_comm_local_turn(c, 1) and (c, 0) and hands the GPU over whenever it waits for the others inside
+   a collective; lrge_hip_comm_busy_ms returns the time it held the turn (what its share of the job takes on a GPU of its
+   own, link transfers aside).  Results are unaffected. */
+int  lrge_hip_comm_local_group_serialize(void *group, int on);
+int  lrge_hip_comm_local_turn(lrge_hip_comm *c, int begin);
+double lrge_hip_comm_busy_ms(lrge_hip_comm *c, int reset);
 
 /* per_read_estimate over n reads on the device (f32, no contraction). out[i] = +inf if counts[i]==0 */
 int  lrge_hip_estimates(lrge_hip_ctx *ctx, const uint32_t *counts, const uint32_t *read_lens,

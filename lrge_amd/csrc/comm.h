@@ -28,6 +28,11 @@ struct RcclApi {
     int (*CommDestroy)(lrge_ncclComm_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, lrge_ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, lrge_ncclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, lrge_ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, lrge_ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*CommCount)(const lrge_ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string err;
     bool load() {
@@ -42,6 +47,11 @@ struct RcclApi {
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
         AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
         AllGather = (decltype(AllGather))sym("ncclAllGather");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        CommCount = (decltype(CommCount))sym("ncclCommCount");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
         if (!ok) { dlclose(lib); lib = nullptr; }
         return ok;
@@ -56,12 +66,27 @@ struct LocalGroup {
     std::mutex mu; std::condition_variable cv;
     int arrived = 0; u64 gen = 0;
     std::vector<const void *> slot;
-    explicit LocalGroup(int w) : world(w), slot((size_t)w, nullptr) {}
-    void barrier() {
+    std::vector<const u64 *> slot2;      // all-to-all: every rank's send offsets (elements), world + 1 of them
+    bool aborted = false;                // a rank failed between two barriers: everybody leaves with an error
+    // Timing emulation of a world on ONE GPU: with `serialize` the ranks take turns -- a rank computes only while it holds
+    // the token and hands it over whenever it waits at a barrier, so its kernels never share the GPU with another rank's
+    // and the time it holds the token is the time its share of the job takes on a GPU of its own (link transfers aside).
+    bool serialize = false; std::mutex token;
+    explicit LocalGroup(int w) : world(w), slot((size_t)w, nullptr), slot2((size_t)w, nullptr) {}
+    // false: the group was aborted (by this call's peer or earlier) -- the collective fails on every rank instead of
+    // leaving the others blocked on a rank that will never arrive
+    bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const u64 g = gen;
         if (++arrived == world) { arrived = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        else cv.wait(lk, [&] { return gen != g || aborted; });
+        return !aborted;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = true; arrived = 0; ++gen;
+        cv.notify_all();
     }
 };
 
@@ -73,7 +98,37 @@ struct lrge_hip_comm {
     // host transport: the caller's own collectives (MPI, gloo, ...) on host buffers; the library stages through the host
     lrge_hip_host_allreduce_fn cb_allreduce = nullptr; lrge_hip_host_allgather_fn cb_allgather = nullptr; void *cb_user = nullptr;
     std::vector<char> hbuf;              // host staging of the local / host transports
+    bool in_turn = false; double busy_ms = 0, t_acquired = 0;     // (serialized local groups)
 };
+
+static void comm_turn(lrge_hip_comm *c, bool begin) {
+    if (!c || !c->grp || !c->grp->serialize) return;
+    if (begin) { c->grp->token.lock(); c->in_turn = true; c->t_acquired = DevPool::now_ms(); return; }
+    if (!c->in_turn) return;
+    (void)hipStreamSynchronize(c->ctx->stream); (void)hipStreamSynchronize(c->ctx->stream2); (void)hipStreamSynchronize(c->ctx->copy_stream);
+    c->busy_ms += DevPool::now_ms() - c->t_acquired;
+    c->in_turn = false;
+    c->grp->token.unlock();
+}
+// barrier of the local transport; a serialized group hands the GPU to another rank while this one waits
+static bool grp_barrier(lrge_hip_comm *c) {
+    const bool turn = c->grp->serialize && c->in_turn;
+    if (turn) comm_turn(c, false);
+    const bool ok = c->grp->barrier();
+    if (turn) comm_turn(c, true);
+    return ok;
+}
+
+// HIP call inside a collective of the local transport: a failure wakes the ranks waiting at the barrier
+#define HIPCHK_GRP(c, call)                                                                                         \
+    do {                                                                                                            \
+        hipError_t _e = (call);                                                                                     \
+        if (_e != hipSuccess) {                                                                                     \
+            LRGE_SET_ERR((c)->ctx, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #call); \
+            if ((c)->grp) (c)->grp->abort();                                                                        \
+            return LRGE_ERR_DEVICE;                                                                                 \
+        }                                                                                                           \
+    } while (0)
 
 #define NCCLCHK(ctx, call)                                                                                          \
     do {                                                                                                            \
@@ -93,8 +148,8 @@ static int comm_allreduce_sum(lrge_hip_comm *c, void *dbuf, size_t n, int esz, h
         return LRGE_OK;
     }
     c->hbuf.resize(n * (size_t)esz);
-    HIPCHK(ctx, hipMemcpyAsync(c->hbuf.data(), dbuf, n * (size_t)esz, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK_GRP(c, hipMemcpyAsync(c->hbuf.data(), dbuf, n * (size_t)esz, hipMemcpyDeviceToHost, st));
+    HIPCHK_GRP(c, hipStreamSynchronize(st));
     if (c->cb_allreduce) {
         if (c->cb_allreduce(c->cb_user, c->hbuf.data(), n, esz) != 0) { LRGE_SET_ERR(ctx, "host communicator: all-reduce callback failed"); return LRGE_ERR_DEVICE; }
         HIPCHK(ctx, hipMemcpyAsync(dbuf, c->hbuf.data(), n * (size_t)esz, hipMemcpyHostToDevice, st));
@@ -103,13 +158,13 @@ static int comm_allreduce_sum(lrge_hip_comm *c, void *dbuf, size_t n, int esz, h
     }
     LocalGroup *g = c->grp;
     g->slot[(size_t)c->rank] = c->hbuf.data();
-    g->barrier();
+    if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
     std::vector<char> sum(n * (size_t)esz, 0);
     for (int r = 0; r < c->world; ++r) {
         if (esz == 8) { const u64 *p = (const u64 *)g->slot[(size_t)r]; u64 *o = (u64 *)sum.data(); for (size_t i = 0; i < n; ++i) o[i] += p[i]; }
         else { const u32 *p = (const u32 *)g->slot[(size_t)r]; u32 *o = (u32 *)sum.data(); for (size_t i = 0; i < n; ++i) o[i] += p[i]; }
     }
-    g->barrier();                          // everyone has read every slot: the staging buffers may change again
+    if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }   // everyone has read every slot: the staging buffers may change again
     HIPCHK(ctx, hipMemcpyAsync(dbuf, sum.data(), n * (size_t)esz, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st)); // (`sum` is a local)
     return LRGE_OK;
@@ -122,8 +177,8 @@ static int comm_allgather(lrge_hip_comm *c, const void *dsend, size_t bytes, voi
     if (c->world == 1) { HIPCHK(ctx, hipMemcpyAsync(drecv, dsend, bytes, hipMemcpyDeviceToDevice, st)); return LRGE_OK; }
     if (c->nccl) { NCCLCHK(ctx, g_rccl.AllGather(dsend, drecv, bytes, LRGE_NCCL_UINT8, c->nccl, st)); return LRGE_OK; }
     c->hbuf.resize(bytes);
-    HIPCHK(ctx, hipMemcpyAsync(c->hbuf.data(), dsend, bytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK_GRP(c, hipMemcpyAsync(c->hbuf.data(), dsend, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK_GRP(c, hipStreamSynchronize(st));
     if (c->cb_allgather) {
         std::vector<char> all(bytes * (size_t)c->world);
         if (c->cb_allgather(c->cb_user, c->hbuf.data(), bytes, all.data()) != 0) { LRGE_SET_ERR(ctx, "host communicator: all-gather callback failed"); return LRGE_ERR_DEVICE; }
@@ -133,11 +188,106 @@ static int comm_allgather(lrge_hip_comm *c, const void *dsend, size_t bytes, voi
     }
     LocalGroup *g = c->grp;
     g->slot[(size_t)c->rank] = c->hbuf.data();
-    g->barrier();
+    if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
     std::vector<char> all(bytes * (size_t)c->world);
     for (int r = 0; r < c->world; ++r) memcpy(all.data() + bytes * (size_t)r, g->slot[(size_t)r], bytes);
-    g->barrier();
+    if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
     HIPCHK(ctx, hipMemcpyAsync(drecv, all.data(), all.size(), hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    return LRGE_OK;
+}
+
+// Failure made collective: every rank contributes whether it failed so far (rc != 0); all ranks leave with an error if any
+// did -- so that a rank whose allocation or kernel failed does not leave the others blocked in the next collective.
+static int comm_agree(lrge_hip_comm *c, int rc, hipStream_t st) {
+    if (!c || c->world == 1) return rc;
+    lrge_hip_ctx *ctx = c->ctx;
+    if (c->grp && rc) { c->grp->abort(); return rc; }                    // (threads of one process: wake the others directly)
+    std::string mine = rc ? ctx->err : std::string();
+    Scratch sc(ctx);
+    u32 *d = sc.get<u32>(1);
+    if (!d) { if (c->grp) c->grp->abort(); return LRGE_ERR_DEVICE; }
+    const u32 bad = rc ? 1u : 0u;
+    u32 tot = 0;
+    if (hipMemcpyAsync(d, &bad, 4, hipMemcpyHostToDevice, st) != hipSuccess) { if (c->grp) c->grp->abort(); return LRGE_ERR_DEVICE; }
+    if (hipStreamSynchronize(st) != hipSuccess) { if (c->grp) c->grp->abort(); return LRGE_ERR_DEVICE; }
+    const int r2 = comm_allreduce_sum(c, d, 1, 4, st);
+    if (r2) return rc ? rc : r2;
+    if (hipMemcpyAsync(&tot, d, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LRGE_ERR_DEVICE;
+    if (rc) { ctx->err = mine; return rc; }
+    if (tot) { LRGE_SET_ERR(ctx, "collective call: %u other rank(s) failed", tot); return LRGE_ERR_DEVICE; }
+    return LRGE_OK;
+}
+
+// Variable-size all-to-all between DEVICE buffers: rank r sends elements [soff[d], soff[d + 1]) of `dsend` to rank d and
+// receives rank s's share at element roff[s] of `drecv` (soff / roff: world + 1 prefix sums, in elements of `esz` bytes;
+// the receive counts come from an all-gather of the send counts, which the caller has done).  Ordered on `st`.
+//   RCCL: one ncclSend / ncclRecv pair per peer inside a group (point-to-point over xGMI: every pair has its own link);
+//   local: the ranks are threads of one process -- after a barrier every rank copies its share straight out of the other
+//          ranks' send buffers (device-to-device; hipMemcpyPeer semantics between two GPUs of the process);
+//   host callbacks: an all-gather of the padded send buffers through the caller's collective, each rank picks its slices
+//          (the fallback transport: correct, not fast).
+static int comm_alltoallv(lrge_hip_comm *c, const void *dsend, const u64 *soff, void *drecv, const u64 *roff, size_t esz, hipStream_t st) {
+    lrge_hip_ctx *ctx = c->ctx;
+    const int W = c->world, me = c->rank;
+    if (W == 1) {
+        const u64 n = soff[1] - soff[0];
+        if (n) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[0] * esz, (const char *)dsend + soff[0] * esz, n * esz, hipMemcpyDeviceToDevice, st));
+        return LRGE_OK;
+    }
+    if (c->nccl) {
+        NCCLCHK(ctx, g_rccl.GroupStart());
+        for (int p = 0; p < W; ++p) {
+            const u64 ns = soff[p + 1] - soff[p], nr = roff[p + 1] - roff[p];
+            if (p == me) continue;
+            if (ns) NCCLCHK(ctx, g_rccl.Send((const char *)dsend + soff[p] * esz, ns * esz, LRGE_NCCL_UINT8, p, c->nccl, st));
+            if (nr) NCCLCHK(ctx, g_rccl.Recv((char *)drecv + roff[p] * esz, nr * esz, LRGE_NCCL_UINT8, p, c->nccl, st));
+        }
+        NCCLCHK(ctx, g_rccl.GroupEnd());
+        const u64 n = soff[me + 1] - soff[me];
+        if (n) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[me] * esz, (const char *)dsend + soff[me] * esz, n * esz, hipMemcpyDeviceToDevice, st));
+        return LRGE_OK;
+    }
+    if (c->grp) {
+        LocalGroup *g = c->grp;
+        HIPCHK_GRP(c, hipStreamSynchronize(st));                   // my send buffer is complete before anybody reads it
+        g->slot[(size_t)me] = dsend; g->slot2[(size_t)me] = soff;
+        if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
+        for (int s = 0; s < W; ++s) {
+            const u64 *so = g->slot2[(size_t)s];
+            const u64 n = so[me + 1] - so[me];
+            if (n) HIPCHK_GRP(c, hipMemcpyAsync((char *)drecv + roff[s] * esz, (const char *)g->slot[(size_t)s] + so[me] * esz, n * esz, hipMemcpyDefault, st));
+        }
+        HIPCHK_GRP(c, hipStreamSynchronize(st));
+        if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }   // everybody has read: the send buffers may change
+        return LRGE_OK;
+    }
+    // host callbacks: all-gather of [world + 1 offsets | padded payload]
+    u64 mx = soff[W];
+    {
+        std::vector<u64> mine((size_t)W, 0), all((size_t)W * W, 0);
+        mine[(size_t)me] = soff[W];
+        Scratch sc(ctx);
+        u64 *dv = sc.get<u64>((size_t)W);
+        if (!dv) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemcpyAsync(dv, mine.data(), (size_t)W * 8, hipMemcpyHostToDevice, st));
+        int rc = comm_allreduce_sum(c, dv, (size_t)W, 8, st); if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(mine.data(), dv, (size_t)W * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (int r = 0; r < W; ++r) mx = std::max(mx, mine[(size_t)r]);
+    }
+    const size_t hdr = ((size_t)W + 1) * 8, blk = hdr + (size_t)mx * esz;
+    std::vector<char> sendh(blk, 0), allh(blk * (size_t)W);
+    memcpy(sendh.data(), soff, hdr);
+    if (soff[W]) HIPCHK(ctx, hipMemcpyAsync(sendh.data() + hdr, dsend, soff[W] * esz, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (c->cb_allgather(c->cb_user, sendh.data(), blk, allh.data()) != 0) { LRGE_SET_ERR(ctx, "host communicator: all-gather callback failed"); return LRGE_ERR_DEVICE; }
+    for (int s = 0; s < W; ++s) {
+        const char *b = allh.data() + blk * (size_t)s;
+        const u64 *so = (const u64 *)b;
+        const u64 n = so[me + 1] - so[me];
+        if (n) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[s] * esz, b + hdr + so[me] * esz, n * esz, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));      // (`allh` is a local)
     return LRGE_OK;
 }

@@ -61,6 +61,7 @@ struct DevPool {
     size_t total = 0;                                   // bytes held from the runtime (all segments)
     size_t in_use = 0;
     long fail_every = 0, misses = 0;
+    bool fail_always = false;          // test hook (DEBUG_ALLOC_FAIL_ALWAYS): every request is refused
     // bookkeeping for option VERBOSE: what the device allocator itself cost
     double ms_malloc = 0, ms_free = 0; u64 n_malloc = 0, n_free = 0, n_trim = 0, bytes_malloc = 0;
     static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -84,6 +85,7 @@ struct DevPool {
         return it->first;
     }
     void *alloc(size_t bytes, hipError_t *err) {
+        if (fail_always) { *err = hipErrorOutOfMemory; return nullptr; }
         if (bytes == 0) bytes = kAlign;
         bytes = (bytes + kAlign - 1) & ~(kAlign - 1);
         auto f = free_by_size.lower_bound(bytes);
@@ -190,6 +192,7 @@ struct lrge_hip_ctx {
     bool lsort_ok[3] = {false, false, false};   // which k_seg_sort_local variants this device can launch
     struct lrge_hip_seqset *presk_pending = nullptr; int presk_preset = -1;   // lrge_hip_seqset_presketch request
     int timer_level = 1;                     // see StageTimer
+    u64 shard_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last sharded index build (lrge_hip_last_shard_stats)
     // Small device->host reads (totals, censuses, per-read vectors).  hipMemcpyAsync into pageable memory is a blocking
     // staged copy, one round trip EACH; through this pinned area several reads queue up behind the kernels and cost
     // one round trip at the following d2h_sync(), which also moves the bytes to where the caller wants them.
@@ -285,6 +288,7 @@ struct lrge_hip_index {
     // A target set too large for one index (more than LRGE_HIP_PART_BASES bases: the 2^32-entry limits) is indexed in
     // parts over views of the set.  The occurrence statistics are global (k_part_global_occ), so the parts together
     // behave exactly like one index; a part's own d_* arrays are used as above, the container's are null.
+    lrge_hip_seqset *owned_seqs = nullptr;          // a sharded build's description of the whole target set (freed with the index)
     const lrge_hip_seqset *restrict_set = nullptr;   // lrge_hip_index_build_for: the one set that may be streamed against this index
     std::vector<lrge_hip_index *> parts;
     std::vector<lrge_hip_seqset *> part_sets;

@@ -21,6 +21,7 @@
 #include "k_chain_lpg.h"
 #include "comm.h"
 #include "k_restrict.h"
+#include "k_route.h"
 #include "../../include/lrge_rand.hpp"
 
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
@@ -46,6 +47,7 @@ extern "C" int lrge_hip_ctx_set_option(lrge_hip_ctx *ctx, const char *name, cons
     if (!ctx || !name || !*name) return LRGE_ERR_INVALID;
     if (value) ctx->opts[name] = value; else ctx->opts.erase(name);
     if (!strcmp(name, "DEBUG_ALLOC_FAIL_EVERY")) { ctx->pool.fail_every = value ? atol(value) : 0; ctx->pool.misses = 0; }
+    if (!strcmp(name, "DEBUG_ALLOC_FAIL_ALWAYS")) ctx->pool.fail_always = value != nullptr;
     if (!strcmp(name, "TIMERS") && value) ctx->timer_level = atoi(value);
     return LRGE_OK;
 }
@@ -747,7 +749,163 @@ static int sketch_restrict_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip
 
 // A restricted build (lrge_hip_index_build_for, k_restrict.h): the index holds the entries of the keys that occur in
 // `restrict_to`'s minimizers, its statistics (mid_occ, key and minimizer totals) are those of the whole target set.
-struct IndexBuildOpts { lrge_hip_seqset *restrict_to = nullptr; lrge_hip_comm *comm = nullptr; };
+struct IndexBuildOpts {
+    lrge_hip_seqset *restrict_to = nullptr; lrge_hip_comm *comm = nullptr;
+    // sharded target sketch (lrge_hip_index_build_sharded, k_route.h): this rank's contiguous share of the target reads, whose
+    // first read is read `shard_first` of the whole set (`targets` then describes the whole set: lengths and names, no bases)
+    const lrge_hip_seqset *shard = nullptr; u32 shard_first = 0;
+};
+
+// Work counters of the last sharded build on a context (exchange volumes, for the projection tables of DESIGN.md section 7)
+struct ShardStats { u64 keyset_bytes = 0, entries_sketched = 0, entries_sent = 0, entries_recv = 0, hashes_sent = 0, hashes_recv = 0; };
+static thread_local ShardStats g_shard_stats;
+
+// A collective call must fail on every rank when it fails on one: a rank that leaves early (any `return` of the macros
+// above) still enters the agreement all-reduce the healthy ranks run right before the first data collective, through this
+// guard's destructor; the healthy path calls agree() itself.
+struct CollectiveGuard {
+    lrge_hip_comm *c; hipStream_t st; bool armed = false;
+    ~CollectiveGuard() { if (armed && c) (void)comm_agree(c, LRGE_ERR_DEVICE, st); }
+    int agree() { const bool was = armed; armed = false; return (was && c) ? comm_agree(c, LRGE_OK, st) : LRGE_OK; }
+};
+
+// The three exchanges of a sharded build (k_route.h).  On success so->x [, so->y] hold this rank's kept entries in the order
+// the one index would hold them (so->n of them), *own_hashes / *n_own the hashes of the keys this rank owns.  Collective:
+// a failure on one rank fails the call on every rank (status words ride in the small vectors; comm_agree before the
+// exchanges that follow large allocations).
+static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int preset, bool pk, u32 pk_pos1, u32 pk_ybits,
+                           const IndexBuildOpts *ro, SketchOut *so, u64 **own_hashes, u64 *n_own) {
+    lrge_hip_comm *c = ro->comm;
+    const int W = c->world, me = c->rank;
+    lrge_hip_seqset *S = ro->restrict_to;
+    const lrge_hip_seqset *Tsh = ro->shard;
+    hipStream_t st = ctx->stream;
+    g_shard_stats = ShardStats();
+    int rc = LRGE_OK;
+    // ---- (1) one agreed key-set size: all ranks' streamed base counts (and whether anybody has failed already) ----
+    std::vector<u64> hv((size_t)W + 1, 0);
+    u64 *d_sz = sc.get<u64>((size_t)W + 1);
+    hv[(size_t)me] = S->total_bases; hv[(size_t)W] = d_sz ? 0 : 1;
+    if (!d_sz) { rc = comm_agree(c, LRGE_ERR_DEVICE, st); return rc ? rc : LRGE_ERR_DEVICE; }
+    HIPCHK(ctx, hipMemcpyAsync(d_sz, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));          // (hv is reused below)
+    rc = comm_allreduce_sum(c, d_sz, hv.size(), 8, st); if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(hv.data(), d_sz, hv.size() * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (hv[(size_t)W]) { LRGE_SET_ERR(ctx, "sharded index build: another rank failed"); return LRGE_ERR_DEVICE; }
+    u64 max_bases = 1;
+    for (int r = 0; r < W; ++r) max_bases = std::max(max_bases, hv[(size_t)r]);
+    const u64 bloom_bits = ctx->opt_u64("SHARD_BLOOM_BITS", 4);      // filter bits per streamed base (~3-4 minimizers per 16 bits)
+    u64 n_words = 1ULL << 14;
+    while (n_words < (1ULL << 31) && n_words * 64 < bloom_bits * max_bases) n_words <<= 1;
+    g_shard_stats.keyset_bytes = n_words * 8;
+    // ---- (2) local: the streamed set's sketch + this rank's key set on the side stream, beside the target shard's sketch ----
+    KeySet ks{nullptr, n_words - 1, 0, (u32)(2 * P.k), ceil_log2_u64(n_words)};
+    u64 *gathered = nullptr, *inter = nullptr;
+    SketchOut raw;
+    auto local1 = [&]() -> int {
+        if (!S->presk || S->presk->preset != preset) {
+            ctx->presk_pending = S; ctx->presk_preset = preset;
+            int r = presketch_start_pending(ctx, ~0ULL >> 2); if (r) return r;
+        }
+        if (!S->presk) { LRGE_SET_ERR(ctx, "index_build_sharded: the streamed set is too large to restrict an index to (it is streamed in views)"); return LRGE_ERR_TOO_MANY; }
+        ks.bits = sc.get<u64>(n_words); gathered = sc.get<u64>(n_words * (u64)W); inter = sc.get<u64>(n_words * (u64)W);
+        if (!ks.bits || !gathered || !inter) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemsetAsync(ks.bits, 0, n_words * 8, ctx->stream2));
+        hipLaunchKernelGGL(k_keyset_build, dim3((u32)div_up(S->total_bases + 1, 256)), dim3(256), 0, ctx->stream2, S->presk->x, S->presk->d_total, ks);
+        KCHK(ctx);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+        // the shard's own sketch runs on the main stream meanwhile
+        int r = sketch_device(ctx, sc, Tsh, preset, true, &raw, pk ? pk_pos1 : 0, pk_ybits, nullptr); if (r) return r;
+        sc.drop(raw.mz_off);
+        if (raw.n && ro->shard_first) {     // read index inside the shard -> index in the whole target set
+            if (pk) hipLaunchKernelGGL(k_add_u64, dim3((u32)div_up(raw.n, 256)), dim3(256), 0, st, raw.x, raw.n, (u64)ro->shard_first << pk_pos1);
+            else hipLaunchKernelGGL(k_add_u64, dim3((u32)div_up(raw.n, 256)), dim3(256), 0, st, raw.y, raw.n, (u64)ro->shard_first << 32);
+            KCHK(ctx);
+        }
+        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+        return LRGE_OK;
+    };
+    rc = comm_agree(c, local1(), st); if (rc) return rc;
+    g_shard_stats.entries_sketched = raw.n;
+    rc = comm_allgather(c, ks.bits, n_words * 8, gathered, st); if (rc) return rc;
+    hipLaunchKernelGGL(k_keyset_interleave, dim3((u32)div_up(n_words * (u64)W, 256)), dim3(256), 0, st, gathered, n_words, (u32)W, inter);
+    KCHK(ctx);
+    // ---- (3) local: which ranks ask for every entry, who owns its hash; counts per destination ----
+    const u64 Mr = raw.n;
+    if (Mr >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "sharded index build: this rank's target share yields %llu minimizers (limit 2^32)", (unsigned long long)Mr); }
+    RouteArgs A; A.x = raw.x; A.y = pk ? nullptr : raw.y; A.n = Mr; A.kshift = pk ? pk_ybits : 0;
+    A.ks = KeySetAll{inter, n_words - 1, (u32)W}; A.n_tiles = (u32)std::max<u64>(1, div_up(Mr, RF_TILE));
+    u32 *flags = nullptr, *cnt = nullptr, *d_tot = nullptr;
+    std::vector<u64> mine((size_t)2 * W + 1, 0), matrix(((size_t)2 * W + 1) * (size_t)W, 0);
+    auto local2 = [&]() -> int {
+        if (Mr >= (1ULL << 32)) return LRGE_ERR_TOO_MANY;
+        flags = sc.get<u32>(Mr + 1); cnt = sc.get<u32>((u64)2 * W * A.n_tiles); d_tot = sc.get<u32>((size_t)2 * W);
+        if (!flags || !cnt || !d_tot) return LRGE_ERR_DEVICE;
+        hipLaunchKernelGGL(k_route_count, dim3(A.n_tiles), dim3(RF_THREADS), 0, st, A, flags, cnt);
+        KCHK(ctx);
+        hipLaunchKernelGGL(k_route_scan, dim3((u32)(2 * W)), dim3(1024), 0, st, cnt, A.n_tiles, d_tot);
+        KCHK(ctx);
+        std::vector<u32> tot((size_t)2 * W);
+        HIPCHK(ctx, hipMemcpyAsync(tot.data(), d_tot, tot.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (int q = 0; q < 2 * W; ++q) mine[(size_t)q] = tot[(size_t)q];
+        return LRGE_OK;
+    };
+    mine[(size_t)2 * W] = local2() ? 1 : 0;
+    const int rc2 = mine[(size_t)2 * W] ? LRGE_ERR_DEVICE : LRGE_OK;
+    // ---- (4) everybody learns every (source, destination) count (and whether a rank has failed) ----
+    {
+        u64 *d_mine = sc.get<u64>(mine.size()), *d_all = sc.get<u64>(matrix.size());
+        rc = comm_agree(c, (d_mine && d_all) ? LRGE_OK : LRGE_ERR_DEVICE, st); if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(d_mine, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, st));
+        rc = comm_allgather(c, d_mine, mine.size() * 8, d_all, st); if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(matrix.data(), d_all, matrix.size() * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        sc.drop(d_mine); sc.drop(d_all);
+    }
+    const size_t row = (size_t)2 * W + 1;
+    for (int r = 0; r < W; ++r) if (matrix[(size_t)r * row + 2 * W]) { if (!rc2) LRGE_SET_ERR(ctx, "sharded index build: rank %d failed", r); return LRGE_ERR_DEVICE; }
+    // send / receive offsets (elements) of the two all-to-alls
+    std::vector<u64> ks_off((size_t)W + 1, 0), kr_off((size_t)W + 1, 0), os_off((size_t)W + 1, 0), or_off((size_t)W + 1, 0);
+    for (int d = 0; d < W; ++d) {
+        ks_off[(size_t)d + 1] = ks_off[(size_t)d] + mine[(size_t)d];
+        os_off[(size_t)d + 1] = os_off[(size_t)d] + mine[(size_t)W + d];
+        kr_off[(size_t)d + 1] = kr_off[(size_t)d] + matrix[(size_t)d * row + (size_t)me];
+        or_off[(size_t)d + 1] = or_off[(size_t)d] + matrix[(size_t)d * row + (size_t)W + (size_t)me];
+    }
+    const u64 n_ks = ks_off[(size_t)W], n_kr = kr_off[(size_t)W], n_os = os_off[(size_t)W], n_or = or_off[(size_t)W];
+    g_shard_stats.entries_sent = n_ks - mine[(size_t)me]; g_shard_stats.entries_recv = n_kr - mine[(size_t)me];
+    g_shard_stats.hashes_sent = n_os - mine[(size_t)W + me]; g_shard_stats.hashes_recv = n_or - mine[(size_t)W + me];
+    // ---- (5) local: send buffers grouped by destination (order-preserving), receive buffers ----
+    u64 *sx = nullptr, *sy = nullptr, *sh = nullptr, *rx = nullptr, *ry = nullptr, *rh = nullptr;
+    auto local3 = [&]() -> int {
+        if (n_kr >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32 minimizers (this rank would hold %llu)", (unsigned long long)n_kr); return LRGE_ERR_TOO_MANY; }
+        sx = sc.get<u64>(n_ks + 1); sh = sc.get<u64>(n_os + 1); rx = sc.get<u64>(n_kr + 1); rh = sc.get<u64>(n_or + 1);
+        if (!pk) { sy = sc.get<u64>(n_ks + 1); ry = sc.get<u64>(n_kr + 1); }
+        if (!sx || !sh || !rx || !rh || (!pk && (!sy || !ry))) return LRGE_ERR_DEVICE;
+        RouteBases B;
+        for (int d = 0; d < ROUTE_MAX_WORLD; ++d) { B.keep[d] = d < W ? ks_off[(size_t)d] : 0; B.own[d] = d < W ? os_off[(size_t)d] : 0; }
+        if (Mr) { hipLaunchKernelGGL(k_route_write, dim3(A.n_tiles), dim3(RF_THREADS), 0, st, A, flags, cnt, B, sx, sy, sh); KCHK(ctx); }
+        return LRGE_OK;
+    };
+    rc = comm_agree(c, local3(), st); if (rc) return rc;
+    // ---- (6) the exchanges ----
+    rc = comm_alltoallv(c, sx, ks_off.data(), rx, kr_off.data(), 8, st); if (rc) return rc;
+    if (!pk) { rc = comm_alltoallv(c, sy, ks_off.data(), ry, kr_off.data(), 8, st); if (rc) return rc; }
+    rc = comm_alltoallv(c, sh, os_off.data(), rh, or_off.data(), 8, st); if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(st));        // (the offset vectors are locals; the local transport has synchronised already)
+    sc.drop(raw.x); if (raw.y) sc.drop(raw.y);
+    sc.drop(flags); sc.drop(cnt); sc.drop(d_tot); sc.drop(sx); sc.drop(sh); if (sy) sc.drop(sy);
+    sc.drop(ks.bits); sc.drop(gathered); sc.drop(inter); sc.drop(d_sz);
+    so->x = rx; so->y = ry; so->mz_off = nullptr; so->n = n_kr;
+    *own_hashes = rh; *n_own = n_or;
+    const u64 ss[8] = {g_shard_stats.keyset_bytes, g_shard_stats.entries_sketched, g_shard_stats.entries_sent, g_shard_stats.entries_recv,
+                       g_shard_stats.hashes_sent, g_shard_stats.hashes_recv, (u64)(pk ? 8 : 16), n_kr};
+    memcpy(ctx->shard_stats, ss, sizeof ss);
+    return LRGE_OK;
+}
+
 
 static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_index **out, const IndexBuildOpts *ro = nullptr) {
     *out = nullptr;
@@ -773,7 +931,10 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     SketchOut so;
     int rc = LRGE_OK;
     KeySet ks{nullptr, 0, 0, 0, 0};
-    if (ro && ro->restrict_to) {
+    const bool sharded = ro && ro->shard;
+    CollectiveGuard cg{ro ? ro->comm : nullptr, ctx->stream};
+    cg.armed = ro && ro->comm && !sharded;        // (a sharded build agrees inside sharded_collect first)
+    if (ro && ro->restrict_to && !sharded) {
         // the streamed set's sketch and the key set built from it go to the side stream FIRST, so that they run beside
         // the target sketch below; the main stream meets them (ev_join) where the entries are filtered
         lrge_hip_seqset *S = ro->restrict_to;
@@ -814,8 +975,17 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         }
     }
     bool fused = false; u64 *own_hashes = nullptr; u64 n_own = 0;
+    if (sharded) {
+        // this rank sketches its own share of the targets; key sets, kept entries and owned hashes travel (k_route.h)
+        StageTimer t(ctx, LRGE_T_INDEX_RESTRICT);
+        rc = sharded_collect(ctx, sc, P, preset, pk, pk ? pk_pos1 : 0, pk_ybits, ro, &so, &own_hashes, &n_own);
+        t.stop();
+        if (rc) return rc;
+        cg.armed = ro->comm != nullptr;
+        fused = true;                              // (so holds exactly the entries this rank's index keeps)
+    }
     // (measured at C4: with a world of 2 the key set is so dense that the sweeps of the general form are the faster way)
-    if (ro && ro->restrict_to && !ctx->opt("RESTRICT_SWEEPS") && (own_world >= 4 || ctx->opt("RESTRICT_FUSED"))) {
+    if (!sharded && ro && ro->restrict_to && !ctx->opt("RESTRICT_SWEEPS") && (own_world >= 4 || ctx->opt("RESTRICT_FUSED"))) {
         // fast form: the key-set test inside the target sketch (needs the key set first: the main stream meets the side
         // stream here instead of after the sketch)
         rc = seqset_ready(ctx, targets);
@@ -912,6 +1082,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         ALLOC_OR_FAIL(d_vec, sc, u64, (size_t)head + 2);
         hipLaunchKernelGGL(k_stats_pack, dim3((u32)div_up(head, 256)), dim3(256), 0, ctx->stream, d_nr, Ms, d_hist, head, d_vec);
         KCHK(ctx);
+        rc = cg.agree(); if (rc) return rc;       // every rank got this far, or none goes on
         if (ro->comm) { rc = comm_allreduce_sum(ro->comm, d_vec, (size_t)head + 2, 8, ctx->stream); if (rc) return rc; }
         std::vector<u64> hv((size_t)head + 2);
         HIPCHK(ctx, hipMemcpyAsync(hv.data(), d_vec, hv.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1229,6 +1400,63 @@ extern "C" int lrge_hip_index_build_for(lrge_hip_ctx *ctx, const lrge_hip_seqset
     return index_build_one(ctx, targets, preset, out, &ro);
 }
 
+// A read set known by its lengths and names only (its bases live elsewhere: on the other ranks of a sharded build).
+// It can stand where an index's target set is consulted for lengths and name ranks; it cannot be sketched.
+static int seqset_describe(lrge_hip_ctx *ctx, const uint32_t *lens, uint32_t n, const uint32_t *name_rank, lrge_hip_seqset **out) {
+    *out = nullptr;
+    std::unique_ptr<lrge_hip_seqset, void (*)(lrge_hip_seqset *)> guard(new lrge_hip_seqset(), lrge_hip_seqset_free);
+    lrge_hip_seqset *s = guard.get();
+    s->ctx = ctx; s->n = n; s->pooled = true;
+    s->h_len.assign(lens, lens + n);
+    if (s->h_len.empty()) s->h_len.push_back(0);
+    for (u32 i = 0; i < n; ++i) {
+        if (lens[i] >= (1u << 31)) { LRGE_SET_ERR(ctx, "read %u: length >= 2^31", i); return LRGE_ERR_INVALID; }
+        s->total_bases += lens[i]; s->max_len = std::max(s->max_len, lens[i]); s->has_empty |= lens[i] == 0;
+    }
+    if (name_rank) { s->has_rank = true; s->h_rank.assign(name_rank, name_rank + n); s->dup_rank = ranks_have_duplicate(s->h_rank); }
+    hipError_t e = hipSuccess;
+    const size_t nb = (((size_t)(n ? n : 1) * 4) + 255) & ~(size_t)255;
+    s->d_meta = ctx->pool.alloc(2 * nb, &e);
+    if (!s->d_meta) { LRGE_SET_ERR(ctx, "seqset_describe: device allocation failed: %s", hipGetErrorString(e)); return LRGE_ERR_DEVICE; }
+    s->d_len = (u32 *)s->d_meta; s->d_rank = (u32 *)((char *)s->d_meta + nb);
+    if (n) {
+        HIPCHK(ctx, hipMemcpyAsync(s->d_len, s->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (name_rank) HIPCHK(ctx, hipMemcpyAsync(s->d_rank, s->h_rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *out = guard.release();
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_index_build_sharded(lrge_hip_ctx *ctx, const uint32_t *all_target_lens, const uint32_t *all_target_ranks, uint32_t n_targets,
+                                            const lrge_hip_seqset *target_shard, uint32_t shard_first, int preset, lrge_hip_seqset *streamed,
+                                            lrge_hip_comm *comm, lrge_hip_index **out) {
+    if (!ctx || !out || !all_target_lens || !target_shard || !streamed || !comm) return LRGE_ERR_INVALID;
+    *out = nullptr;
+    // (argument errors below are rank-local by nature -- every rank passes the same job -- so they return before any collective)
+    if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
+    if (streamed->ctx != ctx || target_shard->ctx != ctx || comm->ctx != ctx) { LRGE_SET_ERR(ctx, "index_build_sharded: sets / communicator belong to another context"); return LRGE_ERR_INVALID; }
+    if (comm->world > ROUTE_MAX_WORLD) { LRGE_SET_ERR(ctx, "index_build_sharded: at most %d ranks", ROUTE_MAX_WORLD); return LRGE_ERR_INVALID; }
+    if ((u64)shard_first + target_shard->n > n_targets) { LRGE_SET_ERR(ctx, "index_build_sharded: the shard [%u, %u) lies outside the %u target reads", shard_first, shard_first + target_shard->n, n_targets); return LRGE_ERR_INVALID; }
+    for (u32 i = 0; i < target_shard->n; ++i)
+        if (target_shard->h_len[i] != all_target_lens[shard_first + i]) { LRGE_SET_ERR(ctx, "index_build_sharded: read %u of the shard does not have the length of target read %u", i, shard_first + i); return LRGE_ERR_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    lrge_hip_seqset *meta = nullptr;
+    int rc = seqset_describe(ctx, all_target_lens, n_targets, all_target_ranks, &meta);
+    if (rc) { (void)comm_agree(comm, rc, ctx->stream); return rc; }          // (the others are entering the build's first collective)
+    IndexBuildOpts ro; ro.restrict_to = streamed; ro.comm = comm; ro.shard = target_shard; ro.shard_first = shard_first;
+    rc = index_build_one(ctx, meta, preset, out, &ro);
+    if (rc) { lrge_hip_seqset_free(meta); return rc; }
+    (*out)->owned_seqs = meta;
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_last_shard_stats(const lrge_hip_ctx *ctx, uint64_t out[8]) {
+    if (!ctx || !out) return LRGE_ERR_INVALID;
+    memcpy(out, ctx->shard_stats, sizeof(ctx->shard_stats));
+    return LRGE_OK;
+}
+
 extern "C" void lrge_hip_index_free(lrge_hip_index *ix) {
     if (!ix) return;
     if (!ix->parts.empty() || !ix->part_sets.empty()) {
@@ -1239,6 +1467,7 @@ extern "C" void lrge_hip_index_free(lrge_hip_index *ix) {
     }
     bool ctx_alive;
     { std::lock_guard<std::mutex> g(g_live_mu); ctx_alive = g_live_ctx.count(ix->ctx) != 0; }
+    if (ix->owned_seqs) lrge_hip_seqset_free(ix->owned_seqs);
     if (ctx_alive) {     // (a destroyed context has already freed its pool: an index that outlives it owns nothing)
         ix->ctx->pool.release(ix->d_pos); if (ix->d_skey && ix->d_skey != ix->d_pos) ix->ctx->pool.release(ix->d_skey);
         ix->ctx->pool.release(ix->d_ht);
@@ -2342,6 +2571,52 @@ extern "C" void lrge_hip_comm_destroy(lrge_hip_comm *c) {
 }
 extern "C" int lrge_hip_comm_rank(const lrge_hip_comm *c) { return c ? c->rank : -1; }
 extern "C" int lrge_hip_comm_world(const lrge_hip_comm *c) { return c ? c->world : 0; }
+
+// how many ranks RCCL itself sees in this communicator (ncclCommCount): 0 for the local / host transports
+extern "C" int lrge_hip_comm_rccl_ranks(const lrge_hip_comm *c, int *n) {
+    if (!c || !n) return LRGE_ERR_INVALID;
+    *n = 0;
+    if (!c->nccl) return LRGE_OK;
+    if (g_rccl.CommCount(c->nccl, n) != 0) { *n = 0; return LRGE_ERR_DEVICE; }
+    return LRGE_OK;
+}
+extern "C" int lrge_hip_comm_local_group_serialize(void *grp, int on) {
+    if (!grp) return LRGE_ERR_INVALID;
+    ((LocalGroup *)grp)->serialize = on != 0;
+    return LRGE_OK;
+}
+extern "C" int lrge_hip_comm_local_turn(lrge_hip_comm *c, int begin) {
+    if (!c) return LRGE_ERR_INVALID;
+    comm_turn(c, begin != 0);
+    return LRGE_OK;
+}
+extern "C" double lrge_hip_comm_busy_ms(lrge_hip_comm *c, int reset) {
+    if (!c) return 0.0;
+    const double v = c->busy_ms;
+    if (reset) c->busy_ms = 0;
+    return v;
+}
+
+// host-buffer form of the variable-size all-to-all (the library itself uses the device form inside lrge_hip_index_build_sharded)
+extern "C" int lrge_hip_comm_alltoallv(lrge_hip_comm *c, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off,
+                                       size_t elem_bytes) {
+    if (!c || !send_off || !recv_off || elem_bytes == 0) return LRGE_ERR_INVALID;
+    lrge_hip_ctx *ctx = c->ctx;
+    const int W = c->world;
+    const u64 ns = send_off[W], nr = recv_off[W];
+    if ((ns && !send) || (nr && !recv)) return LRGE_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch sc(ctx);
+    char *ds = sc.get<char>(ns * elem_bytes + 1), *dr = sc.get<char>(nr * elem_bytes + 1);
+    int rc = comm_agree(c, (ds && dr) ? LRGE_OK : LRGE_ERR_DEVICE, ctx->stream);
+    if (rc) return rc;
+    if (ns) HIPCHK(ctx, hipMemcpyAsync(ds, send, ns * elem_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = comm_alltoallv(c, ds, send_off, dr, recv_off, elem_bytes, ctx->stream);
+    if (rc) return rc;
+    if (nr) HIPCHK(ctx, hipMemcpyAsync(recv, dr, nr * elem_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LRGE_OK;
+}
 
 // host-buffer forms of the two collectives that close a step
 extern "C" int lrge_hip_comm_allreduce_u32(lrge_hip_comm *c, uint32_t *inout, size_t n) {

@@ -187,9 +187,26 @@ class SeqSet:
 class Index:
     """AlignerWrapper::new(target_file, threads, preset, dual) -- aligner.rs:310-328."""
 
-    def __init__(self, ctx, targets, preset=_ffi.PRESET_AVA_ONT, streamed=None, comm=None):
+    def __init__(self, ctx, targets, preset=_ffi.PRESET_AVA_ONT, streamed=None, comm=None, shard=None):
+        """shard = (all_target_lens, all_target_ranks or None, shard_first): `targets` is this rank's contiguous share of the
+        target reads and the build is the collective lrge_hip_index_build_sharded (the target sketch is sharded too)."""
         self.ctx, self.targets, self.preset = ctx, targets, preset
         h = C.c_void_p()
+        if shard is not None:
+            lens = np.ascontiguousarray(shard[0], dtype=np.uint32)
+            ranks = None if shard[1] is None else np.ascontiguousarray(shard[1], dtype=np.uint32)
+            self.streamed = streamed
+            self.n_targets = lens.size
+            ctx._check(ctx._lib.lrge_hip_index_build_sharded(ctx.h, lens.ctypes.data, None if ranks is None else ranks.ctypes.data, lens.size,
+                                                             targets.h, int(shard[2]), preset, streamed.h, comm.h, C.byref(h)))
+            self.h = h
+            self.build_timings = ctx.timings()
+            self.build_counters = ctx.counters()
+            a = (C.c_uint64 * 8)()
+            ctx._lib.lrge_hip_last_shard_stats(ctx.h, C.byref(a))
+            self.shard_stats = dict(zip(["keyset_bytes", "entries_sketched", "entries_sent", "entries_recv", "hashes_sent", "hashes_recv",
+                                         "entry_bytes", "entries_kept"], [int(x) for x in a]))
+            return
         # streamed / comm: an index built for ONE streamed set, occurrence statistics still over all targets; with a
         # communicator every rank passes its own range of the streamed reads (lrge_hip_index_build_for)
         self.streamed = streamed

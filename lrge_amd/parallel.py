@@ -58,6 +58,35 @@ class _Comm:
         m = max(max_len, 1)
         return np.concatenate([recv[r * m:r * m + lens[r]] for r in range(self.world)])
 
+    def all_to_all_v(self, send, send_counts):
+        """Variable-size all-to-all of a 1-d numpy array: send_counts[d] consecutive elements go to rank d.  Returns
+        (received array, receive counts) -- the counts travel first (one all-gather), as the C ABI asks."""
+        import ctypes as C
+        send = np.ascontiguousarray(send)
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        allc = np.empty(self.world * self.world, dtype=np.uint64)
+        self.ctx._check(self.ctx._lib.lrge_hip_comm_allgather(self.h, sc.ctypes.data, C.c_size_t(sc.nbytes), allc.ctypes.data))
+        rc = allc.reshape(self.world, self.world)[:, self.rank].copy()
+        so = np.zeros(self.world + 1, dtype=np.uint64); np.cumsum(sc, out=so[1:])
+        ro = np.zeros(self.world + 1, dtype=np.uint64); np.cumsum(rc, out=ro[1:])
+        recv = np.empty(max(int(ro[-1]), 1), dtype=send.dtype)
+        self.ctx._check(self.ctx._lib.lrge_hip_comm_alltoallv(self.h, send.ctypes.data if send.size else None, so.ctypes.data, recv.ctypes.data,
+                                                              ro.ctypes.data, C.c_size_t(send.dtype.itemsize)))
+        return recv[:int(ro[-1])], rc
+
+    def rccl_ranks(self):
+        import ctypes as C
+        n = C.c_int()
+        self.ctx._check(self.ctx._lib.lrge_hip_comm_rccl_ranks(self.h, C.byref(n)))
+        return n.value
+
+    def turn(self, begin):
+        """Serialized local groups (timing emulation of a world on one GPU): take / give back the GPU."""
+        self.ctx._lib.lrge_hip_comm_local_turn(self.h, 1 if begin else 0)
+
+    def busy_ms(self, reset=False):
+        return float(self.ctx._lib.lrge_hip_comm_busy_ms(self.h, 1 if reset else 0))
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx._lib.lrge_hip_comm_destroy(self.h)
@@ -150,6 +179,10 @@ class LocalGroup:
         rc = self._lib.lrge_hip_comm_local_group_create(world, C.byref(self.h))
         if rc != 0:
             raise RuntimeError("local group: %d" % rc)
+
+    def serialize(self, on=True):
+        """The ranks take turns on the GPU (see lrge_hip_comm_local_group_serialize): clean per-rank timings on one GPU."""
+        self._lib.lrge_hip_comm_local_group_serialize(self.h, 1 if on else 0)
 
     def comm(self, ctx, rank):
         import ctypes as C

@@ -371,29 +371,43 @@ lo_index_t *lo_index_build(const char *bases, const uint64_t *offs, uint32_t n,
            one index (y = rid << 32 | pos << 1 | strand is unique), so where an entry lands inside its bucket before the
            sort does not matter */
         const int shift = 2 * opt->k > 12 ? 2 * opt->k - 12 : 0;
-        uint64_t *bstart = (uint64_t *)calloc(4097 + 1, 8), *fill;
-        int64_t b, ii;
+        uint64_t *bstart = (uint64_t *)calloc(4097 + 1, 8), *loc;
+        int64_t b;
+        int nth = 1, t;
 #pragma omp parallel
         {
-            uint64_t *loc = (uint64_t *)calloc(4096, 8);
-            int64_t t;
-#pragma omp for schedule(static) nowait
-            for (t = 0; t < (int64_t)ix->n_mz; ++t) ++loc[(v.a[t].x >> 8) >> shift];
-#pragma omp critical
-            for (t = 0; t < 4096; ++t) bstart[t + 1] += loc[t];
-            free(loc);
+#pragma omp single
+            nth = omp_get_num_threads();
         }
-        for (i = 0; i < 4096; ++i) bstart[i + 1] += bstart[i];
-        fill = (uint64_t *)malloc(4097 * 8);
-        memcpy(fill, bstart, 4097 * 8);
-#pragma omp parallel for schedule(static)
-        for (ii = 0; ii < (int64_t)ix->n_mz; ++ii) {
-            uint64_t h = v.a[ii].x >> 8, d;
-#pragma omp atomic capture
-            d = fill[h >> shift]++;
-            hy[d].h = h; hy[d].y = v.a[ii].y;
+        /* thread t scatters the t-th contiguous slice of the entries to positions of its own inside every bucket
+           (counts per (thread, bucket), then one scan in bucket-major order): no atomics, no shared counters */
+        loc = (uint64_t *)calloc((size_t)nth * 4096, 8);
+#pragma omp parallel num_threads(nth)
+        {
+            const int me = omp_get_thread_num();
+            const uint64_t per = (ix->n_mz + (uint64_t)nth - 1) / (uint64_t)nth, lo = per * (uint64_t)me, hi = lo + per < ix->n_mz ? lo + per : ix->n_mz;
+            uint64_t *l = loc + (size_t)me * 4096, q;
+            for (q = lo; q < hi; ++q) ++l[(v.a[q].x >> 8) >> shift];
         }
-        free(fill);
+        {
+            uint64_t run = 0, bq;
+            for (bq = 0; bq < 4096; ++bq) {
+                bstart[bq] = run;
+                for (t = 0; t < nth; ++t) { uint64_t c = loc[(size_t)t * 4096 + bq]; loc[(size_t)t * 4096 + bq] = run; run += c; }
+            }
+            bstart[4096] = run;
+        }
+#pragma omp parallel num_threads(nth)
+        {
+            const int me = omp_get_thread_num();
+            const uint64_t per = (ix->n_mz + (uint64_t)nth - 1) / (uint64_t)nth, lo = per * (uint64_t)me, hi = lo + per < ix->n_mz ? lo + per : ix->n_mz;
+            uint64_t *l = loc + (size_t)me * 4096, q;
+            for (q = lo; q < hi; ++q) {
+                const uint64_t h = v.a[q].x >> 8, d = l[h >> shift]++;
+                hy[d].h = h; hy[d].y = v.a[q].y;
+            }
+        }
+        free(loc);
 #pragma omp parallel for schedule(dynamic, 8)
         for (b = 0; b < 4096; ++b)
             if (bstart[b + 1] > bstart[b]) qsort(hy + bstart[b], bstart[b + 1] - bstart[b], sizeof(hy_t), cmp_hy);

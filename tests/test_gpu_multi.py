@@ -79,8 +79,10 @@ def _run_world(world, ds, preset, mode):
     from lrge_amd import engine, parallel
     grp = parallel.LocalGroup(world)
     qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
-    out, errs = [None] * world, []
-    bounds = parallel.shard_by_bases(ds.q.lens() if mode == "twoset" else ds.t.lens(), world)
+    out, errs, shard_stats = [None] * world, [], []
+    _run_world.shard_stats = shard_stats
+    bounds = parallel.shard_by_bases(ds.t.lens() if mode == "inverse" else ds.q.lens(), world)
+    tb = parallel.shard_by_bases(ds.t.lens(), world)        # sharded target sketch: contiguous shares in rank order
     avg_t = np.float32(ds.t.lens().sum()) / np.float32(ds.t.n)
 
     def rank_main(r):
@@ -88,11 +90,18 @@ def _run_world(world, ds, preset, mode):
             c = engine.Context(0)
             comm = grp.comm(c, r)
             lo, hi = bounds[r], bounds[r + 1]
-            if mode == "twoset":       # forward: targets indexed (restricted per rank), this rank's queries streamed
-                Td = c.upload(ds.t.bases, ds.t.offsets, tr)
+            if mode in ("twoset", "sharded"):   # forward: targets indexed (restricted per rank), this rank's queries streamed
                 sub = ds.q.slice(lo, hi)
                 Qd = c.upload(sub.bases, sub.offsets, qr[lo:hi])
-                ix = engine.Index(c, Td, preset, streamed=Qd, comm=comm)
+                if mode == "sharded":      # ... and every rank sketches only its own share of the targets
+                    t0, t1 = tb[r], tb[r + 1]
+                    tsub = ds.t.slice(t0, t1)
+                    Td = c.upload(tsub.bases, tsub.offsets, tr[t0:t1])
+                    ix = engine.Index(c, Td, preset, streamed=Qd, comm=comm, shard=(ds.t.lens(), tr, t0))
+                    shard_stats.append(ix.shard_stats)
+                else:
+                    Td = c.upload(ds.t.bases, ds.t.offsets, tr)
+                    ix = engine.Index(c, Td, preset, streamed=Qd, comm=comm)
                 counts, has = ix.overlap_twoset(Qd)
                 est = c.estimates(counts, sub.lens(), float(avg_t), ds.t.n, 100)
                 lens = [bounds[i + 1] - bounds[i] for i in range(world)]
@@ -140,6 +149,102 @@ def test_world_of_threads_forward(ctx, oracle, tiny_ont, tiny_hifi, preset, worl
     ixo = oracle.Index(oracle.ReadSet(ds.t.seqs(), ds.t.names), opt)
     rc, ec, eh = ixo.twoset_counts(oracle.ReadSet(ds.q.seqs(), ds.q.names), threads=8)
     assert np.array_equal(counts, ec) and ixo.mid_occ == st["mid_occ"]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("layout", ["packed", "pairs"])
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_world_of_threads_sharded_target_sketch(ctx, tiny_ont, tiny_hifi, preset, layout, world, monkeypatch):
+    """lrge_hip_index_build_sharded: every rank sketches only its share of the targets; key sets, kept entries and owned
+    hashes travel through the communicator (all-gather + two variable-size all-to-alls).  Worlds of 2, 3 and 8 threads on
+    one GPU give the single-GPU counts, has_mapping, estimates and index statistics on every rank, both presets and both
+    entry layouts; a starved Bloom filter (many false positives: more entries travel, none is missed) changes nothing."""
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    if layout == "pairs":
+        monkeypatch.setenv("LRGE_HIP_NO_PACKED_INDEX", "1")       # (read when the ranks' contexts are created)
+    if world == 3:
+        monkeypatch.setenv("LRGE_HIP_SHARD_BLOOM_BITS", "1")
+    Qd, Td, counts, has, st = _single(ctx, ds, PRESETS[preset])
+    avg_t = np.float32(ds.t.lens().sum()) / np.float32(ds.t.n)
+    est = ctx.estimates(counts, ds.q.lens(), float(avg_t), ds.t.n, 100)
+    out, bounds = _run_world(world, ds, PRESETS[preset], "sharded")
+    for r, (c, h, s, allest) in enumerate(out):
+        assert s == st, (r, s, st)
+        assert np.array_equal(c, counts[bounds[r]:bounds[r + 1]]) and np.array_equal(h, has[bounds[r]:bounds[r + 1]])
+        assert np.array_equal(allest.view(np.uint32), est.view(np.uint32))
+    ss = _run_world.shard_stats
+    assert len(ss) == world and sum(x["entries_sketched"] for x in ss) == st["n_minimizers"]      # every target minimizer sketched exactly once
+    assert sum(x["entries_sent"] for x in ss) == sum(x["entries_recv"] for x in ss) and sum(x["hashes_sent"] for x in ss) == sum(x["hashes_recv"] for x in ss)
+
+
+def test_alltoallv_behind_the_abi(ctx):
+    """lrge_hip_comm_alltoallv on host buffers, world of 3 threads: rank s sends s * 10 + d repeated (s + d + 1) times to rank d."""
+    from lrge_amd import engine, parallel
+    world = 3
+    grp = parallel.LocalGroup(world)
+    got, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            c = engine.Context(0)
+            comm = grp.comm(c, r)
+            counts = [r + d + 1 for d in range(world)]
+            send = np.concatenate([np.full(n, r * 10 + d, dtype=np.uint64) for d, n in enumerate(counts)])
+            recv, rc = comm.all_to_all_v(send, counts)
+            got[r] = (recv.copy(), rc.copy())
+            e32, _ = comm.all_to_all_v(send.astype(np.uint32), counts)       # another element size
+            assert np.array_equal(e32, recv.astype(np.uint32))
+            comm.close(); c.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append((r, repr(e)))
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    grp.close()
+    assert not errs, errs
+    for d in range(world):
+        recv, rc = got[d]
+        assert rc.tolist() == [s + d + 1 for s in range(world)]
+        assert recv.tolist() == [s * 10 + d for s in range(world) for _ in range(s + d + 1)]
+
+
+def test_a_failing_rank_fails_the_collective_build(ctx, tiny_ont):
+    """a rank whose allocation fails inside the collective index build must not leave the others blocked.  Rank 1's
+    pool refuses every new segment (DEBUG_ALLOC_FAIL_ALWAYS); all ranks return an error, nobody hangs."""
+    from lrge_amd import _ffi, engine, parallel
+    ds = tiny_ont
+    world = 2
+    grp = parallel.LocalGroup(world)
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    bounds = parallel.shard_by_bases(ds.q.lens(), world)
+    res = [None] * world
+
+    def rank_main(r):
+        c = engine.Context(0)
+        comm = grp.comm(c, r)
+        try:
+            Td = c.upload(ds.t.bases, ds.t.offsets, tr)
+            sub = ds.q.slice(bounds[r], bounds[r + 1])
+            Qd = c.upload(sub.bases, sub.offsets, qr[bounds[r]:bounds[r + 1]])
+            if r == 1:
+                c.set_option("DEBUG_ALLOC_FAIL_ALWAYS", "1")
+            engine.Index(c, Td, 0, streamed=Qd, comm=comm)
+            res[r] = "built"
+        except _ffi.LrgeHipError as e:
+            res[r] = "error: %s" % e
+        finally:
+            c.set_option("DEBUG_ALLOC_FAIL_ALWAYS", None)
+            comm.close(); c.close()
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert all(not t.is_alive() for t in th), "a rank is still blocked in the collective"
+    grp.close()
+    assert all(x is not None and x.startswith("error") for x in res), res
 
 
 def test_world_of_threads_inverse(ctx, tiny_ont):

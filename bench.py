@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="N",
+                    help="projection on ONE GPU of an N-rank strong-scaling run of the forward strategy with the target sketch sharded: "
+                         "all N ranks run for real as threads of this process (one context each, the library's local communicator), "
+                         "taking turns on the GPU, so that every rank's share is timed alone; results are checked against the "
+                         "one-GPU run.  A projection input (per-rank busy time + exchange volumes), not a bench result")
     ap.add_argument("--emulate-rank", default=None, metavar="R/N",
                     help="timing emulation on ONE GPU of rank R of an N-rank strong-scaling run: this process maps rank R's query "
                          "range against an index restricted to it and counts R's 1/N share of the occurrence statistics; nobody "
@@ -124,6 +129,82 @@ def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
                        "threads (%.1f s); pro-rated x%.1f in the target dimension (index time and per-read map time both scale with "
                        "the number of target reads) and to all %d queries" % (nt, Tn, t_index, done, cores, t_map, scale, Qn),
                 index_s_sample=t_index, map_s_sample=t_map, reads_mapped=done)
+
+
+XGMI_LINK_GBPS = 64.0     # one direction of one xGMI link, what a point-to-point transfer between two GPUs sustains (7 links per GPU)
+
+
+def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device):
+    """--emulate-world N (see parse()).  Prints one JSON line."""
+    import threading
+    N = a.emulate_world
+    # the one-GPU job first: the reference time and the reference results
+    one = RankJob(ctx0, None, 0, 1, device)
+    for _ in range(max(1, a.warmup)):
+        one.step(one.qs.ptr, one.ts.ptr)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ref = one.step(one.qs.ptr, one.ts.ptr)
+    t_one = (time.perf_counter() - t0) * 1e3 / a.steps
+    ref_counts, ref_est, ref_med, _, _, _, ref_st = ref
+    if hasattr(one.qs, "dev"):
+        one.qs.dev.free(); one.ts.dev.free()
+    one.qs = one.ts = None
+    grp = parallel.LocalGroup(N)
+    grp.serialize(True)
+    res, errs = [None] * N, []
+
+    def rank_main(r):
+        try:
+            c = engine.Context(device)
+            comm = grp.comm(c, r)
+            comm.turn(True)
+            job = RankJob(c, comm, r, N, device)
+            comm.turn(False)
+            for it in range(max(1, a.warmup) + a.steps):
+                if it == max(1, a.warmup):
+                    comm.busy_ms(reset=True)
+                comm.turn(True)
+                out = job.step(job.qs.ptr, job.ts.ptr)
+                comm.turn(False)
+            busy = comm.busy_ms() / a.steps
+            counts, est_all, med, tb, tm, cn, st = out
+            lo, hi = job.bounds[r], job.bounds[r + 1]
+            ok = bool(np.array_equal(counts, ref_counts[lo:hi]) and st == ref_st and np.array_equal(est_all.view(np.uint32), ref_est.view(np.uint32)))
+            res[r] = dict(rank=r, busy_ms_per_step=busy, results_equal_one_gpu=ok, query_reads=hi - lo, shard=job.shard_stats,
+                          stage_ms={**{"index_" + k: round(v, 3) for k, v in tb.items() if v and k != "total"}, **{k: round(v, 3) for k, v in tm.items() if v}})
+            comm.close(); c.close()
+        except Exception as e:      # noqa: BLE001 -- reported below
+            errs.append((r, repr(e)))
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(N)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    grp.close()
+    if errs:
+        print(json.dumps({"emulate_world": N, "errors": errs}))
+        return
+    busy = max(r_["busy_ms_per_step"] for r_ in res)
+    # link model: the all-gather of the key sets as a ring (per-link bound), the two all-to-alls point to point (every peer
+    # has its own link; the slowest pair bounds the exchange)
+    ss = [r_["shard"] for r_ in res if r_["shard"]]
+    link_ms = None
+    if ss:
+        eb = ss[0]["entry_bytes"]
+        ring = (N - 1) * ss[0]["keyset_bytes"] / (XGMI_LINK_GBPS * 1e9) * 1e3
+        a2a = max((x["entries_recv"] * eb + x["hashes_recv"] * 8) / max(N - 1, 1) for x in ss) / (XGMI_LINK_GBPS * 1e9) * 1e3
+        link_ms = {"keyset_allgather_ring_ms": ring, "alltoall_ms": a2a, "per_link_GBps": XGMI_LINK_GBPS,
+                   "note": "model: D2D copies stand in for the links inside busy_ms (those run at HBM speed); this is what the links add at best-case even spreading"}
+    print(json.dumps({"emulate_world": N, "NOT_A_BENCH_RESULT": "all ranks on one GPU, taking turns; a projection input", "config": a.config,
+                      "one_gpu_ms_per_step": t_one, "max_rank_busy_ms_per_step": busy,
+                      "projected_speedup_compute_only": t_one / busy,
+                      "projected_speedup_with_link_model": None if not link_ms else t_one / (busy + link_ms["keyset_allgather_ring_ms"] + link_ms["alltoall_ms"]),
+                      "link_model": link_ms, "all_ranks_equal_one_gpu": all(r_["results_equal_one_gpu"] for r_ in res),
+                      "exchange_bytes_total": None if not ss else {"keysets": N * (N - 1) * ss[0]["keyset_bytes"],
+                                                                   "entries": sum(x["entries_sent"] for x in ss) * ss[0]["entry_bytes"],
+                                                                   "hashes": sum(x["hashes_sent"] for x in ss) * 8},
+                      "ranks": res}))
 
 
 def main():
@@ -209,37 +290,99 @@ def main():
         assert world == 1 and 0 <= er < en
         emu = (er, en)
         ctx.set_option("DEBUG_OWN_SHARE", "%d,%d" % (en, er))
-    n_shards = emu[1] if emu else world
-    my = emu[0] if emu else rank
-    # strong scaling: the STREAMED set is cut into contiguous ranges with equal base counts -- the queries in the forward
-    # strategy (twoset.rs:266-334), the targets with --inverse (--use-min-ref, twoset.rs:485-565)
-    bounds = parallel.shard_by_bases(t_lens if a.inverse else q_lens, n_shards)
-    lo, hi = bounds[my], bounds[my + 1]
-    q_rng = (0, Qn) if (a.inverse or n_shards == 1) else (lo, hi)       # this rank's reads of each set
-    t_rng = (lo, hi) if (a.inverse and n_shards > 1) else (0, Tn)
     avg_t = np.float32(t_lens.sum()) / np.float32(Tn)
-    shard_lens = [bounds[i + 1] - bounds[i] for i in range(n_shards)]
-    max_shard = max(shard_lens)
+    if gen != "cb":
+        qr_all, tr_all = engine.name_ranks(q.names, t.names)
+    else:       # names are r%08d of the read index, so the index is the lexicographic rank over the union of both sets
+        qr_all, tr_all = np.arange(0, Qn, dtype=np.uint32), np.arange(Qn, Qn + Tn, dtype=np.uint32)
+    # forward strategy on more than one GPU: the target sketch is sharded too (lrge_hip_index_build_sharded)
+    # unless LRGE_BENCH_REPLICATED_SKETCH asks for round 2's form (every rank sketches all targets: lrge_hip_index_build_for)
+    shard_targets = not a.inverse and not os.environ.get("LRGE_BENCH_REPLICATED_SKETCH")
 
     class Src:
-        """One read set of this rank's job: offsets, name ranks, and where its ASCII bases live (HBM; host on request)."""
+        """One read set of one rank's job: offsets, name ranks, and where its ASCII bases live (HBM; host on request)."""
 
-    qs, ts = Src(), Src()
-    if gen == "cb":
-        # names are r%08d of the read index, so the index is the lexicographic rank over the union of both sets
-        for S, (r0, r1), first in ((qs, q_rng, 0), (ts, t_rng, Qn)):
-            S.dev = spec.device_reads(first + r0, r1 - r0, local_rank)      # ASCII straight into HBM
-            S.n, S.offsets, S.rank, S.nbytes, S.ptr = r1 - r0, S.dev.offsets, S.dev.name_ranks(), S.dev.total_bases, S.dev.ptr
-            S.host = S.dev.to_host
-    else:
-        qr, tr = engine.name_ranks(q.names, t.names)
-        for S, R, rk, (r0, r1) in ((qs, q, qr, q_rng), (ts, t, tr, t_rng)):
-            sub = R if (r0, r1) == (0, R.n) else R.slice(r0, r1)
-            S.n, S.offsets, S.rank, S.nbytes = sub.n, sub.offsets, rk[r0:r1], sub.bases.size
-            S.tensor = torch.from_numpy(sub.bases).cuda()               # the ASCII reads resident in HBM (value)
-            S.ptr = S.tensor.data_ptr()
-            S.host = (lambda sub=sub: sub.bases)
-    qs_lens = q_lens[q_rng[0]:q_rng[1]]
+    class RankJob:
+        """What one rank does per step.  my / n_shards: which share of the STREAMED set it owns -- contiguous ranges with equal
+        base counts, the queries in the forward strategy (twoset.rs:266-334), the targets with --inverse (twoset.rs:485-565)."""
+
+        def __init__(self, ctx, comm, my, n_shards, device, emulated_share=False):
+            self.ctx, self.comm, self.my, self.n_shards = ctx, comm, my, n_shards
+            self.bounds = parallel.shard_by_bases(t_lens if a.inverse else q_lens, n_shards)
+            lo, hi = self.bounds[my], self.bounds[my + 1]
+            q_rng = (0, Qn) if (a.inverse or n_shards == 1) else (lo, hi)
+            t_rng = (lo, hi) if (a.inverse and n_shards > 1) else (0, Tn)
+            self.sharded = shard_targets and n_shards > 1 and comm is not None
+            if self.sharded:
+                tb_ = parallel.shard_by_bases(t_lens, n_shards)
+                t_rng = (tb_[my], tb_[my + 1])
+            self.restrict = (comm is not None or emulated_share or bool(os.environ.get("LRGE_BENCH_RESTRICT"))) and not a.inverse
+            self.q_rng, self.t_rng = q_rng, t_rng
+            self.shard_lens = [self.bounds[i + 1] - self.bounds[i] for i in range(n_shards)]
+            self.max_shard = max(self.shard_lens)
+            self.qs, self.ts = Src(), Src()
+            if gen == "cb":
+                for S, (r0, r1), first in ((self.qs, q_rng, 0), (self.ts, t_rng, Qn)):
+                    S.dev = spec.device_reads(first + r0, r1 - r0, device)      # ASCII straight into HBM
+                    S.n, S.offsets, S.rank, S.nbytes, S.ptr = r1 - r0, S.dev.offsets, S.dev.name_ranks(), S.dev.total_bases, S.dev.ptr
+                    S.host = S.dev.to_host
+            else:
+                for S, R, rk, (r0, r1) in ((self.qs, q, qr_all, q_rng), (self.ts, t, tr_all, t_rng)):
+                    sub = R if (r0, r1) == (0, R.n) else R.slice(r0, r1)
+                    S.n, S.offsets, S.rank, S.nbytes = sub.n, sub.offsets, rk[r0:r1], sub.bases.size
+                    S.tensor = torch.from_numpy(sub.bases).to("cuda:%d" % device)     # the ASCII reads resident in HBM (value)
+                    S.ptr = S.tensor.data_ptr()
+                    S.host = (lambda sub=sub: sub.bases)
+            self.qs_lens = q_lens[q_rng[0]:q_rng[1]]
+            self.shard_stats = None
+
+        def step(self, src_q, src_t):
+            """src_*: int device pointer (ASCII resident in HBM) or PinnedBuffer (ASCII in pinned host memory)."""
+            ctx, comm, qs, ts = self.ctx, self.comm, self.qs, self.ts
+            if a.inverse:
+                # index = the query set (small), the streamed targets of this rank travel / pack while it is built
+                Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)
+                Td = ctx.upload(src_t, ts.offsets, ts.rank, wait=False)
+                if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
+                    Td.presketch(preset)
+                ix = engine.Index(ctx, Qd, preset)
+                tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
+                counts = ix.overlap_inverse(Td)
+                tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
+                ix.free(); Qd.free(); Td.free()
+                if comm is not None:    # the one collective that closes the step: count vector keyed by indexed read (twoset.rs:520-523)
+                    counts = comm.all_reduce_u32(counts)
+                est_all = ctx.estimates(counts, q_lens, float(avg_t), Tn, 100)
+            else:
+                Td = ctx.upload(src_t, ts.offsets, ts.rank, wait=False)      # K0 pack (and PCIe, from the host) on the copy stream
+                Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)      # travels / packs while the index is built
+                if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
+                    Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
+                if self.sharded:
+                    ix = engine.Index(ctx, Td, preset, streamed=Qd, comm=comm, shard=(t_lens, tr_all, self.t_rng[0]))
+                    self.shard_stats = ix.shard_stats
+                else:
+                    ix = engine.Index(ctx, Td, preset, streamed=Qd if self.restrict else None, comm=comm)
+                tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
+                counts, has = ix.overlap_twoset(Qd)
+                tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
+                est = ctx.estimates(counts, self.qs_lens, float(avg_t), Tn, 100)
+                ix.free(); Qd.free(); Td.free()
+                if comm is not None:    # the one collective that closes the step: per-read estimate vectors over RCCL/xGMI
+                    est_all = comm.all_gather_f32(est, self.max_shard, self.shard_lens)
+                else:
+                    est_all = est
+            med = engine.median(est_all, True, 0.15, 0.65)
+            for k_ in ("rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes"):   # the index build sorts too
+                cn[k_] = cn.get(k_, 0) + cb_.get(k_, 0)
+            return counts, est_all, med, tb, tm, cn, st
+
+    if a.emulate_world:
+        emulate_world(a, ctx, RankJob, Qn, engine, parallel, local_rank)
+        ctx.close()
+        return
+    job = RankJob(ctx, comm, emu[0] if emu else rank, emu[1] if emu else world, local_rank, emulated_share=bool(emu))
+    qs, ts, step = job.qs, job.ts, job.step
     torch.cuda.synchronize()
 
     def sync_all():
@@ -247,42 +390,6 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-
-    def step(src_q, src_t):
-        """src_*: int device pointer (ASCII resident in HBM) or PinnedBuffer (ASCII in pinned host memory)."""
-        if a.inverse:
-            # index = the query set (small), the streamed targets of this rank travel / pack while it is built
-            Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)
-            Td = ctx.upload(src_t, ts.offsets, ts.rank, wait=False)
-            if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
-                Td.presketch(preset)
-            ix = engine.Index(ctx, Qd, preset)
-            tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
-            counts = ix.overlap_inverse(Td)
-            tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
-            ix.free(); Qd.free(); Td.free()
-            if comm is not None:    # the one collective that closes the step: count vector keyed by indexed read (twoset.rs:520-523)
-                counts = comm.all_reduce_u32(counts)
-            est_all = ctx.estimates(counts, q_lens, float(avg_t), Tn, 100)
-        else:
-            Td = ctx.upload(src_t, ts.offsets, ts.rank, wait=False)      # K0 pack (and PCIe, from the host) on the copy stream
-            Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)      # travels / packs while the index is built
-            if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
-                Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
-            ix = engine.Index(ctx, Td, preset, streamed=Qd if comm is not None or emu or os.environ.get("LRGE_BENCH_RESTRICT") else None, comm=comm)
-            tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
-            counts, has = ix.overlap_twoset(Qd)
-            tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
-            est = ctx.estimates(counts, qs_lens, float(avg_t), Tn, 100)
-            ix.free(); Qd.free(); Td.free()
-            if comm is not None:    # the one collective that closes the step: per-read estimate vectors over RCCL/xGMI
-                est_all = comm.all_gather_f32(est, max_shard, shard_lens)
-            else:
-                est_all = est
-        med = engine.median(est_all, True, 0.15, 0.65)
-        for k_ in ("rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes"):   # the index build sorts too
-            cn[k_] = cn.get(k_, 0) + cb_.get(k_, 0)
-        return counts, est_all, med, tb, tm, cn, st
 
     def timed(src_q, src_t, warmup, steps):
         for _ in range(warmup):
@@ -385,8 +492,13 @@ def main():
                        "query_reads": Qn, "target_reads": Tn,
                        "parallelism": ("one job, streamed targets cut into %d ranges by bases; query index replicated; counts all-reduced" % world) if a.inverse else
                                       ("one job, queries cut into %d ranges by bases; index %s" %
-                                       (world, "restricted to each rank's query minimizers, global occurrence statistics by one all-reduce" if world > 1 else "over all targets")),
+                                       (world, ("restricted to each rank's query minimizers, global occurrence statistics by one all-reduce" +
+                                                ("; every rank sketches 1/%d of the targets, key sets all-gathered, kept entries and owned hashes by all-to-all" % world if job.sharded else ""))
+                                        if world > 1 else "over all targets")),
                        "collectives": transport if use_dist else None,
+                       "rccl_ranks": (comm.rccl_ranks() if (comm is not None and hasattr(comm, "rccl_ranks")) else None),
+                       "target_sketch": ("sharded (lrge_hip_index_build_sharded)" if job.sharded else "replicated") if world > 1 and not a.inverse else None,
+                       "exchange_per_step_rank0": job.shard_stats,
                        "scale": a.scale, "data_gen_s": round(t_gen, 1)},
             "from_host": from_host,
             "genome_size_true": gsize,

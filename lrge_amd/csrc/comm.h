@@ -99,6 +99,7 @@ struct lrge_hip_comm {
     lrge_hip_host_allreduce_fn cb_allreduce = nullptr; lrge_hip_host_allgather_fn cb_allgather = nullptr; void *cb_user = nullptr;
     std::vector<char> hbuf;              // host staging of the local / host transports
     bool in_turn = false; double busy_ms = 0, t_acquired = 0;     // (serialized local groups)
+    double wait_ms = 0;                   // wall time spent inside barriers of the local transport (waiting for the other ranks)
 };
 
 static void comm_turn(lrge_hip_comm *c, bool begin) {
@@ -113,9 +114,11 @@ static void comm_turn(lrge_hip_comm *c, bool begin) {
 // barrier of the local transport; a serialized group hands the GPU to another rank while this one waits
 static bool grp_barrier(lrge_hip_comm *c) {
     const bool turn = c->grp->serialize && c->in_turn;
+    const double t0 = DevPool::now_ms();
     if (turn) comm_turn(c, false);
     const bool ok = c->grp->barrier();
     if (turn) comm_turn(c, true);
+    c->wait_ms += DevPool::now_ms() - t0;
     return ok;
 }
 
@@ -176,6 +179,19 @@ static int comm_allgather(lrge_hip_comm *c, const void *dsend, size_t bytes, voi
     if (bytes == 0) return LRGE_OK;
     if (c->world == 1) { HIPCHK(ctx, hipMemcpyAsync(drecv, dsend, bytes, hipMemcpyDeviceToDevice, st)); return LRGE_OK; }
     if (c->nccl) { NCCLCHK(ctx, g_rccl.AllGather(dsend, drecv, bytes, LRGE_NCCL_UINT8, c->nccl, st)); return LRGE_OK; }
+    if (c->grp && bytes >= ((size_t)64 << 10)) {
+        // threads of one process, a large payload (the key sets of a sharded build): every rank copies the others' buffers
+        // device to device instead of meeting in pageable host memory
+        LocalGroup *g = c->grp;
+        HIPCHK_GRP(c, hipStreamSynchronize(st));                   // my buffer is complete before anybody reads it
+        g->slot[(size_t)c->rank] = dsend;
+        if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
+        for (int r = 0; r < c->world; ++r)
+            HIPCHK_GRP(c, hipMemcpyAsync((char *)drecv + bytes * (size_t)r, g->slot[(size_t)r], bytes, hipMemcpyDefault, st));
+        HIPCHK_GRP(c, hipStreamSynchronize(st));
+        if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
+        return LRGE_OK;
+    }
     c->hbuf.resize(bytes);
     HIPCHK_GRP(c, hipMemcpyAsync(c->hbuf.data(), dsend, bytes, hipMemcpyDeviceToHost, st));
     HIPCHK_GRP(c, hipStreamSynchronize(st));

@@ -21,7 +21,7 @@
 #define ROUTE_MAX_WORLD 16
 
 struct KeySetAll {
-    const u64 *bits;    // interleaved: word w of rank r at bits[w * world + r]
+    const u64 *bits;    // interleaved: word w of rank r at bits[w * STRIDE + r], STRIDE = 8 (world <= 8) or 16 slots per word, unused slots zero
     u64 word_mask;      // n_words - 1
     u32 world;
 };
@@ -33,12 +33,17 @@ __device__ __forceinline__ void ksa_locate(u64 word_mask, u64 hash, u64 *word, u
     *mask = 1ULL << (m & 63) | 1ULL << ((m >> 6) & 63) | 1ULL << ((m >> 12) & 63);
 }
 
-// [rank][word] (what the all-gather delivers) -> [word][rank]
+// [rank][word] (what the all-gather delivers) -> [word][STRIDE slots, rank r in slot r, the rest zero]: one thread per word
+// (coalesced reads of every rank's filter, one contiguous STRIDE * 8 byte run written per thread)
+template <int STRIDE>
 __global__ __launch_bounds__(256) void k_keyset_interleave(const u64 *__restrict__ in, u64 n_words, u32 world, u64 *__restrict__ out) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;       // output index
-    if (i >= n_words * world) return;
-    const u64 w = i / world; const u32 r = (u32)(i - w * world);
-    out[i] = in[(u64)r * n_words + w];
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    u64 v[STRIDE];
+#pragma unroll
+    for (int r = 0; r < STRIDE; ++r) v[r] = r < (int)world ? in[(u64)r * n_words + w] : 0;
+#pragma unroll
+    for (int r = 0; r < STRIDE; r += 2) *(ulonglong2 *)(out + w * STRIDE + r) = make_ulonglong2(v[r], v[r + 1]);
 }
 
 // entries of a shard carry the read's index inside the shard: make it the index in the whole target set
@@ -55,36 +60,61 @@ struct RouteArgs {
 };
 
 // flags[i] = mask of the ranks that ask for entry i's key | owner << 16; cnt[s * n_tiles + tile] = entries of the tile
-// that go to stream s (s < world: kept for rank s; s >= world: owned by rank s - world)
+// that go to stream s (s < world: kept for rank s; s >= world: owned by rank s - world).
+// STRIDE (8 or 16) words per filter line, a compile-time constant: every entry's line is fetched with STRIDE / 2 16-byte
+// loads issued back to back, and all rows' loads are in flight before the first is tested (with a run-time rank count the
+// compiler made it one load and one wait per rank and row: 3.5 ms per 30 M entries, now latency-hidden).
+template <int STRIDE>
 __global__ __launch_bounds__(RF_THREADS) void k_route_count(RouteArgs A, u32 *__restrict__ flags, u32 *__restrict__ cnt) {
     __shared__ u32 sc[2 * ROUTE_MAX_WORLD];
     const u32 W = A.ks.world;
     if (threadIdx.x < 2 * W) sc[threadIdx.x] = 0;
     __syncthreads();
     const u64 tile_base = (u64)blockIdx.x * RF_TILE;
-    u32 mine[2 * ROUTE_MAX_WORLD];
-#pragma unroll
-    for (int s = 0; s < 2 * ROUTE_MAX_WORLD; ++s) mine[s] = 0;
+    u64 hs[RF_ITEMS];
 #pragma unroll
     for (int r = 0; r < RF_ITEMS; ++r) {
         const u64 i = tile_base + (u64)r * RF_THREADS + threadIdx.x;
-        if (i < A.n) {
-            const u64 h = A.x[i] >> A.kshift;
-            u64 w, m;
-            ksa_locate(A.ks.word_mask, h, &w, &m);
-            const u64 *line = A.ks.bits + w * W;
-            u32 want = 0;
-            for (u32 q = 0; q < W; ++q) want |= ((line[q] & m) == m ? 1u : 0u) << q;
-            const u32 owner = (u32)(((ks_mix(h) >> 32) * (u64)W) >> 32);
-            flags[i] = want | owner << 16;
+        hs[r] = i < A.n ? A.x[i] >> A.kshift : 0;
+    }
+    u32 keep[STRIDE], own[STRIDE];
 #pragma unroll
-            for (int s = 0; s < ROUTE_MAX_WORLD; ++s) if (s < (int)W) { mine[s] += (want >> s) & 1u; mine[ROUTE_MAX_WORLD + s] += owner == (u32)s; }
+    for (int s = 0; s < STRIDE; ++s) { keep[s] = 0; own[s] = 0; }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        ulonglong2 ln[RF_ITEMS / 2][STRIDE / 2];
+        u64 ms[RF_ITEMS / 2];
+#pragma unroll
+        for (int rr = 0; rr < RF_ITEMS / 2; ++rr) {
+            u64 w;
+            ksa_locate(A.ks.word_mask, hs[half * (RF_ITEMS / 2) + rr], &w, &ms[rr]);
+            const ulonglong2 *line = (const ulonglong2 *)(A.ks.bits + w * STRIDE);
+#pragma unroll
+            for (int q = 0; q < STRIDE / 2; ++q) ln[rr][q] = line[q];
+        }
+#pragma unroll
+        for (int rr = 0; rr < RF_ITEMS / 2; ++rr) {
+            const int r = half * (RF_ITEMS / 2) + rr;
+            const u64 i = tile_base + (u64)r * RF_THREADS + threadIdx.x;
+            if (i < A.n) {
+                const u64 m = ms[rr];
+                u32 want = 0;
+#pragma unroll
+                for (int q = 0; q < STRIDE / 2; ++q) {
+                    want |= ((ln[rr][q].x & m) == m ? 1u : 0u) << (2 * q);
+                    want |= ((ln[rr][q].y & m) == m ? 1u : 0u) << (2 * q + 1);
+                }
+                const u32 owner = (u32)(((ks_mix(hs[r]) >> 32) * (u64)W) >> 32);
+                flags[i] = want | owner << 16;
+#pragma unroll
+                for (int s = 0; s < STRIDE; ++s) { keep[s] += (want >> s) & 1u; own[s] += owner == (u32)s; }
+            }
         }
     }
 #pragma unroll
-    for (int s = 0; s < ROUTE_MAX_WORLD; ++s) {
+    for (int s = 0; s < STRIDE; ++s) {
         if (s < (int)W) {
-            u32 a = mine[s], b = mine[ROUTE_MAX_WORLD + s];
+            u32 a = keep[s], b = own[s];
             for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d, 64); b += __shfl_down(b, d, 64); }
             if (lane_id() == 0) { if (a) atomicAdd(&sc[s], a); if (b) atomicAdd(&sc[W + s], b); }
         }

@@ -782,6 +782,15 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
     hipStream_t st = ctx->stream;
     g_shard_stats = ShardStats();
     int rc = LRGE_OK;
+    // option VERBOSE: time this rank spent in each phase, the waits for the other ranks (local transport) taken out
+    double t_mark = DevPool::now_ms(), w_mark = c->wait_ms;
+    auto mark = [&](const char *what) {
+        if (!ctx->opt("VERBOSE")) return;
+        (void)hipStreamSynchronize(st);
+        const double now = DevPool::now_ms();
+        fprintf(stderr, "[lrge_hip] rank %d sharded build: %-28s %7.3f ms (+ %.3f ms waiting)\n", me, what, (now - t_mark) - (c->wait_ms - w_mark), c->wait_ms - w_mark);
+        t_mark = now; w_mark = c->wait_ms;
+    };
     // ---- (1) one agreed key-set size: all ranks' streamed base counts (and whether anybody has failed already) ----
     std::vector<u64> hv((size_t)W + 1, 0);
     u64 *d_sz = sc.get<u64>((size_t)W + 1);
@@ -799,6 +808,7 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
     u64 n_words = 1ULL << 14;
     while (n_words < (1ULL << 31) && n_words * 64 < bloom_bits * max_bases) n_words <<= 1;
     g_shard_stats.keyset_bytes = n_words * 8;
+    mark("sizes all-reduce");
     // ---- (2) local: the streamed set's sketch + this rank's key set on the side stream, beside the target shard's sketch ----
     KeySet ks{nullptr, n_words - 1, 0, (u32)(2 * P.k), ceil_log2_u64(n_words)};
     u64 *gathered = nullptr, *inter = nullptr;
@@ -809,7 +819,7 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
             int r = presketch_start_pending(ctx, ~0ULL >> 2); if (r) return r;
         }
         if (!S->presk) { LRGE_SET_ERR(ctx, "index_build_sharded: the streamed set is too large to restrict an index to (it is streamed in views)"); return LRGE_ERR_TOO_MANY; }
-        ks.bits = sc.get<u64>(n_words); gathered = sc.get<u64>(n_words * (u64)W); inter = sc.get<u64>(n_words * (u64)W);
+        ks.bits = sc.get<u64>(n_words); gathered = sc.get<u64>(n_words * (u64)W); inter = sc.get<u64>(n_words * (u64)(W <= 8 ? 8 : 16));
         if (!ks.bits || !gathered || !inter) return LRGE_ERR_DEVICE;
         HIPCHK(ctx, hipMemsetAsync(ks.bits, 0, n_words * 8, ctx->stream2));
         hipLaunchKernelGGL(k_keyset_build, dim3((u32)div_up(S->total_bases + 1, 256)), dim3(256), 0, ctx->stream2, S->presk->x, S->presk->d_total, ks);
@@ -826,10 +836,15 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
         HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
         return LRGE_OK;
     };
-    rc = comm_agree(c, local1(), st); if (rc) return rc;
+    rc = local1();
+    mark("sketches + key set");
+    rc = comm_agree(c, rc, st); if (rc) return rc;
     g_shard_stats.entries_sketched = raw.n;
+    mark("agree");
     rc = comm_allgather(c, ks.bits, n_words * 8, gathered, st); if (rc) return rc;
-    hipLaunchKernelGGL(k_keyset_interleave, dim3((u32)div_up(n_words * (u64)W, 256)), dim3(256), 0, st, gathered, n_words, (u32)W, inter);
+    mark("key-set all-gather");
+    if (W <= 8) hipLaunchKernelGGL(k_keyset_interleave<8>, dim3((u32)div_up(n_words, 256)), dim3(256), 0, st, gathered, n_words, (u32)W, inter);
+    else hipLaunchKernelGGL(k_keyset_interleave<16>, dim3((u32)div_up(n_words, 256)), dim3(256), 0, st, gathered, n_words, (u32)W, inter);
     KCHK(ctx);
     // ---- (3) local: which ranks ask for every entry, who owns its hash; counts per destination ----
     const u64 Mr = raw.n;
@@ -842,7 +857,8 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
         if (Mr >= (1ULL << 32)) return LRGE_ERR_TOO_MANY;
         flags = sc.get<u32>(Mr + 1); cnt = sc.get<u32>((u64)2 * W * A.n_tiles); d_tot = sc.get<u32>((size_t)2 * W);
         if (!flags || !cnt || !d_tot) return LRGE_ERR_DEVICE;
-        hipLaunchKernelGGL(k_route_count, dim3(A.n_tiles), dim3(RF_THREADS), 0, st, A, flags, cnt);
+        if (W <= 8) hipLaunchKernelGGL(k_route_count<8>, dim3(A.n_tiles), dim3(RF_THREADS), 0, st, A, flags, cnt);
+        else hipLaunchKernelGGL(k_route_count<16>, dim3(A.n_tiles), dim3(RF_THREADS), 0, st, A, flags, cnt);
         KCHK(ctx);
         hipLaunchKernelGGL(k_route_scan, dim3((u32)(2 * W)), dim3(1024), 0, st, cnt, A.n_tiles, d_tot);
         KCHK(ctx);
@@ -853,6 +869,7 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
         return LRGE_OK;
     };
     mine[(size_t)2 * W] = local2() ? 1 : 0;
+    mark("interleave + route count");
     const int rc2 = mine[(size_t)2 * W] ? LRGE_ERR_DEVICE : LRGE_OK;
     // ---- (4) everybody learns every (source, destination) count (and whether a rank has failed) ----
     {
@@ -864,6 +881,7 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
         HIPCHK(ctx, hipStreamSynchronize(st));
         sc.drop(d_mine); sc.drop(d_all);
     }
+    mark("counts all-gather");
     const size_t row = (size_t)2 * W + 1;
     for (int r = 0; r < W; ++r) if (matrix[(size_t)r * row + 2 * W]) { if (!rc2) LRGE_SET_ERR(ctx, "sharded index build: rank %d failed", r); return LRGE_ERR_DEVICE; }
     // send / receive offsets (elements) of the two all-to-alls
@@ -889,12 +907,16 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
         if (Mr) { hipLaunchKernelGGL(k_route_write, dim3(A.n_tiles), dim3(RF_THREADS), 0, st, A, flags, cnt, B, sx, sy, sh); KCHK(ctx); }
         return LRGE_OK;
     };
-    rc = comm_agree(c, local3(), st); if (rc) return rc;
+    rc = local3();
+    mark("route write");
+    rc = comm_agree(c, rc, st); if (rc) return rc;
+    mark("agree");
     // ---- (6) the exchanges ----
     rc = comm_alltoallv(c, sx, ks_off.data(), rx, kr_off.data(), 8, st); if (rc) return rc;
     if (!pk) { rc = comm_alltoallv(c, sy, ks_off.data(), ry, kr_off.data(), 8, st); if (rc) return rc; }
     rc = comm_alltoallv(c, sh, os_off.data(), rh, or_off.data(), 8, st); if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(st));        // (the offset vectors are locals; the local transport has synchronised already)
+    mark("all-to-alls");
     sc.drop(raw.x); if (raw.y) sc.drop(raw.y);
     sc.drop(flags); sc.drop(cnt); sc.drop(d_tot); sc.drop(sx); sc.drop(sh); if (sy) sc.drop(sy);
     sc.drop(ks.bits); sc.drop(gathered); sc.drop(inter); sc.drop(d_sz);

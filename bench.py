@@ -176,15 +176,21 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device):
             comm.close(); c.close()
         except Exception as e:      # noqa: BLE001 -- reported below
             errs.append((r, repr(e)))
+            try:
+                comm.turn(False)    # a rank that fails while it holds the GPU must hand it back, or the others wait for ever
+            except Exception:       # noqa: BLE001
+                pass
     th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(N)]
     for t_ in th:
         t_.start()
+    deadline = time.perf_counter() + float(os.environ.get("LRGE_BENCH_EMULATE_TIMEOUT", "240"))
     for t_ in th:
-        t_.join()
+        t_.join(timeout=max(1.0, deadline - time.perf_counter()))
+    if errs or any(t_.is_alive() for t_ in th):
+        print(json.dumps({"emulate_world": N, "errors": errs, "ranks_still_running": sum(t_.is_alive() for t_ in th)}))
+        sys.stdout.flush()
+        os._exit(1)
     grp.close()
-    if errs:
-        print(json.dumps({"emulate_world": N, "errors": errs}))
-        return
     busy = max(r_["busy_ms_per_step"] for r_ in res)
     # link model: the all-gather of the key sets as a ring (per-link bound), the two all-to-alls point to point (every peer
     # has its own link; the slowest pair bounds the exchange)

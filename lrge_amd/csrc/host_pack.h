@@ -1,0 +1,157 @@
+// host_pack.h -- the 2-bit pack (K0) on the HOST for read sets that start in host memory, and the background uploader.
+//
+// lrge_hip_seqset_upload* hands over ASCII bases (the (name, seq) records of twoset.rs:216-241).  Sent as they are they
+// cross PCIe at 1 byte per base -- 13 ms for the 720 Mbases of the headline workload's targets, none of which can hide
+// behind anything (the index needs all of them).  The packed image the device works on is 0.375 bytes per base, so a set
+// that starts in host memory is packed by a few host threads (AVX2 + BMI2 where the CPU has them: ~40 instructions per 32
+// bases) in chunks, chunk i travelling while chunk i + 1 is packed; the device-side k_pack (k_sketch.h) remains the path of
+// reads that are already resident in HBM, and both produce the same image bit for bit (tests/test_gpu_upload.py).
+// The work is done by an uploader thread per context, so that lrge_hip_seqset_upload_async returns at once and a second
+// set is packed and travels while the first one is being indexed (the reference's producer thread, twoset.rs:216-241).
+#pragma once
+#include <immintrin.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "internal.h"
+
+// A/a=0 C/c=1 G/g=2 T/t/U/u=3, everything else "ambiguous" (mask bit set, code 0): the host twin of nt4_code() in k_sketch.h
+static inline u32 hp_nt4(u8 c) {
+    const u32 b = (c >> 1) & 3;
+    const bool letter = (c & 0xC0u) == 0x40u && ((0x0030008Au >> (c & 31)) & 1u);
+    return letter ? (b ^ (b >> 1)) : 4u;
+}
+
+// one 32-base word: cnt bases at src (cnt <= 32; positions past cnt are padding: ambiguous, code 0)
+static inline void hp_word_scalar(const u8 *src, u32 cnt, u64 *bits, u32 *mask) {
+    u64 b = 0; u32 m = 0;
+    for (u32 i = 0; i < cnt; ++i) { const u32 c = hp_nt4(src[i]); b |= (u64)(c & 3) << (2 * i); m |= (c >> 2) << i; }
+    if (cnt < 32) m |= ~0u << cnt;
+    *bits = b; *mask = m;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2,bmi2"))) static inline void hp_word_avx2(const u8 *src, u64 *bits, u32 *mask) {
+    const __m256i v = _mm256_loadu_si256((const __m256i *)src);
+    const __m256i up = _mm256_and_si256(v, _mm256_set1_epi8((char)0xDF));            // fold case
+    __m256i ok = _mm256_cmpeq_epi8(up, _mm256_set1_epi8('A'));
+    ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(up, _mm256_set1_epi8('C')));
+    ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(up, _mm256_set1_epi8('G')));
+    ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(up, _mm256_set1_epi8('T')));
+    ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(up, _mm256_set1_epi8('U')));
+    const u32 letters = (u32)_mm256_movemask_epi8(ok);
+    alignas(32) u64 q[4];
+    _mm256_store_si256((__m256i *)q, v);
+    u64 b = 0;
+    for (int t = 0; t < 4; ++t) {
+        const u64 two = _pext_u64(q[t], 0x0606060606060606ull);                      // bits 1..2 of every byte: 16 bits
+        const u64 code = two ^ ((two >> 1) & 0x5555ull);                             // b ^ (b >> 1) inside every pair
+        const u64 keep = _pdep_u64((letters >> (8 * t)) & 0xffu, 0x5555ull) * 3;      // 11 for a letter, 00 otherwise
+        b |= (code & keep) << (16 * t);
+    }
+    *bits = b; *mask = ~letters;
+}
+#endif
+
+static bool hp_have_avx2() {
+#if defined(__x86_64__)
+    static const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+    return ok;
+#else
+    return false;
+#endif
+}
+
+// words [w0, w1) of the packed image of a set (reads start on word boundaries: woff[]; boff[] = base offsets of the reads
+// inside `ascii`) into out_pack / out_mask (indexed from w0)
+static void hp_pack_range(const u8 *ascii, const u64 *boff, const u64 *woff, u32 n_reads, u64 w0, u64 w1, u64 *out_pack, u32 *out_mask) {
+    if (w0 >= w1) return;
+    // the read that holds word w0: the last read whose first word is <= w0 and that owns at least one word
+    u32 r = (u32)(std::upper_bound(woff, woff + n_reads + 1, w0) - woff) - 1;
+    const bool simd = hp_have_avx2();
+    for (u64 w = w0; w < w1;) {
+        while (r + 1 < n_reads && woff[r + 1] <= w) ++r;
+        const u64 len = boff[r + 1] - boff[r], wend = std::min(w1, woff[r + 1]);
+        const u8 *base = ascii + boff[r];
+        for (; w < wend; ++w) {
+            const u64 pos = (w - woff[r]) * 32;
+            const u32 cnt = (u32)std::min<u64>(32, len - pos);
+            u64 b; u32 m;
+#if defined(__x86_64__)
+            if (simd && cnt == 32) hp_word_avx2(base + pos, &b, &m); else
+#endif
+            hp_word_scalar(base + pos, cnt, &b, &m);
+            out_pack[w - w0] = b; out_mask[w - w0] = m;
+        }
+    }
+}
+
+// A few persistent host threads: parallel_for(n, fn) runs fn(0) .. fn(n - 1) on them (and on the caller).
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex mu; std::condition_variable cv_go, cv_done;
+    std::function<void(u32)> fn; u32 n_tasks = 0; std::atomic<u32> next{0}; u32 running = 0; u64 gen = 0; bool quit = false;
+    void start(u32 n_threads) {
+        if (!th.empty()) return;
+        for (u32 t = 0; t < n_threads; ++t) th.emplace_back([this] { worker(); });
+    }
+    void worker() {
+        u64 seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(mu); cv_go.wait(lk, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; }
+            for (u32 i; (i = next.fetch_add(1)) < n_tasks;) fn(i);
+            { std::lock_guard<std::mutex> lk(mu); if (--running == 0) cv_done.notify_all(); }
+        }
+    }
+    void parallel_for(u32 n, std::function<void(u32)> f) {
+        if (n == 0) return;
+        if (th.empty() || n == 1) { for (u32 i = 0; i < n; ++i) f(i); return; }
+        { std::lock_guard<std::mutex> lk(mu); fn = std::move(f); n_tasks = n; next = 0; running = (u32)th.size(); ++gen; }
+        cv_go.notify_all();
+        for (u32 i; (i = next.fetch_add(1)) < n_tasks;) fn(i);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return running == 0; });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+
+// The uploader of a context: jobs run one after the other on its thread (FIFO: a second set is packed behind the first).
+struct Uploader {
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    std::deque<std::function<void()>> jobs; bool quit = false, started = false;
+    HostPool pool;
+    void submit(std::function<void()> j) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!started) { started = true; th = std::thread([this] { run(); }); }
+        jobs.push_back(std::move(j));
+        cv.notify_all();
+    }
+    void run() {
+        for (;;) {
+            std::function<void()> j;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return quit || !jobs.empty(); }); if (jobs.empty()) return; j = std::move(jobs.front()); jobs.pop_front(); }
+            j();
+        }
+    }
+    ~Uploader() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
+// completion of one upload job (the set's side of it)
+struct UploadJob {
+    std::mutex mu; std::condition_variable cv; bool done = false; int rc = 0; std::string err;
+    void finish(int r, const std::string &e) { { std::lock_guard<std::mutex> lk(mu); done = true; rc = r; err = e; } cv.notify_all(); }
+    int wait(std::string *e) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); if (rc && e) *e = err; return rc; }
+};

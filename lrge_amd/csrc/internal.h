@@ -10,6 +10,7 @@
 #include <cstring>
 #include <iterator>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -164,6 +165,8 @@ struct DevPool {
 };
 
 struct TimerRec;
+struct Uploader;
+struct UploadJob;
 struct lrge_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -174,6 +177,8 @@ struct lrge_hip_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_gate = nullptr;            // main stream -> copy stream ordering at the start of an upload
     char *stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; size_t stage_cap = 0;
+    // host-side pack (host_pack.h): the uploader thread of the context and its two pinned chunk buffers (packed words + masks)
+    Uploader *uploader = nullptr; char *hp_stage[2] = {nullptr, nullptr}; hipEvent_t hp_ev[2] = {nullptr, nullptr}; size_t hp_words = 0;
     // pinned arena for the per-read arrays of an upload (offsets, lengths, ranks, chunk and block maps): they are laid out
     // in it back to back and travel as ONE transfer (six copies from pageable vectors cost ~0.1 ms each of host time in
     // front of every index build).  Bump allocation; rewound when no upload is in flight.
@@ -263,6 +268,7 @@ struct lrge_hip_seqset {
     void *d_meta = nullptr;     // pooled sets: ONE device block behind d_woff, d_len, d_rank, d_cs, stg_boff, stg_blk
     bool meta_arena = false;    // the upload's per-read arrays sit in the context's pinned arena until the set is ready
     std::vector<u64> h_boff; std::vector<u32> h_blk;
+    std::shared_ptr<UploadJob> job;   // host-side pack + chunked transfer running on the context's uploader thread (ev_ready is recorded by it)
     std::vector<u32> h_cs;
     // host copies needed for planning
     std::vector<u64> h_woff;

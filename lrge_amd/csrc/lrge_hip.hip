@@ -20,6 +20,7 @@
 #include "k_chain_hw.h"
 #include "k_chain_lpg.h"
 #include "comm.h"
+#include "host_pack.h"
 #include "k_restrict.h"
 #include "k_route.h"
 #include "../../include/lrge_rand.hpp"
@@ -158,8 +159,10 @@ extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
     pool_report(ctx, "ctx_destroy");
     { std::lock_guard<std::mutex> g(g_live_mu); g_live_ctx.erase(ctx); }
     (void)hipSetDevice(ctx->device);
+    delete ctx->uploader; ctx->uploader = nullptr;      // (drains its queue)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->copy_stream);
+    for (int b = 0; b < 2; ++b) { if (ctx->hp_stage[b]) (void)hipHostFree(ctx->hp_stage[b]); if (ctx->hp_ev[b]) (void)hipEventDestroy(ctx->hp_ev[b]); }
     ctx->resolve_timers();
     for (int b = 0; b < 2; ++b) { if (ctx->stage[b]) (void)hipHostFree(ctx->stage[b]); if (ctx->stage_ev[b]) (void)hipEventDestroy(ctx->stage_ev[b]); }
     (void)hipEventDestroy(ctx->ev_gate); (void)hipStreamDestroy(ctx->copy_stream);
@@ -240,11 +243,23 @@ extern "C" int lrge_hip_host_alloc(size_t bytes, void **out) {
 }
 extern "C" void lrge_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+// a host-side pack still running on the uploader thread: its last act is to record the set's ev_ready, so nobody may wait
+// for that event on the device before the job has finished on the host
+static int seqset_job_wait(lrge_hip_ctx *ctx, lrge_hip_seqset *s) {
+    if (!s->job) return LRGE_OK;
+    std::string e;
+    const int rc = s->job->wait(&e);
+    s->job.reset();
+    if (rc) { ctx->err = e; return rc; }
+    return LRGE_OK;
+}
+
 // Every consumer of a set's device arrays calls this first: work queued on the main stream after it runs behind the
 // set's upload; the staging blocks of the upload return to the pool (recycled in main-stream order from here on).
 static int seqset_ready(lrge_hip_ctx *ctx, const lrge_hip_seqset *cs) {
     lrge_hip_seqset *s = const_cast<lrge_hip_seqset *>(cs);
     if (!s->pending) return LRGE_OK;
+    { int jrc = seqset_job_wait(ctx, s); if (jrc) return jrc; }
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_ready, 0));
     s->pending = false;
     if (s->meta_arena) { s->meta_arena = false; if (--ctx->meta_inflight == 0) ctx->meta_used = 0; }
@@ -332,7 +347,10 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
         } else (void)hipGetLastError();
     }
     const u8 *d_ascii = (const u8 *)src;
-    if (kind != 0 && s->total_bases) {
+    // a set that starts in host memory is packed on the host and travels packed (host_pack.h); option NO_HOST_PACK sends the
+    // ASCII and packs on the device as rounds 1-2 did
+    const bool host_pack = kind != 0 && s->total_bases > 0 && !ctx->opt("NO_HOST_PACK");
+    if (kind != 0 && s->total_bases && !host_pack) {
         s->stg_ascii = alloc(s->total_bases);
         if (!s->stg_ascii) { LRGE_SET_ERR(ctx, "seqset_upload: device allocation failed: %s", hipGetErrorString(e)); return LRGE_ERR_DEVICE; }
         d_ascii = (const u8 *)s->stg_ascii;
@@ -391,7 +409,67 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
             HIPCHK(ctx, hipEventRecord(ctx->ev_meta, cs));
         }
     }
-    if (kind == 1) {
+    if (host_pack) {
+        // pinned chunk buffers + the uploader thread, once per context
+        const size_t CH = (size_t)ctx->opt_u64("HOST_PACK_CHUNK_WORDS", (u64)2 << 20);      // 64 Mbases per chunk
+        if (!ctx->hp_stage[0] || ctx->hp_words != CH) {
+            for (int b = 0; b < 2; ++b) {
+                if (ctx->hp_stage[b]) { HIPCHK(ctx, hipStreamSynchronize(cs)); (void)hipHostFree(ctx->hp_stage[b]); ctx->hp_stage[b] = nullptr; }
+                HIPCHK(ctx, hipHostMalloc((void **)&ctx->hp_stage[b], CH * 12, hipHostMallocDefault));
+                if (!ctx->hp_ev[b]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->hp_ev[b], hipEventDisableTiming));
+                HIPCHK(ctx, hipEventRecord(ctx->hp_ev[b], cs));
+            }
+            ctx->hp_words = CH;
+        }
+        if (!ctx->uploader) {
+            ctx->uploader = new Uploader();
+            const u32 hw = std::max(2u, std::thread::hardware_concurrency());
+            ctx->uploader->pool.start((u32)ctx->opt_u64("HOST_PACK_THREADS", std::min<u32>(32, std::max<u32>(2, hw / 2))) - 1);
+        }
+        s->h_boff.resize((size_t)n + 1);
+        { const u64 o0 = offsets[0]; for (u32 i = 0; i <= n; ++i) s->h_boff[i] = offsets[i] - o0; }
+        auto job = std::make_shared<UploadJob>();
+        s->job = job;
+        hipEvent_t ev_ready = s->ev_ready;
+        const int device = ctx->device;
+        const u64 n_words = w;
+        u64 *d_pack = s->d_pack; u32 *d_nmask = s->d_nmask;
+        const u64 *boff = s->h_boff.data(), *woff = s->h_woff.data();
+        Uploader *up = ctx->uploader;
+        char **stage = ctx->hp_stage; hipEvent_t *sev = ctx->hp_ev;
+        const u8 *hsrc = (const u8 *)src;
+        const bool verbose = ctx->opt("VERBOSE") != nullptr;
+        auto work = [=]() {
+            hipError_t e = hipSetDevice(device);
+            int b = 0;
+            const double t_job = DevPool::now_ms(); double t_pack = 0, t_wait = 0;
+            for (u64 w0 = 0; w0 < n_words && e == hipSuccess; w0 += CH, b ^= 1) {
+                const u64 w1 = std::min<u64>(n_words, w0 + CH), nw = w1 - w0;
+                const double t0 = DevPool::now_ms();
+                e = hipEventSynchronize(sev[b]);                      // the DMA that last read this buffer
+                if (e != hipSuccess) break;
+                const double t1 = DevPool::now_ms(); t_wait += t1 - t0;
+                u64 *hp = (u64 *)stage[b]; u32 *hm = (u32 *)(stage[b] + CH * 8);
+                const u32 n_tasks = (u32)std::min<u64>(256, std::max<u64>(1, nw / 16384));
+                up->pool.parallel_for(n_tasks, [=](u32 t) {
+                    const u64 a = w0 + nw * t / n_tasks, z = w0 + nw * (t + 1) / n_tasks;
+                    hp_pack_range(hsrc, boff, woff, n, a, z, hp + (a - w0), hm + (a - w0));
+                });
+                t_pack += DevPool::now_ms() - t1;
+                e = hipMemcpyAsync(d_pack + w0, hp, nw * 8, hipMemcpyHostToDevice, cs);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_nmask + w0, hm, nw * 4, hipMemcpyHostToDevice, cs);
+                if (e == hipSuccess) e = hipEventRecord(sev[b], cs);
+            }
+            if (e == hipSuccess) e = hipEventRecord(ev_ready, cs);
+            if (verbose) fprintf(stderr, "[lrge_hip] host-side pack of %llu words: job %.2f ms on the uploader thread (packing %.2f ms, waiting for a chunk buffer %.2f ms)\n",
+                                 (unsigned long long)n_words, DevPool::now_ms() - t_job, t_pack, t_wait);
+            job->finish(e == hipSuccess ? LRGE_OK : LRGE_ERR_DEVICE, e == hipSuccess ? std::string() : std::string("host-side pack / upload: ") + hipGetErrorString(e));
+        };
+        // a pinned source stays valid until the set is consumed (the contract of the async form): the job runs in the
+        // background.  A pageable source may change as soon as this call returns, and the blocking form waits anyway.
+        if (async && kind == 1) up->submit(work);
+        else { up->submit(work); std::string em; const int jrc = job->wait(&em); s->job.reset(); if (jrc) { ctx->err = em; return jrc; } }
+    } else if (kind == 1) {
         HIPCHK(ctx, hipMemcpyAsync(s->stg_ascii, src, s->total_bases, hipMemcpyHostToDevice, cs));
     } else if (kind == 2 && s->total_bases) {
         if (!ctx->stage[0]) {
@@ -412,7 +490,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
             HIPCHK(ctx, hipEventRecord(ctx->stage_ev[b], cs));
         }
     }
-    if (w) {
+    if (w && !host_pack) {
         // (timed only in the blocking form: a pending event pair would make the next call's timer resolution wait for
         // this upload on the host)
         std::unique_ptr<StageTimer> t(async ? nullptr : new StageTimer(ctx, LRGE_T_PACK, cs));
@@ -420,7 +498,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
                            (const u32 *)s->stg_blk, n, w, s->d_pack, s->d_nmask);
         KCHK(ctx);
     }
-    HIPCHK(ctx, hipEventRecord(s->ev_ready, cs));
+    if (!host_pack) HIPCHK(ctx, hipEventRecord(s->ev_ready, cs));      // (a host-side pack records it at the end of its job)
     // async: the per-read arrays travel from the set's own host copies (they live as long as the set); only `bases`
     // must stay valid, and only when it is pinned host memory (a pageable source has been copied out by now)
     if (!async) { HIPCHK(ctx, hipStreamSynchronize(cs)); ctx->resolve_timers(); }
@@ -442,6 +520,7 @@ extern "C" int lrge_hip_seqset_wait(lrge_hip_seqset *s) {
     if (!s) return LRGE_ERR_INVALID;
     lrge_hip_ctx *ctx = s->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    { int jrc = seqset_job_wait(ctx, s); if (jrc) return jrc; }
     if (s->pending) HIPCHK(ctx, hipEventSynchronize(s->ev_ready));
     return LRGE_OK;
 }
@@ -466,6 +545,7 @@ extern "C" void lrge_hip_seqset_free(lrge_hip_seqset *s) {
     if (s->pooled) {
         if (ctx_alive) {       // (a destroyed context has already freed its pool)
             lrge_hip_ctx *ctx = s->ctx;
+            if (s->job) { (void)s->job->wait(nullptr); s->job.reset(); }
             if (s->pending) (void)hipStreamSynchronize(ctx->copy_stream);          // an upload nobody consumed
             DevPool &P = ctx->pool;
             if (s->meta_arena && --ctx->meta_inflight == 0) ctx->meta_used = 0;
@@ -646,6 +726,7 @@ static int presketch_start_pending(lrge_hip_ctx *ctx, u64 indexed_bases) {
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
     // an upload of the set still in flight: only the side stream waits for it -- the main stream goes on with the index
     // (its own seqset_ready comes with the overlap call, which also returns the staging blocks to the pool)
+    if (s->job && seqset_job_wait(ctx, s) != LRGE_OK) { ctx->event_pool.push_back(p->ev_start); ctx->event_pool.push_back(p->ev_done); delete p->sc; delete p; return LRGE_OK; }
     if (e == hipSuccess && s->pending) e = hipStreamWaitEvent(ctx->stream2, s->ev_ready, 0);
     if (e == hipSuccess) e = hipEventRecord(p->ev_start, ctx->stream2);
     if (e == hipSuccess) {

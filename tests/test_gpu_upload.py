@@ -43,7 +43,12 @@ class _DevBuf:
         self.hip.hipFree(self.ptr)
 
 
-def test_every_source_gives_the_same_minimizers(ctx, oracle):
+@pytest.mark.parametrize("host_pack", [True, False], ids=["host-pack", "device-pack"])
+def test_every_source_gives_the_same_minimizers(ctx, oracle, knobs, host_pack):
+    """host_pack: sets that start in host memory are packed by the uploader thread's workers (AVX2 / scalar words) and travel
+    packed (default); NO_HOST_PACK sends the ASCII and packs on the device (k_pack), as device-resident sources always do."""
+    if not host_pack:
+        knobs.set("NO_HOST_PACK", "1")
     seqs = _reads()
     bases, offs = to_arrays(seqs)
     ref = ctx.upload(bases, offs)                         # pageable, blocking
@@ -83,6 +88,17 @@ def test_large_pageable_upload_is_staged_in_chunks(ctx):
     B = ctx.upload(pinned, offs)
     xa, ya = A.sketch(0); xb, yb = B.sketch(0)
     assert len(xa) > 0.3 * n * L / 1.0 * 0.9 and np.array_equal(xa, xb) and np.array_equal(ya, yb)
+    # the same set through the other pack (ASCII over PCIe, k_pack on the device) and in small host-pack chunks, two in flight
+    ctx.set_option("NO_HOST_PACK", "1")
+    C = ctx.upload(bases, offs); D = ctx.upload(pinned, offs, None, wait=False)
+    ctx.set_option("NO_HOST_PACK", None)
+    ctx.set_option("HOST_PACK_CHUNK_WORDS", str(1 << 17))
+    E = ctx.upload(pinned, offs, None, wait=False); F = ctx.upload(pinned, offs, None, wait=False)
+    ctx.set_option("HOST_PACK_CHUNK_WORDS", None)
+    for S in (C, D, E, F):
+        x, y = S.sketch(0)
+        assert np.array_equal(x, xa) and np.array_equal(y, ya)
+        S.free()
     A.free(); B.free(); pinned.free()
 
 

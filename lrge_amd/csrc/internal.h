@@ -242,6 +242,7 @@ struct PreSketch {
 struct lrge_hip_seqset {
     lrge_hip_ctx *ctx;
     PreSketch *presk = nullptr;
+    u64 uid = 0, parent_uid = 0; // identity of the set (of a view's parent) for the life of the process: addresses are recycled
     bool is_view = false;       // reads [r0, r1) of another set: shares its device arrays, owns only d_cs
     const lrge_hip_seqset *parent = nullptr;   // (of a view)
     u32 n = 0;
@@ -296,6 +297,7 @@ struct lrge_hip_index {
     // behave exactly like one index; a part's own d_* arrays are used as above, the container's are null.
     lrge_hip_seqset *owned_seqs = nullptr;          // a sharded build's description of the whole target set (freed with the index)
     const lrge_hip_seqset *restrict_set = nullptr;   // lrge_hip_index_build_for: the one set that may be streamed against this index
+    u64 restrict_uid = 0;       // (its identity: a freed set's address may be reused by another one)
     std::vector<lrge_hip_index *> parts;
     std::vector<lrge_hip_seqset *> part_sets;
     std::vector<u32> part_r0;

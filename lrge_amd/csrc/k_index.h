@@ -32,7 +32,16 @@ __host__ __device__ __forceinline__ u32 ht_fix_of(int k) {
     return (u32)(64 - 8 * nb) | (u32)(8 - part) << 8;
 }
 // + the exponent of the distribution correction of the partial byte (0: linear stretch only)
-__host__ __device__ __forceinline__ u32 ht_fix_with_power(int k, u32 pw) { const u32 f = ht_fix_of(k); return f ? f | pw << 16 : 0u; }
+// pw is clamped to what ht_home's arithmetic holds: u^pw must span at least the 8 output bits and fit 56 (bits * pw in
+// [8, 56]); a value outside -- option HT_POWER is the caller's -- would shift by a negative amount or overflow and make the
+// map non-monotone, i.e. an ordered table whose lookups miss present keys
+__host__ __device__ __forceinline__ u32 ht_fix_with_power(int k, u32 pw) {
+    const u32 f = ht_fix_of(k);
+    if (!f) return 0u;
+    const u32 bits = 8 - ((f >> 8) & 0xff);
+    if (pw) { const u32 lo = (8 + bits - 1) / bits, hi = 56 / bits; pw = pw < lo ? lo : pw > hi ? hi : pw; }
+    return f | pw << 16;
+}
 __device__ __forceinline__ u64 ht_home(u64 key, u64 cap, u32 fix) {
     u64 bs = __builtin_bswap64(key);
     const u32 pos = fix & 0xff, tsh = (fix >> 8) & 0xff, pw = fix >> 16;

@@ -28,6 +28,7 @@
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
 static std::mutex g_live_mu;
 static std::set<lrge_hip_ctx *> g_live_ctx;   // contexts that have not been destroyed
+static std::atomic<u64> g_seqset_uid{1};
 
 extern char **environ;
 
@@ -292,7 +293,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
     ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
     std::unique_ptr<lrge_hip_seqset, void (*)(lrge_hip_seqset *)> guard(new lrge_hip_seqset(), lrge_hip_seqset_free);
     lrge_hip_seqset *s = guard.get();
-    s->ctx = ctx; s->n = n; s->pooled = true;
+    s->ctx = ctx; s->n = n; s->pooled = true; s->uid = g_seqset_uid.fetch_add(1);
     // one pass over the offsets: word offsets, lengths, sketch chunk map (read -> first chunk, fixed for the life of the set)
     s->h_woff.resize((size_t)n + 1); s->h_len.resize(n ? n : 1); s->h_cs.resize((size_t)n + 1);
     u64 w = 0, nc = 0;
@@ -472,13 +473,22 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
     } else if (kind == 1) {
         HIPCHK(ctx, hipMemcpyAsync(s->stg_ascii, src, s->total_bases, hipMemcpyHostToDevice, cs));
     } else if (kind == 2 && s->total_bases) {
-        if (!ctx->stage[0]) {
+        if (!ctx->stage_cap) {       // both buffers and both events, or nothing (a half-made pair would fail every later upload)
             const size_t cap = (size_t)64 << 20;
-            for (int b = 0; b < 2; ++b) {
-                HIPCHK(ctx, hipHostMalloc((void **)&ctx->stage[b], cap, hipHostMallocDefault));
-                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_ev[b], hipEventDisableTiming));
-                HIPCHK(ctx, hipEventRecord(ctx->stage_ev[b], cs));
+            char *bufs[2] = {nullptr, nullptr}; hipEvent_t evs[2] = {nullptr, nullptr};
+            hipError_t se = hipSuccess;
+            for (int b = 0; b < 2 && se == hipSuccess; ++b) {
+                se = hipHostMalloc((void **)&bufs[b], cap, hipHostMallocDefault);
+                if (se == hipSuccess) se = hipEventCreateWithFlags(&evs[b], hipEventDisableTiming);
+                if (se == hipSuccess) se = hipEventRecord(evs[b], cs);
             }
+            if (se != hipSuccess) {
+                for (int b = 0; b < 2; ++b) { if (bufs[b]) (void)hipHostFree(bufs[b]); if (evs[b]) (void)hipEventDestroy(evs[b]); }
+                (void)hipGetLastError();
+                LRGE_SET_ERR(ctx, "seqset_upload: pinned staging buffers: %s", hipGetErrorString(se));
+                return LRGE_ERR_DEVICE;
+            }
+            for (int b = 0; b < 2; ++b) { ctx->stage[b] = bufs[b]; ctx->stage_ev[b] = evs[b]; }
             ctx->stage_cap = cap;
         }
         int b = 0;
@@ -501,7 +511,14 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
     if (!host_pack) HIPCHK(ctx, hipEventRecord(s->ev_ready, cs));      // (a host-side pack records it at the end of its job)
     // async: the per-read arrays travel from the set's own host copies (they live as long as the set); only `bases`
     // must stay valid, and only when it is pinned host memory (a pageable source has been copied out by now)
-    if (!async) { HIPCHK(ctx, hipStreamSynchronize(cs)); ctx->resolve_timers(); }
+    if (!async) {
+        HIPCHK(ctx, hipStreamSynchronize(cs));
+        ctx->resolve_timers();
+        // the set is complete: its 1 B/base ASCII staging block goes back now, not when somebody consumes the set
+        s->pending = false;
+        if (s->meta_arena) { s->meta_arena = false; if (--ctx->meta_inflight == 0) ctx->meta_used = 0; }
+        ctx->pool.release(s->stg_ascii); s->stg_ascii = nullptr;
+    }
     if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] upload of %u reads: %.3f ms of host time\n", n,
                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     *out = guard.release();
@@ -1344,7 +1361,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     }
     if (have_global) {      // restricted build: what mm_idx_stat / mm_idx_cal_max_occ report for the whole target set
         ix->mid_occ = g_mid_occ; ix->n_keys = g_distinct; ix->n_mz = g_mz;
-        ix->restrict_set = ro->restrict_to;
+        ix->restrict_set = ro->restrict_to; ix->restrict_uid = ro->restrict_to->uid;
     }
     // the sorted hashes of the (hash, y) pair layout are only read again by index_dump (tests); a part of a partitioned index
     // cannot be dumped and is short of memory, so it gives them back (8 of its 16 bytes per minimizer)
@@ -1367,6 +1384,7 @@ static int seqset_view(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, u32 r0, u32 
     if (rrc) return rrc;
     lrge_hip_seqset *v = new lrge_hip_seqset();
     v->ctx = ctx; v->is_view = true; v->n = r1 - r0; v->parent = s->parent ? s->parent : s;
+    v->uid = g_seqset_uid.fetch_add(1); v->parent_uid = s->parent ? s->parent_uid : s->uid;
     v->has_rank = s->has_rank; v->dup_rank = s->dup_rank;
     v->d_pack = s->d_pack; v->d_nmask = s->d_nmask; v->d_woff = s->d_woff + r0; v->d_len = s->d_len + r0;
     v->d_rank = s->d_rank ? s->d_rank + r0 : nullptr;
@@ -1509,7 +1527,7 @@ static int seqset_describe(lrge_hip_ctx *ctx, const uint32_t *lens, uint32_t n, 
     *out = nullptr;
     std::unique_ptr<lrge_hip_seqset, void (*)(lrge_hip_seqset *)> guard(new lrge_hip_seqset(), lrge_hip_seqset_free);
     lrge_hip_seqset *s = guard.get();
-    s->ctx = ctx; s->n = n; s->pooled = true;
+    s->ctx = ctx; s->n = n; s->pooled = true; s->uid = g_seqset_uid.fetch_add(1);
     s->h_len.assign(lens, lens + n);
     if (s->h_len.empty()) s->h_len.push_back(0);
     for (u32 i = 0; i < n; ++i) {
@@ -2354,7 +2372,7 @@ static int check_common(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_
     if (!ix) { LRGE_SET_ERR(ctx, "No index"); return LRGE_ERR_MAP; }   // aligner.rs:210-212
     if (!q) { LRGE_SET_ERR(ctx, "null read set"); return LRGE_ERR_INVALID; }
     if (ix->ctx != ctx || q->ctx != ctx) { LRGE_SET_ERR(ctx, "index / read set belong to another context"); return LRGE_ERR_INVALID; }
-    if (ix->restrict_set && q != ix->restrict_set && q->parent != ix->restrict_set) {
+    if (ix->restrict_set && q->uid != ix->restrict_uid && q->parent_uid != ix->restrict_uid) {
         LRGE_SET_ERR(ctx, "this index was built for one streamed set (lrge_hip_index_build_for): only that set may be streamed against it");
         return LRGE_ERR_INVALID;
     }
@@ -2508,22 +2526,33 @@ extern "C" int lrge_hip_overlap_ava(lrge_hip_ctx *ctx, const lrge_hip_index *ix,
     OverlapJob job; job.mode = MODE_AVA; job.dual = 0;
     job.prm = p ? *p : lrge_hip_params{0, 0.2f};
     job.counts = counts;
-    if (ix->parts.empty()) return run_overlap(ctx, ix, reads, job);
-    // partitioned index: every part sees all reads as queries; a pair is found in the part that holds its larger-named
-    // read (NO_DUAL), and both of its counts live in the one vector keyed by the whole set
-    if (!(ix->seqs->has_rank && reads->has_rank)) { LRGE_SET_ERR(ctx, "all-vs-all against a partitioned index needs name ranks"); return LRGE_ERR_INVALID; }
-    if (reads->total_bases > stream_limit(ctx)) { LRGE_SET_ERR(ctx, "all-vs-all: read sets above STREAM_BASES bases are not implemented"); return LRGE_ERR_TOO_MANY; }
+    const bool in_views = reads->total_bases > stream_limit(ctx) && reads->n >= 2;
+    if (ix->parts.empty() && !in_views) return run_overlap(ctx, ix, reads, job);
+    // A partitioned index: every part sees all reads as queries; a pair is found in the part that holds its larger-named
+    // read (NO_DUAL), and both of its counts live in the one vector keyed by the whole set.  A read set above STREAM_BASES
+    // bases (ava.rs:165-366 has no such limit) goes through in views like the streamed set of the two-set strategies: a view
+    // is a shard of the reads, and the shards' contributions add up (see the header).
+    if (!(ix->seqs->has_rank && reads->has_rank)) { LRGE_SET_ERR(ctx, "all-vs-all against a partitioned index / over more than STREAM_BASES bases needs name ranks"); return LRGE_ERR_INVALID; }
     const u32 n_all = ix->seqs->n;
     std::vector<u32> c((size_t)n_all + 1);
     if (counts) std::fill(counts, counts + n_all, 0u);
     StageAcc acc;
-    for (size_t pi = 0; pi < ix->parts.size(); ++pi) {
-        OverlapJob j = job;
-        j.counts = c.data(); j.rid_base = ix->part_r0[pi]; j.indexed_top = ix->seqs;
-        rc = run_overlap(ctx, ix->parts[pi], reads, j);
-        acc.add(ctx);
+    const std::vector<u32> cuts = in_views ? stream_cuts(reads) : std::vector<u32>{0, reads->n};
+    const size_t n_parts = ix->parts.empty() ? 1 : ix->parts.size();
+    for (size_t v = 0; v + 1 < cuts.size(); ++v) {
+        lrge_hip_seqset *view = nullptr;
+        if (in_views) { rc = seqset_view(ctx, reads, cuts[v], cuts[v + 1], &view); if (rc) return rc; }
+        for (size_t pi = 0; pi < n_parts; ++pi) {
+            OverlapJob j = job;
+            j.counts = c.data(); j.indexed_top = ix->seqs;
+            if (!ix->parts.empty()) j.rid_base = ix->part_r0[pi];
+            rc = run_overlap(ctx, ix->parts.empty() ? ix : ix->parts[pi], in_views ? view : reads, j);
+            acc.add(ctx);
+            if (rc) break;
+            if (counts) for (u32 i = 0; i < n_all; ++i) counts[i] += c[i];
+        }
+        if (view) lrge_hip_seqset_free(view);
         if (rc) return rc;
-        if (counts) for (u32 i = 0; i < n_all; ++i) counts[i] += c[i];
     }
     acc.store(ctx);
     return LRGE_OK;

@@ -101,6 +101,13 @@ def tiny_hifi():
 
 
 @pytest.fixture(scope="session")
+def tiny_ava():
+    from lrge_amd import synth
+    gsize, reads, _ = synth.make_config("tiny_ava")
+    return reads
+
+
+@pytest.fixture(scope="session")
 def edge_set():
     """A target set = sampled reads + edge-case reads; queries = other sampled reads + the same edge
     reads under different names (so self/diagonal logic is NOT triggered) ."""

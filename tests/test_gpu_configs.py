@@ -183,7 +183,17 @@ def test_c4_sampled_and_properties(ctx, oracle):
     #  * idempotence: the same call again
     c2, h2 = ix.overlap_twoset(Qd)
     assert np.array_equal(c2, counts) and np.array_equal(h2, has)
-    ix.free(); Qd.free(); Td.free(); Sd.free()
+    ix.free()
+    #  * the table's home-slot function never changes a result, whatever exponent option HT_POWER asks for (out-of-range
+    #    values used to shift by a negative amount / overflow, i.e. an ordered table that misses present keys -- they are clamped now)
+    for pw in ("0", "1", "2", "9", "11", "50"):
+        ctx.set_option("HT_POWER", pw)
+        ixp = engine.Index(ctx, Td, 0)
+        ctx.set_option("HT_POWER", None)
+        c_p, h_p = ixp.overlap_twoset(Sd)
+        assert np.array_equal(c_p, counts[lo:hi]) and np.array_equal(h_p, has[lo:hi]), pw
+        ixp.free()
+    Qd.free(); Td.free(); Sd.free()
 
     n = 1024
     ixo = _oracle_index(oracle, t, 0)

@@ -725,6 +725,30 @@ def test_streamed_set_in_views_is_exact(ctx, oracle, tiny_ont, tiny_hifi, preset
     assert np.array_equal(ref_inv[False], einv)
 
 
+def test_all_vs_all_in_views_is_exact(ctx, tiny_ava, knobs):
+    """ava.rs:165-366 has no size limit; here a read set above STREAM_BASES bases goes through lrge_hip_overlap_ava in views
+    (each a shard of the reads: contributions add up), alone and against a partitioned index."""
+    from lrge_amd import engine
+    rb = tiny_ava
+    (ranks,) = engine.name_ranks(rb.names)
+    Rd = ctx.upload(rb.bases, rb.offsets, ranks)
+    ix = engine.Index(ctx, Rd, 0)
+    ref = {F: ix.overlap_ava(remove_internal=F) for F in (False, True)}
+    ix.free()
+    assert int(ref[False].sum()) > 0
+    tb = int(rb.lens().sum())
+    for n_views, part_bases in ((3, None), (7, None), (4, tb // 3 + 1)):
+        knobs.set("STREAM_BASES", str(tb // n_views + 1))
+        if part_bases:
+            knobs.set("PART_BASES", str(part_bases))
+        ixv = engine.Index(ctx, Rd, 0)
+        for F in (False, True):
+            assert np.array_equal(ixv.overlap_ava(remove_internal=F), ref[F]), (n_views, part_bases, F)
+        ixv.free()
+        knobs.unset("PART_BASES")
+    Rd.free()
+
+
 def test_allocator_retry_leaves_no_stale_error(tiny_ont):
     """Under memory pressure the pool's first hipMalloc fails, the cache is trimmed and the retry succeeds -- the failed
     attempt must not surface later as the "last error" of a launch check (it did, at C5: the overlap call of a run whose

@@ -97,6 +97,20 @@ def cpu_baseline(q, t, budget_s, preset):
         (np.concatenate(counts) if counts else np.zeros(0, np.uint32)), ix.mid_occ
 
 
+def committed_traffic(config):
+    """HBM bytes per step of the whole path from the round's committed rocprofv3 --pmc passes (profiles/r03_hbm_traffic.json,
+    made by tools/summarize_profiles.py from the FETCH_SIZE / WRITE_SIZE passes of this same command), next to the algorithmic
+    bytes: the counters cannot be read inside a timed run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")) as f:
+            d = json.load(f)
+        if d.get("config") != config:
+            return None
+        return {k: d[k] for k in ("fetch_GB_per_step", "write_GB_per_step", "algorithmic_GB_per_step", "traffic_over_algorithmic", "source") if k in d}
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
     """The same leg for a job whose target set the host cannot index inside a bench run (H. sapiens-scale: 30 Gbases):
     the oracle indexes 1/F of the target reads (host twin of the generator) and maps query reads against that index
@@ -462,12 +476,17 @@ def main():
                     "frac": ach / HBM_PEAK_GBPS, "traffic": None, "alg_bytes_per_launch": alg, "alg_bytes": bytes_note,
                     "avg_launch_ms": avg_ms, "launches_per_step": launches / K, "ms_per_step": ms_total / K}
 
-        # Candidate kernels, each with HIP event pairs on the stream it runs on during the TIMED steps; `roofline` is the one
-        # with the most time per step.  Algorithmic bytes per launch follow SURVEY.md 8(d)'s per-unit terms:
-        #   k_lookup     16 B per query minimizer (one hash/offset entry per lookup)
-        #   k_chain_lpg  16 B per anchor it chains (8 B key + 8 B value in)
-        # traffic: not measured inside this run (PMC counters need rocprofv3's own passes): null here, the per-launch
-        # HBM bytes of the same command are in profiles/r02_*pmc*.csv.
+        # Candidates, each timed with HIP event pairs on the stream it runs on during the TIMED steps; `roofline` is the one with
+        # the most time per step.  Algorithmic bytes per launch follow SURVEY.md 8(d)'s per-unit terms:
+        #   k_lookup           16 B per query minimizer (one hash/offset entry per lookup)
+        #   k_chain_lpg        16 B per anchor it chains (8 B key + 8 B value in)
+        #   index radix sort   the kernel FAMILY of the index sort (k_rs_hist + scan + k_rs_scatter, all passes, one unit per
+        #                      step): every entry read once and written once -- what any sort must move (8(d) itself counts
+        #                      the ordering of the index as zero algorithmic bytes, so this is the kindest denominator)
+        #   index sketch       L/4 B of packed bases in + one entry out per minimizer (k_sketch_direct + k_sketch_compact)
+        #   k_expand           8 B position-list entry in + 8 B anchor out per anchor
+        # traffic: not measured inside this run (PMC counters need rocprofv3's own passes): null here; the per-launch HBM bytes
+        # of the same command are committed under profiles/ (summary: profiles/README.md).
         cands = []
         if acc_cn.get("lookup_launches", 0):
             cands.append(roof("k_lookup", acc_tm.get("k_lookup", 0.0), acc_cn["lookup_launches"],
@@ -475,6 +494,18 @@ def main():
         if acc_cn.get("lpg_launches", 0):
             cands.append(roof("k_chain_lpg", acc_tm.get("chain_lpg", 0.0), acc_cn["lpg_launches"], 16.0 * acc_cn.get("lpg_anchors", 0),
                               "16 B x anchors chained by the launch (SURVEY 8d: anchor in for chaining)"))
+        n_idx = float(st["n_minimizers"]) if not (world > 1 and not a.inverse) else float(acc_cn.get("rs_scatter_items", 0)) / max(1, K) / 4.0
+        entry_b = 8.0 if (2 * (19 if preset else 15) + int(np.ceil(np.log2((Qn if a.inverse else Tn) + 1))) + int(np.ceil(np.log2(float((q_lens if a.inverse else t_lens).max()) + 1))) + 1) <= 64 else 16.0
+        if acc_tb.get("index_sort", 0.0) > 0 and world == 1:
+            cands.append(roof("index radix sort (k_rs_hist + scan + k_rs_scatter, all passes)", acc_tb["index_sort"], K, 2.0 * entry_b * n_idx * K,
+                              "%d B in + %d B out per index entry: one read and one write of every entry" % (entry_b, entry_b)))
+        if acc_tb.get("sketch", 0.0) > 0 and world == 1:
+            L_idx = float((q_lens if a.inverse else t_lens).sum())
+            cands.append(roof("index sketch (k_sketch_direct + k_sketch_compact)", acc_tb["sketch"], K, (L_idx / 4.0 + entry_b * n_idx) * K,
+                              "L/4 B of packed bases in + %d B per minimizer out" % entry_b))
+        if acc_tm.get("expand", 0.0) > 0:
+            cands.append(roof("k_expand", acc_tm["expand"], max(1, acc_cn.get("batches", K)), 16.0 * acc_cn.get("anchors", 0),
+                              "8 B position-list entry in + 8 B anchor out per anchor"))
         cands.sort(key=lambda r: -r["ms_per_step"])
         r_sc = roof("k_rs_scatter", (tm2.get("rs_scatter", 0.0) + tb2.get("rs_scatter", 0.0)) * K, cn2.get("rs_scatter_launches", 0) * K,
                     float(cn2.get("rs_scatter_bytes", 0)) * K, "bytes each launch has to read + write (32 / pair, 16 / packed key, 24 unpacking)")
@@ -512,7 +543,8 @@ def main():
             "genome_size_abs_error": None if med[1] is None else abs(float(med[1]) - gsize),
             "estimate_q15_q65": [None if med[0] is None else float(med[0]), None if med[2] is None else float(med[2])],
             "mid_occ": st["mid_occ"],
-            "roofline": {**r_dom, "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS},
+            "roofline": {**r_dom, "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS,
+                         "whole_path_traffic": committed_traffic(a.config)},
             "roofline_other": cands[1:] + [r_sc],
             "stage_ms_per_step": {**{"index_" + k: v / K for k, v in acc_tb.items() if v and k != "total"},
                                   **{k: v / K for k, v in acc_tm.items() if v}},

@@ -17,6 +17,12 @@
 #define HT_EMPTY (~0ULL)
 #define HT_CNT_BITS 24
 #define HT_CNT_MAX ((1u << HT_CNT_BITS) - 1)
+// A key that occurs ONCE -- most keys of a noisy read set: 242 M entries over ~190 M distinct keys at C4 -- carries its one
+// position in the slot itself: value = HT_INLINE | y (y = rid << 32 | pos << 1 | strand < 2^63).  The expansion then never
+// touches pos[] for it; before, every such key cost one random 64-byte sector for 8 useful bytes (minimap2 itself keeps
+// singletons inside its khash: mm2:index.c mm_idx_get).  Every other key: value = start << 24 | min(count, 2^24 - 1).
+#define HT_INLINE (1ULL << 63)
+__device__ __forceinline__ u32 ht_count(u64 v) { return (v & HT_INLINE) ? 1u : (u32)(v & HT_CNT_MAX); }
 
 // Home slot = position of the key in the byte-reversed order, scaled to [0, cap).  A hash of B = 2k bits fills its top byte only
 // partly (k = 15: 6 of 8 bits; k = 19 likewise), and byte-reversed that byte sits in the MIDDLE of the 64-bit value: left as it
@@ -126,7 +132,9 @@ __global__ __launch_bounds__(1024) void k_place_scan(u32 *data, u32 n) {
 __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
                                                                u32 n_runs, u64 n, u64 cap, u64 n_slots, const u32 *__restrict__ bpre,
                                                                u64 *__restrict__ ht, u32 *__restrict__ occ_hist, u32 max_bin,
-                                                               u32 *__restrict__ overflow, u32 kshift, u32 fix, u32 *__restrict__ last_slot) {
+                                                               u32 *__restrict__ overflow, u32 kshift, u32 fix, u32 *__restrict__ last_slot,
+                                                               const u64 *__restrict__ ypos, u32 pk_pos1, u32 inline_single) {
+    // ypos: the y values of the (hash, y) pair layout (null: packed entries, y is decoded from the entry itself)
     // last_slot != null: the table has NOT been cleared.  The runs of a wavefront occupy increasing slots, and the slot of the
     // run in front of the wavefront's first one is known from the same max-scan: every wavefront owns the contiguous slot
     // range (slot of the run before its first, slot of its last], composes it in LDS -- empty slots and entries -- and writes
@@ -170,6 +178,12 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
         const u64 slot = in ? (u64)m - (n_runs - r) : 0;
         if (in) disp_sum += (u32)(slot - (u64)(d - (n_runs - r)));      // slot - home
         ulonglong2 e; e.x = key; e.y = (u64)st << HT_CNT_BITS | (cnt < HT_CNT_MAX ? cnt : HT_CNT_MAX);
+        if (in && cnt == 1 && inline_single) {
+            u64 y;
+            if (ypos) y = ypos[st];
+            else { const u64 yb = skey[st] & ((1ULL << kshift) - 1); y = (yb >> pk_pos1) << 32 | (yb & ((1ULL << pk_pos1) - 1)); }
+            e.y = HT_INLINE | y;
+        }
         if (in && slot + 1 >= n_slots) *overflow = 1u;      // the last slot must stay empty
         if (!last_slot) {
             if (in && slot + 1 < n_slots) *(ulonglong2 *)(ht + 2 * slot) = e;
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(256) void k_fill_tail(u64 *__restrict__ ht, u64 n_s
 // predecessor, so a probe can stop at the first entry that is not smaller in that order -- an absent key (most query
 // minimizers of noisy reads) costs no more than a present one instead of a walk to the next empty slot.  An empty slot
 // (all ones) compares as the largest key.
-__device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u32 fix, u64 key, u64 *start, u32 *cnt) {
+__device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u32 fix, u64 key, u64 *value) {
     u64 slot = ht_home(key, cap, fix);
     const u64 bk = __builtin_bswap64(key);
     for (;; ++slot) {
@@ -241,7 +255,7 @@ __device__ __forceinline__ bool ht_lookup(const u64 *__restrict__ ht, u64 cap, u
 #endif
         if (__builtin_bswap64(e.x) >= bk) {
             if (e.x != key) return false;
-            *start = e.y >> HT_CNT_BITS; *cnt = (u32)(e.y & HT_CNT_MAX);
+            *value = e.y;
             return true;
         }
     }
@@ -271,12 +285,12 @@ __global__ __launch_bounds__(256) void k_part_global_occ(const u64 *__restrict__
         if (slot < n_slots) {
             const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
             if (e.x != HT_EMPTY) {
-                u64 sum = e.y & HT_CNT_MAX;
+                u64 sum = ht_count(e.y);
                 first = true;
                 for (int o = 0; o < T.n; ++o) {
                     if (o == self) continue;
-                    u64 st; u32 c;
-                    if (ht_lookup(T.ht[o], T.cap[o], T.fix, e.x, &st, &c)) { sum += c; if (o < self) first = false; }
+                    u64 v;
+                    if (ht_lookup(T.ht[o], T.cap[o], T.fix, e.x, &v)) { sum += ht_count(v); if (o < self) first = false; }
                 }
                 total = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sum;
             }
@@ -300,13 +314,14 @@ __global__ __launch_bounds__(256) void k_part_drop(u64 *__restrict__ ht, u64 n_s
     if (slot >= n_slots) return;
     const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
     if (e.x == HT_EMPTY) return;
-    const u32 local = (u32)(e.y & HT_CNT_MAX);
+    const u32 local = ht_count(e.y);
     if (local > mid_occ) return;
     u64 sum = local;
     for (int o = 0; o < T.n && sum <= mid_occ; ++o) {
         if (o == self) continue;
-        u64 st; u32 c;
-        if (ht_lookup(T.ht[o], T.cap[o], T.fix, e.x, &st, &c)) sum += c;
+        u64 v;
+        if (ht_lookup(T.ht[o], T.cap[o], T.fix, e.x, &v)) sum += ht_count(v);
     }
-    if (sum > mid_occ) ht[2 * slot + 1] = (e.y & ~(u64)HT_CNT_MAX) | (u64)(mid_occ + 1);
+    // (an inline singleton becomes an ordinary entry whose list is never expanded)
+    if (sum > mid_occ) ht[2 * slot + 1] = ((e.y & HT_INLINE) ? 0ULL : (e.y & ~(u64)HT_CNT_MAX)) | (u64)(mid_occ + 1);
 }

@@ -32,19 +32,28 @@ __device__ __forceinline__ u64 index_y(const SeedParams &sp, u64 i) {
     return (yb >> sp.pk_pos1) << 32 | (yb & ((1ULL << sp.pk_pos1) - 1));
 }
 
+// hit j of a list that lives at `st` (k_lookup): the inline position of a singleton, or entry st + j of pos[]
+__device__ __forceinline__ u64 list_y(const SeedParams &sp, u64 st, u32 j) {
+    return (st & HT_INLINE) ? (st & ~HT_INLINE) : index_y(sp, st + j);
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int l) {
+    return (u64)(u32)__shfl((i32)(u32)v, l, 64) | (u64)(u32)__shfl((i32)(u32)(v >> 32), l, 64) << 32;
+}
+
 // K3: one lane per query minimizer: probe the index.  hs = list start, hc = raw list length (0 when
 // the hash is absent).  The mid_occ filter and skip_seed are applied by k_seed_counts, after the query
 // occurrence filter had its say.
 // hn (may be null): the kept list length k_seed_counts would derive from hc -- written here when no name checks are needed
 // (two-set runs without shared reads), so that the common path, in which mm_seed_mz_flt removes nothing, needs no second
 // pass over the 10^8 counters.
+// hs: where the list lives -- its start in pos[], or HT_INLINE | y for a key that occurs once (k_index.h)
 __global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, u64 n_mz, SeedParams sp,
-                                                u32 *__restrict__ hs, u32 *__restrict__ hc, u32 *__restrict__ hn) {
+                                                u64 *__restrict__ hs, u32 *__restrict__ hc, u32 *__restrict__ hn) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_mz) return;
-    u64 st = 0; u32 cnt = 0;
-    if (!ht_lookup(sp.ht, sp.ht_cap, sp.ht_fix, qx[i] >> 8, &st, &cnt)) { st = 0; cnt = 0; }
-    hs[i] = (u32)st; hc[i] = cnt;
+    u64 v = 0; u64 st = 0; u32 cnt = 0;
+    if (ht_lookup(sp.ht, sp.ht_cap, sp.ht_fix, qx[i] >> 8, &v)) { cnt = ht_count(v); st = (v & HT_INLINE) ? v : v >> HT_CNT_BITS; }
+    hs[i] = st; hc[i] = cnt;
     if (hn) hn[i] = (cnt != 0 && (i64)cnt <= (i64)sp.mid_occ) ? cnt : 0;   // m[i].n > max_occ -> flt (as in k_seed_counts)
 }
 
@@ -54,7 +63,7 @@ __global__ __launch_bounds__(256) void k_lookup(const u64 *__restrict__ qx, u64 
 // k_expand: the position-list reads are consecutive across the wave and every lane does useful work (one lane per
 // minimizer looping over its own list diverged on the list lengths and gathered 8 bytes per lane per step).
 __global__ __launch_bounds__(256) void k_seed_counts(const u64 *__restrict__ qy, u64 n_mz, SeedParams sp,
-                                                     const u32 *__restrict__ hs, const u32 *__restrict__ hc,
+                                                     const u64 *__restrict__ hs, const u32 *__restrict__ hc,
                                                      u32 *__restrict__ hn, u32 *__restrict__ hv) {
     __shared__ u32 kept[4][64];
     const u32 lane = lane_id(), w = threadIdx.x >> 6;
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(256) void k_seed_counts(const u64 *__restrict__ qy,
     const u32 incl = wave_incl_scan_u32(n);
     const u32 total = (u32)__builtin_amdgcn_readlane((i32)incl, 63);
     const u32 rs = incl - n;
-    u32 m_st = 0, m_qpos = 0, m_ql = 0, m_qr = 0;
+    u32 m_qpos = 0, m_ql = 0, m_qr = 0; u64 m_st = 0;
     if (n) {
         const u64 y = qy[i];
         const u32 q = (u32)(y >> 32);
@@ -88,10 +97,10 @@ __global__ __launch_bounds__(256) void k_seed_counts(const u64 *__restrict__ qy,
             l = v <= r ? l + step : l;
         }
         const u32 j = r - (u32)__shfl((i32)rs, (int)l, 64);
-        const u32 st = (u32)__shfl((i32)m_st, (int)l, 64), qpos = (u32)__shfl((i32)m_qpos, (int)l, 64);
+        const u64 st = shfl_u64(m_st, (int)l); const u32 qpos = (u32)__shfl((i32)m_qpos, (int)l, 64);
         const u32 ql = (u32)__shfl((i32)m_ql, (int)l, 64), qr = (u32)__shfl((i32)m_qr, (int)l, 64);
         if (r < total) {
-            const u64 h = index_y(sp, (u64)st + j);
+            const u64 h = list_y(sp, st, j);
             const u32 rid = (u32)(h >> 32);
             const u32 tr = sp.t_rank[rid];
             bool skip = false;
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256) void k_query_anchor_totals(const u32 *__restri
 // both the reads of the position lists and the (key, val) writes are consecutive across the wave.
 // Output order = minimizer order, then list order, exactly as collect_seed_hits emits them.
 __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 mz_begin,
-                                                u64 mz_end, SeedParams sp, const u32 *__restrict__ hs,
+                                                u64 mz_end, SeedParams sp, const u64 *__restrict__ hs,
                                                 const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
                                                 const u32 *__restrict__ krank, const u32 *__restrict__ qmz_off, u32 q0,
                                                 KeyLayout kl, u64 *__restrict__ akey, u64 *__restrict__ aval, u32 packed_bits_qy) {
@@ -149,13 +158,13 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
     // (this kernel is bound by the length of its chain of dependent loads, not by bytes)
     const u32 n = in ? hn[i] : 0;
     const u64 x = in ? qx[i] : 0, y = in ? qy[i] : 0;
-    const u32 st_i = in ? hs[i] : 0;
+    const u64 st_i = in ? hs[i] : 0;
     const u32 incl = wave_incl_scan_u32(n);
     const u32 total = (u32)__builtin_amdgcn_readlane((i32)incl, 63);
     if (total == 0) return;
     const u32 rs = incl - n;                                     // first raw index of my minimizer
     // per-minimizer fields, fetched by the lanes that expand its hits
-    u32 m_st = 0, m_q = 0, m_qpos = 0, m_flags = 0, m_ql = 0, m_qr = 0, m_rank = 0;
+    u64 m_st = 0; u32 m_q = 0, m_qpos = 0, m_flags = 0, m_ql = 0, m_qr = 0, m_rank = 0;
     if (n) {
         m_q = (u32)(y >> 32); m_qpos = (u32)y >> 1;
         m_flags = ((u32)y & 1) | ((u32)x & 0xff) << 8;          // strand | span << 8
@@ -176,14 +185,14 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
             l = v <= r ? l + step : l;
         }
         const u32 j = r - (u32)__shfl((i32)rs, (int)l, 64);
-        const u32 st = (u32)__shfl((i32)m_st, (int)l, 64), q = (u32)__shfl((i32)m_q, (int)l, 64);
+        const u64 st = shfl_u64(m_st, (int)l); const u32 q = (u32)__shfl((i32)m_q, (int)l, 64);
         const u32 qpos = (u32)__shfl((i32)m_qpos, (int)l, 64), fl = (u32)__shfl((i32)m_flags, (int)l, 64);
         const u32 ql = (u32)__shfl((i32)m_ql, (int)l, 64), qr = (u32)__shfl((i32)m_qr, (int)l, 64);
         const u32 rk = (u32)__shfl((i32)m_rank, (int)l, 64);
         bool keep = r < total;
         u64 key = 0, val = 0;
         if (keep) {
-            const u64 h = index_y(sp, (u64)st + j);
+            const u64 h = list_y(sp, st, j);
             const u32 rid = (u32)(h >> 32), rpos = (u32)h >> 1, qstrand = fl & 1, span = fl >> 8;
             u64 self = 0;
             if (sp.check_names) {

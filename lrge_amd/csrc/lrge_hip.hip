@@ -1311,7 +1311,8 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_apply, dim3(std::min<u32>(n_tiles, (u32)ctx->n_cu * 8)), dim3(PLACE_THREADS), 0, ctx->stream,
                                    skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1, pk_ybits, ht_fix,
-                                   fused_fill ? bmax + n_tiles : (u32 *)nullptr);
+                                   fused_fill ? bmax + n_tiles : (u32 *)nullptr, pk ? (const u64 *)nullptr : (const u64 *)spos, pk ? pk_pos1 : 0u,
+                                   ctx->opt("NO_INLINE_SINGLETONS") ? 0u : 1u);
                 KCHK(ctx);
                 if (fused_fill) {
                     hipLaunchKernelGGL(k_fill_tail, dim3((u32)std::min<u64>(div_up(n_slots - cap / 2, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, ht, n_slots, bmax + n_tiles);
@@ -1715,7 +1716,8 @@ struct OverlapRun {
     // seeds: query minimizers, their index lookups, per-query anchor totals
     SketchOut so; std::vector<u32> h_mzoff, h_qtot; u64 Mq = 0; SeedParams sp;
     std::unique_ptr<Scratch> presk_sc;   // memory of a consumed presketch (released with the run)
-    u32 *hs = nullptr, *hc = nullptr, *hn = nullptr, *hv = nullptr, *krank = nullptr, *aoff_all = nullptr;
+    u64 *hs = nullptr;                   // where every seed's list lives: start in pos[], or HT_INLINE | y (k_index.h)
+    u32 *hc = nullptr, *hn = nullptr, *hv = nullptr, *krank = nullptr, *aoff_all = nullptr;
     // batch plan
     u64 batch_cap = 0; KeyLayout kl; u32 max_bits_q = 0, min_n = 0; ChainParams cp;
     std::vector<SegTile> h_tiles;   // per batch; lives until the batch's next host sync (the async H2D copy reads it)
@@ -1822,7 +1824,7 @@ int OverlapRun::seeds() {
     // without name checks every kept hit survives skip_seed: hv IS hn, and k_lookup fills it (k_seed_counts only runs again
     // if the exact query occurrence filter had to change hc)
     const bool counts_in_lookup = !sp.check_names && !ctx->opt("COUNTS_AFTER_LOOKUP");   // (option: the separate pass, for A/B runs)
-    hs = sc.get<u32>(Mq + 1); hc = sc.get<u32>(Mq + 1); hn = sc.get<u32>(Mq + 1); hv = counts_in_lookup ? hn : sc.get<u32>(Mq + 1); krank = sc.get<u32>(Mq + 1);
+    hs = sc.get<u64>(Mq + 1); hc = sc.get<u32>(Mq + 1); hn = sc.get<u32>(Mq + 1); hv = counts_in_lookup ? hn : sc.get<u32>(Mq + 1); krank = sc.get<u32>(Mq + 1);
     u32 *d_qtot = sc.get<u32>((size_t)nq + 1);
     aoff_all = sc.get<u32>(Mq + 1);
     if (!hs || !hc || !hn || !hv || !krank || !d_qtot || !aoff_all) return LRGE_ERR_DEVICE;

@@ -75,5 +75,15 @@ out = {
     "valu_issue_note": "measured (tools/micro/valu_rate.hip): a SIMD issues a wave64 v_add / v_fma / v_cndmask every 2.4-2.7 cycles, v_cmp / v_max / DPP every 4.3; one wavefront issues a dependent instruction every ~9 cycles",
     "kernels": per,
 }
+# whole path: every kernel's raw counters summed over the pass, per step (the pass runs `steps_in_pass` steps: the timed one and
+# the instrumented one that follows it), next to the algorithmic bytes of SURVEY.md 8(d) the bench line reports
+steps_in_pass = 2
+tot_f = sum(v["FETCH_SIZE"][1] for v in fetch.values() if "FETCH_SIZE" in v) * 1024 / steps_in_pass
+tot_w = sum(v["WRITE_SIZE"][1] for v in write.values() if "WRITE_SIZE" in v) * 1024 / steps_in_pass
+alg = bench.get("roofline", {}).get("whole_path_alg_GBps", 0.0) * bench.get("ms_per_step", 0.0) * 1e-3
+cfg_name = (bench.get("config", {}).get("workload") or "").split(":")[0]
+out.update({"config": cfg_name, "fetch_GB_per_step": tot_f / 1e9, "write_GB_per_step": tot_w / 1e9, "algorithmic_GB_per_step": alg,
+            "traffic_over_algorithmic": {"raw_counters": (tot_f + tot_w) / 1e9 / alg if alg else None,
+                                         "reads_x2_correction": (2 * tot_f + tot_w) / 1e9 / alg if alg else None}})
 json.dump(out, open(os.path.join(P, rnd + "_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v["hbm_bytes_per_launch_corrected"] for k, v in per.items()}, indent=1))

@@ -717,3 +717,269 @@ __global__ __launch_bounds__(THREADS) void k_seg_sort_local(const u64 *__restric
         out_v[sd.start + pp] = ((pk >> (up.sb + up.bits_qy + 8)) & 1) << 43 | ((pk >> (up.sb + up.bits_qy)) & 0xff) << 32 | ((pk >> up.sb) & qmask);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Index sort, hybrid form (round 3).  The LSD sort of the index entries moved every 8-byte entry four times (k = 15:
+// 30 hash bits in 8-bit digits), each pass reading the keys twice (histogram, scatter): 96 bytes per entry, 7 ms of the
+// 32 ms headline step for an ordering SURVEY 8(d) counts as zero algorithmic bytes.  Here the two MOST significant digits
+// go first -- one plain global pass, one pass segmented by the first digit's 256 buckets (the machinery of the anchor
+// sort: SegTile) -- which leaves 65 536 sub-buckets of a few thousand entries, each contiguous and each small enough for
+// a workgroup's LDS: the remaining digits are sorted there in one kernel, 8 bytes in, 8 bytes out (k_seg_sort_keys, the
+// keys-only sibling of k_seg_sort_local).  64 bytes per entry instead of 96.  Every pass is a stable counting sort by
+// one digit, so the result is the order the LSD passes produce: by (d0, d1, ..., d_last), equal keys in arrival order.
+// Sub-buckets above the LDS capacity (repeat-rich data: one hash a hundred thousand times) take segmented global passes.
+// ------------------------------------------------------------------------------------------
+struct LocalPasses { int n; int shift[4]; int bits[4]; };      // LSD order: pass 0 = least significant of the remaining digits
+
+template <int THREADS, int ITEMS, int DB>
+__global__ __launch_bounds__(THREADS) void k_seg_sort_keys(const u64 *__restrict__ in, u64 *__restrict__ out, const SegDesc *__restrict__ segs,
+                                                           LocalPasses lp) {
+    constexpr int WAVES = THREADS / 64, CAP = THREADS * ITEMS, NDIG = 1 << DB;
+    static_assert(THREADS >= NDIG, "one thread per digit in the scan step");
+    typedef typename std::conditional<(DB > 8), u16, u32>::type CT;
+    extern __shared__ u64 lsort_mem[];
+    u64 *stage = lsort_mem;                                   // [CAP]
+    u32 *wtot = (u32 *)(lsort_mem + CAP);                     // [NDIG / 64]
+    CT *cnt = (CT *)(wtot + 16);                              // [WAVES][NDIG]
+    const SegDesc sd = segs[blockIdx.x];
+    const u32 n = sd.len;
+    const u64 *src = in + sd.start;
+    const u32 w = threadIdx.x >> 6, lane = lane_id();
+    const u32 l0 = w * (ITEMS * 64) + lane;
+    u64 k[ITEMS];
+    // rows of 64 items; a row that lies wholly behind the segment's end is skipped in every phase (wavefront-uniform test):
+    // a block's work follows the segment's length, not the class capacity.  The padding of the last partial row has every
+    // digit all ones, sorts last, and lands behind the n real entries.
+    const u32 w_base = w * (ITEMS * 64);
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n ? src[l0 + (u32)r * 64] : ~0ULL;
+    for (int p = 0; p < lp.n; ++p) {
+        const int shift = lp.shift[p], nbp = lp.bits[p];
+        const u32 dmask = (1u << nbp) - 1u;
+        for (u32 i = threadIdx.x; i < (u32)WAVES * NDIG; i += THREADS) cnt[i] = 0;
+        __syncthreads();
+        u32 rank[ITEMS];
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            if (w_base + (u32)r * 64 >= n) { rank[r] = 0; continue; }
+            const u32 d = (u32)(k[r] >> shift) & dmask;
+            u32 a_lo = 0, a_hi = 0;
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+                if (b < nbp) wave_match_bit(d, b, a_lo, a_hi);   // (wavefront-uniform)
+            const u32 m_lo = ~a_lo, m_hi = ~a_hi;
+            const u32 before = wave_match_before(m_lo, m_hi);
+            const u32 old = cnt[w * NDIG + d];                  // see k_rs_scatter
+            if (before == 0) cnt[w * NDIG + d] = (CT)(old + wave_match_total(m_lo, m_hi));
+            rank[r] = old + before;
+        }
+        __syncthreads();
+        u32 tot = 0, inc = 0;
+        if (threadIdx.x < NDIG) {
+            for (int ww = 0; ww < WAVES; ++ww) tot += cnt[ww * NDIG + threadIdx.x];
+            inc = wave_incl_scan_u32(tot);
+            if (lane == 63) wtot[threadIdx.x >> 6] = inc;
+        }
+        __syncthreads();
+        if (threadIdx.x < NDIG) {
+            u32 run = inc - tot;
+            for (u32 g = 0; g < (threadIdx.x >> 6); ++g) run += wtot[g];
+            for (int ww = 0; ww < WAVES; ++ww) { const u32 c = cnt[ww * NDIG + threadIdx.x]; cnt[ww * NDIG + threadIdx.x] = (CT)run; run += c; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            if (w_base + (u32)r * 64 >= n) continue;
+            const u32 d = (u32)(k[r] >> shift) & dmask;
+            stage[cnt[w * NDIG + d] + rank[r]] = k[r];
+        }
+        __syncthreads();
+        if (p + 1 < lp.n) {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) if (w_base + (u32)r * 64 < n) k[r] = stage[l0 + (u32)r * 64];
+            __syncthreads();
+        }
+    }
+    for (u32 pp = threadIdx.x; pp < n; pp += THREADS) out[sd.start + pp] = stage[pp];
+}
+
+// start of every (segment, digit) sub-bucket after a segmented pass: the scanned histogram entry of the segment's first tile
+__global__ void k_subbucket_starts(const u32 *__restrict__ hist_scanned, const u32 *__restrict__ seg_tile_base, const u32 *__restrict__ seg_n_tiles,
+                                   u32 n_segs, u32 *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;          // seg * 256 + digit
+    if (i >= n_segs * 256) return;
+    const u32 s = i >> 8, d = i & 255;
+    // (an empty segment has no tile: its sub-buckets start where the next non-empty segment does; the host fills those in)
+    out[i] = seg_n_tiles[s] ? hist_scanned[256u * seg_tile_base[s] + d * seg_n_tiles[s]] : 0xFFFFFFFFu;
+}
+__global__ void k_gather_strided_u32(const u32 *__restrict__ src, u64 stride, u32 n, u32 *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[(u64)i * stride];
+}
+__global__ void k_copy_segments(const u64 *__restrict__ in, u64 *__restrict__ out, const SegDesc *__restrict__ segs) {
+    const SegDesc sd = segs[blockIdx.x];
+    for (u32 i = threadIdx.x; i < sd.len; i += blockDim.x) out[sd.start + i] = in[sd.start + i];
+}
+
+// Sorts the packed index entries k0[0, n) by the hash bits [begin_bit, begin_bit + nbits) in BYTE-REVERSED digit order (what
+// radix_sort_keys(..., reverse_digits = true) produces).  k1: a second buffer of n + 1 entries; *res = buffer holding the result.
+// *done = false: the input does not suit the hybrid form (too few entries per sub-bucket to be worth it, or too many for LDS
+// on average) and nothing has been touched -- the caller runs the LSD passes.
+static int index_sort_hybrid(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64 n, int begin_bit, int nbits, u64 **res, bool *done) {
+    *done = false; *res = k0;
+    const int passes = (nbits + 7) / 8;
+    if (passes < 3 || passes > 6 || n < ctx->opt_u64("HYBRID_SORT_MIN", 1ULL << 22) || n >= (1ULL << 32) || n / 65536 > 6000 || ctx->opt("NO_HYBRID_SORT")) return LRGE_OK;
+    // MEASURED (tools/micro/sort_bench.hip, 242 M packed entries, 30 hash bits): 4.77 ms against the LSD form's 5.00 ms alone, and
+    // inside the C4 step 7.87 against 7.61 ms (its two host round trips -- bucket and sub-bucket boundaries -- leave the GPU idle
+    // while the query sketch is not there to fill the gap).  The bytes fall from 96 to 64 per entry as planned, but the in-LDS
+    // passes are bound by their ranking arithmetic (~45 wave instructions per row of 64 keys and pass), not by memory, and a global
+    // pass already runs at ~4 TB/s.  So the form is exact, tested (tests/test_gpu_parity.py::test_hybrid_index_sort_is_exact) and
+    // OFF unless option HYBRID_SORT asks for it.
+    if (!ctx->opt("HYBRID_SORT") && !ctx->opt("HYBRID_SORT_MIN")) return LRGE_OK;
+    if (!ctx->lsort_ok[1] || !ctx->lsort_ok[2]) return LRGE_OK;
+    // LDS classes: 256 x 8, 256 x 16 (8-bit digits), 512 x 16, 1024 x 16 (9-bit digits)
+    const u32 cap_lim[4] = {(u32)std::min<u64>(2048, ctx->opt_u64("DEBUG_LSORT_CAP0", 2048)), (u32)std::min<u64>(4096, ctx->opt_u64("DEBUG_LSORT_CAP0", 4096)),
+                            (u32)std::min<u64>(8192, ctx->opt_u64("DEBUG_LSORT_CAP1", 8192)), (u32)std::min<u64>(16384, ctx->opt_u64("DEBUG_LSORT_CAP2", 16384))};
+    // digit d of the reversed order = hash bits [8 d, 8 d + 8) (the last one narrower); d = 0 is the most significant
+    auto dshift = [&](int d) { return begin_bit + 8 * d; };
+    auto dbits = [&](int d) { return nbits - 8 * d >= 8 ? 8 : nbits - 8 * d; };
+    const u32 nb = (u32)div_up(n, RS_TILE);
+    ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * (nb + 256 + 1));
+    // ---- pass A: the most significant digit, over everything ----
+    {
+        UnpackParams up{0, 0, 0, (1u << dbits(0)) - 1u};
+        hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, k0, n, dshift(0), nb, hist, (const SegTile *)nullptr, up.dmask);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr); if (rc) return rc;
+        StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+        hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_KEYS>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, k0, (const u64 *)nullptr, k1, (u64 *)nullptr, n, dshift(0), nb,
+                           hist, (const SegTile *)nullptr, up);
+        KCHK(ctx);
+        ts.stop();
+        ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 16 * n;
+    }
+    std::vector<u32> bstart(257);
+    {
+        ALLOC_OR_FAIL(d_b, sc, u32, 256);
+        hipLaunchKernelGGL(k_gather_strided_u32, dim3(1), dim3(256), 0, ctx->stream, hist, (u64)nb, 256u, d_b);
+        KCHK(ctx);
+        HIPCHK(ctx, ctx->d2h(bstart.data(), d_b, 256 * 4, ctx->stream));
+        HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+        bstart[256] = (u32)n;
+        sc.drop(d_b);
+    }
+    // ---- pass B: the second digit inside every bucket of the first (segmented: a tile never straddles two buckets) ----
+    std::vector<SegTile> tiles; std::vector<u32> seg_tb(256), seg_nt(256);
+    u32 tb = 0;
+    for (u32 s = 0; s < 256; ++s) {
+        const u32 c = bstart[s + 1] - bstart[s], nt = (u32)div_up((u64)c, RS_TILE);
+        seg_tb[s] = tb; seg_nt[s] = nt;
+        for (u32 lt = 0; lt < nt; ++lt) tiles.push_back(SegTile{bstart[s] + lt * RS_TILE, std::min<u32>(RS_TILE, c - lt * RS_TILE), 256u * tb + lt, nt, s, 0u});
+        tb += nt;
+    }
+    const u32 n_tiles = (u32)tiles.size();
+    ALLOC_OR_FAIL(d_tiles, sc, u32, (size_t)n_tiles * (sizeof(SegTile) / 4) + 4);
+    ALLOC_OR_FAIL(d_segmeta, sc, u32, 512);
+    ALLOC_OR_FAIL(d_sub, sc, u32, 65536);
+    std::vector<u32> segmeta(512);
+    for (u32 s = 0; s < 256; ++s) { segmeta[s] = seg_tb[s]; segmeta[256 + s] = seg_nt[s]; }
+    HIPCHK(ctx, hipMemcpyAsync(d_tiles, tiles.data(), (size_t)n_tiles * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_segmeta, segmeta.data(), 512 * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<u32> sub(65536);
+    {
+        UnpackParams up{0, 0, 0, (1u << dbits(1)) - 1u};
+        hipLaunchKernelGGL(k_rs_hist<true>, dim3(n_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, n, dshift(1), n_tiles, hist, (const SegTile *)d_tiles, up.dmask);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * n_tiles, nullptr); if (rc) return rc;
+        hipLaunchKernelGGL(k_subbucket_starts, dim3(256), dim3(256), 0, ctx->stream, hist, d_segmeta, d_segmeta + 256, 256u, d_sub);
+        KCHK(ctx);
+        HIPCHK(ctx, ctx->d2h(sub.data(), d_sub, 65536 * 4, ctx->stream));
+        StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+        hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(n_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, (const u64 *)nullptr, k0, (u64 *)nullptr, n, dshift(1), n_tiles,
+                           hist, (const SegTile *)d_tiles, up);
+        KCHK(ctx);
+        ts.stop();
+        ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 16 * n;
+        HIPCHK(ctx, ctx->d2h_sync(ctx->stream));          // (also: `tiles` / `segmeta` have travelled)
+    }
+    // ---- the remaining digits inside every sub-bucket ----
+    // sub[s * 256 + d] = start of sub-bucket (s, d) (0xFFFFFFFF for an empty first-level bucket): sizes by differences
+    std::vector<SegDesc> cls[4], big;
+    {
+        u32 next = (u32)n;
+        for (int i = 65535; i >= 0; --i) {
+            const u32 s = (u32)i >> 8;
+            u32 st = sub[(size_t)i];
+            if (st == 0xFFFFFFFFu) st = bstart[s];            // (empty bucket: zero-length sub-buckets)
+            const u32 len = next - st;
+            next = st;
+            if (!len) continue;
+            const int c = len <= cap_lim[0] ? 0 : len <= cap_lim[1] ? 1 : len <= cap_lim[2] ? 2 : len <= cap_lim[3] ? 3 : 4;
+            (c < 4 ? cls[c] : big).push_back(SegDesc{st, len, 0, 0});
+        }
+    }
+    if (ctx->opt("VERBOSE"))
+        fprintf(stderr, "[lrge_hip] hybrid index sort: %llu entries, sub-buckets in LDS classes %zu / %zu / %zu / %zu, %zu on global passes\n",
+                (unsigned long long)n, cls[0].size(), cls[1].size(), cls[2].size(), cls[3].size(), big.size());
+    LocalPasses lp; lp.n = 0;
+    for (int d = passes - 1; d >= 2; --d) { lp.shift[lp.n] = dshift(d); lp.bits[lp.n] = dbits(d); ++lp.n; }    // least significant first
+    SegDesc *d_seg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int c = 0; c < 5; ++c) {
+        std::vector<SegDesc> &v = c < 4 ? cls[c] : big;
+        if (v.empty()) continue;
+        d_seg[c] = (SegDesc *)sc.get<u32>(v.size() * 4);
+        if (!d_seg[c]) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemcpyAsync(d_seg[c], v.data(), v.size() * sizeof(SegDesc), hipMemcpyHostToDevice, ctx->stream));
+    }
+    // (input k0, output k1)
+    if (d_seg[3]) { hipLaunchKernelGGL((k_seg_sort_keys<1024, 16, LSORT_DB>), dim3((u32)cls[3].size()), dim3(1024), LSORT_BYTES(1024, 16, LSORT_DB), ctx->stream, k0, k1, d_seg[3], lp); KCHK(ctx); }
+    if (d_seg[2]) { hipLaunchKernelGGL((k_seg_sort_keys<512, 16, LSORT_DB>), dim3((u32)cls[2].size()), dim3(512), LSORT_BYTES(512, 16, LSORT_DB), ctx->stream, k0, k1, d_seg[2], lp); KCHK(ctx); }
+    if (d_seg[1]) { hipLaunchKernelGGL((k_seg_sort_keys<256, 16, 8>), dim3((u32)cls[1].size()), dim3(256), LSORT_BYTES(256, 16, 8), ctx->stream, k0, k1, d_seg[1], lp); KCHK(ctx); }
+    if (d_seg[0]) { hipLaunchKernelGGL((k_seg_sort_keys<256, 8, 8>), dim3((u32)cls[0].size()), dim3(256), LSORT_BYTES(256, 8, 8), ctx->stream, k0, k1, d_seg[0], lp); KCHK(ctx); }
+    std::vector<SegTile> btiles;
+    if (d_seg[4]) {
+        // sub-buckets above a workgroup's LDS: the remaining digits as segmented global passes (k0 <-> k1), then into k1
+        u32 tb2 = 0;
+        for (size_t s = 0; s < big.size(); ++s) {
+            const u32 nt = (u32)div_up((u64)big[s].len, RS_TILE);
+            for (u32 lt = 0; lt < nt; ++lt) btiles.push_back(SegTile{big[s].start + lt * RS_TILE, std::min<u32>(RS_TILE, big[s].len - lt * RS_TILE), 256u * tb2 + lt, nt, (u32)s, 0u});
+            tb2 += nt;
+        }
+        const u32 nbt = (u32)btiles.size();
+        ALLOC_OR_FAIL(d_bt, sc, u32, (size_t)nbt * (sizeof(SegTile) / 4) + 4);
+        ALLOC_OR_FAIL(bh, sc, u32, (u64)256 * nbt);
+        HIPCHK(ctx, hipMemcpyAsync(d_bt, btiles.data(), (size_t)nbt * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
+        // the histogram of a segmented pass counts tiled items only, and the tiles of these few sub-buckets are scattered over
+        // the stream: every tile's destination is its own sub-bucket's start + what the scan says (delta = start of the
+        // sub-bucket minus the tiled items in front of it)
+        {
+            u32 acc = 0;
+            size_t ti = 0;
+            for (size_t s = 0; s < big.size(); ++s) {
+                const u32 nt = (u32)div_up((u64)big[s].len, RS_TILE);
+                for (u32 lt = 0; lt < nt; ++lt) btiles[ti++].delta = big[s].start - acc;
+                acc += big[s].len;
+            }
+            HIPCHK(ctx, hipMemcpyAsync(d_bt, btiles.data(), (size_t)nbt * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
+        }
+        u64 *ki = k0, *ko = k1;
+        for (int p = 0; p < lp.n; ++p) {
+            UnpackParams up{0, 0, 0, (1u << lp.bits[p]) - 1u};
+            hipLaunchKernelGGL(k_rs_hist<true>, dim3(nbt), dim3(RS_THREADS), 0, ctx->stream, ki, n, lp.shift[p], nbt, bh, (const SegTile *)d_bt, up.dmask);
+            KCHK(ctx);
+            int rc = scan_exclusive_u32(ctx, sc, bh, bh, (u64)256 * nbt, nullptr); if (rc) return rc;
+            hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(nbt), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, ko, (u64 *)nullptr, n, lp.shift[p], nbt,
+                               bh, (const SegTile *)d_bt, up);
+            KCHK(ctx);
+            u64 *t = ki; ki = ko; ko = t;
+        }
+        if (ki != k1) { hipLaunchKernelGGL(k_copy_segments, dim3((u32)big.size()), dim3(256), 0, ctx->stream, ki, k1, d_seg[4]); KCHK(ctx); }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));        // (`btiles` is a local)
+        sc.drop(d_bt); sc.drop(bh);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));            // (the descriptor vectors are locals)
+    for (int c = 0; c < 5; ++c) if (d_seg[c]) sc.drop((u32 *)d_seg[c]);
+    sc.drop(hist); sc.drop((u32 *)d_tiles); sc.drop(d_segmeta); sc.drop(d_sub);
+    *res = k1; *done = true;
+    return LRGE_OK;
+}

@@ -136,6 +136,9 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
                                                                (int)LSORT_BYTES(512, 16, LSORT_DB)) == hipSuccess;
     ctx->lsort_ok[2] = ctx->lsort_ok[0] && hipFuncSetAttribute((const void *)k_seg_sort_local<1024, 16, LSORT_DB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                (int)LSORT_BYTES(1024, 16, LSORT_DB)) == hipSuccess;
+    // (the keys-only siblings used by the index sort: same LDS footprints)
+    if (hipFuncSetAttribute((const void *)k_seg_sort_keys<512, 16, LSORT_DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSORT_BYTES(512, 16, LSORT_DB)) != hipSuccess) ctx->lsort_ok[1] = false;
+    if (hipFuncSetAttribute((const void *)k_seg_sort_keys<1024, 16, LSORT_DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSORT_BYTES(1024, 16, LSORT_DB)) != hipSuccess) ctx->lsort_ok[2] = false;
     (void)hipGetLastError();
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));
@@ -1240,8 +1243,11 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         StageTimer t(ctx, LRGE_T_INDEX_SORT);
         ALLOC_OR_FAIL(k1, sc, u64, M + 1);
         if (pk) {
-            u64 *rk;
-            rc = radix_sort_keys(ctx, sc, so.x, k1, M, (int)pk_ybits, 2 * P.k, &rk, /*reverse_digits=*/true, pass_from, -1);   // see k_index.h
+            u64 *rk = so.x;
+            bool hybrid = false;
+            // two most-significant-digit passes, then the rest inside LDS (k_prims.h: index_sort_hybrid) where the entries suit it
+            if (pass_from == 0) { rc = index_sort_hybrid(ctx, sc, so.x, k1, M, (int)pk_ybits, 2 * P.k, &rk, &hybrid); if (rc) return rc; }
+            if (!hybrid) rc = radix_sort_keys(ctx, sc, so.x, k1, M, (int)pk_ybits, 2 * P.k, &rk, /*reverse_digits=*/true, pass_from, -1);   // see k_index.h
             if (rc) return rc;
             skey = rk; spos = rk;
             sc.drop(rk == so.x ? k1 : so.x);

@@ -1,5 +1,7 @@
-// sort_bench.hip -- the index sort (radix_sort_keys of csrc/k_prims.h) alone: correctness against std::stable_sort on a small
-// input, order + permutation checks and timing at index scale.  Development harness, not part of the product or the tests.
+// sort_bench.hip -- the index sort of csrc/k_prims.h alone, in its three forms: the LSD passes (radix_sort_keys), the hybrid form
+// (index_sort_hybrid: two most-significant-digit passes, the rest inside LDS) and the hybrid form with tiny LDS classes (every
+// sub-bucket takes the segmented global passes).  Exact against std::stable_sort on the small inputs, order + permutation
+// checks and timing at index scale.  Development harness, not part of the product or the tests.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/micro/_bin/sort_bench tools/micro/sort_bench.hip && tools/micro/_bin/sort_bench [n]
 #include "../../lrge_amd/csrc/k_prims.h"
 
@@ -48,7 +50,14 @@ int main(int argc, char **argv) {
     ctx.timer_level = 0;
     if (hipStreamCreate(&ctx.stream) != hipSuccess) { fprintf(stderr, "no device\n"); return 2; }
     int rc_all = 0;
+    ctx.lsort_ok[0] = true;
+    ctx.lsort_ok[1] = hipFuncSetAttribute((const void *)k_seg_sort_keys<512, 16, LSORT_DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSORT_BYTES(512, 16, LSORT_DB)) == hipSuccess;
+    ctx.lsort_ok[2] = hipFuncSetAttribute((const void *)k_seg_sort_keys<1024, 16, LSORT_DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSORT_BYTES(1024, 16, LSORT_DB)) == hipSuccess;
+    ctx.opts["HYBRID_SORT_MIN"] = "2"; ctx.opts["VERBOSE"] = "1";
+    for (int form = 0; form < 3; ++form)
     for (u64 n : {(u64)1, (u64)4095, (u64)4096, (u64)4097, (u64)1000003, n_big}) {
+        if (form == 2 && n > 2000000) continue;
+        if (form == 2) { ctx.opts["DEBUG_LSORT_CAP0"] = "3"; ctx.opts["DEBUG_LSORT_CAP1"] = "5"; ctx.opts["DEBUG_LSORT_CAP2"] = "9"; }
         Scratch sc(&ctx);
         u64 *k0 = sc.get<u64>(n), *k1 = sc.get<u64>(n);
         unsigned long long *d_chk = sc.get<unsigned long long>(4);
@@ -65,7 +74,9 @@ int main(int argc, char **argv) {
             if (r) hipLaunchKernelGGL(k_fill, dim3((u32)div_up(n, 256)), dim3(256), 0, ctx.stream, k0, n, ybits, hbits, 12345ULL);
             hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
             (void)hipEventRecord(a, ctx.stream);
-            const int rc = radix_sort_keys(&ctx, sc, k0, k1, n, ybits, hbits, &res, /*reverse_digits=*/true);
+            int rc; bool hyb = false;
+            if (form == 0) rc = radix_sort_keys(&ctx, sc, k0, k1, n, ybits, hbits, &res, /*reverse_digits=*/true);
+            else { rc = index_sort_hybrid(&ctx, sc, k0, k1, n, ybits, hbits, &res, &hyb); if (!rc && !hyb) rc = radix_sort_keys(&ctx, sc, k0, k1, n, ybits, hbits, &res, true); }
             (void)hipEventRecord(b, ctx.stream);
             if (rc || hipStreamSynchronize(ctx.stream) != hipSuccess) { fprintf(stderr, "sort failed: %s / %s\n", ctx.err.c_str(), hipGetErrorString(hipGetLastError())); return 1; }
             float ms = 0; (void)hipEventElapsedTime(&ms, a, b); best = std::min(best, ms);
@@ -80,8 +91,9 @@ int main(int argc, char **argv) {
             std::vector<u64> h_out(n); (void)hipMemcpy(h_out.data(), res, n * 8, hipMemcpyDeviceToHost);
             ok = ok && h_out == h_in;
         }
-        printf("n = %llu: %s  (order violations %llu, checksum %s)  %.3f ms  %.2f G keys/s\n", (unsigned long long)n, ok ? "ok" : "WRONG", h[2],
+        printf("%s n = %llu: %s  (order violations %llu, checksum %s)  %.3f ms  %.2f G keys/s\n", form == 0 ? "LSD   " : form == 1 ? "hybrid" : "hybrid, tiny LDS classes", (unsigned long long)n, ok ? "ok" : "WRONG", h[2],
                h[1] == h[3] ? "equal" : "DIFFERENT", best, n / best * 1e-6);
+        (void)0;
         if (!ok) rc_all = 1;
     }
     ctx.pool.destroy();

@@ -54,6 +54,10 @@ extern "C" {
     fn lrge_hip_index_build_for(ctx: *mut lrge_hip_ctx, targets: *const lrge_hip_seqset, preset: c_int,
                                 streamed: *mut lrge_hip_seqset, comm: *mut lrge_hip_comm,
                                 out: *mut *mut lrge_hip_index) -> c_int;
+    fn lrge_hip_index_build_sharded(ctx: *mut lrge_hip_ctx, all_target_lens: *const u32, all_target_ranks: *const u32,
+                                    n_targets: u32, target_shard: *const lrge_hip_seqset, shard_first: u32, preset: c_int,
+                                    streamed: *mut lrge_hip_seqset, comm: *mut lrge_hip_comm,
+                                    out: *mut *mut lrge_hip_index) -> c_int;
     fn lrge_hip_index_free(ix: *mut lrge_hip_index);
     fn lrge_hip_overlap_twoset(ctx: *mut lrge_hip_ctx, ix: *const lrge_hip_index, queries: *const lrge_hip_seqset,
                                p: *const lrge_hip_params, counts: *mut u32, has_mapping: *mut u32) -> c_int;
@@ -340,8 +344,9 @@ unsafe impl Send for SendPtr {}
 unsafe impl Sync for SendPtr {}
 
 /// Two-set forward over `devices` (strong scaling of the one job, twoset.rs:266-334 sharded by query): every rank owns a
-/// range of the queries end to end, its index is built for that range (`lrge_hip_index_build_for`: one small all-reduce
-/// makes `mid_occ` global, no index data moves), one all-gather returns the estimates in query order.
+/// range of the queries end to end AND a contiguous share of the target reads, which is all it uploads, packs and sketches;
+/// `lrge_hip_index_build_sharded` exchanges key sets, the entries each rank's queries can ask for and the hashes for the
+/// global `mid_occ` (include/lrge_hip.h), one all-gather returns the estimates in query order.
 pub fn twoset_estimates_multi(job: &TwoSetJob, devices: &[i32]) -> crate::Result<(Vec<f32>, u32)> {
     let world = devices.len();
     if world <= 1 { return twoset_estimates(job); }
@@ -350,7 +355,9 @@ pub fn twoset_estimates_multi(job: &TwoSetJob, devices: &[i32]) -> crate::Result
     let q = read_set(job.query_file)?;
     let ranks = name_ranks(&[&t.names, &q.names]);
     let q_lens = q.lens();
+    let t_lens = t.lens();
     let bounds = shard_by_bases(&q_lens, world);
+    let t_bounds = shard_by_bases(&t_lens, world);
     let max_len = (0..world).map(|r| bounds[r + 1] - bounds[r]).max().unwrap_or(0);
     let mut group = ptr::null_mut();
     check!(ptr::null(), lrge_hip_comm_local_group_create(world as c_int, &mut group));
@@ -358,7 +365,7 @@ pub fn twoset_estimates_multi(job: &TwoSetJob, devices: &[i32]) -> crate::Result
     let p = lrge_hip_params { remove_internal: job.remove_internal as i32, max_overhang_ratio: job.max_overhang_ratio };
     let results: Vec<crate::Result<(Vec<f32>, u32)>> = std::thread::scope(|sc| {
         let handles: Vec<_> = (0..world).map(|r| {
-            let (t, q, ranks, bounds, q_lens, group) = (&t, &q, &ranks, &bounds, &q_lens, &group);
+            let (t, q, ranks, bounds, q_lens, group, t_lens, t_bounds) = (&t, &q, &ranks, &bounds, &q_lens, &group, &t_lens, &t_bounds);
             let device = devices[r];
             sc.spawn(move || -> crate::Result<(Vec<f32>, u32)> {
                 let (lo, hi) = (bounds[r], bounds[r + 1]);
@@ -370,9 +377,19 @@ pub fn twoset_estimates_multi(job: &TwoSetJob, devices: &[i32]) -> crate::Result
                     offsets: q.offsets[lo..=hi].iter().map(|o| o - q.offsets[lo]).collect(),
                     names: q.names[lo..hi].to_vec(),
                 };
-                let ts = ctx.upload(t, &ranks[0])?;
+                // this rank's share of the targets (shares in rank order: position lists keep the order of the one index)
+                let (t0, t1) = (t_bounds[r], t_bounds[r + 1]);
+                let tsub = ReadSet {
+                    bases: t.bases[t.offsets[t0] as usize..t.offsets[t1] as usize].to_vec(),
+                    offsets: t.offsets[t0..=t1].iter().map(|o| o - t.offsets[t0]).collect(),
+                    names: t.names[t0..t1].to_vec(),
+                };
+                let ts = ctx.upload(&tsub, &ranks[0][t0..t1])?;
                 let qs = ctx.upload(&sub, &ranks[1][lo..hi])?;
-                let ix = ctx.index_for(&ts, preset, &qs, comm)?;          // collective
+                let mut h = ptr::null_mut();
+                check!(ctx.h, lrge_hip_index_build_sharded(ctx.h, t_lens.as_ptr(), ranks[0].as_ptr(), t_lens.len() as u32, ts.h,
+                                                           t0 as u32, preset, qs.h, comm, &mut h));       // collective
+                let ix = Index { h, _ctx: &ctx };
                 let (counts, has) = ctx.overlap_twoset(&ix, &qs, &p)?;
                 let est = ctx.estimates(&counts, &q_lens[lo..hi], job.avg_target_len, job.target_num_reads as u64, 100)?;
                 let mut send = vec![f32::NAN; max_len.max(1)];

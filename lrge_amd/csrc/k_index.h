@@ -271,7 +271,9 @@ struct PartTables { const u64 *ht[MAX_INDEX_PARTS]; u64 cap[MAX_INDEX_PARTS]; in
 // atomics on the same few dozen bins serialise at L2).
 __global__ __launch_bounds__(256) void k_part_global_occ(const u64 *__restrict__ ht, u64 n_slots, PartTables T, int self,
                                                          u32 *__restrict__ hist, u32 max_bin,
-                                                         unsigned long long *__restrict__ n_distinct) {
+                                                         unsigned long long *__restrict__ n_distinct, u32 *__restrict__ gsum) {
+    // gsum (may be null): the key's occurrence count over all parts, per slot of THIS part -- k_part_drop then needs no
+    // second round of probes (round 3: the two kernels were 272 of 1 848 ms of a full-size C5 step, half of it the re-probing)
     __shared__ u32 lh[OCC_LDS_BINS];
     __shared__ u32 l_first;
     for (u32 i = threadIdx.x; i < OCC_LDS_BINS; i += blockDim.x) lh[i] = 0;
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(256) void k_part_global_occ(const u64 *__restrict__
                 }
                 total = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sum;
             }
+            if (gsum) gsum[slot] = total;
         }
         const u32 hb = total < max_bin ? total : max_bin;
         const u64 mf = __ballot(first);
@@ -306,12 +309,18 @@ __global__ __launch_bounds__(256) void k_part_global_occ(const u64 *__restrict__
 }
 
 // A key whose GLOBAL count exceeds mid_occ must be dropped in every part: lift its local count above the threshold, which
-// is all k_lookup's consumers test (a dropped list is never expanded, so its true length is not needed any more).  The
-// sum over the parts is taken again here rather than kept from k_part_global_occ: 4 bytes per slot of every part would
-// have to stay resident between the two kernels, and memory is what a partitioned index is short of.
-__global__ __launch_bounds__(256) void k_part_drop(u64 *__restrict__ ht, u64 n_slots, PartTables T, int self, u32 mid_occ) {
+// is all k_lookup's consumers test (a dropped list is never expanded, so its true length is not needed any more).
+// gsum: the global counts k_part_global_occ left per slot (null: memory was short -- the sum over the parts is taken again)
+__global__ __launch_bounds__(256) void k_part_drop(u64 *__restrict__ ht, u64 n_slots, PartTables T, int self, u32 mid_occ, const u32 *__restrict__ gsum) {
     const u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
+    if (gsum) {
+        if (gsum[slot] <= mid_occ) return;                // (0 for an empty slot)
+        const u64 v = ht[2 * slot + 1];
+        if (ht_count(v) > mid_occ) return;
+        ht[2 * slot + 1] = ((v & HT_INLINE) ? 0ULL : (v & ~(u64)HT_CNT_MAX)) | (u64)(mid_occ + 1);
+        return;
+    }
     const ulonglong2 e = *(const ulonglong2 *)(ht + 2 * slot);
     if (e.x == HT_EMPTY) return;
     const u32 local = ht_count(e.y);

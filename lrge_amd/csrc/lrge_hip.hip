@@ -1472,10 +1472,19 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     HIPCHK(ctx, hipMemsetAsync(d_nd, 0, 8, ctx->stream));
     PartTables T; T.n = np; T.fix = top->parts[0]->ht_fix;
     for (int p = 0; p < np; ++p) { T.ht[p] = top->parts[p]->d_ht; T.cap[p] = top->parts[p]->ht_cap; }
+    // every slot's global count stays resident between the two sweeps (4 bytes per slot) unless memory is short
+    std::vector<u32 *> gsum((size_t)np, nullptr);
+    if (!ctx->opt("PART_NO_GSUM")) {
+        for (int p = 0; p < np; ++p) {
+            gsum[(size_t)p] = sc.get<u32>(top->parts[p]->ht_slots);
+            if (!gsum[(size_t)p]) { (void)hipGetLastError(); for (int q = 0; q < p; ++q) { sc.drop(gsum[(size_t)q]); gsum[(size_t)q] = nullptr; } ctx->err.clear(); break; }
+        }
+    }
+    const bool have_gsum = np > 0 && gsum[(size_t)np - 1] != nullptr;
     for (int p = 0; p < np; ++p) {
         const u64 ns = top->parts[p]->ht_slots;
         hipLaunchKernelGGL(k_part_global_occ, dim3((u32)std::min<u64>(div_up(ns, 256), (u64)ctx->n_cu * 16)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, T, p,
-                           d_hist, max_bin, d_nd);
+                           d_hist, max_bin, d_nd, have_gsum ? gsum[(size_t)p] : (u32 *)nullptr);
         KCHK(ctx);
     }
     std::vector<u32> occ((size_t)max_bin + 1);
@@ -1499,7 +1508,8 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     }
     for (int p = 0; p < np; ++p) {
         const u64 ns = top->parts[p]->ht_slots;
-        hipLaunchKernelGGL(k_part_drop, dim3((u32)div_up(ns, 256)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, T, p, (u32)top->mid_occ);
+        hipLaunchKernelGGL(k_part_drop, dim3((u32)div_up(ns, 256)), dim3(256), 0, ctx->stream, top->parts[p]->d_ht, ns, T, p, (u32)top->mid_occ,
+                           have_gsum ? (const u32 *)gsum[(size_t)p] : (const u32 *)nullptr);
         KCHK(ctx);
         top->parts[p]->mid_occ = top->mid_occ;
     }

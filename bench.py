@@ -213,7 +213,7 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device):
     if ss:
         eb = ss[0]["entry_bytes"]
         ring = (N - 1) * ss[0]["keyset_bytes"] / (XGMI_LINK_GBPS * 1e9) * 1e3
-        a2a = max((x["entries_recv"] * eb + x["hashes_recv"] * 8) / max(N - 1, 1) for x in ss) / (XGMI_LINK_GBPS * 1e9) * 1e3
+        a2a = max((x["entries_recv"] * eb + x["hashes_recv"] * x.get("hash_bytes", 8)) / max(N - 1, 1) for x in ss) / (XGMI_LINK_GBPS * 1e9) * 1e3
         link_ms = {"keyset_allgather_ring_ms": ring, "alltoall_ms": a2a, "per_link_GBps": XGMI_LINK_GBPS,
                    "note": "model: D2D copies stand in for the links inside busy_ms (those run at HBM speed); this is what the links add at best-case even spreading"}
     print(json.dumps({"emulate_world": N, "NOT_A_BENCH_RESULT": "all ranks on one GPU, taking turns; a projection input", "config": a.config,
@@ -223,7 +223,7 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device):
                       "link_model": link_ms, "all_ranks_equal_one_gpu": all(r_["results_equal_one_gpu"] for r_ in res),
                       "exchange_bytes_total": None if not ss else {"keysets": N * (N - 1) * ss[0]["keyset_bytes"],
                                                                    "entries": sum(x["entries_sent"] for x in ss) * ss[0]["entry_bytes"],
-                                                                   "hashes": sum(x["hashes_sent"] for x in ss) * 8},
+                                                                   "hashes": sum(x["hashes_sent"] * x.get("hash_bytes", 8) for x in ss)},
                       "ranks": res}))
 
 

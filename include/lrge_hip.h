@@ -180,7 +180,8 @@ int  lrge_hip_index_build_sharded(lrge_hip_ctx *ctx, const uint32_t *all_target_
                                   uint32_t n_targets, const lrge_hip_seqset *target_shard, uint32_t shard_first, int preset,
                                   lrge_hip_seqset *streamed, lrge_hip_comm *comm, lrge_hip_index **out);
 /* Exchange volumes of the last lrge_hip_index_build_sharded on this context: {key-set bytes contributed, entries sketched here,
-   entries sent to other ranks, entries received from other ranks, hashes sent, hashes received, bytes per entry, entries kept}. */
+   entries sent to other ranks, entries received from other ranks, hashes sent, hashes received, bytes per entry | bytes per hash << 8
+   (4 when the hash has at most 32 bits: k = 15), entries kept}. */
 int  lrge_hip_last_shard_stats(const lrge_hip_ctx *ctx, uint64_t out[8]);
 void lrge_hip_index_free(lrge_hip_index *ix);
 int  lrge_hip_index_stats(const lrge_hip_index *ix, uint64_t *n_minimizers, uint64_t *n_keys,

@@ -152,6 +152,13 @@ struct Uploader {
 // completion of one upload job (the set's side of it)
 struct UploadJob {
     std::mutex mu; std::condition_variable cv; bool done = false; int rc = 0; std::string err;
+    // chunk gates: chunk j of the packed image -- words [.., gate_w1[j]) -- is on its way once gate_ev[j] has been RECORDED on the
+    // copy stream (gates_recorded > j); a consumer that waits for that event on the device may work on those words while
+    // the later chunks are still being packed (the index sketch does: lrge_hip.hip, sketch_launch)
+    std::vector<hipEvent_t> gate_ev; std::vector<u64> gate_w1; int gates_recorded = 0;
+    void gate_recorded() { { std::lock_guard<std::mutex> lk(mu); ++gates_recorded; } cv.notify_all(); }
+    // true when gate j has been recorded; false when the job ended (failed) before it
+    bool wait_gate(int j) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return gates_recorded > j || done; }); return gates_recorded > j; }
     void finish(int r, const std::string &e) { { std::lock_guard<std::mutex> lk(mu); done = true; rc = r; err = e; } cv.notify_all(); }
     int wait(std::string *e) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); if (rc && e) *e = err; return rc; }
 };

@@ -151,7 +151,9 @@ struct RouteBases { u64 keep[ROUTE_MAX_WORLD]; u64 own[ROUTE_MAX_WORLD]; };   //
 
 // order-preserving scatter of the entries into the send buffers (grouped by destination)
 __global__ __launch_bounds__(RF_THREADS) void k_route_write(RouteArgs A, const u32 *__restrict__ flags, const u32 *__restrict__ off, RouteBases B,
-                                                            u64 *__restrict__ out_x, u64 *__restrict__ out_y, u64 *__restrict__ out_hash) {
+                                                            u64 *__restrict__ out_x, u64 *__restrict__ out_y, u64 *__restrict__ out_hash,
+                                                            u32 *__restrict__ out_hash32) {
+    // out_hash32 != null: the hash has at most 32 bits (k <= 16) and travels as 4 bytes (out_hash unused)
     __shared__ u32 cw[RF_ITEMS][RF_THREADS / 64];
     const u32 W = A.ks.world;
     const u64 tile_base = (u64)blockIdx.x * RF_TILE;
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_route_write(RouteArgs A, const u
             if (p[r]) {
                 const u64 d = o + before + pos[r];
                 if (s < W) { out_x[d] = xs[r]; if (out_y) out_y[d] = A.y[tile_base + (u64)r * RF_THREADS + threadIdx.x]; }
+                else if (out_hash32) out_hash32[d] = (u32)(xs[r] >> A.kshift);
                 else out_hash[d] = xs[r] >> A.kshift;
             }
             o += total;

@@ -253,6 +253,8 @@ static int seqset_job_wait(lrge_hip_ctx *ctx, lrge_hip_seqset *s) {
     if (!s->job) return LRGE_OK;
     std::string e;
     const int rc = s->job->wait(&e);
+    for (hipEvent_t g : s->job->gate_ev) ctx->event_pool.push_back(g);
+    s->job->gate_ev.clear();
     s->job.reset();
     if (rc) { ctx->err = e; return rc; }
     return LRGE_OK;
@@ -434,6 +436,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
         { const u64 o0 = offsets[0]; for (u32 i = 0; i <= n; ++i) s->h_boff[i] = offsets[i] - o0; }
         auto job = std::make_shared<UploadJob>();
         s->job = job;
+        for (u64 w0 = 0; w0 < w; w0 += CH) { job->gate_ev.push_back(ctx->get_event()); job->gate_w1.push_back(std::min<u64>(w, w0 + CH)); }
         hipEvent_t ev_ready = s->ev_ready;
         const int device = ctx->device;
         const u64 n_words = w;
@@ -463,6 +466,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
                 e = hipMemcpyAsync(d_pack + w0, hp, nw * 8, hipMemcpyHostToDevice, cs);
                 if (e == hipSuccess) e = hipMemcpyAsync(d_nmask + w0, hm, nw * 4, hipMemcpyHostToDevice, cs);
                 if (e == hipSuccess) e = hipEventRecord(sev[b], cs);
+                if (e == hipSuccess) { e = hipEventRecord(job->gate_ev[(size_t)(w0 / CH)], cs); if (e == hipSuccess) job->gate_recorded(); }
             }
             if (e == hipSuccess) e = hipEventRecord(ev_ready, cs);
             if (verbose) fprintf(stderr, "[lrge_hip] host-side pack of %llu words: job %.2f ms on the uploader thread (packing %.2f ms, waiting for a chunk buffer %.2f ms)\n",
@@ -472,7 +476,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
         // a pinned source stays valid until the set is consumed (the contract of the async form): the job runs in the
         // background.  A pageable source may change as soon as this call returns, and the blocking form waits anyway.
         if (async && kind == 1) up->submit(work);
-        else { up->submit(work); std::string em; const int jrc = job->wait(&em); s->job.reset(); if (jrc) { ctx->err = em; return jrc; } }
+        else { up->submit(work); const int jrc = seqset_job_wait(ctx, s); if (jrc) return jrc; }
     } else if (kind == 1) {
         HIPCHK(ctx, hipMemcpyAsync(s->stg_ascii, src, s->total_bases, hipMemcpyHostToDevice, cs));
     } else if (kind == 2 && s->total_bases) {
@@ -565,7 +569,7 @@ extern "C" void lrge_hip_seqset_free(lrge_hip_seqset *s) {
     if (s->pooled) {
         if (ctx_alive) {       // (a destroyed context has already freed its pool)
             lrge_hip_ctx *ctx = s->ctx;
-            if (s->job) { (void)s->job->wait(nullptr); s->job.reset(); }
+            if (s->job) (void)seqset_job_wait(ctx, s);
             if (s->pending) (void)hipStreamSynchronize(ctx->copy_stream);          // an upload nobody consumed
             DevPool &P = ctx->pool;
             if (s->meta_arena && --ctx->meta_inflight == 0) ctx->meta_used = 0;
@@ -591,7 +595,8 @@ struct SketchOut {
 // pk_ybits != 0 (index only): packed 8-byte entries in o->x, o->y stays null (k_sketch.h PK)
 template <int K, int W, bool HPC>
 static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o, u32 pk_pos1, u32 pk_ybits,
-                         std::vector<u32> *h_mzoff) {
+                         std::vector<u32> *h_mzoff, bool gated = false) {
+    // gated: the caller has NOT waited for the set's upload (seqset_ready): this function does, as late as it can
     if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
     u32 n_chunks = (u32)s->n_chunks;
     const u32 *d_cs = s->d_cs;           // chunk map, uploaded with the set
@@ -619,7 +624,44 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     for (int pass = 0; pass < 2; ++pass) {       // second round only after a slot overflow
         HIPCHK(ctx, hipMemsetAsync(d_total, 0, 8, ctx->stream));
         if (n_chunks) {
-            if (one_pass) {
+            if (one_pass && gated && pass == 0) {
+                // the set's upload is still in flight (host-side pack, chunk after chunk): the sketch chunks that lie wholly inside
+                // the words of upload chunk j run behind gate j, while the later chunks are still being packed and sent
+                lrge_hip_seqset *ms = const_cast<lrge_hip_seqset *>(s);
+                std::shared_ptr<UploadJob> job = ms->job;
+                u32 c_prev = 0;
+                const size_t ng = job->gate_w1.size();
+                for (size_t j = 0; j < ng; ++j) {
+                    if (!job->wait_gate((int)j)) break;                          // (the job failed: seqset_ready below reports it)
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, job->gate_ev[j], 0));
+                    const u64 w1 = job->gate_w1[j];
+                    u32 c_end = n_chunks;
+                    if (w1 < s->n_words) {
+                        const u32 r = (u32)(std::upper_bound(s->h_woff.begin(), s->h_woff.end(), w1) - s->h_woff.begin()) - 1;
+                        const u64 avail = w1 - s->h_woff[r];                      // words of read r that have arrived: 4 per 128-base chunk
+                        c_end = s->h_cs[r] + (u32)std::min<u64>(avail / (SK_CHUNK / 32), (u64)(s->h_cs[r + 1] - s->h_cs[r]));
+                    }
+                    if (c_end > c_prev) {
+                        const dim3 g((u32)div_up(c_end - c_prev, SK_THREADS));
+                        if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
+                                                   s->d_woff, s->d_len, cm, c_end, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap, c_prev);
+                        else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
+                                                s->d_nmask, s->d_woff, s->d_len, cm, c_end, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap, c_prev);
+                        KCHK(ctx);
+                        c_prev = c_end;
+                    }
+                }
+                int rr = seqset_ready(ctx, s); if (rr) return rr;
+                if (c_prev < n_chunks) {                                          // (whatever a failed / odd gate sequence left)
+                    const dim3 g((u32)div_up(n_chunks - c_prev, SK_THREADS));
+                    if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
+                                               s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap, c_prev);
+                    else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
+                                            s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap, c_prev);
+                    KCHK(ctx);
+                }
+            } else if (one_pass) {
+                if (gated && pass == 0) { int rr = seqset_ready(ctx, s); if (rr) return rr; }
                 if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
                                            s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap);
                 else if (index_keys) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
@@ -627,6 +669,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                 else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, false, false>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
                                         s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap);
             } else {
+                if (gated && pass == 0) { int rr = seqset_ready(ctx, s); if (rr) return rr; }
                 hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm,
                                    n_chunks, d_cnt);
             }
@@ -678,11 +721,16 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
 
 static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o,
                          u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr) {
-    int rc = seqset_ready(ctx, s);
+    // A set whose host-side pack is still running on the uploader thread (chunk gates: host_pack.h) is sketched chunk by chunk
+    // behind its transfer -- index sketches of the non-HPC preset only (an HPC step may read a homopolymer run past its chunk,
+    // i.e. words that have not arrived; a streamed set's upload hides behind the index build anyway).  option NO_GATED_SKETCH: wait first.
+    const bool gated = index_keys && preset != LRGE_PRESET_AVA_PB && s->pending && s->job && !s->job->gate_ev.empty() && s->n_words != 0 &&
+                       !s->is_view && !ctx->opt("NO_GATED_SKETCH") && s->n_chunks != 0 && s->n_chunks < (1ULL << 32);
+    int rc = gated ? LRGE_OK : seqset_ready(ctx, s);
     if (rc) return rc;
     StageTimer t(ctx, LRGE_T_SKETCH);
-    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff)
-                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff);
+    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, false)
+                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated);
     t.stop();
     return rc;
 }
@@ -998,14 +1046,17 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
     g_shard_stats.hashes_sent = n_os - mine[(size_t)W + me]; g_shard_stats.hashes_recv = n_or - mine[(size_t)W + me];
     // ---- (5) local: send buffers grouped by destination (order-preserving), receive buffers ----
     u64 *sx = nullptr, *sy = nullptr, *sh = nullptr, *rx = nullptr, *ry = nullptr, *rh = nullptr;
+    u32 *sh32 = nullptr, *rh32 = nullptr;
+    const bool narrow = 2 * P.k <= 32 && !ctx->opt("SHARD_WIDE_HASHES");     // k = 15: the hashes of the second exchange travel as 4 bytes
     auto local3 = [&]() -> int {
         if (n_kr >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32 minimizers (this rank would hold %llu)", (unsigned long long)n_kr); return LRGE_ERR_TOO_MANY; }
-        sx = sc.get<u64>(n_ks + 1); sh = sc.get<u64>(n_os + 1); rx = sc.get<u64>(n_kr + 1); rh = sc.get<u64>(n_or + 1);
+        sx = sc.get<u64>(n_ks + 1); rx = sc.get<u64>(n_kr + 1); rh = sc.get<u64>(n_or + 1);
+        if (narrow) { sh32 = sc.get<u32>(n_os + 1); rh32 = sc.get<u32>(n_or + 1); } else sh = sc.get<u64>(n_os + 1);
         if (!pk) { sy = sc.get<u64>(n_ks + 1); ry = sc.get<u64>(n_kr + 1); }
-        if (!sx || !sh || !rx || !rh || (!pk && (!sy || !ry))) return LRGE_ERR_DEVICE;
+        if (!sx || !rx || !rh || (narrow ? (!sh32 || !rh32) : !sh) || (!pk && (!sy || !ry))) return LRGE_ERR_DEVICE;
         RouteBases B;
         for (int d = 0; d < ROUTE_MAX_WORLD; ++d) { B.keep[d] = d < W ? ks_off[(size_t)d] : 0; B.own[d] = d < W ? os_off[(size_t)d] : 0; }
-        if (Mr) { hipLaunchKernelGGL(k_route_write, dim3(A.n_tiles), dim3(RF_THREADS), 0, st, A, flags, cnt, B, sx, sy, sh); KCHK(ctx); }
+        if (Mr) { hipLaunchKernelGGL(k_route_write, dim3(A.n_tiles), dim3(RF_THREADS), 0, st, A, flags, cnt, B, sx, sy, sh, sh32); KCHK(ctx); }
         return LRGE_OK;
     };
     rc = local3();
@@ -1015,16 +1066,19 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
     // ---- (6) the exchanges ----
     rc = comm_alltoallv(c, sx, ks_off.data(), rx, kr_off.data(), 8, st); if (rc) return rc;
     if (!pk) { rc = comm_alltoallv(c, sy, ks_off.data(), ry, kr_off.data(), 8, st); if (rc) return rc; }
-    rc = comm_alltoallv(c, sh, os_off.data(), rh, or_off.data(), 8, st); if (rc) return rc;
+    if (narrow) {
+        rc = comm_alltoallv(c, sh32, os_off.data(), rh32, or_off.data(), 4, st); if (rc) return rc;
+        if (n_or) { hipLaunchKernelGGL(k_u32_to_u64, dim3((u32)div_up(n_or, 256)), dim3(256), 0, st, rh32, n_or, rh); KCHK(ctx); }
+    } else { rc = comm_alltoallv(c, sh, os_off.data(), rh, or_off.data(), 8, st); if (rc) return rc; }
     HIPCHK(ctx, hipStreamSynchronize(st));        // (the offset vectors are locals; the local transport has synchronised already)
     mark("all-to-alls");
     sc.drop(raw.x); if (raw.y) sc.drop(raw.y);
-    sc.drop(flags); sc.drop(cnt); sc.drop(d_tot); sc.drop(sx); sc.drop(sh); if (sy) sc.drop(sy);
+    sc.drop(flags); sc.drop(cnt); sc.drop(d_tot); sc.drop(sx); if (sh) sc.drop(sh); if (sh32) sc.drop(sh32); if (rh32) sc.drop(rh32); if (sy) sc.drop(sy);
     sc.drop(ks.bits); sc.drop(gathered); sc.drop(inter); sc.drop(d_sz);
     so->x = rx; so->y = ry; so->mz_off = nullptr; so->n = n_kr;
     *own_hashes = rh; *n_own = n_or;
     const u64 ss[8] = {g_shard_stats.keyset_bytes, g_shard_stats.entries_sketched, g_shard_stats.entries_sent, g_shard_stats.entries_recv,
-                       g_shard_stats.hashes_sent, g_shard_stats.hashes_recv, (u64)(pk ? 8 : 16), n_kr};
+                       g_shard_stats.hashes_sent, g_shard_stats.hashes_recv, (u64)(pk ? 8 : 16) | (u64)(narrow ? 4 : 8) << 8, n_kr};
     memcpy(ctx->shard_stats, ss, sizeof ss);
     return LRGE_OK;
 }

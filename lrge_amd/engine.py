@@ -206,6 +206,8 @@ class Index:
             ctx._lib.lrge_hip_last_shard_stats(ctx.h, C.byref(a))
             self.shard_stats = dict(zip(["keyset_bytes", "entries_sketched", "entries_sent", "entries_recv", "hashes_sent", "hashes_recv",
                                          "entry_bytes", "entries_kept"], [int(x) for x in a]))
+            self.shard_stats["hash_bytes"] = self.shard_stats["entry_bytes"] >> 8 or 8
+            self.shard_stats["entry_bytes"] &= 0xFF
             return
         # streamed / comm: an index built for ONE streamed set, occurrence statistics still over all targets; with a
         # communicator every rank passes its own range of the streamed reads (lrge_hip_index_build_for)

@@ -78,20 +78,33 @@ __device__ __forceinline__ u64 ht_home(u64 key, u64 cap, u32 fix) {
 #define PLACE_TILE (PLACE_THREADS * PLACE_ROWS)
 #define PLACE_COMP 384      // slots a wavefront composes in LDS (64 runs at load 1/2 span ~128)
 
+// The hash of entry `st` of the sorted stream.  seg_start != null: a segment-packed index (k_prims.h: index_sort_segpacked) --
+// the entry holds the hash without its low byte, which is the number of the segment the entry lies in.
+__device__ __forceinline__ u64 entry_hash(const u64 *__restrict__ skey, u32 st, u32 kshift, const u32 *__restrict__ seg_start) {
+    const u64 h = skey[st] >> kshift;
+    if (!seg_start) return h;
+    u32 lo = 0, hi = 256;                              // last segment whose start is <= st (empty segments share their start with the next)
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (seg_start[mid] <= st) lo = mid; else hi = mid; }
+    while (lo + 1 < 256 && seg_start[lo + 1] <= st) ++lo;
+    return h << 8 | lo;
+}
+
 // d(r) = home(r) + (n_runs - r): slot(r) = prefix-max(d)(r) - (n_runs - r).  Needs cap + n_runs < 2^32.
-__device__ __forceinline__ u32 place_d(const u64 *__restrict__ skey, const u32 *__restrict__ run_start, u32 r, u32 n_runs, u64 cap, u32 kshift, u32 fix) {
-    return (u32)ht_home(skey[run_start[r]] >> kshift, cap, fix) + (n_runs - r);
+__device__ __forceinline__ u32 place_d(const u64 *__restrict__ skey, const u32 *__restrict__ run_start, u32 r, u32 n_runs, u64 cap, u32 kshift, u32 fix,
+                                       const u32 *__restrict__ seg_start) {
+    return (u32)ht_home(entry_hash(skey, run_start[r], kshift, seg_start), cap, fix) + (n_runs - r);
 }
 
 __global__ __launch_bounds__(PLACE_THREADS) void k_place_reduce(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
-                                                                u32 n_runs, u64 cap, u32 *__restrict__ bmax, u32 kshift, u32 fix) {
+                                                                u32 n_runs, u64 cap, u32 *__restrict__ bmax, u32 kshift, u32 fix,
+                                                                const u32 *__restrict__ seg_start) {
     __shared__ u32 wm[PLACE_THREADS / 64];
     u32 m = 0;
     const u32 base = blockIdx.x * PLACE_TILE;
 #pragma unroll
     for (int i = 0; i < PLACE_ROWS; ++i) {
         const u32 r = base + i * PLACE_THREADS + threadIdx.x;
-        if (r < n_runs) { const u32 d = place_d(skey, run_start, r, n_runs, cap, kshift, fix); m = d > m ? d : m; }
+        if (r < n_runs) { const u32 d = place_d(skey, run_start, r, n_runs, cap, kshift, fix, seg_start); m = d > m ? d : m; }
     }
     for (int d = 32; d > 0; d >>= 1) { const u32 o = (u32)__shfl_xor((i32)m, d, 64); m = o > m ? o : m; }
     if (lane_id() == 0) wm[threadIdx.x >> 6] = m;
@@ -133,7 +146,8 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
                                                                u32 n_runs, u64 n, u64 cap, u64 n_slots, const u32 *__restrict__ bpre,
                                                                u64 *__restrict__ ht, u32 *__restrict__ occ_hist, u32 max_bin,
                                                                u32 *__restrict__ overflow, u32 kshift, u32 fix, u32 *__restrict__ last_slot,
-                                                               const u64 *__restrict__ ypos, u32 pk_pos1, u32 inline_single) {
+                                                               const u64 *__restrict__ ypos, u32 pk_pos1, u32 inline_single,
+                                                               const u32 *__restrict__ seg_start) {
     // ypos: the y values of the (hash, y) pair layout (null: packed entries, y is decoded from the entry itself)
     // last_slot != null: the table has NOT been cleared.  The runs of a wavefront occupy increasing slots, and the slot of the
     // run in front of the wavefront's first one is known from the same max-scan: every wavefront owns the contiguous slot
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
             st = run_start[r];
             const u64 en = (r + 1 < n_runs) ? run_start[r + 1] : n;
             cnt = (u32)(en - st);
-            key = skey[st] >> kshift;
+            key = entry_hash(skey, st, kshift, seg_start);
             d = (u32)ht_home(key, cap, fix) + (n_runs - r);
         }
         u32 inc = d;

@@ -257,6 +257,7 @@ struct UnpackParams { u32 sb, bits_qy, sh_q, dmask; };   // dmask: digit mask of
 #define RS_MODE_PAIRS 0
 #define RS_MODE_KEYS 1
 #define RS_MODE_UNPACK 2
+#define RS_MODE_PACK 3      // (hash, y) pairs in, ONE packed u64 out: (hash >> 8) << up.sb | rid << up.bits_qy | (pos << 1 | strand); `shift` addresses the packed value
 
 // Blocks are observed to be dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Tile t and
 // tile t + 1 of a pass write adjacent runs in every digit's region, so they should meet in ONE L2: XCD x takes the
@@ -318,9 +319,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     // all loads of the tile are issued up front: the values arrive while the keys are being ranked
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n_tile ? keys_in[base + (u64)r * 64] : ~0ULL;
-    if (MODE == RS_MODE_PAIRS) {
+    if (MODE == RS_MODE_PAIRS || MODE == RS_MODE_PACK) {
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) v[r] = l0 + (u32)r * 64 < n_tile ? vals_in[base + (u64)r * 64] : 0;
+    }
+    if (MODE == RS_MODE_PACK) {
+        // the low hash byte is implied by the segment the tile lies in (index_sort_segpacked): what is left of the hash and
+        // the position fit one word, and every later pass moves 8 bytes per entry instead of 16
+        const u64 pmask = (1ULL << up.bits_qy) - 1;
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r)
+            if (l0 + (u32)r * 64 < n_tile) k[r] = (k[r] >> 8) << up.sb | (v[r] >> 32) << up.bits_qy | (v[r] & pmask);
     }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         u32 p = (u32)r * RS_THREADS + threadIdx.x;
         if (p < n_tile) { ko[r] = stage[p]; keys_out[gbase[(u32)(ko[r] >> shift) & dmask] + p] = ko[r]; }
     }
-    if (MODE == RS_MODE_KEYS) return;
+    if (MODE == RS_MODE_KEYS || MODE == RS_MODE_PACK) return;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
@@ -523,6 +532,21 @@ static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64
 #define HC_ITEMS 16
 #define HC_TILE (HC_THREADS * HC_ITEMS)
 
+// seg_start (may be null; n_seg + 1 ascending entries): positions that start a run whatever the keys say -- the entries of a
+// segment-packed index (index_sort_segpacked) carry their hash without its low byte, so two neighbours on either side of a
+// segment boundary may look alike
+__device__ __forceinline__ u32 hc_boundary_flags(const u32 *__restrict__ seg_start, u32 n_seg, u64 n, u64 base) {
+    u32 lo = 0, hi = n_seg + 1;                      // first boundary >= base
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((u64)seg_start[mid] < base) lo = mid + 1; else hi = mid; }
+    u32 f = 0;
+    for (; lo <= n_seg; ++lo) {
+        const u64 b = seg_start[lo];
+        if (b >= base + 16 || b >= n) break;
+        f |= 1u << (u32)(b - base);
+    }
+    return f;
+}
+
 __device__ __forceinline__ u32 hc_load_flags(const u64 *__restrict__ keys, u64 n, u32 shift, u64 base) {
     // bit t set: element base + t starts a run
     u32 f = 0;
@@ -551,10 +575,11 @@ __device__ __forceinline__ u32 hc_load_flags(const u64 *__restrict__ keys, u64 n
 
 // flags: the 16 head bits of every thread's line, kept for k_heads_fill (2 bytes instead of re-reading 128 bytes of keys)
 __global__ __launch_bounds__(HC_THREADS) void k_heads_count(const u64 *__restrict__ keys, u64 n, u32 shift, u32 *__restrict__ bcount,
-                                                            u16 *__restrict__ flags) {
+                                                            u16 *__restrict__ flags, const u32 *__restrict__ seg_start = nullptr, u32 n_seg = 0) {
     __shared__ u32 ws[HC_THREADS / 64];
     const u64 base = (u64)blockIdx.x * HC_TILE + (u64)threadIdx.x * HC_ITEMS;
-    const u32 f = hc_load_flags(keys, n, shift, base);
+    u32 f = hc_load_flags(keys, n, shift, base);
+    if (seg_start && base < n) f |= hc_boundary_flags(seg_start, n_seg, n, base);
     flags[(u64)blockIdx.x * HC_THREADS + threadIdx.x] = (u16)f;
     u32 c = (u32)__popc(f);
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
@@ -601,14 +626,15 @@ static int compact_heads_async(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, 
 }
 
 // d_starts receives a pool block of n_heads + 1 entries (the extra one is not written); n < 2^32
-static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n, u32 shift, u32 **d_starts, u32 *n_heads) {
+static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n, u32 shift, u32 **d_starts, u32 *n_heads,
+                         const u32 *seg_start = nullptr, u32 n_seg = 0) {
     *d_starts = nullptr; *n_heads = 0;
     if (n == 0) return LRGE_OK;
     const u32 nb = (u32)div_up(n, HC_TILE);
     ALLOC_OR_FAIL(bc, sc, u32, (size_t)nb + 1);
     ALLOC_OR_FAIL(d_tot, sc, u32, 1);
     ALLOC_OR_FAIL(fl, sc, u16, (size_t)nb * HC_THREADS);
-    hipLaunchKernelGGL(k_heads_count, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc, fl);
+    hipLaunchKernelGGL(k_heads_count, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc, fl, seg_start, n_seg);
     KCHK(ctx);
     int rc = scan_exclusive_u32(ctx, sc, bc, bc, nb, d_tot);
     if (rc) return rc;
@@ -981,5 +1007,83 @@ static int index_sort_hybrid(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u
     for (int c = 0; c < 5; ++c) if (d_seg[c]) sc.drop((u32 *)d_seg[c]);
     sc.drop(hist); sc.drop((u32 *)d_tiles); sc.drop(d_segmeta); sc.drop(d_sub);
     *res = k1; *done = true;
+    return LRGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Index sort of the (hash, y) PAIR layout, segment-packed form (round 3).  When 2k + bits(rid) + bits(pos) + 1 exceeds 64 --
+// the HiFi preset on any sizeable read set -- the index entries are 16-byte pairs and the LSD sort moves 32 bytes per entry and
+// pass: five passes for k = 19, 100 GB of traffic per step at C5/10, the largest kernel family of that regime.  Here the MOST
+// significant digit of the (byte-reversed) order -- the low hash byte -- goes first, as one pair pass; inside each of its 256
+// segments that byte is implied, and what is left of the hash (2k - 8 bits) and the position (rid, pos, strand) fit ONE word
+// whenever 2k - 8 + ybits <= 64.  The first of the remaining LSD passes reads the pairs and writes that word (RS_MODE_PACK), the
+// others are keys-only passes segmented by the first digit: 40 + 32 + 24 (passes - 2) bytes per entry instead of 40 passes
+// (k = 19: 144 instead of 200), and the resident index is 8 bytes per entry.  Stable passes, most significant digit first then
+// LSD inside the segments: the order is the pair sort's.  seg_start[257] (host copy returned, device copy allocated from `sc`
+// and handed to the caller) says where every segment begins: run detection and the table build need the low byte back.
+// ------------------------------------------------------------------------------------------
+static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky, u64 *k1, u64 *v1, u64 n, int nbits, u32 ybits, u32 pos1,
+                                u64 **res, u32 **d_seg_start, std::vector<u32> *h_seg_start) {
+    const int passes = (nbits + 7) / 8;
+    auto dbits = [&](int d) { return nbits - 8 * d >= 8 ? 8 : nbits - 8 * d; };
+    const u32 nb = (u32)div_up(n, RS_TILE);
+    ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * (nb + 256 + 1));
+    // ---- pass A: pairs by the low hash byte ----
+    {
+        hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, kx, n, 0, nb, hist, (const SegTile *)nullptr, 255u);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr); if (rc) return rc;
+        StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+        hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_PAIRS>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, kx, ky, k1, v1, n, 0, nb, hist, (const SegTile *)nullptr,
+                           UnpackParams{0, 0, 0, 255});
+        KCHK(ctx);
+        ts.stop();
+        ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 32 * n;
+    }
+    u32 *d_b = sc.get<u32>(257);
+    if (!d_b) return LRGE_ERR_DEVICE;
+    std::vector<u32> &bstart = *h_seg_start;
+    bstart.assign(257, 0);
+    hipLaunchKernelGGL(k_gather_strided_u32, dim3(1), dim3(256), 0, ctx->stream, hist, (u64)nb, 256u, d_b);
+    KCHK(ctx);
+    const u32 n32 = (u32)n;
+    HIPCHK(ctx, hipMemcpyAsync(d_b + 256, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, ctx->d2h(bstart.data(), d_b, 256 * 4, ctx->stream));
+    HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+    bstart[256] = n32;
+    // ---- tiles of the segmented passes ----
+    std::vector<SegTile> tiles;
+    u32 tb = 0;
+    for (u32 s = 0; s < 256; ++s) {
+        const u32 c = bstart[s + 1] - bstart[s], nt = (u32)div_up((u64)c, RS_TILE);
+        for (u32 lt = 0; lt < nt; ++lt) tiles.push_back(SegTile{bstart[s] + lt * RS_TILE, std::min<u32>(RS_TILE, c - lt * RS_TILE), 256u * tb + lt, nt, s, 0u});
+        tb += nt;
+    }
+    const u32 n_tiles = (u32)tiles.size();
+    ALLOC_OR_FAIL(d_tiles, sc, u32, (size_t)n_tiles * (sizeof(SegTile) / 4) + 4);
+    HIPCHK(ctx, hipMemcpyAsync(d_tiles, tiles.data(), (size_t)n_tiles * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
+    // ---- the remaining digits, least significant first: d = passes - 1 (pairs in, packed out), then passes - 2 .. 1 ----
+    u64 *pi = kx, *po = ky;          // (the sketch's pair buffers are free once pass A has read them: they carry the packed words)
+    for (int d = passes - 1; d >= 1; --d) {
+        const bool first = d == passes - 1;
+        const u32 dm = (1u << dbits(d)) - 1u;
+        const int pshift = (int)ybits + 8 * (d - 1);             // where digit d sits in the packed word
+        if (first) hipLaunchKernelGGL(k_rs_hist<true>, dim3(n_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, n, 8 * d, n_tiles, hist, (const SegTile *)d_tiles, dm);
+        else hipLaunchKernelGGL(k_rs_hist<true>, dim3(n_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, n, pshift, n_tiles, hist, (const SegTile *)d_tiles, dm);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * n_tiles, nullptr); if (rc) return rc;
+        StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+        if (first) hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_PACK>), dim3(n_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, v1, pi, (u64 *)nullptr, n, pshift, n_tiles, hist,
+                                      (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm});
+        else hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(n_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, (const u64 *)nullptr, po, (u64 *)nullptr, n, pshift, n_tiles,
+                                hist, (const SegTile *)d_tiles, UnpackParams{0, 0, 0, dm});
+        KCHK(ctx);
+        ts.stop();
+        ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (first ? 24 : 16) * n;
+        if (!first) { u64 *t = pi; pi = po; po = t; }
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // (`tiles` is a local)
+    sc.drop(hist); sc.drop((u32 *)d_tiles);
+    *res = pi; *d_seg_start = d_b;
     return LRGE_OK;
 }

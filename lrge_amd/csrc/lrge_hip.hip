@@ -1293,6 +1293,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     }
 
     u64 *skey = so.x, *spos = so.y;
+    bool seg_packed = false; u32 kshift_t = pk_ybits; u32 *d_seg_start = nullptr; std::vector<u32> h_seg_start;
     {
         StageTimer t(ctx, LRGE_T_INDEX_SORT);
         ALLOC_OR_FAIL(k1, sc, u64, M + 1);
@@ -1307,6 +1308,17 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             sc.drop(rk == so.x ? k1 : so.x);
         } else {
             ALLOC_OR_FAIL(v1, sc, u64, M + 1);
+            // the pair layout, segment-packed (k_prims.h: index_sort_segpacked): behind the first digit the low hash byte is implied
+            // and the rest of the entry fits one word -- fewer bytes through the remaining passes, 8 bytes per entry resident
+            const u32 yb_p = pk_rid + pk_pos1;
+            if (pass_from == 0 && 2 * (u32)P.k - 8 + yb_p <= 64 && 2 * P.k > 16 && !ctx->opt("NO_SEG_PACK") && M >= ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22)) {
+                u64 *rk = nullptr;
+                rc = index_sort_segpacked(ctx, sc, so.x, so.y, k1, v1, M, 2 * P.k, yb_p, pk_pos1, &rk, &d_seg_start, &h_seg_start);
+                if (rc) return rc;
+                seg_packed = true; kshift_t = yb_p;
+                skey = rk; spos = rk;
+                sc.drop(rk == so.x ? so.y : so.x); sc.drop(k1); sc.drop(v1);
+            } else {
             u64 *rk, *rv;
             rc = radix_sort_pairs(ctx, sc, so.x, so.y, k1, v1, M, 0, 2 * P.k, &rk, &rv, /*reverse_digits=*/true, nullptr, 0, pass_from, -1);   // see k_index.h
             if (rc) return rc;
@@ -1314,9 +1326,11 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             skey = rk; spos = rv;
             sc.drop(rk == so.x ? k1 : so.x);
             sc.drop(rv == so.y ? v1 : so.y);
+            }
         }
         t.stop();
     }
+    const bool pk_t = pk || seg_packed;          // what the table build and the lookups see: one packed word per entry
 
     lrge_hip_index *ix = new lrge_hip_index();
     IndexGuard ix_guard(ix);
@@ -1329,7 +1343,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         const u32 ht_fix = ctx->opt("HT_NO_FIX") ? 0u : ht_fix_with_power(P.k, (u32)ctx->opt_u64("HT_POWER", 3));   // (HT_POWER: exponent of the distribution correction, 0 = linear stretch only; measured 2-4 alike, mean displacement 0.30 slots at 3)     // (option HT_NO_FIX: the clustered homes of rounds 1-2, for A/B runs)
         u32 *d_runstart = nullptr;
         if (M) {
-            rc = compact_heads(ctx, sc, skey, M, pk_ybits, &d_runstart, &n_runs);    // runs of equal hash
+            rc = compact_heads(ctx, sc, skey, M, kshift_t, &d_runstart, &n_runs, d_seg_start, seg_packed ? 256u : 0u);    // runs of equal hash
             if (rc) return rc;
         }
 #ifndef HT_CAP_NUM
@@ -1365,14 +1379,14 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
                 const u32 n_tiles = (u32)div_up(n_runs, PLACE_TILE);
                 u32 *bmax = sc.get<u32>((size_t)n_tiles + 1);
                 if (!bmax) return LRGE_ERR_DEVICE;
-                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax, pk_ybits, ht_fix);
+                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax, kshift_t, ht_fix, (const u32 *)d_seg_start);
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_scan, dim3(1), dim3(1024), 0, ctx->stream, bmax, n_tiles);
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_apply, dim3(std::min<u32>(n_tiles, (u32)ctx->n_cu * 8)), dim3(PLACE_THREADS), 0, ctx->stream,
-                                   skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1, pk_ybits, ht_fix,
-                                   fused_fill ? bmax + n_tiles : (u32 *)nullptr, pk ? (const u64 *)nullptr : (const u64 *)spos, pk ? pk_pos1 : 0u,
-                                   ctx->opt("NO_INLINE_SINGLETONS") ? 0u : 1u);
+                                   skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1, kshift_t, ht_fix,
+                                   fused_fill ? bmax + n_tiles : (u32 *)nullptr, pk_t ? (const u64 *)nullptr : (const u64 *)spos, pk_t ? pk_pos1 : 0u,
+                                   ctx->opt("NO_INLINE_SINGLETONS") ? 0u : 1u, (const u32 *)d_seg_start);
                 KCHK(ctx);
                 if (fused_fill) {
                     hipLaunchKernelGGL(k_fill_tail, dim3((u32)std::min<u64>(div_up(n_slots - cap / 2, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, ht, n_slots, bmax + n_tiles);
@@ -1429,7 +1443,8 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     ix->d_pos = spos; sc.keep(spos);
     if (skey != spos && targets->is_view) { ix->d_skey = nullptr; }          // stays with `sc`: released at scope exit
     else { ix->d_skey = skey; if (skey != spos) sc.keep(skey); }
-    ix->pk_pos1 = pk ? pk_pos1 : 0; ix->pk_ybits = pk_ybits;
+    ix->pk_pos1 = pk_t ? pk_pos1 : 0; ix->pk_ybits = kshift_t;
+    if (seg_packed) { ix->h_seg_start = h_seg_start; sc.drop(d_seg_start); }     // (the device copy served the table build; the dump needs the host copy)
     t_total.stop();
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->resolve_timers();
@@ -1697,6 +1712,9 @@ extern "C" int lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, 
             const u64 e = hk[i], yb = e & ym;
             hk[i] = e >> ix->pk_ybits; hp[i] = (yb >> ix->pk_pos1) << 32 | (yb & pm);
         }
+        if (!ix->h_seg_start.empty())        // segment-packed: the low hash byte is the number of the entry's segment
+            for (u32 sgm = 0; sgm < 256; ++sgm)
+                for (u64 i = ix->h_seg_start[sgm]; i < ix->h_seg_start[sgm + 1]; ++i) hk[i] = hk[i] << 8 | sgm;
     }
     std::vector<u32> ord(ix->n_entries);
     for (u64 i = 0; i < ix->n_entries; ++i) ord[i] = (u32)i;

@@ -67,6 +67,39 @@ def test_index_parity(ctx, oracle, edge_set, preset, packed, knobs):
     assert np.array_equal(pos, mz["y"][order])
 
 
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_segment_packed_pair_index_is_exact(ctx, oracle, edge_set, tiny_ont, tiny_hifi, preset, knobs):
+    """The (hash, y) pair layout sorted in its segment-packed form (k_prims.h: index_sort_segpacked: the low hash byte first, then
+    one packed word per entry inside its 256 segments) only engages above 4 M entries -- C5/10 and full-size C5 run it at scale.
+    Forced here onto small sets: index entries, lists, mid_occ and counts must be those of the plain pair sort and of the oracle."""
+    from lrge_amd import engine
+    knobs.set("NO_PACKED_INDEX", "1")
+    knobs.set("SEG_PACK_MIN", "1")
+    qseqs, qnames, tseqs, tnames = edge_set
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset)
+    keys, pos = ixd.dump()
+    mz = ixo.minimizers()
+    order = np.lexsort((mz["y"], mz["x"] >> np.uint64(8)))
+    assert np.array_equal(keys, (mz["x"] >> np.uint64(8))[order]) and np.array_equal(pos, mz["y"][order])
+    st = ixd.stats()
+    assert st["mid_occ"] == ixo.mid_occ and st["n_keys"] == ixo.n_keys
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Q2, T2 = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
+    res = {}
+    for seg in (True, False):
+        if not seg:
+            knobs.set("NO_SEG_PACK", "1")
+        ix = engine.Index(ctx, T2, PRESETS[preset])
+        res[seg] = (ix.overlap_twoset(Q2), ix.overlap_twoset(Q2, remove_internal=True), ix.stats())
+        ch = ix.chains(Q2)
+        res[seg] += (np.sort(ch, order=["query", "target", "rev", "qs", "rs"]),)
+        ix.free()
+    for a, b in zip(res[True][:2], res[False][:2]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert res[True][2] == res[False][2] and np.array_equal(res[True][3], res[False][3]) and int(res[True][0][0].sum()) > 0
+
+
 @pytest.mark.parametrize("caps", [None, (3, 5, 9), (64, 300, 700)], ids=["lds", "all-global", "mixed"])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
 def test_hybrid_index_sort_is_exact(ctx, oracle, edge_set, tiny_ont, tiny_hifi, preset, caps, knobs):

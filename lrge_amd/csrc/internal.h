@@ -185,6 +185,7 @@ struct lrge_hip_ctx {
     char *meta_pin = nullptr; size_t meta_cap = 0, meta_used = 0; int meta_inflight = 0;
     hipEvent_t ev_meta = nullptr;            // behind the last transfer out of the arena: waited for before a rewound arena is written again
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_presk = nullptr;           // where the side stream may start a presketch (lrge_hip.hip: presketch_start_pending)
     std::string err;
     DevPool pool;
     // options: LRGE_HIP_<NAME> from the environment at creation, lrge_hip_ctx_set_option afterwards (never read per call)
@@ -196,6 +197,7 @@ struct lrge_hip_ctx {
     int n_cu = 256;
     bool lsort_ok[3] = {false, false, false};   // which k_seg_sort_local variants this device can launch
     struct lrge_hip_seqset *presk_pending = nullptr; int presk_preset = -1;   // lrge_hip_seqset_presketch request
+    struct PreSketch *presk_prepared = nullptr; struct lrge_hip_seqset *presk_prepared_set = nullptr;   // memory taken, kernels not yet queued
     int timer_level = 1;                     // see StageTimer
     u64 shard_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last sharded index build (lrge_hip_last_shard_stats)
     // Small device->host reads (totals, censuses, per-read vectors).  hipMemcpyAsync into pageable memory is a blocking
@@ -235,6 +237,7 @@ struct PreSketch {
     int preset = -1;
     u64 *x = nullptr, *y = nullptr;     // worst-case sized (one minimizer per base)
     u32 *mz_off = nullptr, *d_total = nullptr;
+    u32 *cnt = nullptr, *bs = nullptr;  // per-chunk counts and the scan's block sums (taken with the rest, before the launch)
     Scratch *sc = nullptr;              // owns every allocation of the launch until the consumer is done with them
     hipEvent_t ev_start = nullptr, ev_done = nullptr;
 };

@@ -204,15 +204,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32 *in, u32 
 // out may alias in.  d_total (device u32) receives the grand total (may be null).  `st`: stream (default ctx->stream);
 // `keep`: the block-sum scratch stays with `sc` instead of going back to the pool at once -- required when `st` is not
 // ctx->stream, because the pool recycles memory in the order of ctx->stream only.
+// bs_pre: the caller's own block-sum array (n / SCAN_TILE + 2 words; single level only: n <= 8192 * SCAN_TILE) -- nothing is allocated
 static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32 *out, u64 n, u32 *d_total, hipStream_t st = nullptr,
-                              bool keep = false) {
+                              bool keep = false, u32 *bs_pre = nullptr) {
     if (!st) st = ctx->stream;
     if (n == 0) {
         if (d_total) HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, st));
         return LRGE_OK;
     }
     u64 nb = div_up(n, SCAN_TILE);
-    ALLOC_OR_FAIL(bs, sc, u32, nb + 1);
+    if (bs_pre && nb > 8192) return LRGE_ERR_INVALID;
+    u32 *bs = bs_pre ? bs_pre : sc.get<u32>(nb + 1);
+    if (!bs) return LRGE_ERR_DEVICE;
     hipLaunchKernelGGL(k_scan_reduce, dim3((u32)nb), dim3(SCAN_THREADS), 0, st, in, n, bs);
     KCHK(ctx);
     if (nb <= 8192) {
@@ -224,7 +227,7 @@ static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32
     }
     hipLaunchKernelGGL(k_scan_apply, dim3((u32)nb), dim3(SCAN_THREADS), 0, st, in, out, n, bs, d_total);
     KCHK(ctx);
-    if (!keep) sc.drop(bs);
+    if (!keep && !bs_pre) sc.drop(bs);
     return LRGE_OK;
 }
 

@@ -121,6 +121,7 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
         pick_side_stream(ctx) != hipSuccess || hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_gate, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_presk, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         g_last_error = "hipSetDevice/hipStreamCreate failed";
         delete ctx;
@@ -176,7 +177,7 @@ extern "C" void lrge_hip_ctx_destroy(lrge_hip_ctx *ctx) {
     if (ctx->ev_meta) (void)hipEventDestroy(ctx->ev_meta);
     if (ctx->meta_pin) (void)hipHostFree(ctx->meta_pin);
     (void)hipStreamSynchronize(ctx->stream2);
-    (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join);
+    (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); (void)hipEventDestroy(ctx->ev_presk);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -429,8 +430,10 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
         }
         if (!ctx->uploader) {
             ctx->uploader = new Uploader();
-            const u32 hw = std::max(2u, std::thread::hardware_concurrency());
-            ctx->uploader->pool.start((u32)ctx->opt_u64("HOST_PACK_THREADS", std::min<u32>(32, std::max<u32>(2, hw / 2))) - 1);
+            if (!ctx->opt("HOST_PACK_NO_PIN")) ctx->uploader->cpus = hp_gpu_node_cpus(ctx->device);     // the GPU's own NUMA node
+            const u32 hw = ctx->uploader->cpus.empty() ? std::max(2u, std::thread::hardware_concurrency()) : (u32)ctx->uploader->cpus.size() * 2;
+            ctx->uploader->pool.start((u32)ctx->opt_u64("HOST_PACK_THREADS", std::min<u32>(32, std::max<u32>(2, hw / 2))) - 1, ctx->uploader->cpus);
+            if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] host-side pack: %zu worker threads on %zu CPUs of the GPU's NUMA node\n", ctx->uploader->pool.th.size(), ctx->uploader->cpus.size());
         }
         s->h_boff.resize((size_t)n + 1);
         { const u64 o0 = offsets[0]; for (u32 i = 0; i <= n; ++i) s->h_boff[i] = offsets[i] - o0; }
@@ -549,9 +552,11 @@ extern "C" int lrge_hip_seqset_wait(lrge_hip_seqset *s) {
     return LRGE_OK;
 }
 
+static void presketch_drop_prepared(lrge_hip_ctx *ctx);
 static void presketch_discard(lrge_hip_seqset *s) {
     lrge_hip_ctx *ctx = s->ctx;
     if (ctx->presk_pending == s) ctx->presk_pending = nullptr;
+    if (ctx->presk_prepared_set == s) presketch_drop_prepared(ctx);
     if (!s->presk) return;
     (void)hipStreamSynchronize(ctx->stream2);          // its kernels may still be running
     delete s->presk->sc;
@@ -736,48 +741,70 @@ static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
 }
 
 // ---- presketch: the streamed set's minimizers, computed on the side stream with no host round trip ----
-template <int K, int W, bool HPC>
-static int presketch_launch(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, PreSketch *p, hipStream_t st) {
+// Two steps, because the device arena recycles blocks in the order of the MAIN stream: everything the side stream will touch
+// is allocated where it forks (presketch_prepare: nothing released by the index build after that point can be handed to it),
+// the kernels may be queued later (presketch_launch_prepared).
+static int presketch_alloc(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, PreSketch *p) {
     if (s->n_chunks >= (1ULL << 32) || s->total_bases + 1 >= (1ULL << 32)) return LRGE_ERR_TOO_MANY;
     Scratch &sc = *p->sc;
-    const u32 n_chunks = (u32)s->n_chunks;
-    ALLOC_OR_FAIL(d_cnt, sc, u32, (size_t)n_chunks + 1);
+    const u64 nb = div_up(s->n_chunks, SCAN_TILE);
+    if (nb > 8192) return LRGE_ERR_TOO_MANY;                   // (single-level scan with the caller's block sums)
+    ALLOC_OR_FAIL(d_cnt, sc, u32, (size_t)s->n_chunks + 1);
+    ALLOC_OR_FAIL(d_bs, sc, u32, (size_t)nb + 2);
     ALLOC_OR_FAIL(d_total, sc, u32, 1);
     ALLOC_OR_FAIL(d_mzoff, sc, u32, (size_t)s->n + 1);
     // the count is not known on the host when the write pass is queued: room for one minimizer per base
     ALLOC_OR_FAIL(dx, sc, u64, (size_t)s->total_bases + 1);
     ALLOC_OR_FAIL(dy, sc, u64, (size_t)s->total_bases + 1);
+    p->cnt = d_cnt; p->bs = d_bs; p->x = dx; p->y = dy; p->mz_off = d_mzoff; p->d_total = d_total;
+    return LRGE_OK;
+}
+
+template <int K, int W, bool HPC>
+static int presketch_launch(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, PreSketch *p, hipStream_t st) {
+    Scratch &sc = *p->sc;
+    const u32 n_chunks = (u32)s->n_chunks;
     ChunkMap cm{s->d_cs, s->n};
     const dim3 sgrid((u32)div_up(n_chunks, SK_THREADS));
     // Two passes here, not the one-pass form of sketch_launch: this runs beside the index's memory-bound sort passes, and
     // a second VALU-bound pass overlaps with them where the one-pass form's streaming compaction competes (measured:
     // the sort loses what the sketch gains).
     if (n_chunks) {
-        hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), sgrid, dim3(SK_THREADS), 0, st, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt);
+        hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), sgrid, dim3(SK_THREADS), 0, st, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, p->cnt);
         KCHK(ctx);
-        int rc = scan_exclusive_u32(ctx, sc, d_cnt, d_cnt, n_chunks, d_total, st, true);
+        int rc = scan_exclusive_u32(ctx, sc, p->cnt, p->cnt, n_chunks, p->d_total, st, true, p->bs);
         if (rc) return rc;
     } else {
-        HIPCHK(ctx, hipMemsetAsync(d_total, 0, 4, st));
+        HIPCHK(ctx, hipMemsetAsync(p->d_total, 0, 4, st));
     }
-    hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, st, s->d_cs, d_cnt, s->n, n_chunks, d_total,
-                       d_mzoff);
+    hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, st, s->d_cs, p->cnt, s->n, n_chunks, p->d_total,
+                       p->mz_off);
     KCHK(ctx);
     if (n_chunks) {
         hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false, false>), sgrid, dim3(SK_THREADS), 0, st, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm,
-                           n_chunks, d_cnt, dx, dy, 0u, 0u);
+                           n_chunks, p->cnt, p->x, p->y, 0u, 0u);
         KCHK(ctx);
     }
-    p->x = dx; p->y = dy; p->mz_off = d_mzoff; p->d_total = d_total;
     return LRGE_OK;
 }
 
-// Called by the index build right after its own sketch has been queued on ctx->stream.
+static void presketch_drop_prepared(lrge_hip_ctx *ctx) {
+    PreSketch *p = ctx->presk_prepared;
+    if (!p) return;
+    ctx->presk_prepared = nullptr; ctx->presk_prepared_set = nullptr;
+    delete p->sc;                                        // (nothing has been queued on these blocks)
+    ctx->event_pool.push_back(p->ev_start); ctx->event_pool.push_back(p->ev_done);
+    delete p;
+}
+
+// Called by the index build right after its own sketch has been queued on ctx->stream: marks the point of the main stream
+// the side stream starts from and takes the memory of the streamed set's sketch.
 // indexed_bases: size of the set whose index build would hide the sketch.  A streamed set several times larger than the
 // indexed one (the inverse strategy on a big job: 3 Gbases streamed against a 150 Mbase index) finds nothing to hide behind --
 // the two VALU-bound sketches and the small sort just share the chip -- so the hint is ignored there and the overlap call
 // sketches in line (C5/10 inverse: 95 -> 89 ms per step).
-static int presketch_start_pending(lrge_hip_ctx *ctx, u64 indexed_bases) {
+static int presketch_prepare(lrge_hip_ctx *ctx, u64 indexed_bases) {
+    presketch_drop_prepared(ctx);
     lrge_hip_seqset *s = ctx->presk_pending;
     if (!s) return LRGE_OK;
     ctx->presk_pending = nullptr;
@@ -788,15 +815,27 @@ static int presketch_start_pending(lrge_hip_ctx *ctx, u64 indexed_bases) {
     p->preset = ctx->presk_preset;
     p->sc = new Scratch(ctx);
     p->ev_start = ctx->get_event(); p->ev_done = ctx->get_event();
+    ctx->presk_prepared = p; ctx->presk_prepared_set = s;
     // behind the index sketch (both are VALU-bound; the point is to run beside the passes that follow it)
-    int rc = LRGE_OK;
-    hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+    if (presketch_alloc(ctx, s, p) != LRGE_OK || hipEventRecord(ctx->ev_presk, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        presketch_drop_prepared(ctx);                    // not fatal: the overlap call sketches the set itself
+    }
+    return LRGE_OK;
+}
+
+// Queues the prepared sketch on the side stream.  May block on the HOST until the set's upload job (host-side pack) is over,
+// which is why the index build calls it only once it has nothing more of its own to queue that could run meanwhile.
+static int presketch_launch_prepared(lrge_hip_ctx *ctx) {
+    PreSketch *p = ctx->presk_prepared; lrge_hip_seqset *s = ctx->presk_prepared_set;
+    if (!p) return LRGE_OK;
+    hipError_t e = hipStreamWaitEvent(ctx->stream2, ctx->ev_presk, 0);
     // an upload of the set still in flight: only the side stream waits for it -- the main stream goes on with the index
     // (its own seqset_ready comes with the overlap call, which also returns the staging blocks to the pool)
-    if (s->job && seqset_job_wait(ctx, s) != LRGE_OK) { ctx->event_pool.push_back(p->ev_start); ctx->event_pool.push_back(p->ev_done); delete p->sc; delete p; return LRGE_OK; }
+    if (s->job && seqset_job_wait(ctx, s) != LRGE_OK) { presketch_drop_prepared(ctx); return LRGE_OK; }
     if (e == hipSuccess && s->pending) e = hipStreamWaitEvent(ctx->stream2, s->ev_ready, 0);
     if (e == hipSuccess) e = hipEventRecord(p->ev_start, ctx->stream2);
+    int rc = LRGE_OK;
     if (e == hipSuccess) {
         rc = p->preset == LRGE_PRESET_AVA_PB ? presketch_launch<19, 5, true>(ctx, s, p, ctx->stream2)
                                              : presketch_launch<15, 5, false>(ctx, s, p, ctx->stream2);
@@ -805,13 +844,17 @@ static int presketch_start_pending(lrge_hip_ctx *ctx, u64 indexed_bases) {
     if (e != hipSuccess || rc != LRGE_OK) {      // not fatal: the overlap call sketches the set itself
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipGetLastError();
-        delete p->sc;
-        ctx->event_pool.push_back(p->ev_start); ctx->event_pool.push_back(p->ev_done);
-        delete p;
+        presketch_drop_prepared(ctx);
         return LRGE_OK;
     }
+    ctx->presk_prepared = nullptr; ctx->presk_prepared_set = nullptr;
     s->presk = p;
     return LRGE_OK;
+}
+
+static int presketch_start_pending(lrge_hip_ctx *ctx, u64 indexed_bases) {
+    int rc = presketch_prepare(ctx, indexed_bases);
+    return rc ? rc : presketch_launch_prepared(ctx);
 }
 
 extern "C" int lrge_hip_seqset_presketch(lrge_hip_ctx *ctx, lrge_hip_seqset *s, int preset) {
@@ -1152,6 +1195,8 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         }
     }
     bool fused = false; u64 *own_hashes = nullptr; u64 n_own = 0;
+    bool presk_deferred = false;
+    struct PreparedGuard { lrge_hip_ctx *c; ~PreparedGuard() { presketch_drop_prepared(c); } } prepared_guard{ctx};   // (an error between the two steps)
     if (sharded) {
         // this rank sketches its own share of the targets; key sets, kept entries and owned hashes travel (k_route.h)
         StageTimer t(ctx, LRGE_T_INDEX_RESTRICT);
@@ -1177,7 +1222,17 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     }
     if (!fused) {
         rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits);
-        if (rc == LRGE_OK && !ctx->opt("NO_PRESKETCH")) rc = presketch_start_pending(ctx, targets->total_bases);
+        if (rc == LRGE_OK && !ctx->opt("NO_PRESKETCH")) {
+            // the streamed set's sketch goes to the side stream right behind this one -- unless its host-side pack is still running
+            // on the uploader thread: waiting for that here would leave the GPU idle, so only the fork point is marked now and the
+            // launch follows once the index sort has been queued (the side stream still starts behind the index sketch)
+            rc = presketch_prepare(ctx, targets->total_bases);
+            lrge_hip_seqset *S = ctx->presk_prepared_set;
+            bool running = false;
+            if (S && S->job) { std::lock_guard<std::mutex> lk(S->job->mu); running = !S->job->done; }
+            if (running) presk_deferred = true;
+            else if (rc == LRGE_OK) rc = presketch_launch_prepared(ctx);
+        }
         if (rc) return rc;
         sc.drop(so.mz_off);
     }
@@ -1330,6 +1385,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         }
         t.stop();
     }
+    if (presk_deferred) { rc = presketch_launch_prepared(ctx); if (rc) return rc; }
     const bool pk_t = pk || seg_packed;          // what the table build and the lookups see: one packed word per entry
 
     lrge_hip_index *ix = new lrge_hip_index();

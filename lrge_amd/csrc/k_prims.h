@@ -274,11 +274,14 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 nb) {
 #endif
 }
 
-template <bool SEG>
+// DB: digit bits (8, or 10: three passes instead of four over a 30-bit hash; the runs a tile writes per digit shrink from 16 to 4
+// keys, which the L2 of the tile's XCD puts together with the neighbouring tiles' -- see xcd_tile)
+template <bool SEG, int DB = 8>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
                                                         u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255) {
-    __shared__ u32 h[256];
-    h[threadIdx.x] = 0;
+    constexpr u32 ND = 1u << DB;
+    __shared__ u32 h[ND];
+    for (u32 i = threadIdx.x; i < ND; i += RS_THREADS) h[i] = 0;
     __syncthreads();
     const u32 bid = xcd_tile(blockIdx.x, gridDim.x);
     const u64 tile0 = SEG ? (u64)tiles[bid].start : (u64)bid * RS_TILE;
@@ -292,11 +295,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
     for (int r = 0; r < RS_ITEMS; ++r)
         if (l0 + (u32)r * 64 < n_tile) atomicAdd(&h[(u32)(kk[r] >> shift) & dmask], 1u);
     __syncthreads();
-    const u64 hi = SEG ? (u64)tiles[bid].hbase + (u64)threadIdx.x * tiles[bid].hstride : (u64)threadIdx.x * nb + bid;
-    hist[hi] = h[threadIdx.x];
+    for (u32 d = threadIdx.x; d < ND; d += RS_THREADS) {
+        const u64 hi = SEG ? (u64)tiles[bid].hbase + (u64)d * tiles[bid].hstride : (u64)d * nb + bid;
+        hist[hi] = h[d];
+    }
 }
 
-template <bool SEG, int MODE>
+template <bool SEG, int MODE, int DB = 8>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict__ keys_in, const u64 *__restrict__ vals_in,
                                                            u64 *__restrict__ keys_out, u64 *__restrict__ vals_out, u64 n,
                                                            int shift, u32 nb, const u32 *__restrict__ hist_scanned,
@@ -304,14 +309,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     // 1. per-wave stable ranks (ballot digit matching + per-wave LDS counters)
     // 2. block-local destinations: the tile is first reordered through LDS so that each digit's
     //    items are contiguous, then written out as coalesced runs (one run per digit per tile)
-    __shared__ u32 cnt[RS_WAVES][256];   // per-wave digit counts -> block-local start of (wave, digit)
-    __shared__ u32 gbase[256];           // global destination of the tile's digit run minus its local start
+    constexpr u32 ND = 1u << DB;         // digits
+    constexpr int DPT = ND / RS_THREADS; // digits per thread in the digit scan (consecutive ones)
+    static_assert(ND % RS_THREADS == 0, "digit count must be a multiple of the block size");
+    __shared__ u32 cnt[RS_WAVES][ND];    // per-wave digit counts -> block-local start of (wave, digit)
+    __shared__ u32 gbase[ND];            // global destination of the tile's digit run minus its local start
     __shared__ u32 wtot[RS_WAVES];
     __shared__ u64 stage[RS_TILE];       // 32 KB: keys, then values
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     const u32 bid = xcd_tile(blockIdx.x, gridDim.x);
     const u32 dmask = MODE == RS_MODE_PAIRS ? 255u : up.dmask;
-    for (u32 i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+    for (u32 i = threadIdx.x; i < RS_WAVES * ND; i += RS_THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const u64 tile0 = SEG ? (u64)tiles[bid].start : (u64)bid * RS_TILE;
     const u32 n_tile = SEG ? tiles[bid].len : (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         const u64 mv = __ballot(valid);
         u32 a_lo = 0, a_hi = 0;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) wave_match_bit(d, b, a_lo, a_hi);
+        for (int b = 0; b < DB; ++b) wave_match_bit(d, b, a_lo, a_hi);
         const u32 m_lo = (u32)mv & ~a_lo, m_hi = (u32)(mv >> 32) & ~a_hi;
         const u32 before = wave_match_before(m_lo, m_hi);
         // every lane of a digit class reads the class counter (one broadcast LDS read), the lowest lane of the class -- the one
@@ -352,21 +360,30 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         rank[r] = old + before;
     }
     __syncthreads();
-    {   // thread d: digit totals -> exclusive scan over digits -> local starts per (wave, digit)
-        const u32 d = threadIdx.x;
-        u32 c[RS_WAVES], tot = 0;
+    {   // thread t: digits [t * DPT, (t + 1) * DPT): totals -> exclusive scan over digits -> local starts per (wave, digit)
+        u32 c[DPT][RS_WAVES], tot[DPT], ttot = 0;
 #pragma unroll
-        for (int ww = 0; ww < RS_WAVES; ++ww) { c[ww] = cnt[ww][d]; tot += c[ww]; }
-        u32 inc = wave_incl_scan_u32(tot);
+        for (int j = 0; j < DPT; ++j) {
+            tot[j] = 0;
+#pragma unroll
+            for (int ww = 0; ww < RS_WAVES; ++ww) { c[j][ww] = cnt[ww][threadIdx.x * DPT + j]; tot[j] += c[j][ww]; }
+            ttot += tot[j];
+        }
+        u32 inc = wave_incl_scan_u32(ttot);
         if (lane == 63) wtot[w] = inc;
         __syncthreads();
-        u32 dstart = inc - tot;
+        u32 dstart = inc - ttot;
         for (u32 ww = 0; ww < w; ++ww) dstart += wtot[ww];
-        const u64 hi = SEG ? (u64)tiles[bid].hbase + (u64)d * tiles[bid].hstride : (u64)d * nb + bid;
-        gbase[d] = hist_scanned[hi] + (SEG ? tiles[bid].delta : 0u) - dstart;
-        u32 run = dstart;
 #pragma unroll
-        for (int ww = 0; ww < RS_WAVES; ++ww) { cnt[ww][d] = run; run += c[ww]; }
+        for (int j = 0; j < DPT; ++j) {
+            const u32 d = threadIdx.x * DPT + j;
+            const u64 hi = SEG ? (u64)tiles[bid].hbase + (u64)d * tiles[bid].hstride : (u64)d * nb + bid;
+            gbase[d] = hist_scanned[hi] + (SEG ? tiles[bid].delta : 0u) - dstart;
+            u32 run = dstart;
+#pragma unroll
+            for (int ww = 0; ww < RS_WAVES; ++ww) { cnt[ww][d] = run; run += c[j][ww]; }
+            dstart += tot[j];
+        }
     }
     __syncthreads();
     u32 lpos[RS_ITEMS];
@@ -491,27 +508,35 @@ static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *
 }
 
 // Stable keys-only LSD sort on bits [begin_bit, begin_bit + nbits) (k0 / k1 ping-pong, *res = buffer holding the result).
+// digit_bits: 8, or 10 (whole sorts only: no pass range)
 static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64 n, int begin_bit, int nbits, u64 **res,
-                           bool reverse_digits, int pass_begin = 0, int pass_end = -1) {
+                           bool reverse_digits, int pass_begin = 0, int pass_end = -1, int digit_bits = 8) {
     *res = k0;
     if (n <= 1 || nbits <= 0) return LRGE_OK;
     if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
+    if (digit_bits != 8 && digit_bits != 10) return LRGE_ERR_INVALID;
+    const int DB = digit_bits;
     const u32 nb = (u32)div_up(n, RS_TILE);
-    ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * nb);
-    const int passes = (nbits + 7) / 8;
+    ALLOC_OR_FAIL(hist, sc, u32, ((u64)1 << DB) * nb);
+    const int passes = (nbits + DB - 1) / DB;
     u64 *ki = k0, *ko = k1;
     for (int p = pass_begin; p < (pass_end < 0 ? passes : std::min(pass_end, passes)); ++p) {
         const int d = reverse_digits ? passes - 1 - p : p;
-        const int shift = begin_bit + d * 8;
-        UnpackParams up{0, 0, 0, nbits - d * 8 >= 8 ? 255u : (1u << (nbits - d * 8)) - 1u};
-        hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, (const SegTile *)nullptr, up.dmask);
+        const int shift = begin_bit + d * DB;
+        UnpackParams up{0, 0, 0, nbits - d * DB >= DB ? (1u << DB) - 1u : (1u << (nbits - d * DB)) - 1u};
+        if (DB == 8) hipLaunchKernelGGL((k_rs_hist<false, 8>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, (const SegTile *)nullptr, up.dmask);
+        else hipLaunchKernelGGL((k_rs_hist<false, 10>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, (const SegTile *)nullptr, up.dmask);
         KCHK(ctx);
-        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, ((u64)1 << DB) * nb, nullptr);
         if (rc) return rc;
         {
             StageTimer ts(ctx, LRGE_T_RS_SCATTER);
-            hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_KEYS>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, ko, (u64 *)nullptr, n, shift, nb,
-                               hist, (const SegTile *)nullptr, up);
+            if (DB == 8)
+                hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_KEYS, 8>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, ko, (u64 *)nullptr, n, shift, nb,
+                                   hist, (const SegTile *)nullptr, up);
+            else
+                hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_KEYS, 10>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, ko, (u64 *)nullptr, n, shift, nb,
+                                   hist, (const SegTile *)nullptr, up);
             KCHK(ctx);
             ts.stop();
             ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
@@ -522,6 +547,244 @@ static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64
     }
     sc.drop(hist);
     *res = ki;
+    return LRGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// One-sweep form of the keys-only LSD sort (index entries: radix_sort_keys_onesweep).  The three-kernel pass above reads every
+// key twice (k_rs_hist, then k_rs_scatter) to know, per tile and digit, where the tile's run starts.  Here the digit totals of ALL
+// passes come from one read of the input (k_rs_hist_all: a digit's total does not depend on the order of the keys), and a tile
+// learns what the tiles in front of it hold from their published counts (decoupled look-back, Merrill & Garland; Adinets &
+// Merrill's Onesweep): (1 + 2 P) n words of traffic instead of 3 P n.
+//   state[tile][digit] = flag << 30 | count:  flag 1 = the tile's own count of the digit, 2 = the count of tiles 0 .. tile.
+// One 32-bit word carries flag and value, written and polled with relaxed agent-scope atomics (sc1: served by memory, not by
+// the writer's or the reader's own L1 / XCD L2), so no ordering between separate words is needed.  Tiles are handed out by a
+// ticket counter: a tile only ever waits for tiles with smaller tickets, which are resident -- no deadlock whatever the
+// dispatch order.  A poll that runs into OS_SPIN_LIMIT raises *err and gives up (the caller reports it; nothing hangs).
+// ------------------------------------------------------------------------------------------
+#define OS_FLAG_SHIFT 30
+#define OS_FLAG_AGG (1u << OS_FLAG_SHIFT)
+#define OS_FLAG_INCL (2u << OS_FLAG_SHIFT)
+#define OS_VAL_MASK ((1u << OS_FLAG_SHIFT) - 1u)
+#define OS_SPIN_LIMIT (1u << 22)
+#define OS_MAX_PASSES 8
+#define OS_LOOK 8
+
+struct OsPasses { int n; int shift[OS_MAX_PASSES]; u32 dmask[OS_MAX_PASSES]; };
+
+// ghist[p * 256 + d] += keys whose digit of pass p is d
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist_all(const u64 *__restrict__ keys, u64 n, OsPasses P, u32 *__restrict__ ghist) {
+    __shared__ u32 h[OS_MAX_PASSES * 256];
+    for (u32 i = threadIdx.x; i < (u32)P.n * 256; i += RS_THREADS) h[i] = 0;
+    __syncthreads();
+    const u64 n_tiles = (n + RS_TILE - 1) / RS_TILE;
+    for (u64 t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const u64 tile0 = t * RS_TILE;
+        const u32 n_tile = (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
+        const u32 l0 = (threadIdx.x >> 6) * (RS_ITEMS * 64) + lane_id();
+        u64 kk[RS_ITEMS];
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) kk[r] = l0 + (u32)r * 64 < n_tile ? keys[tile0 + l0 + (u32)r * 64] : 0;
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r)
+            if (l0 + (u32)r * 64 < n_tile)
+                for (int p = 0; p < P.n; ++p) atomicAdd(&h[p * 256 + ((u32)(kk[r] >> P.shift[p]) & P.dmask[p])], 1u);
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < (u32)P.n * 256; i += RS_THREADS) if (h[i]) atomicAdd(&ghist[i], h[i]);
+}
+
+// one block of 256 threads: ghist[p][.] -> its exclusive prefix sums, in place
+__global__ __launch_bounds__(256) void k_rs_gscan(u32 *__restrict__ ghist, int passes) {
+    __shared__ u32 wt[4];
+    for (int p = 0; p < passes; ++p) {
+        const u32 v = ghist[p * 256 + threadIdx.x];
+        const u32 inc = wave_incl_scan_u32(v);
+        if (lane_id() == 63) wt[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        u32 before = 0;
+        for (u32 w = 0; w < (threadIdx.x >> 6); ++w) before += wt[w];
+        ghist[p * 256 + threadIdx.x] = before + inc - v;
+        __syncthreads();
+    }
+}
+
+typedef unsigned int os_v4u __attribute__((ext_vector_type(4)));
+#define OS_AUX_SC1 16       // aux bits of the raw buffer intrinsics: sc1
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_onesweep(const u64 *__restrict__ keys_in, u64 *__restrict__ keys_out, u64 n, int shift, u32 dmask,
+                                                            const u32 *__restrict__ gstart /* [256]: first output index of every digit */,
+ u32 *__restrict__ state, u32 nb, u32 lg_group, u32 *__restrict__ ticket, u32 *__restrict__ err) {
+    __shared__ u32 cnt[RS_WAVES][256];
+    __shared__ u32 gbase[256];
+    __shared__ u32 dtot[256];            // the tile's digit counts, then (wave 0) the counts of the tiles in front of it
+    __shared__ u32 wtot[RS_WAVES];
+    __shared__ u64 stage[RS_TILE];
+    __shared__ u32 s_tile;
+    const u32 w = threadIdx.x >> 6, lane = lane_id();
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket + (blockIdx.x & 7u), 1u);
+    for (u32 i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    // ticket -> tile.  Blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8: see xcd_tile; a speed matter only), and
+    // every residue class of b has its own ticket counter.  Tiles are taken in groups of G = 2^lg_group consecutive ones, group g
+    // by class g % 8 in ticket order -- the runs a group writes per digit meet in ONE L2.  A tile then waits for tiles of the
+    // other classes at most G tickets ahead of its own; blocks are dispatched in index order, so the classes' counters stay within
+    // one of each other, and the launcher keeps 8 G well below the number of blocks the device holds at once: the tiles a
+    // resident block waits for are drawn whatever else happens.  Past the last full round of 8 groups: tile = 8 ticket + class.
+    const u32 G = 1u << lg_group, n_full = nb & ~(8u * G - 1u);
+    const u32 xc = blockIdx.x & 7u, tq = s_tile;
+    const u32 bid = tq < (n_full >> 3) ? ((((tq >> lg_group) << 3) | xc) << lg_group) | (tq & (G - 1u)) : n_full + ((tq - (n_full >> 3)) << 3) + xc;
+    const u64 tile0 = (u64)bid * RS_TILE;
+    const u32 n_tile = (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
+    const u32 l0 = w * (RS_ITEMS * 64) + lane;
+    const u64 base = tile0 + l0;
+    u64 k[RS_ITEMS];
+    u32 rank[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n_tile ? keys_in[base + (u64)r * 64] : ~0ULL;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {      // per-wave stable ranks: see k_rs_scatter
+        const bool valid = l0 + (u32)r * 64 < n_tile;
+        const u32 d = (u32)(k[r] >> shift) & dmask;
+        const u64 mv = __ballot(valid);
+        u32 a_lo = 0, a_hi = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) wave_match_bit(d, b, a_lo, a_hi);
+        const u32 m_lo = (u32)mv & ~a_lo, m_hi = (u32)(mv >> 32) & ~a_hi;
+        const u32 before = wave_match_before(m_lo, m_hi);
+        const u32 old = cnt[w][d];
+        if (valid && before == 0) cnt[w][d] = old + wave_match_total(m_lo, m_hi);
+        rank[r] = old + before;
+    }
+    __syncthreads();
+    u32 dstart, tot = 0;
+    {   // thread d: digit totals -> exclusive scan over digits -> local starts per (wave, digit)
+        const u32 d = threadIdx.x;
+        u32 c[RS_WAVES];
+#pragma unroll
+        for (int ww = 0; ww < RS_WAVES; ++ww) { c[ww] = cnt[ww][d]; tot += c[ww]; }
+        dtot[d] = tot;
+        u32 inc = wave_incl_scan_u32(tot);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        dstart = inc - tot;
+        for (u32 ww = 0; ww < w; ++ww) dstart += wtot[ww];
+        u32 run = dstart;
+#pragma unroll
+        for (int ww = 0; ww < RS_WAVES; ++ww) { cnt[ww][d] = run; run += c[ww]; }
+    }
+#ifdef OS_DEBUG_PRESCANNED      // (micro-benchmark: tile starts from the scanned histogram of k_rs_hist, passed as `state`; no look-back)
+    if (true) { dtot[threadIdx.x] = state[(u64)threadIdx.x * nb + bid] - gstart[threadIdx.x]; } else
+#endif
+    if (w == 0) {
+        // Wave 0 publishes and looks back for the whole tile: lane l owns digits 4 l .. 4 l + 3, ONE 16-byte word of the tile's
+        // state row, stored and polled write-through / L2-bypassing (sc1) -- a quarter of the transactions of a word per
+        // digit, and a 16-byte sc1 access is never torn, so the four flags of a word always agree.
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(state, 0, (int)(nb * 1024u), 0x00020000);
+        const os_v4u mine = *(const os_v4u *)&dtot[4 * lane];
+        const u32 flag0 = bid == 0 ? OS_FLAG_INCL : OS_FLAG_AGG;
+        __builtin_amdgcn_raw_buffer_store_b128(mine | flag0, rsrc, (int)(bid * 1024u + lane * 16u), 0, OS_AUX_SC1);
+        os_v4u excl = {0u, 0u, 0u, 0u};
+#ifdef OS_DEBUG_NO_LOOKBACK
+        if (false) {
+#else
+        if (bid > 0) {
+#endif
+            bool failed = false, closed = false;
+            u32 p = bid;                                   // tiles [p, bid) are summed
+            u32 spins = 0;
+            // OS_LOOK tiles are polled at once (their loads are in flight together: one trip to memory per OS_LOOK tiles -- at
+            // the start of a launch a thousand resident tiles wait for their predecessors' counts, and a tile-by-tile walk
+            // would cost a microsecond per tile)
+            while (p > 0 && !closed && !failed) {
+                os_v4u v[OS_LOOK];
+#pragma unroll
+                for (int j = 0; j < OS_LOOK; ++j) {
+                    const u32 q = p > (u32)j ? p - 1 - (u32)j : 0u;      // (in front of tile 0: tile 0 again, never used)
+                    v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(q * 1024u + lane * 16u), 0, OS_AUX_SC1);
+                }
+                asm volatile("" ::: "memory");             // (every round reads memory again)
+                bool stalled = false;
+                u32 took = 0;
+#pragma unroll
+                for (int j = 0; j < OS_LOOK; ++j) {
+                    if (closed || stalled || (u32)j >= p) continue;
+                    const u32 f = v[j].x >> OS_FLAG_SHIFT;
+                    if (f == 0) { stalled = true; continue; }      // not published yet: poll again from this tile
+                    excl += v[j] & OS_VAL_MASK;
+                    ++took;
+                    if (f == 2) closed = true;
+                }
+                p -= took;
+                if (stalled) {
+                    if (++spins > OS_SPIN_LIMIT) { failed = true; atomicExch(err, 1u); }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(((excl + mine) & OS_VAL_MASK) | OS_FLAG_INCL, rsrc, (int)(bid * 1024u + lane * 16u), 0, OS_AUX_SC1);
+        }
+        *(os_v4u *)&dtot[4 * lane] = excl;
+    }
+    __syncthreads();
+    gbase[threadIdx.x] = gstart[threadIdx.x] + dtot[threadIdx.x] - dstart;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 d = (u32)(k[r] >> shift) & dmask;
+        if (l0 + (u32)r * 64 < n_tile) stage[cnt[w][d] + rank[r]] = k[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 p = (u32)r * RS_THREADS + threadIdx.x;
+        if (p < n_tile) { const u64 ko = stage[p]; keys_out[gbase[(u32)(ko >> shift) & dmask] + p] = ko; }
+    }
+}
+
+// radix_sort_keys in the one-sweep form: whole sorts of 2^20 <= n < 2^30 keys (*done = false: not taken, nothing was queued).
+// d_err: one word the caller zeroed and reads back at its next synchronisation (non-zero: a look-back gave up, the output is void).
+static int radix_sort_keys_onesweep(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64 n, int begin_bit, int nbits, u64 **res,
+                                    bool reverse_digits, u32 *d_err, bool *done) {
+    *done = false; *res = k0;
+    const int passes = (nbits + 7) / 8;
+    if (n < (1ULL << 20) || n >= (1ULL << OS_FLAG_SHIFT) || nbits <= 0 || passes > OS_MAX_PASSES) return LRGE_OK;
+    const u32 nb = (u32)div_up(n, RS_TILE);
+    OsPasses P; P.n = passes;
+    for (int p = 0; p < passes; ++p) {
+        const int d = reverse_digits ? passes - 1 - p : p;
+        P.shift[p] = begin_bit + d * 8;
+        P.dmask[p] = nbits - d * 8 >= 8 ? 255u : (1u << (nbits - d * 8)) - 1u;
+    }
+    // groups of 2^lg_group tiles per XCD (k_rs_onesweep): 8 G tickets must fit the device at once, with room to spare
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_rs_onesweep, RS_THREADS, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return LRGE_OK; }
+    u32 lg_group = (u32)ctx->opt_u64("ONESWEEP_LG_GROUP", 4);
+    while (lg_group > 0 && (8u << lg_group) * 2u > (u32)ctx->n_cu * (u32)per_cu) --lg_group;
+    ALLOC_OR_FAIL(ghist, sc, u32, (size_t)passes * 256 + 8 * OS_MAX_PASSES);     // + eight ticket counters per pass
+    ALLOC_OR_FAIL(state, sc, u32, (u64)256 * nb);
+    u32 *tickets = ghist + (size_t)passes * 256;
+    HIPCHK(ctx, hipMemsetAsync(ghist, 0, ((size_t)passes * 256 + 8 * OS_MAX_PASSES) * 4, ctx->stream));
+    hipLaunchKernelGGL(k_rs_hist_all, dim3(std::min<u32>(nb, (u32)ctx->n_cu * 8)), dim3(RS_THREADS), 0, ctx->stream, k0, n, P, ghist);
+    KCHK(ctx);
+    hipLaunchKernelGGL(k_rs_gscan, dim3(1), dim3(256), 0, ctx->stream, ghist, passes);
+    KCHK(ctx);
+    u64 *ki = k0, *ko = k1;
+    for (int p = 0; p < passes; ++p) {
+        HIPCHK(ctx, hipMemsetAsync(state, 0, (u64)256 * nb * 4, ctx->stream));
+        {
+            StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+            hipLaunchKernelGGL(k_rs_onesweep, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, ko, n, P.shift[p], P.dmask[p], ghist + (size_t)p * 256, state,
+                               nb, lg_group, tickets + 8 * p, d_err);
+            KCHK(ctx);
+            ts.stop();
+            ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
+            ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;
+            ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 16 * n;
+        }
+        u64 *t = ki; ki = ko; ko = t;
+    }
+    sc.drop(ghist); sc.drop(state);
+    *res = ki; *done = true;
     return LRGE_OK;
 }
 

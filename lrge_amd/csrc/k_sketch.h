@@ -178,92 +178,185 @@ struct MinWindow {  // shift-register form of mm_sketch's ring buffer + running 
     }
 };
 
+// ---- homopolymer-compressed sketch (ava-pb): the steps of mm_sketch's loop as bits ----
+// With HPC a step of the scalar loop is a whole homopolymer run (or one ambiguous base).  Scanned base by base -- "while the
+// next base equals this one" -- the lanes of a wavefront wait for the longest run among them at every step (~4 bases for
+// random sequence) and pay a word lookup per base.  Here the steps of a 32-base word are found at once: bit 2j of `starts`
+// is set when base j begins a step (it differs from base j - 1, or either of them is ambiguous), ~10 operations per word,
+// and the loop goes from set bit to set bit: the run's length is the distance to the next one.
+#define SK_EVEN 0x5555555555555555ULL
+__device__ __forceinline__ u64 spread32(u32 m) {      // bit j -> bit 2j
+    u64 x = m;
+    x = (x | x << 16) & 0x0000FFFF0000FFFFULL;
+    x = (x | x << 8) & 0x00FF00FF00FF00FFULL;
+    x = (x | x << 4) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | x << 2) & 0x3333333333333333ULL;
+    x = (x | x << 1) & SK_EVEN;
+    return x;
+}
+struct RunWords {
+    const u64 *pack; const u32 *nmask; i32 len;
+    u64 w, ns, starts;      // the current word: codes, ambiguity mask (bit 2j), step starts (bit 2j), clipped to the read
+    __device__ __forceinline__ void init(const u64 *p, const u32 *nm, u64 word_base, i32 l) { pack = p + word_base; nmask = nm + word_base; len = l; }
+    // prev2 / prevN: code and ambiguity of the last base of word wi - 1 (wi == 0: prevN = true, base 0 always starts a step)
+    __device__ __forceinline__ void set(i32 wi, u64 word, u32 m, u64 prev2, bool prevN) {
+        w = word;
+        ns = m ? spread32(m) : 0ULL;
+        const u64 x = w ^ (w << 2 | prev2);
+        u64 eq = ~(x | x >> 1) & SK_EVEN;
+        eq &= ~(ns | ns << 2 | (prevN ? 1ULL : 0ULL));
+        starts = ~eq & SK_EVEN;
+        const i32 nvalid = len - wi * 32;
+        if (nvalid < 32) starts &= (1ULL << (2 * nvalid)) - 1;
+    }
+    __device__ __forceinline__ void load(i32 wi) {                 // random access: fetches word wi - 1 too
+        u64 prev2 = 0; bool prevN = true;
+        if (wi > 0) { prev2 = pack[wi - 1] >> 62; prevN = (nmask[wi - 1] >> 31) != 0; }
+        set(wi, pack[wi], nmask[wi], prev2, prevN);
+    }
+    __device__ __forceinline__ void next(i32 wi) {                 // word wi, the current one being wi - 1
+        const u64 prev2 = w >> 62; const bool prevN = (ns >> 62) != 0;
+        set(wi, pack[wi], nmask[wi], prev2, prevN);
+    }
+    __device__ __forceinline__ u32 code(u32 bit) const { return ((ns >> bit) & 1) ? 4u : (u32)((w >> bit) & 3); }
+};
+
+template <int K, int W, typename Emit>
+__device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nmask, u64 word_base, i32 len, u32 rid, i32 s, i32 e, Emit &&emit) {
+    constexpr u64 mask = (1ULL << (2 * K)) - 1;
+    constexpr int shift1 = 2 * (K - 1);
+    constexpr int HALO = W + K - 1;
+    static_assert(K <= 24, "run-length shift register holds 24 runs");
+    if (len <= 0) return;
+    RunWords rw; rw.init(pack, nmask, word_base, len);
+    // ---- the first owned step: the first one that STARTS in [s, e) ----
+    i32 wi = s >> 5;
+    rw.load(wi);
+    u64 m = rw.starts & ~((1ULL << (2 * (s & 31))) - 1);
+    i32 p = len;
+    for (;;) {
+        if (m) { p = wi * 32 + (i32)(__builtin_ctzll(m) >> 1); break; }
+        ++wi;
+        if (wi * 32 >= len) break;
+        rw.next(wi); m = rw.starts;
+    }
+    if (p >= e || p >= len) {
+        // this chunk starts no step; it still owns the end-of-read flush if it holds the last base
+        if (!(e == len && s < len)) return;
+    }
+    s = p;
+    // ---- replay start h: HALO steps before it ----
+    i32 h = 0;
+    if (p > 0) {
+        i32 wb = (p - 1) >> 5;
+        if (wb != wi || p >= len) rw.load(wb);
+        u64 mb = rw.starts;
+        if ((p >> 5) == wb) mb &= (1ULL << (2 * (p & 31))) - 1;
+        int need = HALO;
+        for (;;) {
+            const int c = __popcll(mb);
+            if (c >= need) {
+                for (int t = 1; t < need; ++t) mb &= ~(1ULL << (63 - __builtin_clzll(mb)));
+                h = wb * 32 + ((63 - __builtin_clzll(mb)) >> 1);
+                break;
+            }
+            need -= c;
+            if (wb == 0) break;                              // fewer than HALO steps in front: from the start of the read
+            --wb; rw.load(wb); mb = rw.starts;
+        }
+    }
+    // ---- forward from h ----
+    MinWindow<W, u64, u32> win; win.init();
+    u64 kf = 0, kr = 0;
+    int l = 0, kmer_span = 0;
+    // lengths of the last K runs as a byte shift register in VGPRs (a ring indexed at run time would live in scratch memory);
+    // byte 0 = newest, byte K-1 = the run that leaves the k-mer at the next push, 0 while fewer than K runs are held
+    u32 hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0, hq4 = 0, hq5 = 0;
+    (void)hq3; (void)hq4; (void)hq5;
+    wi = h >> 5;
+    rw.load(wi);
+    m = rw.starts & ~((1ULL << (2 * (h & 31))) - 1);          // (its lowest bit is h itself)
+    i32 ppos = h; u32 pc = rw.code(2 * (h & 31));
+    m &= m - 1;
+    for (;;) {
+        // the next step's start = the end of the pending run
+        i32 nxt = len; u32 ncode = 4;
+        for (;;) {
+            if (m) { const u32 b = (u32)__builtin_ctzll(m); nxt = wi * 32 + (i32)(b >> 1); ncode = rw.code(b); m &= m - 1; break; }
+            ++wi;
+            if (wi * 32 >= len) break;
+            rw.next(wi); m = rw.starts;
+        }
+        if (ppos >= e) break;                                  // steps starting at or beyond e belong to later chunks
+        u64 ix = ~0ULL; u32 iy = ~0u;
+        if (pc < 4) {
+            const i32 run = nxt - ppos;
+            const i32 i = nxt - 1;                               // last base of the run
+            const int rl = run > 255 ? 255 : run;                // spans >= 256 invalidate the k-mer anyway
+            {
+                constexpr int OW = (K - 1) / 4, OB = ((K - 1) % 4) * 8;      // where byte K-1 sits
+                const u32 ow = OW == 0 ? hq0 : OW == 1 ? hq1 : OW == 2 ? hq2 : OW == 3 ? hq3 : OW == 4 ? hq4 : hq5;
+                const int oldest = (int)((ow >> OB) & 0xff);
+                hq5 = hq5 << 8 | hq4 >> 24; hq4 = hq4 << 8 | hq3 >> 24; hq3 = hq3 << 8 | hq2 >> 24;
+                hq2 = hq2 << 8 | hq1 >> 24; hq1 = hq1 << 8 | hq0 >> 24; hq0 = hq0 << 8 | (u32)rl;
+                kmer_span += rl - oldest;
+            }
+            kf = (kf << 2 | pc) & mask;
+            kr = (kr >> 2) | (u64)(3 ^ pc) << shift1;
+            // K is odd for both presets, so kf == kr (strand-symmetric k-mer) cannot happen
+            const u32 z = kf < kr ? 0 : 1;
+            ++l; if (l > W + K) l = W + K;                       // only thresholds up to W+K are ever tested
+            if (l >= K && kmer_span < 256) { ix = mm_hash64(z ? kr : kf, mask) << 8 | (u64)kmer_span; iy = (u32)i << 1 | z; }
+        } else { l = 0; hq0 = hq1 = hq2 = hq3 = hq4 = hq5 = 0; kmer_span = 0; }
+        const bool owned = ppos >= s;
+        win.template step<K>(ix, iy, l, [&](u64 x, u32 y) { if (owned) emit(x, (u64)rid << 32 | (u64)y); });
+        if (nxt >= len) break;
+        ppos = nxt; pc = ncode;
+    }
+    if (e == len && win.minx != win.NONE) emit(win.minx, (u64)rid << 32 | (u64)win.miny);  // final flush by the last chunk
+}
+
 // Runs the state machine over one chunk.  Emission callback is only invoked for owned steps.
 template <int K, int W, bool HPC, typename Emit>
 __device__ __forceinline__ void sketch_chunk(const u64 *pack, const u32 *nmask, u64 word_base, i32 len, u32 rid,
                                              i32 s, i32 e, Emit &&emit) {
+    if constexpr (HPC) { sketch_chunk_hpc<K, W>(pack, nmask, word_base, len, rid, s, e, emit); return; }
     constexpr u64 mask = (1ULL << (2 * K)) - 1;
     constexpr int shift1 = 2 * (K - 1);
     constexpr int HALO = W + K - 1;
-    constexpr bool NARROW = !HPC && 2 * K <= 32;
+    constexpr bool NARROW = 2 * K <= 32;
     using XT = typename std::conditional<NARROW, u32, u64>::type;
     BaseReader rd; rd.init(pack, nmask, word_base);
-    MinWindow<W, XT, XT> win; win.init();
+    MinWindow<W, XT, u32> win; win.init();          // y = pos << 1 | strand; the read id is constant inside a read
     XT kf = 0, kr = 0;
     // narrow values -> the (x, y) pair the callers expect
-    auto emit_xy = [&](XT x, XT y) {
-        if (NARROW) emit((u64)x << 8 | (u64)K, (u64)rid << 32 | (u64)y);
-        else emit((u64)x, (u64)y);
+    auto emit_xy = [&](XT x, u32 y) {
+        if (NARROW) emit((u64)x << 8 | (u64)K, (u64)rid << 32 | (u64)y);      // (the span is always k for a valid k-mer)
+        else emit((u64)x, (u64)rid << 32 | (u64)y);
     };
     int l = 0;
-    // HPC: lengths of the last K runs as a byte shift register in VGPRs (a ring indexed at run time would live
-    // in scratch memory); byte 0 = newest, byte K-1 = the run that leaves the k-mer at the next push, 0 while
-    // fewer than K runs are held
-    static_assert(K <= 24, "run-length shift register holds 24 runs");
-    u32 hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0, hq4 = 0, hq5 = 0;
-    int kmer_span = 0;
-    (void)hq0; (void)hq1; (void)hq2; (void)hq3; (void)hq4; (void)hq5;
-
-    // ---- find the replay start h: HALO steps before the first owned step ----
-    i32 h;
-    if (!HPC) {
-        h = s - HALO; if (h < 0) h = 0;
-    } else {
-        // first owned step = first run (or N) that STARTS in [s, e)
-        i32 p = s;
-        if (p > 0) {  // skip the tail of a run that began before s
-            u32 prev = rd.get(p - 1);
-            if (prev < 4) { while (p < len && rd.get(p) == prev) ++p; }
-        }
-        if (p >= e || p >= len) {
-            // this chunk starts no step; it still owns the end-of-read flush if it holds the last base
-            if (!(e == len && s < len)) return;
-        }
-        s = p;  // first owned step start (may be >= e: then only the final flush can be ours)
-        // walk back HALO steps
-        h = s;
-        int steps = 0;
-        while (h > 0 && steps < HALO) {
-            u32 c = rd.get(h - 1);
-            --h;
-            if (c < 4) { while (h > 0 && rd.get(h - 1) == c) --h; }
-            ++steps;
-        }
-    }
-
+    i32 h = s - HALO; if (h < 0) h = 0;
     i32 i = h;
     while (i < len) {
         if (i >= e) break;  // steps starting at or beyond e belong to later chunks
         const i32 step_start = i;
-        u32 c = rd.get(i);
-        XT ix = (XT)~(XT)0, iy = (XT)~(XT)0;
+        const u32 c = rd.get(i);
+        XT ix = (XT)~(XT)0; u32 iy = ~0u;
         if (c < 4) {
-            if (HPC) {
-                i32 run = 1;
-                while (i + run < len && rd.get(i + run) == c) ++run;
-                i += run - 1;  // i = last base of the run
-                int rl = run > 255 ? 255 : run;  // spans >= 256 invalidate the k-mer anyway
-                {
-                    constexpr int OW = (K - 1) / 4, OB = ((K - 1) % 4) * 8;      // where byte K-1 sits
-                    const u32 ow = OW == 0 ? hq0 : OW == 1 ? hq1 : OW == 2 ? hq2 : OW == 3 ? hq3 : OW == 4 ? hq4 : hq5;
-                    const int oldest = (int)((ow >> OB) & 0xff);
-                    hq5 = hq5 << 8 | hq4 >> 24; hq4 = hq4 << 8 | hq3 >> 24; hq3 = hq3 << 8 | hq2 >> 24;
-                    hq2 = hq2 << 8 | hq1 >> 24; hq1 = hq1 << 8 | hq0 >> 24; hq0 = hq0 << 8 | (u32)rl;
-                    kmer_span += rl - oldest;
-                }
-            } else kmer_span = l + 1 < K ? l + 1 : K;
+            const int kmer_span = l + 1 < K ? l + 1 : K;
             kf = (XT)((kf << 2 | c) & (XT)mask);
             kr = (XT)((kr >> 2) | (XT)(3 ^ c) << shift1);
             // K is odd for both presets, so kf == kr (strand-symmetric k-mer) cannot happen
             const u32 z = kf < kr ? 0 : 1;
             ++l; if (l > W + K) l = W + K;  // only thresholds up to W+K are ever tested
-            if (l >= K && kmer_span < 256) {
-                if (NARROW) { ix = (XT)mm_hash32((u32)(z ? kr : kf), (u32)mask); iy = (XT)((u32)i << 1 | z); }   // (kmer_span == K here)
-                else { ix = (XT)(mm_hash64(z ? kr : kf, mask) << 8 | (u64)kmer_span); iy = (XT)((u64)rid << 32 | (u64)(u32)i << 1 | z); }
+            if (l >= K) {
+                if (NARROW) ix = (XT)mm_hash32((u32)(z ? kr : kf), (u32)mask);   // (kmer_span == K here)
+                else ix = (XT)(mm_hash64(z ? kr : kf, mask) << 8 | (u64)kmer_span);
+                iy = (u32)i << 1 | z;
             }
-        } else { l = 0; hq0 = hq1 = hq2 = hq3 = hq4 = hq5 = 0; kmer_span = 0; }
+        } else l = 0;
         const bool owned = step_start >= s;
-        win.template step<K>(ix, iy, l, [&](XT x, XT y) { if (owned) emit_xy(x, y); });
+        win.template step<K>(ix, iy, l, [&](XT x, u32 y) { if (owned) emit_xy(x, y); });
         ++i;
     }
     if (e == len && win.minx != win.NONE) emit_xy(win.minx, win.miny);  // final flush by the last chunk

@@ -275,7 +275,8 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 nb) {
 }
 
 // DB: digit bits (8, or 10: three passes instead of four over a 30-bit hash; the runs a tile writes per digit shrink from 16 to 4
-// keys, which the L2 of the tile's XCD puts together with the neighbouring tiles' -- see xcd_tile)
+// keys.  MEASURED: one 10-bit pass 0.58 + 0.15 + 1.33 ms against 0.43 + 0.05 + 0.88, the whole sort 5.8 against 5.0 ms -- the
+// index build stays with 8)
 template <bool SEG, int DB = 8>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
                                                         u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255) {
@@ -561,6 +562,12 @@ static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64
 // the writer's or the reader's own L1 / XCD L2), so no ordering between separate words is needed.  Tiles are handed out by a
 // ticket counter: a tile only ever waits for tiles with smaller tickets, which are resident -- no deadlock whatever the
 // dispatch order.  A poll that runs into OS_SPIN_LIMIT raises *err and gives up (the caller reports it; nothing hangs).
+// MEASURED (tools/micro/sort_bench.hip, 242 M keys, 30-bit hash): exact, and SLOWER than the three-kernel passes -- 6.0-6.3 ms
+// against 4.9-5.2.  With the tiles' positions handed to it ready-made the pass runs at the scatter's own 0.88 ms (so the XCD
+// grouping of the tickets keeps the write locality: without it 1.22 ms); what it loses is the wait: a tile is ready to write
+// ~8 us after it starts and then sits on its LDS and registers for ~10 us more until the counts of the ~100 tiles in front
+// have been published and walked (8 tiles per trip to memory), 1.45 ms per pass against 0.43 + 0.05 + 0.88.  NOT used by the
+// index build; kept with its bench as the record of the attempt.
 // ------------------------------------------------------------------------------------------
 #define OS_FLAG_SHIFT 30
 #define OS_FLAG_AGG (1u << OS_FLAG_SHIFT)
@@ -614,7 +621,7 @@ typedef unsigned int os_v4u __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(RS_THREADS) void k_rs_onesweep(const u64 *__restrict__ keys_in, u64 *__restrict__ keys_out, u64 n, int shift, u32 dmask,
                                                             const u32 *__restrict__ gstart /* [256]: first output index of every digit */,
- u32 *__restrict__ state, u32 nb, u32 lg_group, u32 *__restrict__ ticket, u32 *__restrict__ err) {
+                                                            u32 *__restrict__ state, u32 nb, u32 lg_group, u32 *__restrict__ ticket, u32 *__restrict__ err) {
     __shared__ u32 cnt[RS_WAVES][256];
     __shared__ u32 gbase[256];
     __shared__ u32 dtot[256];            // the tile's digit counts, then (wave 0) the counts of the tiles in front of it
@@ -673,9 +680,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_onesweep(const u64 *__restric
 #pragma unroll
         for (int ww = 0; ww < RS_WAVES; ++ww) { cnt[ww][d] = run; run += c[ww]; }
     }
-#ifdef OS_DEBUG_PRESCANNED      // (micro-benchmark: tile starts from the scanned histogram of k_rs_hist, passed as `state`; no look-back)
-    if (true) { dtot[threadIdx.x] = state[(u64)threadIdx.x * nb + bid] - gstart[threadIdx.x]; } else
-#endif
     if (w == 0) {
         // Wave 0 publishes and looks back for the whole tile: lane l owns digits 4 l .. 4 l + 3, ONE 16-byte word of the tile's
         // state row, stored and polled write-through / L2-bypassing (sc1) -- a quarter of the transactions of a word per
@@ -685,11 +689,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_onesweep(const u64 *__restric
         const u32 flag0 = bid == 0 ? OS_FLAG_INCL : OS_FLAG_AGG;
         __builtin_amdgcn_raw_buffer_store_b128(mine | flag0, rsrc, (int)(bid * 1024u + lane * 16u), 0, OS_AUX_SC1);
         os_v4u excl = {0u, 0u, 0u, 0u};
-#ifdef OS_DEBUG_NO_LOOKBACK
-        if (false) {
-#else
         if (bid > 0) {
-#endif
             bool failed = false, closed = false;
             u32 p = bid;                                   // tiles [p, bid) are summed
             u32 spins = 0;

@@ -28,54 +28,78 @@ __device__ __forceinline__ u32 nt4_code(u32 c) {
 }
 
 #define PACK_THREADS 256
-#define PACK_WORDS (PACK_THREADS / 2)     // words per block
+#define PACK_ITEMS 4                                       // 16-base pieces per lane
+#define PACK_WORDS (PACK_THREADS / 2 * PACK_ITEMS)         // words per block
+#define PACK_LREADS 63                                     // reads whose offsets a block keeps in LDS
 // Two lanes per 32-base word of the packed image, 16 bases each: the lanes of a wavefront read consecutive 16-byte pieces
 // of the ASCII (one coalesced 1 KB run per load wherever a read continues), convert them to 32 bits + a 16-bit mask, and
 // the even lane writes the word after one exchange with its neighbour.  `blk_read[b]` (computed on the host with the
-// word offsets) is the read that holds the first word of block b, so a lane finds its read with a short forward scan
-// instead of a binary search.
+// word offsets) is the read that holds the first word of block b; the block fetches the offsets of that read and the
+// PACK_LREADS after it into LDS in ONE round of loads, every lane finds the reads of its PACK_ITEMS pieces there, and all its
+// ASCII loads are in flight together.  (One piece per lane behind a chain of four dependent global loads -- block's read,
+// next read's first word, base offsets, bases -- ran at 0.66 TB/s: latency, not bytes.)
 __global__ __launch_bounds__(PACK_THREADS) void k_pack(const u8 *__restrict__ ascii, const u64 *__restrict__ boff,
                                                        const u64 *__restrict__ woff, const u32 *__restrict__ blk_read, u32 n_reads,
                                                        u64 n_words, u64 *__restrict__ pack, u32 *__restrict__ nmask) {
-    const u64 wid = (u64)blockIdx.x * PACK_WORDS + (threadIdx.x >> 1);
+    __shared__ u64 s_woff[PACK_LREADS + 1], s_boff[PACK_LREADS + 1];
+    const u32 r0 = blk_read[blockIdx.x];
+    const u32 nl = n_reads + 1 - r0 < PACK_LREADS + 1 ? n_reads + 1 - r0 : PACK_LREADS + 1;      // entries r0 .. r0 + nl - 1 of the offset arrays
+    if (threadIdx.x < nl) { s_woff[threadIdx.x] = woff[r0 + threadIdx.x]; s_boff[threadIdx.x] = boff[r0 + threadIdx.x]; }
+    __syncthreads();
     const u32 half = threadIdx.x & 1;
-    const bool in = wid < n_words;
-    u32 bits = 0, m = 0xffffu;
-    if (in) {
-        u32 r = blk_read[blockIdx.x];
-        while (r + 1 < n_reads && woff[r + 1] <= wid) ++r;          // (empty reads own no word and are stepped over)
-        const u64 pos0 = (wid - woff[r]) * 32 + 16 * half;
-        const u64 b0 = boff[r], len = boff[r + 1] - b0;
-        const u8 *src = ascii + b0 + pos0;
-        const u32 cnt = pos0 >= len ? 0u : (u32)(len - pos0 < 16 ? len - pos0 : 16);
-        u32 v[4] = {0, 0, 0, 0};
-        if (cnt == 16) {
-            uint4 q;
-            __builtin_memcpy(&q, src, 16);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {                                                        // the last word of a read: never read past its end
+    u64 wid[PACK_ITEMS]; const u8 *src[PACK_ITEMS]; u32 cnt[PACK_ITEMS];
+    uint4 q[PACK_ITEMS];
+#pragma unroll
+    for (int it = 0; it < PACK_ITEMS; ++it) {
+        wid[it] = (u64)blockIdx.x * PACK_WORDS + (u32)it * (PACK_THREADS / 2) + (threadIdx.x >> 1);
+        cnt[it] = 0; src[it] = ascii; q[it] = make_uint4(0, 0, 0, 0);
+        if (wid[it] < n_words) {
+            // the read that holds the word: the last cached one whose first word is <= wid (empty reads own no word and are stepped over)
+            u32 lo = 0, hi = nl - 1;                               // (entry nl - 1 may be the terminator woff[n_reads] = n_words > wid)
+            while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_woff[mid] <= wid[it]) lo = mid; else hi = mid - 1; }
+            u64 w0 = s_woff[lo], b0 = s_boff[lo], b1;
+            if (lo + 1 < nl) b1 = s_boff[lo + 1];
+            else {                                                  // past the cached reads (a run of tiny reads): the slow way
+                u32 r = r0 + lo;
+                while (r + 1 < n_reads && woff[r + 1] <= wid[it]) ++r;
+                w0 = woff[r]; b0 = boff[r]; b1 = boff[r + 1];
+            }
+            const u64 pos0 = (wid[it] - w0) * 32 + 16 * half, len = b1 - b0;
+            src[it] = ascii + b0 + pos0;
+            cnt[it] = pos0 >= len ? 0u : (u32)(len - pos0 < 16 ? len - pos0 : 16);
+            if (cnt[it] == 16) __builtin_memcpy(&q[it], src[it], 16);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < PACK_ITEMS; ++it) {
+        const bool in = wid[it] < n_words;
+        u32 bits = 0, m = 0xffffu;
+        if (in) {
+            u32 v[4] = {q[it].x, q[it].y, q[it].z, q[it].w};
+            if (cnt[it] < 16) {                                     // the last word of a read: never read past its end
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { const u32 i = 4 * j + t; if (i < cnt[it]) v[j] |= (u32)src[it][i] << (8 * t); }
+                }
+            }
+            m = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { const u32 i = 4 * j + t; if (i < cnt) v[j] |= (u32)src[i] << (8 * t); }
+                for (int t = 0; t < 4; ++t) {
+                    const u32 c = nt4_code((v[j] >> (8 * t)) & 0xffu);
+                    bits |= (c & 3) << (2 * (4 * j + t));
+                    m |= (c >> 2) << (4 * j + t);
+                }
             }
+            if (cnt[it] < 16) { m |= 0xffffu & (~0u << cnt[it]); bits &= cnt[it] ? (~0u >> (32 - 2 * cnt[it])) : 0u; }   // padding past the end is "ambiguous"
         }
-        m = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const u32 c = nt4_code((v[j] >> (8 * t)) & 0xffu);
-                bits |= (c & 3) << (2 * (4 * j + t));
-                m |= (c >> 2) << (4 * j + t);
-            }
+        const u32 obits = (u32)__shfl_xor((i32)bits, 1, 64), om = (u32)__shfl_xor((i32)m, 1, 64);
+        if (in && half == 0) {
+            pack[wid[it]] = (u64)bits | (u64)obits << 32;
+            nmask[wid[it]] = (m & 0xffffu) | om << 16;
         }
-        if (cnt < 16) { m |= 0xffffu & (~0u << cnt); bits &= cnt ? (~0u >> (32 - 2 * cnt)) : 0u; }   // padding past the end is "ambiguous"
-    }
-    const u32 obits = (u32)__shfl_xor((i32)bits, 1, 64), om = (u32)__shfl_xor((i32)m, 1, 64);
-    if (in && half == 0) {
-        pack[wid] = (u64)bits | (u64)obits << 32;
-        nmask[wid] = (m & 0xffffu) | om << 16;
     }
 }
 

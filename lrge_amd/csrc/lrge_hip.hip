@@ -1195,7 +1195,6 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         }
     }
     bool fused = false; u64 *own_hashes = nullptr; u64 n_own = 0;
-    bool presk_deferred = false;
     struct PreparedGuard { lrge_hip_ctx *c; ~PreparedGuard() { presketch_drop_prepared(c); } } prepared_guard{ctx};   // (an error between the two steps)
     if (sharded) {
         // this rank sketches its own share of the targets; key sets, kept entries and owned hashes travel (k_route.h)
@@ -1222,17 +1221,6 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     }
     if (!fused) {
         rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits);
-        if (rc == LRGE_OK && !ctx->opt("NO_PRESKETCH")) {
-            // the streamed set's sketch goes to the side stream right behind this one -- unless its host-side pack is still running
-            // on the uploader thread: waiting for that here would leave the GPU idle, so only the fork point is marked now and the
-            // launch follows once the index sort has been queued (the side stream still starts behind the index sketch)
-            rc = presketch_prepare(ctx, targets->total_bases);
-            lrge_hip_seqset *S = ctx->presk_prepared_set;
-            bool running = false;
-            if (S && S->job) { std::lock_guard<std::mutex> lk(S->job->mu); running = !S->job->done; }
-            if (running) presk_deferred = true;
-            else if (rc == LRGE_OK) rc = presketch_launch_prepared(ctx);
-        }
         if (rc) return rc;
         sc.drop(so.mz_off);
     }
@@ -1385,7 +1373,15 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         }
         t.stop();
     }
-    if (presk_deferred) { rc = presketch_launch_prepared(ctx); if (rc) return rc; }
+    if (!fused && !ctx->opt("NO_PRESKETCH")) {
+        // The streamed set's sketch goes to the side stream here, beside the table build (its memory is taken here too: the arena
+        // recycles in main-stream order).  It is VALU-bound at the full issue rate, so it hides little wherever it runs -- beside
+        // the first sort passes (rounds 2-3) those went from 0.43 + 0.86 to 1.23 + 2.17 ms, beside the run-head and placement
+        // passes these go from 3.2 to 5.5 ms: ~0.7 of its 2.9 ms either way (C4) -- but here the host never has to wait for the
+        // set's upload job with nothing queued behind it.
+        rc = presketch_start_pending(ctx, targets->total_bases);
+        if (rc) return rc;
+    }
     const bool pk_t = pk || seg_packed;          // what the table build and the lookups see: one packed word per entry
 
     lrge_hip_index *ix = new lrge_hip_index();

@@ -143,10 +143,6 @@ int main(int argc, char **argv) {
             hipLaunchKernelGGL(k_rs_gscan, dim3(1), dim3(256), 0, ctx.stream, gh, 4);
             (void)hipEventRecord(e[2], ctx.stream);
             (void)hipMemsetAsync(state, 0, (u64)256 * nb * 4, ctx.stream);
-#ifdef OS_DEBUG_PRESCANNED
-            hipLaunchKernelGGL((k_rs_hist<false, 8>), dim3(nb), dim3(RS_THREADS), 0, ctx.stream, k0, n, P.shift[1], nb, state, (const SegTile *)nullptr, 255u);
-            (void)scan_exclusive_u32(&ctx, sc, state, state, (u64)256 * nb, nullptr);
-#endif
             (void)hipEventRecord(e[3], ctx.stream);
             hipLaunchKernelGGL(k_rs_onesweep, dim3(nb), dim3(RS_THREADS), 0, ctx.stream, k0, k1, n, P.shift[1], P.dmask[1], gh + 256, state, nb, (u32)rep + 3, gh + 1024, gh + 1032);
             (void)hipEventRecord(e[4], ctx.stream);

@@ -194,7 +194,7 @@ struct UploadJob {
     std::mutex mu; std::condition_variable cv; bool done = false; int rc = 0; std::string err;
     // chunk gates: chunk j of the packed image -- words [.., gate_w1[j]) -- is on its way once gate_ev[j] has been RECORDED on the
     // copy stream (gates_recorded > j); a consumer that waits for that event on the device may work on those words while
-    // the later chunks are still being packed (the index sketch does: lrge_hip.hip, sketch_launch)
+    // the later chunks are still being packed (the index sketch does: host_sketch.inl, sketch_launch)
     std::vector<hipEvent_t> gate_ev; std::vector<u64> gate_w1; int gates_recorded = 0;
     void gate_recorded() { { std::lock_guard<std::mutex> lk(mu); ++gates_recorded; } cv.notify_all(); }
     // true when gate j has been recorded; false when the job ended (failed) before it

@@ -1,0 +1,293 @@
+// host_sketch.inl -- part of lrge_hip.hip (one translation unit; included there, in this order): the sketch driver: one-pass / two-pass / gated launches of k_sketch.h, and the presketch of a streamed set on the side stream.
+// ------------------------------------------------------------------------------------------
+// sketch driver
+// ------------------------------------------------------------------------------------------
+struct SketchOut {
+    u64 *x = nullptr, *y = nullptr;   // pool memory (owned by the caller's Scratch)
+    u32 *mz_off = nullptr;            // [n+1] per-read offsets
+    u64 n = 0;
+};
+
+// pk_ybits != 0 (index only): packed 8-byte entries in o->x, o->y stays null (k_sketch.h PK)
+template <int K, int W, bool HPC>
+static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o, u32 pk_pos1, u32 pk_ybits,
+                         std::vector<u32> *h_mzoff, bool gated = false) {
+    // gated: the caller has NOT waited for the set's upload (seqset_ready): this function does, as late as it can
+    if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
+    u32 n_chunks = (u32)s->n_chunks;
+    const u32 *d_cs = s->d_cs;           // chunk map, uploaded with the set
+    const bool pk = index_keys && pk_ybits;
+    ALLOC_OR_FAIL(d_cnt, sc, u32, (size_t)n_chunks + 1);
+    ALLOC_OR_FAIL(d_total, sc, u32, 2);  // [1] = overflow flag of the one-pass form
+    ALLOC_OR_FAIL(d_mzoff, sc, u32, (size_t)s->n + 1);
+    ChunkMap cm{d_cs, s->n};
+    const dim3 sgrid((u32)div_up(n_chunks, SK_THREADS));
+    // One pass (k_sketch_direct into per-chunk slots, then k_sketch_compact) when the slots fit comfortably; the
+    // two-pass form (count, scan, write) otherwise, when a chunk overflows its slot, or on request.
+    const u64 slot_bytes = (u64)n_chunks * SK_CAP * 8 * (pk ? 1 : 2);
+    size_t mfree = (size_t)64 << 30, mtot = 0;
+    if (slot_bytes > ((u64)4 << 30)) (void)hipMemGetInfo(&mfree, &mtot);       // (small sets: no need to ask)
+    bool one_pass = n_chunks && !ctx->opt("SKETCH_TWO_PASS") && slot_bytes < ((u64)mfree + ctx->pool.idle()) / 4;
+    const char *cap_env = ctx->opt("DEBUG_SK_CAP");                      // tests: force the overflow fallback
+    const u32 sk_cap = cap_env ? (u32)std::min<u64>(strtoull(cap_env, nullptr, 10), SK_CAP) : (u32)SK_CAP;
+    u64 *tx = nullptr, *ty = nullptr;
+    if (one_pass) {
+        tx = sc.get<u64>((size_t)n_chunks * SK_CAP);
+        ty = pk ? nullptr : sc.get<u64>((size_t)n_chunks * SK_CAP);
+        if (!tx || (!pk && !ty)) { if (tx) sc.drop(tx); if (ty) sc.drop(ty); tx = ty = nullptr; one_pass = false; (void)hipGetLastError(); }
+    }
+    u32 tot_ovf[2] = {0, 0};
+    for (int pass = 0; pass < 2; ++pass) {       // second round only after a slot overflow
+        HIPCHK(ctx, hipMemsetAsync(d_total, 0, 8, ctx->stream));
+        if (n_chunks) {
+            if (one_pass && gated && pass == 0) {
+                // the set's upload is still in flight (host-side pack, chunk after chunk): the sketch chunks that lie wholly inside
+                // the words of upload chunk j run behind gate j, while the later chunks are still being packed and sent
+                lrge_hip_seqset *ms = const_cast<lrge_hip_seqset *>(s);
+                std::shared_ptr<UploadJob> job = ms->job;
+                u32 c_prev = 0;
+                const size_t ng = job->gate_w1.size();
+                for (size_t j = 0; j < ng; ++j) {
+                    if (!job->wait_gate((int)j)) break;                          // (the job failed: seqset_ready below reports it)
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, job->gate_ev[j], 0));
+                    const u64 w1 = job->gate_w1[j];
+                    u32 c_end = n_chunks;
+                    if (w1 < s->n_words) {
+                        const u32 r = (u32)(std::upper_bound(s->h_woff.begin(), s->h_woff.end(), w1) - s->h_woff.begin()) - 1;
+                        const u64 avail = w1 - s->h_woff[r];                      // words of read r that have arrived: 4 per 128-base chunk
+                        c_end = s->h_cs[r] + (u32)std::min<u64>(avail / (SK_CHUNK / 32), (u64)(s->h_cs[r + 1] - s->h_cs[r]));
+                    }
+                    if (c_end > c_prev) {
+                        const dim3 g((u32)div_up(c_end - c_prev, SK_THREADS));
+                        if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
+                                                   s->d_woff, s->d_len, cm, c_end, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap, c_prev);
+                        else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
+                                                s->d_nmask, s->d_woff, s->d_len, cm, c_end, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap, c_prev);
+                        KCHK(ctx);
+                        c_prev = c_end;
+                    }
+                }
+                int rr = seqset_ready(ctx, s); if (rr) return rr;
+                if (c_prev < n_chunks) {                                          // (whatever a failed / odd gate sequence left)
+                    const dim3 g((u32)div_up(n_chunks - c_prev, SK_THREADS));
+                    if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
+                                               s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap, c_prev);
+                    else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
+                                            s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap, c_prev);
+                    KCHK(ctx);
+                }
+            } else if (one_pass) {
+                if (gated && pass == 0) { int rr = seqset_ready(ctx, s); if (rr) return rr; }
+                if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
+                                           s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap);
+                else if (index_keys) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
+                                                        s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap);
+                else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, false, false>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
+                                        s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap);
+            } else {
+                if (gated && pass == 0) { int rr = seqset_ready(ctx, s); if (rr) return rr; }
+                hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm,
+                                   n_chunks, d_cnt);
+            }
+            KCHK(ctx);
+            int rc = scan_exclusive_u32(ctx, sc, d_cnt, d_cnt, n_chunks, d_total);
+            if (rc) return rc;
+        }
+        // per-read offsets follow from the chunk scan alone: they travel to the host with the total, in the one sync
+        hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, ctx->stream, d_cs, d_cnt, s->n,
+                           n_chunks, d_total, d_mzoff);
+        KCHK(ctx);
+        HIPCHK(ctx, ctx->d2h(tot_ovf, d_total, 8, ctx->stream));
+        if (h_mzoff) {
+            h_mzoff->resize((size_t)s->n + 1);
+            HIPCHK(ctx, ctx->d2h(h_mzoff->data(), d_mzoff, ((size_t)s->n + 1) * 4, ctx->stream));
+        }
+        HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+        if (!(one_pass && tot_ovf[1])) break;
+        one_pass = false;                        // a chunk held more than SK_CAP minimizers: redo in two passes
+        sc.drop(tx); if (ty) sc.drop(ty); tx = ty = nullptr;
+    }
+    const u32 total = tot_ovf[0];
+    ALLOC_OR_FAIL(dx, sc, u64, (size_t)total + 1);
+    u64 *dy = nullptr;
+    if (!pk) { dy = sc.get<u64>((size_t)total + 1); if (!dy) return LRGE_ERR_DEVICE; }
+    if (n_chunks && one_pass) {
+        const dim3 cgrid((u32)div_up(div_up(n_chunks, 64), 4));
+        if (pk) hipLaunchKernelGGL(k_sketch_compact<false>, cgrid, dim3(256), 0, ctx->stream, tx, ty, d_cnt, d_total, n_chunks, dx, dy);
+        else hipLaunchKernelGGL(k_sketch_compact<true>, cgrid, dim3(256), 0, ctx->stream, tx, ty, d_cnt, d_total, n_chunks, dx, dy);
+        KCHK(ctx);
+        sc.drop(tx); if (ty) sc.drop(ty);
+    } else if (n_chunks) {
+        if (pk)
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, true>), sgrid, dim3(SK_THREADS), 0,
+                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, pk_pos1, pk_ybits);
+        else if (index_keys)
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, false>), sgrid, dim3(SK_THREADS), 0,
+                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, 0u, 0u);
+        else
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false, false>), sgrid, dim3(SK_THREADS), 0,
+                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, 0u, 0u);
+        KCHK(ctx);
+    }
+    // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
+    sc.drop(d_cnt); sc.drop(d_total);
+    o->x = dx; o->y = dy; o->mz_off = d_mzoff; o->n = total;
+    return LRGE_OK;
+}
+
+static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o,
+                         u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr) {
+    // A set whose host-side pack is still running on the uploader thread (chunk gates: host_pack.h) is sketched chunk by chunk
+    // behind its transfer -- index sketches of the non-HPC preset only (an HPC step may read a homopolymer run past its chunk,
+    // i.e. words that have not arrived; a streamed set's upload hides behind the index build anyway).  option NO_GATED_SKETCH: wait first.
+    const bool gated = index_keys && preset != LRGE_PRESET_AVA_PB && s->pending && s->job && !s->job->gate_ev.empty() && s->n_words != 0 &&
+                       !s->is_view && !ctx->opt("NO_GATED_SKETCH") && s->n_chunks != 0 && s->n_chunks < (1ULL << 32);
+    int rc = gated ? LRGE_OK : seqset_ready(ctx, s);
+    if (rc) return rc;
+    StageTimer t(ctx, LRGE_T_SKETCH);
+    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, false)
+                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated);
+    t.stop();
+    return rc;
+}
+
+// ---- presketch: the streamed set's minimizers, computed on the side stream with no host round trip ----
+// Two steps, because the device arena recycles blocks in the order of the MAIN stream: everything the side stream will touch
+// is allocated where it forks (presketch_prepare: nothing released by the index build after that point can be handed to it),
+// the kernels may be queued later (presketch_launch_prepared).
+static int presketch_alloc(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, PreSketch *p) {
+    if (s->n_chunks >= (1ULL << 32) || s->total_bases + 1 >= (1ULL << 32)) return LRGE_ERR_TOO_MANY;
+    Scratch &sc = *p->sc;
+    const u64 nb = div_up(s->n_chunks, SCAN_TILE);
+    if (nb > 8192) return LRGE_ERR_TOO_MANY;                   // (single-level scan with the caller's block sums)
+    ALLOC_OR_FAIL(d_cnt, sc, u32, (size_t)s->n_chunks + 1);
+    ALLOC_OR_FAIL(d_bs, sc, u32, (size_t)nb + 2);
+    ALLOC_OR_FAIL(d_total, sc, u32, 1);
+    ALLOC_OR_FAIL(d_mzoff, sc, u32, (size_t)s->n + 1);
+    // the count is not known on the host when the write pass is queued: room for one minimizer per base
+    ALLOC_OR_FAIL(dx, sc, u64, (size_t)s->total_bases + 1);
+    ALLOC_OR_FAIL(dy, sc, u64, (size_t)s->total_bases + 1);
+    p->cnt = d_cnt; p->bs = d_bs; p->x = dx; p->y = dy; p->mz_off = d_mzoff; p->d_total = d_total;
+    return LRGE_OK;
+}
+
+template <int K, int W, bool HPC>
+static int presketch_launch(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, PreSketch *p, hipStream_t st) {
+    Scratch &sc = *p->sc;
+    const u32 n_chunks = (u32)s->n_chunks;
+    ChunkMap cm{s->d_cs, s->n};
+    const dim3 sgrid((u32)div_up(n_chunks, SK_THREADS));
+    // Two passes here, not the one-pass form of sketch_launch: this runs beside the index's memory-bound sort passes, and
+    // a second VALU-bound pass overlaps with them where the one-pass form's streaming compaction competes (measured:
+    // the sort loses what the sketch gains).
+    if (n_chunks) {
+        hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), sgrid, dim3(SK_THREADS), 0, st, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, p->cnt);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, p->cnt, p->cnt, n_chunks, p->d_total, st, true, p->bs);
+        if (rc) return rc;
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(p->d_total, 0, 4, st));
+    }
+    hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, st, s->d_cs, p->cnt, s->n, n_chunks, p->d_total,
+                       p->mz_off);
+    KCHK(ctx);
+    if (n_chunks) {
+        hipLaunchKernelGGL((k_sketch_write<K, W, HPC, false, false>), sgrid, dim3(SK_THREADS), 0, st, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm,
+                           n_chunks, p->cnt, p->x, p->y, 0u, 0u);
+        KCHK(ctx);
+    }
+    return LRGE_OK;
+}
+
+static void presketch_drop_prepared(lrge_hip_ctx *ctx) {
+    PreSketch *p = ctx->presk_prepared;
+    if (!p) return;
+    ctx->presk_prepared = nullptr; ctx->presk_prepared_set = nullptr;
+    delete p->sc;                                        // (nothing has been queued on these blocks)
+    ctx->event_pool.push_back(p->ev_start); ctx->event_pool.push_back(p->ev_done);
+    delete p;
+}
+
+// Called by the index build right after its own sketch has been queued on ctx->stream: marks the point of the main stream
+// the side stream starts from and takes the memory of the streamed set's sketch.
+// indexed_bases: size of the set whose index build would hide the sketch.  A streamed set several times larger than the
+// indexed one (the inverse strategy on a big job: 3 Gbases streamed against a 150 Mbase index) finds nothing to hide behind --
+// the two VALU-bound sketches and the small sort just share the chip -- so the hint is ignored there and the overlap call
+// sketches in line (C5/10 inverse: 95 -> 89 ms per step).
+static int presketch_prepare(lrge_hip_ctx *ctx, u64 indexed_bases) {
+    presketch_drop_prepared(ctx);
+    lrge_hip_seqset *s = ctx->presk_pending;
+    if (!s) return LRGE_OK;
+    ctx->presk_pending = nullptr;
+    if (s->total_bases > 2 * indexed_bases && !ctx->opt("PRESKETCH_ALWAYS")) return LRGE_OK;
+    if (s->total_bases > ctx->opt_u64("STREAM_BASES", 4000000000ull)) return LRGE_OK;   // streamed in views: sketched per view
+    if (s->presk) presketch_discard(s);
+    PreSketch *p = new PreSketch();
+    p->preset = ctx->presk_preset;
+    p->sc = new Scratch(ctx);
+    p->ev_start = ctx->get_event(); p->ev_done = ctx->get_event();
+    ctx->presk_prepared = p; ctx->presk_prepared_set = s;
+    // behind the index sketch (both are VALU-bound; the point is to run beside the passes that follow it)
+    if (presketch_alloc(ctx, s, p) != LRGE_OK || hipEventRecord(ctx->ev_presk, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        presketch_drop_prepared(ctx);                    // not fatal: the overlap call sketches the set itself
+    }
+    return LRGE_OK;
+}
+
+// Queues the prepared sketch on the side stream.  May block on the HOST until the set's upload job (host-side pack) is over,
+// which is why the index build calls it only once it has nothing more of its own to queue that could run meanwhile.
+static int presketch_launch_prepared(lrge_hip_ctx *ctx) {
+    PreSketch *p = ctx->presk_prepared; lrge_hip_seqset *s = ctx->presk_prepared_set;
+    if (!p) return LRGE_OK;
+    hipError_t e = hipStreamWaitEvent(ctx->stream2, ctx->ev_presk, 0);
+    // an upload of the set still in flight: only the side stream waits for it -- the main stream goes on with the index
+    // (its own seqset_ready comes with the overlap call, which also returns the staging blocks to the pool)
+    if (s->job && seqset_job_wait(ctx, s) != LRGE_OK) { presketch_drop_prepared(ctx); return LRGE_OK; }
+    if (e == hipSuccess && s->pending) e = hipStreamWaitEvent(ctx->stream2, s->ev_ready, 0);
+    if (e == hipSuccess) e = hipEventRecord(p->ev_start, ctx->stream2);
+    int rc = LRGE_OK;
+    if (e == hipSuccess) {
+        rc = p->preset == LRGE_PRESET_AVA_PB ? presketch_launch<19, 5, true>(ctx, s, p, ctx->stream2)
+                                             : presketch_launch<15, 5, false>(ctx, s, p, ctx->stream2);
+        if (rc == LRGE_OK) e = hipEventRecord(p->ev_done, ctx->stream2);
+    }
+    if (e != hipSuccess || rc != LRGE_OK) {      // not fatal: the overlap call sketches the set itself
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipGetLastError();
+        presketch_drop_prepared(ctx);
+        return LRGE_OK;
+    }
+    ctx->presk_prepared = nullptr; ctx->presk_prepared_set = nullptr;
+    s->presk = p;
+    return LRGE_OK;
+}
+
+static int presketch_start_pending(lrge_hip_ctx *ctx, u64 indexed_bases) {
+    int rc = presketch_prepare(ctx, indexed_bases);
+    return rc ? rc : presketch_launch_prepared(ctx);
+}
+
+extern "C" int lrge_hip_seqset_presketch(lrge_hip_ctx *ctx, lrge_hip_seqset *s, int preset) {
+    if (!ctx || !s || s->ctx != ctx) return LRGE_ERR_INVALID;
+    if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
+    ctx->presk_pending = s; ctx->presk_preset = preset;
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_sketch_dump(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, int preset, uint64_t *x, uint64_t *y,
+                                    uint64_t cap, uint64_t *n_out) {
+    if (!ctx || !s || !n_out) return LRGE_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->pin_items.clear(); ctx->pin_used = 0;      // reads an earlier, failed call may have left queued
+    Scratch sc(ctx);
+    SketchOut o;
+    int rc = sketch_device(ctx, sc, s, preset, false, &o);
+    if (rc) return rc;
+    *n_out = o.n;
+    u64 m = o.n < cap ? o.n : cap;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // blocking copies below run on the null stream
+    if (m && x) HIPCHK(ctx, hipMemcpy(x, o.x, m * 8, hipMemcpyDeviceToHost));
+    if (m && y) HIPCHK(ctx, hipMemcpy(y, o.y, m * 8, hipMemcpyDeviceToHost));
+    return LRGE_OK;
+}

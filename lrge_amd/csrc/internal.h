@@ -185,7 +185,7 @@ struct lrge_hip_ctx {
     char *meta_pin = nullptr; size_t meta_cap = 0, meta_used = 0; int meta_inflight = 0;
     hipEvent_t ev_meta = nullptr;            // behind the last transfer out of the arena: waited for before a rewound arena is written again
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_presk = nullptr;           // where the side stream may start a presketch (lrge_hip.hip: presketch_start_pending)
+    hipEvent_t ev_presk = nullptr;           // where the side stream may start a presketch (host_sketch.inl: presketch_prepare)
     std::string err;
     DevPool pool;
     // options: LRGE_HIP_<NAME> from the environment at creation, lrge_hip_ctx_set_option afterwards (never read per call)

@@ -33,7 +33,7 @@
 #define LPG_WAVES 1   // wavefronts per workgroup (they share the penalty table; every wavefront has its own ring)
 #endif
 #define LPG_RING_BYTES ((2 * (LPG_CH / 2) * 128 * 2 + LPG_CH * 64) * 8)      // per wavefront
-#define LPG_MAX_AUTO 0xFFFFFFFEu   // split chosen per batch from the group-size census (lrge_hip.hip)
+#define LPG_MAX_AUTO 0xFFFFFFFEu   // split chosen per batch from the group-size census (host_overlap.inl: OverlapRun::batch)
 
 struct LpgChainArgs {
     const u64 *akey, *aval;

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_direct(const u64 *__restr
                                                              u64 *__restrict__ tmp_x, u64 *__restrict__ tmp_y, u32 pk_pos1, u32 pk_ybits,
                                                              u32 cap /* <= SK_CAP; smaller only in tests */, u32 c_base = 0) {
     // chunks [c_base, n_chunks): a set whose upload is still in flight is sketched range by range, each behind the chunk of the
-    // packed image it needs (lrge_hip.hip, sketch_launch)
+    // packed image it needs (host_sketch.inl, sketch_launch)
     u32 c = c_base + blockIdx.x * SK_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     u32 r = cm.find(c);

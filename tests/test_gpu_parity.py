@@ -48,6 +48,50 @@ def test_sketch_parity(ctx, oracle, edge_set, preset, form, knobs):
     assert bad.size == 0, "first mismatch at %d: read %d" % (bad[0], int(ey[bad[0]] >> 32))
 
 
+def test_hpc_sketch_run_structure(ctx, oracle):
+    """The homopolymer-compressed sketch finds the steps of mm_sketch's loop as bit masks per 32-base word (k_sketch.h,
+    sketch_chunk_hpc): runs that cross word and 128-base chunk boundaries, runs of 255 / 256 / 700 bases (a span >= 256
+    invalidates the k-mer), ambiguous bases at run boundaries and in a row, two-letter reads (nothing but long runs), and
+    read lengths around the word and chunk sizes -- every minimizer against the oracle."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def runs(n_runs, max_run, alphabet=4, n_rate=0.0):
+        out = []
+        prev = -1
+        for _ in range(n_runs):
+            c = int(rng.integers(alphabet))
+            if c == prev:
+                c = (c + 1) % alphabet
+            prev = c
+            ln = int(rng.integers(1, max_run + 1)) if rng.random() < 0.3 else 1
+            out.append(bytes([acgt[c]]) * ln)
+            if n_rate and rng.random() < n_rate:
+                out.append(b"N" * int(rng.integers(1, 4)))
+                prev = -1
+        return b"".join(out)
+
+    seqs = []
+    for ln in (18, 19, 23, 24, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 1023, 1024, 1025):
+        seqs.append(bytes(acgt[rng.integers(4, size=ln)]))                     # lengths around words and chunks
+    seqs += [runs(400, 6), runs(300, 40), runs(200, 140), runs(300, 12, alphabet=2), runs(500, 5, n_rate=0.05), runs(300, 70, n_rate=0.1)]
+    g = bytes(acgt[rng.integers(4, size=4000)])
+    for big in (254, 255, 256, 257, 700):                                       # the span limit, from both sides
+        seqs.append(g[:900] + b"C" * big + g[900:1800])
+    seqs.append(b"N" + g[:200] + b"NN" + b"A" * 130 + b"N" + b"A" * 130 + g[200:600] + b"N")
+    seqs.append(b"G" * 127 + b"T" * 129 + b"G" * 128 + g[:500])               # runs that end on / just past chunk boundaries
+    seqs.append((b"A" * 31 + b"C") * 40 + (b"G" * 32) + (b"T" * 33) + g[:300])  # run ends around word boundaries
+    b, o = to_arrays(seqs)
+    S = ctx.upload(b, o, None)
+    x, y = S.sketch(PRESETS["pb"])
+    exp = [oracle.sketch(s, 5, 19, rid=i, is_hpc=True) for i, s in enumerate(seqs) if len(s)]
+    ex = np.concatenate([e["x"] for e in exp]); ey = np.concatenate([e["y"] for e in exp])
+    assert len(x) == len(ex), "minimizer count differs: %d vs %d" % (len(x), len(ex))
+    bad = np.nonzero((x != ex) | (y != ey))[0]
+    assert bad.size == 0, "first mismatch at %d: read %d" % (bad[0], int(ey[bad[0]] >> 32))
+    assert len(x) > 500
+
+
 @pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
 def test_index_parity(ctx, oracle, edge_set, preset, packed, knobs):

@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c4_dmel_twoset")
-    ap.add_argument("--preset", default="ont", choices=["ont", "pb"])
+    ap.add_argument("--preset", default=None, choices=["ont", "pb"], help="minimap2 preset (default: by the configuration's platform: pb for the HiFi sets, ont otherwise)")
     ap.add_argument("--inverse", action="store_true", help="--use-min-ref: index the queries, stream the targets")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the config (debug only; invalid as a result)")
     ap.add_argument("--generator", default="auto", choices=["auto", "pcg", "cb"],
@@ -244,6 +244,8 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("LRGE_BENCH_FORCE_DIST") == "1"   # the switch lets a 1-GPU box exercise RCCL
+    if a.preset is None:
+        a.preset = "pb" if a.config.startswith("c5_") else "ont"        # (the C5 configurations are the HiFi ones)
     preset = 1 if a.preset == "pb" else 0
 
     # ---- synthetic inputs (untimed; every rank draws the same seeded job) ----

@@ -354,14 +354,16 @@ int OverlapRun::plan() {
     const lrge_hip_seqset *T = ix->seqs; const Preset &P = ix->P; const u32 nq = Q->n, nt = T->n;
     (void)T; (void)P; (void)nq; (void)nt;
     // ---- 4. batches ----
-    // Anchors per batch.  Every batch pays the latency of its longest chain group once (the chain kernels are
-    // bound by it), so batches are as large as memory allows: ~64 B of scratch per anchor, at most half of the
-    // free HBM, at most 2^30 anchors (positions are 32-bit).
-    batch_cap = 1ULL << 30;
+    // Anchors per batch.  Every batch pays the latency of its longest chain group once (the chain kernels are bound by it:
+    // T steps of ~4 us whatever the batch holds), so batches are as large as memory and the 32-bit anchor positions allow: 2^31
+    // anchors (full-size C5: one batch per index part / per view instead of two -- 15 -> 8 batches, chain 273 -> 184 ms,
+    // inverse step 1.135 -> 1.041 s, counts identical), ~40 B of scratch per anchor at the peak (four 8-byte arrays through the
+    // sort; 16 + group starts + records + marks behind it), budgeted as 48 B out of 4/5 of the free HBM.
+    batch_cap = 1ULL << 31;
     {
         size_t mfree = 0, mtotal = 0;
         if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
-            const u64 by_mem = ((u64)mfree + ctx->pool.idle()) / 2 / 64;     // the pool's idle blocks are reusable too (not the ones in use: a resident index)
+            const u64 by_mem = ((u64)mfree + ctx->pool.idle()) / 5 * 4 / 48;     // the pool's idle blocks are reusable too (not the ones in use: a resident index)
             if (by_mem < batch_cap) batch_cap = by_mem;
         }
         if (batch_cap < (1ULL << 20)) batch_cap = 1ULL << 20;

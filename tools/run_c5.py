@@ -103,6 +103,7 @@ def main():
         r = dict(step_s=round(dt, 4), reads_per_s=round(Q / dt, 1), index_ms=round(tb["total"], 1), overlap_ms=round(tm["total"], 1),
                  mid_occ=st["mid_occ"], n_minimizers_index=st["n_minimizers"], n_keys_index=st["n_keys"], anchors=cn["anchors"], batches=cn["batches"],
                  groups=cn["groups"], groups_chained=cn["groups_chained"], no_mapping=int((has == 0).sum()),
+                 counts_crc32=int(__import__("zlib").crc32(np.ascontiguousarray(counts).tobytes())), counts_sum=int(counts.astype(np.int64).sum()),
                  estimate=None if med[1] is None else float(med[1]), rel_err=None if med[1] is None else abs(float(med[1]) - spec.gsize) / spec.gsize,
                  q15_q65=[None if med[0] is None else float(med[0]), None if med[2] is None else float(med[2])],
                  stage_ms={**{"index_" + k: round(v, 1) for k, v in tb.items() if v and k != "total"}, **{k: round(v, 1) for k, v in tm.items() if v}})

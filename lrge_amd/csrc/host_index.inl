@@ -656,17 +656,56 @@ static int seqset_view(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, u32 r0, u32 
 }
 
 // mm_idx_reader_read with batch_size = max (aligner.rs:112-122) makes ONE index whatever the size of the target file.
-// Here a target set above LRGE_HIP_PART_BASES bases (default 4e9: the 2^32-entry limits of one part) is indexed in parts
-// over views of the set; the occurrence statistics are then taken over all parts together (k_part_global_occ), mid_occ
+// Here a target set above ONE_INDEX_BASES (4e9 bases: the 32-bit entry counts and base offsets of one build) is indexed in
+// parts over views of the set; the occurrence statistics are then taken over all parts together (k_part_global_occ), mid_occ
 // from that global histogram, and a key that is too frequent globally is marked so in every part (k_part_drop) -- the
 // parts answer every lookup exactly as the one index would.
+// How many parts: every part costs the queries one more round of lookups and one more batch of anchors with its chain-latency
+// floor, so as few as the limits allow -- a part's minimizers must stay below 2^32 (with a margin: ~0.25 per base with HPC,
+// ~0.34 without) and its sort must fit the free HBM.  Full-size C5 (30 Gbases): 8 parts of 4e9 bases 1.47 s per step, 4 parts
+// 1.33 s, 3 parts 1.24 s, 2 parts 1.20 s, the same counts every time.  Option PART_BASES pins the size; a part that turns out
+// too large for either limit makes the build start over with parts of half the size.
+#define ONE_INDEX_BASES 4000000000ull
+static u64 auto_part_bases(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset) {
+    const bool hpc = preset == LRGE_PRESET_AVA_PB;
+    const double density = hpc ? 0.27 : 0.36;                       // minimizers per base, rounded up
+    u64 by_limit = (u64)(3.4e9 / density);                           // < 2^32 entries with ~25 % to spare
+    size_t mfree = 0, mtot = 0;
+    if (hipMemGetInfo(&mfree, &mtot) == hipSuccess) {
+        // the sort's two buffers of 16-byte pairs (8-byte packed entries where they fit), the resident entries and the table
+        const double per_base = density * 48.0;
+        const u64 by_mem = (u64)(((double)mfree + (double)ctx->pool.idle()) * 0.6 / per_base);
+        if (by_mem < by_limit) by_limit = by_mem;
+    } else (void)hipGetLastError();
+    if (by_limit < ONE_INDEX_BASES / 4) by_limit = ONE_INDEX_BASES / 4;
+    // parts of equal size
+    const u64 np = div_up(targets->total_bases, by_limit);
+    return div_up(targets->total_bases, np) + targets->max_len;
+}
+
+static int index_build_parts(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, u64 part_bases, lrge_hip_index **out);
+
 extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_index **out) {
     if (!ctx || !targets || !out) return LRGE_ERR_INVALID;
     if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
     *out = nullptr;
-    const u64 part_bases = ctx->opt_u64("PART_BASES", 4000000000ull);
-    if (targets->total_bases <= part_bases || targets->n < 2 || targets->is_view) return index_build_one(ctx, targets, preset, out);
+    const bool pinned = ctx->opt("PART_BASES") != nullptr;
+    if (targets->total_bases <= (pinned ? ctx->opt_u64("PART_BASES", ONE_INDEX_BASES) : ONE_INDEX_BASES) || targets->n < 2 || targets->is_view)
+        return index_build_one(ctx, targets, preset, out);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    u64 part_bases = pinned ? ctx->opt_u64("PART_BASES", ONE_INDEX_BASES) : auto_part_bases(ctx, targets, preset);
+    for (int attempt = 0;; ++attempt) {
+        const int rc = index_build_parts(ctx, targets, preset, part_bases, out);
+        // a part with >= 2^32 minimizers, or one the memory could not hold: smaller parts (the failed attempt released everything)
+        if ((rc != LRGE_ERR_TOO_MANY && rc != LRGE_ERR_DEVICE) || pinned || attempt >= 3 || part_bases <= ONE_INDEX_BASES / 4) return rc;
+        if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] index parts of %llu bases failed (%s): trying half\n", (unsigned long long)part_bases, ctx->err.c_str());
+        (void)hipGetLastError();
+        ctx->pool.trim();
+        part_bases /= 2;
+    }
+}
+
+static int index_build_parts(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, u64 part_bases, lrge_hip_index **out) {
     // cut by reads, every part at most part_bases bases (a single longer read gets a part of its own)
     std::vector<u32> cuts{0};
     u64 acc = 0;
@@ -676,7 +715,7 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     }
     cuts.push_back(targets->n);
     const int np = (int)cuts.size() - 1;
-    if (np > MAX_INDEX_PARTS) { LRGE_SET_ERR(ctx, "target set needs %d index parts (limit %d)", np, MAX_INDEX_PARTS); return LRGE_ERR_TOO_MANY; }
+    if (np > MAX_INDEX_PARTS) { LRGE_SET_ERR(ctx, "target set needs %d index parts (limit %d)", np, MAX_INDEX_PARTS); return LRGE_ERR_INVALID; }
     lrge_hip_index *top = new lrge_hip_index();
     IndexGuard top_guard(top);
     top->ctx = ctx; top->seqs = targets; top->preset_id = preset;
@@ -768,8 +807,8 @@ extern "C" int lrge_hip_index_build_for(lrge_hip_ctx *ctx, const lrge_hip_seqset
     *out = nullptr;
     if (!streamed) { LRGE_SET_ERR(ctx, "index_build_for: a communicator needs the streamed set of this rank"); return LRGE_ERR_INVALID; }
     if (streamed->ctx != ctx || targets->ctx != ctx || (comm && comm->ctx != ctx)) { LRGE_SET_ERR(ctx, "index_build_for: sets / communicator belong to another context"); return LRGE_ERR_INVALID; }
-    if (targets->total_bases > ctx->opt_u64("PART_BASES", 4000000000ull)) {
-        LRGE_SET_ERR(ctx, "index_build_for: target sets above PART_BASES bases (a partitioned index) are not implemented for restricted builds");
+    if (targets->total_bases > ctx->opt_u64("PART_BASES", ONE_INDEX_BASES)) {
+        LRGE_SET_ERR(ctx, "index_build_for: target sets above 4e9 bases (a partitioned index) are not implemented for restricted builds");
         return LRGE_ERR_TOO_MANY;
     }
     IndexBuildOpts ro; ro.restrict_to = streamed; ro.comm = comm;

@@ -670,6 +670,8 @@ static u64 auto_part_bases(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     const bool hpc = preset == LRGE_PRESET_AVA_PB;
     const double density = hpc ? 0.27 : 0.36;                       // minimizers per base, rounded up
     u64 by_limit = (u64)(3.4e9 / density);                           // < 2^32 entries with ~25 % to spare
+    by_limit = ctx->opt_u64("DEBUG_PART_LIMIT_BASES", by_limit);      // (tests: parts on small sets)
+    const u64 floor_bases = std::min<u64>(ONE_INDEX_BASES / 4, by_limit);
     size_t mfree = 0, mtot = 0;
     if (hipMemGetInfo(&mfree, &mtot) == hipSuccess) {
         // the sort's two buffers of 16-byte pairs (8-byte packed entries where they fit), the resident entries and the table
@@ -677,7 +679,7 @@ static u64 auto_part_bases(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         const u64 by_mem = (u64)(((double)mfree + (double)ctx->pool.idle()) * 0.6 / per_base);
         if (by_mem < by_limit) by_limit = by_mem;
     } else (void)hipGetLastError();
-    if (by_limit < ONE_INDEX_BASES / 4) by_limit = ONE_INDEX_BASES / 4;
+    if (by_limit < floor_bases) by_limit = floor_bases;
     // parts of equal size
     const u64 np = div_up(targets->total_bases, by_limit);
     return div_up(targets->total_bases, np) + targets->max_len;
@@ -690,14 +692,18 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
     if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
     *out = nullptr;
     const bool pinned = ctx->opt("PART_BASES") != nullptr;
-    if (targets->total_bases <= (pinned ? ctx->opt_u64("PART_BASES", ONE_INDEX_BASES) : ONE_INDEX_BASES) || targets->n < 2 || targets->is_view)
+    const u64 one_index = ctx->opt_u64("DEBUG_ONE_INDEX_BASES", ONE_INDEX_BASES);
+    if (targets->total_bases <= (pinned ? ctx->opt_u64("PART_BASES", one_index) : one_index) || targets->n < 2 || targets->is_view)
         return index_build_one(ctx, targets, preset, out);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     u64 part_bases = pinned ? ctx->opt_u64("PART_BASES", ONE_INDEX_BASES) : auto_part_bases(ctx, targets, preset);
+    const int fail_first = (int)ctx->opt_u64("DEBUG_PART_FAIL_ATTEMPTS", 0);          // (tests: the start-over path)
     for (int attempt = 0;; ++attempt) {
-        const int rc = index_build_parts(ctx, targets, preset, part_bases, out);
+        int rc;
+        if (attempt < fail_first) { LRGE_SET_ERR(ctx, "index limited to < 2^32 minimizers (injected)"); rc = LRGE_ERR_TOO_MANY; }
+        else rc = index_build_parts(ctx, targets, preset, part_bases, out);
         // a part with >= 2^32 minimizers, or one the memory could not hold: smaller parts (the failed attempt released everything)
-        if ((rc != LRGE_ERR_TOO_MANY && rc != LRGE_ERR_DEVICE) || pinned || attempt >= 3 || part_bases <= ONE_INDEX_BASES / 4) return rc;
+        if ((rc != LRGE_ERR_TOO_MANY && rc != LRGE_ERR_DEVICE) || pinned || attempt >= 3 || (part_bases <= ONE_INDEX_BASES / 4 && attempt >= fail_first)) return rc;
         if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] index parts of %llu bases failed (%s): trying half\n", (unsigned long long)part_bases, ctx->err.c_str());
         (void)hipGetLastError();
         ctx->pool.trim();

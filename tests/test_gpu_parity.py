@@ -789,6 +789,19 @@ def test_partitioned_index_is_exact(ctx, oracle, tiny_ont, tiny_hifi, data, pres
             for a, b in zip(ixp.paf_stats(Qd), ref_paf):
                 assert np.array_equal(a, b), n_parts
         ixp.free()
+    # the part size chosen by the library (as few parts as the entry limit and the memory allow; thresholds scaled down to
+    # this set), with the first attempt failing as a part above 2^32 minimizers would: the build starts over with half-size parts
+    knobs.unset("PART_BASES"); knobs.unset("NO_PACKED_INDEX")
+    knobs.set("DEBUG_ONE_INDEX_BASES", str(total // 4)); knobs.set("DEBUG_PART_LIMIT_BASES", str(total // 2 + 1)); knobs.set("DEBUG_PART_FAIL_ATTEMPTS", "1")
+    ixp = engine.Index(ctx, Td, PRESETS[preset])
+    st = ixp.stats()
+    assert (st["n_minimizers"], st["n_keys"], st["mid_occ"]) == (ref_stats["n_minimizers"], ref_stats["n_keys"], ref_stats["mid_occ"])
+    counts, has = ixp.overlap_twoset(Qd)
+    assert np.array_equal(counts, ref[False][0]) and np.array_equal(has, ref[False][1])
+    assert ctx.counters()["batches"] >= 3                      # (one batch per part at least: the parts are there)
+    ixp.free()
+    for k_ in ("DEBUG_ONE_INDEX_BASES", "DEBUG_PART_LIMIT_BASES", "DEBUG_PART_FAIL_ATTEMPTS"):
+        knobs.unset(k_)
     # the oracle agrees with the single index (and hence with the parts)
     opt = oracle.make_opt(oracle.PRESET_AVA_PB if preset == "pb" else oracle.PRESET_AVA_ONT, dual=True)
     ixo = oracle.Index(oracle.ReadSet(ds.t.seqs(), ds.t.names), opt)

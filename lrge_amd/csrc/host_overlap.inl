@@ -443,6 +443,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
     if (A == 0 || me == mb) return LRGE_OK;
     ctx->counters[LRGE_C_ANCHORS] += A;
     Scratch bsc(ctx);
+    bsc.max_bytes = (size_t)ctx->opt_u64("DEBUG_BATCH_ALLOC_MAX_BYTES", 0);
     u64 *akey, *aval, *akey2, *aval2, *skey, *sval;
     // count-only runs carry one packed u64 per anchor through the expansion and the sort (k_prims.h UnpackParams);
     // chain records (PAF) need the seed rank as well and keep the (key, value) pairs
@@ -730,6 +731,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
     const u32 nq = Q->n;
     u32 q0 = job.dump_anchors ? job.dump_query : 0;
     const u32 q_end = job.dump_anchors ? job.dump_query + 1 : nq;
+    int shrinks = 0;
     while (q0 < q_end) {
         u32 q1 = q0; u64 A = 0;
         while (q1 < q_end && (q1 - q0) < (1u << std::min<u32>(R.max_bits_q, 24)) && (q1 == q0 || A + R.h_qtot[q1] <= R.batch_cap)) { A += R.h_qtot[q1]; ++q1; }
@@ -738,6 +740,19 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         R.kl.bits_q = std::max<u32>(1, ceil_log2_u64((u64)(q1 - q0)));
         R.cp.kl = R.kl; R.cp.q0 = q0;
         rc = R.batch(q0, q1, A);
+        if (rc == LRGE_ERR_DEVICE && q1 - q0 > 1 && shrinks < 6 && ctx->err.compare(0, 17, "device allocation") == 0 && !ctx->opt("NO_BATCH_RETRY")) {
+            // The batch's scratch did not fit after all (the plan budgets 48 B per anchor out of 4/5 of the free HBM; other users of
+            // the device, a fragmented arena): nothing of the batch has reached the counts yet (k_count is its last launch and
+            // needs no memory), so drain both streams, give idle segments back and take the same queries in smaller batches.
+            (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); (void)hipGetLastError();
+            ctx->pool.trim();
+            ctx->counters[LRGE_C_BATCHES] -= 1; ctx->counters[LRGE_C_ANCHORS] -= A;
+            R.batch_cap = std::max<u64>(A / 2, 1024);
+            ++shrinks;
+            if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] batch of %llu anchors did not fit (%s): batches of at most %llu from here\n", (unsigned long long)A, ctx->err.c_str(), (unsigned long long)R.batch_cap);
+            ctx->err.clear();
+            continue;
+        }
         if (rc) return done(rc);
         q0 = q1;
     }

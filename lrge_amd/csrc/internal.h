@@ -330,11 +330,12 @@ struct lrge_hip_index {
 struct Scratch {
     lrge_hip_ctx *ctx;
     std::vector<void *> ptrs;
+    size_t max_bytes = 0;       // test hook (OverlapRun::batch, DEBUG_BATCH_ALLOC_MAX_BYTES): larger requests are refused, as a fuller device would
     explicit Scratch(lrge_hip_ctx *c) : ctx(c) {}
     ~Scratch() { for (void *p : ptrs) ctx->pool.release(p); }
     template <typename T> T *get(size_t n) {
-        hipError_t e = hipSuccess;
-        void *p = ctx->pool.alloc(n * sizeof(T), &e);
+        hipError_t e = hipErrorOutOfMemory;
+        void *p = (max_bytes && n * sizeof(T) > max_bytes) ? nullptr : ctx->pool.alloc(n * sizeof(T), &e);
         if (!p) { LRGE_SET_ERR(ctx, "device allocation of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e)); return nullptr; }
         ptrs.push_back(p);
         return (T *)p;

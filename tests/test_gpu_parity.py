@@ -871,6 +871,33 @@ def test_all_vs_all_in_views_is_exact(ctx, tiny_ava, knobs):
     Rd.free()
 
 
+def test_batch_that_does_not_fit_is_taken_in_smaller_ones(ctx, tiny_ont, knobs):
+    """The anchor batches are planned from the free HBM (48 B per anchor out of 4/5 of it, at most 2^31 anchors); when a batch's
+    scratch does not fit after all -- here: the batch's allocator refuses requests above three quarters of one anchor array
+    (DEBUG_BATCH_ALLOC_MAX_BYTES) -- the same queries are taken in batches of half the size, and the counts are those of the one
+    batch."""
+    from lrge_amd import engine
+    ds = tiny_ont
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Qd, Td = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
+    ix = engine.Index(ctx, Td, 0)
+    ref = ix.overlap_twoset(Qd)
+    cn = ctx.counters()
+    A = cn["anchors"]
+    assert cn["batches"] == 1 and A > 1000
+    knobs.set("DEBUG_BATCH_ALLOC_MAX_BYTES", str((A + 8) * 8 * 3 // 4))       # the largest single request of a batch is (A + 8) * 8 bytes
+    got = ix.overlap_twoset(Qd)
+    cn2 = ctx.counters()
+    assert cn2["batches"] >= 2 and cn2["anchors"] == A
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    knobs.set("NO_BATCH_RETRY", "1")                       # without the retry the same call fails, loudly
+    with pytest.raises(Exception, match="device allocation"):
+        ix.overlap_twoset(Qd)
+    knobs.unset("NO_BATCH_RETRY"); knobs.unset("DEBUG_BATCH_ALLOC_MAX_BYTES")
+    assert np.array_equal(ix.overlap_twoset(Qd)[0], ref[0])
+    ix.free()
+
+
 def test_allocator_retry_leaves_no_stale_error(tiny_ont):
     """Under memory pressure the pool's first hipMalloc fails, the cache is trimmed and the retry succeeds -- the failed
     attempt must not surface later as the "last error" of a launch check (it did, at C5: the overlap call of a run whose

@@ -62,7 +62,7 @@ for kern in sorted(set(fetch) | set(write)):
                  "valu_insts_per_launch": v[1] / v[0] if v else None}
 big = 0.0
 for r in csv.DictReader(open(os.path.join(G, tag + "_fetch", "f_counter_collection.csv"))):
-    if r["Kernel_Name"].startswith("void k_rs_hist<false>") and r["Counter_Name"] == "FETCH_SIZE":
+    if r["Kernel_Name"].startswith("void k_rs_hist<false") and r["Counter_Name"] == "FETCH_SIZE":
         big = max(big, float(r["Counter_Value"]))
 out = {
     "source": "tools/profile_round.sh %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes, bench.py --steps 1 --warmup 0; "

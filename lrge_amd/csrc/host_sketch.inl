@@ -177,9 +177,10 @@ static int presketch_launch(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, PreSket
     const u32 n_chunks = (u32)s->n_chunks;
     ChunkMap cm{s->d_cs, s->n};
     const dim3 sgrid((u32)div_up(n_chunks, SK_THREADS));
-    // Two passes here, not the one-pass form of sketch_launch: this runs beside the index's memory-bound sort passes, and
-    // a second VALU-bound pass overlaps with them where the one-pass form's streaming compaction competes (measured:
-    // the sort loses what the sketch gains).
+    // Two passes here, not the one-pass form of sketch_launch: beside the index's memory-bound passes a second VALU-bound pass
+    // overlaps where the one-pass form's streaming compaction competes.  Measured twice: beside the sort passes (round 2: the sort
+    // loses what the sketch gains) and beside the table build, where this runs now (round 3: C4 step 32.7-32.8 ms with two passes,
+    // 33.1-33.4 with slots + compaction on the same box).
     if (n_chunks) {
         hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), sgrid, dim3(SK_THREADS), 0, st, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, p->cnt);
         KCHK(ctx);

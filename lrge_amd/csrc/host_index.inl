@@ -337,7 +337,10 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         if (rc) return rc;
     }
     if (!fused) {
-        rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits);
+        // plain build of packed entries: the sort's first pass reads the sketch's per-chunk slots, no compaction in between
+        // (k_prims.h: radix_sort_keys_first_pass_from_slots; option NO_SLOT_SORT: compact first, rounds 1-3)
+        const bool keep_slots = pk && !ro && !ctx->opt("NO_SLOT_SORT") && !ctx->opt("HYBRID_SORT") && !ctx->opt("HYBRID_SORT_MIN");
+        rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits, nullptr, keep_slots);
         if (rc) return rc;
         sc.drop(so.mz_off);
     }
@@ -457,7 +460,17 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     {
         StageTimer t(ctx, LRGE_T_INDEX_SORT);
         ALLOC_OR_FAIL(k1, sc, u64, M + 1);
-        if (pk) {
+        if (pk && so.slots) {
+            ALLOC_OR_FAIL(k0, sc, u64, M + 1);
+            rc = radix_sort_keys_first_pass_from_slots(ctx, sc, so.slots, so.offs, so.n_chunks, (u32)SK_CAP, k1, M, (int)pk_ybits, 2 * P.k, /*reverse_digits=*/true);
+            if (rc) return rc;
+            sc.drop(so.slots); sc.drop(so.offs);          // (recycled in stream order)
+            u64 *rk = k1;
+            rc = radix_sort_keys(ctx, sc, k1, k0, M, (int)pk_ybits, 2 * P.k, &rk, /*reverse_digits=*/true, 1, -1);
+            if (rc) return rc;
+            skey = rk; spos = rk;
+            sc.drop(rk == k1 ? k0 : k1);
+        } else if (pk) {
             u64 *rk = so.x;
             bool hybrid = false;
             // two most-significant-digit passes, then the rest inside LDS (k_prims.h: index_sort_hybrid) where the entries suit it

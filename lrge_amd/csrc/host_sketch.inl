@@ -6,12 +6,15 @@ struct SketchOut {
     u64 *x = nullptr, *y = nullptr;   // pool memory (owned by the caller's Scratch)
     u32 *mz_off = nullptr;            // [n+1] per-read offsets
     u64 n = 0;
+    // keep_slots (packed index entries, one-pass form): x stays null -- the entries still sit in the per-chunk slots of k_sketch_direct
+    // (chunk c at slots[c * SK_CAP ...), offs[] = exclusive scan of the per-chunk counts) and the index sort's first pass reads them there
+    u64 *slots = nullptr; u32 *offs = nullptr; u32 n_chunks = 0;
 };
 
 // pk_ybits != 0 (index only): packed 8-byte entries in o->x, o->y stays null (k_sketch.h PK)
 template <int K, int W, bool HPC>
 static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o, u32 pk_pos1, u32 pk_ybits,
-                         std::vector<u32> *h_mzoff, bool gated = false) {
+                         std::vector<u32> *h_mzoff, bool gated = false, bool keep_slots = false) {
     // gated: the caller has NOT waited for the set's upload (seqset_ready): this function does, as late as it can
     if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
     u32 n_chunks = (u32)s->n_chunks;
@@ -108,6 +111,13 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
         sc.drop(tx); if (ty) sc.drop(ty); tx = ty = nullptr;
     }
     const u32 total = tot_ovf[0];
+    if (keep_slots && pk && one_pass && n_chunks && sk_cap == (u32)SK_CAP) {
+        // no compaction: the caller's sort reads the slots (k_prims.h: radix_sort_keys_first_pass_from_slots)
+        sc.drop(d_total);
+        o->x = nullptr; o->y = nullptr; o->mz_off = d_mzoff; o->n = total;
+        o->slots = tx; o->offs = d_cnt; o->n_chunks = n_chunks;
+        return LRGE_OK;
+    }
     ALLOC_OR_FAIL(dx, sc, u64, (size_t)total + 1);
     u64 *dy = nullptr;
     if (!pk) { dy = sc.get<u64>((size_t)total + 1); if (!dy) return LRGE_ERR_DEVICE; }
@@ -136,7 +146,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
 }
 
 static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o,
-                         u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr) {
+                         u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr, bool keep_slots = false) {
     // A set whose host-side pack is still running on the uploader thread (chunk gates: host_pack.h) is sketched chunk by chunk
     // behind its transfer -- index sketches of the non-HPC preset only (an HPC step may read a homopolymer run past its chunk,
     // i.e. words that have not arrived; a streamed set's upload hides behind the index build anyway).  option NO_GATED_SKETCH: wait first.
@@ -145,8 +155,8 @@ static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     int rc = gated ? LRGE_OK : seqset_ready(ctx, s);
     if (rc) return rc;
     StageTimer t(ctx, LRGE_T_SKETCH);
-    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, false)
-                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated);
+    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, false, keep_slots)
+                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots);
     t.stop();
     return rc;
 }

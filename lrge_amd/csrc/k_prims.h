@@ -274,14 +274,81 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 nb) {
 #endif
 }
 
+// A sort whose FIRST pass reads the sketch's per-chunk slots in place of a dense array (k_sketch.h: k_sketch_direct writes chunk c's
+// entries to slots[c * cap ...), offs[] = exclusive scan of the per-chunk counts): dense index i lives in chunk c = the last one
+// with offs[c] <= i, at slots[c * cap + i - offs[c]].  What that saves is k_sketch_compact: one read and one write of every entry.
+struct SlotSrc { const u64 *slots; const u32 *offs; const u32 *tile_chunk; u32 n_chunks, cap, total; };
+#define SLOT_LDS 384        // chunk offsets a tile keeps in LDS (4096 entries span ~95 chunks of ~43; more: read from memory)
+
+// tile_chunk[t] = the chunk that holds dense index t * RS_TILE (the last c with offs[c] <= it)
+__global__ __launch_bounds__(256) void k_tile_chunks(const u32 *__restrict__ offs, u32 n_chunks, u32 n_tiles, u32 *__restrict__ tile_chunk) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const u64 target = (u64)t * RS_TILE;
+    u32 lo = 0, hi = n_chunks - 1;
+    while (lo < hi) { const u32 mid = lo + (hi - lo + 1) / 2; if ((u64)offs[mid] <= target) lo = mid; else hi = mid - 1; }
+    tile_chunk[t] = lo;
+}
+
+// the keys of tile `bid` in the wave-major item layout of the sort kernels (row (w, r) = 64 consecutive dense indices), from the slots.
+// The chunk offsets the tile needs sit in LDS behind a sentinel (the total); the chunk of a row's first entry moves on from the row
+// before (wave-uniform), the lanes of a row pick theirs among the one to three chunks the row spans.  A tile of more than SLOT_LDS - 2
+// chunks (tiny reads: chunks of a few entries) takes the general path: offsets from memory, one search per entry.
+__device__ __forceinline__ void rs_load_from_slots(const SlotSrc &S, u32 bid, u64 tile0, u32 n_tile, u32 *s_offs, u64 (&k)[RS_ITEMS], u64 fill) {
+    const u32 c_lo = S.tile_chunk[bid];
+    const u32 left = S.n_chunks - c_lo;                                  // offsets c_lo .. n_chunks - 1 exist; offs[n_chunks] = total
+    const u32 n_l = left + 1 < SLOT_LDS ? left + 1 : SLOT_LDS;           // cached: s_offs[j] = off(c_lo + j), j < n_l
+    for (u32 j = threadIdx.x; j < n_l; j += RS_THREADS) s_offs[j] = j < left ? S.offs[c_lo + j] : S.total;
+    __syncthreads();
+    const u32 w = threadIdx.x >> 6, lane = lane_id();
+    const u32 last = (u32)tile0 + n_tile - 1;                            // the tile's last dense index
+    const bool cached = s_offs[n_l - 1] > last;                          // the cached offsets reach past the tile
+    if (cached) {
+        u32 jr = 0;                                                      // (relative) chunk of the row's first entry
+        {
+            const u32 i0 = (u32)tile0 + w * (RS_ITEMS * 64);
+            u32 lo = 0, hi = n_l - 1;                                    // last j with s_offs[j] <= i0 (s_offs[0] <= tile0 <= i0)
+            while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_offs[mid] <= i0) lo = mid; else hi = mid - 1; }
+            jr = lo;
+        }
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {
+            const u32 i0 = (u32)tile0 + w * (RS_ITEMS * 64) + (u32)r * 64, i = i0 + lane;
+            k[r] = fill;
+            if (i0 > last) continue;                                     // (wave-uniform)
+            while (s_offs[jr + 1] <= i0) ++jr;                           // wave-uniform: the sentinel stops it
+            u32 jm = jr, jc = jr;
+            while (s_offs[jc + 1] < i0 + 64 && jc + 1 < n_l - 1) { ++jc; if (i >= s_offs[jc]) jm = jc; }   // chunks that begin inside the row
+            if (i <= last) k[r] = S.slots[(u64)(c_lo + jm) * S.cap + (i - s_offs[jm])];
+        }
+        return;
+    }
+    auto off_of = [&](u32 c) -> u32 { return c >= S.n_chunks ? S.total : S.offs[c]; };
+    u32 c = c_lo;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 il = w * (RS_ITEMS * 64) + (u32)r * 64 + lane;
+        k[r] = fill;
+        if (il < n_tile) {
+            const u32 i = (u32)tile0 + il;
+            u32 lo = c, hi = S.n_chunks - 1;                             // last chunk with off <= i
+            while (lo < hi) { const u32 mid = lo + (hi - lo + 1) / 2; if (off_of(mid) <= i) lo = mid; else hi = mid - 1; }
+            c = lo;
+            k[r] = S.slots[(u64)c * S.cap + (i - off_of(c))];
+        }
+    }
+}
+
 // DB: digit bits (8, or 10: three passes instead of four over a 30-bit hash; the runs a tile writes per digit shrink from 16 to 4
 // keys.  MEASURED: one 10-bit pass 0.58 + 0.15 + 1.33 ms against 0.43 + 0.05 + 0.88, the whole sort 5.8 against 5.0 ms -- the
 // index build stays with 8)
-template <bool SEG, int DB = 8>
+template <bool SEG, int DB = 8, bool SLOTS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
-                                                        u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255) {
+                                                        u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255, SlotSrc src = SlotSrc()) {
     constexpr u32 ND = 1u << DB;
+    static_assert(!SLOTS || !SEG, "slots feed whole (unsegmented) sorts only");
     __shared__ u32 h[ND];
+    __shared__ u32 s_offs[SLOTS ? SLOT_LDS : 1];
     for (u32 i = threadIdx.x; i < ND; i += RS_THREADS) h[i] = 0;
     __syncthreads();
     const u32 bid = xcd_tile(blockIdx.x, gridDim.x);
@@ -290,8 +357,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
     // the whole tile in flight before the first count (the 4-deep unrolled load -> atomic loop ran at 2.7 TB/s)
     const u32 l0 = (threadIdx.x >> 6) * (RS_ITEMS * 64) + lane_id();
     u64 kk[RS_ITEMS];
+    if (SLOTS) rs_load_from_slots(src, bid, tile0, n_tile, s_offs, kk, 0ULL);
+    else {
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) kk[r] = l0 + (u32)r * 64 < n_tile ? keys[tile0 + l0 + (u32)r * 64] : 0;
+        for (int r = 0; r < RS_ITEMS; ++r) kk[r] = l0 + (u32)r * 64 < n_tile ? keys[tile0 + l0 + (u32)r * 64] : 0;
+    }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r)
         if (l0 + (u32)r * 64 < n_tile) atomicAdd(&h[(u32)(kk[r] >> shift) & dmask], 1u);
@@ -302,11 +372,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
     }
 }
 
-template <bool SEG, int MODE, int DB = 8>
+template <bool SEG, int MODE, int DB = 8, bool SLOTS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict__ keys_in, const u64 *__restrict__ vals_in,
                                                            u64 *__restrict__ keys_out, u64 *__restrict__ vals_out, u64 n,
                                                            int shift, u32 nb, const u32 *__restrict__ hist_scanned,
-                                                           const SegTile *__restrict__ tiles, UnpackParams up) {
+                                                           const SegTile *__restrict__ tiles, UnpackParams up, SlotSrc src = SlotSrc()) {
+    static_assert(!SLOTS || (!SEG && MODE == RS_MODE_KEYS), "slots feed whole keys-only sorts only");
+    __shared__ u32 s_offs[SLOTS ? SLOT_LDS : 1];
     // 1. per-wave stable ranks (ballot digit matching + per-wave LDS counters)
     // 2. block-local destinations: the tile is first reordered through LDS so that each digit's
     //    items are contiguous, then written out as coalesced runs (one run per digit per tile)
@@ -329,8 +401,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     u64 k[RS_ITEMS], v[RS_ITEMS];
     u32 rank[RS_ITEMS];
     // all loads of the tile are issued up front: the values arrive while the keys are being ranked
+    if (SLOTS) rs_load_from_slots(src, bid, tile0, n_tile, s_offs, k, ~0ULL);
+    else {
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n_tile ? keys_in[base + (u64)r * 64] : ~0ULL;
+        for (int r = 0; r < RS_ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n_tile ? keys_in[base + (u64)r * 64] : ~0ULL;
+    }
     if (MODE == RS_MODE_PAIRS || MODE == RS_MODE_PACK) {
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) v[r] = l0 + (u32)r * 64 < n_tile ? vals_in[base + (u64)r * 64] : 0;
@@ -505,6 +580,38 @@ static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *
         u64 *t = ki; ki = ko; ko = t;
     }
     sc.drop(hist);
+    return LRGE_OK;
+}
+
+// Pass 0 of radix_sort_keys (8-bit digits) with the sketch's slots as its input: the keys land in `out` (n entries), ordered by the
+// pass's digit; the caller goes on with radix_sort_keys(out, other, ..., pass_begin = 1).
+static int radix_sort_keys_first_pass_from_slots(lrge_hip_ctx *ctx, Scratch &sc, const u64 *slots, const u32 *offs, u32 n_chunks, u32 cap, u64 *out, u64 n,
+                                                 int begin_bit, int nbits, bool reverse_digits) {
+    if (n == 0 || nbits <= 0) return LRGE_OK;
+    if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
+    const u32 nb = (u32)div_up(n, RS_TILE);
+    const int passes = (nbits + 7) / 8, d = reverse_digits ? passes - 1 : 0, shift = begin_bit + d * 8;
+    UnpackParams up{0, 0, 0, nbits - d * 8 >= 8 ? 255u : (1u << (nbits - d * 8)) - 1u};
+    ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * nb);
+    ALLOC_OR_FAIL(tile_chunk, sc, u32, (size_t)nb + 1);
+    hipLaunchKernelGGL(k_tile_chunks, dim3((u32)div_up(nb, 256)), dim3(256), 0, ctx->stream, offs, n_chunks, nb, tile_chunk);
+    KCHK(ctx);
+    SlotSrc src{slots, offs, tile_chunk, n_chunks, cap, (u32)n};
+    hipLaunchKernelGGL((k_rs_hist<false, 8, true>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)nullptr, n, shift, nb, hist, (const SegTile *)nullptr, up.dmask, src);
+    KCHK(ctx);
+    int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
+    if (rc) return rc;
+    {
+        StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+        hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_KEYS, 8, true>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)nullptr, (const u64 *)nullptr, out, (u64 *)nullptr, n,
+                           shift, nb, hist, (const SegTile *)nullptr, up, src);
+        KCHK(ctx);
+        ts.stop();
+        ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
+        ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;
+        ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 16 * n;
+    }
+    sc.drop(hist); sc.drop(tile_chunk);
     return LRGE_OK;
 }
 

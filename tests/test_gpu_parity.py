@@ -111,6 +111,44 @@ def test_index_parity(ctx, oracle, edge_set, preset, packed, knobs):
     assert np.array_equal(pos, mz["y"][order])
 
 
+@pytest.mark.parametrize("slot_sort", [True, False])
+def test_index_of_tiny_reads(ctx, oracle, slot_sort, knobs):
+    """The packed index's sort reads the sketch's per-chunk slots in its first pass (no compaction in between: k_prims.h,
+    rs_load_from_slots).  A tile of 4096 entries normally spans ~95 chunks, whose offsets it keeps in LDS; reads of a few dozen
+    bases make chunks of one to five entries, i.e. tiles of a thousand chunks and more -- the general path (offsets from memory,
+    one search per entry), mixed here with ordinary reads, empty reads and reads shorter than k.  Against the oracle, and against
+    the compact-first form (NO_SLOT_SORT)."""
+    from lrge_amd import engine
+    if not slot_sort:
+        knobs.set("NO_SLOT_SORT", "1")
+    rng = np.random.Generator(np.random.PCG64(77))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rng.integers(4, size=400_000)]
+    seqs = []
+    for _ in range(30000):                                      # tiny reads: 0-5 minimizers each
+        st = int(rng.integers(0, len(genome) - 100)); ln = int(rng.integers(12, 46))
+        seqs.append(genome[st:st + ln].tobytes())
+    for _ in range(40):                                         # ordinary ones in between and behind
+        st = int(rng.integers(0, len(genome) - 9000)); ln = int(rng.integers(2000, 9000))
+        seqs.insert(int(rng.integers(0, len(seqs))), genome[st:st + ln].tobytes())
+    seqs[5] = b""; seqs[77] = b"ACG"
+    names = [b"t%06d" % i for i in range(len(seqs))]
+    b, o = to_arrays(seqs)
+    Td = ctx.upload(b, o, np.arange(len(seqs), dtype=np.uint32))
+    ixd = engine.Index(ctx, Td, PRESETS["ont"])
+    opt = oracle.make_opt(oracle.PRESET_AVA_ONT, dual=True)
+    ixo = oracle.Index(oracle.ReadSet(seqs, names), opt)
+    st = ixd.stats()
+    assert st["n_minimizers"] == ixo.n_minimizers and st["n_minimizers"] > 50000
+    assert st["n_keys"] == ixo.n_keys and st["mid_occ"] == ixo.mid_occ
+    keys, pos = ixd.dump()
+    mz = ixo.minimizers()
+    order = np.lexsort((mz["y"], mz["x"] >> np.uint64(8)))
+    assert np.array_equal(keys, (mz["x"] >> np.uint64(8))[order])
+    assert np.array_equal(pos, mz["y"][order])
+    ixd.free()
+
+
 @pytest.mark.parametrize("preset", ["ont", "pb"])
 def test_segment_packed_pair_index_is_exact(ctx, oracle, edge_set, tiny_ont, tiny_hifi, preset, knobs):
     """The (hash, y) pair layout sorted in its segment-packed form (k_prims.h: index_sort_segpacked: the low hash byte first, then

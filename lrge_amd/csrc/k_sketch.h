@@ -505,13 +505,17 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_direct(const u64 *__restr
 // One wavefront per 64 consecutive chunks: their minimizers form one contiguous output range, which the lanes walk 64
 // entries at a time (the chunk of an entry by a 6-step search through the 64 scanned counts), so the writes are
 // consecutive across the wave and the reads touch the fronts of two or three slots.
+// c_base / out_cap / ovf: the ranged form (host_sketch.inl: a set whose slots do not fit at once is sketched range by range into the
+// same slots): the launch covers chunks [c_base, n_chunks), `*d_total` is the output offset behind the range, and an entry that
+// would land at or beyond out_cap raises *ovf instead (the caller's estimate of the output size was too small: it starts over).
 template <bool PAIRS>
 __global__ __launch_bounds__(256) void k_sketch_compact(const u64 *__restrict__ tmp_x, const u64 *__restrict__ tmp_y,
                                                         const u32 *__restrict__ offs, const u32 *__restrict__ d_total, u32 n_chunks,
-                                                        u64 *__restrict__ out_x, u64 *__restrict__ out_y) {
+                                                        u64 *__restrict__ out_x, u64 *__restrict__ out_y, u32 c_base = 0, u32 out_cap = 0xFFFFFFFFu,
+                                                        u32 *__restrict__ ovf = nullptr) {
     __shared__ u32 so[4][65];
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 c0 = (blockIdx.x * 4 + w) * 64;
+    const u32 c0 = c_base + (blockIdx.x * 4 + w) * 64;
     const u32 c = c0 + lane;
     if (c0 < n_chunks) {
         so[w][lane] = c < n_chunks ? offs[c] : *d_total;
@@ -526,10 +530,22 @@ __global__ __launch_bounds__(256) void k_sketch_compact(const u64 *__restrict__ 
         for (int st = 32; st > 0; st >>= 1) if (so[w][j + st] <= o) j += st;
         const u32 within = o - so[w][j];
         if (within >= SK_CAP) continue;                  // a chunk that overflowed its slot (the caller discards this output)
+        if (o >= out_cap) { if (ovf) *ovf = 1u; continue; }
         const u64 src = (u64)(c0 + j) * SK_CAP + within;
         out_x[o] = tmp_x[src];
         if (PAIRS) out_y[o] = tmp_y[src];
     }
+}
+
+// ranged sketch: offs[i] += *base for the range's chunks ...
+__global__ __launch_bounds__(256) void k_add_base_u32(u32 *__restrict__ a, u32 n, const u32 *__restrict__ base) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += *base;
+}
+// ... and then *run += *add (one thread, behind it on the stream); the sum is clamped so that a 32-bit wrap shows as an overflow
+__global__ void k_bump_u32(u32 *__restrict__ run, const u32 *__restrict__ add, u32 *__restrict__ ovf) {
+    const u64 s = (u64)*run + *add;
+    if (s > 0xFFFFFFFFull) { *ovf = 1u; *run = 0xFFFFFFFFu; } else *run = (u32)s;
 }
 
 // per-read minimizer offsets from per-chunk offsets: mz_off[r] = offs[chunk_start[r]]

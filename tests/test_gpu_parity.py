@@ -27,15 +27,18 @@ def _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset, dual=True):
     return Qd, Td, ixd, Qo, To, ixo
 
 
-@pytest.mark.parametrize("form", ["one-pass", "two-pass", "overflow-fallback"])
+@pytest.mark.parametrize("form", ["one-pass", "two-pass", "overflow-fallback", "ranged"])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
 def test_sketch_parity(ctx, oracle, edge_set, preset, form, knobs):
-    # one-pass (per-chunk slots + compaction, the default), the two-pass form (count, scan, write), and the fallback from
-    # the first to the second when a chunk overflows its slot (forced here by a tiny slot capacity)
+    # one-pass (per-chunk slots + compaction, the default), the two-pass form (count, scan, write), the fallback from
+    # the first to the second when a chunk overflows its slot (forced here by a tiny slot capacity), and the ranged one-pass
+    # form of sets whose slots do not fit at once (ranges of 256 chunks here: ~12 ranges, reads crossing their borders)
     if form == "two-pass":
         knobs.set("SKETCH_TWO_PASS", "1")
     elif form == "overflow-fallback":
         knobs.set("DEBUG_SK_CAP", "9")
+    elif form == "ranged":
+        knobs.set("DEBUG_SK_RANGE_CHUNKS", "256")
     qseqs, qnames, tseqs, tnames = edge_set
     seqs = tseqs + [b"", b"A", b"ACGTTGCA" * 3]            # empty and tiny reads keep their rid
     S = _upload(ctx, seqs)

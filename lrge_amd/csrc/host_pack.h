@@ -38,31 +38,37 @@ static inline void hp_word_scalar(const u8 *src, u32 cnt, u64 *bits, u32 *mask) 
 }
 
 #if defined(__x86_64__)
-__attribute__((target("avx2,bmi2"))) static inline void hp_word_avx2(const u8 *src, u64 *bits, u32 *mask) {
+// 32 bases at once.  Letters: a table lookup on the low nibble of the case-folded byte gives the high nibble the byte must have
+// (A 0x41, C 0x43, G 0x47: 4; T 0x54, U 0x55: 5).  Codes: bits 1..2 of the byte, b ^ (b >> 1), zeroed for non-letters, then two
+// multiply-adds put four 2-bit codes into the low byte of every dword (c0 + 4 c1, then x0 + 16 x1) and one byte shuffle
+// collects them: ~18 vector operations per word, AVX2 only (the first form used four pext / pdep pairs per word, ~45 operations and
+// BMI2).  MEASURED: the pack of the headline workload's 720 Mbases takes 6.1-6.3 ms on 32 threads either way, and 5.7 on 96 -- it
+// reads the caller's buffer at ~120 GB/s, which is what ONE NUMA node of the host delivers: the memory, not the arithmetic.
+__attribute__((target("avx2"))) static inline void hp_word_avx2(const u8 *src, u64 *bits, u32 *mask) {
     const __m256i v = _mm256_loadu_si256((const __m256i *)src);
     const __m256i up = _mm256_and_si256(v, _mm256_set1_epi8((char)0xDF));            // fold case
-    __m256i ok = _mm256_cmpeq_epi8(up, _mm256_set1_epi8('A'));
-    ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(up, _mm256_set1_epi8('C')));
-    ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(up, _mm256_set1_epi8('G')));
-    ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(up, _mm256_set1_epi8('T')));
-    ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(up, _mm256_set1_epi8('U')));
+    const __m256i nib = _mm256_set1_epi8(0x0F);
+    const __m256i want = _mm256_setr_epi8(-1, 4, -1, 4, 5, 5, -1, 4, -1, -1, -1, -1, -1, -1, -1, -1,
+                                          -1, 4, -1, 4, 5, 5, -1, 4, -1, -1, -1, -1, -1, -1, -1, -1);
+    const __m256i hi = _mm256_and_si256(_mm256_srli_epi16(up, 4), nib);
+    const __m256i ok = _mm256_cmpeq_epi8(_mm256_shuffle_epi8(want, _mm256_and_si256(up, nib)), hi);
     const u32 letters = (u32)_mm256_movemask_epi8(ok);
-    alignas(32) u64 q[4];
-    _mm256_store_si256((__m256i *)q, v);
-    u64 b = 0;
-    for (int t = 0; t < 4; ++t) {
-        const u64 two = _pext_u64(q[t], 0x0606060606060606ull);                      // bits 1..2 of every byte: 16 bits
-        const u64 code = two ^ ((two >> 1) & 0x5555ull);                             // b ^ (b >> 1) inside every pair
-        const u64 keep = _pdep_u64((letters >> (8 * t)) & 0xffu, 0x5555ull) * 3;      // 11 for a letter, 00 otherwise
-        b |= (code & keep) << (16 * t);
-    }
-    *bits = b; *mask = ~letters;
+    __m256i c = _mm256_and_si256(_mm256_srli_epi16(v, 1), _mm256_set1_epi8(3));                    // bits 1..2 of every byte
+    c = _mm256_xor_si256(c, _mm256_and_si256(_mm256_srli_epi16(c, 1), _mm256_set1_epi8(1)));      // b ^ (b >> 1)
+    c = _mm256_and_si256(c, ok);
+    const __m256i x = _mm256_maddubs_epi16(c, _mm256_set1_epi16(0x0401));                           // c0 + 4 c1 per 16 bits
+    const __m256i y = _mm256_madd_epi16(x, _mm256_set1_epi32(0x00100001));                          // x0 + 16 x1 per 32 bits: 4 codes in the low byte
+    const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                          0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const __m256i z = _mm256_shuffle_epi8(y, pick);
+    const u64 lo = (u32)_mm256_cvtsi256_si32(z), hi32 = (u32)_mm256_extract_epi32(z, 4);
+    *bits = lo | hi32 << 32; *mask = ~letters;
 }
 #endif
 
 static bool hp_have_avx2() {
 #if defined(__x86_64__)
-    static const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+    static const bool ok = __builtin_cpu_supports("avx2");
     return ok;
 #else
     return false;

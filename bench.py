@@ -1,23 +1,28 @@
 #!/usr/bin/env python
 """bench.py -- reads overlapped/sec of the liblrge overlap hot path on MI355X.
 
-Workload (N=1 and N>1): BASELINE.json configs[3], the configuration the metric is quoted on that fits one GPU and
-generates in seconds -- D. melanogaster-scale 143 Mbp synthetic ONT set, two-set forward -Q 50000 -T 100000, preset
-ava-ont (what the reference CLI always runs: lrge/src/main.rs:56-85 never forwards -P).  `--config c2_bact_twoset`
-(configs[1]), `--config c5_human_tenth`, `--inverse` select other two-set workloads.
+Workload (default): BASELINE.json configs[4], the configuration the >= 10x target is quoted on and that fits ONE GPU since
+round 3 -- H. sapiens-scale 3.1 Gbp synthetic PacBio HiFi set, two-set forward -Q 100000 -T 2000000 (31.5 Gbases), preset
+ava-pb (liblrge's PacBio semantics; `--preset ont` is what the reference CLI runs: lrge/src/main.rs:56-85 never forwards -P).
+The reads come from the counter-based generator (lrge_amd/synth_cb.py; 31.5 Gbases in ~1 s, untimed).  `--config
+c4_dmel_twoset` (configs[3], rounds 1-3's line), `c2_bact_twoset` (configs[1]), `c5_human_tenth`, `--inverse` select the others.
 
-One "step" = the whole job on one batch of reads whose ASCII bases are already resident in HBM when the clock starts:
-2-bit pack (K0) of both sets, minimizer index build over the targets, sketch + seed + chain of every query,
-distinct-target counts, per-read estimates, median (twoset.rs:587-606 from "reads in memory" on).  `value` = query reads
-/ wall time.  The same loop is then run from ASCII reads in pinned HOST memory (upload over PCIe inside the clock,
-queries travelling while the target index is built): reported as `from_host`, never as `value`.
+One "step" = the whole job on one batch of reads: 2-bit pack (K0) of both sets, minimizer index build over the targets,
+sketch + seed + chain of every query, distinct-target counts, per-read estimates, median (twoset.rs:587-606 from "reads in
+memory" on).  TWO clocks, both measured in every run:
+  * `value` / `ms_per_step` -- SURVEY.md 8(d)'s clock: the ASCII reads are FASTA-parsed reads in (pinned) HOST memory when the
+    clock starts; host-side 2-bit pack, the PCIe transfer (targets first, the queries travel while the target index is built)
+    and everything behind them are inside.  This is the figure VERDICT r03 credits, and the smaller of the two.
+  * `resident` -- the same step with the ASCII reads already resident in HBM (pack on the device, no PCIe): what rounds 1-3
+    reported as `value`.  `--clock resident` makes it `value` again (and says so in config.clock).
+`value` = query reads / wall time of EXACTLY --steps steps after --warmup warm-up steps, barrier + device synchronise on both sides.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of the one job.  The query set is cut into
 N contiguous ranges with equal base counts; every rank owns its range end to end.  The target index a rank needs is
-restricted to the minimizers its own queries carry: every rank sketches all targets, keeps 1/N of
-the key space for the global occurrence statistics (one small all-reduce fixes mid_occ exactly) and the entries whose
-key occurs in its queries for its index.  One all-gather of the per-read estimates closes the step (RCCL through the
-library's C ABI: lrge_hip_comm_*).  value = all query reads / max-over-ranks time.
+restricted to the minimizers its own queries carry: every rank sketches 1/N of the targets, key sets are
+all-gathered, kept entries and owned hashes travel by all-to-all (one small all-reduce fixes mid_occ exactly).  One all-gather of
+the per-read estimates closes the step (RCCL through the library's C ABI: lrge_hip_comm_*).  value = all query reads /
+max-over-ranks time.
 """
 import argparse
 import json
@@ -37,9 +42,16 @@ HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c4_dmel_twoset")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c5_human_twoset")
+    ap.add_argument("--clock", default="host", choices=["host", "resident"],
+                    help="which clock `value` is quoted on: host = SURVEY 8(d): ASCII reads in pinned host memory when the clock "
+                         "starts (default); resident = ASCII reads already in HBM (rounds 1-3).  The other one is measured too "
+                         "(`resident` / `from_host` on the line) unless --no-from-host / --no-resident")
+    ap.add_argument("--no-resident", action="store_true")
+    ap.add_argument("--parity-sample", type=int, default=256, help="query reads whose FORWARD counts the CPU oracle recomputes at full "
+                                                                   "H. sapiens scale (restricted index: oracle/c5_sample.py); 0 = skip")
     ap.add_argument("--preset", default=None, choices=["ont", "pb"], help="minimap2 preset (default: by the configuration's platform: pb for the HiFi sets, ont otherwise)")
     ap.add_argument("--inverse", action="store_true", help="--use-min-ref: index the queries, stream the targets")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the config (debug only; invalid as a result)")
@@ -97,18 +109,49 @@ def cpu_baseline(q, t, budget_s, preset):
         (np.concatenate(counts) if counts else np.zeros(0, np.uint32)), ix.mid_occ
 
 
-def committed_traffic(config):
-    """HBM bytes per step of the whole path from the round's committed rocprofv3 --pmc passes (profiles/r03_hbm_traffic.json,
-    made by tools/summarize_profiles.py from the FETCH_SIZE / WRITE_SIZE passes of this same command), next to the algorithmic
-    bytes: the counters cannot be read inside a timed run."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")) as f:
-            d = json.load(f)
-        if d.get("config") != config:
-            return None
-        return {k: d[k] for k in ("fetch_GB_per_step", "write_GB_per_step", "algorithmic_GB_per_step", "traffic_over_algorithmic", "source") if k in d}
-    except Exception:      # noqa: BLE001
+PROFILE_ROUND = "r04"
+
+
+def _committed(config, inverse):
+    """profiles/r04_hbm_traffic[_<config>].json: made by tools/summarize_profiles.py from the FETCH_SIZE / WRITE_SIZE passes of
+    this same command (tools/profile_round.sh)."""
+    for name in ("%s_hbm_traffic_%s%s.json" % (PROFILE_ROUND, config, "_inverse" if inverse else ""), "%s_hbm_traffic.json" % PROFILE_ROUND):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            if d.get("config") == config and bool(d.get("inverse", False)) == bool(inverse):
+                return d, name
+        except Exception:      # noqa: BLE001
+            pass
+    return None, None
+
+
+def committed_traffic(config, inverse=False):
+    """HBM bytes per step of the whole path from the round's committed rocprofv3 --pmc passes, next to the algorithmic bytes:
+    the counters cannot be read inside a timed run."""
+    d, name = _committed(config, inverse)
+    if d is None:
         return None
+    out = {k: d[k] for k in ("fetch_GB_per_step", "write_GB_per_step", "algorithmic_GB_per_step", "traffic_over_algorithmic", "source") if k in d}
+    out["file"] = "profiles/" + name
+    return out
+
+
+def committed_kernel_traffic(config, inverse, kernel):
+    """(HBM bytes per launch of `kernel` [2 x FETCH_SIZE + WRITE_SIZE, averaged over its launches and template instantiations
+    in the committed pass], detail) or (None, None)."""
+    d, name = _committed(config, inverse)
+    if d is None:
+        return None, None
+    n = f = w = 0.0
+    for k, v in d.get("kernels", {}).items():
+        if k == kernel or k.startswith(kernel + "<"):
+            ln = float(v.get("launches_in_pass", 0))
+            n += ln; f += ln * v["fetch_raw_bytes_per_launch"]; w += ln * v["write_raw_bytes_per_launch"]
+    if not n:
+        return None, None
+    return (2.0 * f + w) / n, {"fetch_raw_bytes_per_launch": f / n, "write_raw_bytes_per_launch": w / n, "launches_in_pass": n,
+                               "correction": "reads x2 (gfx950 tallies 128-B read requests at 64 B), writes x1", "file": "profiles/" + name}
 
 
 def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
@@ -142,7 +185,11 @@ def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
                 sample="SAMPLE of the job: oracle index over %d of the %d target reads (%.1f s), %d query reads mapped against it on %d "
                        "threads (%.1f s); pro-rated x%.1f in the target dimension (index time and per-read map time both scale with "
                        "the number of target reads) and to all %d queries" % (nt, Tn, t_index, done, cores, t_map, scale, Qn),
-                index_s_sample=t_index, map_s_sample=t_map, reads_mapped=done)
+                index_s_sample=t_index, map_s_sample=t_map, reads_mapped=done,
+                measured_only={"what": "what was actually timed, nothing pro-rated: %d query reads mapped against an index of %d target reads"
+                                       % (done, nt), "reads_per_s_map_only": done / t_map, "index_s": t_index, "map_s": t_map},
+                pro_rating={"target_factor": scale, "assumption": "index time and per-read map time linear in the number of target reads "
+                                                                  "(the per-read sketch is not: the estimate slightly overstates the CPU's time per read)"})
 
 
 XGMI_LINK_GBPS = 64.0     # one direction of one xGMI link, what a point-to-point transfer between two GPUs sustains (7 links per GPU)
@@ -343,11 +390,9 @@ def main():
             self.shard_lens = [self.bounds[i + 1] - self.bounds[i] for i in range(n_shards)]
             self.max_shard = max(self.shard_lens)
             self.qs, self.ts = Src(), Src()
+            self.device = device
             if gen == "cb":
-                for S, (r0, r1), first in ((self.qs, q_rng, 0), (self.ts, t_rng, Qn)):
-                    S.dev = spec.device_reads(first + r0, r1 - r0, device)      # ASCII straight into HBM
-                    S.n, S.offsets, S.rank, S.nbytes, S.ptr = r1 - r0, S.dev.offsets, S.dev.name_ranks(), S.dev.total_bases, S.dev.ptr
-                    S.host = S.dev.to_host
+                self.load_resident()
             else:
                 for S, R, rk, (r0, r1) in ((self.qs, q, qr_all, q_rng), (self.ts, t, tr_all, t_rng)):
                     sub = R if (r0, r1) == (0, R.n) else R.slice(r0, r1)
@@ -357,6 +402,13 @@ def main():
                     S.host = (lambda sub=sub: sub.bases)
             self.qs_lens = q_lens[q_rng[0]:q_rng[1]]
             self.shard_stats = None
+
+        def load_resident(self):
+            """(counter-based generator) the ASCII reads of this rank written into HBM by the device twin"""
+            for S, (r0, r1), first in ((self.qs, self.q_rng, 0), (self.ts, self.t_rng, Qn)):
+                S.dev = spec.device_reads(first + r0, r1 - r0, self.device)      # ASCII straight into HBM
+                S.n, S.offsets, S.rank, S.nbytes, S.ptr = r1 - r0, S.dev.offsets, S.dev.name_ranks(), S.dev.total_bases, S.dev.ptr
+                S.host = S.dev.to_host
 
         def step(self, src_q, src_t):
             """src_*: int device pointer (ASCII resident in HBM) or PinnedBuffer (ASCII in pinned host memory)."""
@@ -433,27 +485,75 @@ def main():
             elapsed = float(tt.item())
         return elapsed, acc_tb, acc_tm, acc_cn, last
 
-    elapsed, acc_tb, acc_tm, acc_cn, last = timed(qs.ptr, ts.ptr, a.warmup, a.steps)
-    counts, est_all, med, _, _, _, st = last
-    # one instrumented step AFTER the timed region: an event pair around every k_rs_scatter launch (timer level 2 costs
-    # host work between launches, so the timed steps run at the default level)
-    ctx.set_timer_level(2)
-    _, _, _, tb2, tm2, cn2, _ = step(qs.ptr, ts.ptr)
-    ctx.set_timer_level(1)
+    # big jobs (launches of milliseconds): an event pair around every k_rs_scatter launch costs nothing there, so the TIMED steps
+    # carry them; small jobs time that kernel in one instrumented step behind the timed region (timer level 2 is host work
+    # between launches: ~2 % of a C2 step)
+    lvl2_all = float(q_lens.sum()) + float(t_lens.sum()) > 5e9
+    if lvl2_all:
+        ctx.set_timer_level(2)
+    # ---- the two clocks ----
+    # host (`value` by default): the ASCII reads sit in pinned host memory when the clock starts.  The pinned copies are
+    # made from the resident reads first (untimed); with the counter-based generator the resident copies then make room for
+    # the staging blocks of the uploads and are written again by the device twin before the resident clock runs.
+    clock_host = a.clock == "host" and not emu
+    want_host = clock_host or (not a.no_from_host and not emu)
+    want_res = (not clock_host) or not a.no_resident
+    res_host = res_res = None
+    k_other = a.steps if a.config != "c5_human_twoset" else max(2, a.steps // 3)    # steps of the clock that is not `value`
+    hq = ht = None
 
-    from_host = None
-    if not a.no_from_host and not emu:
+    def run_host(warmup, steps):
+        return timed(hq, ht, warmup, steps)
+
+    def run_resident(warmup, steps):
+        return timed(qs.ptr, ts.ptr, warmup, steps)
+
+    if want_host:
         hq = ctx.host_alloc(max(qs.nbytes, 1)); ht = ctx.host_alloc(max(ts.nbytes, 1))
         hq.array[:qs.nbytes] = qs.host(); ht.array[:ts.nbytes] = ts.host()
-        if gen == "cb":       # the resident copies have done their part: their room goes to the staging blocks of the uploads
+    if clock_host:
+        if gen == "cb":
             qs.dev.free(); ts.dev.free()
-        k2 = max(3, a.steps // 2)
-        e2, _, _, _, last2 = timed(hq, ht, 1, k2)
-        from_host = {"ms_per_step": e2 * 1e3 / k2, "value": Qn * k2 / e2, "unit": "reads/s", "steps": k2,
-                     "what": "same step with the ASCII reads in pinned host memory when the clock starts: %.2f GB over PCIe "
-                             "inside the timed region, on the copy stream (queries travel while the target index is built)"
-                             % ((qs.nbytes + ts.nbytes) / 1e9),
-                     "counts_equal_resident_run": bool(np.array_equal(last2[0], counts))}
+        res_host = run_host(a.warmup, a.steps)
+        if want_res:
+            if gen == "cb":
+                job.load_resident()
+            res_res = run_resident(1, k_other)
+    else:
+        res_res = run_resident(a.warmup, a.steps)
+        if want_host:
+            if gen == "cb":
+                qs.dev.free(); ts.dev.free()
+            res_host = run_host(1, k_other)
+            if gen == "cb":
+                job.load_resident()
+    main_res = res_host if clock_host else res_res
+    elapsed, acc_tb, acc_tm, acc_cn, last = main_res
+    counts, est_all, med, _, _, _, st = last
+    # one instrumented step AFTER the timed regions: an event pair around every k_rs_scatter launch (timer level 2 costs
+    # host work between launches, so the timed steps run at the default level)
+    tb2 = tm2 = cn2 = {}
+    if not lvl2_all:
+        ctx.set_timer_level(2)
+        if clock_host and not want_res:
+            _, _, _, tb2, tm2, cn2, _ = step(hq, ht)
+        else:
+            _, _, _, tb2, tm2, cn2, _ = step(qs.ptr, ts.ptr)
+        ctx.set_timer_level(1)
+
+    def clock_block(res, steps, what):
+        if res is None:
+            return None
+        e_, _, tm_, _, last_ = res
+        return {"ms_per_step": e_ * 1e3 / steps, "value": Qn * steps / e_, "unit": "reads/s", "steps": steps, "what": what,
+                "counts_equal_other_clock": bool(np.array_equal(last_[0], counts))}
+    what_host = ("ASCII reads in pinned host memory when the clock starts (SURVEY 8d): %.2f GB handed over per step; host-side 2-bit "
+                 "pack + PCIe on the copy stream inside the timed region (targets first, the queries travel while the index is built)"
+                 % ((qs.nbytes + ts.nbytes) / 1e9))
+    what_res = "ASCII reads already resident in HBM when the clock starts; 2-bit pack on the device inside the step (rounds 1-3's `value`)"
+    from_host = None if clock_host else clock_block(res_host, k_other, what_host)
+    resident = clock_block(res_res, k_other, what_res) if clock_host else None
+    if hq is not None:
         hq.free(); ht.free()
 
     if emu:
@@ -478,18 +578,23 @@ def main():
                     "frac": ach / HBM_PEAK_GBPS, "traffic": None, "alg_bytes_per_launch": alg, "alg_bytes": bytes_note,
                     "avg_launch_ms": avg_ms, "launches_per_step": launches / K, "ms_per_step": ms_total / K}
 
-        # Candidates, each timed with HIP event pairs on the stream it runs on during the TIMED steps; `roofline` is the one with
-        # the most time per step.  Algorithmic bytes per launch follow SURVEY.md 8(d)'s per-unit terms:
+        # Candidates, each timed with HIP event pairs on the stream it runs on during the TIMED steps.  `roofline` is the SINGLE
+        # KERNEL with the most time per step; kernel families (all kernels of a sort, of the sketch) are
+        # reported beside it in `roofline_other` with kind = "family".  Algorithmic bytes per launch follow SURVEY.md 8(d):
         #   k_lookup           16 B per query minimizer (one hash/offset entry per lookup)
         #   k_chain_lpg        16 B per anchor it chains (8 B key + 8 B value in)
-        #   index radix sort   the kernel FAMILY of the index sort (k_rs_hist + scan + k_rs_scatter, all passes, one unit per
-        #                      step): every entry read once and written once -- what any sort must move (8(d) itself counts
-        #                      the ordering of the index as zero algorithmic bytes, so this is the kindest denominator)
-        #   index sketch       L/4 B of packed bases in + one entry out per minimizer (k_sketch_direct + k_sketch_compact)
         #   k_expand           8 B position-list entry in + 8 B anchor out per anchor
-        # traffic: not measured inside this run (PMC counters need rocprofv3's own passes): null here; the per-launch HBM bytes
-        # of the same command are committed under profiles/ (summary: profiles/README.md).
-        cands = []
+        #   k_rs_scatter       8(d) counts the ORDERING of index entries and anchors as implementation overhead (zero algorithmic
+        #                      bytes); the kindest honest denominator is what any sort must move -- every index entry and every
+        #                      anchor read once and written once per STEP -- dealt over the launches that do the moving: a sort of
+        #                      P passes can reach at most 1/P of the roof on this scale.  (`streamed`: the bytes the launches
+        #                      actually read + write, i.e. the kernel as a streaming kernel.)
+        #   families           index radix sort (k_rs_hist + scan + k_rs_scatter, all passes): one read + one write of every entry;
+        #                      index sketch (k_sketch_direct + k_sketch_compact): L/4 B of packed bases in + one entry out
+        # traffic: HBM bytes per launch of that kernel from the round's committed rocprofv3 --pmc passes of this same command
+        # (profiles/r04_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950); the counters
+        # cannot be read inside a timed run.
+        cands, fams = [], []
         if acc_cn.get("lookup_launches", 0):
             cands.append(roof("k_lookup", acc_tm.get("k_lookup", 0.0), acc_cn["lookup_launches"],
                               16.0 * acc_cn.get("query_minimizers", 0), "16 B x query minimizers (SURVEY 8d: one hash/offset entry per lookup)"))
@@ -499,35 +604,56 @@ def main():
         n_idx = float(st["n_minimizers"]) if not (world > 1 and not a.inverse) else float(acc_cn.get("rs_scatter_items", 0)) / max(1, K) / 4.0
         entry_b = 8.0 if (2 * (19 if preset else 15) + int(np.ceil(np.log2((Qn if a.inverse else Tn) + 1))) + int(np.ceil(np.log2(float((q_lens if a.inverse else t_lens).max()) + 1))) + 1) <= 64 else 16.0
         if acc_tb.get("index_sort", 0.0) > 0 and world == 1:
-            cands.append(roof("index radix sort (k_rs_hist + scan + k_rs_scatter, all passes)", acc_tb["index_sort"], K, 2.0 * entry_b * n_idx * K,
-                              "%d B in + %d B out per index entry: one read and one write of every entry" % (entry_b, entry_b)))
+            fams.append(roof("index radix sort (k_rs_hist + scan + k_rs_scatter, all passes)", acc_tb["index_sort"], K, 2.0 * entry_b * n_idx * K,
+                             "%d B in + %d B out per index entry: one read and one write of every entry" % (entry_b, entry_b)))
         if acc_tb.get("sketch", 0.0) > 0 and world == 1:
             L_idx = float((q_lens if a.inverse else t_lens).sum())
-            cands.append(roof("index sketch (k_sketch_direct + k_sketch_compact)", acc_tb["sketch"], K, (L_idx / 4.0 + entry_b * n_idx) * K,
-                              "L/4 B of packed bases in + %d B per minimizer out" % entry_b))
+            fams.append(roof("index sketch (k_sketch_direct + k_sketch_compact)", acc_tb["sketch"], K, (L_idx / 4.0 + entry_b * n_idx) * K,
+                             "L/4 B of packed bases in + %d B per minimizer out" % entry_b))
+        if acc_tm.get("anchor_sort", 0.0) > 0:
+            fams.append(roof("anchor sort (k_seg_sort_local / k_rs_hist + scan + k_rs_scatter)", acc_tm["anchor_sort"], K, 24.0 * acc_cn.get("anchors", 0),
+                             "8 B packed anchor in + 16 B (key, value) out per anchor"))
         if acc_tm.get("expand", 0.0) > 0:
             cands.append(roof("k_expand", acc_tm["expand"], max(1, acc_cn.get("batches", K)), 16.0 * acc_cn.get("anchors", 0),
                               "8 B position-list entry in + 8 B anchor out per anchor"))
+        # k_rs_scatter: in the timed steps when they run at timer level 2 (big jobs), else in the instrumented step behind them
+        if lvl2_all:
+            sc_ms, sc_n, sc_bytes, sc_how = acc_tm.get("rs_scatter", 0.0) + acc_tb.get("rs_scatter", 0.0), acc_cn.get("rs_scatter_launches", 0), float(acc_cn.get("rs_scatter_bytes", 0)), "event pair around every launch of the timed steps"
+            anchors_moved = float(acc_cn.get("anchors", 0))
+        else:
+            sc_ms, sc_n, sc_bytes, sc_how = (tm2.get("rs_scatter", 0.0) + tb2.get("rs_scatter", 0.0)) * K, cn2.get("rs_scatter_launches", 0) * K, float(cn2.get("rs_scatter_bytes", 0)) * K, "one instrumented step after the timed region (event pair around every launch)"
+            anchors_moved = float(cn2.get("anchors", 0)) * K
+        if sc_n:
+            r_sc = roof("k_rs_scatter", sc_ms, sc_n, 2.0 * entry_b * n_idx * K + 16.0 * anchors_moved,
+                        "what any sort must move, once per step: %d B in + %d B out per index entry, 8 B in + 8 B out per anchor -- dealt over this "
+                        "kernel's launches (SURVEY 8d counts ordering as zero algorithmic bytes)" % (entry_b, entry_b))
+            r_sc["measured"] = sc_how
+            r_sc["streamed"] = {"bytes_per_launch": sc_bytes / sc_n, "GBps": sc_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0,
+                                "what": "bytes the launches read + write (32 / pair, 16 / packed key, 24 unpacking): the kernel as a streaming kernel"}
+            cands.append(r_sc)
+        for r_ in cands: r_["kind"] = "kernel"
+        for r_ in fams: r_["kind"] = "family"
         cands.sort(key=lambda r: -r["ms_per_step"])
-        r_sc = roof("k_rs_scatter", (tm2.get("rs_scatter", 0.0) + tb2.get("rs_scatter", 0.0)) * K, cn2.get("rs_scatter_launches", 0) * K,
-                    float(cn2.get("rs_scatter_bytes", 0)) * K, "bytes each launch has to read + write (32 / pair, 16 / packed key, 24 unpacking)")
-        r_sc["measured"] = "one instrumented step after the timed region (event pair around every launch)"
+        for r_ in cands + fams:
+            r_["traffic"], r_["traffic_detail"] = committed_kernel_traffic(a.config, a.inverse, r_["kernel"]) if r_["kind"] == "kernel" else (None, None)
         # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
         # (streamed set: the queries, or the targets with --inverse; for N > 1 rank 0's counters times the world size)
         L = float((t_lens if a.inverse else q_lens).sum()); M = world * acc_cn.get("query_minimizers", 0) / K; H = world * acc_cn.get("anchors", 0) / K
         B_q = L / 4 + 32 * M + 8 * H + 32 * H + 4 * Qn
         B_idx = float((q_lens if a.inverse else t_lens).sum()) / 4 + 16 * st["n_minimizers"]
         e2e_gbps = (B_q + B_idx) / (ms_per_step * 1e-3) / 1e9
-        r_dom = cands[0] if cands else r_sc
+        r_dom = cands[0] if cands else {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 0.0, "traffic": None}
+        clock_txt = ("ASCII reads in pinned HOST memory when the clock starts (SURVEY 8d): host-side 2-bit pack + PCIe inside the step"
+                     if clock_host else "ASCII reads resident in HBM, 2-bit pack inside the step")
         out = {
             "metric": "reads overlapped/sec (whole node)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 keys / i32 chain scores / f32 gap penalty", "data": "synthetic",
-            "config": {"workload": "%s: %.1f Mbp genome, %s reads, two-set %s -Q %d -T %d, preset %s, dual=yes; ASCII reads "
-                                   "resident in HBM, 2-bit pack inside the step"
+            "config": {"workload": "%s: %.1f Mbp genome, %s reads, two-set %s -Q %d -T %d, preset %s, dual=yes; %s"
                                    % (a.config, gsize / 1e6, cfg["platform"], "--use-min-ref (index = queries, targets streamed)" if a.inverse else "forward",
-                                      Qn, Tn, "ava-pb" if preset else "ava-ont"),
+                                      Qn, Tn, "ava-pb" if preset else "ava-ont", clock_txt),
+                       "clock": "host" if clock_host else "resident",
                        "query_reads": Qn, "target_reads": Tn,
                        "parallelism": ("one job, streamed targets cut into %d ranges by bases; query index replicated; counts all-reduced" % world) if a.inverse else
                                       ("one job, queries cut into %d ranges by bases; index %s" %
@@ -539,6 +665,7 @@ def main():
                        "target_sketch": ("sharded (lrge_hip_index_build_sharded)" if job.sharded else "replicated") if world > 1 and not a.inverse else None,
                        "exchange_per_step_rank0": job.shard_stats,
                        "scale": a.scale, "data_gen_s": round(t_gen, 1)},
+            "resident": resident,
             "from_host": from_host,
             "genome_size_true": gsize,
             "genome_size_estimate": None if med[1] is None else float(med[1]),
@@ -546,8 +673,8 @@ def main():
             "estimate_q15_q65": [None if med[0] is None else float(med[0]), None if med[2] is None else float(med[2])],
             "mid_occ": st["mid_occ"],
             "roofline": {**r_dom, "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS,
-                         "whole_path_traffic": committed_traffic(a.config)},
-            "roofline_other": cands[1:] + [r_sc],
+                         "whole_path_traffic": committed_traffic(a.config, a.inverse)},
+            "roofline_other": cands[1:] + fams,
             "stage_ms_per_step": {**{"index_" + k: v / K for k, v in acc_tb.items() if v and k != "total"},
                                   **{k: v / K for k, v in acc_tm.items() if v}},
             "work_per_step": {k: (v if k == "lpg_split" else v / K) for k, v in acc_cn.items()},
@@ -556,8 +683,28 @@ def main():
             if gen == "cb" and Tn > 400000:
                 cb = cpu_baseline_sampled(spec, Qn, Tn, a.cpu_seconds, preset)
                 out["cpu_baseline"] = cb
-                out["gpu_vs_cpu_port"] = value / cb["value"]
-                out["parity_vs_oracle_sample"] = None      # (no full-size oracle index inside a bench run: tests/test_gpu_configs.py::test_c5_full)
+                out["gpu_vs_cpu_port_SAMPLE"] = value / cb["value"]      # (the denominator is a pro-rated SAMPLE: see cpu_baseline.sample)
+                out["parity_vs_oracle_sample"] = None
+                if a.parity_sample > 0 and a.config == "c5_human_twoset" and a.scale == 1.0:
+                    # FORWARD counts of a sample of queries against the oracle at full size: the oracle's index restricted to the keys
+                    # of the sample (oracle/c5_sample.py; every target read goes through the oracle's mm_sketch), mid_occ / n_keys /
+                    # n_minimizers from the oracle's committed KeyStats fixture
+                    from oracle import c5_sample
+                    fx = c5_sample.fixture_stats(spec, Qn, Tn, "ava-pb" if preset else "ava-ont")
+                    idx = c5_sample.sample_indices(Qn, a.parity_sample)
+                    if job.qs.dev.ptr:       # make room: the sample's target chunks are written by the device twin
+                        job.qs.dev.free(); job.ts.dev.free()
+                    r = c5_sample.forward_sample(spec, Qn, Tn, preset, idx, fx["mid_occ"], source="device", device=local_rank)
+                    out["parity_vs_oracle_sample"] = {
+                        "reads": int(len(idx)), "which": "query reads i * Q / %d, i = 0 .. %d (every anchor batch and index part)" % (len(idx), len(idx) - 1),
+                        "counts_equal": bool(np.array_equal(r["counts"], counts[idx])),
+                        "mid_occ_equal": bool(fx["mid_occ"] == st["mid_occ"]),
+                        "n_minimizers_equal": bool(fx["n_minimizers"] == st["n_minimizers"] == r["n_minimizers_seen"]),
+                        "n_keys_equal": bool(fx["n_keys"] == st["n_keys"]),
+                        "oracle": "restricted index (lo_ridx_*): complete position lists of the sample's keys out of all %d target minimizers "
+                                  "(%d kept); %.1f s on %d threads (reads %.1f, sketch + filter %.1f, map %.1f)"
+                                  % (r["n_minimizers_seen"], r["n_kept"], r["seconds"], os.cpu_count() or 1, r["seconds_reads"], r["seconds_sketch"], r["seconds_map"]),
+                        "overlaps_in_sample": int(r["counts"].sum())}
             else:
                 if gen == "cb":
                     q, t = spec.host_reads(first=0, n=Qn), spec.host_reads(first=Qn, n=Tn)

@@ -382,10 +382,12 @@ lo_index_t *lo_index_build(const char *bases, const uint64_t *offs, uint32_t n,
         /* thread t scatters the t-th contiguous slice of the entries to positions of its own inside every bucket
            (counts per (thread, bucket), then one scan in bucket-major order): no atomics, no shared counters */
         loc = (uint64_t *)calloc((size_t)nth * 4096, 8);
-#pragma omp parallel num_threads(nth)
-        {
-            const int me = omp_get_thread_num();
-            const uint64_t per = (ix->n_mz + (uint64_t)nth - 1) / (uint64_t)nth, lo = per * (uint64_t)me, hi = lo + per < ix->n_mz ? lo + per : ix->n_mz;
+        /* (slices are dealt by a loop over 0..nth, not by omp_get_thread_num(): whatever number of threads the runtime
+           grants for a region -- OMP_DYNAMIC, OMP_THREAD_LIMIT, nesting -- every slice is counted and scattered) */
+#pragma omp parallel for schedule(static, 1)
+        for (t = 0; t < nth; ++t) {
+            const int me = t;
+            const uint64_t per = (ix->n_mz + (uint64_t)nth - 1) / (uint64_t)nth, lo = per * (uint64_t)me < ix->n_mz ? per * (uint64_t)me : ix->n_mz, hi = lo + per < ix->n_mz ? lo + per : ix->n_mz;
             uint64_t *l = loc + (size_t)me * 4096, q;
             for (q = lo; q < hi; ++q) ++l[(v.a[q].x >> 8) >> shift];
         }
@@ -397,10 +399,10 @@ lo_index_t *lo_index_build(const char *bases, const uint64_t *offs, uint32_t n,
             }
             bstart[4096] = run;
         }
-#pragma omp parallel num_threads(nth)
-        {
-            const int me = omp_get_thread_num();
-            const uint64_t per = (ix->n_mz + (uint64_t)nth - 1) / (uint64_t)nth, lo = per * (uint64_t)me, hi = lo + per < ix->n_mz ? lo + per : ix->n_mz;
+#pragma omp parallel for schedule(static, 1)
+        for (t = 0; t < nth; ++t) {
+            const int me = t;
+            const uint64_t per = (ix->n_mz + (uint64_t)nth - 1) / (uint64_t)nth, lo = per * (uint64_t)me < ix->n_mz ? per * (uint64_t)me : ix->n_mz, hi = lo + per < ix->n_mz ? lo + per : ix->n_mz;
             uint64_t *l = loc + (size_t)me * 4096, q;
             for (q = lo; q < hi; ++q) {
                 const uint64_t h = v.a[q].x >> 8, d = l[h >> shift]++;
@@ -466,11 +468,13 @@ uint64_t lo_index_n_keys(const lo_index_t *ix) { return ix->n_keys; }
 uint64_t lo_index_dump_minimizers(const lo_index_t *ix, lo_mm128_t *out, uint64_t cap)
 {
     uint64_t n = ix->n_mz < cap ? ix->n_mz : cap;
+    if (!ix->mz) return 0;      /* a restricted index (lo_ridx_finish) keeps no sketch-order copy */
     if (out) memcpy(out, ix->mz, n * sizeof(lo_mm128_t));
     return ix->n_mz;
 }
 
 static int cmp_u64(const void *pa, const void *pb);
+static void set_threads(int threads);
 /* ------------------------------------------------------------------------------------------ */
 /* Index statistics of a target set too large to index here in one piece (H. sapiens-scale: 30 Gbases): the reads go  */
 /* through mm_sketch chunk by chunk, only the minimizer hashes are kept, and n_minimizers, n_keys and mid_occ follow   */
@@ -578,6 +582,183 @@ int lo_kstat_finish(lo_kstat_t *s, int threads, uint64_t *n_mz, uint64_t *n_keys
     if (s->opt.max_mid_occ > s->opt.min_mid_occ && thres > s->opt.max_mid_occ) thres = s->opt.max_mid_occ;
     *n_mz = s->n; *n_keys = nk; *mid_occ = thres;
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Restricted index: the index of a target set too large to hold here (H. sapiens-scale: 7.5 G minimizers), reduced   */
+/* to what a SAMPLE of query reads can ask for.  mm_idx_get (index.c) is only ever called with the minimizers of the   */
+/* query at hand (seed.c:mm_seed_collect_all), and its answer is the key's complete position list; an index that holds  */
+/* the complete lists of exactly the keys occurring in the sample answers every one of those calls as the full index   */
+/* would.  What the lists cannot tell is mid_occ (a statistic over ALL keys: mm_idx_cal_max_occ): it is handed in     */
+/* (lo_kstat_* computes it for the same set).  The targets are fed chunk by chunk; every read keeps its rid, name and  */
+/* length (skip_seed and the PAF fields read them).                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+struct lo_ridx {
+    lo_opt_t opt;
+    uint64_t *tab, tab_mask;          /* open-addressing set of the sample's hashes (value + 1; 0 = empty) */
+    uint64_t n_sample_keys;
+    hy_t *hy; uint64_t n, m;          /* kept entries, any order */
+    uint64_t n_mz_seen;               /* minimizers of all targets fed so far */
+    uint32_t n_seq, m_seq;
+    char **name; int32_t *len;
+};
+
+static inline uint64_t ridx_mix(uint64_t h) { h ^= h >> 31; h *= 0x9E3779B97F4A7C15ULL; h ^= h >> 29; return h; }
+
+static int ridx_has(const lo_ridx_t *r, uint64_t h)
+{
+    uint64_t i = ridx_mix(h) & r->tab_mask;
+    for (;;) {
+        const uint64_t e = r->tab[i];
+        if (e == 0) return 0;
+        if (e == h + 1) return 1;
+        i = (i + 1) & r->tab_mask;
+    }
+}
+
+lo_ridx_t *lo_ridx_new(const lo_opt_t *opt, const char *qbases, const uint64_t *qoffs, uint32_t nq)
+{
+    lo_ridx_t *r = (lo_ridx_t *)calloc(1, sizeof(*r));
+    vec128_t v = {0, 0, 0};
+    uint64_t cap = 1024, i;
+    uint32_t q;
+    r->opt = *opt;
+    for (q = 0; q < nq; ++q)
+        if (qoffs[q + 1] > qoffs[q])
+            sketch_into(qbases + qoffs[q], (int32_t)(qoffs[q + 1] - qoffs[q]), opt->w, opt->k, q, opt->is_hpc, &v);
+    while (cap < 4 * (uint64_t)v.n + 16) cap <<= 1;
+    r->tab = (uint64_t *)calloc(cap, 8);
+    r->tab_mask = cap - 1;
+    for (i = 0; i < (uint64_t)v.n; ++i) {
+        const uint64_t h = v.a[i].x >> 8;
+        uint64_t j = ridx_mix(h) & r->tab_mask;
+        while (r->tab[j] != 0 && r->tab[j] != h + 1) j = (j + 1) & r->tab_mask;
+        if (r->tab[j] == 0) { r->tab[j] = h + 1; ++r->n_sample_keys; }
+    }
+    free(v.a);
+    return r;
+}
+
+void lo_ridx_free(lo_ridx_t *r)
+{
+    uint32_t i;
+    if (!r) return;
+    for (i = 0; i < r->n_seq; ++i) free(r->name[i]);
+    free(r->name); free(r->len); free(r->hy); free(r->tab); free(r);
+}
+
+uint64_t lo_ridx_n_sample_keys(const lo_ridx_t *r) { return r->n_sample_keys; }
+uint64_t lo_ridx_n_minimizers_seen(const lo_ridx_t *r) { return r->n_mz_seen; }
+uint64_t lo_ridx_n_kept(const lo_ridx_t *r) { return r->n; }
+
+/* the next n target reads (rid = reads fed before + index in this call) */
+int lo_ridx_add(lo_ridx_t *r, const char *bases, const uint64_t *offs, uint32_t n, const char *const *names, int threads)
+{
+    const uint32_t rid0 = r->n_seq;
+    int64_t i;
+    int fail = 0;
+    if ((uint64_t)rid0 + n > 0x7fffffffULL) return -3;
+    if (rid0 + n > r->m_seq) {
+        r->m_seq = (rid0 + n) * 2 + 1024;
+        r->name = (char **)realloc(r->name, (size_t)r->m_seq * sizeof(char *));
+        r->len = (int32_t *)realloc(r->len, (size_t)r->m_seq * sizeof(int32_t));
+        if (!r->name || !r->len) return -1;
+    }
+    for (i = 0; i < (int64_t)n; ++i) {
+        const char *nm = names && names[i] ? names[i] : "";
+        r->name[rid0 + i] = (char *)malloc(strlen(nm) + 1);
+        strcpy(r->name[rid0 + i], nm);
+        r->len[rid0 + i] = (int32_t)(offs[i + 1] - offs[i]);
+    }
+    r->n_seq = rid0 + n;
+    set_threads(threads);
+#pragma omp parallel
+    {
+        vec128_t v = {0, 0, 0};
+        hy_t *loc = 0; uint64_t ln = 0, lm = 0, seen = 0;
+#pragma omp for schedule(dynamic, 16) nowait
+        for (i = 0; i < (int64_t)n; ++i) {
+            int64_t t;
+            if (offs[i + 1] <= offs[i]) continue;
+            v.n = 0;
+            sketch_into(bases + offs[i], (int32_t)(offs[i + 1] - offs[i]), r->opt.w, r->opt.k, rid0 + (uint32_t)i, r->opt.is_hpc, &v);
+            seen += (uint64_t)v.n;
+            for (t = 0; t < v.n; ++t) {
+                const uint64_t h = v.a[t].x >> 8;
+                if (!ridx_has(r, h)) continue;
+                if (ln == lm) { lm = lm ? lm * 2 : 4096; loc = (hy_t *)realloc(loc, lm * sizeof(hy_t)); if (!loc) { fail = 1; lm = ln = 0; break; } }
+                loc[ln].h = h; loc[ln].y = v.a[t].y; ++ln;
+            }
+        }
+#pragma omp critical
+        {
+            r->n_mz_seen += seen;
+            if (ln) {
+                if (r->n + ln > r->m) { r->m = (r->n + ln) * 3 / 2 + 4096; r->hy = (hy_t *)realloc(r->hy, r->m * sizeof(hy_t)); if (!r->hy) { fail = 1; r->m = r->n = 0; } }
+                if (r->hy) { memcpy(r->hy + r->n, loc, ln * sizeof(hy_t)); r->n += ln; }
+            }
+        }
+        free(loc); free(v.a);
+    }
+    return fail ? -1 : 0;
+}
+
+/* -> an index usable with lo_map / lo_twoset_counts / lo_anchors for the SAMPLE queries (and for nothing else);
+   mid_occ: that of the whole target set (> 0).  The builder is consumed (and freed). */
+lo_index_t *lo_ridx_finish(lo_ridx_t *r, lo_opt_t *opt, int32_t mid_occ, int threads)
+{
+    lo_index_t *ix;
+    nameidx_t *ni;
+    uint64_t i, j, n = r->n;
+    hy_t *hy = r->hy;
+    const uint32_t ns = r->n_seq;
+    if (mid_occ <= 0) return 0;
+    set_threads(threads);
+    ix = (lo_index_t *)calloc(1, sizeof(*ix));
+    ix->n_seq = ns; ix->k = r->opt.k; ix->w = r->opt.w; ix->is_hpc = r->opt.is_hpc;
+    ix->name = r->name; ix->len = r->len; r->name = 0; r->len = 0; r->n_seq = 0;
+    if (!ix->name) { ix->name = (char **)calloc(1, sizeof(char *)); ix->len = (int32_t *)calloc(1, sizeof(int32_t)); }
+    ix->name_rank = (uint32_t *)calloc(ns ? ns : 1, sizeof(uint32_t));
+    ni = (nameidx_t *)malloc((ns ? ns : 1) * sizeof(nameidx_t));
+    for (i = 0; i < ns; ++i) { ni[i].s = ix->name[i]; ni[i].i = (uint32_t)i; }
+    qsort(ni, ns, sizeof(nameidx_t), cmp_name);
+    for (i = 0, j = 0; i < ns; ++i) {
+        if (i > 0 && strcmp(ni[i].s, ni[i - 1].s) != 0) j = i;
+        ix->name_rank[ni[i].i] = (uint32_t)j;
+    }
+    free(ni);
+    {   /* (hash, y) is a total order on the entries (y is unique): bucket on the top 12 hash bits, sort the buckets in parallel */
+        const int shift = 2 * r->opt.k > 12 ? 2 * r->opt.k - 12 : 0;
+        uint64_t *bstart = (uint64_t *)calloc(4097, 8), *fill = (uint64_t *)malloc(4097 * 8);
+        hy_t *srt = (hy_t *)malloc((n ? n : 1) * sizeof(hy_t));
+        int64_t b;
+        for (i = 0; i < n; ++i) ++bstart[(hy[i].h >> shift) + 1];
+        for (i = 0; i < 4096; ++i) bstart[i + 1] += bstart[i];
+        memcpy(fill, bstart, 4097 * 8);
+        for (i = 0; i < n; ++i) srt[fill[hy[i].h >> shift]++] = hy[i];
+        free(fill); free(hy); r->hy = 0; hy = srt;
+#pragma omp parallel for schedule(dynamic, 8)
+        for (b = 0; b < 4096; ++b)
+            if (bstart[b + 1] > bstart[b]) qsort(hy + bstart[b], bstart[b + 1] - bstart[b], sizeof(hy_t), cmp_hy);
+        free(bstart);
+    }
+    ix->n_mz = n; ix->mz = 0;
+    for (i = 0, j = 0; i < n; ++i) j += (i == 0 || hy[i].h != hy[i - 1].h);
+    ix->n_keys = j;
+    ix->key = (uint64_t *)malloc((j ? j : 1) * 8);
+    ix->off = (uint64_t *)malloc((j + 1) * 8);
+    ix->pos = (uint64_t *)malloc((n ? n : 1) * 8);
+    for (i = 0, j = 0; i < n; ++i) {
+        if (i == 0 || hy[i].h != hy[i - 1].h) { ix->key[j] = hy[i].h; ix->off[j] = i; ++j; }
+        ix->pos[i] = hy[i].y;
+    }
+    ix->off[j] = n;
+    free(hy);
+    opt->mid_occ = mid_occ;
+    if (opt->bw_long < opt->bw) opt->bw_long = opt->bw;
+    ix->mid_occ = mid_occ;
+    lo_ridx_free(r);
+    return ix;
 }
 
 int32_t lo_index_get(const lo_index_t *ix, uint64_t minier, const uint64_t **list)

@@ -90,6 +90,19 @@ int  lo_kstat_add(lo_kstat_t *s, const char *bases, const uint64_t *offs, uint32
 int  lo_kstat_finish(lo_kstat_t *s, int threads, uint64_t *n_mz, uint64_t *n_keys, int32_t *mid_occ);
 void lo_kstat_free(lo_kstat_t *s);
 
+/* The index of a target set too large to hold on the host, restricted to the keys a SAMPLE of query reads carries: complete
+   position lists for exactly those keys (identical mm_idx_get answers for the sample), mid_occ handed in (lo_kstat_* gives
+   it for the same set).  new: sketches the sample; add: the next n target reads, in rid order; finish: consumes the
+   builder.  Usable with lo_map / lo_anchors / lo_twoset_counts for the sample queries only. */
+typedef struct lo_ridx lo_ridx_t;
+lo_ridx_t *lo_ridx_new(const lo_opt_t *opt, const char *qbases, const uint64_t *qoffs, uint32_t nq);
+int  lo_ridx_add(lo_ridx_t *r, const char *bases, const uint64_t *offs, uint32_t n, const char *const *names, int threads);
+lo_index_t *lo_ridx_finish(lo_ridx_t *r, lo_opt_t *opt, int32_t mid_occ, int threads);
+void lo_ridx_free(lo_ridx_t *r);
+uint64_t lo_ridx_n_sample_keys(const lo_ridx_t *r);
+uint64_t lo_ridx_n_minimizers_seen(const lo_ridx_t *r);
+uint64_t lo_ridx_n_kept(const lo_ridx_t *r);
+
 /* stage outputs for one query: sorted anchors (after collect_seed_hits) */
 int64_t lo_anchors(const lo_index_t *ix, const lo_opt_t *opt, const char *seq, int32_t qlen,
                    const char *qname, lo_mm128_t *out, int64_t cap);

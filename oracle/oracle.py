@@ -102,6 +102,15 @@ def lib():
         L.lo_kstat_add.argtypes = [vp, vp, vp, C.c_uint32, C.c_int]
         L.lo_kstat_finish.argtypes = [vp, C.c_int, u64p, u64p, C.POINTER(C.c_int32)]
         L.lo_kstat_free.argtypes = [vp]
+        L.lo_ridx_new.restype = vp
+        L.lo_ridx_new.argtypes = [C.POINTER(Opt), vp, vp, C.c_uint32]
+        L.lo_ridx_add.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_int]
+        L.lo_ridx_finish.restype = vp
+        L.lo_ridx_finish.argtypes = [vp, C.POINTER(Opt), C.c_int32, C.c_int]
+        L.lo_ridx_free.argtypes = [vp]
+        for f in (L.lo_ridx_n_sample_keys, L.lo_ridx_n_minimizers_seen, L.lo_ridx_n_kept):
+            f.restype = C.c_uint64
+            f.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -146,11 +155,11 @@ class ReadSet:
 
 
 class Index:
-    def __init__(self, rs, opt):
+    def __init__(self, rs, opt, _handle=None):
         self.rs = rs
         self.opt = opt
-        self.h = lib().lo_index_build(rs.bases.ctypes.data, rs.offsets.ctypes.data, rs.n,
-                                      C.cast(rs._cnames, C.c_void_p), C.byref(opt))
+        self.h = _handle if _handle is not None else lib().lo_index_build(rs.bases.ctypes.data, rs.offsets.ctypes.data, rs.n,
+                                                                          C.cast(rs._cnames, C.c_void_p), C.byref(opt))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -245,6 +254,54 @@ class KeyStats:
     def __del__(self):
         if getattr(self, "h", None):
             lib().lo_kstat_free(self.h)
+            self.h = None
+
+
+class RestrictedIndexBuilder:
+    """lo_ridx_*: the index of a target set too large to hold on the host, restricted to the keys of a SAMPLE of query
+    reads (complete position lists for exactly those keys => the answers mm_idx_get gives the sample are those of the full
+    index).  Feed the targets chunk by chunk, in rid order; finish(mid_occ) hands back an Index that is valid for the sample
+    queries only (twoset_counts / map / anchors); mid_occ is the whole set's (KeyStats / tests/golden/c5_full_index_stats.json)."""
+
+    def __init__(self, opt, sample):
+        self.opt = opt
+        self.h = lib().lo_ridx_new(C.byref(opt), sample.bases.ctypes.data, sample.offsets.ctypes.data, sample.n)
+        self.n_targets = 0
+
+    def add(self, bases, offsets, names, threads=0):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        assert len(names) == n
+        cn = _names_array(names)
+        rc = lib().lo_ridx_add(self.h, bases.ctypes.data if bases.size else None, offsets.ctypes.data, n, C.cast(cn, C.c_void_p), threads)
+        assert rc == 0, rc
+        self.n_targets += n
+
+    @property
+    def n_minimizers_seen(self):
+        return lib().lo_ridx_n_minimizers_seen(self.h)
+
+    @property
+    def n_kept(self):
+        return lib().lo_ridx_n_kept(self.h)
+
+    @property
+    def n_sample_keys(self):
+        return lib().lo_ridx_n_sample_keys(self.h)
+
+    def finish(self, mid_occ, threads=0):
+        h = lib().lo_ridx_finish(self.h, C.byref(self.opt), int(mid_occ), threads)
+        assert h, "lo_ridx_finish: mid_occ must be the whole target set's (> 0)"
+        self.h = None                # (consumed)
+
+        class _Described:            # what Index consults of its read set: the number of reads (inverse_counts / ava_counts are not valid here)
+            n = self.n_targets
+        return Index(_Described(), self.opt, _handle=h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lo_ridx_free(self.h)
             self.h = None
 
 

@@ -280,8 +280,10 @@ def test_c5_full(ctx, oracle):
       * all 2 000 000 targets through the additivity of the strategy (twoset.rs:520-523: every streamed read adds one to
         the reads it hits): counts(all) = counts(before the range) + counts(range) + counts(after the range).
     forward (one index whatever the target size, aligner.rs:111-120 -- here 8 parts with global occurrence statistics):
-      * n_minimizers / n_keys / mid_occ of the 8-part index against the oracle's (tests/golden/c5_full_index_stats.json,
+      * n_minimizers / n_keys / mid_occ of the partitioned index against the oracle's (tests/golden/c5_full_index_stats.json,
         made by tests/golden/make_c5_fixture.py from the host twin's reads);
+      * the counts of 256 queries spread over the set, and every PAF line of 8 of them, against the oracle's index RESTRICTED
+        to those queries' keys (all 2 000 000 targets through the oracle's mm_sketch; oracle/c5_sample.py);
       * size-independent properties on all 100 000 queries: sub-range independence, no count above the number of truly
         overlapping targets, sensitivity, idempotence, and agreement with the (oracle-anchored) inverse counts.
     """
@@ -339,6 +341,52 @@ def test_c5_full(ctx, oracle):
     assert {k: st[k] for k in ("n_minimizers", "n_keys", "mid_occ")} == {k: fx["ava-pb"][k] for k in ("n_minimizers", "n_keys", "mid_occ")}
     assert st["n_minimizers"] > 2**32          # more than one index part can hold
     counts, has = ix.overlap_twoset(Qd)
+    #  * FORWARD counts against the oracle at full size: 256 queries spread over the whole set (every index
+    #    part and every anchor batch).  No host holds the oracle's index of 7.5 G minimizers: all 2 000 000 targets stream through
+    #    the oracle's mm_sketch into an index restricted to the keys of the sample -- complete position lists for exactly the keys
+    #    mm_idx_get is asked about (oracle/c5_sample.py; tests/test_oracle_restricted.py checks that form against the full
+    #    index where it fits); mid_occ from the oracle's KeyStats fixture compared above.  The PAF lines of 8 of them too
+    #    (aligner.rs:244-291: every PafRecord field through the 3-part index).
+    from lrge_amd import paf
+    from oracle import c5_sample
+    idx = c5_sample.sample_indices(Q, 256)
+    fs = c5_sample.forward_sample(spec, Q, T, preset, idx, fx["ava-pb"]["mid_occ"], source="device", threads=THREADS)
+    assert fs["n_minimizers_seen"] == st["n_minimizers"]
+    assert np.array_equal(counts[idx], fs["counts"]), "forward counts differ from the oracle on %d of %d sampled queries" % (int((counts[idx] != fs["counts"]).sum()), len(idx))
+    assert np.array_equal(has[idx], fs["has_mapping"])
+    assert int(fs["counts"].sum()) > 3000
+    ixo_r, hs = fs["index"], fs["reads"]
+    ixo_r.opt.sort_mode = oracle.SORT_MM2           # (the other tie policy gives the same counts here too)
+    rc, ec2, _ = ixo_r.twoset_counts(fs["sample"], threads=THREADS)
+    ixo_r.opt.sort_mode = oracle.SORT_STABLE
+    assert rc == 0 and np.array_equal(ec2, fs["counts"])
+    n_paf = 8
+    sub = hs.slice(0, n_paf)
+    Pd = ctx.upload(sub.bases, sub.offsets, idx[:n_paf].astype(np.uint32))
+    chains = ix.chains(Pd, dual=True)
+    rl, ss, nk = ix.paf_stats(Pd)
+    Pd.free()
+
+    class _TNames:                                   # r%08d of the read's index in the whole job (queries first)
+        def __getitem__(self, i):
+            return b"r%08d" % (Q + int(i))
+    tnames, tlens_all = _TNames(), np.diff(dt.offsets).astype(np.int64)
+    sub_lens = [int(x) for x in sub.lens()]
+    got = sorted(paf.paf_lines(chains, sub.names, sub_lens, tnames, tlens_all, rl, ss, nk))
+    exp = []
+    seqs = sub.seqs()
+    for qi in range(n_paf):
+        for r in ixo_r.map(seqs[qi], sub.names[qi]):
+            ti = int(r["rid"])
+            exp.append("\t".join([sub.names[qi].decode(), str(sub_lens[qi]), str(r["qs"]), str(r["qe"]), "-" if r["rev"] else "+",
+                                  tnames[ti].decode(), str(int(tlens_all[ti])), str(r["rs"]), str(r["re"]), str(r["mlen"]), str(r["blen"]), "0",
+                                  "tp:A:S", "cm:i:%d" % r["cnt"], "s1:i:%d" % r["score"], "dv:f:" + paf.format_dv(r["dv"]),
+                                  "rl:i:%d" % r["rep_len"]]))
+    exp.sort()
+    assert len(exp) > 100 and len(got) == len(exp), (len(got), len(exp))
+    bad = [i for i, (a_, b_) in enumerate(zip(got, exp)) if a_ != b_]
+    assert not bad, "first differing PAF line:\n%s\n%s" % (got[bad[0]], exp[bad[0]])
+    del fs, ixo_r
     #  * sub-range independence
     a, b = 40000, 42000
     d = spec.device_reads(a, b - a)

@@ -22,15 +22,91 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+_BUILT = {}
+
+
+def _search_dirs():
+    import glob
+    dirs = []
+    for v in ("CONDA_PREFIX", "VIRTUAL_ENV", "MAMBA_ROOT_PREFIX"):
+        if os.environ.get(v):
+            dirs.append(os.path.join(os.environ[v], "bin"))
+    home = os.path.expanduser("~")
+    dirs += ["/usr/local/bin", "/usr/bin", "/opt/bin", os.path.join(home, "bin"), os.path.join(home, ".local", "bin"),
+             os.path.join(home, ".cargo", "bin")]
+    dirs += sorted(glob.glob("/opt/*/bin")) + sorted(glob.glob("/opt/*/*/bin")) + sorted(glob.glob(os.path.join(home, "*conda*", "bin")))
+    return [d for d in dirs if os.path.isdir(d)]
+
+
+def _source_trees():
+    """minimap2 source trees (a release tarball unpacked somewhere, a cargo registry checkout of minimap2-sys): Makefile + minimap.h."""
+    import glob
+    home = os.path.expanduser("~")
+    pats = []
+    for root in ("/opt", "/usr/local/src", "/usr/src", "/usr/local", home, os.path.join(home, "src"), "/tmp", "/workspace", "/data"):
+        pats += [os.path.join(root, "minimap2*"), os.path.join(root, "*", "minimap2*")]
+    pats += [os.path.join(home, ".cargo", "registry", "src", "*", "minimap2-sys-*", "minimap2")]
+    out = []
+    for pat in pats:
+        for d in sorted(glob.glob(pat)):
+            if os.path.isdir(d) and os.path.exists(os.path.join(d, "Makefile")) and os.path.exists(os.path.join(d, "minimap.h")):
+                out.append(d)
+    return out
+
+
+def _build_from_source(tree):
+    """`make` in a private copy of the tree (nothing outside the temporary directory is written)."""
+    if tree in _BUILT:
+        return _BUILT[tree]
+    exe = None
+    try:
+        d = tempfile.mkdtemp(prefix="mm2pin_")
+        dst = os.path.join(d, "minimap2")
+        shutil.copytree(tree, dst, symlinks=True)
+        r = subprocess.run(["make", "-C", dst, "-j", str(min(16, os.cpu_count() or 4)), "minimap2"], capture_output=True, timeout=600)
+        if r.returncode == 0 and os.path.exists(os.path.join(dst, "minimap2")):
+            exe = os.path.join(dst, "minimap2")
+    except Exception:      # noqa: BLE001
+        exe = None
+    _BUILT[tree] = exe
+    return exe
+
+
 def _have_minimap2():
+    """("binary", path) | ("mappy", None) | None.  Looked for, in this order: $LRGE_MINIMAP2 / $MINIMAP2, PATH, the usual prefix
+    directories (conda / venv / /usr/local / /opt/*/bin / ~/.local/bin / ~/.cargo/bin), the `mappy` module, and a minimap2 SOURCE
+    tree to build with make (a release tarball, or cargo's checkout of minimap2-sys)."""
+    for v in ("LRGE_MINIMAP2", "MINIMAP2"):
+        e = os.environ.get(v)
+        if e and os.path.isfile(e) and os.access(e, os.X_OK):
+            return ("binary", e)
     exe = shutil.which("minimap2")
     if exe:
         return ("binary", exe)
+    for d in _search_dirs():
+        e = os.path.join(d, "minimap2")
+        if os.path.isfile(e) and os.access(e, os.X_OK):
+            return ("binary", e)
     try:
         import mappy  # noqa: F401
         return ("mappy", None)
     except Exception:      # noqa: BLE001
-        return None
+        pass
+    for tree in _source_trees():
+        e = _build_from_source(tree)
+        if e:
+            return ("binary", e)
+    return None
+
+
+def _version(kind, exe):
+    try:
+        if kind == "binary":
+            return subprocess.run([exe, "--version"], capture_output=True, timeout=30).stdout.decode().strip()
+        import mappy
+        return getattr(mappy, "__version__", "?")
+    except Exception:      # noqa: BLE001
+        return "?"
 
 
 def _paf_with_real_minimap2(kind, exe, tnames, tseqs, qnames, qseqs):
@@ -78,9 +154,12 @@ def _paf_with_oracle(oracle, tnames, tseqs, qnames, qseqs):
 def test_oracle_against_real_minimap2_if_the_box_has_one(oracle):
     have = _have_minimap2()
     if not have:
-        pytest.skip("PARITY STILL UNPINNED: neither a `minimap2` binary on PATH nor `mappy` on this box -- the oracle "
-                    "(oracle/lrge_oracle.c, restatement of minimap2 2.30) has never been compared with the real tool")
+        pytest.skip("PARITY STILL UNPINNED: no `minimap2` binary ($LRGE_MINIMAP2, PATH, conda / venv / /usr/local / /opt/*/bin / ~/.local/bin "
+                    "searched), no `mappy`, no minimap2 source tree to build on this box -- the oracle (oracle/lrge_oracle.c, restatement "
+                    "of minimap2 2.30) has never been compared with the real tool")
     kind, exe = have
+    ver = _version(kind, exe)
+    print("pinning the oracle against real minimap2: %s %s (version %s; the reference pins 2.30: Cargo.lock:710-719)" % (kind, exe, ver))
     # 1. the reference's own toy reads, first 400 as targets, last 100 as queries
     names, seqs, cur = [], [], None
     with gzip.open(os.path.join(HERE, "golden", "toy_reads.fa.gz"), "rb") as f:
@@ -99,4 +178,4 @@ def test_oracle_against_real_minimap2_if_the_box_has_one(oracle):
         real = _paf_with_real_minimap2(kind, exe, tn, ts, qn, qq)
         mine = _paf_with_oracle(oracle, tn, ts, qn, qq)
         assert len(real) > 0
-        assert mine == real, "oracle and real minimap2 differ on %d of %d mappings" % (len(set(mine) ^ set(real)), len(real))
+        assert mine == real, "oracle and real minimap2 (%s) differ on %d of %d mappings" % (ver, len(set(mine) ^ set(real)), len(real))

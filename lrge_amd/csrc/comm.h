@@ -98,6 +98,9 @@ struct lrge_hip_comm {
     // host transport: the caller's own collectives (MPI, gloo, ...) on host buffers; the library stages through the host
     lrge_hip_host_allreduce_fn cb_allreduce = nullptr; lrge_hip_host_allgather_fn cb_allgather = nullptr; void *cb_user = nullptr;
     std::vector<char> hbuf;              // host staging of the local / host transports
+    // RCCL transport: a small device block taken ONCE at creation for the host-buffer collectives below (the status-carrying
+    // vectors of a collective build), so that a rank that has just run out of memory can still JOIN a collective to say so
+    char *d_small = nullptr; static constexpr size_t kSmall = (size_t)1 << 20;
     bool in_turn = false; double busy_ms = 0, t_acquired = 0;     // (serialized local groups)
     double wait_ms = 0;                   // wall time spent inside barriers of the local transport (waiting for the other ranks)
 };
@@ -213,23 +216,84 @@ static int comm_allgather(lrge_hip_comm *c, const void *dsend, size_t bytes, voi
     return LRGE_OK;
 }
 
+// ---- small collectives on HOST vectors (sizes, counts, statistics -- each carrying a status word) ----
+// Same wire shape as the device-buffer forms above (RCCL: the same ncclAllReduce / ncclAllGather; host callbacks: the same callback;
+// local: the same two barriers), but no allocation and, off RCCL, no device round trip: a rank whose allocation or kernel has failed
+// can always take part, which is what makes failure collective (CollectiveGuard, host_index.inl).
+static int comm_small_stage(lrge_hip_comm *c, size_t bytes, Scratch &sc, char **d) {
+    if (bytes <= lrge_hip_comm::kSmall && c->d_small) { *d = c->d_small; return LRGE_OK; }
+    *d = sc.get<char>(bytes);
+    return *d ? LRGE_OK : LRGE_ERR_DEVICE;
+}
+
+// In-place SUM all-reduce of n elements of `esz` bytes (4: u32, 8: u64) in HOST memory.
+static int comm_allreduce_sum_host(lrge_hip_comm *c, void *hbuf, size_t n, int esz, hipStream_t st) {
+    lrge_hip_ctx *ctx = c->ctx;
+    if (c->world == 1 || n == 0) return LRGE_OK;
+    const size_t bytes = n * (size_t)esz;
+    if (c->nccl) {
+        Scratch sc(ctx); char *d = nullptr;
+        if (comm_small_stage(c, bytes, sc, &d)) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemcpyAsync(d, hbuf, bytes, hipMemcpyHostToDevice, st));
+        NCCLCHK(ctx, g_rccl.AllReduce(d, d, n, esz == 8 ? LRGE_NCCL_UINT64 : LRGE_NCCL_UINT32, LRGE_NCCL_SUM, c->nccl, st));
+        HIPCHK(ctx, hipMemcpyAsync(hbuf, d, bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        return LRGE_OK;
+    }
+    if (c->cb_allreduce) {
+        if (c->cb_allreduce(c->cb_user, hbuf, n, esz) != 0) { LRGE_SET_ERR(ctx, "host communicator: all-reduce callback failed"); return LRGE_ERR_DEVICE; }
+        return LRGE_OK;
+    }
+    LocalGroup *g = c->grp;
+    g->slot[(size_t)c->rank] = hbuf;
+    if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
+    std::vector<char> sum(bytes, 0);
+    for (int r = 0; r < c->world; ++r) {
+        if (esz == 8) { const u64 *p = (const u64 *)g->slot[(size_t)r]; u64 *o = (u64 *)sum.data(); for (size_t i = 0; i < n; ++i) o[i] += p[i]; }
+        else { const u32 *p = (const u32 *)g->slot[(size_t)r]; u32 *o = (u32 *)sum.data(); for (size_t i = 0; i < n; ++i) o[i] += p[i]; }
+    }
+    if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }   // everyone has read every slot
+    memcpy(hbuf, sum.data(), bytes);
+    return LRGE_OK;
+}
+
+// All-gather of `bytes` bytes per rank between HOST buffers (hrecv holds world * bytes).
+static int comm_allgather_host(lrge_hip_comm *c, const void *hsend, size_t bytes, void *hrecv, hipStream_t st) {
+    lrge_hip_ctx *ctx = c->ctx;
+    if (bytes == 0) return LRGE_OK;
+    if (c->world == 1) { memcpy(hrecv, hsend, bytes); return LRGE_OK; }
+    if (c->nccl) {
+        Scratch sc(ctx); char *d = nullptr;
+        if (comm_small_stage(c, bytes * ((size_t)c->world + 1), sc, &d)) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemcpyAsync(d, hsend, bytes, hipMemcpyHostToDevice, st));
+        NCCLCHK(ctx, g_rccl.AllGather(d, d + bytes, bytes, LRGE_NCCL_UINT8, c->nccl, st));
+        HIPCHK(ctx, hipMemcpyAsync(hrecv, d + bytes, bytes * (size_t)c->world, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        return LRGE_OK;
+    }
+    if (c->cb_allgather) {
+        if (c->cb_allgather(c->cb_user, hsend, bytes, hrecv) != 0) { LRGE_SET_ERR(ctx, "host communicator: all-gather callback failed"); return LRGE_ERR_DEVICE; }
+        return LRGE_OK;
+    }
+    LocalGroup *g = c->grp;
+    g->slot[(size_t)c->rank] = hsend;
+    if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
+    for (int r = 0; r < c->world; ++r) memcpy((char *)hrecv + bytes * (size_t)r, g->slot[(size_t)r], bytes);
+    if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
+    return LRGE_OK;
+}
+
 // Failure made collective: every rank contributes whether it failed so far (rc != 0); all ranks leave with an error if any
 // did -- so that a rank whose allocation or kernel failed does not leave the others blocked in the next collective.
+// One u32 all-reduce on a host word: no allocation, and no device round trip off RCCL.
 static int comm_agree(lrge_hip_comm *c, int rc, hipStream_t st) {
     if (!c || c->world == 1) return rc;
     lrge_hip_ctx *ctx = c->ctx;
     if (c->grp && rc) { c->grp->abort(); return rc; }                    // (threads of one process: wake the others directly)
     std::string mine = rc ? ctx->err : std::string();
-    Scratch sc(ctx);
-    u32 *d = sc.get<u32>(1);
-    if (!d) { if (c->grp) c->grp->abort(); return LRGE_ERR_DEVICE; }
-    const u32 bad = rc ? 1u : 0u;
-    u32 tot = 0;
-    if (hipMemcpyAsync(d, &bad, 4, hipMemcpyHostToDevice, st) != hipSuccess) { if (c->grp) c->grp->abort(); return LRGE_ERR_DEVICE; }
-    if (hipStreamSynchronize(st) != hipSuccess) { if (c->grp) c->grp->abort(); return LRGE_ERR_DEVICE; }
-    const int r2 = comm_allreduce_sum(c, d, 1, 4, st);
-    if (r2) return rc ? rc : r2;
-    if (hipMemcpyAsync(&tot, d, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return LRGE_ERR_DEVICE;
+    u32 tot = rc ? 1u : 0u;
+    const int r2 = comm_allreduce_sum_host(c, &tot, 1, 4, st);
+    if (r2) { if (rc) ctx->err = mine; return rc ? rc : r2; }
     if (rc) { ctx->err = mine; return rc; }
     if (tot) { LRGE_SET_ERR(ctx, "collective call: %u other rank(s) failed", tot); return LRGE_ERR_DEVICE; }
     return LRGE_OK;
@@ -253,13 +317,18 @@ static int comm_alltoallv(lrge_hip_comm *c, const void *dsend, const u64 *soff, 
     }
     if (c->nccl) {
         NCCLCHK(ctx, g_rccl.GroupStart());
-        for (int p = 0; p < W; ++p) {
+        int gerr = 0;      // a failed Send / Recv must not leave the group open on this thread: later RCCL calls would queue silently
+        for (int p = 0; p < W && !gerr; ++p) {
             const u64 ns = soff[p + 1] - soff[p], nr = roff[p + 1] - roff[p];
             if (p == me) continue;
-            if (ns) NCCLCHK(ctx, g_rccl.Send((const char *)dsend + soff[p] * esz, ns * esz, LRGE_NCCL_UINT8, p, c->nccl, st));
-            if (nr) NCCLCHK(ctx, g_rccl.Recv((char *)drecv + roff[p] * esz, nr * esz, LRGE_NCCL_UINT8, p, c->nccl, st));
+            if (ns) gerr = g_rccl.Send((const char *)dsend + soff[p] * esz, ns * esz, LRGE_NCCL_UINT8, p, c->nccl, st);
+            if (nr && !gerr) gerr = g_rccl.Recv((char *)drecv + roff[p] * esz, nr * esz, LRGE_NCCL_UINT8, p, c->nccl, st);
         }
-        NCCLCHK(ctx, g_rccl.GroupEnd());
+        const int gend = g_rccl.GroupEnd();
+        if (gerr || gend) {
+            LRGE_SET_ERR(ctx, "RCCL error %s in the all-to-all's send / receive group", g_rccl.GetErrorString ? g_rccl.GetErrorString(gerr ? gerr : gend) : "?");
+            return LRGE_ERR_DEVICE;
+        }
         const u64 n = soff[me + 1] - soff[me];
         if (n) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[me] * esz, (const char *)dsend + soff[me] * esz, n * esz, hipMemcpyDeviceToDevice, st));
         return LRGE_OK;

@@ -23,6 +23,7 @@ extern "C" int lrge_hip_comm_create(lrge_hip_ctx *ctx, int rank, int world, cons
     std::unique_ptr<lrge_hip_comm> c(new lrge_hip_comm());
     c->ctx = ctx; c->rank = rank; c->world = world;
     NCCLCHK(ctx, g_rccl.CommInitRank(&c->nccl, world, id, rank));
+    if (hipMalloc((void **)&c->d_small, lrge_hip_comm::kSmall) != hipSuccess) { (void)hipGetLastError(); c->d_small = nullptr; }   // (then the pool serves)
     *out = c.release();
     return LRGE_OK;
 }
@@ -59,6 +60,7 @@ extern "C" void lrge_hip_comm_destroy(lrge_hip_comm *c) {
         bool ctx_alive;
         { std::lock_guard<std::mutex> g(g_live_mu); ctx_alive = g_live_ctx.count(c->ctx) != 0; }
         if (ctx_alive) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); }
+        if (c->d_small) (void)hipFree(c->d_small);
         (void)g_rccl.CommDestroy(c->nccl);
     }
     delete c;

@@ -69,21 +69,49 @@ struct IndexBuildOpts {
 struct ShardStats { u64 keyset_bytes = 0, entries_sketched = 0, entries_sent = 0, entries_recv = 0, hashes_sent = 0, hashes_recv = 0; };
 static thread_local ShardStats g_shard_stats;
 
-// A collective call must fail on every rank when it fails on one: a rank that leaves early (any `return` of the macros
-// above) still enters the agreement all-reduce the healthy ranks run right before the first data collective, through this
-// guard's destructor; the healthy path calls agree() itself.
+// A collective call must fail on every rank when it fails on one, and nobody may hang.  The builds below are a fixed sequence of
+// collectives; a rank that leaves early (any `return` of the macros above) is, at that moment, owed to ONE of them -- the next
+// status-carrying collective its healthy peers will enter.  The guard knows which (expect() is called as the sequence advances)
+// and its destructor JOINS that collective in its own shape with the status word set: an all-reduce of n u64 with a 1 at
+// `status_at`, an all-gather of n u64 per rank likewise, or the one-word agreement.  The joins work on host vectors
+// (comm.h: comm_*_host), so they need no allocation and -- off RCCL -- no working device.  Threads of one process simply abort
+// the group's barrier.  (a failing rank used to enter a ONE-word agreement while its peers were in the (W + 1)-word
+// sizes all-reduce.)
 struct CollectiveGuard {
-    lrge_hip_comm *c; hipStream_t st; bool armed = false;
-    ~CollectiveGuard() { if (armed && c) (void)comm_agree(c, LRGE_ERR_DEVICE, st); }
-    int agree() { const bool was = armed; armed = false; return (was && c) ? comm_agree(c, LRGE_OK, st) : LRGE_OK; }
+    lrge_hip_comm *c; hipStream_t st;
+    enum Next { NONE = 0, AGREE, ALLREDUCE_U64, ALLGATHER_U64 };
+    int next = NONE; size_t n = 0, status_at = 0;
+    void expect(int k, size_t n_ = 0, size_t at = 0) { next = k; n = n_; status_at = at; }
+    void disarm() { next = NONE; }
+    void join_failed() {
+        if (!c || c->world == 1 || next == NONE) { next = NONE; return; }
+        const int k = next; next = NONE;
+        const std::string mine = c->ctx->err;            // (the join must not overwrite this rank's own error text)
+        if (c->grp) c->grp->abort();
+        else if (k == AGREE) (void)comm_agree(c, LRGE_ERR_DEVICE, st);
+        else if (k == ALLREDUCE_U64) { std::vector<u64> v(n, 0); v[status_at] = 1; (void)comm_allreduce_sum_host(c, v.data(), n, 8, st); }
+        else { std::vector<u64> v(n, 0), all(n * (size_t)c->world, 0); v[status_at] = 1; (void)comm_allgather_host(c, v.data(), n * 8, all.data(), st); }
+        c->ctx->err = mine;
+    }
+    ~CollectiveGuard() { join_failed(); }
 };
+// test hook (option DEBUG_SHARD_FAIL_AT = stage number, set by lrge_hip_ctx_set_option only): this rank fails at that stage of a
+// collective build, as an allocation or a kernel would
+static bool shard_fail_at(lrge_hip_ctx *ctx, int stage) {
+    if ((int)ctx->opt_u64("DEBUG_SHARD_FAIL_AT", 0) != stage) return false;
+    LRGE_SET_ERR(ctx, "injected failure at stage %d of the collective index build", stage);
+    return true;
+}
+// words of the statistics all-reduce that closes the collective part of a restricted / sharded build: [distinct, minimizers,
+// head bins..., status]
+static size_t stats_vec_words(const Preset &P) { return (size_t)std::min<u32>(4096, (u32)P.max_mid_occ + 2) + 3; }
 
 // The three exchanges of a sharded build (k_route.h).  On success so->x [, so->y] hold this rank's kept entries in the order
 // the one index would hold them (so->n of them), *own_hashes / *n_own the hashes of the keys this rank owns.  Collective:
 // a failure on one rank fails the call on every rank (status words ride in the small vectors; comm_agree before the
 // exchanges that follow large allocations).
 static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int preset, bool pk, u32 pk_pos1, u32 pk_ybits,
-                           const IndexBuildOpts *ro, SketchOut *so, u64 **own_hashes, u64 *n_own) {
+                           const IndexBuildOpts *ro, SketchOut *so, u64 **own_hashes, u64 *n_own, CollectiveGuard &cg) {
     lrge_hip_comm *c = ro->comm;
     const int W = c->world, me = c->rank;
     lrge_hip_seqset *S = ro->restrict_to;
@@ -101,16 +129,13 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
         t_mark = now; w_mark = c->wait_ms;
     };
     // ---- (1) one agreed key-set size: all ranks' streamed base counts (and whether anybody has failed already) ----
+    // (the caller armed the guard for this very all-reduce: lrge_hip_index_build_sharded)
     std::vector<u64> hv((size_t)W + 1, 0);
-    u64 *d_sz = sc.get<u64>((size_t)W + 1);
-    hv[(size_t)me] = S->total_bases; hv[(size_t)W] = d_sz ? 0 : 1;
-    if (!d_sz) { rc = comm_agree(c, LRGE_ERR_DEVICE, st); return rc ? rc : LRGE_ERR_DEVICE; }
-    HIPCHK(ctx, hipMemcpyAsync(d_sz, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));          // (hv is reused below)
-    rc = comm_allreduce_sum(c, d_sz, hv.size(), 8, st); if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(hv.data(), d_sz, hv.size() * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    if (hv[(size_t)W]) { LRGE_SET_ERR(ctx, "sharded index build: another rank failed"); return LRGE_ERR_DEVICE; }
+    hv[(size_t)me] = S->total_bases; hv[(size_t)W] = shard_fail_at(ctx, 1) ? 1 : 0;
+    const bool failed1 = hv[(size_t)W] != 0;
+    cg.disarm();
+    rc = comm_allreduce_sum_host(c, hv.data(), hv.size(), 8, st); if (rc) return rc;
+    if (hv[(size_t)W]) { if (!failed1) LRGE_SET_ERR(ctx, "sharded index build: another rank failed"); return LRGE_ERR_DEVICE; }
     u64 max_bases = 1;
     for (int r = 0; r < W; ++r) max_bases = std::max(max_bases, hv[(size_t)r]);
     const u64 bloom_bits = ctx->opt_u64("SHARD_BLOOM_BITS", 4);      // filter bits per streamed base (~3-4 minimizers per 16 bits)
@@ -123,6 +148,7 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
     u64 *gathered = nullptr, *inter = nullptr;
     SketchOut raw;
     auto local1 = [&]() -> int {
+        if (shard_fail_at(ctx, 2)) return LRGE_ERR_DEVICE;
         if (!S->presk || S->presk->preset != preset) {
             ctx->presk_pending = S; ctx->presk_preset = preset;
             int r = presketch_start_pending(ctx, ~0ULL >> 2); if (r) return r;
@@ -145,16 +171,16 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
         HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
         return LRGE_OK;
     };
+    cg.expect(CollectiveGuard::AGREE);               // (large allocations behind us or failed: one word says which, before the key sets travel)
     rc = local1();
     mark("sketches + key set");
+    cg.disarm();
     rc = comm_agree(c, rc, st); if (rc) return rc;
     g_shard_stats.entries_sketched = raw.n;
     mark("agree");
     rc = comm_allgather(c, ks.bits, n_words * 8, gathered, st); if (rc) return rc;
     mark("key-set all-gather");
-    if (W <= 8) hipLaunchKernelGGL(k_keyset_interleave<8>, dim3((u32)div_up(n_words, 256)), dim3(256), 0, st, gathered, n_words, (u32)W, inter);
-    else hipLaunchKernelGGL(k_keyset_interleave<16>, dim3((u32)div_up(n_words, 256)), dim3(256), 0, st, gathered, n_words, (u32)W, inter);
-    KCHK(ctx);
+    cg.expect(CollectiveGuard::ALLGATHER_U64, (size_t)2 * W + 1, (size_t)2 * W);      // the counts all-gather of (4)
     // ---- (3) local: which ranks ask for every entry, who owns its hash; counts per destination ----
     const u64 Mr = raw.n;
     if (Mr >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "sharded index build: this rank's target share yields %llu minimizers (limit 2^32)", (unsigned long long)Mr); }
@@ -163,6 +189,10 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
     u32 *flags = nullptr, *cnt = nullptr, *d_tot = nullptr;
     std::vector<u64> mine((size_t)2 * W + 1, 0), matrix(((size_t)2 * W + 1) * (size_t)W, 0);
     auto local2 = [&]() -> int {
+        if (shard_fail_at(ctx, 3)) return LRGE_ERR_DEVICE;
+        if (W <= 8) hipLaunchKernelGGL(k_keyset_interleave<8>, dim3((u32)div_up(n_words, 256)), dim3(256), 0, st, gathered, n_words, (u32)W, inter);
+        else hipLaunchKernelGGL(k_keyset_interleave<16>, dim3((u32)div_up(n_words, 256)), dim3(256), 0, st, gathered, n_words, (u32)W, inter);
+        KCHK(ctx);
         if (Mr >= (1ULL << 32)) return LRGE_ERR_TOO_MANY;
         flags = sc.get<u32>(Mr + 1); cnt = sc.get<u32>((u64)2 * W * A.n_tiles); d_tot = sc.get<u32>((size_t)2 * W);
         if (!flags || !cnt || !d_tot) return LRGE_ERR_DEVICE;
@@ -180,16 +210,9 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
     mine[(size_t)2 * W] = local2() ? 1 : 0;
     mark("interleave + route count");
     const int rc2 = mine[(size_t)2 * W] ? LRGE_ERR_DEVICE : LRGE_OK;
-    // ---- (4) everybody learns every (source, destination) count (and whether a rank has failed) ----
-    {
-        u64 *d_mine = sc.get<u64>(mine.size()), *d_all = sc.get<u64>(matrix.size());
-        rc = comm_agree(c, (d_mine && d_all) ? LRGE_OK : LRGE_ERR_DEVICE, st); if (rc) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(d_mine, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, st));
-        rc = comm_allgather(c, d_mine, mine.size() * 8, d_all, st); if (rc) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(matrix.data(), d_all, matrix.size() * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        sc.drop(d_mine); sc.drop(d_all);
-    }
+    // ---- (4) everybody learns every (source, destination) count (and whether a rank has failed): host vectors, no allocation ----
+    cg.disarm();
+    rc = comm_allgather_host(c, mine.data(), mine.size() * 8, matrix.data(), st); if (rc) return rc;
     mark("counts all-gather");
     const size_t row = (size_t)2 * W + 1;
     for (int r = 0; r < W; ++r) if (matrix[(size_t)r * row + 2 * W]) { if (!rc2) LRGE_SET_ERR(ctx, "sharded index build: rank %d failed", r); return LRGE_ERR_DEVICE; }
@@ -209,6 +232,7 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
     u32 *sh32 = nullptr, *rh32 = nullptr;
     const bool narrow = 2 * P.k <= 32 && !ctx->opt("SHARD_WIDE_HASHES");     // k = 15: the hashes of the second exchange travel as 4 bytes
     auto local3 = [&]() -> int {
+        if (shard_fail_at(ctx, 4)) return LRGE_ERR_DEVICE;
         if (n_kr >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32 minimizers (this rank would hold %llu)", (unsigned long long)n_kr); return LRGE_ERR_TOO_MANY; }
         sx = sc.get<u64>(n_ks + 1); rx = sc.get<u64>(n_kr + 1); rh = sc.get<u64>(n_or + 1);
         if (narrow) { sh32 = sc.get<u32>(n_os + 1); rh32 = sc.get<u32>(n_or + 1); } else sh = sc.get<u64>(n_os + 1);
@@ -219,8 +243,10 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
         if (Mr) { hipLaunchKernelGGL(k_route_write, dim3(A.n_tiles), dim3(RF_THREADS), 0, st, A, flags, cnt, B, sx, sy, sh, sh32); KCHK(ctx); }
         return LRGE_OK;
     };
+    cg.expect(CollectiveGuard::AGREE);               // (the send / receive buffers are the build's largest allocations)
     rc = local3();
     mark("route write");
+    cg.disarm();
     rc = comm_agree(c, rc, st); if (rc) return rc;
     mark("agree");
     // ---- (6) the exchanges ----
@@ -230,11 +256,14 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
         rc = comm_alltoallv(c, sh32, os_off.data(), rh32, or_off.data(), 4, st); if (rc) return rc;
         if (n_or) { hipLaunchKernelGGL(k_u32_to_u64, dim3((u32)div_up(n_or, 256)), dim3(256), 0, st, rh32, n_or, rh); KCHK(ctx); }
     } else { rc = comm_alltoallv(c, sh, os_off.data(), rh, or_off.data(), 8, st); if (rc) return rc; }
+    // from here to the statistics all-reduce of index_build_one a rank that fails owes its peers THAT collective
+    cg.expect(CollectiveGuard::ALLREDUCE_U64, stats_vec_words(P), stats_vec_words(P) - 1);
+    if (shard_fail_at(ctx, 5)) return LRGE_ERR_DEVICE;
     HIPCHK(ctx, hipStreamSynchronize(st));        // (the offset vectors are locals; the local transport has synchronised already)
     mark("all-to-alls");
     sc.drop(raw.x); if (raw.y) sc.drop(raw.y);
     sc.drop(flags); sc.drop(cnt); sc.drop(d_tot); sc.drop(sx); if (sh) sc.drop(sh); if (sh32) sc.drop(sh32); if (rh32) sc.drop(rh32); if (sy) sc.drop(sy);
-    sc.drop(ks.bits); sc.drop(gathered); sc.drop(inter); sc.drop(d_sz);
+    sc.drop(ks.bits); sc.drop(gathered); sc.drop(inter);
     so->x = rx; so->y = ry; so->mz_off = nullptr; so->n = n_kr;
     *own_hashes = rh; *n_own = n_or;
     const u64 ss[8] = {g_shard_stats.keyset_bytes, g_shard_stats.entries_sketched, g_shard_stats.entries_sent, g_shard_stats.entries_recv,
@@ -270,7 +299,12 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     KeySet ks{nullptr, 0, 0, 0, 0};
     const bool sharded = ro && ro->shard;
     CollectiveGuard cg{ro ? ro->comm : nullptr, ctx->stream};
-    cg.armed = ro && ro->comm && !sharded;        // (a sharded build agrees inside sharded_collect first)
+    // the collective this rank owes its peers if it fails now: a sharded build opens with the sizes all-reduce of sharded_collect,
+    // a replicated-sketch build (lrge_hip_index_build_for with a communicator) has ONE collective, the statistics all-reduce
+    if (ro && ro->comm) {
+        if (sharded) cg.expect(CollectiveGuard::ALLREDUCE_U64, (size_t)ro->comm->world + 1, (size_t)ro->comm->world);
+        else cg.expect(CollectiveGuard::ALLREDUCE_U64, stats_vec_words(P), stats_vec_words(P) - 1);
+    }
     if (ro && ro->restrict_to && !sharded) {
         // the streamed set's sketch and the key set built from it go to the side stream FIRST, so that they run beside
         // the target sketch below; the main stream meets them (ev_join) where the entries are filtered
@@ -316,10 +350,9 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     if (sharded) {
         // this rank sketches its own share of the targets; key sets, kept entries and owned hashes travel (k_route.h)
         StageTimer t(ctx, LRGE_T_INDEX_RESTRICT);
-        rc = sharded_collect(ctx, sc, P, preset, pk, pk ? pk_pos1 : 0, pk_ybits, ro, &so, &own_hashes, &n_own);
+        rc = sharded_collect(ctx, sc, P, preset, pk, pk ? pk_pos1 : 0, pk_ybits, ro, &so, &own_hashes, &n_own, cg);
         t.stop();
         if (rc) return rc;
-        cg.armed = ro->comm != nullptr;
         fused = true;                              // (so holds exactly the entries this rank's index keeps)
     }
     // (measured at C4: with a world of 2 the key set is so dense that the sweeps of the general form are the faster way)
@@ -422,11 +455,17 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         ALLOC_OR_FAIL(d_vec, sc, u64, (size_t)head + 2);
         hipLaunchKernelGGL(k_stats_pack, dim3((u32)div_up(head, 256)), dim3(256), 0, ctx->stream, d_nr, Ms, d_hist, head, d_vec);
         KCHK(ctx);
-        rc = cg.agree(); if (rc) return rc;       // every rank got this far, or none goes on
-        if (ro->comm) { rc = comm_allreduce_sum(ro->comm, d_vec, (size_t)head + 2, 8, ctx->stream); if (rc) return rc; }
-        std::vector<u64> hv((size_t)head + 2);
-        HIPCHK(ctx, hipMemcpyAsync(hv.data(), d_vec, hv.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        // the statistics of the whole target set: ONE all-reduce of [distinct, minimizers, head bins, status] on a host vector.  The
+        // status word is what used to be a one-word agreement in front of it: every rank got this far, or none goes on
+        std::vector<u64> hv((size_t)head + 3, 0);
+        HIPCHK(ctx, hipMemcpyAsync(hv.data(), d_vec, ((size_t)head + 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (shard_fail_at(ctx, 6)) return LRGE_ERR_DEVICE;
+        cg.disarm();
+        if (ro->comm) {
+            rc = comm_allreduce_sum_host(ro->comm, hv.data(), hv.size(), 8, ctx->stream); if (rc) return rc;
+            if (hv[(size_t)head + 2]) { LRGE_SET_ERR(ctx, "collective index build: %llu other rank(s) failed", (unsigned long long)hv[(size_t)head + 2]); return LRGE_ERR_DEVICE; }
+        }
         g_distinct = hv[0]; g_mz = hv[1];
         // mm_idx_cal_max_occ + mm_mapopt_update clamps over the distinct keys of the whole target set (same arithmetic as below)
         int thres = INT32_MAX;
@@ -435,9 +474,18 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             u64 cum = 0; u32 v = max_bin_; bool found = false;
             for (u32 b = 0; b < head; ++b) { cum += hv[2 + b]; if (cum > kth) { v = b; found = true; break; } }
             if (!found && head < max_bin_ + 1) {      // the k-th count lies beyond the head bins: the whole histogram travels
-                ALLOC_OR_FAIL(d_full, sc, u64, (size_t)max_bin_ + 1);
-                hipLaunchKernelGGL(k_u32_to_u64, dim3((u32)div_up((u64)max_bin_ + 1, 256)), dim3(256), 0, ctx->stream, d_hist, (u64)max_bin_ + 1, d_full);
-                KCHK(ctx);
+                // (every rank takes this branch or none does: it follows from the reduced vector.  One more allocation in front of a
+                // collective, so one word of agreement first)
+                cg.expect(CollectiveGuard::AGREE);
+                u64 *d_full = sc.get<u64>((size_t)max_bin_ + 1);
+                int arc = d_full ? LRGE_OK : LRGE_ERR_DEVICE;
+                if (d_full) {
+                    hipLaunchKernelGGL(k_u32_to_u64, dim3((u32)div_up((u64)max_bin_ + 1, 256)), dim3(256), 0, ctx->stream, d_hist, (u64)max_bin_ + 1, d_full);
+                    if (hipGetLastError() != hipSuccess) arc = LRGE_ERR_DEVICE;
+                }
+                cg.disarm();
+                if (ro->comm) { rc = comm_agree(ro->comm, arc, ctx->stream); if (rc) return rc; }
+                else if (arc) return arc;
                 if (ro->comm) { rc = comm_allreduce_sum(ro->comm, d_full, (size_t)max_bin_ + 1, 8, ctx->stream); if (rc) return rc; }
                 std::vector<u64> full((size_t)max_bin_ + 1);
                 HIPCHK(ctx, hipMemcpyAsync(full.data(), d_full, full.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -509,7 +557,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         // the first sort passes (rounds 2-3) those went from 0.43 + 0.86 to 1.23 + 2.17 ms, beside the run-head and placement
         // passes these go from 3.2 to 5.5 ms: ~0.7 of its 2.9 ms either way (C4) -- but here the host never has to wait for the
         // set's upload job with nothing queued behind it.
-        rc = presketch_start_pending(ctx, targets->total_bases);
+        rc = presketch_start_pending(ctx, targets->total_bases, /*may_block=*/!targets->is_view);
         if (rc) return rc;
     }
     const bool pk_t = pk || seg_packed;          // what the table build and the lookups see: one packed word per entry
@@ -638,10 +686,14 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
 // Reads [r0, r1) of `s` as a set of its own: the packed image, the masks and the per-read arrays are shared (word offsets
 // are absolute), only the sketch chunk map is rebuilt so that chunk ids start at 0.
 static int seqset_view(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, u32 r0, u32 r1, lrge_hip_seqset **out) {
-    int rrc = seqset_ready(ctx, s);
-    if (rrc) return rrc;
+    // A parent whose upload is still in flight (host-side pack + chunked transfer, host_pack.h) is NOT waited for: the view
+    // remembers the chunk gate that covers its last word and its consumers wait for that one (seqset_ready).  Everything a view
+    // is made of here comes from the parent's host-side arrays, which exist from the moment the upload call returned.
+    lrge_hip_seqset *root = const_cast<lrge_hip_seqset *>(s->parent ? s->parent : s);
+    const bool gate_ok = root->pending && root->job && !root->job->gate_ev.empty() && !ctx->opt("NO_VIEW_GATES");
+    if (!gate_ok) { const int rrc = seqset_ready(ctx, s); if (rrc) return rrc; }
     lrge_hip_seqset *v = new lrge_hip_seqset();
-    v->ctx = ctx; v->is_view = true; v->n = r1 - r0; v->parent = s->parent ? s->parent : s;
+    v->ctx = ctx; v->is_view = true; v->n = r1 - r0; v->parent = root;
     v->uid = g_seqset_uid.fetch_add(1); v->parent_uid = s->parent ? s->parent_uid : s->uid;
     v->has_rank = s->has_rank; v->dup_rank = s->dup_rank;
     v->d_pack = s->d_pack; v->d_nmask = s->d_nmask; v->d_woff = s->d_woff + r0; v->d_len = s->d_len + r0;
@@ -661,9 +713,18 @@ static int seqset_view(lrge_hip_ctx *ctx, const lrge_hip_seqset *s, u32 r0, u32 
         if (s->h_len[i] == 0) v->has_empty = true;
     }
     v->n_words = s->h_woff[r1] - s->h_woff[r0];
-    hipError_t e = hipMalloc((void **)&v->d_cs, ((size_t)v->n + 1) * 4);
-    if (e == hipSuccess) e = hipMemcpy(v->d_cs, v->h_cs.data(), ((size_t)v->n + 1) * 4, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { LRGE_SET_ERR(ctx, "seqset view: %s", hipGetErrorString(e)); if (v->d_cs) (void)hipFree(v->d_cs); delete v; return LRGE_ERR_DEVICE; }
+    if (gate_ok) {
+        const std::vector<u64> &gw = root->job->gate_w1;          // (word offsets are absolute in views too)
+        const u64 w_end = s->h_woff[r1];
+        size_t j = (size_t)(std::lower_bound(gw.begin(), gw.end(), w_end) - gw.begin());
+        if (j >= gw.size()) j = gw.size() - 1;
+        v->view_job = root->job; v->view_gate = (int)j; v->view_root = root;
+    }
+    // the chunk map: a pool block filled on the main stream from the view's own host copy (which lives as long as the view)
+    hipError_t e = hipSuccess;
+    v->d_cs = (u32 *)ctx->pool.alloc(((size_t)v->n + 1) * 4, &e);
+    if (v->d_cs) e = hipMemcpyAsync(v->d_cs, v->h_cs.data(), ((size_t)v->n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (!v->d_cs || e != hipSuccess) { LRGE_SET_ERR(ctx, "seqset view: %s", hipGetErrorString(e)); if (v->d_cs) ctx->pool.release(v->d_cs); delete v; (void)hipGetLastError(); return LRGE_ERR_DEVICE; }
     *out = v;
     return LRGE_OK;
 }
@@ -874,10 +935,14 @@ extern "C" int lrge_hip_index_build_sharded(lrge_hip_ctx *ctx, const uint32_t *a
     if ((u64)shard_first + target_shard->n > n_targets) { LRGE_SET_ERR(ctx, "index_build_sharded: the shard [%u, %u) lies outside the %u target reads", shard_first, shard_first + target_shard->n, n_targets); return LRGE_ERR_INVALID; }
     for (u32 i = 0; i < target_shard->n; ++i)
         if (target_shard->h_len[i] != all_target_lens[shard_first + i]) { LRGE_SET_ERR(ctx, "index_build_sharded: read %u of the shard does not have the length of target read %u", i, shard_first + i); return LRGE_ERR_INVALID; }
+    // from here on a failure is owed to the build's first collective, the (world + 1)-word sizes all-reduce of sharded_collect
+    CollectiveGuard eg{comm, ctx->stream};
+    eg.expect(CollectiveGuard::ALLREDUCE_U64, (size_t)comm->world + 1, (size_t)comm->world);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     lrge_hip_seqset *meta = nullptr;
     int rc = seqset_describe(ctx, all_target_lens, n_targets, all_target_ranks, &meta);
-    if (rc) { (void)comm_agree(comm, rc, ctx->stream); return rc; }          // (the others are entering the build's first collective)
+    if (rc || shard_fail_at(ctx, 7)) { if (meta) lrge_hip_seqset_free(meta); return rc ? rc : LRGE_ERR_DEVICE; }
+    eg.disarm();                 // (index_build_one arms its own guard for the same collective)
     IndexBuildOpts ro; ro.restrict_to = streamed; ro.comm = comm; ro.shard = target_shard; ro.shard_first = shard_first;
     rc = index_build_one(ctx, meta, preset, out, &ro);
     if (rc) { lrge_hip_seqset_free(meta); return rc; }

@@ -206,5 +206,6 @@ struct UploadJob {
     // true when gate j has been recorded; false when the job ended (failed) before it
     bool wait_gate(int j) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return gates_recorded > j || done; }); return gates_recorded > j; }
     void finish(int r, const std::string &e) { { std::lock_guard<std::mutex> lk(mu); done = true; rc = r; err = e; } cv.notify_all(); }
+    bool is_done() { std::lock_guard<std::mutex> lk(mu); return done; }
     int wait(std::string *e) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); if (rc && e) *e = err; return rc; }
 };

@@ -62,6 +62,21 @@ static int seqset_job_wait(lrge_hip_ctx *ctx, lrge_hip_seqset *s) {
 // set's upload; the staging blocks of the upload return to the pool (recycled in main-stream order from here on).
 static int seqset_ready(lrge_hip_ctx *ctx, const lrge_hip_seqset *cs) {
     lrge_hip_seqset *s = const_cast<lrge_hip_seqset *>(cs);
+    if (s->is_view) {
+        if (s->view_gate < 0) return LRGE_OK;
+        lrge_hip_seqset *root = s->view_root;
+        if (root->job && root->job == s->view_job) {
+            // the parent's upload is (or was) running: wait for the chunk that carries this view's last word -- on the host until its
+            // transfer has been queued, on the device for the transfer itself (the per-read arrays went ahead of the first chunk)
+            if (!s->view_job->wait_gate(s->view_gate)) { const int jrc = seqset_job_wait(ctx, root); return jrc ? jrc : LRGE_ERR_DEVICE; }
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->view_job->gate_ev[(size_t)s->view_gate], 0));
+        } else if (root->pending) {
+            // somebody has consumed the job object since (its gate events are recycled): the set's own event covers everything
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, root->ev_ready, 0));
+        }
+        s->view_gate = -1; s->view_job.reset();
+        return LRGE_OK;
+    }
     if (!s->pending) return LRGE_OK;
     { int jrc = seqset_job_wait(ctx, s); if (jrc) return jrc; }
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_ready, 0));
@@ -367,7 +382,10 @@ extern "C" void lrge_hip_seqset_free(lrge_hip_seqset *s) {
     bool ctx_alive;
     { std::lock_guard<std::mutex> g(g_live_mu); ctx_alive = g_live_ctx.count(s->ctx) != 0; }
     if (ctx_alive) { (void)hipSetDevice(s->ctx->device); presketch_discard(s); }   // (a set that outlives its context only owns its own arrays)
-    if (s->is_view) { (void)hipFree(s->d_cs); delete s; return; }                   // a view owns its chunk map only
+    if (s->is_view) {      // a view owns its chunk map only (a pool block: hipFree would synchronise the device, i.e. wait for an upload in flight)
+        if (ctx_alive) s->ctx->pool.release(s->d_cs);
+        delete s; return;
+    }
     if (s->pooled) {
         if (ctx_alive) {       // (a destroyed context has already freed its pool)
             lrge_hip_ctx *ctx = s->ctx;

@@ -15,9 +15,40 @@ struct SketchOut {
 template <int K, int W, bool HPC>
 static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o, u32 pk_pos1, u32 pk_ybits,
                          std::vector<u32> *h_mzoff, bool gated = false, bool keep_slots = false) {
-    // gated: the caller has NOT waited for the set's upload (seqset_ready): this function does, as late as it can
+    // gated: the caller has NOT waited for the set's upload (seqset_ready): this function does, as late as it can -- chunk range by
+    // chunk range behind the upload's gates where the form allows it
     if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
     u32 n_chunks = (u32)s->n_chunks;
+    // the upload job whose gates cover this set's words (a view: its root's), and how far the sketch may go behind gate j:
+    // every chunk that lies wholly inside the words that have arrived -- with HPC only the chunks of reads that have arrived
+    // WHOLLY (a homopolymer-compressed step may run past its chunk, to the end of the read at most)
+    std::shared_ptr<UploadJob> gjob;
+    if (gated) {
+        const lrge_hip_seqset *root = s->is_view ? s->view_root : s;
+        gjob = s->is_view ? s->view_job : s->job;
+        if (!gjob || !root || root->job != gjob || gjob->gate_ev.empty()) { gjob.reset(); }
+    }
+    auto chunks_behind = [&](u64 w1) -> u32 {        // w1: absolute word offset the gate covers up to
+        if (w1 >= s->h_woff[s->n]) return n_chunks;
+        if (w1 <= s->h_woff[0]) return 0;
+        const u32 r = (u32)(std::upper_bound(s->h_woff.begin(), s->h_woff.end(), w1) - s->h_woff.begin()) - 1;
+        if (HPC) return s->h_cs[r];
+        const u64 avail = w1 - s->h_woff[r];                      // words of read r that have arrived: 4 per 128-base chunk
+        return s->h_cs[r] + (u32)std::min<u64>(avail / (SK_CHUNK / 32), (u64)(s->h_cs[r + 1] - s->h_cs[r]));
+    };
+    // the first gate behind which chunks [.., c1) of this set may be sketched (waited for on the host until its transfer has been
+    // queued, then on the device); false: the upload failed
+    size_t g_next = 0;
+    auto wait_chunks = [&](u32 c1) -> int {
+        if (!gjob) return LRGE_OK;
+        const size_t ng = gjob->gate_w1.size();
+        size_t j = g_next;
+        while (j + 1 < ng && chunks_behind(gjob->gate_w1[j]) < c1) ++j;
+        if (!gjob->wait_gate((int)j)) return LRGE_ERR_DEVICE;       // (the job failed: seqset_ready reports it)
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, gjob->gate_ev[j], 0));
+        g_next = j;
+        return LRGE_OK;
+    };
     const u32 *d_cs = s->d_cs;           // chunk map, uploaded with the set
     const bool pk = index_keys && pk_ybits;
     ALLOC_OR_FAIL(d_cnt, sc, u32, (size_t)n_chunks + 1);
@@ -52,7 +83,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
         R = ctx->opt_u64("DEBUG_SK_RANGE_CHUNKS", R);
         const u64 est = std::min<u64>((u64)s->total_bases + 1, (u64)((double)s->total_bases * 0.40) + 65536);
         if (R >= 256 && R < n_chunks && est < (1ULL << 32) && est * 8 * (pk ? 1 : 2) < avail / 2) {
-            if (gated) { int rr = seqset_ready(ctx, s); if (rr) return rr; gated = false; }
+            if (gated && !gjob) { int rr = seqset_ready(ctx, s); if (rr) return rr; gated = false; }
             u64 *rx = sc.get<u64>((size_t)R * SK_CAP), *ry = pk ? nullptr : sc.get<u64>((size_t)R * SK_CAP);
             u64 *dx = sc.get<u64>((size_t)est + 1), *dy = pk ? nullptr : sc.get<u64>((size_t)est + 1);
             u32 *d_run = sc.get<u32>(2);                  // [0] output offset behind the ranges done, [1] the current range's count
@@ -61,6 +92,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                 HIPCHK(ctx, hipMemsetAsync(d_run, 0, 8, ctx->stream));
                 for (u64 c0 = 0; c0 < n_chunks; c0 += R) {
                     const u32 c1 = (u32)std::min<u64>(c0 + R, n_chunks), len = c1 - (u32)c0;
+                    if (gated && wait_chunks(c1) != LRGE_OK) { int rr = seqset_ready(ctx, s); return rr ? rr : LRGE_ERR_DEVICE; }   // this range's reads have arrived; the later ones may still travel
                     u64 *sx = rx - c0 * SK_CAP, *sy = ry ? ry - c0 * SK_CAP : nullptr;      // (the kernels index slots by chunk number)
                     const dim3 g((u32)div_up(len, SK_THREADS));
                     if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
@@ -80,6 +112,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                     else hipLaunchKernelGGL(k_sketch_compact<true>, cgrid, dim3(256), 0, ctx->stream, sx, sy, d_cnt, d_run, c1, dx, dy, (u32)c0, (u32)est, d_total + 1);
                     KCHK(ctx);
                 }
+                if (gated) { int rr = seqset_ready(ctx, s); if (rr) return rr; gated = false; }
                 hipLaunchKernelGGL(k_read_mz_offsets, dim3((u32)div_up((u64)s->n + 1, 256)), dim3(256), 0, ctx->stream, d_cs, d_cnt, s->n, n_chunks, d_run, d_mzoff);
                 KCHK(ctx);
                 u32 h_run = 0, h_ovf = 0;
@@ -109,21 +142,14 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
             if (one_pass && gated && pass == 0) {
                 // the set's upload is still in flight (host-side pack, chunk after chunk): the sketch chunks that lie wholly inside
                 // the words of upload chunk j run behind gate j, while the later chunks are still being packed and sent
-                lrge_hip_seqset *ms = const_cast<lrge_hip_seqset *>(s);
-                std::shared_ptr<UploadJob> job = ms->job;
                 u32 c_prev = 0;
-                const size_t ng = job->gate_w1.size();
-                for (size_t j = 0; j < ng; ++j) {
-                    if (!job->wait_gate((int)j)) break;                          // (the job failed: seqset_ready below reports it)
-                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, job->gate_ev[j], 0));
-                    const u64 w1 = job->gate_w1[j];
-                    u32 c_end = n_chunks;
-                    if (w1 < s->n_words) {
-                        const u32 r = (u32)(std::upper_bound(s->h_woff.begin(), s->h_woff.end(), w1) - s->h_woff.begin()) - 1;
-                        const u64 avail = w1 - s->h_woff[r];                      // words of read r that have arrived: 4 per 128-base chunk
-                        c_end = s->h_cs[r] + (u32)std::min<u64>(avail / (SK_CHUNK / 32), (u64)(s->h_cs[r + 1] - s->h_cs[r]));
-                    }
-                    if (c_end > c_prev) {
+                const size_t ng = gjob ? gjob->gate_w1.size() : 0;
+                for (size_t j = 0; j < ng && c_prev < n_chunks; ++j) {
+                    const u32 c_end = chunks_behind(gjob->gate_w1[j]);
+                    if (c_end <= c_prev) continue;                               // (a gate in front of this view, or inside one long read)
+                    if (!gjob->wait_gate((int)j)) break;                         // (the job failed: seqset_ready below reports it)
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, gjob->gate_ev[j], 0));
+                    {
                         const dim3 g((u32)div_up(c_end - c_prev, SK_THREADS));
                         if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
                                                    s->d_woff, s->d_len, cm, c_end, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap, c_prev);
@@ -211,14 +237,17 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
 static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o,
                          u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr, bool keep_slots = false) {
     // A set whose host-side pack is still running on the uploader thread (chunk gates: host_pack.h) is sketched chunk by chunk
-    // behind its transfer -- index sketches of the non-HPC preset only (an HPC step may read a homopolymer run past its chunk,
-    // i.e. words that have not arrived; a streamed set's upload hides behind the index build anyway).  option NO_GATED_SKETCH: wait first.
-    const bool gated = index_keys && preset != LRGE_PRESET_AVA_PB && s->pending && s->job && !s->job->gate_ev.empty() && s->n_words != 0 &&
-                       !s->is_view && !ctx->opt("NO_GATED_SKETCH") && s->n_chunks != 0 && s->n_chunks < (1ULL << 32);
+    // behind its transfer -- index sketches only (a streamed set's upload hides behind the index build anyway).  Since round 4 also
+    // VIEWS of such a set (the parts of a partitioned index: part 0 is sketched, sorted and tabled while parts 1.. still travel)
+    // and the HPC preset (whole reads only: an HPC step may read a homopolymer run past its chunk).  option NO_GATED_SKETCH: wait first.
+    const lrge_hip_seqset *root_ = s->is_view ? s->view_root : s;
+    const std::shared_ptr<UploadJob> &job_ = s->is_view ? s->view_job : s->job;
+    const bool gated = index_keys && root_ && root_->pending && job_ && root_->job == job_ && !job_->gate_ev.empty() && s->n_words != 0 &&
+                       (!s->is_view || s->view_gate >= 0) && !ctx->opt("NO_GATED_SKETCH") && s->n_chunks != 0 && s->n_chunks < (1ULL << 32);
     int rc = gated ? LRGE_OK : seqset_ready(ctx, s);
     if (rc) return rc;
     StageTimer t(ctx, LRGE_T_SKETCH);
-    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, false, keep_slots)
+    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots)
                                             : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots);
     t.stop();
     return rc;
@@ -337,7 +366,11 @@ static int presketch_launch_prepared(lrge_hip_ctx *ctx) {
     return LRGE_OK;
 }
 
-static int presketch_start_pending(lrge_hip_ctx *ctx, u64 indexed_bases) {
+// may_block = false (one part of a partitioned index): a streamed set whose upload job is still running -- it is queued behind
+// the targets' own on the uploader thread, i.e. behind parts that have not even arrived -- keeps its request for the next part's
+// build instead of stalling the host (with this part's table passes unqueued) until the whole transfer is over
+static int presketch_start_pending(lrge_hip_ctx *ctx, u64 indexed_bases, bool may_block = true) {
+    if (!may_block && ctx->presk_pending && ctx->presk_pending->job && !ctx->presk_pending->job->is_done()) return LRGE_OK;
     int rc = presketch_prepare(ctx, indexed_bases);
     return rc ? rc : presketch_launch_prepared(ctx);
 }

@@ -248,6 +248,10 @@ struct lrge_hip_seqset {
     u64 uid = 0, parent_uid = 0; // identity of the set (of a view's parent) for the life of the process: addresses are recycled
     bool is_view = false;       // reads [r0, r1) of another set: shares its device arrays, owns only d_cs
     const lrge_hip_seqset *parent = nullptr;   // (of a view)
+    // a view made while its parent's upload (host-side pack, chunk gates: host_pack.h) is still in flight waits for the GATE that
+    // covers its last word, not for the whole set: the first part of a partitioned index is built -- the first view of a streamed set
+    // is mapped -- while the later reads are still being packed and sent (seqset_view / seqset_ready)
+    std::shared_ptr<UploadJob> view_job; int view_gate = -1; lrge_hip_seqset *view_root = nullptr;
     u32 n = 0;
     u64 total_bases = 0;
     u64 n_words = 0;            // 32-base words in the packed image (reads start on a word)

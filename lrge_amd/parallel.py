@@ -168,6 +168,82 @@ class HostComm(_Comm):
         super().__init__(ctx, h, rank, world)
 
 
+class ThreadHostGroup:
+    """The library's HOST-CALLBACK transport (lrge_hip_comm_create_host) between the threads of one process: the two callbacks meet
+    behind a threading.Barrier.  A stand-in for a caller's own MPI / gloo, and a STRICT one: every rank of a collective must
+    arrive with the same operation and the same shape, as a real transport demands -- a mismatch (or a rank that never arrives:
+    the barrier times out) fails the collective on every rank and is recorded in `faults`.  tests/test_gpu_multi.py drives the
+    sharded index build through it, with a rank failing at every stage, to show that no rank is ever left in a collective its
+    peers do not enter."""
+
+    def __init__(self, world, timeout=60.0):
+        import threading
+        self.world, self.timeout = world, timeout
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+        self.faults = []
+        self.log = [[] for _ in range(world)]        # per rank: (op, shape) of every collective entered
+        self._keep = []
+
+    def _meet(self, rank, desc, payload):
+        """-> list of every rank's payload, or None on a mismatch / timeout"""
+        import threading
+        self.log[rank].append(desc)
+        self.slots[rank] = (desc, payload)
+        try:
+            self.bar.wait(self.timeout)
+            got = list(self.slots)
+            self.bar.wait(self.timeout)
+        except threading.BrokenBarrierError:
+            self.faults.append(("rank %d: a peer never entered %r" % (rank, desc)))
+            return None
+        if any(g[0] != desc for g in got):
+            if rank == 0:
+                self.faults.append("mismatched collectives: %r" % [g[0] for g in got])
+            return None
+        return [g[1] for g in got]
+
+    def comm(self, ctx, rank):
+        import ctypes as C
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+        world = self.world
+
+        def allreduce(_user, buf, n, esz):
+            try:
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint64 if esz == 8 else C.c_uint32)), shape=(n,))
+                got = self._meet(rank, ("allreduce", int(n), int(esz)), a.copy())
+                if got is None:
+                    return 1
+                a[:] = np.sum(np.stack(got), axis=0, dtype=a.dtype)
+                return 0
+            except Exception as e:      # noqa: BLE001 -- reported through the return code
+                self.faults.append(repr(e))
+                return 1
+
+        def allgather(_user, send, nbytes, recv):
+            try:
+                s_ = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                got = self._meet(rank, ("allgather", int(nbytes)), s_.copy())
+                if got is None:
+                    return 1
+                r_ = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+                r_[:] = np.concatenate(got)
+                return 0
+            except Exception as e:      # noqa: BLE001
+                self.faults.append(repr(e))
+                return 1
+
+        ar, ag = AR(allreduce), AG(allgather)
+        self._keep += [ar, ag]                         # keep the trampolines alive
+        h = C.c_void_p()
+        ctx._check(ctx._lib.lrge_hip_comm_create_host(ctx.h, rank, world, C.cast(ar, C.c_void_p), C.cast(ag, C.c_void_p), None, C.byref(h)))
+        return _Comm(ctx, h, rank, world)
+
+    def close(self):
+        pass
+
+
 class LocalGroup:
     """The ranks are threads of this process (one context each); see lrge_hip_comm_create_local."""
 

@@ -247,6 +247,95 @@ def test_a_failing_rank_fails_the_collective_build(ctx, tiny_ont):
     assert all(x is not None and x.startswith("error") for x in res), res
 
 
+def _sharded_world_over(grp, world, ds, preset, fail=None, replicated=False):
+    """The ranks of a sharded (or replicated-sketch) collective build as threads, joined by `grp`; fail = (rank, stage) injects a
+    failure (DEBUG_SHARD_FAIL_AT) or (rank, "alloc") refuses every allocation of that rank.  -> per rank "error: ..." or the results."""
+    from lrge_amd import _ffi, engine, parallel
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    bounds = parallel.shard_by_bases(ds.q.lens(), world)
+    tb = parallel.shard_by_bases(ds.t.lens(), world)
+    res = [None] * world
+
+    def rank_main(r):
+        c = engine.Context(0)
+        comm = grp.comm(c, r)
+        try:
+            sub = ds.q.slice(bounds[r], bounds[r + 1])
+            Qd = c.upload(sub.bases, sub.offsets, qr[bounds[r]:bounds[r + 1]])
+            if replicated:
+                Td = c.upload(ds.t.bases, ds.t.offsets, tr)
+            else:
+                tsub = ds.t.slice(tb[r], tb[r + 1])
+                Td = c.upload(tsub.bases, tsub.offsets, tr[tb[r]:tb[r + 1]])
+            if fail and fail[0] == r:
+                if fail[1] == "alloc":
+                    c.set_option("DEBUG_ALLOC_FAIL_ALWAYS", "1")
+                else:
+                    c.set_option("DEBUG_SHARD_FAIL_AT", str(fail[1]))
+            if replicated:
+                ix = engine.Index(c, Td, preset, streamed=Qd, comm=comm)
+            else:
+                ix = engine.Index(c, Td, preset, streamed=Qd, comm=comm, shard=(ds.t.lens(), tr, tb[r]))
+            counts, has = ix.overlap_twoset(Qd)
+            res[r] = (counts, has, ix.stats())
+        except _ffi.LrgeHipError as e:
+            res[r] = "error: %s" % e
+        except Exception as e:      # noqa: BLE001
+            res[r] = "exception: %r" % e
+        finally:
+            c.set_option("DEBUG_ALLOC_FAIL_ALWAYS", None); c.set_option("DEBUG_SHARD_FAIL_AT", None)
+            comm.close(); c.close()
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    assert all(not t.is_alive() for t in th), "a rank is still blocked in a collective"
+    return res, bounds
+
+
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_sharded_build_over_host_callbacks(ctx, tiny_ont, tiny_hifi, preset):
+    """The sharded target sketch over the HOST-CALLBACK transport (a caller's own MPI / gloo: here threads behind a barrier that
+    insists on matching shapes): the single-GPU counts, has_mapping and statistics on every rank, no mismatched collective."""
+    from lrge_amd import parallel
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    Qd, Td, counts, has, st = _single(ctx, ds, PRESETS[preset])
+    grp = parallel.ThreadHostGroup(3)
+    res, bounds = _sharded_world_over(grp, 3, ds, PRESETS[preset])
+    assert not grp.faults, grp.faults
+    for r, x in enumerate(res):
+        assert not isinstance(x, str), x
+        c, h, s = x
+        assert s == st and np.array_equal(c, counts[bounds[r]:bounds[r + 1]]) and np.array_equal(h, has[bounds[r]:bounds[r + 1]])
+    assert grp.log[0] == grp.log[1] == grp.log[2] and len(grp.log[0]) >= 6
+
+
+@pytest.mark.parametrize("replicated", [False, True])
+@pytest.mark.parametrize("stage", [1, 2, 3, 4, 5, 6, 7, "alloc"])
+@pytest.mark.parametrize("bad_rank", [0, 2])
+def test_a_failing_rank_fails_the_sharded_build_on_every_transport(ctx, tiny_ont, stage, bad_rank, replicated):
+    """a rank that fails inside lrge_hip_index_build_sharded -- at any stage: before the sizes all-reduce, in the
+    sketches, the routing, the exchange buffers, behind the all-to-alls, in front of the statistics -- must JOIN the collective its
+    peers enter next, in that collective's shape, with the status word set; never a one-word agreement against a (W + 1)-word
+    all-reduce, never no collective at all.  Through the host-callback transport (which fails loudly on a shape mismatch and times
+    out on a missing rank) and through the local transport: every rank gets an error, none hangs, no mismatch is seen; the
+    sequence of collectives every rank went through is the same.  `replicated`: lrge_hip_index_build_for with a communicator
+    (one collective: the statistics all-reduce)."""
+    from lrge_amd import parallel
+    if replicated and stage in (1, 2, 3, 4, 5, 7):
+        pytest.skip("stage of the sharded build only")
+    world = 3
+    for make in (lambda: parallel.ThreadHostGroup(world, timeout=60.0), lambda: parallel.LocalGroup(world)):
+        grp = make()
+        res, _ = _sharded_world_over(grp, world, tiny_ont, 0, fail=(bad_rank, stage), replicated=replicated)
+        assert all(isinstance(x, str) and x.startswith("error") for x in res), res
+        if isinstance(grp, parallel.ThreadHostGroup):
+            assert not grp.faults, grp.faults
+            assert grp.log[0] == grp.log[1] == grp.log[2], grp.log
+        grp.close()
+
+
 def test_world_of_threads_inverse(ctx, tiny_ont):
     from lrge_amd import engine
     ds = tiny_ont

@@ -372,7 +372,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     if (!fused) {
         // plain build of packed entries: the sort's first pass reads the sketch's per-chunk slots, no compaction in between
         // (k_prims.h: radix_sort_keys_first_pass_from_slots; option NO_SLOT_SORT: compact first, rounds 1-3)
-        const bool keep_slots = pk && !ro && !ctx->opt("NO_SLOT_SORT") && !ctx->opt("HYBRID_SORT") && !ctx->opt("HYBRID_SORT_MIN");
+        const bool keep_slots = pk && !ro && !ctx->opt("NO_SLOT_SORT");
         rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits, nullptr, keep_slots);
         if (rc) return rc;
         sc.drop(so.mz_off);
@@ -520,10 +520,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             sc.drop(rk == k1 ? k0 : k1);
         } else if (pk) {
             u64 *rk = so.x;
-            bool hybrid = false;
-            // two most-significant-digit passes, then the rest inside LDS (k_prims.h: index_sort_hybrid) where the entries suit it
-            if (pass_from == 0) { rc = index_sort_hybrid(ctx, sc, so.x, k1, M, (int)pk_ybits, 2 * P.k, &rk, &hybrid); if (rc) return rc; }
-            if (!hybrid) rc = radix_sort_keys(ctx, sc, so.x, k1, M, (int)pk_ybits, 2 * P.k, &rk, /*reverse_digits=*/true, pass_from, -1);   // see k_index.h
+            rc = radix_sort_keys(ctx, sc, so.x, k1, M, (int)pk_ybits, 2 * P.k, &rk, /*reverse_digits=*/true, pass_from, -1);   // see k_index.h
             if (rc) return rc;
             skey = rk; spos = rk;
             sc.drop(rk == so.x ? k1 : so.x);

@@ -137,9 +137,6 @@ extern "C" int lrge_hip_ctx_create(int device, lrge_hip_ctx **out) {
                                                                (int)LSORT_BYTES(512, 16, LSORT_DB)) == hipSuccess;
     ctx->lsort_ok[2] = ctx->lsort_ok[0] && hipFuncSetAttribute((const void *)k_seg_sort_local<1024, 16, LSORT_DB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                (int)LSORT_BYTES(1024, 16, LSORT_DB)) == hipSuccess;
-    // (the keys-only siblings used by the index sort: same LDS footprints)
-    if (hipFuncSetAttribute((const void *)k_seg_sort_keys<512, 16, LSORT_DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSORT_BYTES(512, 16, LSORT_DB)) != hipSuccess) ctx->lsort_ok[1] = false;
-    if (hipFuncSetAttribute((const void *)k_seg_sort_keys<1024, 16, LSORT_DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSORT_BYTES(1024, 16, LSORT_DB)) != hipSuccess) ctx->lsort_ok[2] = false;
     (void)hipGetLastError();
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));

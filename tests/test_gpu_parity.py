@@ -185,38 +185,6 @@ def test_segment_packed_pair_index_is_exact(ctx, oracle, edge_set, tiny_ont, tin
     assert res[True][2] == res[False][2] and np.array_equal(res[True][3], res[False][3]) and int(res[True][0][0].sum()) > 0
 
 
-@pytest.mark.parametrize("caps", [None, (3, 5, 9), (64, 300, 700)], ids=["lds", "all-global", "mixed"])
-@pytest.mark.parametrize("preset", ["ont", "pb"])
-def test_hybrid_index_sort_is_exact(ctx, oracle, edge_set, tiny_ont, tiny_hifi, preset, caps, knobs):
-    """The index sort's hybrid form (two most-significant-digit passes, the remaining digits inside LDS; k_prims.h) only
-    engages above 4 M entries -- C2 / C3 / C4 run it at scale.  Here it is forced onto small sets: the index must be the
-    oracle's entry for entry (lists ascending in y: the sort is stable), with the sub-buckets sorted in LDS, all pushed onto
-    the segmented global passes (tiny LDS classes), and a mix of both."""
-    from lrge_amd import engine
-    knobs.set("HYBRID_SORT_MIN", "2")
-    if caps:
-        for i, c in enumerate(caps):
-            knobs.set("DEBUG_LSORT_CAP%d" % i, str(c))
-    qseqs, qnames, tseqs, tnames = edge_set
-    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset)
-    keys, pos = ixd.dump()
-    mz = ixo.minimizers()
-    order = np.lexsort((mz["y"], mz["x"] >> np.uint64(8)))
-    assert np.array_equal(keys, (mz["x"] >> np.uint64(8))[order]) and np.array_equal(pos, mz["y"][order])
-    assert ixd.stats()["mid_occ"] == ixo.mid_occ
-    ds = tiny_ont if preset == "ont" else tiny_hifi
-    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
-    Q2, T2 = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
-    ix = engine.Index(ctx, T2, PRESETS[preset])
-    counts, has = ix.overlap_twoset(Q2)
-    ix.free()
-    knobs.set("NO_HYBRID_SORT", "1")
-    ix = engine.Index(ctx, T2, PRESETS[preset])
-    c0, h0 = ix.overlap_twoset(Q2)
-    ix.free()
-    assert np.array_equal(counts, c0) and np.array_equal(has, h0) and int(c0.sum()) > 0
-
-
 @pytest.mark.parametrize("preset,dual", [("ont", True), ("ont", False), ("pb", True)])
 def test_anchor_parity(ctx, oracle, edge_set, preset, dual):
     qseqs, qnames, tseqs, tnames = edge_set

@@ -3,7 +3,7 @@
 // sub-bucket takes the segmented global passes).  Exact against std::stable_sort on the small inputs, order + permutation
 // checks and timing at index scale.  Development harness, not part of the product or the tests.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/micro/_bin/sort_bench tools/micro/sort_bench.hip && tools/micro/_bin/sort_bench [n]
-#include "../../lrge_amd/csrc/k_prims.h"
+#include "sort_forms.h"      // (includes ../../lrge_amd/csrc/k_prims.h and the retired forms it was split from in round 4)
 
 #include <algorithm>
 #include <chrono>
@@ -78,7 +78,7 @@ int main(int argc, char **argv) {
             (void)hipEventRecord(a, ctx.stream);
             int rc; bool hyb = false;
             if (form == 0) rc = radix_sort_keys(&ctx, sc, k0, k1, n, ybits, hbits, &res, /*reverse_digits=*/true);
-            else if (form == 3) rc = radix_sort_keys(&ctx, sc, k0, k1, n, ybits, hbits, &res, /*reverse_digits=*/true, 0, -1, 10);
+            else if (form == 3) rc = radix_sort_keys_db10(&ctx, sc, k0, k1, n, ybits, hbits, &res, /*reverse_digits=*/true);
             else if (form == 4) {
                 (void)hipMemsetAsync(d_chk + 3, 0, 8, ctx.stream);       // (d_chk[3] is rewritten by the check below)
                 rc = radix_sort_keys_onesweep(&ctx, sc, k0, k1, n, ybits, hbits, &res, true, (u32 *)(d_chk + 3), &hyb);

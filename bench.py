@@ -611,18 +611,18 @@ def main():
             fams.append(roof("index sketch (k_sketch_direct + k_sketch_compact)", acc_tb["sketch"], K, (L_idx / 4.0 + entry_b * n_idx) * K,
                              "L/4 B of packed bases in + %d B per minimizer out" % entry_b))
         if acc_tm.get("anchor_sort", 0.0) > 0:
-            fams.append(roof("anchor sort (k_seg_sort_local / k_rs_hist + scan + k_rs_scatter)", acc_tm["anchor_sort"], K, 24.0 * acc_cn.get("anchors", 0),
-                             "8 B packed anchor in + 16 B (key, value) out per anchor"))
+            fams.append(roof("anchor sort (k_seg_sort_local / k_rs_hist + scan + k_rs_scatter)", acc_tm["anchor_sort"], K, 24.0 * acc_cn.get("anchors_kept", acc_cn.get("anchors", 0)),
+                             "8 B packed anchor in + 16 B (key, value) out per anchor that left the expansion"))
         if acc_tm.get("expand", 0.0) > 0:
             cands.append(roof("k_expand", acc_tm["expand"], max(1, acc_cn.get("batches", K)), 16.0 * acc_cn.get("anchors", 0),
                               "8 B position-list entry in + 8 B anchor out per anchor"))
         # k_rs_scatter: in the timed steps when they run at timer level 2 (big jobs), else in the instrumented step behind them
         if lvl2_all:
             sc_ms, sc_n, sc_bytes, sc_how = acc_tm.get("rs_scatter", 0.0) + acc_tb.get("rs_scatter", 0.0), acc_cn.get("rs_scatter_launches", 0), float(acc_cn.get("rs_scatter_bytes", 0)), "event pair around every launch of the timed steps"
-            anchors_moved = float(acc_cn.get("anchors", 0))
+            anchors_moved = float(acc_cn.get("anchors_kept", acc_cn.get("anchors", 0)))      # (what leaves the expansion: the sort moves those)
         else:
             sc_ms, sc_n, sc_bytes, sc_how = (tm2.get("rs_scatter", 0.0) + tb2.get("rs_scatter", 0.0)) * K, cn2.get("rs_scatter_launches", 0) * K, float(cn2.get("rs_scatter_bytes", 0)) * K, "one instrumented step after the timed region (event pair around every launch)"
-            anchors_moved = float(cn2.get("anchors", 0)) * K
+            anchors_moved = float(cn2.get("anchors_kept", cn2.get("anchors", 0))) * K
         if sc_n:
             r_sc = roof("k_rs_scatter", sc_ms, sc_n, 2.0 * entry_b * n_idx * K + 16.0 * anchors_moved,
                         "what any sort must move, once per step: %d B in + %d B out per index entry, 8 B in + 8 B out per anchor -- dealt over this "

@@ -100,6 +100,8 @@ enum {
     LRGE_C_LOOKUP_LAUNCHES /* k_lookup launches (one per pass over a streamed set / index part) */,
     LRGE_C_TABLE_DISP_SUM /* last index build: sum over the distinct keys of their distance from the home slot in the ordered
                              table; divided by the number of keys it is ~0.5 at load 1/2 when the home slots are uniform */,
+    LRGE_C_ANCHORS_KEPT /* of LRGE_C_ANCHORS (every seed hit expanded: minimap2's n_a), the anchors that left the expansion: the
+                           dead-pair filter of count-only runs drops those of (target, strand) pairs too small to chain */,
     LRGE_C_N
 };
 

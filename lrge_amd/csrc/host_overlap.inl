@@ -89,6 +89,7 @@ struct OverlapRun {
     std::vector<SegTile> h_tiles;   // per batch; lives until the batch's next host sync (the async H2D copy reads it)
     std::vector<SegDesc> h_local[3];
     u32 n_local_items = 0;         // anchors of the batch sorted by k_seg_sort_local
+    std::vector<u32> h_qkept;      // dead-pair filter (k_expand_q): anchors every query of the batch kept
 
     OverlapRun(lrge_hip_ctx *c, const lrge_hip_index *i, const lrge_hip_seqset *q, OverlapJob &j) : ctx(c), ix(i), Q(q), job(j), sc(c) {}
     int prepare();                              // output buffers, shard map, empty-set shortcut
@@ -96,7 +97,7 @@ struct OverlapRun {
     int plan();                                 // batch size, key layout, chaining parameters
     int batch(u32 q0, u32 q1, u64 A);           // K4 expand, sort, K5 groups, K6 chain, K7 count for queries [q0, q1)
     int finish();                               // results to the host
-    void plan_anchor_sort(u32 q0, u32 q1, bool packed);          // which queries sort inside LDS, tiles for the rest
+    void plan_anchor_sort(u32 q0, u32 q1, bool packed, const u32 *kept);   // which queries sort inside LDS, tiles for the rest
     int dump_sorted_anchors(const u64 *skey, const u64 *sval, u64 A);   // lrge_hip_anchors_dump: one query's anchors, mm2 encoding
 };
 
@@ -387,26 +388,28 @@ int OverlapRun::plan() {
 // query's segment.  Packed (count-only) runs sort the segments that fit a workgroup's LDS there (k_seg_sort_local,
 // capacity classes 2048 / 8192 / 16384 anchors); everything else is cut into RS_TILE tiles for the segmented
 // global passes (SegTile, k_prims.h), whose scanned histogram is offset by the items sorted locally (delta).
-void OverlapRun::plan_anchor_sort(u32 q0, u32 q1, bool packed) {
+// kept != null (dead-pair filter): query q's anchors are the first kept[q - q0] of its slot of h_qtot[q] in the expansion's
+// output; the sort gathers them from there (src) into the dense layout (start) every later stage works in.
+void OverlapRun::plan_anchor_sort(u32 q0, u32 q1, bool packed, const u32 *kept) {
     h_tiles.clear();
     for (auto &v : h_local) v.clear();
-    u32 off = 0, tb = 0, &n_local = n_local_items;
+    u32 off = 0, src = 0, tb = 0, &n_local = n_local_items;
     n_local = 0;
     const bool local_ok = !ctx->opt("NO_LOCAL_SORT");
     const int local_max = ctx->opt("LOCAL_SORT_MAX") ? atoi(ctx->opt("LOCAL_SORT_MAX")) : 2;   // largest class sorted in LDS
     for (u32 q = q0; q < q1; ++q) {
-        const u32 c = h_qtot[q];
+        const u32 c = kept ? kept[q - q0] : h_qtot[q], slot = h_qtot[q];
         if (packed && c) {
             const int cls = c <= 2048 ? 0 : c <= 8192 ? 1 : c <= 16384 ? 2 : 3;
-            if (cls < 3 && cls <= local_max && local_ok && ctx->lsort_ok[cls]) { h_local[cls].push_back(SegDesc{off, c, q - q0, 0}); off += c; n_local += c; continue; }
+            if (cls < 3 && cls <= local_max && local_ok && ctx->lsort_ok[cls]) { h_local[cls].push_back(SegDesc{off, c, q - q0, src}); off += c; src += slot; n_local += c; continue; }
         }
         const u32 nt_q = (u32)div_up((u64)c, RS_TILE);
         for (u32 lt = 0; lt < nt_q; ++lt) {
             SegTile t; t.start = off + lt * RS_TILE; t.len = std::min<u32>(RS_TILE, c - lt * RS_TILE);
-            t.hbase = 256u * tb + lt; t.hstride = nt_q; t.seg = q - q0; t.delta = n_local;
+            t.hbase = 256u * tb + lt; t.hstride = nt_q; t.seg = q - q0; t.delta = n_local; t.src = src + lt * RS_TILE; t.pad = 0;
             h_tiles.push_back(t);
         }
-        off += c; tb += nt_q;
+        off += c; src += slot; tb += nt_q;
     }
 }
 
@@ -449,21 +452,49 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
     // chain records (PAF) need the seed rank as well and keep the (key, value) pairs
     const u32 bits_qy = std::max<u32>(1, ceil_log2_u64((u64)Q->max_len + 1));
     const bool packed = !d_chains && !job.dump_anchors && kl.sh_q() + bits_qy + 9 <= 64 && !ctx->opt_u64("NO_PACKED", 0);
+    // Dead-pair filter (count-only runs, k_seed.h: k_expand_q): anchors of (target, strand) pairs that cannot reach the min_n anchors
+    // the group stage asks for are dropped where they are made -- A shrinks to what the sort, the group stage and the chain
+    // kernels see (a third of it at H. sapiens scale).  option NO_GROUP_FILTER: the plain expansion (tests compare the two).
+    const bool filt = packed && !ctx->opt("NO_GROUP_FILTER") && min_n >= 2;
+    const u64 A_all = A;
     {
         StageTimer t(ctx, LRGE_T_EXPAND);
         const u32 *aoff = aoff_all;
-        // (+8: k_chain_lpg streams anchors in 16-byte pairs and may read one element past the last group)
-        akey = bsc.get<u64>(A + 8); aval = bsc.get<u64>(A + 8); akey2 = bsc.get<u64>(A + 8); aval2 = bsc.get<u64>(A + 8);
-        if (!aoff || !akey || !aval || !akey2 || !aval2) return LRGE_ERR_DEVICE;
-        hipLaunchKernelGGL(k_expand, dim3((u32)div_up(me - mb, 256)), dim3(256), 0, ctx->stream, so.x, so.y, mb, me, sp, hs, hn, aoff,
-                           need_rank ? krank : (const u32 *)nullptr, so.mz_off, q0, kl, akey, aval, packed ? bits_qy : 0u);
-        KCHK(ctx);
-        // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
-        t.stop();
+        if (!aoff) return LRGE_ERR_DEVICE;
+        if (filt) {
+            akey = bsc.get<u64>(A_all + 8);
+            u32 *d_kept = bsc.get<u32>((size_t)(q1 - q0) + 1);
+            if (!akey || !d_kept) return LRGE_ERR_DEVICE;
+            hipLaunchKernelGGL(k_expand_q, dim3(q1 - q0), dim3(EXPQ_THREADS), 0, ctx->stream, so.x, so.y, mb, sp, hs, hn, aoff, so.mz_off, q0, kl, akey, bits_qy,
+                               std::min<u32>(min_n, EXPQ_PLANES), d_kept);
+            KCHK(ctx);
+            t.stop();
+            h_qkept.resize((size_t)(q1 - q0));
+            HIPCHK(ctx, ctx->d2h(h_qkept.data(), d_kept, (size_t)(q1 - q0) * 4, ctx->stream));
+            HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+            bsc.drop(d_kept);
+            A = 0;
+            for (u32 c : h_qkept) A += c;
+            ctx->counters[LRGE_C_ANCHORS_KEPT] += A;
+            if (A == 0) return LRGE_OK;                       // nothing can chain: every count of the batch stays 0
+            // (+8: k_chain_lpg streams anchors in 16-byte pairs and may read one element past the last group)
+            aval = bsc.get<u64>(A + 8); akey2 = bsc.get<u64>(A + 8); aval2 = bsc.get<u64>(A + 8);
+            if (!aval || !akey2 || !aval2) return LRGE_ERR_DEVICE;
+        } else {
+            // (+8: k_chain_lpg streams anchors in 16-byte pairs and may read one element past the last group)
+            akey = bsc.get<u64>(A + 8); aval = bsc.get<u64>(A + 8); akey2 = bsc.get<u64>(A + 8); aval2 = bsc.get<u64>(A + 8);
+            if (!akey || !aval || !akey2 || !aval2) return LRGE_ERR_DEVICE;
+            hipLaunchKernelGGL(k_expand, dim3((u32)div_up(me - mb, 256)), dim3(256), 0, ctx->stream, so.x, so.y, mb, me, sp, hs, hn, aoff,
+                               need_rank ? krank : (const u32 *)nullptr, so.mz_off, q0, kl, akey, aval, packed ? bits_qy : 0u);
+            KCHK(ctx);
+            ctx->counters[LRGE_C_ANCHORS_KEPT] += A;
+            // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
+            t.stop();
+        }
     }
     {
         StageTimer t(ctx, LRGE_T_ANCHOR_SORT);
-        plan_anchor_sort(q0, q1, packed);
+        plan_anchor_sort(q0, q1, packed, filt ? h_qkept.data() : nullptr);
         SegTile *d_tiles = (SegTile *)bsc.get<u32>(h_tiles.size() * (sizeof(SegTile) / 4) + 4);
         if (!d_tiles) return LRGE_ERR_DEVICE;
         HIPCHK(ctx, hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
@@ -500,7 +531,7 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                 hipLaunchKernelGGL((k_seg_sort_local<256, 8, 8>), dim3((u32)h_local[0].size()), dim3(256), LSORT_BYTES(256, 8, 8), ctx->stream, akey, aval, aval2, d_seg[0], up, nbits);
                 KCHK(ctx);
             }
-            rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up, A - n_local_items);
+            rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up, A - n_local_items, /*src_first=*/filt);
             if (rc) return rc;
             if (side) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             skey = aval; sval = aval2;

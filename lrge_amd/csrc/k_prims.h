@@ -251,7 +251,10 @@ static int scan_exclusive_u32(lrge_hip_ctx *ctx, Scratch &sc, const u32 *in, u32
 // global destination of that digit's run -- segments never mix and the segment id costs no sort pass.
 // hist index of digit d: hbase + d * hstride; seg = segment id; delta = items in front of the segment that are NOT covered by
 // tiles of this sort (segments sorted elsewhere): the scanned histogram only counts tiled items
-struct SegTile { u32 start, len, hbase, hstride, seg, delta; };
+// src: where the tile's items lie in the input of the FIRST pass when that differs from `start` (use_src: the expansion leaves a
+// query's kept anchors at the front of a sparse slot and the first pass gathers them into the dense layout every later pass --
+// and every later stage -- works in; OverlapRun::batch)
+struct SegTile { u32 start, len, hbase, hstride, seg, delta, src, pad; };
 
 // Packed anchors (count-only runs): one u64 = [self 1 | span 8 | qpos bits_qy | sort bits sb], sorted KEYS-ONLY on the
 // low sb bits; the last scatter pass unpacks every record into the (key, value) pair the chain kernels read
@@ -343,7 +346,8 @@ __device__ __forceinline__ void rs_load_from_slots(const SlotSrc &S, u32 bid, u6
 // (tools/micro/sort_forms.h: one 10-bit pass 0.58 + 0.15 + 1.33 ms against 0.43 + 0.05 + 0.88, the whole sort 5.8 against 5.0 ms)
 template <bool SEG, int DB = 8, bool SLOTS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
-                                                        u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255, SlotSrc src = SlotSrc()) {
+                                                        u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255, SlotSrc src = SlotSrc(),
+                                                        u32 use_src = 0) {
     constexpr u32 ND = 1u << DB;
     static_assert(!SLOTS || !SEG, "slots feed whole (unsegmented) sorts only");
     __shared__ u32 h[ND];
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
     for (u32 i = threadIdx.x; i < ND; i += RS_THREADS) h[i] = 0;
     __syncthreads();
     const u32 bid = xcd_tile(blockIdx.x, gridDim.x);
-    const u64 tile0 = SEG ? (u64)tiles[bid].start : (u64)bid * RS_TILE;
+    const u64 tile0 = SEG ? (u64)(use_src ? tiles[bid].src : tiles[bid].start) : (u64)bid * RS_TILE;
     const u32 n_tile = SEG ? tiles[bid].len : (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
     // the whole tile in flight before the first count (the 4-deep unrolled load -> atomic loop ran at 2.7 TB/s)
     const u32 l0 = (threadIdx.x >> 6) * (RS_ITEMS * 64) + lane_id();
@@ -375,7 +379,7 @@ template <bool SEG, int MODE, int DB = 8, bool SLOTS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict__ keys_in, const u64 *__restrict__ vals_in,
                                                            u64 *__restrict__ keys_out, u64 *__restrict__ vals_out, u64 n,
                                                            int shift, u32 nb, const u32 *__restrict__ hist_scanned,
-                                                           const SegTile *__restrict__ tiles, UnpackParams up, SlotSrc src = SlotSrc()) {
+                                                           const SegTile *__restrict__ tiles, UnpackParams up, SlotSrc src = SlotSrc(), u32 use_src = 0) {
     static_assert(!SLOTS || (!SEG && MODE == RS_MODE_KEYS), "slots feed whole keys-only sorts only");
     __shared__ u32 s_offs[SLOTS ? SLOT_LDS : 1];
     // 1. per-wave stable ranks (ballot digit matching + per-wave LDS counters)
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     const u32 dmask = MODE == RS_MODE_PAIRS ? 255u : up.dmask;
     for (u32 i = threadIdx.x; i < RS_WAVES * ND; i += RS_THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    const u64 tile0 = SEG ? (u64)tiles[bid].start : (u64)bid * RS_TILE;
+    const u64 tile0 = SEG ? (u64)(use_src ? tiles[bid].src : tiles[bid].start) : (u64)bid * RS_TILE;
     const u32 n_tile = SEG ? tiles[bid].len : (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
     const u32 l0 = w * (RS_ITEMS * 64) + lane;           // tile-local index of my first item
     const u64 base = tile0 + l0;
@@ -549,8 +553,9 @@ static int radix_sort_pairs(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *v0, u6
 // Segmented keys-only sort of packed anchors on their low `nbits` bits (pk0/pk1 ping-pong); the last pass unpacks
 // into (out_k, out_v).  See UnpackParams.
 // n_items = items covered by the tiles (for the byte counters).
+// src_first: the first pass reads tile t at tiles[t].src of pk0 (a sparse layout), everything after it is dense.
 static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *pk1, u64 *out_k, u64 *out_v, u64 n, int nbits,
-                                 const SegTile *d_tiles, u32 n_tiles, UnpackParams up, u64 n_items) {
+                                 const SegTile *d_tiles, u32 n_tiles, UnpackParams up, u64 n_items, bool src_first = false) {
     if (n == 0 || n_tiles == 0) return LRGE_OK;
     if (n >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "radix sort limited to < 2^32 items (got %llu)", (unsigned long long)n); return LRGE_ERR_INVALID; }
     const u32 nb = n_tiles;
@@ -560,16 +565,17 @@ static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *
     for (int p = 0; p < passes; ++p) {
         const int shift = p * 8;
         up.dmask = nbits - shift >= 8 ? 255u : (1u << (nbits - shift)) - 1u;   // bits above nbits are payload, not key
-        hipLaunchKernelGGL(k_rs_hist<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, d_tiles, up.dmask);
+        const u32 us = (src_first && p == 0) ? 1u : 0u;
+        hipLaunchKernelGGL(k_rs_hist<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, d_tiles, up.dmask, SlotSrc(), us);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
         if (rc) return rc;
         {
             StageTimer ts(ctx, LRGE_T_RS_SCATTER);
             if (p + 1 < passes)
-                hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, ko, (u64 *)nullptr, n, shift, nb, hist, d_tiles, up);
+                hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, ko, (u64 *)nullptr, n, shift, nb, hist, d_tiles, up, SlotSrc(), us);
             else
-                hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_UNPACK>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, out_k, out_v, n, shift, nb, hist, d_tiles, up);
+                hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_UNPACK>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, (const u64 *)nullptr, out_k, out_v, n, shift, nb, hist, d_tiles, up, SlotSrc(), us);
             KCHK(ctx);
             ts.stop();
             ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1;
@@ -785,7 +791,7 @@ static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n,
 // matching + per-wave counters) as k_rs_scatter, so the resulting order is identical to the tiled global sort.
 // Segments above the variant's capacity stay on the global segmented sort.
 // ------------------------------------------------------------------------------------------
-struct SegDesc { u32 start, len, seg, pad; };
+struct SegDesc { u32 start, len, seg, src; };     // src: offset of the segment in the INPUT array (the output goes to start)
 // DB = digit bits of a pass.  9-bit digits (the 512- and 1024-thread variants: one digit per thread in the scan step) sort the
 // 34 key bits of the headline workload in 4 passes instead of 5; their counters are 16-bit (a count is at most CAP <= 16384)
 // so that the LDS footprint, hence the residency, stays that of the 8-bit form.
@@ -806,7 +812,7 @@ __global__ __launch_bounds__(THREADS) void k_seg_sort_local(const u64 *__restric
     CT *cnt = (CT *)(wtot + 16);                              // [WAVES][NDIG]
     const SegDesc sd = segs[blockIdx.x];
     const u32 n = sd.len;
-    const u64 *src = pk_in + sd.start;
+    const u64 *src = pk_in + sd.src;                         // (input offset: the output goes to sd.start)
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     const u32 l0 = w * (ITEMS * 64) + lane;
     u64 k[ITEMS];

@@ -142,15 +142,22 @@ __global__ __launch_bounds__(256) void k_query_anchor_totals(const u32 *__restri
 // through the scanned counts, applies skip_seed, and the survivors are compacted with a ballot so that
 // both the reads of the position lists and the (key, val) writes are consecutive across the wave.
 // Output order = minimizer order, then list order, exactly as collect_seed_hits emits them.
-__global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 mz_begin,
-                                                u64 mz_end, SeedParams sp, const u64 *__restrict__ hs,
-                                                const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
-                                                const u32 *__restrict__ krank, const u32 *__restrict__ qmz_off, u32 q0,
-                                                KeyLayout kl, u64 *__restrict__ akey, u64 *__restrict__ aval, u32 packed_bits_qy) {
+//
+// MARK (k_expand_q below): every emitted anchor also counts its (target, strand) pair in the block's unary bit planes.
+#define EXPQ_THREADS 256
+#define EXPQ_LOG2B 17                              // buckets of the pair census: 2^17 bits per plane
+#define EXPQ_WORDS (1u << (EXPQ_LOG2B - 5))        // 32-bit words per plane (16 KB)
+#define EXPQ_PLANES 3
+#define EXPQ_ITEMS 8
+__device__ __forceinline__ u32 pair_bucket(u32 rid_rev) { return (rid_rev * 0x9E3779B1u) >> (32 - EXPQ_LOG2B); }
+
+template <bool MARK>
+__device__ __forceinline__ void expand_wave_chunk(const u64 w0, const u64 mz_begin, const u64 mz_end, const u64 *__restrict__ qx, const u64 *__restrict__ qy,
+                                                  const SeedParams &sp, const u64 *__restrict__ hs, const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
+                                                  const u32 *__restrict__ krank, const u32 *__restrict__ qmz_off, const u32 q0, const KeyLayout &kl,
+                                                  u64 *__restrict__ akey, u64 *__restrict__ aval, const u32 packed_bits_qy, u32 *planes, const u32 n_planes) {
     // packed_bits_qy != 0: count-only run, one packed u64 per anchor (UnpackParams in k_prims.h), aval unused
     const u32 lane = lane_id();
-    const u64 w0 = mz_begin + ((u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
-    if (w0 >= mz_end) return;
     const u64 i = w0 + lane;
     const bool in = i < mz_end;
     // the per-minimizer streams are read for every lane, kept seed or not, TOGETHER with the counts: a third of the seeds are
@@ -207,6 +214,14 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
             const u32 yq_rev = ql - (qpos + 1 - span) - 1;
             key = (u64)(q - q0) << kl.sh_q() | (u64)rid << kl.sh_rid() | (u64)(rev ? 1 : 0) << kl.sh_rev() | rpos;
             val = (u64)rk << AVAL_RANK_SHIFT | self | (u64)span << 32 | (rev ? yq_rev : qpos);
+            if (MARK && keep) {
+                // unary count of the pair's bucket: plane j is set by the (j + 1)-th anchor that arrives (each atomicOr hands exactly
+                // one arrival the "was clear" answer), so plane n_planes - 1 set <=> at least n_planes anchors hashed here
+                const u32 b = pair_bucket(rid << 1 | (rev ? 1u : 0u)), wd = b >> 5, bit = 1u << (b & 31);
+                if (!(planes[(n_planes - 1) * EXPQ_WORDS + wd] & bit))
+                    for (u32 lvl = 0; lvl < n_planes; ++lvl)
+                        if (!(atomicOr(&planes[lvl * EXPQ_WORDS + wd], bit) & bit)) break;
+            }
         }
         const u64 km = __ballot(keep);
         if (keep) {
@@ -219,6 +234,77 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
         }
         o += (u32)__popcll(km);
     }
+}
+
+__global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 mz_begin,
+                                                u64 mz_end, SeedParams sp, const u64 *__restrict__ hs,
+                                                const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
+                                                const u32 *__restrict__ krank, const u32 *__restrict__ qmz_off, u32 q0,
+                                                KeyLayout kl, u64 *__restrict__ akey, u64 *__restrict__ aval, u32 packed_bits_qy) {
+    const u64 w0 = mz_begin + ((u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+    if (w0 >= mz_end) return;
+    expand_wave_chunk<false>(w0, mz_begin, mz_end, qx, qy, sp, hs, hn, aoff, krank, qmz_off, q0, kl, akey, aval, packed_bits_qy, nullptr, 0);
+}
+
+// K4 with the DEAD-PAIR FILTER (count-only runs; round 4).  A chain needs min_cnt anchors on ONE (target, strand) pair, and the
+// group stage only ever chains pairs with at least min_n of them (OverlapRun::plan) -- but most anchors of a real job are
+// singletons: chance k-mer matches on some unrelated read (H. sapiens-scale HiFi: 71 % of 10.9 G anchors per step, 7.4 G groups
+// of which 41 M are chained; C4: 55 %).  They used to travel through the whole anchor sort before the group stage dropped them.
+// Here ONE workgroup owns a query: while its wavefronts expand the hits (the code of k_expand, chunk by chunk of 64 minimizers,
+// into the same slots), every anchor counts its pair in a hashed unary counter in LDS (n_planes = min(min_n, 3) bit planes of
+// 2^17 buckets); a bucket's count bounds the size of every pair hashed into it from above, so an anchor whose bucket stayed below
+// n_planes belongs to a pair the group stage would discard -- dropping it changes no chain, no count.  Then the block streams
+// over the slot once more and compacts the survivors to its front, in order (the sort is stable: ties keep emission order).
+// kept[q - q0] tells the host how many; the sort gathers them from the sparse slots into the dense layout (SegTile.src).
+__global__ __launch_bounds__(EXPQ_THREADS) void k_expand_q(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 mz_begin, SeedParams sp,
+                                                           const u64 *__restrict__ hs, const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
+                                                           const u32 *__restrict__ qmz_off, u32 q0, KeyLayout kl, u64 *__restrict__ akey,
+                                                           u32 packed_bits_qy, u32 n_planes, u32 *__restrict__ kept) {
+    __shared__ u32 planes[EXPQ_PLANES * EXPQ_WORDS];
+    __shared__ u32 wsum[2][EXPQ_THREADS / 64];
+    constexpr u32 NW = EXPQ_THREADS / 64;
+    const u32 q = q0 + blockIdx.x;
+    const u64 mb = qmz_off[q], me = qmz_off[q + 1];
+    const u32 seg0 = aoff[mb] - aoff[mz_begin], tot = aoff[me] - aoff[mb];
+    if (tot == 0) { if (threadIdx.x == 0) kept[blockIdx.x] = 0; return; }      // (block-uniform)
+    for (u32 i = threadIdx.x; i < n_planes * EXPQ_WORDS; i += EXPQ_THREADS) planes[i] = 0;
+    __syncthreads();
+    const u32 wv = threadIdx.x >> 6, lane = lane_id();
+    for (u64 w0 = mb + 64ull * wv; w0 < me; w0 += 64ull * NW)
+        expand_wave_chunk<true>(w0, mz_begin, me, qx, qy, sp, hs, hn, aoff, nullptr, qmz_off, q0, kl, akey, nullptr, packed_bits_qy, planes, n_planes);
+    __syncthreads();                     // the slot is written (same workgroup: visible), the planes are final
+    const u32 *top = planes + (n_planes - 1) * EXPQ_WORDS;
+    const u32 sb = kl.sh_q(), sh_rev = kl.sh_rev();
+    const u64 smask = (1ULL << sb) - 1;
+    u64 *slot = akey + seg0;
+    u32 base = 0, it = 0;
+    for (u32 i0 = 0; i0 < tot; i0 += EXPQ_THREADS * EXPQ_ITEMS, ++it) {
+        // wave-major item order (wave w: items i0 + w * 64 * ITEMS + r * 64 + lane), so that ranks follow the slot's order
+        const u32 l0 = i0 + wv * (64 * EXPQ_ITEMS) + lane;
+        u64 v[EXPQ_ITEMS]; u64 km[EXPQ_ITEMS];
+        u32 wtot = 0;
+#pragma unroll
+        for (int r = 0; r < EXPQ_ITEMS; ++r) v[r] = l0 + (u32)r * 64 < tot ? slot[l0 + (u32)r * 64] : 0;
+#pragma unroll
+        for (int r = 0; r < EXPQ_ITEMS; ++r) {
+            bool k = l0 + (u32)r * 64 < tot;
+            if (k) { const u32 b = pair_bucket((u32)((v[r] & smask) >> sh_rev)); k = (top[b >> 5] >> (b & 31)) & 1; }
+            km[r] = __ballot(k);
+            wtot += (u32)__popcll(km[r]);
+        }
+        if (lane == 0) wsum[it & 1][wv] = wtot;
+        __syncthreads();                 // every load of this round has landed before any store of it (stores go to indices below i0 + round size)
+        u32 run = base, all = 0;
+#pragma unroll
+        for (u32 w = 0; w < NW; ++w) { const u32 c = wsum[it & 1][w]; if (w < wv) run += c; all += c; }
+#pragma unroll
+        for (int r = 0; r < EXPQ_ITEMS; ++r) {
+            if ((km[r] >> lane) & 1) slot[run + (u32)__popcll(km[r] & lanemask_lt())] = v[r];
+            run += (u32)__popcll(km[r]);
+        }
+        base += all;
+    }
+    if (threadIdx.x == 0) kept[blockIdx.x] = base;
 }
 
 // ------------------------------------------------------------------------------------------

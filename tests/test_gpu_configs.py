@@ -57,6 +57,10 @@ def test_c2_full(ctx, oracle):
     Qd.presketch(0)
     ix = engine.Index(ctx, Td, 0)
     counts, has = ix.overlap_twoset(Qd)
+    cn = ctx.counters()
+    # the dead-pair filter (k_expand_q) drops the chance matches -- most anchors of a real job -- before the sort, and not one
+    # anchor of a pair that is chained
+    assert cn["anchors_kept"] < 0.8 * cn["anchors"] and cn["chain_anchors"] <= cn["anchors_kept"], cn
     st = ix.stats()
     avg = np.float32(t.lens().sum()) / np.float32(t.n)
     est = ctx.estimates(counts, q.lens(), float(avg), t.n, 100)

@@ -400,6 +400,47 @@ def test_packed_anchor_path_is_invisible(ctx, oracle, tiny_ont, knobs, mode):
     assert int(np.asarray(a).sum()) > 0
 
 
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+@pytest.mark.parametrize("mode", ["twoset", "twoset-F", "inverse", "ava"])
+def test_dead_pair_filter_is_invisible(ctx, oracle, tiny_ont, tiny_hifi, edge_set, knobs, mode, preset):
+    """Count-only runs drop, inside the expansion, the anchors of (target, strand) pairs that cannot reach the min_n anchors the
+    group stage asks for (k_seed.h: k_expand_q -- a hashed unary count per query in LDS, an upper bound of every pair's size).  The
+    counts must be those of the plain expansion (NO_GROUP_FILTER) and of the oracle, in every mode, with the survivors sorted in
+    LDS and through the tiled global passes (their first pass gathers from the sparse slots), and in several small batches; and
+    the filter must actually drop something."""
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    if mode == "ava":
+        Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, ds.t.seqs(), ds.t.names, ds.t.seqs(), ds.t.names, preset, False)
+        run = lambda: ixd.overlap_ava()
+        rc, exp = ixo.ava_counts(threads=8)
+    elif mode == "inverse":
+        Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, ds.t.seqs(), ds.t.names, ds.q.seqs(), ds.q.names, preset)     # index = the queries
+        run = lambda: ixd.overlap_inverse(Qd)
+        rc, exp = ixo.inverse_counts(Qo, threads=8)
+    else:
+        F = mode.endswith("-F")
+        Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, ds.q.seqs(), ds.q.names, ds.t.seqs(), ds.t.names, preset)
+        run = lambda: ixd.overlap_twoset(Qd, remove_internal=F)[0]
+        rc, exp, _ = ixo.twoset_counts(Qo, remove_internal=F, threads=8)
+    assert rc == 0
+    a = np.asarray(run())
+    cn = ctx.counters()
+    assert np.array_equal(a, exp) and int(a.sum()) > 0
+    assert 0 < cn["anchors_kept"] <= cn["anchors"], cn           # (that it drops a lot where there is a lot to drop: test_c2_full)
+    knobs.set("NO_LOCAL_SORT", "1")               # survivors through the tiled passes
+    assert np.array_equal(np.asarray(run()), a)
+    knobs.unset("NO_LOCAL_SORT")
+    knobs.set("BATCH_ANCHORS", "20000")            # several batches
+    assert np.array_equal(np.asarray(run()), a) and ctx.counters()["batches"] > 1
+    knobs.unset("BATCH_ANCHORS")
+    knobs.set("NO_GROUP_FILTER", "1")
+    b = np.asarray(run())
+    cn2 = ctx.counters()
+    assert np.array_equal(a, b)
+    assert cn2["anchors_kept"] == cn2["anchors"] == cn["anchors"]
+    assert cn2["groups"] >= cn["groups"] and cn2["groups_chained"] == cn["groups_chained"] and cn2["chain_anchors"] == cn["chain_anchors"]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_ava_and_inverse_shards_sum_to_the_whole(ctx, oracle, tiny_ont, world):
     """Multi-GPU decomposition on one GPU: the shards a world of `world` ranks would process, run one

@@ -89,7 +89,7 @@ struct OverlapRun {
     std::vector<SegTile> h_tiles;   // per batch; lives until the batch's next host sync (the async H2D copy reads it)
     std::vector<SegDesc> h_local[3];
     u32 n_local_items = 0;         // anchors of the batch sorted by k_seg_sort_local
-    std::vector<u32> h_qkept;      // dead-pair filter (k_expand_q): anchors every query of the batch kept
+    std::vector<u32> h_qkept, h_qlist;   // dead-pair filter (k_expand_q): anchors every query of the batch kept; the queries by size class
 
     OverlapRun(lrge_hip_ctx *c, const lrge_hip_index *i, const lrge_hip_seqset *q, OverlapJob &j) : ctx(c), ix(i), Q(q), job(j), sc(c) {}
     int prepare();                              // output buffers, shard map, empty-set shortcut
@@ -463,16 +463,28 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
         if (!aoff) return LRGE_ERR_DEVICE;
         if (filt) {
             akey = bsc.get<u64>(A_all + 8);
-            u32 *d_kept = bsc.get<u32>((size_t)(q1 - q0) + 1);
-            if (!akey || !d_kept) return LRGE_ERR_DEVICE;
-            hipLaunchKernelGGL(k_expand_q, dim3(q1 - q0), dim3(EXPQ_THREADS), 0, ctx->stream, so.x, so.y, mb, sp, hs, hn, aoff, so.mz_off, q0, kl, akey, bits_qy,
-                               std::min<u32>(min_n, EXPQ_PLANES), d_kept);
+            const u32 nqb = q1 - q0;
+            u32 *d_kept = bsc.get<u32>((size_t)nqb + 1), *d_qlist = bsc.get<u32>((size_t)nqb + 1);
+            if (!akey || !d_kept || !d_qlist) return LRGE_ERR_DEVICE;
+            // the queries by the size of their slot: one launch per class (k_seed.h), largest first so that the long workgroups start early
+            h_qlist.resize(nqb);
+            u32 n_cls[3] = {0, 0, 0};
+            const u32 smax = (u32)ctx->opt_u64("DEBUG_EXPQ_SMALL_MAX", EXPQ_SMALL_MAX), mmax = (u32)ctx->opt_u64("DEBUG_EXPQ_MID_MAX", EXPQ_MID_MAX);   // (tests: every class on small sets)
+            auto cls_of = [&](u32 c) { return c <= smax ? 0 : c <= mmax ? 1 : 2; };
+            for (u32 q = q0; q < q1; ++q) ++n_cls[cls_of(h_qtot[q])];
+            u32 at[3] = {n_cls[2] + n_cls[1], n_cls[2], 0};
+            for (u32 q = q0; q < q1; ++q) h_qlist[at[cls_of(h_qtot[q])]++] = q - q0;
+            HIPCHK(ctx, hipMemcpyAsync(d_qlist, h_qlist.data(), (size_t)nqb * 4, hipMemcpyHostToDevice, ctx->stream));
+            const u32 npl = std::min<u32>(min_n, EXPQ_PLANES);
+            if (n_cls[2]) hipLaunchKernelGGL((k_expand_q<1024, 17>), dim3(n_cls[2]), dim3(1024), 0, ctx->stream, so.x, so.y, mb, sp, hs, hn, aoff, so.mz_off, q0, d_qlist, kl, akey, bits_qy, npl, d_kept);
+            if (n_cls[1]) hipLaunchKernelGGL((k_expand_q<512, 16>), dim3(n_cls[1]), dim3(512), 0, ctx->stream, so.x, so.y, mb, sp, hs, hn, aoff, so.mz_off, q0, d_qlist + n_cls[2], kl, akey, bits_qy, npl, d_kept);
+            if (n_cls[0]) hipLaunchKernelGGL((k_expand_q<256, 14>), dim3(n_cls[0]), dim3(256), 0, ctx->stream, so.x, so.y, mb, sp, hs, hn, aoff, so.mz_off, q0, d_qlist + n_cls[2] + n_cls[1], kl, akey, bits_qy, npl, d_kept);
             KCHK(ctx);
             t.stop();
             h_qkept.resize((size_t)(q1 - q0));
             HIPCHK(ctx, ctx->d2h(h_qkept.data(), d_kept, (size_t)(q1 - q0) * 4, ctx->stream));
             HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
-            bsc.drop(d_kept);
+            bsc.drop(d_kept); bsc.drop(d_qlist);
             A = 0;
             for (u32 c : h_qkept) A += c;
             ctx->counters[LRGE_C_ANCHORS_KEPT] += A;

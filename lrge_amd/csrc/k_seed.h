@@ -144,14 +144,16 @@ __global__ __launch_bounds__(256) void k_query_anchor_totals(const u32 *__restri
 // Output order = minimizer order, then list order, exactly as collect_seed_hits emits them.
 //
 // MARK (k_expand_q below): every emitted anchor also counts its (target, strand) pair in the block's unary bit planes.
-#define EXPQ_THREADS 256
-#define EXPQ_LOG2B 17                              // buckets of the pair census: 2^17 bits per plane
-#define EXPQ_WORDS (1u << (EXPQ_LOG2B - 5))        // 32-bit words per plane (16 KB)
 #define EXPQ_PLANES 3
 #define EXPQ_ITEMS 8
-__device__ __forceinline__ u32 pair_bucket(u32 rid_rev) { return (rid_rev * 0x9E3779B1u) >> (32 - EXPQ_LOG2B); }
+// size classes of k_expand_q (threads per workgroup, log2 of the census buckets): a query's slot of <= EXPQ_SMALL_MAX anchors /
+// <= EXPQ_MID_MAX / anything.  The census is LDS, and LDS is residency: 3 planes of 2^14 bits are 6 KB (the chip stays full of
+// small queries: C4), of 2^17 bits 48 KB (two 1024-thread workgroups per CU: H. sapiens-scale HiFi, ~36 000 hits per query and part)
+#define EXPQ_SMALL_MAX 8192u
+#define EXPQ_MID_MAX 32768u
+template <int LOG2B> __device__ __forceinline__ u32 pair_bucket(u32 rid_rev) { return (rid_rev * 0x9E3779B1u) >> (32 - LOG2B); }
 
-template <bool MARK>
+template <int LOG2B>      // LOG2B != 0: mark the pair census (k_expand_q)
 __device__ __forceinline__ void expand_wave_chunk(const u64 w0, const u64 mz_begin, const u64 mz_end, const u64 *__restrict__ qx, const u64 *__restrict__ qy,
                                                   const SeedParams &sp, const u64 *__restrict__ hs, const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
                                                   const u32 *__restrict__ krank, const u32 *__restrict__ qmz_off, const u32 q0, const KeyLayout &kl,
@@ -214,13 +216,14 @@ __device__ __forceinline__ void expand_wave_chunk(const u64 w0, const u64 mz_beg
             const u32 yq_rev = ql - (qpos + 1 - span) - 1;
             key = (u64)(q - q0) << kl.sh_q() | (u64)rid << kl.sh_rid() | (u64)(rev ? 1 : 0) << kl.sh_rev() | rpos;
             val = (u64)rk << AVAL_RANK_SHIFT | self | (u64)span << 32 | (rev ? yq_rev : qpos);
-            if (MARK && keep) {
+            if (LOG2B != 0 && keep) {
                 // unary count of the pair's bucket: plane j is set by the (j + 1)-th anchor that arrives (each atomicOr hands exactly
                 // one arrival the "was clear" answer), so plane n_planes - 1 set <=> at least n_planes anchors hashed here
-                const u32 b = pair_bucket(rid << 1 | (rev ? 1u : 0u)), wd = b >> 5, bit = 1u << (b & 31);
-                if (!(planes[(n_planes - 1) * EXPQ_WORDS + wd] & bit))
+                constexpr u32 WORDS = LOG2B ? 1u << (LOG2B > 5 ? LOG2B - 5 : 0) : 1u;
+                const u32 b = pair_bucket<LOG2B ? LOG2B : 5>(rid << 1 | (rev ? 1u : 0u)), wd = b >> 5, bit = 1u << (b & 31);
+                if (!(planes[(n_planes - 1) * WORDS + wd] & bit))
                     for (u32 lvl = 0; lvl < n_planes; ++lvl)
-                        if (!(atomicOr(&planes[lvl * EXPQ_WORDS + wd], bit) & bit)) break;
+                        if (!(atomicOr(&planes[lvl * WORDS + wd], bit) & bit)) break;
             }
         }
         const u64 km = __ballot(keep);
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
                                                 KeyLayout kl, u64 *__restrict__ akey, u64 *__restrict__ aval, u32 packed_bits_qy) {
     const u64 w0 = mz_begin + ((u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
     if (w0 >= mz_end) return;
-    expand_wave_chunk<false>(w0, mz_begin, mz_end, qx, qy, sp, hs, hn, aoff, krank, qmz_off, q0, kl, akey, aval, packed_bits_qy, nullptr, 0);
+    expand_wave_chunk<0>(w0, mz_begin, mz_end, qx, qy, sp, hs, hn, aoff, krank, qmz_off, q0, kl, akey, aval, packed_bits_qy, nullptr, 0);
 }
 
 // K4 with the DEAD-PAIR FILTER (count-only runs; round 4).  A chain needs min_cnt anchors on ONE (target, strand) pair, and the
@@ -256,29 +259,31 @@ __global__ __launch_bounds__(256) void k_expand(const u64 *__restrict__ qx, cons
 // n_planes belongs to a pair the group stage would discard -- dropping it changes no chain, no count.  Then the block streams
 // over the slot once more and compacts the survivors to its front, in order (the sort is stable: ties keep emission order).
 // kept[q - q0] tells the host how many; the sort gathers them from the sparse slots into the dense layout (SegTile.src).
-__global__ __launch_bounds__(EXPQ_THREADS) void k_expand_q(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 mz_begin, SeedParams sp,
-                                                           const u64 *__restrict__ hs, const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
-                                                           const u32 *__restrict__ qmz_off, u32 q0, KeyLayout kl, u64 *__restrict__ akey,
-                                                           u32 packed_bits_qy, u32 n_planes, u32 *__restrict__ kept) {
-    __shared__ u32 planes[EXPQ_PLANES * EXPQ_WORDS];
-    __shared__ u32 wsum[2][EXPQ_THREADS / 64];
-    constexpr u32 NW = EXPQ_THREADS / 64;
-    const u32 q = q0 + blockIdx.x;
+// qlist: the queries (relative to q0) of this launch's size class.
+template <int THREADS, int LOG2B>
+__global__ __launch_bounds__(THREADS) void k_expand_q(const u64 *__restrict__ qx, const u64 *__restrict__ qy, u64 mz_begin, SeedParams sp,
+                                                      const u64 *__restrict__ hs, const u32 *__restrict__ hn, const u32 *__restrict__ aoff,
+                                                      const u32 *__restrict__ qmz_off, u32 q0, const u32 *__restrict__ qlist, KeyLayout kl,
+                                                      u64 *__restrict__ akey, u32 packed_bits_qy, u32 n_planes, u32 *__restrict__ kept) {
+    constexpr u32 WORDS = 1u << (LOG2B - 5), NW = THREADS / 64;
+    __shared__ u32 planes[EXPQ_PLANES * WORDS];
+    __shared__ u32 wsum[2][NW];
+    const u32 ql = qlist[blockIdx.x], q = q0 + ql;
     const u64 mb = qmz_off[q], me = qmz_off[q + 1];
     const u32 seg0 = aoff[mb] - aoff[mz_begin], tot = aoff[me] - aoff[mb];
-    if (tot == 0) { if (threadIdx.x == 0) kept[blockIdx.x] = 0; return; }      // (block-uniform)
-    for (u32 i = threadIdx.x; i < n_planes * EXPQ_WORDS; i += EXPQ_THREADS) planes[i] = 0;
+    if (tot == 0) { if (threadIdx.x == 0) kept[ql] = 0; return; }      // (block-uniform)
+    for (u32 i = threadIdx.x; i < n_planes * WORDS; i += THREADS) planes[i] = 0;
     __syncthreads();
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     for (u64 w0 = mb + 64ull * wv; w0 < me; w0 += 64ull * NW)
-        expand_wave_chunk<true>(w0, mz_begin, me, qx, qy, sp, hs, hn, aoff, nullptr, qmz_off, q0, kl, akey, nullptr, packed_bits_qy, planes, n_planes);
+        expand_wave_chunk<LOG2B>(w0, mz_begin, me, qx, qy, sp, hs, hn, aoff, nullptr, qmz_off, q0, kl, akey, nullptr, packed_bits_qy, planes, n_planes);
     __syncthreads();                     // the slot is written (same workgroup: visible), the planes are final
-    const u32 *top = planes + (n_planes - 1) * EXPQ_WORDS;
+    const u32 *top = planes + (n_planes - 1) * WORDS;
     const u32 sb = kl.sh_q(), sh_rev = kl.sh_rev();
     const u64 smask = (1ULL << sb) - 1;
     u64 *slot = akey + seg0;
     u32 base = 0, it = 0;
-    for (u32 i0 = 0; i0 < tot; i0 += EXPQ_THREADS * EXPQ_ITEMS, ++it) {
+    for (u32 i0 = 0; i0 < tot; i0 += THREADS * EXPQ_ITEMS, ++it) {
         // wave-major item order (wave w: items i0 + w * 64 * ITEMS + r * 64 + lane), so that ranks follow the slot's order
         const u32 l0 = i0 + wv * (64 * EXPQ_ITEMS) + lane;
         u64 v[EXPQ_ITEMS]; u64 km[EXPQ_ITEMS];
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(EXPQ_THREADS) void k_expand_q(const u64 *__restrict
 #pragma unroll
         for (int r = 0; r < EXPQ_ITEMS; ++r) {
             bool k = l0 + (u32)r * 64 < tot;
-            if (k) { const u32 b = pair_bucket((u32)((v[r] & smask) >> sh_rev)); k = (top[b >> 5] >> (b & 31)) & 1; }
+            if (k) { const u32 b = pair_bucket<LOG2B>((u32)((v[r] & smask) >> sh_rev)); k = (top[b >> 5] >> (b & 31)) & 1; }
             km[r] = __ballot(k);
             wtot += (u32)__popcll(km[r]);
         }
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(EXPQ_THREADS) void k_expand_q(const u64 *__restrict
         }
         base += all;
     }
-    if (threadIdx.x == 0) kept[blockIdx.x] = base;
+    if (threadIdx.x == 0) kept[ql] = base;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -50,6 +50,7 @@ struct LpgChainArgs {
     // when the group has left the window more than slow_entries times (or has cost more than slow_budget iterations):
     // it is appended to redo_list and chained afterwards by k_chain_hw_redo, whose slow paths scan 64 candidates per step.
     u32 *redo_list, *redo_count; u32 slow_budget, slow_entries;
+    u32 no_prune;      // option LPG_NO_PRUNE: never cut the candidate scan short (tests: the full loop and its slow paths)
 };
 
 // PENTAB: with chain_skip_scale == 0 (every preset lrge uses) comput_sc's penalty depends on dd alone --
@@ -128,6 +129,15 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
     for (int k = 0; k < LPG_W; ++k) { WX[k] = 0; WY[k] = INT32_MAX; WF[k] = 0; WS[k] = 0; WO[k] = 0; }
     i32 mi = -1, mi_x = 0, mi_y = 0, mi_f = 0, mi_sp = 0;
     u64 bkey = 0;                                   // best chain end: f << 32 | i  (f >= min_sc)
+    // PRUNED SCAN (round 4).  comput_sc(i, j) <= span(j) (it is min(span(j), dg) minus penalties), so candidate j can lift anchor
+    // i's score to at most g(j) = f[j] + span(j).  PMa / PMb = the largest g over every anchor of the group that lies BEHIND the first
+    // / the first two blocks of the window (slots >= LPG_B / >= 2 LPG_B, and everything that has left the window).  Once max_f has
+    // reached that bound no later candidate can be STRICTLY better -- mg_lchain_dp's `sc > max_f` -- nor can the max_ii shortcut
+    // (its candidate is either one of those, or already scanned), so (f, p) of the anchor are final and the scan stops: exact.  The
+    // t[] marks and n_skip only live inside one anchor's scan.  Measured on the oracle's own loop: 24.8 candidates per anchor as
+    // minimap2 scans them, 2.2 until the bound holds (ONT; all within 8), 26.6 -> 5.3 at HiFi (96.4 % within 8, all but 3e-6 within
+    // 16): a wavefront leaves the candidate loop after the first block or two instead of the fourth.
+    i32 PMa = R.no_prune ? INT32_MAX : 0, PMb = PMa;
 
     u32 slow_iters = 0, slow_entries = 0;
     bool abandoned = false;
@@ -225,18 +235,22 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
                 n_skip = brk ? 0u : n_skip;
                 marks |= (valid ? WO[k] : 0u) << (k + 1);
             }
-            // every live lane's loop has stopped (max_skip break) -- in the long tail of the kernel, where a wavefront
-            // holds one or two unfinished groups, that is the usual case after 16 or 24 candidates: the remaining
-            // blocks would change nothing (min(S, lim) is invalid for all of them)
+            if (kb == 0 || kb == LPG_B) {       // (compile-time) the bound behind this block: see PMa / PMb above
+                const bool prune = lim == INT32_MAX && max_f >= (kb == 0 ? PMa : PMb);
+                end_k = prune ? -2 : end_k;          // (-2: stopped by the bound, not by a max_skip break)
+                lim = prune ? INT32_MIN : lim;
+            }
+            // every live lane's loop has stopped (bound reached, or max_skip break): the remaining blocks would change
+            // nothing (min(S, lim) is invalid for all of them)
             if (FASTREACH && kb + LPG_B < LPG_W && __ballot(lim == INT32_MAX) == 0) break;
         }
         i32 max_j = max_k < 0 ? -1 : i - 1 - max_k;
         const i32 end_b = end_k < 0 ? -1 : i - 1 - end_k;
         // end of the loop: a break, the window start (x out of reach / max_iter), or more candidates behind the window
-        const bool broke = end_b >= 0;
+        const bool broke = end_b >= 0, pruned = end_k == -2;
         n_reach = n_reach < kcap ? n_reach : kcap;               // empty slots may have counted as "in reach"
         i32 end_j = broke ? end_b : (FASTREACH ? -1 : i - 1 - n_reach);
-        const bool cont = alive && !broke && more && (FASTREACH ? xi - WX[LPG_W - 1] <= maxdx : n_reach == LPG_W);   // (more: i > 32, the window is full)
+        const bool cont = alive && !broke && !pruned && more && (FASTREACH ? xi - WX[LPG_W - 1] <= maxdx : n_reach == LPG_W);   // (more: i > 32, the window is full)
         if (__ballot(cont)) {
             // rare: a lane's loop runs past its 32-anchor window; continue that lane's loop through HBM
             slow_iters += cont ? LPG_W : 0;
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
                 }
             }
         }
-        const bool shortcut = alive && mi >= 0 && mi < end_j;
+        const bool shortcut = alive && !pruned && mi >= 0 && mi < end_j;
         if (__ballot(shortcut)) {
             const i32 tmp = comput_sc_dev(xi, yi, mi_x, mi_y, mi_sp, P);
             if (shortcut && tmp != SC_NONE && max_f < tmp + mi_f) { max_f = tmp + mi_f; max_j = mi; }
@@ -319,6 +333,11 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
         } else if (__ballot(alive && i == n - 1)) {                 // a group ends inside its chunk
             if (alive && i == n - 1)
                 for (i32 t = 0; t <= r4; ++t) grec[i - r4 + t] = ring_o[t * 64 + lane];
+        }
+        // the bounds of the next step: the slots that leave the first / the first two blocks when the window moves on
+        if (alive) {
+            const i32 ga = WF[LPG_B - 1] + WS[LPG_B - 1], gb = WF[2 * LPG_B - 1] + WS[2 * LPG_B - 1];
+            PMa = ga > PMa ? ga : PMa; PMb = gb > PMb ? gb : PMb;
         }
         // shift the window, insert anchor i at slot 0
         const u32 reli = (u32)(i - 1 - max_j);                       // >= 32 (or "no predecessor"): no mark inside the window

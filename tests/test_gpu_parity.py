@@ -332,19 +332,26 @@ def test_batching_is_invisible(ctx, oracle, tiny_ont, knobs):
     assert np.array_equal(ref, small)
 
 
-@pytest.mark.parametrize("kernel", ["hw", "lpg", "lpg_notab", "lpg_redo", "auto64"])
+@pytest.mark.parametrize("kernel", ["hw", "lpg", "lpg_full_scan", "lpg_notab", "lpg_redo", "auto64"])
 @pytest.mark.parametrize("max_skip,max_iter", [(25, 5000), (100000, 5000), (100000, 40), (3, 90)])
 def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, knobs, kernel, max_skip, max_iter):
     """Both chain kernels (half-wave, lane-per-group) and their forced variants against the oracle, including the
     paths the default heuristics almost never take: no max_skip break (the candidate loop walks the
     whole 5000-bp window, far past the 64 anchors held in registers) and a tight max_iter clamp.
-    HiFi reads give dense anchor groups (hundreds of anchors inside one window)."""
+    HiFi reads give dense anchor groups (hundreds of anchors inside one window).
+    k_chain_lpg stops an anchor's candidate scan once its score has reached what ANY remaining candidate could lift it to
+    (round 4: max f + span over the anchors behind the scanned block; exact, see k_chain_lpg.h) -- "lpg" runs with that bound under
+    every max_skip / max_iter setting, "lpg_full_scan" / "lpg_redo" without it (LPG_NO_PRUNE): the full loops and their slow paths."""
     if kernel == "auto64":     # the default split (big groups -> k_chain_hw, the rest -> k_chain_lpg) at a low threshold
         knobs.unset("CHAIN")
         knobs.set("LPG_MAX", "64")
     elif kernel == "lpg_redo":   # k_chain_lpg gives every group that touches a slow path to k_chain_hw_redo
         knobs.set("CHAIN", "lpg")
         knobs.set("LPG_SLOW_BUDGET", "0")
+        knobs.set("LPG_NO_PRUNE", "1")
+    elif kernel == "lpg_full_scan":
+        knobs.set("CHAIN", "lpg")
+        knobs.set("LPG_NO_PRUNE", "1")
     elif kernel == "lpg_notab":  # k_chain_lpg with the f32 penalty computed per candidate instead of tabulated
         knobs.set("CHAIN", "lpg")
         knobs.set("LPG_NOTAB", "1")

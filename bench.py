@@ -231,8 +231,9 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device):
             busy = comm.busy_ms() / a.steps
             counts, est_all, med, tb, tm, cn, st = out
             lo, hi = job.bounds[r], job.bounds[r + 1]
-            ok = bool(np.array_equal(counts, ref_counts[lo:hi]) and st == ref_st and np.array_equal(est_all.view(np.uint32), ref_est.view(np.uint32)))
-            res[r] = dict(rank=r, busy_ms_per_step=busy, results_equal_one_gpu=ok, query_reads=hi - lo, shard=job.shard_stats,
+            mine = ref_counts if a.inverse else ref_counts[lo:hi]       # (inverse: the all-reduced vector over all indexed reads)
+            ok = bool(np.array_equal(counts, mine) and st == ref_st and np.array_equal(est_all.view(np.uint32), ref_est.view(np.uint32)))
+            res[r] = dict(rank=r, busy_ms_per_step=busy, results_equal_one_gpu=ok, streamed_reads_of_rank=hi - lo, shard=job.shard_stats,
                           stage_ms={**{"index_" + k: round(v, 3) for k, v in tb.items() if v and k != "total"}, **{k: round(v, 3) for k, v in tm.items() if v}})
             comm.close(); c.close()
         except Exception as e:      # noqa: BLE001 -- reported below
@@ -263,10 +264,15 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device):
         a2a = max((x["entries_recv"] * eb + x["hashes_recv"] * x.get("hash_bytes", 8)) / max(N - 1, 1) for x in ss) / (XGMI_LINK_GBPS * 1e9) * 1e3
         link_ms = {"keyset_allgather_ring_ms": ring, "alltoall_ms": a2a, "per_link_GBps": XGMI_LINK_GBPS,
                    "note": "model: D2D copies stand in for the links inside busy_ms (those run at HBM speed); this is what the links add at best-case even spreading"}
+    if not ss and a.inverse:      # inverse: one all-reduce of the u32 count vector over the indexed (query) reads closes the step
+        vec = 4.0 * Qn
+        link_ms = {"count_allreduce_ring_ms": 2.0 * (N - 1) / N * vec / (XGMI_LINK_GBPS * 1e9) * 1e3, "per_link_GBps": XGMI_LINK_GBPS,
+                   "keyset_allgather_ring_ms": 0.0, "alltoall_ms": 0.0, "note": "one ring all-reduce of %d bytes; latency-bound in practice (~0.1 ms)" % int(vec)}
     print(json.dumps({"emulate_world": N, "NOT_A_BENCH_RESULT": "all ranks on one GPU, taking turns; a projection input", "config": a.config,
+                      "strategy": "inverse (--use-min-ref: index = queries, replicated; streamed targets cut by bases)" if a.inverse else "forward (target sketch sharded, restricted index per rank)",
                       "one_gpu_ms_per_step": t_one, "max_rank_busy_ms_per_step": busy,
                       "projected_speedup_compute_only": t_one / busy,
-                      "projected_speedup_with_link_model": None if not link_ms else t_one / (busy + link_ms["keyset_allgather_ring_ms"] + link_ms["alltoall_ms"]),
+                      "projected_speedup_with_link_model": None if not link_ms else t_one / (busy + link_ms["keyset_allgather_ring_ms"] + link_ms["alltoall_ms"] + link_ms.get("count_allreduce_ring_ms", 0.0)),
                       "link_model": link_ms, "all_ranks_equal_one_gpu": all(r_["results_equal_one_gpu"] for r_ in res),
                       "exchange_bytes_total": None if not ss else {"keysets": N * (N - 1) * ss[0]["keyset_bytes"],
                                                                    "entries": sum(x["entries_sent"] for x in ss) * ss[0]["entry_bytes"],

@@ -241,6 +241,10 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
         RouteBases B;
         for (int d = 0; d < ROUTE_MAX_WORLD; ++d) { B.keep[d] = d < W ? ks_off[(size_t)d] : 0; B.own[d] = d < W ? os_off[(size_t)d] : 0; }
         if (Mr) { hipLaunchKernelGGL(k_route_write, dim3(A.n_tiles), dim3(RF_THREADS), 0, st, A, flags, cnt, B, sx, sy, sh, sh32); KCHK(ctx); }
+        // the raw sketch has been read for the last time: its blocks serve this rank's later requests (recycled in stream order) --
+        // at H. sapiens scale 15 GB per rank that need not stay resident across the exchanges
+        sc.drop(raw.x); raw.x = nullptr; if (raw.y) { sc.drop(raw.y); raw.y = nullptr; }
+        sc.drop(flags); flags = nullptr; sc.drop(cnt); cnt = nullptr; sc.drop(d_tot); d_tot = nullptr;
         return LRGE_OK;
     };
     cg.expect(CollectiveGuard::AGREE);               // (the send / receive buffers are the build's largest allocations)
@@ -261,8 +265,8 @@ static int sharded_collect(lrge_hip_ctx *ctx, Scratch &sc, const Preset &P, int 
     if (shard_fail_at(ctx, 5)) return LRGE_ERR_DEVICE;
     HIPCHK(ctx, hipStreamSynchronize(st));        // (the offset vectors are locals; the local transport has synchronised already)
     mark("all-to-alls");
-    sc.drop(raw.x); if (raw.y) sc.drop(raw.y);
-    sc.drop(flags); sc.drop(cnt); sc.drop(d_tot); sc.drop(sx); if (sh) sc.drop(sh); if (sh32) sc.drop(sh32); if (rh32) sc.drop(rh32); if (sy) sc.drop(sy);
+    if (raw.x) sc.drop(raw.x); if (raw.y) sc.drop(raw.y);
+    if (flags) sc.drop(flags); if (cnt) sc.drop(cnt); if (d_tot) sc.drop(d_tot); sc.drop(sx); if (sh) sc.drop(sh); if (sh32) sc.drop(sh32); if (rh32) sc.drop(rh32); if (sy) sc.drop(sy);
     sc.drop(ks.bits); sc.drop(gathered); sc.drop(inter);
     so->x = rx; so->y = ry; so->mz_off = nullptr; so->n = n_kr;
     *own_hashes = rh; *n_own = n_or;

@@ -22,12 +22,20 @@
 #pragma once
 #include "k_chain_hw.h"
 
+#ifndef LPG_W
 #define LPG_W 32
+#endif
+#ifndef LPG_OCC
+#define LPG_OCC 2   // wavefronts per SIMD the register allocation aims at
+#endif
 #ifndef LPG_B
 #define LPG_B 8    // candidates per evaluate / resolve block
 #endif
 #ifndef LPG_CH
 #define LPG_CH 8   // anchors per input / output staging chunk
+#endif
+#ifndef LPG_NPM
+#define LPG_NPM 2  // block boundaries at which the candidate scan tests its bound (pruned scan, below)
 #endif
 #ifndef LPG_WAVES
 #define LPG_WAVES 1   // wavefronts per workgroup (they share the penalty table; every wavefront has its own ring)
@@ -63,7 +71,7 @@ struct LpgChainArgs {
 // of end_j unless the window is exhausted, and an exhausted window with more candidates behind it takes the slow path,
 // which computes end_j itself.  Saves a compare, a select and an add per candidate and 32 live compare masks.
 template <bool PENTAB, bool FASTREACH>
-__global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
+__global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(2, LPG_OCC))) void k_chain_lpg(LpgChainArgs R, ChainParams P, GroupOut out) {
     extern __shared__ i32 pen_tab[];   // [bw + 2] when PENTAB, then the anchor / record staging ring (LPG_RING_BYTES)
     // this kernel's longest wavefronts are the critical path of the chain stage; k_chain_hw's wavefronts on
     // the other stream share the SIMDs and should fill the gaps, not compete for issue slots
@@ -130,14 +138,16 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
     i32 mi = -1, mi_x = 0, mi_y = 0, mi_f = 0, mi_sp = 0;
     u64 bkey = 0;                                   // best chain end: f << 32 | i  (f >= min_sc)
     // PRUNED SCAN (round 4).  comput_sc(i, j) <= span(j) (it is min(span(j), dg) minus penalties), so candidate j can lift anchor
-    // i's score to at most g(j) = f[j] + span(j).  PMa / PMb = the largest g over every anchor of the group that lies BEHIND the first
-    // / the first two blocks of the window (slots >= LPG_B / >= 2 LPG_B, and everything that has left the window).  Once max_f has
+    // i's score to at most g(j) = f[j] + span(j).  PM[k] = the largest g over every anchor of the group that lies BEHIND the first
+    // k + 1 blocks of the window (slots >= (k + 1) LPG_B, and everything that has left the window).  Once max_f has
     // reached that bound no later candidate can be STRICTLY better -- mg_lchain_dp's `sc > max_f` -- nor can the max_ii shortcut
     // (its candidate is either one of those, or already scanned), so (f, p) of the anchor are final and the scan stops: exact.  The
     // t[] marks and n_skip only live inside one anchor's scan.  Measured on the oracle's own loop: 24.8 candidates per anchor as
     // minimap2 scans them, 2.2 until the bound holds (ONT; all within 8), 26.6 -> 5.3 at HiFi (96.4 % within 8, all but 3e-6 within
     // 16): a wavefront leaves the candidate loop after the first block or two instead of the fourth.
-    i32 PMa = R.no_prune ? INT32_MAX : 0, PMb = PMa;
+    i32 PM[LPG_NPM];
+#pragma unroll
+    for (int k = 0; k < LPG_NPM; ++k) PM[k] = R.no_prune ? INT32_MAX : 0;
 
     u32 slow_iters = 0, slow_entries = 0;
     bool abandoned = false;
@@ -235,8 +245,8 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
                 n_skip = brk ? 0u : n_skip;
                 marks |= (valid ? WO[k] : 0u) << (k + 1);
             }
-            if (kb == 0 || kb == LPG_B) {       // (compile-time) the bound behind this block: see PMa / PMb above
-                const bool prune = lim == INT32_MAX && max_f >= (kb == 0 ? PMa : PMb);
+            if (kb / LPG_B < LPG_NPM) {          // (compile-time) the bound behind this block: see PM[] above
+                const bool prune = lim == INT32_MAX && max_f >= PM[kb / LPG_B < LPG_NPM ? kb / LPG_B : 0];
                 end_k = prune ? -2 : end_k;          // (-2: stopped by the bound, not by a max_skip break)
                 lim = prune ? INT32_MIN : lim;
             }
@@ -336,8 +346,8 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
         }
         // the bounds of the next step: the slots that leave the first / the first two blocks when the window moves on
         if (alive) {
-            const i32 ga = WF[LPG_B - 1] + WS[LPG_B - 1], gb = WF[2 * LPG_B - 1] + WS[2 * LPG_B - 1];
-            PMa = ga > PMa ? ga : PMa; PMb = gb > PMb ? gb : PMb;
+#pragma unroll
+            for (int k = 0; k < LPG_NPM; ++k) { const i32 g = WF[(k + 1) * LPG_B - 1] + WS[(k + 1) * LPG_B - 1]; PM[k] = g > PM[k] ? g : PM[k]; }
         }
         // shift the window, insert anchor i at slot 0
         const u32 reli = (u32)(i - 1 - max_j);                       // >= 32 (or "no predecessor"): no mark inside the window

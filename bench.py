@@ -211,6 +211,10 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device):
     if hasattr(one.qs, "dev"):
         one.qs.dev.free(); one.ts.dev.free()
     one.qs = one.ts = None
+    # the one-GPU job's context goes now: its arena holds most of the HBM (segments are kept until the context dies), and the ranks'
+    # contexts need that room
+    del one
+    ctx0.close()
     grp = parallel.LocalGroup(N)
     grp.serialize(True)
     res, errs = [None] * N, []

@@ -195,7 +195,7 @@ def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
 XGMI_LINK_GBPS = 64.0     # one direction of one xGMI link, what a point-to-point transfer between two GPUs sustains (7 links per GPU)
 
 
-def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device):
+def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_lens_all):
     """--emulate-world N (see parse()).  Prints one JSON line."""
     import threading
     N = a.emulate_world
@@ -215,16 +215,29 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device):
     # contexts need that room
     del one
     ctx0.close()
+
+    def free_gb():
+        try:
+            from lrge_amd import synth_cb
+            f, t = synth_cb.mem_info(device)
+            return "%.1f of %.1f GB free" % (f / 1e9, t / 1e9)
+        except Exception as e:      # noqa: BLE001
+            return "mem_info: %r" % e
+    sys.stderr.write("[emulate-world] reference context closed: %s\n" % free_gb())
     grp = parallel.LocalGroup(N)
-    grp.serialize(True)
+    big = float(q_lens_all.sum() + t_lens_all.sum()) > 5e9
+    grp.serialize(2 if big else True)      # big jobs: N arenas sized for a GPU each do not fit one GPU -- idle segments go back between turns (allocator time is kept out of busy_ms)
     res, errs = [None] * N, []
 
     def rank_main(r):
         try:
             c = engine.Context(device)
+            if big:
+                c.set_option("POOL_SEG_MAX_MB", "4096")
             comm = grp.comm(c, r)
             comm.turn(True)
             job = RankJob(c, comm, r, N, device)
+            sys.stderr.write("[emulate-world] rank %d holds its reads: %s\n" % (r, free_gb()))
             comm.turn(False)
             for it in range(max(1, a.warmup) + a.steps):
                 if it == max(1, a.warmup):
@@ -242,6 +255,7 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device):
             comm.close(); c.close()
         except Exception as e:      # noqa: BLE001 -- reported below
             errs.append((r, repr(e)))
+            sys.stderr.write("[emulate-world] rank %d failed (%r): %s\n" % (r, e, free_gb()))
             try:
                 comm.turn(False)    # a rank that fails while it holds the GPU must hand it back, or the others wait for ever
             except Exception:       # noqa: BLE001
@@ -462,7 +476,7 @@ def main():
             return counts, est_all, med, tb, tm, cn, st
 
     if a.emulate_world:
-        emulate_world(a, ctx, RankJob, Qn, engine, parallel, local_rank)
+        emulate_world(a, ctx, RankJob, Qn, engine, parallel, local_rank, q_lens, t_lens)
         ctx.close()
         return
     job = RankJob(ctx, comm, emu[0] if emu else rank, emu[1] if emu else world, local_rank, emulated_share=bool(emu))

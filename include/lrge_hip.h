@@ -275,7 +275,9 @@ int  lrge_hip_comm_rccl_ranks(const lrge_hip_comm *c, int *n);
 /* Timing emulation of a world on ONE GPU (local groups only): with serialize on, the ranks of the group take turns -- a rank
    computes between lrge_hip_comm_local_turn(c, 1) and (c, 0) and hands the GPU over whenever it waits for the others inside
    a collective; lrge_hip_comm_busy_ms returns the time it held the turn (what its share of the job takes on a GPU of its
-   own, link transfers aside).  Results are unaffected. */
+   own, link transfers aside).  Results are unaffected.  on = 2: a rank that hands the GPU over also returns the idle segments of its
+   device arena to the runtime (N arenas each sized for a whole GPU do not fit one), and the time inside the device allocator
+   -- which a warm arena on a GPU of its own does not pay -- is kept out of busy_ms. */
 int  lrge_hip_comm_local_group_serialize(void *group, int on);
 int  lrge_hip_comm_local_turn(lrge_hip_comm *c, int begin);
 double lrge_hip_comm_busy_ms(lrge_hip_comm *c, int reset);

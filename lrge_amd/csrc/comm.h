@@ -72,6 +72,10 @@ struct LocalGroup {
     // the token and hands it over whenever it waits at a barrier, so its kernels never share the GPU with another rank's
     // and the time it holds the token is the time its share of the job takes on a GPU of its own (link transfers aside).
     bool serialize = false; std::mutex token;
+    // trim_on_yield: a rank that hands the GPU over gives its IDLE arena segments back to the runtime first -- eight contexts' arenas,
+    // each sized as if it owned the 288 GB, do not fit one GPU; the time inside hipMalloc / hipFree (25 ms per GB: a warm arena on a
+    // GPU of its own pays none of it after the first step) is kept out of the rank's busy time
+    bool trim_on_yield = false;
     explicit LocalGroup(int w) : world(w), slot((size_t)w, nullptr), slot2((size_t)w, nullptr) {}
     // false: the group was aborted (by this call's peer or earlier) -- the collective fails on every rank instead of
     // leaving the others blocked on a rank that will never arrive
@@ -101,16 +105,22 @@ struct lrge_hip_comm {
     // RCCL transport: a small device block taken ONCE at creation for the host-buffer collectives below (the status-carrying
     // vectors of a collective build), so that a rank that has just run out of memory can still JOIN a collective to say so
     char *d_small = nullptr; static constexpr size_t kSmall = (size_t)1 << 20;
-    bool in_turn = false; double busy_ms = 0, t_acquired = 0;     // (serialized local groups)
+    bool in_turn = false; double busy_ms = 0, t_acquired = 0, alloc_ms0 = 0;     // (serialized local groups)
     double wait_ms = 0;                   // wall time spent inside barriers of the local transport (waiting for the other ranks)
 };
 
 static void comm_turn(lrge_hip_comm *c, bool begin) {
     if (!c || !c->grp || !c->grp->serialize) return;
-    if (begin) { c->grp->token.lock(); c->in_turn = true; c->t_acquired = DevPool::now_ms(); return; }
+    if (begin) {
+        c->grp->token.lock(); c->in_turn = true;
+        c->alloc_ms0 = c->ctx->pool.ms_malloc + c->ctx->pool.ms_free;
+        c->t_acquired = DevPool::now_ms();
+        return;
+    }
     if (!c->in_turn) return;
     (void)hipStreamSynchronize(c->ctx->stream); (void)hipStreamSynchronize(c->ctx->stream2); (void)hipStreamSynchronize(c->ctx->copy_stream);
-    c->busy_ms += DevPool::now_ms() - c->t_acquired;
+    c->busy_ms += (DevPool::now_ms() - c->t_acquired) - (c->grp->trim_on_yield ? (c->ctx->pool.ms_malloc + c->ctx->pool.ms_free) - c->alloc_ms0 : 0.0);
+    if (c->grp->trim_on_yield) c->ctx->pool.trim();
     c->in_turn = false;
     c->grp->token.unlock();
 }

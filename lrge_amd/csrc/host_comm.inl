@@ -79,6 +79,7 @@ extern "C" int lrge_hip_comm_rccl_ranks(const lrge_hip_comm *c, int *n) {
 extern "C" int lrge_hip_comm_local_group_serialize(void *grp, int on) {
     if (!grp) return LRGE_ERR_INVALID;
     ((LocalGroup *)grp)->serialize = on != 0;
+    ((LocalGroup *)grp)->trim_on_yield = on == 2;       // (2: the ranks also hand their idle arena segments back between turns)
     return LRGE_OK;
 }
 extern "C" int lrge_hip_comm_local_turn(lrge_hip_comm *c, int begin) {

@@ -63,6 +63,7 @@ struct DevPool {
     size_t in_use = 0;
     long fail_every = 0, misses = 0;
     bool fail_always = false;          // test hook (DEBUG_ALLOC_FAIL_ALWAYS): every request is refused
+    size_t seg_max = (size_t)32 << 30; // largest segment asked of the runtime at once (option POOL_SEG_MAX_MB: several contexts sharing one GPU keep it small, so that what one of them holds between two turns is not padded to 32 GB)
     // bookkeeping for option VERBOSE: what the device allocator itself cost
     double ms_malloc = 0, ms_free = 0; u64 n_malloc = 0, n_free = 0, n_trim = 0, bytes_malloc = 0;
     static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -96,7 +97,7 @@ struct DevPool {
         // test hook (option DEBUG_ALLOC_FAIL_EVERY, per context, set by lrge_hip_ctx_set_option only): every n-th miss asks
         // for an impossible size first, i.e. takes the genuine failure + retry path
         const bool sabotage = fail_every > 0 && (++misses % fail_every) == 0;
-        size_t want = std::max(bytes, std::max(kMinSeg, std::min(total, (size_t)32 << 30)));
+        size_t want = std::max(bytes, std::max(kMinSeg, std::min(total, seg_max)));
         want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
         void *p = nullptr;
         const double t0 = now_ms();

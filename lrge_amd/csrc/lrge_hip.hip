@@ -51,6 +51,7 @@ extern "C" int lrge_hip_ctx_set_option(lrge_hip_ctx *ctx, const char *name, cons
     if (!strcmp(name, "DEBUG_ALLOC_FAIL_EVERY")) { ctx->pool.fail_every = value ? atol(value) : 0; ctx->pool.misses = 0; }
     if (!strcmp(name, "DEBUG_ALLOC_FAIL_ALWAYS")) ctx->pool.fail_always = value != nullptr;
     if (!strcmp(name, "TIMERS") && value) ctx->timer_level = atoi(value);
+    if (!strcmp(name, "POOL_SEG_MAX_MB")) ctx->pool.seg_max = value ? (size_t)std::max<u64>(64, strtoull(value, nullptr, 10)) << 20 : (size_t)32 << 30;
     return LRGE_OK;
 }
 

@@ -258,7 +258,7 @@ class LocalGroup:
 
     def serialize(self, on=True):
         """The ranks take turns on the GPU (see lrge_hip_comm_local_group_serialize): clean per-rank timings on one GPU."""
-        self._lib.lrge_hip_comm_local_group_serialize(self.h, 1 if on else 0)
+        self._lib.lrge_hip_comm_local_group_serialize(self.h, int(on) if on in (0, 1, 2) else (1 if on else 0))     # 2: + idle arena segments go back to the runtime between turns
 
     def comm(self, ctx, rank):
         import ctypes as C

@@ -250,7 +250,12 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
             lo, hi = job.bounds[r], job.bounds[r + 1]
             mine = ref_counts if a.inverse else ref_counts[lo:hi]       # (inverse: the all-reduced vector over all indexed reads)
             ok = bool(np.array_equal(counts, mine) and st == ref_st and np.array_equal(est_all.view(np.uint32), ref_est.view(np.uint32)))
-            res[r] = dict(rank=r, busy_ms_per_step=busy, results_equal_one_gpu=ok, streamed_reads_of_rank=hi - lo, shard=job.shard_stats,
+            detail = None
+            if not ok:
+                nd = int((counts != mine).sum()) if len(counts) == len(mine) else -1
+                detail = dict(counts_differ=nd, first=[int(x) for x in np.nonzero(counts != mine)[0][:8]] if nd > 0 else [], stats=st, ref_stats=ref_st,
+                              estimates_equal=bool(np.array_equal(est_all.view(np.uint32), ref_est.view(np.uint32))))
+            res[r] = dict(rank=r, busy_ms_per_step=busy, results_equal_one_gpu=ok, mismatch=detail, streamed_reads_of_rank=hi - lo, shard=job.shard_stats,
                           stage_ms={**{"index_" + k: round(v, 3) for k, v in tb.items() if v and k != "total"}, **{k: round(v, 3) for k, v in tm.items() if v}})
             comm.close(); c.close()
         except Exception as e:      # noqa: BLE001 -- reported below

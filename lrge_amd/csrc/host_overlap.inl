@@ -543,9 +543,15 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                 hipLaunchKernelGGL((k_seg_sort_local<256, 8, 8>), dim3((u32)h_local[0].size()), dim3(256), LSORT_BYTES(256, 8, 8), ctx->stream, akey, aval, aval2, d_seg[0], up, nbits);
                 KCHK(ctx);
             }
+            // With the dead-pair filter the segments are READ in the expansion's sparse layout and WRITTEN in the dense one, and the
+            // tiled sort's second pass writes into akey -- dense positions that are other queries' unread sparse slots.  The local
+            // sorts on this stream are over by then (stream order); the largest class on the side stream is not: the tiled passes
+            // wait for it.  (Found at C5/2: counts off on the ~9 000 queries whose slots a tiled segment's output overwrote.)
+            bool joined = false;
+            if (side && filt && !h_tiles.empty()) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); joined = true; }
             rc = radix_sort_packed_seg(ctx, bsc, akey, akey2, aval, aval2, A, (int)kl.sh_q(), d_tiles, (u32)h_tiles.size(), up, A - n_local_items, /*src_first=*/filt);
             if (rc) return rc;
-            if (side) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            if (side && !joined) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             skey = aval; sval = aval2;
             bsc.drop((u32 *)d_tiles);
             bsc.drop(akey); bsc.drop(akey2);

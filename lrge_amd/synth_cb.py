@@ -199,6 +199,7 @@ def mem_info(device=0):
 # Configurations (two-set: reads [0, Q) are the queries, [Q, Q + T) the targets -- file order of SURVEY.md Appendix C).
 CONFIGS = {
     "c5_human_twoset": dict(genome=3_100_000_000, seed=31001, platform="hifi", Q=100000, T=2000000),   # BASELINE configs[4]
+    "c5_human_half": dict(genome=1_550_000_000, seed=31001, platform="hifi", Q=50000, T=1000000),
     "c5_human_tenth": dict(genome=310_000_000, seed=31001, platform="hifi", Q=10000, T=200000),
     "c4_dmel_twoset": dict(genome=143_000_000, seed=14301, platform="ont", Q=50000, T=100000),
     "tiny_hifi": dict(genome=300_000, seed=79, platform="hifi", Q=20, T=120),

@@ -58,9 +58,9 @@ def test_c2_full(ctx, oracle):
     ix = engine.Index(ctx, Td, 0)
     counts, has = ix.overlap_twoset(Qd)
     cn = ctx.counters()
-    # the dead-pair filter (k_expand_q) drops the chance matches -- most anchors of a real job -- before the sort, and not one
-    # anchor of a pair that is chained
-    assert cn["anchors_kept"] < 0.8 * cn["anchors"] and cn["chain_anchors"] <= cn["anchors_kept"], cn
+    # the dead-pair filter (k_expand_q) drops chance matches before the sort (few on a 4.4 Mbp genome: 3 %; more than half of all
+    # anchors at C4, 71 % at H. sapiens scale) and not one anchor of a pair that is chained
+    assert cn["chain_anchors"] <= cn["anchors_kept"] < cn["anchors"], cn
     st = ix.stats()
     avg = np.float32(t.lens().sum()) / np.float32(t.n)
     est = ctx.estimates(counts, q.lens(), float(avg), t.n, 100)
@@ -156,6 +156,8 @@ def test_c4_sampled_and_properties(ctx, oracle):
     # of this size shows it.
     assert ix.build_counters["table_disp_sum"] < 0.6 * ix.stats()["n_keys"]
     counts, has = ix.overlap_twoset(Qd)
+    cn = ctx.counters()
+    assert cn["chain_anchors"] <= cn["anchors_kept"] < 0.6 * cn["anchors"], cn      # (the dead-pair filter: more than half of C4's anchors are chance matches)
     st = ix.stats()
     # size-independent properties on all 50 000 queries
     #  * streamed reads are independent: any sub-range of the queries gives the same counts for those reads

@@ -195,7 +195,7 @@ def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
 XGMI_LINK_GBPS = 64.0     # one direction of one xGMI link, what a point-to-point transfer between two GPUs sustains (7 links per GPU)
 
 
-def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_lens_all):
+def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_lens_all, forward_mode="tshard"):
     """--emulate-world N (see parse()).  Prints one JSON line."""
     import threading
     N = a.emulate_world
@@ -248,7 +248,7 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
             busy = comm.busy_ms() / a.steps
             counts, est_all, med, tb, tm, cn, st = out
             lo, hi = job.bounds[r], job.bounds[r + 1]
-            mine = ref_counts if a.inverse else ref_counts[lo:hi]       # (inverse: the all-reduced vector over all indexed reads)
+            mine = ref_counts if (a.inverse or job.tshard) else ref_counts[lo:hi]       # (inverse / target-sharded forward: the all-reduced vector)
             ok = bool(np.array_equal(counts, mine) and st == ref_st and np.array_equal(est_all.view(np.uint32), ref_est.view(np.uint32)))
             detail = None
             if not ok:
@@ -284,6 +284,8 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
     if ss:
         eb = ss[0]["entry_bytes"]
         ring = (N - 1) * ss[0]["keyset_bytes"] / (XGMI_LINK_GBPS * 1e9) * 1e3
+        if forward_mode == "tshard" and not a.inverse:      # + the closing all-reduce of the two u32[Q] vectors (ring)
+            ring += 2.0 * (N - 1) / N * 8.0 * Qn / (XGMI_LINK_GBPS * 1e9) * 1e3
         a2a = max((x["entries_recv"] * eb + x["hashes_recv"] * x.get("hash_bytes", 8)) / max(N - 1, 1) for x in ss) / (XGMI_LINK_GBPS * 1e9) * 1e3
         link_ms = {"keyset_allgather_ring_ms": ring, "alltoall_ms": a2a, "per_link_GBps": XGMI_LINK_GBPS,
                    "note": "model: D2D copies stand in for the links inside busy_ms (those run at HBM speed); this is what the links add at best-case even spreading"}
@@ -292,7 +294,9 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
         link_ms = {"count_allreduce_ring_ms": 2.0 * (N - 1) / N * vec / (XGMI_LINK_GBPS * 1e9) * 1e3, "per_link_GBps": XGMI_LINK_GBPS,
                    "keyset_allgather_ring_ms": 0.0, "alltoall_ms": 0.0, "note": "one ring all-reduce of %d bytes; latency-bound in practice (~0.1 ms)" % int(vec)}
     print(json.dumps({"emulate_world": N, "NOT_A_BENCH_RESULT": "all ranks on one GPU, taking turns; a projection input", "config": a.config,
-                      "strategy": "inverse (--use-min-ref: index = queries, replicated; streamed targets cut by bases)" if a.inverse else "forward (target sketch sharded, restricted index per rank)",
+                      "strategy": "inverse (--use-min-ref: index = queries, replicated; streamed targets cut by bases)" if a.inverse else
+                                  ("forward, TARGETS sharded (lrge_hip_index_build_tsharded): every rank maps all queries against its share, counts all-reduced" if forward_mode == "tshard"
+                                   else "forward, queries sharded (target sketch sharded, restricted index per rank)"),
                       "one_gpu_ms_per_step": t_one, "max_rank_busy_ms_per_step": busy,
                       "projected_speedup_compute_only": t_one / busy,
                       "projected_speedup_with_link_model": None if not link_ms else t_one / (busy + link_ms["keyset_allgather_ring_ms"] + link_ms["alltoall_ms"] + link_ms.get("count_allreduce_ring_ms", 0.0)),
@@ -396,6 +400,10 @@ def main():
     # forward strategy on more than one GPU: the target sketch is sharded too (lrge_hip_index_build_sharded)
     # unless LRGE_BENCH_REPLICATED_SKETCH asks for round 2's form (every rank sketches all targets: lrge_hip_index_build_for)
     shard_targets = not a.inverse and not os.environ.get("LRGE_BENCH_REPLICATED_SKETCH")
+    # ... and since round 4 the default multi-GPU form of the forward strategy shards the TARGETS (lrge_hip_index_build_tsharded): every
+    # rank indexes its share of the targets and maps ALL queries, the count vectors add up in one all-reduce; no index entry crosses a
+    # link.  LRGE_BENCH_FORWARD=qshard selects the query-sharded form of rounds 2-3.
+    forward_mode = os.environ.get("LRGE_BENCH_FORWARD", "tshard")
 
     class Src:
         """One read set of one rank's job: offsets, name ranks, and where its ASCII bases live (HBM; host on request)."""
@@ -410,10 +418,14 @@ def main():
             lo, hi = self.bounds[my], self.bounds[my + 1]
             q_rng = (0, Qn) if (a.inverse or n_shards == 1) else (lo, hi)
             t_rng = (lo, hi) if (a.inverse and n_shards > 1) else (0, Tn)
-            self.sharded = shard_targets and n_shards > 1 and comm is not None
-            if self.sharded:
+            self.tshard = forward_mode == "tshard" and not a.inverse and n_shards > 1 and comm is not None
+            self.sharded = shard_targets and n_shards > 1 and comm is not None and not self.tshard
+            if self.sharded or self.tshard:
                 tb_ = parallel.shard_by_bases(t_lens, n_shards)
                 t_rng = (tb_[my], tb_[my + 1])
+            if self.tshard:
+                q_rng = (0, Qn)
+                self.bounds = tb_
             self.restrict = (comm is not None or emulated_share or bool(os.environ.get("LRGE_BENCH_RESTRICT"))) and not a.inverse
             self.q_rng, self.t_rng = q_rng, t_rng
             self.shard_lens = [self.bounds[i + 1] - self.bounds[i] for i in range(n_shards)]
@@ -461,7 +473,10 @@ def main():
                 Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)      # travels / packs while the index is built
                 if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
                     Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
-                if self.sharded:
+                if self.tshard:
+                    ix = engine.Index(ctx, Td, preset, comm=comm, tshard=True)
+                    self.shard_stats = ix.shard_stats
+                elif self.sharded:
                     ix = engine.Index(ctx, Td, preset, streamed=Qd, comm=comm, shard=(t_lens, tr_all, self.t_rng[0]))
                     self.shard_stats = ix.shard_stats
                 else:
@@ -469,19 +484,23 @@ def main():
                 tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
                 counts, has = ix.overlap_twoset(Qd)
                 tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
-                est = ctx.estimates(counts, self.qs_lens, float(avg_t), Tn, 100)
                 ix.free(); Qd.free(); Td.free()
-                if comm is not None:    # the one collective that closes the step: per-read estimate vectors over RCCL/xGMI
-                    est_all = comm.all_gather_f32(est, self.max_shard, self.shard_lens)
+                if self.tshard:         # the one collective that closes the step: the count vectors over disjoint targets add up
+                    counts = comm.all_reduce_u32(counts)
+                    est_all = ctx.estimates(counts, q_lens, float(avg_t), Tn, 100)
                 else:
-                    est_all = est
+                    est = ctx.estimates(counts, self.qs_lens, float(avg_t), Tn, 100)
+                    if comm is not None:    # the one collective that closes the step: per-read estimate vectors over RCCL/xGMI
+                        est_all = comm.all_gather_f32(est, self.max_shard, self.shard_lens)
+                    else:
+                        est_all = est
             med = engine.median(est_all, True, 0.15, 0.65)
             for k_ in ("rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes"):   # the index build sorts too
                 cn[k_] = cn.get(k_, 0) + cb_.get(k_, 0)
             return counts, est_all, med, tb, tm, cn, st
 
     if a.emulate_world:
-        emulate_world(a, ctx, RankJob, Qn, engine, parallel, local_rank, q_lens, t_lens)
+        emulate_world(a, ctx, RankJob, Qn, engine, parallel, local_rank, q_lens, t_lens, forward_mode)
         ctx.close()
         return
     job = RankJob(ctx, comm, emu[0] if emu else rank, emu[1] if emu else world, local_rank, emulated_share=bool(emu))
@@ -685,13 +704,16 @@ def main():
                        "clock": "host" if clock_host else "resident",
                        "query_reads": Qn, "target_reads": Tn,
                        "parallelism": ("one job, streamed targets cut into %d ranges by bases; query index replicated; counts all-reduced" % world) if a.inverse else
+                                      ("one job, TARGETS cut into %d ranges by bases: every rank indexes its range and maps all queries; occurrence statistics made "
+                                       "global by one all-to-all of (key, count) pairs; the count vectors all-reduced" % world) if job.tshard else
                                       ("one job, queries cut into %d ranges by bases; index %s" %
                                        (world, ("restricted to each rank's query minimizers, global occurrence statistics by one all-reduce" +
                                                 ("; every rank sketches 1/%d of the targets, key sets all-gathered, kept entries and owned hashes by all-to-all" % world if job.sharded else ""))
                                         if world > 1 else "over all targets")),
                        "collectives": transport if use_dist else None,
                        "rccl_ranks": (comm.rccl_ranks() if (comm is not None and hasattr(comm, "rccl_ranks")) else None),
-                       "target_sketch": ("sharded (lrge_hip_index_build_sharded)" if job.sharded else "replicated") if world > 1 and not a.inverse else None,
+                       "target_sketch": ("targets sharded, all queries mapped by every rank (lrge_hip_index_build_tsharded)" if job.tshard else
+                                         "sharded (lrge_hip_index_build_sharded)" if job.sharded else "replicated") if world > 1 and not a.inverse else None,
                        "exchange_per_step_rank0": job.shard_stats,
                        "scale": a.scale, "data_gen_s": round(t_gen, 1)},
             "resident": resident,

@@ -181,6 +181,17 @@ int  lrge_hip_index_build_for(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets,
 int  lrge_hip_index_build_sharded(lrge_hip_ctx *ctx, const uint32_t *all_target_lens, const uint32_t *all_target_ranks,
                                   uint32_t n_targets, const lrge_hip_seqset *target_shard, uint32_t shard_first, int preset,
                                   lrge_hip_seqset *streamed, lrge_hip_comm *comm, lrge_hip_index **out);
+/* The forward strategy over several GPUs with the TARGETS sharded (round 4; replaces, as the default multi-GPU form of
+   twoset.rs:204-367, the query-sharded builds above -- those still stand).  Rank r indexes ITS contiguous share of the target
+   reads (`target_shard`, uploaded on this context) and the caller maps ALL query reads against it with lrge_hip_overlap_twoset:
+   the shards hold disjoint targets, so the per-query counts of the one index (aligner.rs:111-120) are the SUM of the ranks'
+   counts (one lrge_hip_comm_allreduce_u32 of the count vector, and of has_mapping), bit for bit.  What is made global here is
+   what mm_idx_cal_max_occ / mm_mapopt_update see (aligner.rs:189): every rank sends (hash, local count) per distinct key of its
+   table to the hash's owner rank, the owners add up, one small all-reduce yields n_keys / n_minimizers / mid_occ of the whole
+   target set (lrge_hip_index_stats reports those), and the keys above mid_occ are dropped in every rank's table.  No index entry
+   crosses a link.  Collective: every rank of `comm` calls it; a failure on one rank fails it on all. */
+int  lrge_hip_index_build_tsharded(lrge_hip_ctx *ctx, const lrge_hip_seqset *target_shard, int preset, lrge_hip_comm *comm,
+                                   lrge_hip_index **out);
 /* Exchange volumes of the last lrge_hip_index_build_sharded on this context: {key-set bytes contributed, entries sketched here,
    entries sent to other ranks, entries received from other ranks, hashes sent, hashes received, bytes per entry | bytes per hash << 8
    (4 when the hash has at most 32 bits: k = 15), entries kept}. */

@@ -816,6 +816,11 @@ static int index_build_parts(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, 
         for (int i = 0; i < LRGE_C_N; ++i) cn_acc[i] += ctx->counters[i];
     }
     top->P = top->parts[0]->P;
+    if (ctx->ts_build) {       // one rank's shard of a target-sharded build: the statistics are taken over ALL ranks' tables (host_tshard.inl)
+        memcpy(ctx->ms, ms_acc, sizeof ms_acc); memcpy(ctx->counters, cn_acc, sizeof cn_acc);
+        *out = top_guard.release();
+        return LRGE_OK;
+    }
     // ---- global occurrence statistics ----
     ctx->resolve_timers();
     memset(ctx->ms, 0, sizeof(ctx->ms));

@@ -1,0 +1,220 @@
+// host_tshard.inl -- part of lrge_hip.hip (one translation unit; included there, in this order): lrge_hip_index_build_tsharded, the
+// collective index build of the forward strategy with the TARGETS sharded over the ranks (k_tshard.h says why and what travels).
+// ------------------------------------------------------------------------------------------
+// A collective call: the sequence of collectives is fixed, a rank that fails joins the next one in its own shape with the status
+// word set (CollectiveGuard, host_index.inl).
+//   C1 all-gather  u64[W + 1]   pairs this rank sends to every owner, status
+//   A1 agreement                (send / receive buffers taken)
+//   C2 all-to-all  u64          hashes          C3 all-to-all u32 local counts
+//   C4 all-reduce  u64[head+3]  distinct keys, minimizers, head bins of the occurrence histogram, status   -> mid_occ
+//   C5 all-gather  u64[2]       too-frequent keys this rank owns, status
+//   A2 agreement                (room for everybody's list)
+//   C6 all-gather  u64[max]     the lists
+struct TsTable { u64 *ht; u64 cap, slots; };
+
+static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm *c, CollectiveGuard &cg) {
+    const int W = c->world, me = c->rank;
+    hipStream_t st = ctx->stream;
+    const Preset &P = ix->P;
+    Scratch sc(ctx);
+    std::vector<TsTable> tabs;
+    if (ix->parts.empty()) tabs.push_back(TsTable{ix->d_ht, ix->ht_cap, ix->ht_slots});
+    else for (lrge_hip_index *p : ix->parts) tabs.push_back(TsTable{p->d_ht, p->ht_cap, p->ht_slots});
+    const u32 fix = ix->parts.empty() ? ix->ht_fix : ix->parts[0]->ht_fix;
+    u64 local_mz = ix->parts.empty() ? ix->n_mz : 0;
+    if (!ix->parts.empty()) for (lrge_hip_index *p : ix->parts) local_mz += p->n_mz;
+    (void)local_mz;
+    // ---- C1: how many (key, count) pairs go to every owner ----
+    std::vector<u64> mine((size_t)W + 1, 0), matrix(((size_t)W + 1) * (size_t)W, 0);
+    unsigned long long *d_tot = nullptr;
+    auto local1 = [&]() -> int {
+        if (shard_fail_at(ctx, 11)) return LRGE_ERR_DEVICE;
+        d_tot = (unsigned long long *)sc.get<u64>(2 * TS_MAX_WORLD);
+        if (!d_tot) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemsetAsync(d_tot, 0, 2 * TS_MAX_WORLD * 8, st));
+        for (const TsTable &t : tabs)
+            if (t.slots) { hipLaunchKernelGGL(k_ts_count, dim3((u32)std::min<u64>(div_up(t.slots, TS_THREADS), (u64)ctx->n_cu * 16)), dim3(TS_THREADS), 0, st, t.ht, t.slots, (u32)W, d_tot); KCHK(ctx); }
+        std::vector<unsigned long long> h(TS_MAX_WORLD);
+        HIPCHK(ctx, hipMemcpyAsync(h.data(), d_tot, TS_MAX_WORLD * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (int o = 0; o < W; ++o) mine[(size_t)o] = h[(size_t)o];
+        return LRGE_OK;
+    };
+    int rc = local1();
+    const bool failed1 = rc != LRGE_OK;
+    mine[(size_t)W] = failed1 ? 1 : 0;
+    cg.disarm();
+    rc = comm_allgather_host(c, mine.data(), mine.size() * 8, matrix.data(), st); if (rc) return rc;
+    const size_t row = (size_t)W + 1;
+    for (int r = 0; r < W; ++r) if (matrix[(size_t)r * row + W]) { if (!failed1) LRGE_SET_ERR(ctx, "target-sharded index build: rank %d failed", r); return LRGE_ERR_DEVICE; }
+    std::vector<u64> s_off((size_t)W + 1, 0), r_off((size_t)W + 1, 0);
+    for (int d = 0; d < W; ++d) { s_off[(size_t)d + 1] = s_off[(size_t)d] + mine[(size_t)d]; r_off[(size_t)d + 1] = r_off[(size_t)d] + matrix[(size_t)d * row + (size_t)me]; }
+    const u64 n_s = s_off[(size_t)W], n_r = r_off[(size_t)W];
+    const u64 ss[8] = {0, 0, 0, 0, n_s - mine[(size_t)me], n_r - mine[(size_t)me], (u64)8 | (u64)12 << 8, 0};      // (hashes_sent / _recv slots: pairs of 12 bytes)
+    memcpy(ctx->shard_stats, ss, sizeof ss);
+    // ---- A1, C2, C3: the pairs travel ----
+    u64 *sh = nullptr, *rh = nullptr; u32 *scn = nullptr, *rcn = nullptr;
+    cg.expect(CollectiveGuard::AGREE);
+    auto local2 = [&]() -> int {
+        if (shard_fail_at(ctx, 12)) return LRGE_ERR_DEVICE;
+        if (n_r >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "target-sharded index build: this rank owns %llu (key, count) pairs (limit 2^32)", (unsigned long long)n_r); return LRGE_ERR_TOO_MANY; }
+        sh = sc.get<u64>(n_s + 1); scn = sc.get<u32>(n_s + 1); rh = sc.get<u64>(n_r + 1); rcn = sc.get<u32>(n_r + 1);
+        if (!sh || !scn || !rh || !rcn) return LRGE_ERR_DEVICE;
+        std::vector<unsigned long long> cur(TS_MAX_WORLD, 0);
+        for (int o = 0; o < W; ++o) cur[(size_t)o] = s_off[(size_t)o];
+        HIPCHK(ctx, hipMemcpyAsync(d_tot + TS_MAX_WORLD, cur.data(), TS_MAX_WORLD * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));          // (`cur` is a local)
+        for (const TsTable &t : tabs)
+            if (t.slots) { hipLaunchKernelGGL(k_ts_emit, dim3((u32)div_up(t.slots, TS_THREADS * TS_ITEMS)), dim3(TS_THREADS), 0, st, t.ht, t.slots, (u32)W, d_tot + TS_MAX_WORLD, sh, scn); KCHK(ctx); }
+        return LRGE_OK;
+    };
+    rc = local2();
+    cg.disarm();
+    rc = comm_agree(c, rc, st); if (rc) return rc;
+    rc = comm_alltoallv(c, sh, s_off.data(), rh, r_off.data(), 8, st); if (rc) return rc;
+    rc = comm_alltoallv(c, scn, s_off.data(), rcn, r_off.data(), 4, st); if (rc) return rc;
+    // ---- C4: the owner adds the counts up; the statistics of the one index ----
+    const u32 max_bin = (u32)P.max_mid_occ + 1, head = std::min<u32>(4096, max_bin + 1);
+    cg.expect(CollectiveGuard::ALLREDUCE_U64, stats_vec_words(P), stats_vec_words(P) - 1);
+    u64 *rk = nullptr; u32 *starts = nullptr, *d_nr = nullptr, *gcnt = nullptr, *d_hist = nullptr;
+    unsigned long long *d_mz = nullptr;
+    std::vector<u64> hv((size_t)head + 3, 0);
+    {
+        if (shard_fail_at(ctx, 13)) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipStreamSynchronize(st));        // (the offset vectors above are locals)
+        sc.drop(sh); sc.drop(scn);
+        ALLOC_OR_FAIL(k1, sc, u64, n_r + 1); ALLOC_OR_FAIL(v0, sc, u64, n_r + 1); ALLOC_OR_FAIL(v1, sc, u64, n_r + 1);
+        if (n_r) { hipLaunchKernelGGL(k_u32_to_u64, dim3((u32)div_up(n_r, 256)), dim3(256), 0, st, rcn, n_r, v0); KCHK(ctx); }
+        u64 *rv = nullptr;
+        rc = radix_sort_pairs(ctx, sc, rh, v0, k1, v1, n_r, 0, 2 * P.k, &rk, &rv); if (rc) return rc;
+        starts = sc.get<u32>(n_r + 2); d_nr = sc.get<u32>(1); gcnt = sc.get<u32>(n_r + 1); d_hist = sc.get<u32>((size_t)max_bin + 2);
+        d_mz = (unsigned long long *)sc.get<u64>(1);
+        if (!starts || !d_nr || !gcnt || !d_hist || !d_mz) return LRGE_ERR_DEVICE;
+        rc = compact_heads_async(ctx, sc, rk, n_r, 0, starts, d_nr); if (rc) return rc;
+        HIPCHK(ctx, hipMemsetAsync(d_hist, 0, ((size_t)max_bin + 2) * 4, st));
+        HIPCHK(ctx, hipMemsetAsync(d_mz, 0, 8, st));
+        if (n_r) {
+            hipLaunchKernelGGL(k_ts_reduce, dim3((u32)std::min<u64>(div_up(n_r, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, st, rv, starts, d_nr, n_r, gcnt, d_hist, max_bin, d_mz);
+            KCHK(ctx);
+        } else HIPCHK(ctx, hipMemsetAsync(d_nr, 0, 4, st));
+        u32 h_nr = 0; unsigned long long h_mz = 0;
+        std::vector<u32> hb(head);
+        HIPCHK(ctx, hipMemcpyAsync(&h_nr, d_nr, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(&h_mz, d_mz, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(hb.data(), d_hist, (size_t)head * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        hv[0] = h_nr; hv[1] = h_mz;
+        for (u32 b = 0; b < head; ++b) hv[2 + (size_t)b] = hb[b];
+    }
+    cg.disarm();
+    rc = comm_allreduce_sum_host(c, hv.data(), hv.size(), 8, st); if (rc) return rc;
+    if (hv[(size_t)head + 2]) { LRGE_SET_ERR(ctx, "target-sharded index build: %llu other rank(s) failed", (unsigned long long)hv[(size_t)head + 2]); return LRGE_ERR_DEVICE; }
+    const u64 g_distinct = hv[0], g_mz = hv[1];
+    int thres = INT32_MAX;
+    if (g_distinct) {      // mm_idx_cal_max_occ + the clamps of mm_mapopt_update, over the distinct keys of ALL targets (index_build_one's arithmetic)
+        const u64 kth = (u64)((1. - (double)P.mid_occ_frac) * (double)g_distinct);
+        u64 cum = 0; u32 v = max_bin; bool found = false;
+        for (u32 b = 0; b < head; ++b) { cum += hv[2 + (size_t)b]; if (cum > kth) { v = b; found = true; break; } }
+        if (!found && head < max_bin + 1) {      // beyond the head bins: the whole histogram travels (every rank takes this branch or none)
+            cg.expect(CollectiveGuard::AGREE);
+            u64 *d_full = sc.get<u64>((size_t)max_bin + 1);
+            int arc = d_full ? LRGE_OK : LRGE_ERR_DEVICE;
+            if (d_full) { hipLaunchKernelGGL(k_u32_to_u64, dim3((u32)div_up((u64)max_bin + 1, 256)), dim3(256), 0, st, d_hist, (u64)max_bin + 1, d_full); if (hipGetLastError() != hipSuccess) arc = LRGE_ERR_DEVICE; }
+            cg.disarm();
+            rc = comm_agree(c, arc, st); if (rc) return rc;
+            rc = comm_allreduce_sum(c, d_full, (size_t)max_bin + 1, 8, st); if (rc) return rc;
+            std::vector<u64> full((size_t)max_bin + 1);
+            HIPCHK(ctx, hipMemcpyAsync(full.data(), d_full, full.size() * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            cum = 0;
+            for (u32 b = 0; b <= max_bin; ++b) { cum += full[b]; if (cum > kth) { v = b; break; } }
+        }
+        thres = (int)v + 1;
+    }
+    if (thres < P.min_mid_occ) thres = P.min_mid_occ;
+    if (P.max_mid_occ > P.min_mid_occ && thres > P.max_mid_occ) thres = P.max_mid_occ;
+    const u32 mid_occ = (u32)thres;
+    // ---- C5, A2, C6: the too-frequent keys go to everybody ----
+    const u32 cap_list = 1u << 22;
+    u64 *d_list = nullptr; u32 *d_nf = nullptr;
+    std::vector<u64> mine2(2, 0), all2((size_t)2 * W, 0);
+    cg.expect(CollectiveGuard::ALLGATHER_U64, 2, 1);
+    auto local3 = [&]() -> int {
+        if (shard_fail_at(ctx, 14)) return LRGE_ERR_DEVICE;
+        d_list = sc.get<u64>(cap_list); d_nf = sc.get<u32>(TS_MAX_WORLD + 1);
+        if (!d_list || !d_nf) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipMemsetAsync(d_nf, 0, 4, st));
+        if (n_r) { hipLaunchKernelGGL(k_ts_frequent, dim3((u32)div_up(n_r, 256)), dim3(256), 0, st, rk, starts, d_nr, gcnt, mid_occ, d_list, cap_list, d_nf); KCHK(ctx); }
+        u32 nf = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&nf, d_nf, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (nf > cap_list) { LRGE_SET_ERR(ctx, "target-sharded index build: %u too-frequent keys on one rank (limit %u)", nf, cap_list); return LRGE_ERR_TOO_MANY; }
+        mine2[0] = nf;
+        return LRGE_OK;
+    };
+    rc = local3();
+    const bool failed3 = rc != LRGE_OK;
+    mine2[1] = failed3 ? 1 : 0;
+    cg.disarm();
+    rc = comm_allgather_host(c, mine2.data(), 16, all2.data(), st); if (rc) return rc;
+    u64 max_nf = 0;
+    for (int r = 0; r < W; ++r) {
+        if (all2[(size_t)2 * r + 1]) { if (!failed3) LRGE_SET_ERR(ctx, "target-sharded index build: rank %d failed", r); return LRGE_ERR_DEVICE; }
+        max_nf = std::max(max_nf, all2[(size_t)2 * r]);
+    }
+    if (max_nf) {
+        cg.expect(CollectiveGuard::AGREE);
+        u64 *d_all = sc.get<u64>(max_nf * (u64)W);
+        std::vector<u32> nof(TS_MAX_WORLD, 0);
+        for (int r = 0; r < W; ++r) nof[(size_t)r] = (u32)all2[(size_t)2 * r];
+        int arc = d_all ? LRGE_OK : LRGE_ERR_DEVICE;
+        if (d_all && hipMemcpyAsync(d_nf + 1, nof.data(), TS_MAX_WORLD * 4, hipMemcpyHostToDevice, st) != hipSuccess) arc = LRGE_ERR_DEVICE;
+        if (d_all && hipStreamSynchronize(st) != hipSuccess) arc = LRGE_ERR_DEVICE;
+        if (shard_fail_at(ctx, 15)) arc = LRGE_ERR_DEVICE;
+        cg.disarm();
+        rc = comm_agree(c, arc, st); if (rc) return rc;
+        rc = comm_allgather(c, d_list, max_nf * 8, d_all, st); if (rc) return rc;
+        for (const TsTable &t : tabs) {
+            hipLaunchKernelGGL(k_ts_mark, dim3((u32)div_up(max_nf, 256), (u32)W), dim3(256), 0, st, t.ht, t.cap, fix, d_all, d_nf + 1, (u32)W, (u32)max_nf, mid_occ);
+            KCHK(ctx);
+        }
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    ix->mid_occ = (int)mid_occ; ix->n_keys = g_distinct; ix->n_mz = g_mz;
+    for (lrge_hip_index *p : ix->parts) p->mid_occ = (int)mid_occ;
+    return LRGE_OK;
+}
+
+extern "C" int lrge_hip_index_build_tsharded(lrge_hip_ctx *ctx, const lrge_hip_seqset *target_shard, int preset, lrge_hip_comm *comm, lrge_hip_index **out) {
+    if (!ctx || !target_shard || !comm || !out) return LRGE_ERR_INVALID;
+    *out = nullptr;
+    // (argument errors are rank-local by nature -- every rank passes the same job -- so they return before any collective)
+    if (preset != LRGE_PRESET_AVA_ONT && preset != LRGE_PRESET_AVA_PB) { LRGE_SET_ERR(ctx, "Preset not found: %d", preset); return LRGE_ERR_INVALID; }
+    if (target_shard->ctx != ctx || comm->ctx != ctx) { LRGE_SET_ERR(ctx, "index_build_tsharded: set / communicator belong to another context"); return LRGE_ERR_INVALID; }
+    if (comm->world > TS_MAX_WORLD) { LRGE_SET_ERR(ctx, "index_build_tsharded: at most %d ranks", TS_MAX_WORLD); return LRGE_ERR_INVALID; }
+    // from here on a failure is owed to the build's first collective: the (world + 1)-word counts all-gather
+    CollectiveGuard cg{comm, ctx->stream};
+    cg.expect(CollectiveGuard::ALLGATHER_U64, (size_t)comm->world + 1, (size_t)comm->world);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (shard_fail_at(ctx, 10)) return LRGE_ERR_DEVICE;
+    lrge_hip_index *ix = nullptr;
+    ctx->ts_build = true;                         // (a partitioned local index leaves its occurrence statistics to ts_global_stats)
+    int rc = lrge_hip_index_build(ctx, target_shard, preset, &ix);
+    ctx->ts_build = false;
+    if (rc) return rc;
+    IndexGuard g(ix);
+    float ms_keep[LRGE_T_N]; u64 cn_keep[LRGE_C_N];
+    memcpy(ms_keep, ctx->ms, sizeof ms_keep); memcpy(cn_keep, ctx->counters, sizeof cn_keep);
+    hipEvent_t e0 = ctx->get_event(), e1 = ctx->get_event();
+    (void)hipEventRecord(e0, ctx->stream);
+    rc = ts_global_stats(ctx, ix, comm, cg);
+    (void)hipEventRecord(e1, ctx->stream);
+    if (rc) { ctx->event_pool.push_back(e0); ctx->event_pool.push_back(e1); return rc; }
+    (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    ctx->event_pool.push_back(e0); ctx->event_pool.push_back(e1);
+    memcpy(ctx->ms, ms_keep, sizeof ms_keep); memcpy(ctx->counters, cn_keep, sizeof cn_keep);
+    ctx->ms[LRGE_T_INDEX_RESTRICT] += ms; ctx->ms[LRGE_T_TOTAL] += ms;
+    *out = g.release();
+    return LRGE_OK;
+}

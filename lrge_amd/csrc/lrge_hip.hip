@@ -23,6 +23,7 @@
 #include "host_pack.h"
 #include "k_restrict.h"
 #include "k_route.h"
+#include "k_tshard.h"
 #include "../../include/lrge_rand.hpp"
 
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
@@ -204,6 +205,7 @@ extern "C" int lrge_hip_last_counters(const lrge_hip_ctx *ctx, uint64_t c[LRGE_C
 #include "host_seqset.inl"
 #include "host_sketch.inl"
 #include "host_index.inl"
+#include "host_tshard.inl"
 #include "host_overlap.inl"
 #include "host_comm.inl"
 #include "host_estimate.inl"

@@ -187,11 +187,25 @@ class SeqSet:
 class Index:
     """AlignerWrapper::new(target_file, threads, preset, dual) -- aligner.rs:310-328."""
 
-    def __init__(self, ctx, targets, preset=_ffi.PRESET_AVA_ONT, streamed=None, comm=None, shard=None):
+    def __init__(self, ctx, targets, preset=_ffi.PRESET_AVA_ONT, streamed=None, comm=None, shard=None, tshard=False):
         """shard = (all_target_lens, all_target_ranks or None, shard_first): `targets` is this rank's contiguous share of the
-        target reads and the build is the collective lrge_hip_index_build_sharded (the target sketch is sharded too)."""
+        target reads and the build is the collective lrge_hip_index_build_sharded (the target sketch is sharded too).
+        tshard (with comm): `targets` is this rank's share of the target reads and the index holds ALL of its entries, with the
+        occurrence statistics of the whole target set (lrge_hip_index_build_tsharded): the caller maps ALL queries against it
+        and sums the counts over the ranks."""
         self.ctx, self.targets, self.preset = ctx, targets, preset
         h = C.c_void_p()
+        if tshard:
+            self.streamed = None
+            ctx._check(ctx._lib.lrge_hip_index_build_tsharded(ctx.h, targets.h, preset, comm.h, C.byref(h)))
+            self.h = h
+            self.build_timings = ctx.timings()
+            self.build_counters = ctx.counters()
+            a = (C.c_uint64 * 8)()
+            ctx._lib.lrge_hip_last_shard_stats(ctx.h, C.byref(a))
+            self.shard_stats = dict(keyset_bytes=0, entries_sketched=0, entries_sent=0, entries_recv=0, hashes_sent=int(a[4]), hashes_recv=int(a[5]),
+                                    entry_bytes=8, entries_kept=0, hash_bytes=12)      # (hashes_*: (key, count) pairs of 12 bytes)
+            return
         if shard is not None:
             lens = np.ascontiguousarray(shard[0], dtype=np.uint32)
             ranks = None if shard[1] is None else np.ascontiguousarray(shard[1], dtype=np.uint32)

@@ -90,7 +90,18 @@ def _run_world(world, ds, preset, mode):
             c = engine.Context(0)
             comm = grp.comm(c, r)
             lo, hi = bounds[r], bounds[r + 1]
-            if mode in ("twoset", "sharded"):   # forward: targets indexed (restricted per rank), this rank's queries streamed
+            if mode == "tshard":       # forward with the TARGETS sharded: every rank maps ALL queries against its share; counts add up
+                t0, t1 = tb[r], tb[r + 1]
+                tsub = ds.t.slice(t0, t1)
+                Td = c.upload(tsub.bases, tsub.offsets, tr[t0:t1])
+                Qd = c.upload(ds.q.bases, ds.q.offsets, qr)
+                ix = engine.Index(c, Td, preset, comm=comm, tshard=True)
+                shard_stats.append(ix.shard_stats)
+                counts, has = ix.overlap_twoset(Qd)
+                counts = comm.all_reduce_u32(counts); has = (comm.all_reduce_u32(has) > 0).astype(np.uint32)
+                est = c.estimates(counts, ds.q.lens(), float(avg_t), ds.t.n, 100)
+                out[r] = (counts, has, ix.stats(), est)
+            elif mode in ("twoset", "sharded"):   # forward: targets indexed (restricted per rank), this rank's queries streamed
                 sub = ds.q.slice(lo, hi)
                 Qd = c.upload(sub.bases, sub.offsets, qr[lo:hi])
                 if mode == "sharded":      # ... and every rank sketches only its own share of the targets
@@ -175,6 +186,51 @@ def test_world_of_threads_sharded_target_sketch(ctx, tiny_ont, tiny_hifi, preset
     ss = _run_world.shard_stats
     assert len(ss) == world and sum(x["entries_sketched"] for x in ss) == st["n_minimizers"]      # every target minimizer sketched exactly once
     assert sum(x["entries_sent"] for x in ss) == sum(x["entries_recv"] for x in ss) and sum(x["hashes_sent"] for x in ss) == sum(x["hashes_recv"] for x in ss)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("layout", ["packed", "pairs", "parts"])
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_world_of_threads_target_sharded(ctx, tiny_ont, tiny_hifi, preset, layout, world, monkeypatch):
+    """lrge_hip_index_build_tsharded (round 4): every rank indexes ITS share of the targets and maps ALL queries; the count vectors
+    add up to the single-GPU ones (disjoint targets), has_mapping is their OR, and the index statistics every rank reports --
+    n_minimizers, n_keys, mid_occ: what mm_idx_cal_max_occ sees -- are those of the ONE index over all targets.  Worlds of 2, 3
+    and 8 threads on one GPU, both presets, both entry layouts, and local indexes that are themselves partitioned (parts of a
+    rank's share: their keys reach the owners once per part)."""
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    if layout == "pairs":
+        monkeypatch.setenv("LRGE_HIP_NO_PACKED_INDEX", "1")       # (read when the ranks' contexts are created)
+    if layout == "parts":
+        monkeypatch.setenv("LRGE_HIP_PART_BASES", str(int(ds.t.lens().sum()) // (world * 3)))
+    Qd, Td, counts, has, st = _single(ctx, ds, PRESETS[preset])
+    avg_t = np.float32(ds.t.lens().sum()) / np.float32(ds.t.n)
+    est = ctx.estimates(counts, ds.q.lens(), float(avg_t), ds.t.n, 100)
+    out, _ = _run_world(world, ds, PRESETS[preset], "tshard")
+    for r, (c, h, s, e) in enumerate(out):
+        assert s == st, (r, s, st)
+        assert np.array_equal(c, counts) and np.array_equal(h, has)
+        assert np.array_equal(e.view(np.uint32), est.view(np.uint32))
+    ss = _run_world.shard_stats
+    assert len(ss) == world and sum(x["hashes_sent"] for x in ss) == sum(x["hashes_recv"] for x in ss)
+
+
+def test_target_sharded_global_mid_occ_matters(ctx, oracle, monkeypatch):
+    """A repeat-rich target set cut over 3 ranks: a key is dropped by its count over ALL targets (the one index's mid_occ), not by
+    its count in a rank's share -- the summed counts equal the oracle's, and the shares' own thresholds would not have done."""
+    from lrge_amd import synth
+    _, q, t = synth.make_config("c2_repeats", 0.04)
+
+    class DS:
+        pass
+    ds = DS(); ds.q, ds.t = q, t
+    Qd, Td, counts, has, st = _single(ctx, ds, 0)
+    opt = oracle.make_opt(oracle.PRESET_AVA_ONT, dual=True)
+    ixo = oracle.Index(oracle.ReadSet(t.seqs(), t.names), opt)
+    rc, ec, eh = ixo.twoset_counts(oracle.ReadSet(q.seqs(), q.names), threads=8)
+    assert rc == 0 and np.array_equal(counts, ec) and st["mid_occ"] == ixo.mid_occ
+    out, _ = _run_world(3, ds, 0, "tshard")
+    for c, h, s, e in out:
+        assert s == st and np.array_equal(c, ec) and np.array_equal(h, eh)
 
 
 def test_alltoallv_behind_the_abi(ctx):
@@ -330,6 +386,55 @@ def test_a_failing_rank_fails_the_sharded_build_on_every_transport(ctx, tiny_ont
         grp = make()
         res, _ = _sharded_world_over(grp, world, tiny_ont, 0, fail=(bad_rank, stage), replicated=replicated)
         assert all(isinstance(x, str) and x.startswith("error") for x in res), res
+        if isinstance(grp, parallel.ThreadHostGroup):
+            assert not grp.faults, grp.faults
+            assert grp.log[0] == grp.log[1] == grp.log[2], grp.log
+        grp.close()
+
+
+@pytest.mark.parametrize("stage", [10, 11, 12, 13, 14, 15, "alloc"])
+@pytest.mark.parametrize("bad_rank", [0, 2])
+def test_a_failing_rank_fails_the_target_sharded_build(ctx, tiny_ont, stage, bad_rank):
+    """The same contract for lrge_hip_index_build_tsharded: a rank failing before the local build, in the counting pass, at the
+    exchange buffers, in front of the statistics, at the list of too-frequent keys or its gathering joins the next collective in
+    its shape with the status word set -- over the strict host-callback transport and the local one every rank gets an error,
+    nobody hangs, no mismatched collective, the same sequence of collectives on every rank."""
+    from lrge_amd import _ffi, engine, parallel
+    ds, world = tiny_ont, 3
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    tb = parallel.shard_by_bases(ds.t.lens(), world)
+    for make in (lambda: parallel.ThreadHostGroup(world, timeout=60.0), lambda: parallel.LocalGroup(world)):
+        grp = make()
+        res = [None] * world
+
+        def rank_main(r):
+            c = engine.Context(0)
+            comm = grp.comm(c, r)
+            try:
+                tsub = ds.t.slice(tb[r], tb[r + 1])
+                Td = c.upload(tsub.bases, tsub.offsets, tr[tb[r]:tb[r + 1]])
+                if r == bad_rank:
+                    if stage == "alloc":
+                        c.set_option("DEBUG_ALLOC_FAIL_ALWAYS", "1")
+                    else:
+                        c.set_option("DEBUG_SHARD_FAIL_AT", str(stage))
+                engine.Index(c, Td, 0, comm=comm, tshard=True)
+                res[r] = "built"
+            except _ffi.LrgeHipError as e:
+                res[r] = "error: %s" % e
+            finally:
+                c.set_option("DEBUG_ALLOC_FAIL_ALWAYS", None); c.set_option("DEBUG_SHARD_FAIL_AT", None)
+                comm.close(); c.close()
+        th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=180)
+        assert all(not t.is_alive() for t in th), "a rank is still blocked in a collective"
+        if stage == 15 and all(x == "built" for x in res):
+            pass       # (stage 15 only exists when some key is too frequent: clean tiny data has none -- nothing was injected)
+        else:
+            assert all(isinstance(x, str) and x.startswith("error") for x in res), res
         if isinstance(grp, parallel.ThreadHostGroup):
             assert not grp.faults, grp.faults
             assert grp.log[0] == grp.log[1] == grp.log[2], grp.log

@@ -233,7 +233,7 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
         try:
             c = engine.Context(device)
             if big:
-                c.set_option("POOL_SEG_MAX_MB", "4096")
+                c.set_option("POOL_SEG_MAX_MB", "256")      # (every large array gets a segment of its own: what a waiting rank keeps is what it uses)
             comm = grp.comm(c, r)
             comm.turn(True)
             job = RankJob(c, comm, r, N, device)
@@ -269,8 +269,14 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
     for t_ in th:
         t_.start()
     deadline = time.perf_counter() + float(os.environ.get("LRGE_BENCH_EMULATE_TIMEOUT", "240"))
-    for t_ in th:
-        t_.join(timeout=max(1.0, deadline - time.perf_counter()))
+    t_err = None
+    while any(t_.is_alive() for t_ in th) and time.perf_counter() < deadline:
+        for t_ in th:
+            t_.join(timeout=0.5)
+        if errs and t_err is None:
+            t_err = time.perf_counter()
+        if t_err is not None and time.perf_counter() - t_err > 15.0:      # a rank has failed: the others may be waiting for it for ever
+            break
     if errs or any(t_.is_alive() for t_ in th):
         print(json.dumps({"emulate_world": N, "errors": errs, "ranks_still_running": sum(t_.is_alive() for t_ in th)}))
         sys.stdout.flush()
@@ -473,6 +479,12 @@ def main():
                 Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)      # travels / packs while the index is built
                 if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
                     Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
+                _tr = os.environ.get("LRGE_BENCH_TRACE") and self.my == 0 and comm is not None
+
+                def _busy():        # (trace only) flush the turn so that busy_ms is current
+                    comm.turn(False); b = comm.busy_ms(); comm.turn(True); return b
+                _b0 = _busy() if _tr else 0.0
+                _t0 = time.perf_counter()
                 if self.tshard:
                     ix = engine.Index(ctx, Td, preset, comm=comm, tshard=True)
                     self.shard_stats = ix.shard_stats
@@ -482,12 +494,21 @@ def main():
                 else:
                     ix = engine.Index(ctx, Td, preset, streamed=Qd if self.restrict else None, comm=comm)
                 tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
+                _t1 = time.perf_counter()
+                _b1 = _busy() if _tr else 0.0
                 counts, has = ix.overlap_twoset(Qd)
+                _t2 = time.perf_counter()
+                _b2 = _busy() if _tr else 0.0
                 tm = ctx.timings(); cn = ctx.counters(); st = ix.stats()
                 ix.free(); Qd.free(); Td.free()
+                _t3 = time.perf_counter()
                 if self.tshard:         # the one collective that closes the step: the count vectors over disjoint targets add up
                     counts = comm.all_reduce_u32(counts)
                     est_all = ctx.estimates(counts, q_lens, float(avg_t), Tn, 100)
+                    if _tr:
+                        _b3 = _busy()
+                        sys.stderr.write("[trace rank 0] busy: up to the uploads %.2f | index build %.2f | overlap %.2f | all-reduce + estimates %.2f ms;  wall: index %.2f overlap %.2f rest %.2f\n"
+                                         % (_b0, _b1 - _b0, _b2 - _b1, _b3 - _b2, (_t1 - _t0) * 1e3, (_t2 - _t1) * 1e3, (time.perf_counter() - _t3) * 1e3))
                 else:
                     est = ctx.estimates(counts, self.qs_lens, float(avg_t), Tn, 100)
                     if comm is not None:    # the one collective that closes the step: per-read estimate vectors over RCCL/xGMI

@@ -24,6 +24,15 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
     u64 local_mz = ix->parts.empty() ? ix->n_mz : 0;
     if (!ix->parts.empty()) for (lrge_hip_index *p : ix->parts) local_mz += p->n_mz;
     (void)local_mz;
+    // option VERBOSE: time this rank spent in each phase, the waits for the other ranks (local transport) taken out
+    double t_mark = DevPool::now_ms(), w_mark = c->wait_ms;
+    auto mark = [&](const char *what) {
+        if (!ctx->opt("VERBOSE")) return;
+        (void)hipStreamSynchronize(st);
+        const double now = DevPool::now_ms();
+        fprintf(stderr, "[lrge_hip] rank %d target-sharded build: %-28s %7.3f ms (+ %.3f ms waiting)\n", me, what, (now - t_mark) - (c->wait_ms - w_mark), c->wait_ms - w_mark);
+        t_mark = now; w_mark = c->wait_ms;
+    };
     // ---- C1: how many (key, count) pairs go to every owner ----
     std::vector<u64> mine((size_t)W + 1, 0), matrix(((size_t)W + 1) * (size_t)W, 0);
     unsigned long long *d_tot = nullptr;
@@ -41,6 +50,7 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
         return LRGE_OK;
     };
     int rc = local1();
+    mark("pair counts");
     const bool failed1 = rc != LRGE_OK;
     mine[(size_t)W] = failed1 ? 1 : 0;
     cg.disarm();
@@ -69,10 +79,12 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
         return LRGE_OK;
     };
     rc = local2();
+    mark("pair emit");
     cg.disarm();
     rc = comm_agree(c, rc, st); if (rc) return rc;
     rc = comm_alltoallv(c, sh, s_off.data(), rh, r_off.data(), 8, st); if (rc) return rc;
     rc = comm_alltoallv(c, scn, s_off.data(), rcn, r_off.data(), 4, st); if (rc) return rc;
+    mark("all-to-alls");
     // ---- C4: the owner adds the counts up; the statistics of the one index ----
     const u32 max_bin = (u32)P.max_mid_occ + 1, head = std::min<u32>(4096, max_bin + 1);
     cg.expect(CollectiveGuard::ALLREDUCE_U64, stats_vec_words(P), stats_vec_words(P) - 1);
@@ -106,8 +118,10 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
         hv[0] = h_nr; hv[1] = h_mz;
         for (u32 b = 0; b < head; ++b) hv[2 + (size_t)b] = hb[b];
     }
+    mark("owner: sort + reduce");
     cg.disarm();
     rc = comm_allreduce_sum_host(c, hv.data(), hv.size(), 8, st); if (rc) return rc;
+    mark("statistics all-reduce");
     if (hv[(size_t)head + 2]) { LRGE_SET_ERR(ctx, "target-sharded index build: %llu other rank(s) failed", (unsigned long long)hv[(size_t)head + 2]); return LRGE_ERR_DEVICE; }
     const u64 g_distinct = hv[0], g_mz = hv[1];
     int thres = INT32_MAX;
@@ -180,6 +194,7 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
         }
     }
     HIPCHK(ctx, hipStreamSynchronize(st));
+    mark("frequent keys + marking");
     ix->mid_occ = (int)mid_occ; ix->n_keys = g_distinct; ix->n_mz = g_mz;
     for (lrge_hip_index *p : ix->parts) p->mid_occ = (int)mid_occ;
     return LRGE_OK;

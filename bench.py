@@ -200,15 +200,30 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
     import threading
     N = a.emulate_world
     # the one-GPU job first: the reference time and the reference results
+    # clock: as `value` -- the ASCII reads in pinned host memory (a rank's host-side pack and PCIe transfer are part of its busy time),
+    # or resident in HBM with --clock resident
+    from_host = a.clock == "host"
+
+    def sources(job):
+        """-> (src_q, src_t, release): what job.step takes"""
+        if not from_host:
+            return job.qs.ptr, job.ts.ptr, (lambda: None)
+        hq = job.ctx.host_alloc(max(job.qs.nbytes, 1)); ht = job.ctx.host_alloc(max(job.ts.nbytes, 1))
+        hq.array[:job.qs.nbytes] = job.qs.host(); ht.array[:job.ts.nbytes] = job.ts.host()
+        if hasattr(job.qs, "dev"):          # (counter-based generator: the resident copies make room)
+            job.qs.dev.free(); job.ts.dev.free()
+        return hq, ht, (lambda: (hq.free(), ht.free()))
     one = RankJob(ctx0, None, 0, 1, device)
+    sq, st_, rel = sources(one)
     for _ in range(max(1, a.warmup)):
-        one.step(one.qs.ptr, one.ts.ptr)
+        one.step(sq, st_)
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        ref = one.step(one.qs.ptr, one.ts.ptr)
+        ref = one.step(sq, st_)
     t_one = (time.perf_counter() - t0) * 1e3 / a.steps
     ref_counts, ref_est, ref_med, _, _, _, ref_st = ref
-    if hasattr(one.qs, "dev"):
+    rel()
+    if hasattr(one.qs, "dev") and one.qs.dev.ptr:
         one.qs.dev.free(); one.ts.dev.free()
     one.qs = one.ts = None
     # the one-GPU job's context goes now: its arena holds most of the HBM (segments are kept until the context dies), and the ranks'
@@ -237,13 +252,14 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
             comm = grp.comm(c, r)
             comm.turn(True)
             job = RankJob(c, comm, r, N, device)
+            src_q, src_t, release = sources(job)
             sys.stderr.write("[emulate-world] rank %d holds its reads: %s\n" % (r, free_gb()))
             comm.turn(False)
             for it in range(max(1, a.warmup) + a.steps):
                 if it == max(1, a.warmup):
                     comm.busy_ms(reset=True)
                 comm.turn(True)
-                out = job.step(job.qs.ptr, job.ts.ptr)
+                out = job.step(src_q, src_t)
                 comm.turn(False)
             busy = comm.busy_ms() / a.steps
             counts, est_all, med, tb, tm, cn, st = out
@@ -257,6 +273,7 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
                               estimates_equal=bool(np.array_equal(est_all.view(np.uint32), ref_est.view(np.uint32))))
             res[r] = dict(rank=r, busy_ms_per_step=busy, results_equal_one_gpu=ok, mismatch=detail, streamed_reads_of_rank=hi - lo, shard=job.shard_stats,
                           stage_ms={**{"index_" + k: round(v, 3) for k, v in tb.items() if v and k != "total"}, **{k: round(v, 3) for k, v in tm.items() if v}})
+            release()
             comm.close(); c.close()
         except Exception as e:      # noqa: BLE001 -- reported below
             errs.append((r, repr(e)))
@@ -300,6 +317,7 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
         link_ms = {"count_allreduce_ring_ms": 2.0 * (N - 1) / N * vec / (XGMI_LINK_GBPS * 1e9) * 1e3, "per_link_GBps": XGMI_LINK_GBPS,
                    "keyset_allgather_ring_ms": 0.0, "alltoall_ms": 0.0, "note": "one ring all-reduce of %d bytes; latency-bound in practice (~0.1 ms)" % int(vec)}
     print(json.dumps({"emulate_world": N, "NOT_A_BENCH_RESULT": "all ranks on one GPU, taking turns; a projection input", "config": a.config,
+                      "clock": "host (ASCII reads in pinned host memory: a rank's host-side pack and PCIe transfer are inside its busy time)" if from_host else "resident",
                       "strategy": "inverse (--use-min-ref: index = queries, replicated; streamed targets cut by bases)" if a.inverse else
                                   ("forward, TARGETS sharded (lrge_hip_index_build_tsharded): every rank maps all queries against its share, counts all-reduced" if forward_mode == "tshard"
                                    else "forward, queries sharded (target sketch sharded, restricted index per rank)"),

@@ -241,6 +241,8 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
     sys.stderr.write("[emulate-world] reference context closed: %s\n" % free_gb())
     grp = parallel.LocalGroup(N)
     big = float(q_lens_all.sum() + t_lens_all.sum()) > 5e9
+    if big:     # a presketch keeps worst-case buffers (16 B per streamed base) across the build's collectives: N of them do not fit one GPU
+        os.environ["LRGE_BENCH_NO_PRESKETCH"] = "1"
     grp.serialize(2 if big else True)      # big jobs: N arenas sized for a GPU each do not fit one GPU -- idle segments go back between turns (allocator time is kept out of busy_ms)
     res, errs = [None] * N, []
 
@@ -249,6 +251,7 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
             c = engine.Context(device)
             if big:
                 c.set_option("POOL_SEG_MAX_MB", "256")      # (every large array gets a segment of its own: what a waiting rank keeps is what it uses)
+                c.set_option("HT_SLOTS_X100", "125")        # (N resident tables on one GPU: the load a part of a partitioned index runs at)
             comm = grp.comm(c, r)
             comm.turn(True)
             job = RankJob(c, comm, r, N, device)
@@ -427,7 +430,13 @@ def main():
     # ... and since round 4 the default multi-GPU form of the forward strategy shards the TARGETS (lrge_hip_index_build_tsharded): every
     # rank indexes its share of the targets and maps ALL queries, the count vectors add up in one all-reduce; no index entry crosses a
     # link.  LRGE_BENCH_FORWARD=qshard selects the query-sharded form of rounds 2-3.
-    forward_mode = os.environ.get("LRGE_BENCH_FORWARD", "tshard")
+    forward_mode = os.environ.get("LRGE_BENCH_FORWARD", "auto")
+    if forward_mode == "auto":
+        # every rank of the target-sharded form sketches and looks up ALL queries: it pays when that redundant work is small against a
+        # rank's share of the index build -- query bases x ranks <= target bases (H. sapiens scale: 1.5 G x 8 against 30 G: 5.2x at 8
+        # ranks against 3.3x query-sharded; C4: 0.36 G x 8 against 0.72 G: 1.7x against 2.3x the other way round)
+        n_ranks = max(world, a.emulate_world or 1)
+        forward_mode = "tshard" if float(q_lens.sum()) * n_ranks <= float(t_lens.sum()) else "qshard"
 
     class Src:
         """One read set of one rank's job: offsets, name ranks, and where its ASCII bases live (HBM; host on request)."""

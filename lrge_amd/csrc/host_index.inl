@@ -584,6 +584,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         // a part of a partitioned index (a target set of tens of gigabases) gets 1.25 instead of 2 slots per key: the
         // tables of all parts are resident together and memory, not probe length (+15 % lookup time), is what binds there
         u64 cap = targets->is_view ? (u64)n_runs * 5 / 4 : (u64)n_runs * HT_CAP_NUM / HT_CAP_DEN;
+        if (const char *o = ctx->opt("HT_SLOTS_X100")) cap = (u64)n_runs * std::max<u64>(110, strtoull(o, nullptr, 10)) / 100;    // (several contexts sharing one GPU: memory binds there too)
         if (cap < 1024) cap = 1024;
         if (cap + n_runs >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32/3 distinct minimizers (got %u)", n_runs); return LRGE_ERR_TOO_MANY; }
         ix->ht_cap = cap; ix->ht_fix = ht_fix;

@@ -97,8 +97,10 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
         sc.drop(sh); sc.drop(scn);
         ALLOC_OR_FAIL(k1, sc, u64, n_r + 1); ALLOC_OR_FAIL(v0, sc, u64, n_r + 1); ALLOC_OR_FAIL(v1, sc, u64, n_r + 1);
         if (n_r) { hipLaunchKernelGGL(k_u32_to_u64, dim3((u32)div_up(n_r, 256)), dim3(256), 0, st, rcn, n_r, v0); KCHK(ctx); }
+        sc.drop(rcn); rcn = nullptr;
         u64 *rv = nullptr;
         rc = radix_sort_pairs(ctx, sc, rh, v0, k1, v1, n_r, 0, 2 * P.k, &rk, &rv); if (rc) return rc;
+        sc.drop(rk == rh ? k1 : rh); sc.drop(rv == v0 ? v1 : v0);          // (the other halves of the ping-pong: recycled in stream order)
         starts = sc.get<u32>(n_r + 2); d_nr = sc.get<u32>(1); gcnt = sc.get<u32>(n_r + 1); d_hist = sc.get<u32>((size_t)max_bin + 2);
         d_mz = (unsigned long long *)sc.get<u64>(1);
         if (!starts || !d_nr || !gcnt || !d_hist || !d_mz) return LRGE_ERR_DEVICE;
@@ -109,6 +111,7 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
             hipLaunchKernelGGL(k_ts_reduce, dim3((u32)std::min<u64>(div_up(n_r, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, st, rv, starts, d_nr, n_r, gcnt, d_hist, max_bin, d_mz);
             KCHK(ctx);
         } else HIPCHK(ctx, hipMemsetAsync(d_nr, 0, 4, st));
+        sc.drop(rv);                                                          // (the counts are summed: gcnt holds them per key)
         u32 h_nr = 0; unsigned long long h_mz = 0;
         std::vector<u32> hb(head);
         HIPCHK(ctx, hipMemcpyAsync(&h_nr, d_nr, 4, hipMemcpyDeviceToHost, st));

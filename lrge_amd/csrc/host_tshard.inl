@@ -5,7 +5,7 @@
 // word set (CollectiveGuard, host_index.inl).
 //   C1 all-gather  u64[W + 1]   pairs this rank sends to every owner, status
 //   A1 agreement                (send / receive buffers taken)
-//   C2 all-to-all  u64          hashes          C3 all-to-all u32 local counts
+//   C2 all-to-all  u64          the pairs (hash << 24 | local count)
 //   C4 all-reduce  u64[head+3]  distinct keys, minimizers, head bins of the occurrence histogram, status   -> mid_occ
 //   C5 all-gather  u64[2]       too-frequent keys this rank owns, status
 //   A2 agreement                (room for everybody's list)
@@ -60,22 +60,22 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
     std::vector<u64> s_off((size_t)W + 1, 0), r_off((size_t)W + 1, 0);
     for (int d = 0; d < W; ++d) { s_off[(size_t)d + 1] = s_off[(size_t)d] + mine[(size_t)d]; r_off[(size_t)d + 1] = r_off[(size_t)d] + matrix[(size_t)d * row + (size_t)me]; }
     const u64 n_s = s_off[(size_t)W], n_r = r_off[(size_t)W];
-    const u64 ss[8] = {0, 0, 0, 0, n_s - mine[(size_t)me], n_r - mine[(size_t)me], (u64)8 | (u64)12 << 8, 0};      // (hashes_sent / _recv slots: pairs of 12 bytes)
+    const u64 ss[8] = {0, 0, 0, 0, n_s - mine[(size_t)me], n_r - mine[(size_t)me], (u64)8 | (u64)8 << 8, 0};      // (hashes_sent / _recv slots: pairs of 8 bytes)
     memcpy(ctx->shard_stats, ss, sizeof ss);
     // ---- A1, C2, C3: the pairs travel ----
-    u64 *sh = nullptr, *rh = nullptr; u32 *scn = nullptr, *rcn = nullptr;
+    u64 *sh = nullptr, *rh = nullptr;
     cg.expect(CollectiveGuard::AGREE);
     auto local2 = [&]() -> int {
         if (shard_fail_at(ctx, 12)) return LRGE_ERR_DEVICE;
         if (n_r >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "target-sharded index build: this rank owns %llu (key, count) pairs (limit 2^32)", (unsigned long long)n_r); return LRGE_ERR_TOO_MANY; }
-        sh = sc.get<u64>(n_s + 1); scn = sc.get<u32>(n_s + 1); rh = sc.get<u64>(n_r + 1); rcn = sc.get<u32>(n_r + 1);
-        if (!sh || !scn || !rh || !rcn) return LRGE_ERR_DEVICE;
+        sh = sc.get<u64>(n_s + 1); rh = sc.get<u64>(n_r + 1);
+        if (!sh || !rh) return LRGE_ERR_DEVICE;
         std::vector<unsigned long long> cur(TS_MAX_WORLD, 0);
         for (int o = 0; o < W; ++o) cur[(size_t)o] = s_off[(size_t)o];
         HIPCHK(ctx, hipMemcpyAsync(d_tot + TS_MAX_WORLD, cur.data(), TS_MAX_WORLD * 8, hipMemcpyHostToDevice, st));
         HIPCHK(ctx, hipStreamSynchronize(st));          // (`cur` is a local)
         for (const TsTable &t : tabs)
-            if (t.slots) { hipLaunchKernelGGL(k_ts_emit, dim3((u32)div_up(t.slots, TS_THREADS * TS_ITEMS)), dim3(TS_THREADS), 0, st, t.ht, t.slots, (u32)W, d_tot + TS_MAX_WORLD, sh, scn); KCHK(ctx); }
+            if (t.slots) { hipLaunchKernelGGL(k_ts_emit, dim3((u32)div_up(t.slots, TS_THREADS * TS_ITEMS)), dim3(TS_THREADS), 0, st, t.ht, t.slots, (u32)W, d_tot + TS_MAX_WORLD, sh); KCHK(ctx); }
         return LRGE_OK;
     };
     rc = local2();
@@ -83,7 +83,6 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
     cg.disarm();
     rc = comm_agree(c, rc, st); if (rc) return rc;
     rc = comm_alltoallv(c, sh, s_off.data(), rh, r_off.data(), 8, st); if (rc) return rc;
-    rc = comm_alltoallv(c, scn, s_off.data(), rcn, r_off.data(), 4, st); if (rc) return rc;
     mark("all-to-alls");
     // ---- C4: the owner adds the counts up; the statistics of the one index ----
     const u32 max_bin = (u32)P.max_mid_occ + 1, head = std::min<u32>(4096, max_bin + 1);
@@ -94,24 +93,21 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
     {
         if (shard_fail_at(ctx, 13)) return LRGE_ERR_DEVICE;
         HIPCHK(ctx, hipStreamSynchronize(st));        // (the offset vectors above are locals)
-        sc.drop(sh); sc.drop(scn);
-        ALLOC_OR_FAIL(k1, sc, u64, n_r + 1); ALLOC_OR_FAIL(v0, sc, u64, n_r + 1); ALLOC_OR_FAIL(v1, sc, u64, n_r + 1);
-        if (n_r) { hipLaunchKernelGGL(k_u32_to_u64, dim3((u32)div_up(n_r, 256)), dim3(256), 0, st, rcn, n_r, v0); KCHK(ctx); }
-        sc.drop(rcn); rcn = nullptr;
-        u64 *rv = nullptr;
-        rc = radix_sort_pairs(ctx, sc, rh, v0, k1, v1, n_r, 0, 2 * P.k, &rk, &rv); if (rc) return rc;
-        sc.drop(rk == rh ? k1 : rh); sc.drop(rv == v0 ? v1 : v0);          // (the other halves of the ping-pong: recycled in stream order)
+        sc.drop(sh);
+        ALLOC_OR_FAIL(k1, sc, u64, n_r + 1);
+        rc = radix_sort_keys(ctx, sc, rh, k1, n_r, TS_CNT_BITS, 2 * P.k, &rk, /*reverse_digits=*/false); if (rc) return rc;
+        sc.drop(rk == rh ? k1 : rh);                  // (the other half of the ping-pong: recycled in stream order)
+        u64 *rv = rk;
         starts = sc.get<u32>(n_r + 2); d_nr = sc.get<u32>(1); gcnt = sc.get<u32>(n_r + 1); d_hist = sc.get<u32>((size_t)max_bin + 2);
         d_mz = (unsigned long long *)sc.get<u64>(1);
         if (!starts || !d_nr || !gcnt || !d_hist || !d_mz) return LRGE_ERR_DEVICE;
-        rc = compact_heads_async(ctx, sc, rk, n_r, 0, starts, d_nr); if (rc) return rc;
+        rc = compact_heads_async(ctx, sc, rk, n_r, TS_CNT_BITS, starts, d_nr); if (rc) return rc;
         HIPCHK(ctx, hipMemsetAsync(d_hist, 0, ((size_t)max_bin + 2) * 4, st));
         HIPCHK(ctx, hipMemsetAsync(d_mz, 0, 8, st));
         if (n_r) {
             hipLaunchKernelGGL(k_ts_reduce, dim3((u32)std::min<u64>(div_up(n_r, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, st, rv, starts, d_nr, n_r, gcnt, d_hist, max_bin, d_mz);
             KCHK(ctx);
         } else HIPCHK(ctx, hipMemsetAsync(d_nr, 0, 4, st));
-        sc.drop(rv);                                                          // (the counts are summed: gcnt holds them per key)
         u32 h_nr = 0; unsigned long long h_mz = 0;
         std::vector<u32> hb(head);
         HIPCHK(ctx, hipMemcpyAsync(&h_nr, d_nr, 4, hipMemcpyDeviceToHost, st));

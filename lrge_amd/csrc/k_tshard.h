@@ -9,7 +9,7 @@
 // of its counts over the ranks (the argument of the partitioned index, host_index.inl) -- ONE all-reduce of u32[Q] closes the job.
 // What must be global is mm_idx_cal_max_occ's statistic and the mid_occ filter: a key is dropped by its occurrence count over
 // ALL targets.  Each rank therefore sends, per distinct key of its table, (hash, local count) to the rank that owns the hash
-// (12 bytes per distinct key instead of 8-16 per minimizer: the table has done the run-length counting already); the owner adds
+// (ONE 8-byte word per distinct key -- hash << 24 | count -- instead of 8-16 bytes per minimizer: the table has done the run-length counting already); the owner adds
 // the counts up, the all-reduce of k_restrict.h's statistics vector makes n_keys / n_minimizers / mid_occ those of the one index,
 // and the (few: mid_occ_frac = 2e-4 of the keys) too-frequent keys travel back to everybody, who lifts them above the threshold in
 // its own table exactly as k_part_drop does for the parts of a partitioned index.  No index entry ever crosses a link.
@@ -40,8 +40,10 @@ __global__ __launch_bounds__(TS_THREADS) void k_ts_count(const u64 *__restrict__
 
 // the pairs, grouped by owner: a block counts its tile per owner in LDS, reserves one run per owner (cursor[o] starts at the
 // owner's offset in the send buffers) and fills it -- the order inside an owner's share does not matter (the owner sorts)
+// a pair is ONE word: hash << 24 | local count (2k <= 38 bits of hash, and the table caps a count at 2^24 - 1)
+#define TS_CNT_BITS HT_CNT_BITS
 __global__ __launch_bounds__(TS_THREADS) void k_ts_emit(const u64 *__restrict__ ht, u64 n_slots, u32 world, unsigned long long *__restrict__ cursor,
-                                                       u64 *__restrict__ out_h, u32 *__restrict__ out_c) {
+                                                       u64 *__restrict__ out) {
     __shared__ u32 c[TS_MAX_WORLD], fill[TS_MAX_WORLD];
     __shared__ unsigned long long base[TS_MAX_WORLD];
     if (threadIdx.x < TS_MAX_WORLD) { c[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
@@ -65,13 +67,13 @@ __global__ __launch_bounds__(TS_THREADS) void k_ts_emit(const u64 *__restrict__ 
     for (int r = 0; r < TS_ITEMS; ++r)
         if (key[r] != HT_EMPTY) {
             const unsigned long long d = base[own[r]] + atomicAdd(&fill[own[r]], 1u);
-            out_h[d] = key[r]; out_c[d] = cnt[r];
+            out[d] = key[r] << TS_CNT_BITS | cnt[r];
         }
 }
 
 // owner side: the received pairs sorted by hash, run r = [start[r], start[r + 1]): the key's count over all ranks (and parts),
 // the occurrence histogram (mm_idx_cal_max_occ's input), the number of minimizers
-__global__ __launch_bounds__(256) void k_ts_reduce(const u64 *__restrict__ cnt /* widened counts, sorted with the hashes */, const u32 *__restrict__ start,
+__global__ __launch_bounds__(256) void k_ts_reduce(const u64 *__restrict__ pairs /* hash << 24 | count, sorted by hash */, const u32 *__restrict__ start,
                                                    const u32 *__restrict__ d_n_runs, u64 n, u32 *__restrict__ gcnt, u32 *__restrict__ hist, u32 max_bin,
                                                    unsigned long long *__restrict__ n_mz) {
     __shared__ u32 lh[OH_BINS];
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void k_ts_reduce(const u64 *__restrict__ cnt /
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += stride) {
         const u64 en = (r + 1 < n_runs) ? start[r + 1] : n;
         u64 sum = 0;
-        for (u64 i = start[r]; i < en; ++i) sum += cnt[i];
+        for (u64 i = start[r]; i < en; ++i) sum += pairs[i] & HT_CNT_MAX;
         mine += sum;
         const u32 g = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)sum;
         gcnt[r] = g;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void k_ts_frequent(const u64 *__restrict__ key
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_runs || gcnt[r] <= mid_occ) return;
     const u32 d = atomicAdd(n, 1u);
-    if (d < cap) list[d] = keys[start[r]];
+    if (d < cap) list[d] = keys[start[r]] >> TS_CNT_BITS;
 }
 
 // every rank: a key that is too frequent over ALL targets is lifted above the threshold in this table (k_part_drop's marking:

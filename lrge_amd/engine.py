@@ -204,7 +204,7 @@ class Index:
             a = (C.c_uint64 * 8)()
             ctx._lib.lrge_hip_last_shard_stats(ctx.h, C.byref(a))
             self.shard_stats = dict(keyset_bytes=0, entries_sketched=0, entries_sent=0, entries_recv=0, hashes_sent=int(a[4]), hashes_recv=int(a[5]),
-                                    entry_bytes=8, entries_kept=0, hash_bytes=12)      # (hashes_*: (key, count) pairs of 12 bytes)
+                                    entry_bytes=8, entries_kept=0, hash_bytes=8)      # (hashes_*: (key, count) pairs, one 8-byte word each)
             return
         if shard is not None:
             lens = np.ascontiguousarray(shard[0], dtype=np.uint32)

@@ -229,7 +229,7 @@ static int comm_allgather(lrge_hip_comm *c, const void *dsend, size_t bytes, voi
 // ---- small collectives on HOST vectors (sizes, counts, statistics -- each carrying a status word) ----
 // Same wire shape as the device-buffer forms above (RCCL: the same ncclAllReduce / ncclAllGather; host callbacks: the same callback;
 // local: the same two barriers), but no allocation and, off RCCL, no device round trip: a rank whose allocation or kernel has failed
-// can always take part, which is what makes failure collective (CollectiveGuard, host_index.inl).
+// can always take part, which is what makes failure collective (CollectiveGuard, host_index_collective.inl).
 static int comm_small_stage(lrge_hip_comm *c, size_t bytes, Scratch &sc, char **d) {
     if (bytes <= lrge_hip_comm::kSmall && c->d_small) { *d = c->d_small; return LRGE_OK; }
     *d = sc.get<char>(bytes);

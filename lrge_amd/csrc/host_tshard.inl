@@ -2,7 +2,7 @@
 // collective index build of the forward strategy with the TARGETS sharded over the ranks (k_tshard.h says why and what travels).
 // ------------------------------------------------------------------------------------------
 // A collective call: the sequence of collectives is fixed, a rank that fails joins the next one in its own shape with the status
-// word set (CollectiveGuard, host_index.inl).
+// word set (CollectiveGuard, host_index_collective.inl).
 //   C1 all-gather  u64[W + 1]   pairs this rank sends to every owner, status
 //   A1 agreement                (send / receive buffers taken)
 //   C2 all-to-all  u64          the pairs (hash << 24 | local count)

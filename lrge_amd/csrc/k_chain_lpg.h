@@ -41,7 +41,7 @@
 #define LPG_WAVES 1   // wavefronts per workgroup (they share the penalty table; every wavefront has its own ring)
 #endif
 #define LPG_RING_BYTES ((2 * (LPG_CH / 2) * 128 * 2 + LPG_CH * 64) * 8)      // per wavefront
-#define LPG_MAX_AUTO 0xFFFFFFFEu   // split chosen per batch from the group-size census (host_overlap.inl: OverlapRun::batch)
+#define LPG_MAX_AUTO 0xFFFFFFFEu   // split chosen per batch from the group-size census (host_overlap_batch.inl: OverlapRun::batch)
 
 struct LpgChainArgs {
     const u64 *akey, *aval;

@@ -6,7 +6,7 @@
 // HPC 19-mers against 7.5 G minimizers: every key recurs all over the genome) a rank's "restricted" index still holds a tenth of
 // all entries -- 3.3x at 8 ranks (profiles/r04_emulated_world8_c5_half_fwd.json).  Here rank r indexes ITS contiguous share of the
 // target reads and maps ALL queries against it: the shards hold disjoint targets, so a query's distinct-target count is the sum
-// of its counts over the ranks (the argument of the partitioned index, host_index.inl) -- ONE all-reduce of u32[Q] closes the job.
+// of its counts over the ranks (the argument of the partitioned index, host_index_parts.inl) -- ONE all-reduce of u32[Q] closes the job.
 // What must be global is mm_idx_cal_max_occ's statistic and the mid_occ filter: a key is dropped by its occurrence count over
 // ALL targets.  Each rank therefore sends, per distinct key of its table, (hash, local count) to the rank that owns the hash
 // (ONE 8-byte word per distinct key -- hash << 24 | count -- instead of 8-16 bytes per minimizer: the table has done the run-length counting already); the owner adds

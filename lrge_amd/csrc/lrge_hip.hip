@@ -204,8 +204,12 @@ extern "C" int lrge_hip_last_counters(const lrge_hip_ctx *ctx, uint64_t c[LRGE_C
 // ---- the entry points, by family (one translation unit: the kernels of k_*.h are static / templates) ----
 #include "host_seqset.inl"
 #include "host_sketch.inl"
-#include "host_index.inl"
+#include "host_index_collective.inl"
+#include "host_index_build.inl"
+#include "host_index_parts.inl"
 #include "host_tshard.inl"
-#include "host_overlap.inl"
+#include "host_overlap_seeds.inl"
+#include "host_overlap_batch.inl"
+#include "host_overlap_api.inl"
 #include "host_comm.inl"
 #include "host_estimate.inl"

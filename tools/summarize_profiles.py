@@ -2,7 +2,7 @@
 """Turn one tools/profile_round.sh run (gpurun_out/<tag>_*) into the tracked files under profiles/:
    <round>_bench.json, <round>_kernel_stats.csv, <round>_pmc_sq.csv, <round>_pmc_fetch.csv, <round>_pmc_write.csv
    and <round>_hbm_traffic.json (corrected HBM bytes and VALU instructions per launch of every kernel).
-   usage: tools/summarize_profiles.py <tag> <round-prefix>      e.g.  r1k r01"""
+   usage: tools/summarize_profiles.py <tag> <round-prefix> [suffix]     e.g.  r4p r04   (suffix "_c4": profiles/r04_*_c4.*)"""
 import collections
 import csv
 import json
@@ -12,6 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
+suf = sys.argv[3] if len(sys.argv) > 3 else ""
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
@@ -26,15 +27,15 @@ def agg(path):
     return out
 
 
-shutil.copy(os.path.join(G, tag + "_stats", "s_kernel_stats.csv"), os.path.join(P, rnd + "_kernel_stats.csv"))
+shutil.copy(os.path.join(G, tag + "_stats", "s_kernel_stats.csv"), os.path.join(P, rnd + "_kernel_stats" + suf + ".csv"))
 bench = json.loads(open(os.path.join(G, tag + "_bench.json")).read().strip().splitlines()[-1])
-json.dump(bench, open(os.path.join(P, rnd + "_bench.json"), "w"), indent=1)
+json.dump(bench, open(os.path.join(P, rnd + "_bench" + suf + ".json"), "w"), indent=1)
 under = json.loads(open(os.path.join(G, tag + "_stats.json")).read().strip().splitlines()[-1])
-json.dump(under, open(os.path.join(P, rnd + "_bench_under_rocprof.json"), "w"), indent=1)
+json.dump(under, open(os.path.join(P, rnd + "_bench_under_rocprof" + suf + ".json"), "w"), indent=1)
 
 for name, sub, pre in (("sq", "_sq", "q"), ("fetch", "_fetch", "f"), ("write", "_write", "w")):
     a = agg(os.path.join(G, tag + sub, pre + "_counter_collection.csv"))
-    with open(os.path.join(P, "%s_pmc_%s.csv" % (rnd, name)), "w", newline="") as f:
+    with open(os.path.join(P, "%s_pmc_%s%s.csv" % (rnd, name, suf)), "w", newline="") as f:
         wr = csv.writer(f)
         wr.writerow(["kernel", "counter", "dispatches", "sum", "per_dispatch"])
         for k in sorted(a):
@@ -65,8 +66,8 @@ for r in csv.DictReader(open(os.path.join(G, tag + "_fetch", "f_counter_collecti
     if r["Kernel_Name"].startswith("void k_rs_hist<false") and r["Counter_Name"] == "FETCH_SIZE":
         big = max(big, float(r["Counter_Value"]))
 out = {
-    "source": "tools/profile_round.sh %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes, bench.py --steps 1 --warmup 0; "
-              "the pass also holds the instrumented step, so per-launch figures average 2 steps' launches)" % tag,
+    "source": "tools/profile_round.sh %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_*, separate passes of bench.py --no-cpu-baseline --no-resident "
+              "--parity-sample 0 --steps 1 --warmup 0; per-launch figures average the launches of the pass)" % tag,
     "workload": bench.get("config", {}).get("workload"),
     "fetch_correction": 2.0, "write_correction": 1.0,
     "calibration": {"k_rs_hist_false_largest_launch_FETCH_SIZE_KiB": big, "index_minimizers": bench.get("work_per_step", {}).get("rs_scatter_items"),
@@ -75,15 +76,18 @@ out = {
     "valu_issue_note": "measured (tools/micro/valu_rate.hip): a SIMD issues a wave64 v_add / v_fma / v_cndmask every 2.4-2.7 cycles, v_cmp / v_max / DPP every 4.3; one wavefront issues a dependent instruction every ~9 cycles",
     "kernels": per,
 }
-# whole path: every kernel's raw counters summed over the pass, per step (the pass runs `steps_in_pass` steps: the timed one and
-# the instrumented one that follows it), next to the algorithmic bytes of SURVEY.md 8(d) the bench line reports
-steps_in_pass = 2
+# whole path: every kernel's raw counters summed over the pass, per step (a pass runs the timed step and, for small jobs, the
+# instrumented one that follows it: told apart by the k_lookup launches), next to the algorithmic bytes of SURVEY.md 8(d) the bench line reports
+look = [v for k, v in fetch.items() if k.startswith("k_lookup")]
+per_step = max(1.0, float(bench.get("work_per_step", {}).get("lookup_launches", 1) or 1))
+steps_in_pass = max(1, int(round((look[0]["FETCH_SIZE"][0] if look else per_step) / per_step)))
 tot_f = sum(v["FETCH_SIZE"][1] for v in fetch.values() if "FETCH_SIZE" in v) * 1024 / steps_in_pass
 tot_w = sum(v["WRITE_SIZE"][1] for v in write.values() if "WRITE_SIZE" in v) * 1024 / steps_in_pass
 alg = bench.get("roofline", {}).get("whole_path_alg_GBps", 0.0) * bench.get("ms_per_step", 0.0) * 1e-3
 cfg_name = (bench.get("config", {}).get("workload") or "").split(":")[0]
-out.update({"config": cfg_name, "fetch_GB_per_step": tot_f / 1e9, "write_GB_per_step": tot_w / 1e9, "algorithmic_GB_per_step": alg,
+out.update({"config": cfg_name, "inverse": "--use-min-ref" in (bench.get("config", {}).get("workload") or ""), "steps_in_pass": steps_in_pass,
+            "clock": bench.get("config", {}).get("clock"), "fetch_GB_per_step": tot_f / 1e9, "write_GB_per_step": tot_w / 1e9, "algorithmic_GB_per_step": alg,
             "traffic_over_algorithmic": {"raw_counters": (tot_f + tot_w) / 1e9 / alg if alg else None,
                                          "reads_x2_correction": (2 * tot_f + tot_w) / 1e9 / alg if alg else None}})
-json.dump(out, open(os.path.join(P, rnd + "_hbm_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, rnd + "_hbm_traffic" + suf + ".json"), "w"), indent=1)
 print(json.dumps({k: v["hbm_bytes_per_launch_corrected"] for k, v in per.items()}, indent=1))

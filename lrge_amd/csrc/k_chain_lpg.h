@@ -148,6 +148,12 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
     i32 PM[LPG_NPM];
 #pragma unroll
     for (int k = 0; k < LPG_NPM; ++k) PM[k] = R.no_prune ? INT32_MAX : 0;
+    // the same idea for the max_ii rescan ("best f in reach", below): PF = the largest f among the anchors that have LEFT the window.
+    // The rescan wants the newest anchor of maximal f in x-reach; when the window already holds an f >= PF it is in the window (a
+    // tie goes to the newer anchor) and the walk through HBM behind the window -- up to 5000 bp of anchors, the reason groups were
+    // given up to k_chain_hw_redo: 24 ms per H. sapiens-scale step -- is not needed.  (PF also counts anchors out of reach: a
+    // sufficient test, never a wrong one.)
+    i32 PF = R.no_prune ? INT32_MAX : 0;
 
     u32 slow_iters = 0, slow_entries = 0;
     bool abandoned = false;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
                 bj = in ? i - 1 - k : bj;
             }
             if (need_rescan) {
-                if (more && xi - WX[LPG_W - 1] <= maxdx) {
+                if (more && xi - WX[LPG_W - 1] <= maxdx && bf < PF) {
                     drain_stores();
                     for (i32 j = i - 1 - LPG_W; j >= lower; --j) {
                         if (++slow_iters > R.slow_budget) { abandoned = true; break; }
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
         if (alive) {
 #pragma unroll
             for (int k = 0; k < LPG_NPM; ++k) { const i32 g = WF[(k + 1) * LPG_B - 1] + WS[(k + 1) * LPG_B - 1]; PM[k] = g > PM[k] ? g : PM[k]; }
+            PF = WF[LPG_W - 1] > PF ? WF[LPG_W - 1] : PF;
         }
         // shift the window, insert anchor i at slot 0
         const u32 reli = (u32)(i - 1 - max_j);                       // >= 32 (or "no predecessor"): no mark inside the window

@@ -54,6 +54,8 @@ extern "C" {
     fn lrge_hip_index_build_for(ctx: *mut lrge_hip_ctx, targets: *const lrge_hip_seqset, preset: c_int,
                                 streamed: *mut lrge_hip_seqset, comm: *mut lrge_hip_comm,
                                 out: *mut *mut lrge_hip_index) -> c_int;
+    fn lrge_hip_index_build_tsharded(ctx: *mut lrge_hip_ctx, target_shard: *const lrge_hip_seqset, preset: c_int, comm: *mut lrge_hip_comm,
+                                     out: *mut *mut lrge_hip_index) -> c_int;
     fn lrge_hip_index_build_sharded(ctx: *mut lrge_hip_ctx, all_target_lens: *const u32, all_target_ranks: *const u32,
                                     n_targets: u32, target_shard: *const lrge_hip_seqset, shard_first: u32, preset: c_int,
                                     streamed: *mut lrge_hip_seqset, comm: *mut lrge_hip_comm,
@@ -337,6 +339,59 @@ pub fn shard_by_bases(lens: &[u32], world: usize) -> Vec<usize> {
     }
     bounds.push(lens.len());
     bounds
+}
+
+/// Two-set forward over `devices` with the TARGETS sharded (round 4; what pays when query bases x devices <= target bases, i.e. the
+/// human-scale jobs): every rank uploads and indexes ITS contiguous share of the target reads and maps ALL queries against it;
+/// `lrge_hip_index_build_tsharded` makes the occurrence statistics (mid_occ) those of the one index, the count vectors of the
+/// ranks add up (disjoint targets: twoset.rs:286-317 counts distinct target names) in one all-reduce, and the estimates are
+/// computed once from the summed counts.  No index entry crosses a link.
+pub fn twoset_estimates_target_sharded(job: &TwoSetJob, devices: &[i32]) -> crate::Result<(Vec<f32>, u32)> {
+    let world = devices.len();
+    if world <= 1 { return twoset_estimates(job); }
+    let preset = if job.pacbio { LRGE_PRESET_AVA_PB } else { LRGE_PRESET_AVA_ONT };
+    let t = read_set(job.target_file)?;
+    let q = read_set(job.query_file)?;
+    let ranks = name_ranks(&[&t.names, &q.names]);
+    let (q_lens, t_lens) = (q.lens(), t.lens());
+    let t_bounds = shard_by_bases(&t_lens, world);
+    let mut group = ptr::null_mut();
+    check!(ptr::null(), lrge_hip_comm_local_group_create(world as c_int, &mut group));
+    let group = SendPtr(group);
+    let p = lrge_hip_params { remove_internal: job.remove_internal as i32, max_overhang_ratio: job.max_overhang_ratio };
+    let results: Vec<crate::Result<(Vec<f32>, u32)>> = std::thread::scope(|sc| {
+        let handles: Vec<_> = (0..world).map(|r| {
+            let (t, q, ranks, q_lens, group, t_bounds) = (&t, &q, &ranks, &q_lens, &group, &t_bounds);
+            let device = devices[r];
+            sc.spawn(move || -> crate::Result<(Vec<f32>, u32)> {
+                let ctx = Ctx::new(device)?;
+                let mut comm = ptr::null_mut();
+                check!(ctx.h, lrge_hip_comm_create_local(ctx.h, r as c_int, group.0, &mut comm));
+                let (t0, t1) = (t_bounds[r], t_bounds[r + 1]);
+                let tsub = ReadSet {
+                    bases: t.bases[t.offsets[t0] as usize..t.offsets[t1] as usize].to_vec(),
+                    offsets: t.offsets[t0..=t1].iter().map(|o| o - t.offsets[t0]).collect(),
+                    names: t.names[t0..t1].to_vec(),
+                };
+                let ts = ctx.upload(&tsub, &ranks[0][t0..t1])?;
+                let qs = ctx.upload(q, &ranks[1])?;                                 // ALL queries on every rank
+                let mut h = ptr::null_mut();
+                check!(ctx.h, lrge_hip_index_build_tsharded(ctx.h, ts.h, preset, comm, &mut h));     // collective
+                let ix = Index { h, _ctx: &ctx };
+                let (mut counts, mut has) = ctx.overlap_twoset(&ix, &qs, &p)?;
+                check!(ctx.h, lrge_hip_comm_allreduce_u32(comm, counts.as_mut_ptr(), counts.len()));   // disjoint targets: counts add up
+                check!(ctx.h, lrge_hip_comm_allreduce_u32(comm, has.as_mut_ptr(), has.len()));         // ... and has_mapping ORs
+                unsafe { lrge_hip_comm_destroy(comm) };
+                let est = ctx.estimates(&counts, q_lens, job.avg_target_len, job.target_num_reads as u64, 100)?;
+                Ok((est, has.iter().filter(|&&h| h == 0).count() as u32))
+            })
+        }).collect();
+        handles.into_iter().map(|h| h.join().expect("GPU worker panicked")).collect()
+    });
+    unsafe { lrge_hip_comm_local_group_destroy(group.0) };
+    let mut first = None;
+    for r in results { let v = r?; if first.is_none() { first = Some(v); } }
+    Ok(first.expect("world >= 2"))
 }
 
 struct SendPtr(*mut c_void);

@@ -181,13 +181,18 @@ struct Uploader {
         jobs.push_back(std::move(j));
         cv.notify_all();
     }
+    bool busy = false;                  // a job is running on the uploader thread
     void run() {
         for (;;) {
             std::function<void()> j;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return quit || !jobs.empty(); }); if (jobs.empty()) return; j = std::move(jobs.front()); jobs.pop_front(); }
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return quit || !jobs.empty(); }); if (jobs.empty()) return; j = std::move(jobs.front()); jobs.pop_front(); busy = true; }
             j();
+            { std::lock_guard<std::mutex> lk(mu); busy = false; }
+            cv.notify_all();
         }
     }
+    // every queued job has run to its end (the staging buffers may be replaced: ADVICE r03)
+    void drain() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return jobs.empty() && !busy; }); }
     ~Uploader() {
         { std::lock_guard<std::mutex> lk(mu); quit = true; }
         cv.notify_all();

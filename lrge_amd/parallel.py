@@ -329,6 +329,21 @@ def twoset_forward_sharded(overlap_fn, q_lens, comm):
     return allv, int(nm[0]), (lo, hi)
 
 
+def twoset_forward_target_sharded(overlap_fn, t_lens, comm):
+    """Two-set forward over comm.world GPUs with the TARGETS sharded (lrge_hip_index_build_tsharded): the target reads are cut into
+    contiguous ranges with equal base counts, `overlap_fn(t_lo, t_hi) -> (counts u32[Q], has_mapping u32[Q])` maps ALL queries
+    against this rank's range (its index built with the occurrence statistics of the whole target set:
+    engine.Index(ctx, target_shard, preset, comm=comm, tshard=True)); the shards hold disjoint targets, so the distinct-target
+    counts of twoset.rs:286-317 add up and has_mapping ORs: two all-reduces close the step.  Returns (counts, has_mapping 0/1,
+    (t_lo, t_hi))."""
+    b = shard_by_bases(t_lens, comm.world)
+    lo, hi = b[comm.rank], b[comm.rank + 1]
+    counts, has = overlap_fn(lo, hi)
+    counts = comm.all_reduce_u32(np.asarray(counts, dtype=np.uint32))
+    has = (comm.all_reduce_u32(np.asarray(has, dtype=np.uint32)) > 0).astype(np.uint32)
+    return counts, has, (lo, hi)
+
+
 def shard_by_rank_round_robin(name_ranks, rank, world):
     """All-vs-all shards: reads dealt round-robin in NAME-RANK order (NO_DUAL lets the smaller-named read of a pair
     carry it, so contiguous rank ranges would be unbalanced).  Returns this rank's read indices,

@@ -276,6 +276,7 @@ struct lo_index {
     uint64_t *off;         /* n_keys+1 offsets into pos[] */
     uint64_t *pos;         /* y values, ascending within a key */
     int32_t mid_occ;
+    unsigned char *dropped; /* lo_index_drop_keys: keys that are too frequent over a LARGER target set this index is a shard of */
 };
 
 typedef struct { uint64_t h, y; } hy_t;
@@ -458,7 +459,7 @@ void lo_index_free(lo_index_t *ix)
     if (!ix) return;
     for (i = 0; i < ix->n_seq; ++i) free(ix->name[i]);
     free(ix->name); free(ix->len); free(ix->name_rank); free(ix->mz);
-    free(ix->key); free(ix->off); free(ix->pos); free(ix);
+    free(ix->key); free(ix->off); free(ix->pos); free(ix->dropped); free(ix);
 }
 
 int32_t  lo_index_mid_occ(const lo_index_t *ix) { return ix->mid_occ; }
@@ -770,7 +771,23 @@ int32_t lo_index_get(const lo_index_t *ix, uint64_t minier, const uint64_t **lis
     }
     if (lo == ix->n_keys || ix->key[lo] != minier) { if (list) *list = 0; return 0; }
     if (list) *list = ix->pos + ix->off[lo];
+    if (ix->dropped && ix->dropped[lo]) return ix->mid_occ + 1;   /* (callers never walk a list of more than mid_occ entries) */
     return (int32_t)(ix->off[lo + 1] - ix->off[lo]);
+}
+
+/* This index holds a SHARD of a larger target set (the target-sharded multi-GPU form, lrge_hip_index_build_tsharded): keys whose
+   occurrence count over the WHOLE set exceeds mid_occ answer as too frequent here too, whatever their count in the shard --
+   what mm_idx_get would say in the one index.  Returns how many of the keys the shard holds. */
+uint64_t lo_index_drop_keys(lo_index_t *ix, const uint64_t *keys, uint64_t n)
+{
+    uint64_t i, found = 0;
+    if (!ix->dropped) ix->dropped = (unsigned char *)calloc(ix->n_keys ? ix->n_keys : 1, 1);
+    for (i = 0; i < n; ++i) {
+        uint64_t lo = 0, hi = ix->n_keys;
+        while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ix->key[mid] < keys[i]) lo = mid + 1; else hi = mid; }
+        if (lo < ix->n_keys && ix->key[lo] == keys[i]) { ix->dropped[lo] = 1; ++found; }
+    }
+    return found;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -79,6 +79,9 @@ uint64_t lo_index_n_minimizers(const lo_index_t *ix);
 uint64_t lo_index_n_keys(const lo_index_t *ix);
 /* mm_idx_get: number of hits for a minimizer hash (x>>8); *list points at the y values */
 int32_t  lo_index_get(const lo_index_t *ix, uint64_t minier, const uint64_t **list);
+/* the index is a SHARD of a larger target set: these keys are too frequent over the whole set (count > mid_occ there) and answer so
+   here as well (tests of the target-sharded multi-GPU form); returns how many of them the shard holds */
+uint64_t lo_index_drop_keys(lo_index_t *ix, const uint64_t *keys, uint64_t n);
 /* dump all minimizers in sketch order (rid-major) -- for stage-level parity tests */
 uint64_t lo_index_dump_minimizers(const lo_index_t *ix, lo_mm128_t *out, uint64_t cap);
 

@@ -75,6 +75,8 @@ def lib():
         L.lo_index_n_keys.argtypes = [vp]
         L.lo_index_get.restype = C.c_int32
         L.lo_index_get.argtypes = [vp, C.c_uint64, C.POINTER(u64p)]
+        L.lo_index_drop_keys.restype = C.c_uint64
+        L.lo_index_drop_keys.argtypes = [vp, vp, C.c_uint64]
         L.lo_index_dump_minimizers.restype = C.c_uint64
         L.lo_index_dump_minimizers.argtypes = [vp, vp, C.c_uint64]
         L.lo_anchors.restype = C.c_int64
@@ -183,6 +185,11 @@ class Index:
         out = np.zeros(max(n, 1), dtype=MM128)
         lib().lo_index_dump_minimizers(self.h, out.ctypes.data, n)
         return out[:n]
+
+    def drop_keys(self, keys):
+        """This index is a shard of a larger target set: `keys` (hashes) are too frequent over the whole set."""
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        return lib().lo_index_drop_keys(self.h, k.ctypes.data if k.size else None, k.size)
 
     def get(self, minier):
         p = C.POINTER(C.c_uint64)()

@@ -167,3 +167,66 @@ def test_gloo_world2_gather_and_allreduce():
     # dealt in name-rank order: ranks 0,2,4,6 -> shard 0; 1,3,5 -> shard 1
     assert shards[0] == sorted([1, 3, 0, 2]) and shards[1] == sorted([5, 6, 4])
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 11
+
+
+def _ts_worker(rank, world, port, q):
+    """The target-sharded decomposition with the ORACLE standing in for a rank's GPU engine: an oracle index over the rank's share of
+    the targets, mid_occ forced to the whole set's (what lrge_hip_index_build_tsharded makes global)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lrge_amd import synth
+        from oracle import oracle as O
+        _, qs, ts = synth.make_config("c2_repeats", 0.03)
+        full_opt = O.make_opt(O.PRESET_AVA_ONT, dual=True)
+        full = O.Index(O.ReadSet(ts.seqs(), ts.names), full_opt)
+        Qo = O.ReadSet(qs.seqs(), qs.names)
+        rc, ec, eh = full.twoset_counts(Qo, threads=2)
+        assert rc == 0
+
+        # what the collective build makes global: mid_occ, and WHICH keys exceed it over all targets
+        hashes = full.minimizers()["x"] >> np.uint64(8)
+        keys, cnt = np.unique(hashes, return_counts=True)
+        frequent = keys[cnt > full.mid_occ]
+
+        def overlap_fn(lo, hi):
+            sub = ts.slice(lo, hi)
+            opt = O.make_opt(O.PRESET_AVA_ONT, dual=True)
+            opt.mid_occ = full.mid_occ                       # the GLOBAL threshold; a share's own would be smaller
+            ix = O.Index(O.ReadSet(sub.seqs(), sub.names), opt)
+            held = ix.drop_keys(frequent)                    # ... and a key is dropped by its count over ALL targets
+            q.put(("dropped", rank, int(held), int(frequent.size)))
+            rc2, c, h = ix.twoset_counts(Qo, threads=2)
+            assert rc2 == 0
+            own = O.Index(O.ReadSet(sub.seqs(), sub.names), O.make_opt(O.PRESET_AVA_ONT, dual=True)).mid_occ
+            q.put(("own_mid_occ", rank, own, full.mid_occ))
+            return c, h
+        comm = parallel.TorchComm(dist)
+        counts, has, (lo, hi) = parallel.twoset_forward_target_sharded(overlap_fn, ts.lens(), comm)
+        q.put(("result", rank, bool(np.array_equal(counts, ec)), bool(np.array_equal(has, eh)), int(ec.sum()), lo, hi))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_target_sharded_counts_add_up():
+    """lrge_amd.parallel.twoset_forward_target_sharded over gloo, world size 2, on the CPU: with the global mid_occ on every rank the
+    per-shard distinct-target counts SUM to the one index's counts and has_mapping ORs (twoset.rs:286-317; the argument behind
+    lrge_hip_index_build_tsharded) -- on a repeat-rich set, where the threshold actually drops keys."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ts_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    got = [q.get(timeout=300) for _ in range(6)]
+    for p in procs: p.join(timeout=60)
+    res = sorted(x for x in got if x[0] == "result")
+    assert len(res) == 2
+    for _, rank, c_ok, h_ok, total, lo, hi in res:
+        assert c_ok and h_ok and total > 0
+    assert res[0][5] == 0 and res[0][6] == res[1][5]
+    dropped = [x for x in got if x[0] == "dropped"]
+    assert all(x[3] > 0 for x in dropped) and sum(x[2] for x in dropped) > 0       # (the set is repeat-rich: some keys are too frequent, and the shards hold them)
+    own = [x for x in got if x[0] == "own_mid_occ"]
+    assert all(x[2] <= x[3] for x in own)                                          # (a share's own threshold is never above the whole set's)

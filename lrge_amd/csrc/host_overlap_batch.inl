@@ -280,6 +280,8 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
                     la.slow_budget = (u32)ctx->opt_u64("LPG_SLOW_BUDGET", 1024);
                     la.slow_entries = (u32)ctx->opt_u64("LPG_SLOW_ENTRIES", 4);
                     la.no_prune = ctx->opt("LPG_NO_PRUNE") ? 1u : 0u;
+                    la.slow_rate = (u32)ctx->opt_u64("LPG_SLOW_RATE", 4);
+                    la.slow_entry_every = (u32)ctx->opt_u64("LPG_SLOW_ENTRY_EVERY", 32);
                     la.redo_list = bsc.get<u32>((size_t)la.n_list + 1); la.redo_count = bsc.get<u32>(1);
                     if (!la.redo_list || !la.redo_count) return LRGE_ERR_DEVICE;
                     HIPCHK(ctx, hipMemsetAsync(la.redo_count, 0, 4, both ? ctx->stream2 : ctx->stream));

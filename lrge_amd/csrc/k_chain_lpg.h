@@ -58,6 +58,11 @@ struct LpgChainArgs {
     // when the group has left the window more than slow_entries times (or has cost more than slow_budget iterations):
     // it is appended to redo_list and chained afterwards by k_chain_hw_redo, whose slow paths scan 64 candidates per step.
     u32 *redo_list, *redo_count; u32 slow_budget, slow_entries;
+    // ... both allowances GROW with the anchors the lane has chained so far (round 4): slow_rate iterations per anchor and one entry
+    // per slow_entry_every anchors on top of the fixed ones.  A long HiFi group with a detour every few hundred anchors stays here
+    // (giving ~10 000 of them up per H. sapiens-scale step cost 24 ms of k_chain_hw_redo), a repeat-rich group -- tens of slow
+    // iterations per anchor -- still leaves at once.
+    u32 slow_rate, slow_entry_every;
     u32 no_prune;      // option LPG_NO_PRUNE: never cut the candidate scan short (tests: the full loop and its slow paths)
 };
 
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
             // rare: a lane's loop runs past its 32-anchor window; continue that lane's loop through HBM
             slow_iters += cont ? LPG_W : 0;
             slow_entries += cont ? 1u : 0u;
-            if (cont && (slow_iters > R.slow_budget || slow_entries > R.slow_entries)) abandoned = true;
+            if (cont && (slow_iters > R.slow_budget + (u32)i * R.slow_rate || slow_entries > R.slow_entries + (R.slow_entry_every ? (u32)i / R.slow_entry_every : 0u))) abandoned = true;
             else if (cont) {
                 const u32 stamp = (u32)i + 1;
                 // marks the window candidates left on anchors behind the window (all were valid and reached)
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
                 i32 j = i - 1 - LPG_W;
                 for (;; --j) {
                     if (j < lower) { end_j = j; break; }
-                    if (++slow_iters > R.slow_budget) { abandoned = true; break; }
+                    if (++slow_iters > R.slow_budget + (u32)i * R.slow_rate) { abandoned = true; break; }
                     const i32 xj = (i32)(gk[j] & rmask);
                     if (xi - xj > maxdx) { end_j = j; break; }
                     const u64 v = gv[j], r = ld_u64_l2(grec + j);
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(64 * LPG_WAVES) __attribute__((amdgpu_waves_per_eu(
                 if (more && xi - WX[LPG_W - 1] <= maxdx && bf < PF) {
                     drain_stores();
                     for (i32 j = i - 1 - LPG_W; j >= lower; --j) {
-                        if (++slow_iters > R.slow_budget) { abandoned = true; break; }
+                        if (++slow_iters > R.slow_budget + (u32)i * R.slow_rate) { abandoned = true; break; }
                         if (xi - (i32)(gk[j] & rmask) > maxdx) break;
                         const i32 f = grec_f(ld_u64_l2(grec + j));
                         if (f > bf) { bf = f; bj = j; }

@@ -347,7 +347,7 @@ def test_chain_kernels_and_slow_paths(ctx, oracle, tiny_hifi, knobs, kernel, max
         knobs.set("LPG_MAX", "64")
     elif kernel == "lpg_redo":   # k_chain_lpg gives every group that touches a slow path to k_chain_hw_redo
         knobs.set("CHAIN", "lpg")
-        knobs.set("LPG_SLOW_BUDGET", "0")
+        knobs.set("LPG_SLOW_BUDGET", "0"); knobs.set("LPG_SLOW_RATE", "0"); knobs.set("LPG_SLOW_ENTRY_EVERY", "0")
         knobs.set("LPG_NO_PRUNE", "1")
     elif kernel == "lpg_full_scan":
         knobs.set("CHAIN", "lpg")

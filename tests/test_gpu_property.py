@@ -147,7 +147,7 @@ def test_property_cases_are_not_vacuous(ctx, oracle):
     {"LRGE_HIP_CHAIN": "lpg", "LRGE_HIP_DEBUG_MAX_SKIP": "100000"},      # the same with the pruned scan (the default): the bound, not max_skip, ends the loops
     {"LRGE_HIP_CHAIN": "hw", "LRGE_HIP_DEBUG_MAX_SKIP": "100000"},       # half-wave kernel, same
     {"LRGE_HIP_CHAIN": "lpg", "LRGE_HIP_LPG_NOTAB": "1", "LRGE_HIP_DEBUG_MAX_ITER": "40"},
-    {"LRGE_HIP_CHAIN": "lpg", "LRGE_HIP_DEBUG_MAX_SKIP": "100000", "LRGE_HIP_LPG_SLOW_BUDGET": "0", "LRGE_HIP_LPG_NO_PRUNE": "1"},   # every slow-path group is redone by k_chain_hw_redo
+    {"LRGE_HIP_CHAIN": "lpg", "LRGE_HIP_DEBUG_MAX_SKIP": "100000", "LRGE_HIP_LPG_SLOW_BUDGET": "0", "LRGE_HIP_LPG_SLOW_RATE": "0", "LRGE_HIP_LPG_SLOW_ENTRY_EVERY": "0", "LRGE_HIP_LPG_NO_PRUNE": "1"},   # every slow-path group is redone by k_chain_hw_redo
     {"LRGE_HIP_NO_PACKED": "1", "LRGE_HIP_NO_PACKED_INDEX": "1", "LRGE_HIP_QOCC_EXACT": "1", "LRGE_HIP_BATCH_ANCHORS": "3000"},
 ], ids=["lpg-noskip-fullscan", "lpg-noskip", "hw-noskip", "lpg-notab-iter40", "lpg-redo", "unpacked-exact-batched"])
 def test_random_small_sets_forced_paths(ctx, oracle, env):

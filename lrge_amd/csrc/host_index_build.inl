@@ -230,7 +230,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     }
 
     u64 *skey = so.x, *spos = so.y;
-    bool seg_packed = false; u32 kshift_t = pk_ybits; u32 *d_seg_start = nullptr; std::vector<u32> h_seg_start;
+    bool seg_packed = false; u32 kshift_t = pk_ybits, seg_e = 0; u32 *d_seg_start = nullptr; std::vector<u32> h_seg_start;
     {
         StageTimer t(ctx, LRGE_T_INDEX_SORT);
         ALLOC_OR_FAIL(k1, sc, u64, M + 1);
@@ -255,11 +255,18 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             // the pair layout, segment-packed (k_prims.h: index_sort_segpacked): behind the first digit the low hash byte is implied
             // and the rest of the entry fits one word -- fewer bytes through the remaining passes, 8 bytes per entry resident
             const u32 yb_p = pk_rid + pk_pos1;
-            if (pass_from == 0 && 2 * (u32)P.k - 8 + yb_p <= 64 && 2 * P.k > 16 && !ctx->opt("NO_SEG_PACK") && M >= ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22)) {
+            // (round 4) up to SEG_PACK_EXTRA_MAX more implied bits when the word is that much too narrow: full-size C5 in 3 parts has
+            // read ids of 20 bits, 2 bits too many (option DEBUG_SEG_EXTRA forces them on small sets)
+            const u32 over = 2 * (u32)P.k - 8 + yb_p > 64 ? 2 * (u32)P.k - 8 + yb_p - 64 : 0;
+            u32 extra = std::max<u32>(over, (u32)ctx->opt_u64("DEBUG_SEG_EXTRA", 0));
+            const bool extra_ok = extra == 0 || (2 * P.k >= 24 && extra <= (u32)ctx->opt_u64("SEG_PACK_EXTRA_MAX", 4) && extra <= 4);
+            if (pass_from == 0 && extra_ok && 2 * P.k > 16 && !ctx->opt("NO_SEG_PACK") && M >= ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22)) {
                 u64 *rk = nullptr;
-                rc = index_sort_segpacked(ctx, sc, so.x, so.y, k1, v1, M, 2 * P.k, yb_p, pk_pos1, &rk, &d_seg_start, &h_seg_start);
+                rc = index_sort_segpacked(ctx, sc, so.x, so.y, k1, v1, M, 2 * P.k, yb_p, pk_pos1, extra, &rk, &d_seg_start);
                 if (rc) return rc;
-                seg_packed = true; kshift_t = yb_p;
+                h_seg_start.assign((256u << extra) + 1, 0u);              // (the dump wants them: they arrive with the table build's first round trip)
+                HIPCHK(ctx, ctx->d2h(h_seg_start.data(), d_seg_start, h_seg_start.size() * 4, ctx->stream));
+                seg_packed = true; kshift_t = yb_p; seg_e = extra;
                 skey = rk; spos = rk;
                 sc.drop(rk == so.x ? so.y : so.x); sc.drop(k1); sc.drop(v1);
             } else {
@@ -296,7 +303,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         const u32 ht_fix = ctx->opt("HT_NO_FIX") ? 0u : ht_fix_with_power(P.k, (u32)ctx->opt_u64("HT_POWER", 3));   // (HT_POWER: exponent of the distribution correction, 0 = linear stretch only; measured 2-4 alike, mean displacement 0.30 slots at 3)     // (option HT_NO_FIX: the clustered homes of rounds 1-2, for A/B runs)
         u32 *d_runstart = nullptr;
         if (M) {
-            rc = compact_heads(ctx, sc, skey, M, kshift_t, &d_runstart, &n_runs, d_seg_start, seg_packed ? 256u : 0u);    // runs of equal hash
+            rc = compact_heads(ctx, sc, skey, M, kshift_t, &d_runstart, &n_runs, d_seg_start, seg_packed ? 256u << seg_e : 0u);    // runs of equal hash
             if (rc) return rc;
         }
 #ifndef HT_CAP_NUM
@@ -333,14 +340,14 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
                 const u32 n_tiles = (u32)div_up(n_runs, PLACE_TILE);
                 u32 *bmax = sc.get<u32>((size_t)n_tiles + 1);
                 if (!bmax) return LRGE_ERR_DEVICE;
-                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax, kshift_t, ht_fix, (const u32 *)d_seg_start);
+                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax, kshift_t, ht_fix, SegStarts{d_seg_start, seg_e});
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_scan, dim3(1), dim3(1024), 0, ctx->stream, bmax, n_tiles);
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_apply, dim3(std::min<u32>(n_tiles, (u32)ctx->n_cu * 8)), dim3(PLACE_THREADS), 0, ctx->stream,
                                    skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1, kshift_t, ht_fix,
                                    fused_fill ? bmax + n_tiles : (u32 *)nullptr, pk_t ? (const u64 *)nullptr : (const u64 *)spos, pk_t ? pk_pos1 : 0u,
-                                   ctx->opt("NO_INLINE_SINGLETONS") ? 0u : 1u, (const u32 *)d_seg_start);
+                                   ctx->opt("NO_INLINE_SINGLETONS") ? 0u : 1u, SegStarts{d_seg_start, seg_e});
                 KCHK(ctx);
                 if (fused_fill) {
                     hipLaunchKernelGGL(k_fill_tail, dim3((u32)std::min<u64>(div_up(n_slots - cap / 2, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, ht, n_slots, bmax + n_tiles);
@@ -398,7 +405,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     if (skey != spos && targets->is_view) { ix->d_skey = nullptr; }          // stays with `sc`: released at scope exit
     else { ix->d_skey = skey; if (skey != spos) sc.keep(skey); }
     ix->pk_pos1 = pk_t ? pk_pos1 : 0; ix->pk_ybits = kshift_t;
-    if (seg_packed) { ix->h_seg_start = h_seg_start; sc.drop(d_seg_start); }     // (the device copy served the table build; the dump needs the host copy)
+    if (seg_packed) { ix->h_seg_start = h_seg_start; ix->seg_e = seg_e; sc.drop(d_seg_start); }     // (the device copy served the table build; the dump needs the host copy)
     t_total.stop();
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->resolve_timers();

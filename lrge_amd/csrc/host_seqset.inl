@@ -230,8 +230,11 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
     }
     if (host_pack) {
         // pinned chunk buffers + the uploader thread, once per context
-        const size_t CH = (size_t)ctx->opt_u64("HOST_PACK_CHUNK_WORDS", (u64)2 << 20);      // 64 Mbases per chunk
-        if (!ctx->hp_stage[0] || ctx->hp_words != CH) {
+        // words per chunk: 64 Mbases for sets up to 4 Gbases (the first chunk is what the index sketch waits for: 0.9 ms at C4), 1/64
+        // of the set above that, at most 512 Mbases -- every chunk costs the uploader a round of worker wake-ups and two copies, and
+        // the 447 chunks of full-size C5's targets took 370 ms where 64 take 270 (measured: tools/r4_pack_sweep.sh)
+        const size_t CH = (size_t)ctx->opt_u64("HOST_PACK_CHUNK_WORDS", std::min<u64>((u64)16 << 20, std::max<u64>((u64)2 << 20, (w / 64 + 65535) & ~65535ull)));
+        if (!ctx->hp_stage[0] || ctx->hp_words < CH) {          // (hp_words: the buffers' capacity; a job lays its own chunk size out in them)
             if (ctx->uploader) ctx->uploader->drain();        // an earlier upload's job may still pack into the buffers about to go (it captured them and CH by value)
             for (int b = 0; b < 2; ++b) {
                 if (ctx->hp_stage[b]) { HIPCHK(ctx, hipStreamSynchronize(cs)); (void)hipHostFree(ctx->hp_stage[b]); ctx->hp_stage[b] = nullptr; }
@@ -245,7 +248,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
             ctx->uploader = new Uploader();
             if (!ctx->opt("HOST_PACK_NO_PIN")) ctx->uploader->cpus = hp_gpu_node_cpus(ctx->device);     // the GPU's own NUMA node
             const u32 hw = ctx->uploader->cpus.empty() ? std::max(2u, std::thread::hardware_concurrency()) : (u32)ctx->uploader->cpus.size() * 2;
-            ctx->uploader->pool.start((u32)std::max<u64>(1, ctx->opt_u64("HOST_PACK_THREADS", std::min<u32>(32, std::max<u32>(2, hw / 2)))) - 1, ctx->uploader->cpus);    // (>= 1: the uploader thread itself packs)
+            ctx->uploader->pool.start((u32)std::max<u64>(1, ctx->opt_u64("HOST_PACK_THREADS", std::min<u32>(32, std::max<u32>(2, hw / 2)))) - 1, ctx->uploader->cpus, ctx->opt("HOST_PACK_PIN_EACH") != nullptr);    // (>= 1: the uploader thread itself packs)
             if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] host-side pack: %zu worker threads on %zu CPUs of the GPU's NUMA node\n", ctx->uploader->pool.th.size(), ctx->uploader->cpus.size());
         }
         s->h_boff.resize((size_t)n + 1);

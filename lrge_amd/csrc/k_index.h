@@ -78,33 +78,53 @@ __device__ __forceinline__ u64 ht_home(u64 key, u64 cap, u32 fix) {
 #define PLACE_TILE (PLACE_THREADS * PLACE_ROWS)
 #define PLACE_COMP 384      // slots a wavefront composes in LDS (64 runs at load 1/2 span ~128)
 
-// The hash of entry `st` of the sorted stream.  seg_start != null: a segment-packed index (k_prims.h: index_sort_segpacked) --
-// the entry holds the hash without its low byte, which is the number of the segment the entry lies in.
-__device__ __forceinline__ u64 entry_hash(const u64 *__restrict__ skey, u32 st, u32 kshift, const u32 *__restrict__ seg_start) {
+// The hash of entry `st` of the sorted stream.  seg.start != null: a segment-packed index (k_prims.h: index_sort_segpacked) --
+// the entry holds the hash without the bits its segment implies: the low byte b0 and, with seg.e > 0, the top e bits q of the
+// second byte (a prefix of the byte-reversed order: segment number = b0 << e | q, 256 << e segments).
+struct SegStarts { const u32 *start; u32 e; };
+__host__ __device__ __forceinline__ u64 seg_hash(u64 h, u32 sgm, u32 e) {        // h = the stored bits, sgm = the segment's number
+    const u32 lb = 8 - e;                                                          // bits of the second byte that stay in the entry
+    return (h >> lb) << 16 | (u64)(sgm & ((1u << e) - 1)) << (16 - e) | (h & ((1u << lb) - 1)) << 8 | (sgm >> e);
+}
+// the last segment whose start is <= st (empty segments share their start with the next)
+__device__ __forceinline__ u32 seg_of(SegStarts seg, u32 st) {
+    const u32 n_seg = 256u << seg.e;
+    u32 lo = 0, hi = n_seg;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (seg.start[mid] <= st) lo = mid; else hi = mid; }
+    while (lo + 1 < n_seg && seg.start[lo + 1] <= st) ++lo;
+    return lo;
+}
+// hint: a segment at or in front of the entry's (the callers walk runs in ascending order: the segment of a block's first run, found
+// once, is that of nearly all of them -- 10 dependent loads per run otherwise)
+__device__ __forceinline__ u64 entry_hash(const u64 *__restrict__ skey, u32 st, u32 kshift, SegStarts seg, u32 hint = 0xFFFFFFFFu) {
     const u64 h = skey[st] >> kshift;
-    if (!seg_start) return h;
-    u32 lo = 0, hi = 256;                              // last segment whose start is <= st (empty segments share their start with the next)
-    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (seg_start[mid] <= st) lo = mid; else hi = mid; }
-    while (lo + 1 < 256 && seg_start[lo + 1] <= st) ++lo;
-    return h << 8 | lo;
+    if (!seg.start) return h;
+    u32 lo;
+    if (hint == 0xFFFFFFFFu) lo = seg_of(seg, st);
+    else { const u32 n_seg = 256u << seg.e; lo = hint; while (lo + 1 < n_seg && seg.start[lo + 1] <= st) ++lo; }
+    return seg_hash(h, lo, seg.e);
 }
 
 // d(r) = home(r) + (n_runs - r): slot(r) = prefix-max(d)(r) - (n_runs - r).  Needs cap + n_runs < 2^32.
 __device__ __forceinline__ u32 place_d(const u64 *__restrict__ skey, const u32 *__restrict__ run_start, u32 r, u32 n_runs, u64 cap, u32 kshift, u32 fix,
-                                       const u32 *__restrict__ seg_start) {
-    return (u32)ht_home(entry_hash(skey, run_start[r], kshift, seg_start), cap, fix) + (n_runs - r);
+                                       SegStarts seg_start, u32 hint = 0xFFFFFFFFu) {
+    return (u32)ht_home(entry_hash(skey, run_start[r], kshift, seg_start, hint), cap, fix) + (n_runs - r);
 }
 
 __global__ __launch_bounds__(PLACE_THREADS) void k_place_reduce(const u64 *__restrict__ skey, const u32 *__restrict__ run_start,
                                                                 u32 n_runs, u64 cap, u32 *__restrict__ bmax, u32 kshift, u32 fix,
-                                                                const u32 *__restrict__ seg_start) {
+                                                                SegStarts seg_start) {
     __shared__ u32 wm[PLACE_THREADS / 64];
+    __shared__ u32 seg0;
     u32 m = 0;
     const u32 base = blockIdx.x * PLACE_TILE;
+    if (threadIdx.x == 0) seg0 = seg_start.start && base < n_runs ? seg_of(seg_start, run_start[base]) : 0xFFFFFFFFu;
+    __syncthreads();
+    const u32 hint = seg0;
 #pragma unroll
     for (int i = 0; i < PLACE_ROWS; ++i) {
         const u32 r = base + i * PLACE_THREADS + threadIdx.x;
-        if (r < n_runs) { const u32 d = place_d(skey, run_start, r, n_runs, cap, kshift, fix, seg_start); m = d > m ? d : m; }
+        if (r < n_runs) { const u32 d = place_d(skey, run_start, r, n_runs, cap, kshift, fix, seg_start, hint); m = d > m ? d : m; }
     }
     for (int d = 32; d > 0; d >>= 1) { const u32 o = (u32)__shfl_xor((i32)m, d, 64); m = o > m ? o : m; }
     if (lane_id() == 0) wm[threadIdx.x >> 6] = m;
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
                                                                u64 *__restrict__ ht, u32 *__restrict__ occ_hist, u32 max_bin,
                                                                u32 *__restrict__ overflow, u32 kshift, u32 fix, u32 *__restrict__ last_slot,
                                                                const u64 *__restrict__ ypos, u32 pk_pos1, u32 inline_single,
-                                                               const u32 *__restrict__ seg_start) {
+                                                               SegStarts seg_start) {
     // ypos: the y values of the (hash, y) pair layout (null: packed entries, y is decoded from the entry itself)
     // last_slot != null: the table has NOT been cleared.  The runs of a wavefront occupy increasing slots, and the slot of the
     // run in front of the wavefront's first one is known from the same max-scan: every wavefront owns the contiguous slot
@@ -157,7 +177,7 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
     __shared__ ulonglong2 comp[PLACE_THREADS / 64][PLACE_COMP];
     __shared__ u32 lh[OCC_LDS_BINS];
     __shared__ u32 wm[PLACE_THREADS / 64];
-    __shared__ u32 carry_s;
+    __shared__ u32 carry_s, seg0_s;
     for (u32 i = threadIdx.x; i < OCC_LDS_BINS; i += blockDim.x) lh[i] = 0;
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     u32 disp_sum = 0;      // (per lane: at most a few thousand runs x small displacements)
@@ -166,9 +186,10 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
     // addresses from every block, so the number of blocks (not of runs) sets that serialised cost
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     __syncthreads();
-    if (threadIdx.x == 0) carry_s = bpre[tile];
-    __syncthreads();
     const u32 base = tile * PLACE_TILE;
+    if (threadIdx.x == 0) { carry_s = bpre[tile]; seg0_s = seg_start.start && base < n_runs ? seg_of(seg_start, run_start[base]) : 0xFFFFFFFFu; }
+    __syncthreads();
+    const u32 hint = seg0_s;
     for (int row = 0; row < PLACE_ROWS; ++row) {
         const u32 r = base + row * PLACE_THREADS + threadIdx.x;
         const bool in = r < n_runs;
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(PLACE_THREADS) void k_place_apply(const u64 *__rest
             st = run_start[r];
             const u64 en = (r + 1 < n_runs) ? run_start[r + 1] : n;
             cnt = (u32)(en - st);
-            key = entry_hash(skey, st, kshift, seg_start);
+            key = entry_hash(skey, st, kshift, seg_start, hint);
             d = (u32)ht_home(key, cap, fix) + (n_runs - r);
         }
         u32 inc = d;

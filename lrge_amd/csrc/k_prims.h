@@ -264,6 +264,8 @@ struct UnpackParams { u32 sb, bits_qy, sh_q, dmask; };   // dmask: digit mask of
 #define RS_MODE_KEYS 1
 #define RS_MODE_UNPACK 2
 #define RS_MODE_PACK 3      // (hash, y) pairs in, ONE packed u64 out: (hash >> 8) << up.sb | rid << up.bits_qy | (pos << 1 | strand); `shift` addresses the packed value
+#define RS_MODE_PACKQ 4     // the same, and the pass's digit -- the top e = up.sh_q bits of the second hash byte, `shift` = 16 - e addresses the HASH -- is
+                            // left out of the word as well (the pass makes it part of the segment: index_sort_segpacked with e > 0)
 
 // Blocks are observed to be dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Tile t and
 // tile t + 1 of a pass write adjacent runs in every digit's region, so they should meet in ONE L2: XCD x takes the
@@ -392,6 +394,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     __shared__ u32 gbase[ND];            // global destination of the tile's digit run minus its local start
     __shared__ u32 wtot[RS_WAVES];
     __shared__ u64 stage[RS_TILE];       // 32 KB: keys, then values
+    __shared__ u32 dloc[MODE == RS_MODE_PACKQ ? 17 : 1];   // PACKQ: the digit is not in the staged word -- tile-local start of every digit's run (at most 16 digits)
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     const u32 bid = xcd_tile(blockIdx.x, gridDim.x);
     const u32 dmask = MODE == RS_MODE_PAIRS ? 255u : up.dmask;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n_tile ? keys_in[base + (u64)r * 64] : ~0ULL;
     }
-    if (MODE == RS_MODE_PAIRS || MODE == RS_MODE_PACK) {
+    if (MODE == RS_MODE_PAIRS || MODE == RS_MODE_PACK || MODE == RS_MODE_PACKQ) {
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) v[r] = l0 + (u32)r * 64 < n_tile ? vals_in[base + (u64)r * 64] : 0;
     }
@@ -421,6 +424,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         for (int r = 0; r < RS_ITEMS; ++r)
             if (l0 + (u32)r * 64 < n_tile) k[r] = (k[r] >> 8) << up.sb | (v[r] >> 32) << up.bits_qy | (v[r] & pmask);
     }
+    // (PACKQ: the digit comes from the hash itself, so the word is packed only when it is staged)
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const bool valid = l0 + (u32)r * 64 < n_tile;
@@ -458,6 +462,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
             const u32 d = threadIdx.x * DPT + j;
             const u64 hi = SEG ? (u64)tiles[bid].hbase + (u64)d * tiles[bid].hstride : (u64)d * nb + bid;
             gbase[d] = hist_scanned[hi] + (SEG ? tiles[bid].delta : 0u) - dstart;
+            if (MODE == RS_MODE_PACKQ && d <= 16) dloc[d] = dstart;
             u32 run = dstart;
 #pragma unroll
             for (int ww = 0; ww < RS_WAVES; ++ww) { cnt[ww][d] = run; run += c[j][ww]; }
@@ -470,6 +475,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     for (int r = 0; r < RS_ITEMS; ++r) {
         u32 d = (u32)(k[r] >> shift) & dmask;
         lpos[r] = cnt[w][d] + rank[r];
+        if (MODE == RS_MODE_PACKQ) {
+            const u32 lb = 8 - up.sh_q;
+            k[r] = ((k[r] >> 16) << lb | ((k[r] >> 8) & ((1u << lb) - 1))) << up.sb | (v[r] >> 32) << up.bits_qy | (v[r] & ((1ULL << up.bits_qy) - 1));
+        }
         if (l0 + (u32)r * 64 < n_tile) stage[lpos[r]] = k[r];
     }
     __syncthreads();
@@ -492,9 +501,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         u32 p = (u32)r * RS_THREADS + threadIdx.x;
-        if (p < n_tile) { ko[r] = stage[p]; keys_out[gbase[(u32)(ko[r] >> shift) & dmask] + p] = ko[r]; }
+        if (p < n_tile) {
+            ko[r] = stage[p];
+            u32 d = (u32)(ko[r] >> shift) & dmask;
+            if (MODE == RS_MODE_PACKQ) {           // the digit whose run holds p: the last one that starts at or before it
+                d = 0;
+                for (u32 j = 1; j <= dmask; ++j) d += p >= dloc[j] ? 1u : 0u;
+            }
+            keys_out[gbase[d] + p] = ko[r];
+        }
     }
-    if (MODE == RS_MODE_KEYS || MODE == RS_MODE_PACK) return;
+    if (MODE == RS_MODE_KEYS || MODE == RS_MODE_PACK || MODE == RS_MODE_PACKQ) return;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
@@ -773,8 +790,8 @@ static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n,
     KCHK(ctx);
     int rc = scan_exclusive_u32(ctx, sc, bc, bc, nb, d_tot);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(n_heads, d_tot, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, ctx->d2h(n_heads, d_tot, 4, ctx->stream));
+    HIPCHK(ctx, ctx->d2h_sync(ctx->stream));             // (also lands what the caller queued with ctx->d2h: the segment starts of a segment-packed index)
     u32 *st = sc.get<u32>((size_t)*n_heads + 1);
     if (!st) return LRGE_ERR_DEVICE;
     hipLaunchKernelGGL(k_heads_fill, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, fl, bc, st);
@@ -879,6 +896,12 @@ __global__ __launch_bounds__(THREADS) void k_seg_sort_local(const u64 *__restric
     }
 }
 
+// out[i] = src[idx[i]] (idx[i] = ~0: left alone)
+__global__ void k_gather_index_u32(const u32 *__restrict__ src, const u32 *__restrict__ idx, u32 n, u32 *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && idx[i] != 0xFFFFFFFFu) out[i] = src[idx[i]];
+}
+
 // out[i] = src[i * stride] (the starts of the 256 first-digit segments out of a scanned histogram)
 __global__ void k_gather_strided_u32(const u32 *__restrict__ src, u64 stride, u32 n, u32 *__restrict__ out) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -897,12 +920,58 @@ __global__ void k_gather_strided_u32(const u32 *__restrict__ src, u64 stride, u3
 // LSD inside the segments: the order is the pair sort's.  seg_start[257] (host copy returned, device copy allocated from `sc`
 // and handed to the caller) says where every segment begins: run detection and the table build need the low byte back.
 // ------------------------------------------------------------------------------------------
-static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky, u64 *k1, u64 *v1, u64 n, int nbits, u32 ybits, u32 pos1,
-                                u64 **res, u32 **d_seg_start, std::vector<u32> *h_seg_start) {
+// Tile bookkeeping of the segmented passes, on the device: the sort has no host round trip (a part of full-size C5 has 610 000
+// tiles -- building them on the host and copying them cost two stream drains and ~10 ms per part).
+// tb[s] = tiles in front of segment s (exclusive prefix of ceil(count / RS_TILE)), tb[n_seg] = their number.  One block; n_seg <= 4096.
+__global__ __launch_bounds__(1024) void k_seg_tile_scan(const u32 *__restrict__ starts, u32 n_seg, u32 *__restrict__ tb) {
+    __shared__ u32 wsum[16];
+    const u32 per = (n_seg + 1023) / 1024, s0 = threadIdx.x * per;
+    u32 mine = 0;
+    for (u32 j = 0; j < per; ++j) { const u32 s = s0 + j; if (s < n_seg) mine += (starts[s + 1] - starts[s] + RS_TILE - 1) / RS_TILE; }
+    const u32 inc = wave_incl_scan_u32(mine);
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u32 run = inc - mine;
+    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) run += wsum[w];
+    for (u32 j = 0; j < per; ++j) { const u32 s = s0 + j; if (s < n_seg) { tb[s] = run; run += (starts[s + 1] - starts[s] + RS_TILE - 1) / RS_TILE; } }
+    if (threadIdx.x == 1023) tb[n_seg] = run;
+}
+// tiles[t] for t < max_tiles (the grid of every segmented pass): beyond tb[n_seg] an empty tile whose counts go to the spare
+// histogram slot 256 * max_tiles
+__global__ __launch_bounds__(256) void k_seg_tile_fill(const u32 *__restrict__ starts, const u32 *__restrict__ tb, u32 n_seg, u32 max_tiles, SegTile *__restrict__ tiles) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= max_tiles) return;
+    if (t >= tb[n_seg]) { tiles[t] = SegTile{0u, 0u, 256u * max_tiles, 0u, 0u, 0u, 0u, 0u}; return; }
+    u32 lo = 0, hi = n_seg;                            // the last s with tb[s] <= t (it has tiles: tb[s + 1] > t)
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (tb[mid] <= t) lo = mid; else hi = mid; }
+    const u32 lt = t - tb[lo], c = starts[lo + 1] - starts[lo], nt = tb[lo + 1] - tb[lo];
+    const u32 left = c - lt * RS_TILE;
+    tiles[t] = SegTile{starts[lo] + lt * RS_TILE, left < RS_TILE ? left : (u32)RS_TILE, 256u * tb[lo] + lt, nt, lo, 0u, 0u, 0u};
+}
+// where segment (b0, q) begins after pass A2: the scanned count of digit q in the first tile of b0 (hist index 256 tb + q nt); a
+// b0 without tiles is empty and its segments begin where it does.  fine[256 << e] = n.
+__global__ __launch_bounds__(256) void k_seg_fine_starts(const u32 *__restrict__ hist_scanned, const u32 *__restrict__ starts, const u32 *__restrict__ tb, u32 e, u32 n,
+                                                         u32 *__restrict__ fine) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, nf = 256u << e;
+    if (i > nf) return;
+    if (i == nf) { fine[i] = n; return; }
+    const u32 s = i >> e, q = i & ((1u << e) - 1), nt = tb[s + 1] - tb[s];
+    fine[i] = nt ? hist_scanned[256u * tb[s] + q * nt] : starts[s];
+}
+__global__ void k_store_u32(u32 *p, u32 v) { *p = v; }
+
+static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky, u64 *k1, u64 *v1, u64 n, int nbits, u32 ybits, u32 pos1, u32 e,
+                                u64 **res, u32 **d_seg_start) {
+    // e > 0 (round 4): nbits - 8 + ybits exceeds 64 by e bits (large parts: read ids of 19-20 bits), so e more hash bits have to be
+    // implied -- the NEXT bits of the byte-reversed order, the top e bits q of the second byte.  Pass A2 is a most-significant-digit
+    // pass on q inside each of A's 256 segments (pairs in, packed words out: RS_MODE_PACKQ), leaving 256 << e segments numbered
+    // b0 << e | q; the LSD passes behind it are all keys-only, the last one over the 8 - e bits of the second byte that remain.
+    // 32 + 24 + 16 (passes - 1) bytes per entry through the scatters (k = 19, e = 2: 120 instead of 160 for the pair sort).
     const int passes = (nbits + 7) / 8;
     auto dbits = [&](int d) { return nbits - 8 * d >= 8 ? 8 : nbits - 8 * d; };
-    const u32 nb = (u32)div_up(n, RS_TILE);
-    ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * (nb + 256 + 1));
+    const u32 nb = (u32)div_up(n, RS_TILE), n_seg = 256u << e;
+    const u32 max_tiles = nb + n_seg;                  // every segment ends in at most one partial tile
+    ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * (max_tiles + 1) + 256);
     // ---- pass A: pairs by the low hash byte ----
     {
         hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, kx, n, 0, nb, hist, (const SegTile *)nullptr, 255u);
@@ -915,49 +984,61 @@ static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky
         ts.stop();
         ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 32 * n;
     }
-    u32 *d_b = sc.get<u32>(257);
-    if (!d_b) return LRGE_ERR_DEVICE;
-    std::vector<u32> &bstart = *h_seg_start;
-    bstart.assign(257, 0);
-    hipLaunchKernelGGL(k_gather_strided_u32, dim3(1), dim3(256), 0, ctx->stream, hist, (u64)nb, 256u, d_b);
+    u32 *d_b = sc.get<u32>(n_seg + 1), *d_c = e ? sc.get<u32>(257) : nullptr, *d_tb = sc.get<u32>(n_seg + 1);
+    if (!d_b || !d_tb || (e && !d_c)) return LRGE_ERR_DEVICE;
+    u32 *coarse = e ? d_c : d_b;                       // the 256 segments of pass A
+    hipLaunchKernelGGL(k_gather_strided_u32, dim3(1), dim3(256), 0, ctx->stream, hist, (u64)nb, 256u, coarse);
+    hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, ctx->stream, coarse + 256, (u32)n);
     KCHK(ctx);
-    const u32 n32 = (u32)n;
-    HIPCHK(ctx, hipMemcpyAsync(d_b + 256, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, ctx->d2h(bstart.data(), d_b, 256 * 4, ctx->stream));
-    HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
-    bstart[256] = n32;
-    // ---- tiles of the segmented passes ----
-    std::vector<SegTile> tiles;
-    u32 tb = 0;
-    for (u32 s = 0; s < 256; ++s) {
-        const u32 c = bstart[s + 1] - bstart[s], nt = (u32)div_up((u64)c, RS_TILE);
-        for (u32 lt = 0; lt < nt; ++lt) tiles.push_back(SegTile{bstart[s] + lt * RS_TILE, std::min<u32>(RS_TILE, c - lt * RS_TILE), 256u * tb + lt, nt, s, 0u});
-        tb += nt;
-    }
-    const u32 n_tiles = (u32)tiles.size();
-    ALLOC_OR_FAIL(d_tiles, sc, u32, (size_t)n_tiles * (sizeof(SegTile) / 4) + 4);
-    HIPCHK(ctx, hipMemcpyAsync(d_tiles, tiles.data(), (size_t)n_tiles * sizeof(SegTile), hipMemcpyHostToDevice, ctx->stream));
-    // ---- the remaining digits, least significant first: d = passes - 1 (pairs in, packed out), then passes - 2 .. 1 ----
+    ALLOC_OR_FAIL(d_tiles, sc, u32, (size_t)max_tiles * (sizeof(SegTile) / 4) + 8);
+    u32 cur_tiles = nb + 256;                          // the grid of the passes over `cur_seg` segments
+    hipLaunchKernelGGL(k_seg_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)coarse, 256u, d_tb);
+    hipLaunchKernelGGL(k_seg_tile_fill, dim3(div_up(cur_tiles, 256)), dim3(256), 0, ctx->stream, (const u32 *)coarse, (const u32 *)d_tb, 256u, cur_tiles, (SegTile *)d_tiles);
+    KCHK(ctx);
     u64 *pi = kx, *po = ky;          // (the sketch's pair buffers are free once pass A has read them: they carry the packed words)
-    for (int d = passes - 1; d >= 1; --d) {
-        const bool first = d == passes - 1;
-        const u32 dm = (1u << dbits(d)) - 1u;
-        const int pshift = (int)ybits + 8 * (d - 1);             // where digit d sits in the packed word
-        if (first) hipLaunchKernelGGL(k_rs_hist<true>, dim3(n_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, n, 8 * d, n_tiles, hist, (const SegTile *)d_tiles, dm);
-        else hipLaunchKernelGGL(k_rs_hist<true>, dim3(n_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, n, pshift, n_tiles, hist, (const SegTile *)d_tiles, dm);
+    if (e) {
+        // ---- pass A2: inside every segment by q, packing ----
+        const u32 qm = (1u << e) - 1;
+        hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, n, 16 - (int)e, cur_tiles, hist, (const SegTile *)d_tiles, qm);
         KCHK(ctx);
-        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * n_tiles, nullptr); if (rc) return rc;
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * cur_tiles, nullptr); if (rc) return rc;
+        hipLaunchKernelGGL(k_seg_fine_starts, dim3(div_up(n_seg + 1, 256)), dim3(256), 0, ctx->stream, (const u32 *)hist, (const u32 *)coarse, (const u32 *)d_tb, e, (u32)n, d_b);
+        KCHK(ctx);
+        {
+            StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+            hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_PACKQ>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, v1, pi, (u64 *)nullptr, n, 16 - (int)e, cur_tiles, hist,
+                               (const SegTile *)d_tiles, UnpackParams{ybits, pos1, e, qm});
+            KCHK(ctx);
+            ts.stop();
+        }
+        ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 24 * n;
+        cur_tiles = max_tiles;
+        hipLaunchKernelGGL(k_seg_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)d_b, n_seg, d_tb);
+        hipLaunchKernelGGL(k_seg_tile_fill, dim3(div_up(cur_tiles, 256)), dim3(256), 0, ctx->stream, (const u32 *)d_b, (const u32 *)d_tb, n_seg, cur_tiles, (SegTile *)d_tiles);
+        KCHK(ctx);
+    }
+    // ---- the remaining digits, least significant first: d = passes - 1 (e == 0: pairs in, packed out), then passes - 2 .. 1 ----
+    // digit d >= 2 sits at bit 8 (d - 1) - e of the stored hash bits, digit 1 at bit 0 with 8 - e bits
+    for (int d = passes - 1; d >= 1; --d) {
+        const bool first = !e && d == passes - 1;
+        const u32 dm = (1u << (d == 1 ? 8 - (int)e : dbits(d))) - 1u;
+        const int pshift = (int)ybits + (d == 1 ? 0 : 8 * (d - 1) - (int)e);   // where digit d sits in the packed word
+        if (first) hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, n, 8 * d, cur_tiles, hist, (const SegTile *)d_tiles, dm);
+        else hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, n, pshift, cur_tiles, hist, (const SegTile *)d_tiles, dm);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * cur_tiles, nullptr); if (rc) return rc;
         StageTimer ts(ctx, LRGE_T_RS_SCATTER);
-        if (first) hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_PACK>), dim3(n_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, v1, pi, (u64 *)nullptr, n, pshift, n_tiles, hist,
+        if (first) hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_PACK>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, v1, pi, (u64 *)nullptr, n, pshift, cur_tiles, hist,
                                       (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm});
-        else hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(n_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, (const u64 *)nullptr, po, (u64 *)nullptr, n, pshift, n_tiles,
+        else hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, (const u64 *)nullptr, po, (u64 *)nullptr, n, pshift, cur_tiles,
                                 hist, (const SegTile *)d_tiles, UnpackParams{0, 0, 0, dm});
         KCHK(ctx);
         ts.stop();
         ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (first ? 24 : 16) * n;
         if (!first) { u64 *t = pi; pi = po; po = t; }
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // (`tiles` is a local)
+    if (d_c) sc.drop(d_c);
+    sc.drop(d_tb);
     sc.drop(hist); sc.drop((u32 *)d_tiles);
     *res = pi; *d_seg_start = d_b;
     return LRGE_OK;

@@ -152,14 +152,18 @@ def test_index_of_tiny_reads(ctx, oracle, slot_sort, knobs):
     ixd.free()
 
 
-@pytest.mark.parametrize("preset", ["ont", "pb"])
-def test_segment_packed_pair_index_is_exact(ctx, oracle, edge_set, tiny_ont, tiny_hifi, preset, knobs):
+@pytest.mark.parametrize("preset,extra", [("ont", 0), ("pb", 0), ("ont", 1), ("pb", 2), ("ont", 4), ("pb", 3)])
+def test_segment_packed_pair_index_is_exact(ctx, oracle, edge_set, tiny_ont, tiny_hifi, preset, extra, knobs):
     """The (hash, y) pair layout sorted in its segment-packed form (k_prims.h: index_sort_segpacked: the low hash byte first, then
     one packed word per entry inside its 256 segments) only engages above 4 M entries -- C5/10 and full-size C5 run it at scale.
-    Forced here onto small sets: index entries, lists, mid_occ and counts must be those of the plain pair sort and of the oracle."""
+    Forced here onto small sets: index entries, lists, mid_occ and counts must be those of the plain pair sort and of the oracle.
+    extra > 0: the form full-size C5 takes in 3 parts (read ids of 20 bits: the word is 2 bits short) -- the top `extra` bits of
+    the second hash byte are implied by the segment as well (pass A2, 256 << extra segments)."""
     from lrge_amd import engine
     knobs.set("NO_PACKED_INDEX", "1")
     knobs.set("SEG_PACK_MIN", "1")
+    if extra:
+        knobs.set("DEBUG_SEG_EXTRA", str(extra))
     qseqs, qnames, tseqs, tnames = edge_set
     Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset)
     keys, pos = ixd.dump()
@@ -172,6 +176,15 @@ def test_segment_packed_pair_index_is_exact(ctx, oracle, edge_set, tiny_ont, tin
     qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
     Q2, T2 = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
     res = {}
+    if extra:      # the extra pass really runs: one scatter launch more than the plain segment-packed build
+        knobs.set("DEBUG_SEG_EXTRA", "0")
+        c0 = ctx.counters()["rs_scatter_launches"]
+        engine.Index(ctx, T2, PRESETS[preset]).free()
+        c1 = ctx.counters()["rs_scatter_launches"]
+        knobs.set("DEBUG_SEG_EXTRA", str(extra))
+        engine.Index(ctx, T2, PRESETS[preset]).free()
+        c2 = ctx.counters()["rs_scatter_launches"]
+        assert (c2 - c1 == c1 - c0 + 1) or (c2 == c1 + 1), (c0, c1, c2)
     for seg in (True, False):
         if not seg:
             knobs.set("NO_SEG_PACK", "1")

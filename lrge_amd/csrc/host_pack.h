@@ -141,15 +141,9 @@ struct HostPool {
     std::vector<std::thread> th;
     std::mutex mu; std::condition_variable cv_go, cv_done;
     std::function<void(u32)> fn; u32 n_tasks = 0; std::atomic<u32> next{0}; u32 running = 0; u64 gen = 0; bool quit = false;
-    // each_own: worker t gets CPU cpus[t + 1] to itself (the node's cpulist names one hardware thread of every core before the
-    // siblings, so the first entries are distinct cores; entry 0 is left to the caller) instead of the whole set
-    void start(u32 n_threads, const std::vector<int> &cpus = std::vector<int>(), bool each_own = false) {
+    void start(u32 n_threads, const std::vector<int> &cpus = std::vector<int>()) {
         if (!th.empty()) return;
-        for (u32 t = 0; t < n_threads; ++t) {
-            th.emplace_back([this] { worker(); });
-            if (each_own && (size_t)t + 1 < cpus.size()) hp_pin_thread(th.back(), std::vector<int>(1, cpus[t + 1]));
-            else hp_pin_thread(th.back(), cpus);
-        }
+        for (u32 t = 0; t < n_threads; ++t) { th.emplace_back([this] { worker(); }); hp_pin_thread(th.back(), cpus); }
     }
     void worker() {
         u64 seen = 0;

@@ -248,7 +248,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
             ctx->uploader = new Uploader();
             if (!ctx->opt("HOST_PACK_NO_PIN")) ctx->uploader->cpus = hp_gpu_node_cpus(ctx->device);     // the GPU's own NUMA node
             const u32 hw = ctx->uploader->cpus.empty() ? std::max(2u, std::thread::hardware_concurrency()) : (u32)ctx->uploader->cpus.size() * 2;
-            ctx->uploader->pool.start((u32)std::max<u64>(1, ctx->opt_u64("HOST_PACK_THREADS", std::min<u32>(32, std::max<u32>(2, hw / 2)))) - 1, ctx->uploader->cpus, ctx->opt("HOST_PACK_PIN_EACH") != nullptr);    // (>= 1: the uploader thread itself packs)
+            ctx->uploader->pool.start((u32)std::max<u64>(1, ctx->opt_u64("HOST_PACK_THREADS", std::min<u32>(32, std::max<u32>(2, hw / 2)))) - 1, ctx->uploader->cpus);    // (>= 1: the uploader thread itself packs; a CPU of its own per worker instead of the node: measured, no difference)
             if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] host-side pack: %zu worker threads on %zu CPUs of the GPU's NUMA node\n", ctx->uploader->pool.th.size(), ctx->uploader->cpus.size());
         }
         s->h_boff.resize((size_t)n + 1);

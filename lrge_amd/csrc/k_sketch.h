@@ -12,7 +12,9 @@
 #include "internal.h"
 #include "k_prims.h"
 
+#ifndef SK_CHUNK
 #define SK_CHUNK 128            // bases per lane
+#endif
 #define SK_THREADS 256
 
 // ------------------------------------------------------------------------------------------

@@ -111,16 +111,18 @@ int main(int argc, char **argv) {
         u64 *k0 = sc.get<u64>(n), *k1 = sc.get<u64>(n); u32 *hist = sc.get<u32>((u64)1024 * nb);
         hipLaunchKernelGGL(k_fill, dim3((u32)div_up(n, 256)), dim3(256), 0, ctx.stream, k0, n, ybits, hbits, 12345ULL);
         hipEvent_t e[4]; for (auto &x : e) (void)hipEventCreate(&x);
-        for (int db : {8, 10, 8, 10}) {
+        for (int db : {8, 9, 10, 8, 9, 10}) {
             const u32 dm = (1u << db) - 1;
             (void)hipEventRecord(e[0], ctx.stream);
             if (db == 8) hipLaunchKernelGGL((k_rs_hist<false, 8>), dim3(nb), dim3(RS_THREADS), 0, ctx.stream, k0, n, ybits, nb, hist, (const SegTile *)nullptr, dm);
+            else if (db == 9) hipLaunchKernelGGL((k_rs_hist<false, 9>), dim3(nb), dim3(RS_THREADS), 0, ctx.stream, k0, n, ybits, nb, hist, (const SegTile *)nullptr, dm);
             else hipLaunchKernelGGL((k_rs_hist<false, 10>), dim3(nb), dim3(RS_THREADS), 0, ctx.stream, k0, n, ybits, nb, hist, (const SegTile *)nullptr, dm);
             (void)hipEventRecord(e[1], ctx.stream);
             (void)scan_exclusive_u32(&ctx, sc, hist, hist, ((u64)1 << db) * nb, nullptr);
             (void)hipEventRecord(e[2], ctx.stream);
             UnpackParams up{0, 0, 0, dm};
             if (db == 8) hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_KEYS, 8>), dim3(nb), dim3(RS_THREADS), 0, ctx.stream, k0, (const u64 *)nullptr, k1, (u64 *)nullptr, n, ybits, nb, hist, (const SegTile *)nullptr, up);
+            else if (db == 9) hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_KEYS, 9>), dim3(nb), dim3(RS_THREADS), 0, ctx.stream, k0, (const u64 *)nullptr, k1, (u64 *)nullptr, n, ybits, nb, hist, (const SegTile *)nullptr, up);
             else hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_KEYS, 10>), dim3(nb), dim3(RS_THREADS), 0, ctx.stream, k0, (const u64 *)nullptr, k1, (u64 *)nullptr, n, ybits, nb, hist, (const SegTile *)nullptr, up);
             (void)hipEventRecord(e[3], ctx.stream);
             (void)hipStreamSynchronize(ctx.stream);

@@ -613,6 +613,7 @@ def main():
         res_host = run_host(a.warmup, a.steps)
         if want_res:
             if gen == "cb":
+                ctx.set_option("POOL_TRIM", "1")       # the arena of the steps behind us holds most of the HBM: the ASCII reads need 31.5 GB of it back
                 job.load_resident()
             res_res = run_resident(1, k_other)
     else:

@@ -52,6 +52,9 @@ extern "C" int lrge_hip_ctx_set_option(lrge_hip_ctx *ctx, const char *name, cons
     if (!strcmp(name, "DEBUG_ALLOC_FAIL_EVERY")) { ctx->pool.fail_every = value ? atol(value) : 0; ctx->pool.misses = 0; }
     if (!strcmp(name, "DEBUG_ALLOC_FAIL_ALWAYS")) ctx->pool.fail_always = value != nullptr;
     if (!strcmp(name, "TIMERS") && value) ctx->timer_level = atoi(value);
+    // POOL_TRIM: an action, not a setting -- wholly idle arena segments go back to the runtime now (a caller that is about to place
+    // something large of its own beside the context: bench.py between its two clocks)
+    if (!strcmp(name, "POOL_TRIM")) { ctx->opts.erase(name); if (value) { (void)hipSetDevice(ctx->device); (void)hipDeviceSynchronize(); ctx->pool.trim(); } return LRGE_OK; }
     if (!strcmp(name, "POOL_SEG_MAX_MB")) ctx->pool.seg_max = value ? (size_t)std::max<u64>(64, strtoull(value, nullptr, 10)) << 20 : (size_t)32 << 30;
     return LRGE_OK;
 }

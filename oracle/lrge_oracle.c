@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <malloc.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -308,12 +309,31 @@ static int32_t calc_mid_occ(const lo_index_t *ix, const lo_opt_t *o)
     if (o->mid_occ_frac <= 0.f || ix->n_keys == 0) thres = INT32_MAX;
     else {
         uint64_t i, n = ix->n_keys;
-        uint32_t *cnt = (uint32_t *)malloc(n * 4), kth;
-        for (i = 0; i < n; ++i) cnt[i] = (uint32_t)(ix->off[i + 1] - ix->off[i]);
-        qsort(cnt, n, 4, cmp_u32);
-        kth = (uint32_t)((1. - (double)o->mid_occ_frac) * (double)n); /* 0-based k-th smallest */
-        thres = (int32_t)(cnt[kth] + 1);
-        free(cnt);
+        /* the k-th smallest count (mm2: ks_ksmall_uint32_t over all counts).  Small sets: sort, as before; large ones (a full
+           H. sapiens-scale index has 4 x 10^8 keys): select through a histogram of the counts below 2^20 -- the same order statistic */
+        uint64_t kth = (uint64_t)((1. - (double)o->mid_occ_frac) * (double)n); /* 0-based k-th smallest */
+        if (n < (1u << 22)) {
+            uint32_t *cnt = (uint32_t *)malloc(n * 4);
+            for (i = 0; i < n; ++i) cnt[i] = (uint32_t)(ix->off[i + 1] - ix->off[i]);
+            qsort(cnt, n, 4, cmp_u32);
+            thres = (int32_t)(cnt[kth] + 1);
+            free(cnt);
+        } else {
+            const uint32_t HB = 1u << 20;
+            uint64_t *hist = (uint64_t *)calloc((size_t)HB + 1, 8), run = 0, c;
+            uint32_t b, over_n = 0, *over = 0;
+            for (i = 0; i < n; ++i) { c = ix->off[i + 1] - ix->off[i]; ++hist[c < HB ? c : HB]; }
+            for (b = 0; b < HB && run + hist[b] <= kth; ++b) run += hist[b];
+            if (b < HB) thres = (int32_t)(b + 1);
+            else {      /* the k-th count is one of the few >= 2^20: sort those */
+                over = (uint32_t *)malloc((hist[HB] ? hist[HB] : 1) * 4);
+                for (i = 0; i < n; ++i) { c = ix->off[i + 1] - ix->off[i]; if (c >= HB) over[over_n++] = (uint32_t)c; }
+                qsort(over, over_n, 4, cmp_u32);
+                thres = (int32_t)(over[kth - run] + 1);
+                free(over);
+            }
+            free(hist);
+        }
     }
     if (thres < o->min_mid_occ) thres = o->min_mid_occ;
     if (o->max_mid_occ > o->min_mid_occ && thres > o->max_mid_occ) thres = o->max_mid_occ;
@@ -1272,8 +1292,25 @@ int lo_inverse_skip(int32_t qlen, int32_t qs, int32_t qe, int rev, int32_t tlen,
 /* ------------------------------------------------------------------------------------------ */
 #define MAX_REGS_PER_QUERY 65536
 
+/* Every query allocates a dozen arrays sized by its anchors (minimap2 takes them from kalloc, a per-thread arena: mm_tbuf_t,
+   thread_buf.rs:7-42).  With glibc's defaults each one above 128 KB is its own mmap / munmap, and 256 mapping threads then queue
+   for the process's address-space lock instead of mapping -- an artefact of this port, not of the algorithm.  Served from
+   the threads' malloc arenas, never trimmed, the allocations behave like kalloc's.  LO_NO_MALLOPT=1 keeps glibc's defaults
+   (the A/B of tools/cpu_port_scaling.py). */
+static void tune_malloc(void)
+{
+    static int done = 0;
+    if (done) return;
+    done = 1;
+    if (getenv("LO_NO_MALLOPT")) return;
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, INT_MAX);
+    mallopt(M_TOP_PAD, 64 << 20);
+}
+
 static void set_threads(int threads)
 {
+    tune_malloc();
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #else

@@ -152,6 +152,18 @@ class ReadSet:
             if self.n and int(self.offsets[-1]) > 0 else np.zeros(1, dtype=np.uint8)
         self._cnames = _names_array(self.names)
 
+    @classmethod
+    def from_arrays(cls, bases, offsets, names):
+        """The same set from its concatenated bases and offsets as they are (no per-read Python objects: sets of 10^6 reads)."""
+        self = cls.__new__(cls)
+        self.n = len(offsets) - 1
+        self.names = [n if isinstance(n, bytes) else n.encode() for n in names]
+        assert len(self.names) == self.n
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.bases = np.ascontiguousarray(bases, dtype=np.uint8) if len(bases) else np.zeros(1, dtype=np.uint8)
+        self._cnames = _names_array(self.names)
+        return self
+
     def seq(self, i):
         return self.bases[int(self.offsets[i]):int(self.offsets[i + 1])].tobytes()
 

@@ -275,9 +275,12 @@ def test_c5_tenth_forward_and_inverse(ctx, oracle, c5_tenth, preset, knobs):
     Qd.free(); Td.free()
 
 
-def test_c5_full(ctx, oracle):
-    """BASELINE configs[4] at FULL size on one GPU: H. sapiens-scale HiFi, -Q 100 000 -T 2 000 000 (31.5 Gbases), preset
-    ava-pb.  The reads are written straight into HBM by the device twin of the counter-based generator
+@pytest.mark.parametrize("preset", [1, 0], ids=["ava-pb", "ava-ont"])
+def test_c5_full(ctx, oracle, preset):
+    """BASELINE configs[4] at FULL size on one GPU: H. sapiens-scale HiFi, -Q 100 000 -T 2 000 000 (31.5 Gbases), under BOTH
+    presets SURVEY 8(d) asks for: ava-pb (the library's preset for PacBio, preset.rs:24-26) and ava-ont -- what the reference CLI
+    really runs on a HiFi set, because main.rs:56-85 never forwards cli.rs:32-34's -P to the strategy builders (k = 15, no HPC:
+    10.19 G index minimizers instead of 7.49 G, mid_occ 140, ~44 k anchors per query).  The reads are written straight into HBM by the device twin of the counter-based generator
     (lrge_amd/synth_cb.py; the host twin feeds the oracle the very same reads, tests/test_synth_cb.py).
 
     inverse (--use-min-ref, twoset.rs:370-584, what the reference itself picks at this size):
@@ -297,7 +300,7 @@ def test_c5_full(ctx, oracle):
     from lrge_amd import engine, synth_cb
     spec, Q, T = synth_cb.spec_of("c5_human_twoset")
     assert (Q, T) == (100000, 2000000)
-    preset = 1
+    pname = "ava-pb" if preset else "ava-ont"
     dq, dt = spec.device_reads(0, Q), spec.device_reads(Q, T)
     assert dq.total_bases + dt.total_bases > 31_000_000_000
     for dr, first in ((dq, 0), (dt, Q)):                         # the twins agree on this very set (both ends of each set)
@@ -344,7 +347,7 @@ def test_c5_full(ctx, oracle):
     import zlib
     chk = spec.host_reads(idx=[0, Q - 1, Q, Q + T // 2, Q + T - 1])
     assert fx["reads_crc32"] == "%08x" % (zlib.crc32(chk.bases.tobytes()) & 0xFFFFFFFF), "fixture made with another generator"
-    assert {k: st[k] for k in ("n_minimizers", "n_keys", "mid_occ")} == {k: fx["ava-pb"][k] for k in ("n_minimizers", "n_keys", "mid_occ")}
+    assert {k: st[k] for k in ("n_minimizers", "n_keys", "mid_occ")} == {k: fx[pname][k] for k in ("n_minimizers", "n_keys", "mid_occ")}
     assert st["n_minimizers"] > 2**32          # more than one index part can hold
     counts, has = ix.overlap_twoset(Qd)
     #  * FORWARD counts against the oracle at full size: 256 queries spread over the whole set (every index
@@ -356,7 +359,7 @@ def test_c5_full(ctx, oracle):
     from lrge_amd import paf
     from oracle import c5_sample
     idx = c5_sample.sample_indices(Q, 256)
-    fs = c5_sample.forward_sample(spec, Q, T, preset, idx, fx["ava-pb"]["mid_occ"], source="device", threads=THREADS)
+    fs = c5_sample.forward_sample(spec, Q, T, preset, idx, fx[pname]["mid_occ"], source="device", threads=THREADS)
     assert fs["n_minimizers_seen"] == st["n_minimizers"]
     assert np.array_equal(counts[idx], fs["counts"]), "forward counts differ from the oracle on %d of %d sampled queries" % (int((counts[idx] != fs["counts"]).sum()), len(idx))
     assert np.array_equal(has[idx], fs["has_mapping"])

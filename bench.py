@@ -81,7 +81,7 @@ def cpu_baseline(q, t, budget_s, preset):
     (index time scales linearly in target bases and is pro-rated to the full set), then as many query reads as fit in the
     budget are mapped with all cores against it."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = O.default_threads()       # (threads actually used: twice the CPUs the host grants, oracle.host_cpus)
     opt = O.make_opt(O.PRESET_AVA_PB if preset else O.PRESET_AVA_ONT, dual=True)
     T = O.ReadSet(t.seqs(), t.names)
     t0 = time.perf_counter()
@@ -101,7 +101,7 @@ def cpu_baseline(q, t, budget_s, preset):
         done = hi
     frac = done / q.n
     reads_per_s = done / (t_map + t_index * frac)
-    return dict(value=reads_per_s, unit="reads/s", cores=cores, kind="port",
+    return dict(value=reads_per_s, unit="reads/s", cores=cores, kind="port", host_cpus_granted=O.host_cpus(), host_hw_threads=os.cpu_count(),
                 sample="first %d of %d query reads mapped on %d threads (%.1f s) against the full %d-read target index "
                        "(built in %.1f s on the same threads: sketch + bucket sort parallel, scatter serial; pro-rated x%.3f)"
                        % (done, q.n, cores, t_map, t.n, t_index, frac),
@@ -161,7 +161,7 @@ def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
     the seed hits, anchors and chains of a query grow with the number of target reads, its own sketch (a small part)
     does not, so this slightly overstates the CPU's time per read and is labelled as what it is: a sample."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = O.default_threads()       # (threads actually used: twice the CPUs the host grants, oracle.host_cpus)
     F = 40
     nt = max(1000, Tn // F)
     opt = O.make_opt(O.PRESET_AVA_PB if preset else O.PRESET_AVA_ONT, dual=True)
@@ -181,7 +181,7 @@ def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
         done = hi
     scale = Tn / nt
     t_job = scale * t_index + scale * (t_map / done) * Qn
-    return dict(value=Qn / t_job, unit="reads/s", cores=cores, kind="port",
+    return dict(value=Qn / t_job, unit="reads/s", cores=cores, kind="port", host_cpus_granted=O.host_cpus(), host_hw_threads=os.cpu_count(),
                 sample="SAMPLE of the job: oracle index over %d of the %d target reads (%.1f s), %d query reads mapped against it on %d "
                        "threads (%.1f s); pro-rated x%.1f in the target dimension (index time and per-read map time both scale with "
                        "the number of target reads) and to all %d queries" % (nt, Tn, t_index, done, cores, t_map, scale, Qn),
@@ -485,6 +485,19 @@ def main():
                 S.host = S.dev.to_host
 
         def step(self, src_q, src_t):
+            """One step; a rank that fails anywhere in it aborts the communicator (lrge_hip_comm_abort) on its way out, so that its
+            peers leave the collective they are waiting in with an error instead of waiting for ever."""
+            try:
+                return self._step(src_q, src_t)
+            except BaseException:
+                if self.comm is not None:
+                    try:
+                        self.comm.abort()
+                    except Exception:      # noqa: BLE001
+                        pass
+                raise
+
+        def _step(self, src_q, src_t):
             """src_*: int device pointer (ASCII resident in HBM) or PinnedBuffer (ASCII in pinned host memory)."""
             ctx, comm, qs, ts = self.ctx, self.comm, self.qs, self.ts
             if a.inverse:
@@ -790,6 +803,8 @@ def main():
                     # of the sample (oracle/c5_sample.py; every target read goes through the oracle's mm_sketch), mid_occ / n_keys /
                     # n_minimizers from the oracle's committed KeyStats fixture
                     from oracle import c5_sample
+                    from oracle import oracle as _O
+                    O_threads = _O.default_threads()
                     fx = c5_sample.fixture_stats(spec, Qn, Tn, "ava-pb" if preset else "ava-ont")
                     idx = c5_sample.sample_indices(Qn, a.parity_sample)
                     if job.qs.dev.ptr:       # make room: the sample's target chunks are written by the device twin
@@ -803,7 +818,7 @@ def main():
                         "n_keys_equal": bool(fx["n_keys"] == st["n_keys"]),
                         "oracle": "restricted index (lo_ridx_*): complete position lists of the sample's keys out of all %d target minimizers "
                                   "(%d kept); %.1f s on %d threads (reads %.1f, sketch + filter %.1f, map %.1f)"
-                                  % (r["n_minimizers_seen"], r["n_kept"], r["seconds"], os.cpu_count() or 1, r["seconds_reads"], r["seconds_sketch"], r["seconds_map"]),
+                                  % (r["n_minimizers_seen"], r["n_kept"], r["seconds"], O_threads, r["seconds_reads"], r["seconds_sketch"], r["seconds_map"]),
                         "overlaps_in_sample": int(r["counts"].sum())}
             else:
                 if gen == "cb":

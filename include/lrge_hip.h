@@ -189,7 +189,12 @@ int  lrge_hip_index_build_sharded(lrge_hip_ctx *ctx, const uint32_t *all_target_
    what mm_idx_cal_max_occ / mm_mapopt_update see (aligner.rs:189): every rank sends (hash, local count) per distinct key of its
    table to the hash's owner rank, the owners add up, one small all-reduce yields n_keys / n_minimizers / mid_occ of the whole
    target set (lrge_hip_index_stats reports those), and the keys above mid_occ are dropped in every rank's table.  No index entry
-   crosses a link.  Collective: every rank of `comm` calls it; a failure on one rank fails it on all. */
+   crosses a link.  Collective: every rank of `comm` calls it; a failure on one rank fails it on all (the build ends with an
+   agreement: no rank leaves with LRGE_OK alone).
+   PRECONDITION the caller checks (it holds every target's name rank; lrge_amd/parallel.py: cross_shard_duplicates, the Rust shim):
+   no target identifier occurs in two DIFFERENT shards.  The reference counts distinct target NAMES (twoset.rs:286-317) and never
+   rejects a duplicate id in this mode; a duplicate inside one shard is counted once, one across shards would be counted once per
+   shard.  (A partitioned single-GPU index has the same limit and checks it itself: LRGE_ERR_DUPLICATE_ID.) */
 int  lrge_hip_index_build_tsharded(lrge_hip_ctx *ctx, const lrge_hip_seqset *target_shard, int preset, lrge_hip_comm *comm,
                                    lrge_hip_index **out);
 /* Exchange volumes of the last lrge_hip_index_build_sharded on this context: {key-set bytes contributed, entries sketched here,
@@ -282,6 +287,13 @@ int  lrge_hip_comm_allgather(lrge_hip_comm *c, const void *send, size_t bytes, v
 int  lrge_hip_comm_alltoallv(lrge_hip_comm *c, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off,
                              size_t elem_bytes);
 /* Ranks RCCL itself counts in this communicator (ncclCommCount); 0 for the local / host transports. */
+/* A rank that cannot go on between two collectives (a failed upload before a collective index build, a failed overlap call before
+ * the all-reduce that closes the step) calls this instead of leaving its peers waiting for it: the reference's workers propagate a
+ * MapError by ending the whole run (twoset.rs:279-284).  local: the group is aborted -- every rank blocked in, or later entering, one
+ * of its collectives returns LRGE_ERR_DEVICE; RCCL: ncclCommAbort on this rank's communicator (its peers end with their own
+ * processes: the launcher's job); host callbacks: the caller owns the collectives.  Afterwards every collective on c fails at once;
+ * lrge_hip_comm_destroy is still to be called. */
+int  lrge_hip_comm_abort(lrge_hip_comm *c);
 int  lrge_hip_comm_rccl_ranks(const lrge_hip_comm *c, int *n);
 /* Timing emulation of a world on ONE GPU (local groups only): with serialize on, the ranks of the group take turns -- a rank
    computes between lrge_hip_comm_local_turn(c, 1) and (c, 0) and hands the GPU over whenever it waits for the others inside

@@ -75,6 +75,7 @@ extern "C" {
     fn lrge_hip_comm_create_local(ctx: *mut lrge_hip_ctx, rank: c_int, group: *mut c_void,
                                   out: *mut *mut lrge_hip_comm) -> c_int;
     fn lrge_hip_comm_destroy(c: *mut lrge_hip_comm);
+    fn lrge_hip_comm_abort(c: *mut lrge_hip_comm) -> c_int;
     fn lrge_hip_comm_allgather(c: *mut lrge_hip_comm, send: *const c_void, bytes: usize, recv: *mut c_void) -> c_int;
     fn lrge_hip_comm_allreduce_u32(c: *mut lrge_hip_comm, inout: *mut u32, n: usize) -> c_int;
 }
@@ -355,18 +356,20 @@ pub fn twoset_estimates_target_sharded(job: &TwoSetJob, devices: &[i32]) -> crat
     let ranks = name_ranks(&[&t.names, &q.names]);
     let (q_lens, t_lens) = (q.lens(), t.lens());
     let t_bounds = shard_by_bases(&t_lens, world);
+    if cross_shard_duplicates(&ranks[0], &t_bounds) { return twoset_estimates_multi(job, devices); }   // (names shared across shards: sharded by query instead)
     let mut group = ptr::null_mut();
     check!(ptr::null(), lrge_hip_comm_local_group_create(world as c_int, &mut group));
     let group = SendPtr(group);
     let p = lrge_hip_params { remove_internal: job.remove_internal as i32, max_overhang_ratio: job.max_overhang_ratio };
+    let nq = q_lens.len();
     let results: Vec<crate::Result<(Vec<f32>, u32)>> = std::thread::scope(|sc| {
         let handles: Vec<_> = (0..world).map(|r| {
             let (t, q, ranks, q_lens, group, t_bounds) = (&t, &q, &ranks, &q_lens, &group, &t_bounds);
             let device = devices[r];
             sc.spawn(move || -> crate::Result<(Vec<f32>, u32)> {
                 let ctx = Ctx::new(device)?;
-                let mut comm = ptr::null_mut();
-                check!(ctx.h, lrge_hip_comm_create_local(ctx.h, r as c_int, group.0, &mut comm));
+                // from here on a `?` drops `comm` armed: the group is aborted and no peer waits for this rank
+                let mut comm = Comm::local(&ctx, r, group)?;
                 let (t0, t1) = (t_bounds[r], t_bounds[r + 1]);
                 let tsub = ReadSet {
                     bases: t.bases[t.offsets[t0] as usize..t.offsets[t1] as usize].to_vec(),
@@ -376,14 +379,23 @@ pub fn twoset_estimates_target_sharded(job: &TwoSetJob, devices: &[i32]) -> crat
                 let ts = ctx.upload(&tsub, &ranks[0][t0..t1])?;
                 let qs = ctx.upload(q, &ranks[1])?;                                 // ALL queries on every rank
                 let mut h = ptr::null_mut();
-                check!(ctx.h, lrge_hip_index_build_tsharded(ctx.h, ts.h, preset, comm, &mut h));     // collective
+                check!(ctx.h, lrge_hip_index_build_tsharded(ctx.h, ts.h, preset, comm.h, &mut h));   // collective, and failure-collective
                 let ix = Index { h, _ctx: &ctx };
-                let (mut counts, mut has) = ctx.overlap_twoset(&ix, &qs, &p)?;
-                check!(ctx.h, lrge_hip_comm_allreduce_u32(comm, counts.as_mut_ptr(), counts.len()));   // disjoint targets: counts add up
-                check!(ctx.h, lrge_hip_comm_allreduce_u32(comm, has.as_mut_ptr(), has.len()));         // ... and has_mapping ORs
-                unsafe { lrge_hip_comm_destroy(comm) };
-                let est = ctx.estimates(&counts, q_lens, job.avg_target_len, job.target_num_reads as u64, 100)?;
-                Ok((est, has.iter().filter(|&&h| h == 0).count() as u32))
+                // The overlap call is this rank's own: if it fails the rank STILL enters the all-reduce that closes the step -- zeros
+                // and a status word -- and returns its error afterwards; its peers see the word and fail too.  One vector
+                // [counts | has_mapping | status]: disjoint targets, so the counts add up and has_mapping ORs.
+                let mine = ctx.overlap_twoset(&ix, &qs, &p);
+                let mut v = vec![0u32; 2 * nq + 1];
+                match &mine {
+                    Ok((counts, has)) => { v[..nq].copy_from_slice(counts); v[nq..2 * nq].copy_from_slice(has); }
+                    Err(_) => v[2 * nq] = 1,
+                }
+                check!(ctx.h, lrge_hip_comm_allreduce_u32(comm.h, v.as_mut_ptr(), v.len()));
+                comm.done();
+                mine?;
+                if v[2 * nq] != 0 { return Err(crate::LrgeError::ThreadError(format!("{} other GPU worker(s) failed in the overlap step", v[2 * nq]))); }
+                let est = ctx.estimates(&v[..nq], q_lens, job.avg_target_len, job.target_num_reads as u64, 100)?;
+                Ok((est, v[nq..2 * nq].iter().filter(|&&h| h == 0).count() as u32))
             })
         }).collect();
         handles.into_iter().map(|h| h.join().expect("GPU worker panicked")).collect()
@@ -392,6 +404,34 @@ pub fn twoset_estimates_target_sharded(job: &TwoSetJob, devices: &[i32]) -> crat
     let mut first = None;
     for r in results { let v = r?; if first.is_none() { first = Some(v); } }
     Ok(first.expect("world >= 2"))
+}
+
+/// A rank's communicator.  Dropped while still ARMED -- the rank is leaving through `?` between two collectives -- it aborts the
+/// group first (`lrge_hip_comm_abort`): the peers blocked in, or heading for, the next collective return an error instead of waiting
+/// for a rank that will never arrive, `thread::scope` joins, and the run ends with the failed rank's error, as a `MapError` ends the
+/// reference's run (twoset.rs:279-284).
+struct Comm { h: *mut lrge_hip_comm, armed: bool }
+impl Comm {
+    fn local(ctx: &Ctx, rank: usize, group: &SendPtr) -> crate::Result<Comm> {
+        let mut h = ptr::null_mut();
+        check!(ctx.h, lrge_hip_comm_create_local(ctx.h, rank as c_int, group.0, &mut h));
+        Ok(Comm { h, armed: true })
+    }
+    /// the step's last collective has been left: nothing to abort any more
+    fn done(&mut self) { self.armed = false; }
+}
+impl Drop for Comm {
+    fn drop(&mut self) { unsafe { if self.armed { lrge_hip_comm_abort(self.h); } lrge_hip_comm_destroy(self.h) } }
+}
+
+/// True if a target identifier occurs in two DIFFERENT shards (`bounds` from `shard_by_bases`; equal names <=> equal rank).  The
+/// shards' distinct-target counts add up only over disjoint names (twoset.rs:286-317 counts `target_name`s and never rejects a
+/// duplicate id): such a set goes to `twoset_estimates_multi` (queries sharded) or to one GPU.
+pub fn cross_shard_duplicates(target_ranks: &[u32], bounds: &[usize]) -> bool {
+    let mut rp: Vec<(u32, u32)> = Vec::with_capacity(target_ranks.len());
+    for s in 0..bounds.len() - 1 { for i in bounds[s]..bounds[s + 1] { rp.push((target_ranks[i], s as u32)); } }
+    rp.sort_unstable();
+    rp.windows(2).any(|w| w[0].0 == w[1].0 && w[0].1 != w[1].1)
 }
 
 struct SendPtr(*mut c_void);
@@ -425,8 +465,7 @@ pub fn twoset_estimates_multi(job: &TwoSetJob, devices: &[i32]) -> crate::Result
             sc.spawn(move || -> crate::Result<(Vec<f32>, u32)> {
                 let (lo, hi) = (bounds[r], bounds[r + 1]);
                 let ctx = Ctx::new(device)?;
-                let mut comm = ptr::null_mut();
-                check!(ctx.h, lrge_hip_comm_create_local(ctx.h, r as c_int, group.0, &mut comm));
+                let mut comm = Comm::local(&ctx, r, group)?;       // (armed: a `?` below aborts the group instead of leaving the peers waiting)
                 let sub = ReadSet {
                     bases: q.bases[q.offsets[lo] as usize..q.offsets[hi] as usize].to_vec(),
                     offsets: q.offsets[lo..=hi].iter().map(|o| o - q.offsets[lo]).collect(),
@@ -443,18 +482,18 @@ pub fn twoset_estimates_multi(job: &TwoSetJob, devices: &[i32]) -> crate::Result
                 let qs = ctx.upload(&sub, &ranks[1][lo..hi])?;
                 let mut h = ptr::null_mut();
                 check!(ctx.h, lrge_hip_index_build_sharded(ctx.h, t_lens.as_ptr(), ranks[0].as_ptr(), t_lens.len() as u32, ts.h,
-                                                           t0 as u32, preset, qs.h, comm, &mut h));       // collective
+                                                           t0 as u32, preset, qs.h, comm.h, &mut h));     // collective
                 let ix = Index { h, _ctx: &ctx };
                 let (counts, has) = ctx.overlap_twoset(&ix, &qs, &p)?;
                 let est = ctx.estimates(&counts, &q_lens[lo..hi], job.avg_target_len, job.target_num_reads as u64, 100)?;
                 let mut send = vec![f32::NAN; max_len.max(1)];
                 send[..est.len()].copy_from_slice(&est);
                 let mut recv = vec![0f32; max_len.max(1) * world];
-                check!(ctx.h, lrge_hip_comm_allgather(comm, send.as_ptr() as *const c_void, send.len() * 4,
+                check!(ctx.h, lrge_hip_comm_allgather(comm.h, send.as_ptr() as *const c_void, send.len() * 4,
                                                       recv.as_mut_ptr() as *mut c_void));
                 let mut nm = [has.iter().filter(|&&h| h == 0).count() as u32];
-                check!(ctx.h, lrge_hip_comm_allreduce_u32(comm, nm.as_mut_ptr(), 1));
-                unsafe { lrge_hip_comm_destroy(comm) };
+                check!(ctx.h, lrge_hip_comm_allreduce_u32(comm.h, nm.as_mut_ptr(), 1));
+                comm.done();
                 let m = max_len.max(1);
                 let mut all = Vec::with_capacity(q_lens.len());
                 for rr in 0..world { all.extend_from_slice(&recv[rr * m..rr * m + (bounds[rr + 1] - bounds[rr])]); }

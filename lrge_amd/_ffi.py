@@ -26,7 +26,7 @@ EXPORTS = [
     "lrge_hip_comm_alltoallv", "lrge_hip_comm_rccl_ranks", "lrge_hip_comm_local_group_serialize", "lrge_hip_comm_local_turn",
     "lrge_hip_comm_busy_ms",
     "lrge_hip_comm_unique_id", "lrge_hip_comm_create", "lrge_hip_comm_local_group_create", "lrge_hip_comm_local_group_destroy",
-    "lrge_hip_comm_create_local", "lrge_hip_comm_create_host", "lrge_hip_comm_destroy", "lrge_hip_comm_rank", "lrge_hip_comm_world",
+    "lrge_hip_comm_create_local", "lrge_hip_comm_create_host", "lrge_hip_comm_destroy", "lrge_hip_comm_abort", "lrge_hip_comm_rank", "lrge_hip_comm_world",
     "lrge_hip_comm_allreduce_u32", "lrge_hip_comm_allgather", "lrge_hip_index_stats",
     "lrge_hip_overlap_twoset", "lrge_hip_overlap_inverse", "lrge_hip_overlap_ava", "lrge_hip_chains",
     "lrge_hip_estimates", "lrge_hip_median", "lrge_hip_paf_stats",

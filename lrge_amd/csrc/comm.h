@@ -26,6 +26,7 @@ struct RcclApi {
     int (*GetUniqueId)(lrge_ncclUniqueId *) = nullptr;
     int (*CommInitRank)(lrge_ncclComm_t *, int, lrge_ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(lrge_ncclComm_t) = nullptr;
+    int (*CommAbort)(lrge_ncclComm_t) = nullptr;        // (optional symbol)
     int (*AllReduce)(const void *, void *, size_t, int, int, lrge_ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, lrge_ncclComm_t, hipStream_t) = nullptr;
     int (*Send)(const void *, size_t, int, int, lrge_ncclComm_t, hipStream_t) = nullptr;
@@ -45,6 +46,7 @@ struct RcclApi {
         GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
         CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))dlsym(lib, "ncclCommAbort");
         AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
         AllGather = (decltype(AllGather))sym("ncclAllGather");
         Send = (decltype(Send))sym("ncclSend");
@@ -105,6 +107,7 @@ struct lrge_hip_comm {
     // RCCL transport: a small device block taken ONCE at creation for the host-buffer collectives below (the status-carrying
     // vectors of a collective build), so that a rank that has just run out of memory can still JOIN a collective to say so
     char *d_small = nullptr; static constexpr size_t kSmall = (size_t)1 << 20;
+    bool aborted = false;                // lrge_hip_comm_abort: every later collective of this communicator fails at once
     bool in_turn = false; double busy_ms = 0, t_acquired = 0, alloc_ms0 = 0;     // (serialized local groups)
     double wait_ms = 0;                   // wall time spent inside barriers of the local transport (waiting for the other ranks)
 };
@@ -146,6 +149,10 @@ static bool grp_barrier(lrge_hip_comm *c) {
         }                                                                                                           \
     } while (0)
 
+// a communicator this rank has aborted (lrge_hip_comm_abort) takes part in nothing any more
+#define COMM_LIVE(c)                                                                                                \
+    do { if ((c)->aborted && (c)->world > 1) { LRGE_SET_ERR((c)->ctx, "communicator was aborted"); return LRGE_ERR_DEVICE; } } while (0)
+
 #define NCCLCHK(ctx, call)                                                                                          \
     do {                                                                                                            \
         const int _r = (call);                                                                                      \
@@ -158,6 +165,7 @@ static bool grp_barrier(lrge_hip_comm *c) {
 // In-place SUM all-reduce of n elements of `esz` bytes (4: u32, 8: u64) in DEVICE memory, ordered on `st`.
 static int comm_allreduce_sum(lrge_hip_comm *c, void *dbuf, size_t n, int esz, hipStream_t st) {
     lrge_hip_ctx *ctx = c->ctx;
+    COMM_LIVE(c);
     if (c->world == 1 || n == 0) return LRGE_OK;
     if (c->nccl) {
         NCCLCHK(ctx, g_rccl.AllReduce(dbuf, dbuf, n, esz == 8 ? LRGE_NCCL_UINT64 : LRGE_NCCL_UINT32, LRGE_NCCL_SUM, c->nccl, st));
@@ -189,6 +197,7 @@ static int comm_allreduce_sum(lrge_hip_comm *c, void *dbuf, size_t n, int esz, h
 // All-gather of `bytes` bytes per rank between DEVICE buffers (recv holds world * bytes), ordered on `st`.
 static int comm_allgather(lrge_hip_comm *c, const void *dsend, size_t bytes, void *drecv, hipStream_t st) {
     lrge_hip_ctx *ctx = c->ctx;
+    COMM_LIVE(c);
     if (bytes == 0) return LRGE_OK;
     if (c->world == 1) { HIPCHK(ctx, hipMemcpyAsync(drecv, dsend, bytes, hipMemcpyDeviceToDevice, st)); return LRGE_OK; }
     if (c->nccl) { NCCLCHK(ctx, g_rccl.AllGather(dsend, drecv, bytes, LRGE_NCCL_UINT8, c->nccl, st)); return LRGE_OK; }
@@ -239,6 +248,7 @@ static int comm_small_stage(lrge_hip_comm *c, size_t bytes, Scratch &sc, char **
 // In-place SUM all-reduce of n elements of `esz` bytes (4: u32, 8: u64) in HOST memory.
 static int comm_allreduce_sum_host(lrge_hip_comm *c, void *hbuf, size_t n, int esz, hipStream_t st) {
     lrge_hip_ctx *ctx = c->ctx;
+    COMM_LIVE(c);
     if (c->world == 1 || n == 0) return LRGE_OK;
     const size_t bytes = n * (size_t)esz;
     if (c->nccl) {
@@ -270,6 +280,7 @@ static int comm_allreduce_sum_host(lrge_hip_comm *c, void *hbuf, size_t n, int e
 // All-gather of `bytes` bytes per rank between HOST buffers (hrecv holds world * bytes).
 static int comm_allgather_host(lrge_hip_comm *c, const void *hsend, size_t bytes, void *hrecv, hipStream_t st) {
     lrge_hip_ctx *ctx = c->ctx;
+    COMM_LIVE(c);
     if (bytes == 0) return LRGE_OK;
     if (c->world == 1) { memcpy(hrecv, hsend, bytes); return LRGE_OK; }
     if (c->nccl) {
@@ -319,6 +330,7 @@ static int comm_agree(lrge_hip_comm *c, int rc, hipStream_t st) {
 //          (the fallback transport: correct, not fast).
 static int comm_alltoallv(lrge_hip_comm *c, const void *dsend, const u64 *soff, void *drecv, const u64 *roff, size_t esz, hipStream_t st) {
     lrge_hip_ctx *ctx = c->ctx;
+    COMM_LIVE(c);
     const int W = c->world, me = c->rank;
     if (W == 1) {
         const u64 n = soff[1] - soff[0];

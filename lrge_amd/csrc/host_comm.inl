@@ -55,13 +55,13 @@ extern "C" int lrge_hip_comm_create_host(lrge_hip_ctx *ctx, int rank, int world,
 
 extern "C" void lrge_hip_comm_destroy(lrge_hip_comm *c) {
     if (!c) return;
-    if (c->nccl) {
+    if (c->nccl || c->d_small) {
         // (a communicator that outlives its context -- as lrge_hip_index_free / _seqset_free tolerate too -- must not touch it)
         bool ctx_alive;
         { std::lock_guard<std::mutex> g(g_live_mu); ctx_alive = g_live_ctx.count(c->ctx) != 0; }
         if (ctx_alive) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); }
         if (c->d_small) (void)hipFree(c->d_small);
-        (void)g_rccl.CommDestroy(c->nccl);
+        if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);      // (an aborted communicator is gone already)
     }
     delete c;
 }
@@ -115,20 +115,16 @@ extern "C" int lrge_hip_comm_alltoallv(lrge_hip_comm *c, const void *send, const
     return LRGE_OK;
 }
 
-// host-buffer forms of the two collectives that close a step
+// host-buffer forms of the two collectives that close a step.  They work on the caller's host vectors directly
+// (comm_*_host: no device allocation, and off RCCL no device round trip), so a rank that has just run out of device memory can
+// still JOIN the collective that closes its step -- with a status word in its vector, if the caller wants the failure collective
+// (lrge_amd/parallel.py, integration/liblrge_hip_shim.rs).
 extern "C" int lrge_hip_comm_allreduce_u32(lrge_hip_comm *c, uint32_t *inout, size_t n) {
     if (!c || (n && !inout)) return LRGE_ERR_INVALID;
     lrge_hip_ctx *ctx = c->ctx;
     if (c->world == 1 || n == 0) return LRGE_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    Scratch sc(ctx);
-    ALLOC_OR_FAIL(d, sc, u32, n);
-    HIPCHK(ctx, hipMemcpyAsync(d, inout, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    int rc = comm_allreduce_sum(c, d, n, 4, ctx->stream);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(inout, d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return LRGE_OK;
+    if (c->nccl) HIPCHK(ctx, hipSetDevice(ctx->device));
+    return comm_allreduce_sum_host(c, inout, n, 4, ctx->stream);
 }
 
 extern "C" int lrge_hip_comm_allgather(lrge_hip_comm *c, const void *send, size_t bytes, void *recv) {
@@ -136,14 +132,22 @@ extern "C" int lrge_hip_comm_allgather(lrge_hip_comm *c, const void *send, size_
     lrge_hip_ctx *ctx = c->ctx;
     if (bytes == 0) return LRGE_OK;
     if (c->world == 1) { memcpy(recv, send, bytes); return LRGE_OK; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    Scratch sc(ctx);
-    ALLOC_OR_FAIL(ds, sc, char, bytes);
-    ALLOC_OR_FAIL(dr, sc, char, bytes * (size_t)c->world);
-    HIPCHK(ctx, hipMemcpyAsync(ds, send, bytes, hipMemcpyHostToDevice, ctx->stream));
-    int rc = comm_allgather(c, ds, bytes, dr, ctx->stream);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(recv, dr, bytes * (size_t)c->world, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (c->nccl) HIPCHK(ctx, hipSetDevice(ctx->device));
+    return comm_allgather_host(c, send, bytes, recv, ctx->stream);
+}
+
+// A rank that cannot go on (an error between two collectives: a failed upload before a collective index build, a failed overlap
+// call before the all-reduce that closes the step) calls this instead of leaving its peers waiting for it for ever:
+//   local transport  -- the group is aborted: every rank blocked in, or later entering, a collective of the group returns
+//                       LRGE_ERR_DEVICE ("another rank failed");
+//   RCCL             -- ncclCommAbort on this rank's communicator; the peers' pending RCCL operations end when their own processes
+//                       abort (the launcher's job: torch.distributed.run tears the group down when one process fails);
+//   host callbacks   -- the caller owns the collectives; nothing to do here.
+// Afterwards every collective on `c` fails at once; lrge_hip_comm_destroy is still to be called.
+extern "C" int lrge_hip_comm_abort(lrge_hip_comm *c) {
+    if (!c) return LRGE_ERR_INVALID;
+    c->aborted = true;
+    if (c->grp) c->grp->abort();
+    else if (c->nccl && g_rccl.CommAbort) { (void)g_rccl.CommAbort(c->nccl); c->nccl = nullptr; }
     return LRGE_OK;
 }

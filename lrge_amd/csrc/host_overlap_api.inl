@@ -138,7 +138,21 @@ extern "C" int lrge_hip_overlap_twoset(lrge_hip_ctx *ctx, const lrge_hip_index *
         return rc;
     }
     // partitioned index: the parts hold disjoint target reads, so a query's distinct-target count is the sum over the
-    // parts and it has a mapping if it has one in any part; every part sees the same queries and the global mid_occ
+    // parts and it has a mapping if it has one in any part; every part sees the same queries and the global mid_occ.
+    // The reference counts distinct target NAMES (twoset.rs:286-317) and never rejects a duplicate identifier in this mode: a name
+    // that two reads of ONE part share is counted once (k_count's t_dup walk), a name shared across PARTS would be counted once per
+    // part -- refused instead of counted wrongly (the target-sharded multi-GPU form has the same limit: lrge_hip_index_build_tsharded)
+    if (ix->seqs && ix->seqs->dup_rank) {
+        std::vector<std::pair<u32, u32>> rp;      // (name rank, part)
+        for (size_t pi = 0; pi < ix->parts.size(); ++pi)
+            for (u32 r : ix->parts[pi]->seqs->h_rank) rp.emplace_back(r, (u32)pi);
+        std::sort(rp.begin(), rp.end());
+        for (size_t i = 1; i < rp.size(); ++i)
+            if (rp[i].first == rp[i - 1].first && rp[i].second != rp[i - 1].second) {
+                LRGE_SET_ERR(ctx, "Duplicate read identifier across the parts of a partitioned index (target set above PART_BASES bases): distinct target names cannot be counted part by part");
+                return LRGE_ERR_DUPLICATE_ID;
+            }
+    }
     const u32 nq = queries->n;
     std::vector<u32> c((size_t)nq + 1), h((size_t)nq + 1);
     if (counts) std::fill(counts, counts + nq, 0u);

@@ -104,8 +104,9 @@ static void hp_pack_range(const u8 *ascii, const u64 *boff, const u64 *woff, u32
 // first, and the pack runs at twice the speed from its cores (measured on a two-socket box: 6.6 ms against 12.1 ms for 720
 // Mbases, whichever node the source had been filled from: tools/micro/upload_numa.py) -- left to the scheduler a process ends up
 // anywhere in between, and stays there.
-static std::vector<int> hp_gpu_node_cpus(int device) {
+static std::vector<int> hp_gpu_node_cpus(int device, int *node_out = nullptr) {
     std::vector<int> out;
+    if (node_out) *node_out = -1;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return out; }
     for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
@@ -114,6 +115,7 @@ static std::vector<int> hp_gpu_node_cpus(int device) {
     int node = -1;
     if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
     if (node < 0) return out;
+    if (node_out) *node_out = node;
     snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
     FILE *f = fopen(path, "r");
     if (!f) return out;
@@ -129,6 +131,27 @@ static std::vector<int> hp_gpu_node_cpus(int device) {
     fclose(f);
     return out;
 }
+// CPUs this process may keep busy at once: the smaller of its affinity mask and its cgroup's CPU bandwidth limit (v2 cpu.max, v1
+// cpu.cfs_quota_us / cpu.cfs_period_us).  The GPU boxes of this pool show 256 hardware threads and grant 16 CPUs' worth of time
+// (cpu.max = "1600000 100000"): 32 pack threads -- hardware_concurrency / 2, clamped -- beside a main thread that launches kernels spent
+// part of every period throttled (round 5: the pack pool is sized by THIS figure, and one pool serves every context of the process).
+static double hp_cpu_quota() {
+    double q = (double)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t mine; CPU_ZERO(&mine);
+    if (sched_getaffinity(0, sizeof(mine), &mine) == 0 && CPU_COUNT(&mine) > 0) q = std::min(q, (double)CPU_COUNT(&mine));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[32] = {0}; long per = 0;
+        if (fscanf(f, "%31s %ld", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0 && atof(a) > 0) q = std::min(q, atof(a) / (double)per);
+        fclose(f);
+    } else {
+        long quota = -1, per = 0;
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &per) != 1) per = 0; fclose(g); }
+        if (quota > 0 && per > 0) q = std::min(q, (double)quota / (double)per);
+    }
+    return std::max(1.0, q);
+}
+
 static void hp_pin_thread(std::thread &t, const std::vector<int> &cpus) {
     if (cpus.empty()) return;
     cpu_set_t set; CPU_ZERO(&set);
@@ -153,9 +176,11 @@ struct HostPool {
             { std::lock_guard<std::mutex> lk(mu); if (--running == 0) cv_done.notify_all(); }
         }
     }
+    std::mutex use_mu;      // one parallel_for at a time: the pool is shared by the uploaders of every context of the process
     void parallel_for(u32 n, std::function<void(u32)> f) {
         if (n == 0) return;
         if (th.empty() || n == 1) { for (u32 i = 0; i < n; ++i) f(i); return; }
+        std::lock_guard<std::mutex> use(use_mu);
         { std::lock_guard<std::mutex> lk(mu); fn = std::move(f); n_tasks = n; next = 0; running = (u32)th.size(); ++gen; }
         cv_go.notify_all();
         for (u32 i; (i = next.fetch_add(1)) < n_tasks;) fn(i);
@@ -169,11 +194,23 @@ struct HostPool {
     }
 };
 
+// ONE pack pool per process and NUMA node (round 5): eight contexts of one process -- the ranks of a local communicator, a world
+// emulated on one GPU -- used to start min(32, hw / 2) workers EACH, 256 pack threads on a host that grants 16 CPUs; now they take
+// turns, chunk by chunk, on a pool sized for the host.  The pool lives as long as the process.
+static HostPool *hp_shared_pool(int node, u32 n_threads, const std::vector<int> &cpus) {
+    static std::mutex mu; static std::map<int, HostPool *> pools;
+    std::lock_guard<std::mutex> g(mu);
+    HostPool *&p = pools[node];
+    if (!p) { p = new HostPool(); p->start(n_threads, cpus); }
+    return p;
+}
+
 // The uploader of a context: jobs run one after the other on its thread (FIFO: a second set is packed behind the first).
 struct Uploader {
     std::thread th; std::mutex mu; std::condition_variable cv;
     std::deque<std::function<void()>> jobs; bool quit = false, started = false;
-    HostPool pool;
+    HostPool *pool = nullptr;           // hp_shared_pool: shared with the other contexts of the process on the same NUMA node
+    int node = -1;
     std::vector<int> cpus;              // where the uploader and its workers run (hp_gpu_node_cpus; empty: wherever)
     void submit(std::function<void()> j) {
         std::lock_guard<std::mutex> lk(mu);

@@ -246,10 +246,16 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
         }
         if (!ctx->uploader) {
             ctx->uploader = new Uploader();
-            if (!ctx->opt("HOST_PACK_NO_PIN")) ctx->uploader->cpus = hp_gpu_node_cpus(ctx->device);     // the GPU's own NUMA node
+            if (!ctx->opt("HOST_PACK_NO_PIN")) ctx->uploader->cpus = hp_gpu_node_cpus(ctx->device, &ctx->uploader->node);     // the GPU's own NUMA node
+            // threads packing at once = what the host grants this process (hp_cpu_quota: affinity and cgroup bandwidth), less two for
+            // the thread that launches kernels and the runtime's own; at most 32, at most half the node's hardware threads.  The FIRST
+            // context of the process on a NUMA node sizes the pool (HOST_PACK_THREADS overrides); several PROCESSES on one host (one per
+            // GPU over RCCL) share its CPUs without knowing of each other: their launcher divides (bench.py sets HOST_PACK_THREADS)
             const u32 hw = ctx->uploader->cpus.empty() ? std::max(2u, std::thread::hardware_concurrency()) : (u32)ctx->uploader->cpus.size() * 2;
-            ctx->uploader->pool.start((u32)std::max<u64>(1, ctx->opt_u64("HOST_PACK_THREADS", std::min<u32>(32, std::max<u32>(2, hw / 2)))) - 1, ctx->uploader->cpus);    // (>= 1: the uploader thread itself packs; a CPU of its own per worker instead of the node: measured, no difference)
-            if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] host-side pack: %zu worker threads on %zu CPUs of the GPU's NUMA node\n", ctx->uploader->pool.th.size(), ctx->uploader->cpus.size());
+            const double quota = hp_cpu_quota();
+            const u32 dflt = std::min<u32>(std::min<u32>(32, std::max<u32>(2, hw / 2)), (u32)std::max(2.0, quota - 2.0));
+            ctx->uploader->pool = hp_shared_pool(ctx->uploader->node, (u32)std::max<u64>(1, ctx->opt_u64("HOST_PACK_THREADS", dflt)) - 1, ctx->uploader->cpus);    // (>= 1: the uploader thread itself packs; a CPU of its own per worker instead of the node: measured, no difference)
+            if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] host-side pack: %zu worker threads (shared by the process) on %zu CPUs of the GPU's NUMA node; the host grants %.1f CPUs\n", ctx->uploader->pool->th.size(), ctx->uploader->cpus.size(), quota);
         }
         s->h_boff.resize((size_t)n + 1);
         { const u64 o0 = offsets[0]; for (u32 i = 0; i <= n; ++i) s->h_boff[i] = offsets[i] - o0; }
@@ -277,7 +283,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
                 const double t1 = DevPool::now_ms(); t_wait += t1 - t0;
                 u64 *hp = (u64 *)stage[b]; u32 *hm = (u32 *)(stage[b] + CH * 8);
                 const u32 n_tasks = (u32)std::min<u64>(256, std::max<u64>(1, nw / 16384));
-                up->pool.parallel_for(n_tasks, [=](u32 t) {
+                up->pool->parallel_for(n_tasks, [=](u32 t) {
                     const u64 a = w0 + nw * t / n_tasks, z = w0 + nw * (t + 1) / n_tasks;
                     hp_pack_range(hsrc, boff, woff, n, a, z, hp + (a - w0), hm + (a - w0));
                 });

@@ -10,6 +10,7 @@
 //   C5 all-gather  u64[2]       too-frequent keys this rank owns, status
 //   A2 agreement                (room for everybody's list)
 //   C6 all-gather  u64[max]     the lists
+//   A3 agreement                (the lists arrived and the tables are marked on every rank: nobody leaves with LRGE_OK alone)
 struct TsTable { u64 *ht; u64 cap, slots; };
 
 static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm *c, CollectiveGuard &cg) {
@@ -147,23 +148,33 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
     if (thres < P.min_mid_occ) thres = P.min_mid_occ;
     if (P.max_mid_occ > P.min_mid_occ && thres > P.max_mid_occ) thres = P.max_mid_occ;
     const u32 mid_occ = (u32)thres;
-    // ---- C5, A2, C6: the too-frequent keys go to everybody ----
-    const u32 cap_list = 1u << 22;
+    // ---- C5, A2, C6, A3: the too-frequent keys go to everybody ----
+    // the list starts at 2^16 keys (mid_occ_frac = 2 x 10^-4 of the keys an owner holds: thousands at H. sapiens scale); an owner with
+    // more -- a repeat-rich set -- takes a list of exactly that many and lists again (round 5: was a fixed 32 MB block and a hard
+    // limit of 2^22 keys)
+    u32 cap_list = (u32)std::min<u64>(std::max<u64>(n_r, 1), 1u << 16);
     u64 *d_list = nullptr; u32 *d_nf = nullptr;
     std::vector<u64> mine2(2, 0), all2((size_t)2 * W, 0);
     cg.expect(CollectiveGuard::ALLGATHER_U64, 2, 1);
     auto local3 = [&]() -> int {
         if (shard_fail_at(ctx, 14)) return LRGE_ERR_DEVICE;
-        d_list = sc.get<u64>(cap_list); d_nf = sc.get<u32>(TS_MAX_WORLD + 1);
-        if (!d_list || !d_nf) return LRGE_ERR_DEVICE;
-        HIPCHK(ctx, hipMemsetAsync(d_nf, 0, 4, st));
-        if (n_r) { hipLaunchKernelGGL(k_ts_frequent, dim3((u32)div_up(n_r, 256)), dim3(256), 0, st, rk, starts, d_nr, gcnt, mid_occ, d_list, cap_list, d_nf); KCHK(ctx); }
-        u32 nf = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&nf, d_nf, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        if (nf > cap_list) { LRGE_SET_ERR(ctx, "target-sharded index build: %u too-frequent keys on one rank (limit %u)", nf, cap_list); return LRGE_ERR_TOO_MANY; }
-        mine2[0] = nf;
-        return LRGE_OK;
+        d_nf = sc.get<u32>(TS_MAX_WORLD + 1);
+        if (!d_nf) return LRGE_ERR_DEVICE;
+        for (int pass = 0; pass < 2; ++pass) {
+            d_list = sc.get<u64>(cap_list);
+            if (!d_list) return LRGE_ERR_DEVICE;
+            HIPCHK(ctx, hipMemsetAsync(d_nf, 0, 4, st));
+            if (n_r) { hipLaunchKernelGGL(k_ts_frequent, dim3((u32)div_up(n_r, 256)), dim3(256), 0, st, rk, starts, d_nr, gcnt, mid_occ, d_list, cap_list, d_nf); KCHK(ctx); }
+            u32 nf = 0;
+            HIPCHK(ctx, hipMemcpyAsync(&nf, d_nf, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            mine2[0] = nf;
+            if (nf <= cap_list) return LRGE_OK;
+            sc.drop(d_list); d_list = nullptr;
+            cap_list = nf;                                  // (the count is exact: the second pass fits)
+        }
+        LRGE_SET_ERR(ctx, "target-sharded index build: the list of too-frequent keys did not settle");
+        return LRGE_ERR_DEVICE;
     };
     rc = local3();
     const bool failed3 = rc != LRGE_OK;
@@ -175,24 +186,40 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
         if (all2[(size_t)2 * r + 1]) { if (!failed3) LRGE_SET_ERR(ctx, "target-sharded index build: rank %d failed", r); return LRGE_ERR_DEVICE; }
         max_nf = std::max(max_nf, all2[(size_t)2 * r]);
     }
-    if (max_nf) {
-        cg.expect(CollectiveGuard::AGREE);
-        u64 *d_all = sc.get<u64>(max_nf * (u64)W);
-        std::vector<u32> nof(TS_MAX_WORLD, 0);
-        for (int r = 0; r < W; ++r) nof[(size_t)r] = (u32)all2[(size_t)2 * r];
-        int arc = d_all ? LRGE_OK : LRGE_ERR_DEVICE;
-        if (d_all && hipMemcpyAsync(d_nf + 1, nof.data(), TS_MAX_WORLD * 4, hipMemcpyHostToDevice, st) != hipSuccess) arc = LRGE_ERR_DEVICE;
-        if (d_all && hipStreamSynchronize(st) != hipSuccess) arc = LRGE_ERR_DEVICE;
-        if (shard_fail_at(ctx, 15)) arc = LRGE_ERR_DEVICE;
-        cg.disarm();
-        rc = comm_agree(c, arc, st); if (rc) return rc;
-        rc = comm_allgather(c, d_list, max_nf * 8, d_all, st); if (rc) return rc;
-        for (const TsTable &t : tabs) {
-            hipLaunchKernelGGL(k_ts_mark, dim3((u32)div_up(max_nf, 256), (u32)W), dim3(256), 0, st, t.ht, t.cap, fix, d_all, d_nf + 1, (u32)W, (u32)max_nf, mid_occ);
-            KCHK(ctx);
-        }
-    }
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    // From here on nothing a rank does is known to the others unless it says so: the lists' all-gather, the marking kernels and the
+    // last synchronise can fail on one rank alone, and a rank that returned LRGE_OK goes on to the all-reduce that closes the step
+    // while the failed one does not.  One more agreement (A3) closes the build: every rank leaves with the same verdict.
+    cg.expect(CollectiveGuard::AGREE);
+    auto tail = [&]() -> int {
+        if (max_nf) {
+            // (the all-gather reads max_nf words of EVERY rank's list: a list that is shorter is re-taken at that size)
+            if (cap_list < max_nf) {
+                u64 *bigger = sc.get<u64>(max_nf);
+                if (!bigger) return LRGE_ERR_DEVICE;
+                if (mine2[0]) HIPCHK(ctx, hipMemcpyAsync(bigger, d_list, mine2[0] * 8, hipMemcpyDeviceToDevice, st));
+                d_list = bigger;
+            }
+            u64 *d_all = sc.get<u64>(max_nf * (u64)W);
+            std::vector<u32> nof(TS_MAX_WORLD, 0);
+            for (int r = 0; r < W; ++r) nof[(size_t)r] = (u32)all2[(size_t)2 * r];
+            int arc = d_all ? LRGE_OK : LRGE_ERR_DEVICE;
+            if (d_all && hipMemcpyAsync(d_nf + 1, nof.data(), TS_MAX_WORLD * 4, hipMemcpyHostToDevice, st) != hipSuccess) arc = LRGE_ERR_DEVICE;
+            if (d_all && hipStreamSynchronize(st) != hipSuccess) arc = LRGE_ERR_DEVICE;
+            if (shard_fail_at(ctx, 15)) arc = LRGE_ERR_DEVICE;
+            int r2 = comm_agree(c, arc, st); if (r2) return r2;                                   // A2
+            r2 = comm_allgather(c, d_list, max_nf * 8, d_all, st); if (r2) return r2;             // C6
+            if (shard_fail_at(ctx, 16)) return LRGE_ERR_DEVICE;
+            for (const TsTable &t : tabs) {
+                hipLaunchKernelGGL(k_ts_mark, dim3((u32)div_up(max_nf, 256), (u32)W), dim3(256), 0, st, t.ht, t.cap, fix, d_all, d_nf + 1, (u32)W, (u32)max_nf, mid_occ);
+                KCHK(ctx);
+            }
+        } else if (shard_fail_at(ctx, 16)) return LRGE_ERR_DEVICE;
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        return LRGE_OK;
+    };
+    rc = tail();
+    cg.disarm();
+    rc = comm_agree(c, rc, st); if (rc) return rc;                                                // A3
     mark("frequent keys + marking");
     ix->mid_occ = (int)mid_occ; ix->n_keys = g_distinct; ix->n_mz = g_mz;
     for (lrge_hip_index *p : ix->parts) p->mid_occ = (int)mid_occ;

@@ -87,10 +87,58 @@ class _Comm:
     def busy_ms(self, reset=False):
         return float(self.ctx._lib.lrge_hip_comm_busy_ms(self.h, 1 if reset else 0))
 
+    def abort(self):
+        """This rank cannot go on (lrge_hip_comm_abort): its peers leave the collectives they are waiting in with an error instead
+        of waiting for ever (local transport), every later collective here fails at once."""
+        if getattr(self, "h", None):
+            self.ctx._lib.lrge_hip_comm_abort(self.h)
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx._lib.lrge_hip_comm_destroy(self.h)
             self.h = None
+
+
+class RankFailed(RuntimeError):
+    """Another rank of the job failed; this rank's own work was fine."""
+
+
+def _abort(comm):
+    try:
+        comm.abort()
+    except Exception:      # noqa: BLE001 -- communicators without an abort (SoloComm, TorchComm): nothing to wake
+        pass
+
+
+def _close_step(comm, sizes, work):
+    """The all-reduce that closes a sharded step, made failure-collective.  `work()` -> one u32 vector per entry of `sizes`; whatever
+    happens inside it on THIS rank, the rank still enters the all-reduce its peers are heading for -- with zeros and a status word
+    -- and raises afterwards; the peers see the status word and raise RankFailed.  (The reference's workers end the whole run on a
+    MapError: twoset.rs:279-284.)  A failure of the collective itself aborts the communicator."""
+    err = None
+    try:
+        parts = [np.ascontiguousarray(p, dtype=np.uint32) for p in work()]
+        if [len(p) for p in parts] != [int(x) for x in sizes]:
+            raise ValueError("a sharded step returned vectors of %r entries, expected %r" % ([len(p) for p in parts], list(sizes)))
+    except BaseException as e:      # noqa: BLE001 -- re-raised below, after the collective
+        err = e
+        parts = [np.zeros(int(x), np.uint32) for x in sizes]
+    buf = np.concatenate(parts + [np.array([1 if err is not None else 0], np.uint32)])
+    try:
+        buf = comm.all_reduce_u32(buf)
+    except BaseException:
+        _abort(comm)
+        if err is not None:
+            raise err
+        raise
+    if err is not None:
+        raise err
+    if int(buf[-1]):
+        raise RankFailed("%d other rank(s) failed inside the step; this rank's results are discarded" % int(buf[-1]))
+    out, o = [], 0
+    for x in sizes:
+        out.append(buf[o:o + int(x)].copy()); o += int(x)
+    return out
 
 
 class RcclComm(_Comm):
@@ -322,26 +370,80 @@ def twoset_forward_sharded(overlap_fn, q_lens, comm):
     closes the step.  Returns (all estimates in query order, total no_mapping_count, (lo, hi))."""
     b = shard_by_bases(q_lens, comm.world)
     lo, hi = b[comm.rank], b[comm.rank + 1]
-    est, no_map = overlap_fn(lo, hi)
     lens = [b[i + 1] - b[i] for i in range(comm.world)]
-    allv = comm.all_gather_f32(est, max(lens) if lens else 0, lens)
-    nm = comm.all_reduce_u32(np.array([int(no_map)], dtype=np.uint32))
+    # the index build inside overlap_fn is collective (and failure-collective: host_index_collective.inl); a failure around it on
+    # this rank alone still enters the two closing collectives -- NaNs and a status word -- and raises afterwards
+    err = None
+    try:
+        est, no_map = overlap_fn(lo, hi)
+        est = np.ascontiguousarray(est, dtype=np.float32)
+        if len(est) != hi - lo:
+            raise ValueError("a sharded step returned %d estimates for %d queries" % (len(est), hi - lo))
+    except BaseException as e:      # noqa: BLE001 -- re-raised below
+        err, est, no_map = e, np.full(hi - lo, np.nan, np.float32), 0
+    try:
+        allv = comm.all_gather_f32(est, max(lens) if lens else 0, lens)
+        nm = comm.all_reduce_u32(np.array([int(no_map), 1 if err is not None else 0], dtype=np.uint32))
+    except BaseException:
+        _abort(comm)
+        if err is not None:
+            raise err
+        raise
+    if err is not None:
+        raise err
+    if int(nm[1]):
+        raise RankFailed("%d other rank(s) failed inside the step; this rank's results are discarded" % int(nm[1]))
     return allv, int(nm[0]), (lo, hi)
 
 
-def twoset_forward_target_sharded(overlap_fn, t_lens, comm):
+def cross_shard_duplicates(t_ranks, bounds):
+    """True if a target identifier (name rank: equal names <=> equal rank) occurs in two DIFFERENT shards.  The shards' distinct-
+    target counts add up only over disjoint NAMES (twoset.rs:286-317 inserts target_name into a HashSet and never rejects a
+    duplicate id); inside one shard the library dedups by rank, across shards nobody can."""
+    t_ranks = np.asarray(t_ranks)
+    shard = np.searchsorted(np.asarray(bounds[1:-1]), np.arange(len(t_ranks)), side="right")
+    order = np.argsort(t_ranks, kind="stable")
+    r, sh = t_ranks[order], shard[order]
+    return bool(((r[1:] == r[:-1]) & (sh[1:] != sh[:-1])).any())
+
+
+def twoset_forward_target_sharded(overlap_fn, t_lens, comm, n_queries=None, build_fn=None, t_ranks=None):
     """Two-set forward over comm.world GPUs with the TARGETS sharded (lrge_hip_index_build_tsharded): the target reads are cut into
-    contiguous ranges with equal base counts, `overlap_fn(t_lo, t_hi) -> (counts u32[Q], has_mapping u32[Q])` maps ALL queries
-    against this rank's range (its index built with the occurrence statistics of the whole target set:
-    engine.Index(ctx, target_shard, preset, comm=comm, tshard=True)); the shards hold disjoint targets, so the distinct-target
-    counts of twoset.rs:286-317 add up and has_mapping ORs: two all-reduces close the step.  Returns (counts, has_mapping 0/1,
-    (t_lo, t_hi))."""
+    contiguous ranges with equal base counts, every rank maps ALL queries against the index of its range (built with the occurrence
+    statistics of the whole target set: engine.Index(ctx, target_shard, preset, comm=comm, tshard=True)); the shards hold disjoint
+    targets, so the distinct-target counts of twoset.rs:286-317 add up and has_mapping ORs: ONE all-reduce closes the step.
+
+      build_fn(t_lo, t_hi) -> index     (optional) upload + the collective index build.  A failure here -- before or inside the
+                                        build -- aborts the communicator: the peers leave the build with an error.
+      overlap_fn(index) -> (counts u32[Q], has_mapping u32[Q])     with build_fn; failures here are carried by the status word of
+                                        the closing all-reduce (every rank raises, nobody waits)
+      overlap_fn(t_lo, t_hi) -> (counts, has_mapping)              without build_fn (build inside): any failure aborts
+      n_queries                         Q (needed for the status-word form: a failed rank still sends vectors of the right shape)
+      t_ranks                           name ranks of ALL targets: a target identifier that occurs in two shards would be counted
+                                        twice -- refused with ValueError before anything is built (use the query-sharded form, or
+                                        one GPU, for such a set)
+
+    Returns (counts, has_mapping 0/1, (t_lo, t_hi))."""
     b = shard_by_bases(t_lens, comm.world)
     lo, hi = b[comm.rank], b[comm.rank + 1]
-    counts, has = overlap_fn(lo, hi)
-    counts = comm.all_reduce_u32(np.asarray(counts, dtype=np.uint32))
-    has = (comm.all_reduce_u32(np.asarray(has, dtype=np.uint32)) > 0).astype(np.uint32)
-    return counts, has, (lo, hi)
+    if t_ranks is not None and cross_shard_duplicates(t_ranks, b):       # (every rank holds the same ranks: every rank refuses)
+        raise ValueError("Duplicate read identifier across target shards: the target-sharded forward form cannot count distinct names over shards")
+    if build_fn is None or n_queries is None:
+        try:
+            counts, has = overlap_fn(lo, hi)
+            n = len(counts)
+            counts, has = _close_step(comm, (n, n), lambda: (counts, has))
+        except BaseException:
+            _abort(comm)
+            raise
+        return counts, (has > 0).astype(np.uint32), (lo, hi)
+    try:
+        ix = build_fn(lo, hi)
+    except BaseException:
+        _abort(comm)
+        raise
+    counts, has = _close_step(comm, (n_queries, n_queries), lambda: overlap_fn(ix))
+    return counts, (has > 0).astype(np.uint32), (lo, hi)
 
 
 def shard_by_rank_round_robin(name_ranks, rank, world):
@@ -355,17 +457,27 @@ def shard_by_rank_round_robin(name_ranks, rank, world):
 def ava_sharded(overlap_shard_fn, name_ranks, comm):
     """All-vs-all over comm.world GPUs.  `overlap_shard_fn(idx) -> u32[n_reads]`: counts keyed by indexed read that the
     reads `idx`, used as queries against the replicated index, contribute (engine.Index.overlap_ava(shard=...)).
-    One all_reduce(sum) of the count vector closes the step; returns (counts of the whole job, idx)."""
+    One all_reduce(sum) of the count vector closes the step (with a status word: a rank that fails still joins it, and every
+    rank raises); returns (counts of the whole job, idx)."""
     idx = shard_by_rank_round_robin(name_ranks, comm.rank, comm.world)
-    part = np.asarray(overlap_shard_fn(idx), dtype=np.uint32)
-    return comm.all_reduce_u32(part), idx
+    (counts,) = _close_step(comm, (len(name_ranks),), lambda: (overlap_shard_fn(idx),))
+    return counts, idx
 
 
-def inverse_sharded(overlap_shard_fn, streamed_lens, comm):
+def inverse_sharded(overlap_shard_fn, streamed_lens, comm, n_indexed=None):
     """Inverse two-set (--use-min-ref): the index holds the query set (small; replicated, or restricted to the rank's
     streamed reads), the streamed target reads are cut by bases.  `overlap_shard_fn(lo, hi) -> u32[n_indexed]`; one
-    all_reduce(sum) closes the step."""
+    all_reduce(sum) closes the step.  With n_indexed given the all-reduce carries a status word (a failing rank still joins it and
+    every rank raises); without it a failure aborts the communicator."""
     b = shard_by_bases(streamed_lens, comm.world)
     lo, hi = b[comm.rank], b[comm.rank + 1]
-    part = np.asarray(overlap_shard_fn(lo, hi), dtype=np.uint32)
-    return comm.all_reduce_u32(part), (lo, hi)
+    if n_indexed is not None:
+        (counts,) = _close_step(comm, (n_indexed,), lambda: (overlap_shard_fn(lo, hi),))
+        return counts, (lo, hi)
+    try:
+        part = np.asarray(overlap_shard_fn(lo, hi), dtype=np.uint32)
+        (counts,) = _close_step(comm, (len(part),), lambda: (part,))
+    except BaseException:
+        _abort(comm)
+        raise
+    return counts, (lo, hi)

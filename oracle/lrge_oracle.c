@@ -1296,7 +1296,7 @@ int lo_inverse_skip(int32_t qlen, int32_t qs, int32_t qe, int rev, int32_t tlen,
    thread_buf.rs:7-42).  With glibc's defaults each one above 128 KB is its own mmap / munmap, and 256 mapping threads then queue
    for the process's address-space lock instead of mapping -- an artefact of this port, not of the algorithm.  Served from
    the threads' malloc arenas, never trimmed, the allocations behave like kalloc's.  LO_NO_MALLOPT=1 keeps glibc's defaults
-   (the A/B of tools/cpu_port_scaling.py). */
+   (the A/B of tools/cpu_port_scaling.py; on this pool's boxes, which grant 16 CPUs, the two measure alike). */
 static void tune_malloc(void)
 {
     static int done = 0;
@@ -1306,6 +1306,18 @@ static void tune_malloc(void)
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
     mallopt(M_TRIM_THRESHOLD, INT_MAX);
     mallopt(M_TOP_PAD, 64 << 20);
+}
+
+/* the thread count of every parallel region that is not given one (lo_index_build, lo_kstat_*, lo_ridx_*; threads <= 0 in the counting
+   shells): oracle.py sets it to what the host GRANTS (cgroup CPU bandwidth), which on the GPU boxes of this pool is 16 CPUs, not the
+   256 hardware threads omp_get_max_threads() reports */
+void lo_set_default_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 static void set_threads(int threads)

@@ -64,6 +64,8 @@ typedef struct {
 typedef struct lo_index lo_index_t;
 
 void lo_opt_init(lo_opt_t *o, int preset, int dual);
+/* OpenMP threads of every parallel region that is not told otherwise */
+void lo_set_default_threads(int n);
 
 /* mm_sketch: returns number of minimizers (may exceed cap; only the first cap are written) */
 int64_t lo_sketch(const char *seq, int32_t len, int32_t w, int32_t k, uint32_t rid, int32_t is_hpc,

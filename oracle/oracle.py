@@ -52,12 +52,48 @@ def build(force=False):
 _lib = None
 
 
+def host_cpus():
+    """CPUs the host GRANTS this process: the smaller of its affinity mask and its cgroup's CPU bandwidth limit (cpu.max).  The GPU
+    boxes of this pool report 256 hardware threads and grant 16 CPUs (cpu.max = "1600000 100000"): 256 OpenMP threads there spend
+    most of every scheduling period throttled (tools/cpu_port_scaling.py)."""
+    try:
+        q = float(len(os.sched_getaffinity(0)))
+    except Exception:      # noqa: BLE001
+        q = float(os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            a, per = f.read().split()[:2]
+        if a != "max" and float(per) > 0:
+            q = min(q, float(a) / float(per))
+    except Exception:      # noqa: BLE001
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if quota > 0 and per > 0:
+                q = min(q, quota / per)
+        except Exception:      # noqa: BLE001
+            pass
+    return max(1.0, q)
+
+
+def default_threads():
+    """OpenMP threads the oracle runs with unless told otherwise: LO_THREADS, else twice the CPUs the host grants (the mapping loop
+    waits on memory: measured best around 2-4 threads per granted CPU), at most the hardware threads."""
+    if os.environ.get("LO_THREADS"):
+        return max(1, int(os.environ["LO_THREADS"]))
+    return int(max(1, min(os.cpu_count() or 1, round(2 * host_cpus()))))
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
         L = C.CDLL(_LIB_PATH)
+        L.lo_set_default_threads.argtypes = [C.c_int]
+        L.lo_set_default_threads(default_threads())
         vp, u64p, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
         L.lo_opt_init.argtypes = [C.POINTER(Opt), C.c_int, C.c_int]
         L.lo_sketch.restype = C.c_int64

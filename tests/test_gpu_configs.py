@@ -25,7 +25,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-THREADS = os.cpu_count() or 8
+THREADS = 0        # the oracle's default: twice the CPUs the host grants (oracle.default_threads)
 
 
 def _sets(ctx, q, t):

@@ -392,7 +392,7 @@ def test_a_failing_rank_fails_the_sharded_build_on_every_transport(ctx, tiny_ont
         grp.close()
 
 
-@pytest.mark.parametrize("stage", [10, 11, 12, 13, 14, 15, "alloc"])
+@pytest.mark.parametrize("stage", [10, 11, 12, 13, 14, 15, 16, "alloc"])
 @pytest.mark.parametrize("bad_rank", [0, 2])
 def test_a_failing_rank_fails_the_target_sharded_build(ctx, tiny_ont, stage, bad_rank):
     """The same contract for lrge_hip_index_build_tsharded: a rank failing before the local build, in the counting pass, at the

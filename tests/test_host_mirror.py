@@ -230,3 +230,65 @@ def test_gloo_world2_target_sharded_counts_add_up():
     assert all(x[3] > 0 for x in dropped) and sum(x[2] for x in dropped) > 0       # (the set is repeat-rich: some keys are too frequent, and the shards hold them)
     own = [x for x in got if x[0] == "own_mid_occ"]
     assert all(x[2] <= x[3] for x in own)                                          # (a share's own threshold is never above the whole set's)
+
+
+def _fail_worker(rank, world, port, q):
+    """One rank's share fails after the (stand-in) build: it must still enter the closing collective, and EVERY rank must raise."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = parallel.TorchComm(dist)
+        lens = np.arange(1, 12) * 100
+        out = []
+
+        def boom(*_a):
+            if rank == 1:
+                raise MemoryError("rank 1 ran out of memory in its overlap call")
+            return np.ones(5, np.uint32), np.ones(5, np.uint32)
+        for name, call in (
+                ("tshard", lambda: parallel.twoset_forward_target_sharded(boom, lens, comm, n_queries=5, build_fn=lambda lo, hi: "index")),
+                ("inverse", lambda: parallel.inverse_sharded(lambda a, b: boom()[0], lens, comm, n_indexed=5)),
+                ("ava", lambda: parallel.ava_sharded(lambda idx: boom()[0] if rank == 0 else boom(), np.arange(5), comm)),
+                ("qshard", lambda: parallel.twoset_forward_sharded(lambda lo, hi: (boom()[0][:0], 0) if rank == 1 else (np.zeros(hi - lo, np.float32), 0), lens, comm))):
+            try:
+                call()
+                out.append((name, "returned"))
+            except parallel.RankFailed:
+                out.append((name, "RankFailed"))
+            except MemoryError:
+                out.append((name, "MemoryError"))
+        # ... and the communicator is still in step afterwards: a healthy collective works
+        tot = comm.all_reduce_u32(np.array([rank + 1], np.uint32))
+        q.put((rank, out, int(tot[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_a_failing_rank_fails_the_step_on_every_rank():
+    """a rank whose overlap call fails used to return before the all-reduce that closes the step and leave its peers in
+    it for ever.  Now it joins with a status word and raises afterwards; the healthy rank raises RankFailed; nobody hangs."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fail_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = dict((r, (o, t)) for r, o, t in (q.get(timeout=120) for _ in procs))
+    for p in procs: p.join(timeout=60)
+    assert [x[1] for x in res[0][0]] == ["RankFailed"] * 4, res[0]
+    assert [x[1] for x in res[1][0]] == ["MemoryError"] * 4, res[1]
+    assert res[0][1] == res[1][1] == 3
+
+
+def test_cross_shard_duplicate_target_names_are_refused():
+    """distinct-target counts add up over shards only if no target NAME occurs in two shards (twoset.rs:286-317 counts
+    names); the target-sharded form refuses such a set before anything is built."""
+    lens = np.full(8, 100)
+    b = parallel.shard_by_bases(lens, 2)
+    assert not parallel.cross_shard_duplicates(np.array([0, 1, 2, 2, 4, 5, 6, 7]), b)      # a duplicate INSIDE a shard: the library dedups it
+    assert parallel.cross_shard_duplicates(np.array([0, 1, 2, 3, 4, 2, 6, 7]), b)
+    class World2(parallel.SoloComm):
+        rank, world = 0, 2
+    with pytest.raises(ValueError, match="Duplicate read identifier"):
+        parallel.twoset_forward_target_sharded(lambda lo, hi: (np.zeros(3, np.uint32),) * 2, lens, World2(), t_ranks=np.array([0, 1, 2, 3, 4, 2, 6, 7]))

@@ -41,11 +41,11 @@ def main():
     from lrge_amd import engine, synth_cb
     from oracle import oracle as O
     preset = 1 if a.preset == "pb" else 0
-    threads = a.threads or (os.cpu_count() or 1)
+    threads = a.threads or O.default_threads()
     spec, Q, T = synth_cb.spec_of(a.config, a.scale)
     out = {"what": "forward two-set counts of EVERY query read: GPU path vs the CPU oracle's index of ALL targets; oracle times are measured, nothing pro-rated",
            "config": a.config, "scale": a.scale, "preset": "ava-pb" if preset else "ava-ont", "n_query": Q, "n_target": T, "threads": threads,
-           "host": {"cpu_count": os.cpu_count()}}
+           "host": {"hw_threads": os.cpu_count(), "cpus_granted": O.host_cpus()}}
 
     def save():
         if a.out:
@@ -131,7 +131,7 @@ def main():
             out["cpu_port_measured"] = {"reads_per_s": round(Q / job_s, 2), "job_seconds": round(job_s, 1), "index_seconds": round(t_index, 1),
                                         "map_seconds": round(t_map * Q / n_done, 1), "map_reads_per_s": round(n_done / t_map, 1), "threads": threads,
                                         "complete": n_done == Q,
-                                        "note": "oracle = this repo's C restatement of the liblrge / minimap2-2.30 path (a port, not the reference binary), OpenMP on all host threads"
+                                        "note": "oracle = this repo's C restatement of the liblrge / minimap2-2.30 path (a port, not the reference binary), OpenMP, %d threads on the %.0f CPUs the host grants (%d hardware threads)" % (threads, O.host_cpus(), os.cpu_count() or 0)
                                                 + ("" if n_done == Q else "; map time of %d reads scaled to %d" % (n_done, Q))}
             out["gpu_vs_cpu_port_measured"] = round(job_s / best, 1)
         log("chunk %d: %d reads in %.1f s; %d / %d checked, %d differ" % (c, len(idx), dt_c, n_done, Q, n_diff))

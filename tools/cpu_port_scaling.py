@@ -46,8 +46,9 @@ def main():
     ap.add_argument("--config", default="c5_human_twoset")
     ap.add_argument("--targets", type=int, default=50000)
     ap.add_argument("--queries", type=int, default=4096)
-    ap.add_argument("--threads", default="32,128,256")
+    ap.add_argument("--threads", default="16,32,64")
     ap.add_argument("--preset", default="pb")
+    ap.add_argument("--mallopt-ab", action="store_true")
     ap.add_argument("--child", default=None)
     a = ap.parse_args()
     if a.child:
@@ -55,7 +56,7 @@ def main():
         return
     rows = []
     for th in a.threads.split(","):
-        for no in (False, True):
+        for no in ((False, True) if a.mallopt_ab else (False,)):
             env = dict(os.environ)
             env.pop("LO_NO_MALLOPT", None)
             if no:
@@ -66,7 +67,8 @@ def main():
             print(line, flush=True)
             rows.append(json.loads(line))
     sums = {r.get("counts_sum") for r in rows if "counts_sum" in r}
-    print(json.dumps({"summary": "cpu port scaling", "cores": os.cpu_count(), "same_counts_everywhere": len(sums) == 1}))
+    from oracle import oracle as O
+    print(json.dumps({"summary": "cpu port scaling", "hw_threads": os.cpu_count(), "cpus_granted": O.host_cpus(), "same_counts_everywhere": len(sums) == 1}))
 
 
 if __name__ == "__main__":

@@ -120,7 +120,7 @@ def main():
             hq = spec.host_reads(first=0, n=Q)
             ixo = O.Index(O.ReadSet(hq.seqs(), hq.names), opt)
             ht = spec.host_reads(first=Q + lo, n=n)
-            rc, einv = ixo.inverse_counts(O.ReadSet(ht.seqs(), ht.names), threads=os.cpu_count())
+            rc, einv = ixo.inverse_counts(O.ReadSet(ht.seqs(), ht.names), threads=0)
             t_or = time.perf_counter() - t1
             # the same range on the device: a set of its own (device twin again), streamed against the same index
             dsub = spec.device_reads(Q + lo, n)
@@ -139,7 +139,7 @@ def main():
             ixo = O.Index(O.ReadSet(ht.seqs(), ht.names), opt)
             n = min(a.check_queries, Q)
             hq = spec.host_reads(first=0, n=n)
-            rc, ec, eh = ixo.twoset_counts(O.ReadSet(hq.seqs(), hq.names), threads=os.cpu_count())
+            rc, ec, eh = ixo.twoset_counts(O.ReadSet(hq.seqs(), hq.names), threads=0)
             r["oracle_check"] = {"queries": n, "counts_equal": bool(np.array_equal(ec, counts[:n])), "mid_occ_equal": bool(ixo.mid_occ == st["mid_occ"]),
                                  "n_keys_equal": bool(ixo.n_keys == st["n_keys"]) if hasattr(ixo, "n_keys") else None, "oracle_s": round(time.perf_counter() - t1, 1)}
             log("forward oracle check:", r["oracle_check"])

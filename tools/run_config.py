@@ -77,14 +77,14 @@ def main():
             t1 = time.perf_counter()
             if a.inverse:     # the whole target set has to stream through the oracle; the check is over the first `check` indexed reads
                 ixo = O.Index(O.ReadSet(q.seqs(), q.names), opt)
-                rc, einv = ixo.inverse_counts(O.ReadSet(t.seqs(), t.names), threads=os.cpu_count())
+                rc, einv = ixo.inverse_counts(O.ReadSet(t.seqs(), t.names), threads=0)
                 n = min(a.check, q.n)
                 out["oracle_check"] = {"reads": n, "counts_equal": bool(np.array_equal(einv[:n], counts[:n])), "all_equal": bool(np.array_equal(einv, counts)),
                                        "mid_occ_equal": bool(ixo.mid_occ == st["mid_occ"]), "oracle_s": round(time.perf_counter() - t1, 1)}
             else:
                 ixo = O.Index(O.ReadSet(t.seqs(), t.names), opt)
                 sub = q.slice(0, min(a.check, q.n))
-                rc, ec, eh = ixo.twoset_counts(O.ReadSet(sub.seqs(), sub.names), threads=os.cpu_count())
+                rc, ec, eh = ixo.twoset_counts(O.ReadSet(sub.seqs(), sub.names), threads=0)
                 out["oracle_check"] = {"reads": sub.n, "counts_equal": bool(np.array_equal(ec, counts[:sub.n])),
                                        "mid_occ_equal": bool(ixo.mid_occ == st["mid_occ"]), "oracle_s": round(time.perf_counter() - t1, 1)}
     else:

@@ -81,7 +81,7 @@ def cpu_baseline(q, t, budget_s, preset):
     (index time scales linearly in target bases and is pro-rated to the full set), then as many query reads as fit in the
     budget are mapped with all cores against it."""
     from oracle import oracle as O
-    cores = O.default_threads()       # (threads actually used: twice the CPUs the host grants, oracle.host_cpus)
+    cores = O.default_threads()       # (threads actually used: the CPUs the host grants, oracle.host_cpus)
     opt = O.make_opt(O.PRESET_AVA_PB if preset else O.PRESET_AVA_ONT, dual=True)
     T = O.ReadSet(t.seqs(), t.names)
     t0 = time.perf_counter()
@@ -109,13 +109,16 @@ def cpu_baseline(q, t, budget_s, preset):
         (np.concatenate(counts) if counts else np.zeros(0, np.uint32)), ix.mid_occ
 
 
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def _committed(config, inverse):
-    """profiles/r04_hbm_traffic[_<config>].json: made by tools/summarize_profiles.py from the FETCH_SIZE / WRITE_SIZE passes of
+    """profiles/r05_hbm_traffic[_<config>].json (else round 4's): made by tools/summarize_profiles.py from the FETCH_SIZE / WRITE_SIZE passes of
     this same command (tools/profile_round.sh)."""
-    for name in ("%s_hbm_traffic_%s%s.json" % (PROFILE_ROUND, config, "_inverse" if inverse else ""), "%s_hbm_traffic.json" % PROFILE_ROUND):
+    names = []
+    for rnd in (PROFILE_ROUND, "r04"):       # (the newest committed collection of this configuration; the file's name is reported with the figures)
+        names += ["%s_hbm_traffic_%s%s.json" % (rnd, config, "_inverse" if inverse else ""), "%s_hbm_traffic.json" % rnd]
+    for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -161,7 +164,7 @@ def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
     the seed hits, anchors and chains of a query grow with the number of target reads, its own sketch (a small part)
     does not, so this slightly overstates the CPU's time per read and is labelled as what it is: a sample."""
     from oracle import oracle as O
-    cores = O.default_threads()       # (threads actually used: twice the CPUs the host grants, oracle.host_cpus)
+    cores = O.default_threads()       # (threads actually used: the CPUs the host grants, oracle.host_cpus)
     F = 40
     nt = max(1000, Tn // F)
     opt = O.make_opt(O.PRESET_AVA_PB if preset else O.PRESET_AVA_ONT, dual=True)
@@ -323,6 +326,7 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
                       "clock": "host (ASCII reads in pinned host memory: a rank's host-side pack and PCIe transfer are inside its busy time)" if from_host else "resident",
                       "strategy": "inverse (--use-min-ref: index = queries, replicated; streamed targets cut by bases)" if a.inverse else
                                   ("forward, TARGETS sharded (lrge_hip_index_build_tsharded): every rank maps all queries against its share, counts all-reduced" if forward_mode == "tshard"
+                                   else "forward, queries sharded, the WHOLE index built by every rank (north_star's literal form: replicated index, one gather)" if forward_mode == "replicated"
                                    else "forward, queries sharded (target sketch sharded, restricted index per rank)"),
                       "one_gpu_ms_per_step": t_one, "max_rank_busy_ms_per_step": busy,
                       "projected_speedup_compute_only": t_one / busy,
@@ -430,6 +434,9 @@ def main():
     # ... and since round 4 the default multi-GPU form of the forward strategy shards the TARGETS (lrge_hip_index_build_tsharded): every
     # rank indexes its share of the targets and maps ALL queries, the count vectors add up in one all-reduce; no index entry crosses a
     # link.  LRGE_BENCH_FORWARD=qshard selects the query-sharded form of rounds 2-3.
+    # LRGE_BENCH_FORWARD=replicated: north_star's LITERAL form -- the target index replicated (every rank builds the whole of it, no
+    # collective inside the build), the queries cut by bases, one all-gather of the per-read estimates -- selectable so that the forms
+    # above are measured against it instead of argued (missing 6)
     forward_mode = os.environ.get("LRGE_BENCH_FORWARD", "auto")
     if forward_mode == "auto":
         # every rank of the target-sharded form sketches and looks up ALL queries: it pays when that redundant work is small against a
@@ -440,6 +447,33 @@ def main():
 
     class Src:
         """One read set of one rank's job: offsets, name ranks, and where its ASCII bases live (HBM; host on request)."""
+
+    _shared = {}
+
+    class _SharedDev:
+        """A DeviceReads several ranks of an emulated world hold together: free() is the last holder's."""
+
+        def __init__(self, dev):
+            self.__dict__["_d"] = dev
+            self.__dict__["_n"] = 0
+
+        def __getattr__(self, k):
+            return getattr(self._d, k)
+
+        def free(self):
+            self.__dict__["_n"] -= 1
+            if self._n <= 0 and self._d.ptr:
+                self._d.free()
+                _shared.pop(self._key, None)
+
+    def _shared_reads(first, n, device):
+        key = (first, n, device)
+        if key not in _shared or not _shared[key]._d.ptr:
+            sd = _SharedDev(spec.device_reads(first, n, device))
+            sd.__dict__["_key"] = key
+            _shared[key] = sd
+        _shared[key].__dict__["_n"] += 1
+        return _shared[key]
 
     class RankJob:
         """What one rank does per step.  my / n_shards: which share of the STREAMED set it owns -- contiguous ranges with equal
@@ -452,14 +486,15 @@ def main():
             q_rng = (0, Qn) if (a.inverse or n_shards == 1) else (lo, hi)
             t_rng = (lo, hi) if (a.inverse and n_shards > 1) else (0, Tn)
             self.tshard = forward_mode == "tshard" and not a.inverse and n_shards > 1 and comm is not None
-            self.sharded = shard_targets and n_shards > 1 and comm is not None and not self.tshard
+            self.replicated = forward_mode == "replicated" and not a.inverse and n_shards > 1 and comm is not None
+            self.sharded = shard_targets and n_shards > 1 and comm is not None and not self.tshard and not self.replicated
             if self.sharded or self.tshard:
                 tb_ = parallel.shard_by_bases(t_lens, n_shards)
                 t_rng = (tb_[my], tb_[my + 1])
             if self.tshard:
                 q_rng = (0, Qn)
                 self.bounds = tb_
-            self.restrict = (comm is not None or emulated_share or bool(os.environ.get("LRGE_BENCH_RESTRICT"))) and not a.inverse
+            self.restrict = (comm is not None or emulated_share or bool(os.environ.get("LRGE_BENCH_RESTRICT"))) and not a.inverse and not self.replicated
             self.q_rng, self.t_rng = q_rng, t_rng
             self.shard_lens = [self.bounds[i + 1] - self.bounds[i] for i in range(n_shards)]
             self.max_shard = max(self.shard_lens)
@@ -480,7 +515,10 @@ def main():
         def load_resident(self):
             """(counter-based generator) the ASCII reads of this rank written into HBM by the device twin"""
             for S, (r0, r1), first in ((self.qs, self.q_rng, 0), (self.ts, self.t_rng, Qn)):
-                S.dev = spec.device_reads(first + r0, r1 - r0, self.device)      # ASCII straight into HBM
+                if self.replicated and S is self.ts:      # every rank of an emulated world reads the SAME targets: one copy serves them all
+                    S.dev = _shared_reads(first + r0, r1 - r0, self.device)
+                else:
+                    S.dev = spec.device_reads(first + r0, r1 - r0, self.device)      # ASCII straight into HBM
                 S.n, S.offsets, S.rank, S.nbytes, S.ptr = r1 - r0, S.dev.offsets, S.dev.name_ranks(), S.dev.total_bases, S.dev.ptr
                 S.host = S.dev.to_host
 
@@ -531,6 +569,8 @@ def main():
                 elif self.sharded:
                     ix = engine.Index(ctx, Td, preset, streamed=Qd, comm=comm, shard=(t_lens, tr_all, self.t_rng[0]))
                     self.shard_stats = ix.shard_stats
+                elif self.replicated:      # the whole index on every rank: the plain single-GPU build, no collective
+                    ix = engine.Index(ctx, Td, preset)
                 else:
                     ix = engine.Index(ctx, Td, preset, streamed=Qd if self.restrict else None, comm=comm)
                 tb = dict(ix.build_timings); cb_ = dict(ix.build_counters)
@@ -585,7 +625,7 @@ def main():
             _, _, _, tb, tm, cn, _ = last
             for k, v in tb.items(): acc_tb[k] = acc_tb.get(k, 0.0) + v
             for k, v in tm.items(): acc_tm[k] = acc_tm.get(k, 0.0) + v
-            for k, v in cn.items(): acc_cn[k] = v if k == "lpg_split" else acc_cn.get(k, 0) + v
+            for k, v in cn.items(): acc_cn[k] = v if k in ("lpg_split", "index_parts") else acc_cn.get(k, 0) + v
         sync_all()
         elapsed = time.perf_counter() - t0
         if use_dist:
@@ -702,7 +742,7 @@ def main():
         #   families           index radix sort (k_rs_hist + scan + k_rs_scatter, all passes): one read + one write of every entry;
         #                      index sketch (k_sketch_direct + k_sketch_compact): L/4 B of packed bases in + one entry out
         # traffic: HBM bytes per launch of that kernel from the round's committed rocprofv3 --pmc passes of this same command
-        # (profiles/r04_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950); the counters
+        # (profiles/r05_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950); the counters
         # cannot be read inside a timed run.
         cands, fams = [], []
         if acc_cn.get("lookup_launches", 0):
@@ -748,10 +788,18 @@ def main():
             r_["traffic"], r_["traffic_detail"] = committed_kernel_traffic(a.config, a.inverse, r_["kernel"]) if r_["kind"] == "kernel" else (None, None)
         # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
         # (streamed set: the queries, or the targets with --inverse; for N > 1 rank 0's counters times the world size)
-        L = float((t_lens if a.inverse else q_lens).sum()); M = world * acc_cn.get("query_minimizers", 0) / K; H = world * acc_cn.get("anchors", 0) / K
+        # M = minimizers of the streamed set, counted ONCE: against a partitioned index every part looks all of them up, and the
+        # library's counter adds them up per part (1.122 G = 3 x 374 M had inflated B_q by 24 GB)
+        n_parts = max(1, int(acc_cn.get("index_parts", 0)))
+        L = float((t_lens if a.inverse else q_lens).sum()); M = world * acc_cn.get("query_minimizers", 0) / K / n_parts; H = world * acc_cn.get("anchors", 0) / K
         B_q = L / 4 + 32 * M + 8 * H + 32 * H + 4 * Qn
         B_idx = float((q_lens if a.inverse else t_lens).sum()) / 4 + 16 * st["n_minimizers"]
         e2e_gbps = (B_q + B_idx) / (ms_per_step * 1e-3) / 1e9
+        whole_path = {"what": "SURVEY 8(d), strictly: sum over queries of B_q = L/4 + 32 M + 40 H + 4, plus B_idx = L_T/4 + 16 M_T, over the step's wall time; "
+                              "ordering (every radix pass) counts as ZERO algorithmic bytes",
+                      "alg_GB_per_step": (B_q + B_idx) / 1e9, "B_q_GB": B_q / 1e9, "B_idx_GB": B_idx / 1e9, "alg_GBps": e2e_gbps, "peak_GBps": HBM_PEAK_GBPS,
+                      "frac": e2e_gbps / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": e2e_gbps / 6290.0,
+                      "streamed_minimizers": M, "anchors": H, "index_minimizers": st["n_minimizers"], "index_parts": n_parts}
         r_dom = cands[0] if cands else {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 0.0, "traffic": None}
         clock_txt = ("ASCII reads in pinned HOST memory when the clock starts (SURVEY 8d): host-side 2-bit pack + PCIe inside the step"
                      if clock_host else "ASCII reads resident in HBM, 2-bit pack inside the step")
@@ -768,6 +816,8 @@ def main():
                        "parallelism": ("one job, streamed targets cut into %d ranges by bases; query index replicated; counts all-reduced" % world) if a.inverse else
                                       ("one job, TARGETS cut into %d ranges by bases: every rank indexes its range and maps all queries; occurrence statistics made "
                                        "global by one all-to-all of (key, count) pairs; the count vectors all-reduced" % world) if job.tshard else
+                                      ("one job, queries cut into %d ranges by bases; the WHOLE target index built on every rank (north_star's literal form: "
+                                       "replicated index, one gather of the estimates)" % world) if job.replicated else
                                       ("one job, queries cut into %d ranges by bases; index %s" %
                                        (world, ("restricted to each rank's query minimizers, global occurrence statistics by one all-reduce" +
                                                 ("; every rank sketches 1/%d of the targets, key sets all-gathered, kept entries and owned hashes by all-to-all" % world if job.sharded else ""))
@@ -775,7 +825,7 @@ def main():
                        "collectives": transport if use_dist else None,
                        "rccl_ranks": (comm.rccl_ranks() if (comm is not None and hasattr(comm, "rccl_ranks")) else None),
                        "target_sketch": ("targets sharded, all queries mapped by every rank (lrge_hip_index_build_tsharded)" if job.tshard else
-                                         "sharded (lrge_hip_index_build_sharded)" if job.sharded else "replicated") if world > 1 and not a.inverse else None,
+                                         "sharded (lrge_hip_index_build_sharded)" if job.sharded else "replicated (whole index per rank)" if job.replicated else "replicated") if world > 1 and not a.inverse else None,
                        "exchange_per_step_rank0": job.shard_stats,
                        "scale": a.scale, "data_gen_s": round(t_gen, 1)},
             "resident": resident,
@@ -785,12 +835,15 @@ def main():
             "genome_size_abs_error": None if med[1] is None else abs(float(med[1]) - gsize),
             "estimate_q15_q65": [None if med[0] is None else float(med[0]), None if med[2] is None else float(med[2])],
             "mid_occ": st["mid_occ"],
+            # the path's roofline fraction is `roofline_whole_path.frac`; `roofline` below is ONE kernel (the dominant one among those timed
+            # with event pairs), and for k_rs_scatter its denominator is not 8(d)'s (which counts ordering as zero) but what any sort must move
+            "roofline_whole_path": whole_path,
             "roofline": {**r_dom, "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS,
                          "whole_path_traffic": committed_traffic(a.config, a.inverse)},
             "roofline_other": cands[1:] + fams,
             "stage_ms_per_step": {**{"index_" + k: v / K for k, v in acc_tb.items() if v and k != "total"},
                                   **{k: v / K for k, v in acc_tm.items() if v}},
-            "work_per_step": {k: (v if k == "lpg_split" else v / K) for k, v in acc_cn.items()},
+            "work_per_step": {k: (v if k in ("lpg_split", "index_parts") else v / K) for k, v in acc_cn.items()},
         }
         if world == 1 and not a.no_cpu_baseline and not a.inverse:   # (the CPU leg times the forward strategy)
             if gen == "cb" and Tn > 400000:

@@ -102,6 +102,8 @@ enum {
                              table; divided by the number of keys it is ~0.5 at load 1/2 when the home slots are uniform */,
     LRGE_C_ANCHORS_KEPT /* of LRGE_C_ANCHORS (every seed hit expanded: minimap2's n_a), the anchors that left the expansion: the
                            dead-pair filter of count-only runs drops those of (target, strand) pairs too small to chain */,
+    LRGE_C_INDEX_PARTS /* parts of the (partitioned) index the last overlap call went through, 0 = one index: LRGE_C_QUERY_MINIMIZERS and
+                          LRGE_C_LOOKUP_LAUNCHES count every streamed minimizer once PER PART */,
     LRGE_C_N
 };
 

@@ -255,11 +255,19 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             // the pair layout, segment-packed (k_prims.h: index_sort_segpacked): behind the first digit the low hash byte is implied
             // and the rest of the entry fits one word -- fewer bytes through the remaining passes, 8 bytes per entry resident
             const u32 yb_p = pk_rid + pk_pos1;
-            // (round 4) up to SEG_PACK_EXTRA_MAX more implied bits when the word is that much too narrow: full-size C5 in 3 parts has
-            // read ids of 20 bits, 2 bits too many (option DEBUG_SEG_EXTRA forces them on small sets)
+            // `over` more hash bits must be implied by the segment for the word to fit (full-size C5 in 3 parts has read ids of 20 bits:
+            // 2 too many); beyond that, e is chosen so that what is LEFT of the hash, nr = 2k - 8 - e bits, takes as few 8-bit LSD
+            // passes as possible (round 5: k = 19 -> e = 6, nr = 24: passes A + A2 + 3 instead of A + A2 + 4; k = 15 -> e = 0, 22 bits
+            // in 3 passes either way).  DEBUG_SEG_EXTRA forces an e on small sets; SEG_PACK_EXTRA_MAX caps it (0: never an A2 pass).
             const u32 over = 2 * (u32)P.k - 8 + yb_p > 64 ? 2 * (u32)P.k - 8 + yb_p - 64 : 0;
-            u32 extra = std::max<u32>(over, (u32)ctx->opt_u64("DEBUG_SEG_EXTRA", 0));
-            const bool extra_ok = extra == 0 || (2 * P.k >= 24 && extra <= (u32)ctx->opt_u64("SEG_PACK_EXTRA_MAX", 4) && extra <= 4);
+            const u32 e_cap = std::min<u32>(7, (u32)ctx->opt_u64("SEG_PACK_EXTRA_MAX", 7));
+            u32 extra = over;
+            if (ctx->opt("DEBUG_SEG_EXTRA")) extra = std::max<u32>(over, (u32)ctx->opt_u64("DEBUG_SEG_EXTRA", 0));
+            else {
+                auto n_pass = [&](u32 e) { return 1u + (e ? 1u : 0u) + (2 * (u32)P.k - 8 - e + 7) / 8; };
+                for (u32 e = over + 1; e <= e_cap && 2 * (u32)P.k > 16 + e; ++e) if (n_pass(e) < n_pass(extra)) extra = e;
+            }
+            const bool extra_ok = extra == 0 || (extra <= e_cap && 2 * (u32)P.k > 16 + extra);
             if (pass_from == 0 && extra_ok && 2 * P.k > 16 && !ctx->opt("NO_SEG_PACK") && M >= ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22)) {
                 u64 *rk = nullptr;
                 rc = index_sort_segpacked(ctx, sc, so.x, so.y, k1, v1, M, 2 * P.k, yb_p, pk_pos1, extra, &rk, &d_seg_start);
@@ -340,14 +348,14 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
                 const u32 n_tiles = (u32)div_up(n_runs, PLACE_TILE);
                 u32 *bmax = sc.get<u32>((size_t)n_tiles + 1);
                 if (!bmax) return LRGE_ERR_DEVICE;
-                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax, kshift_t, ht_fix, SegStarts{d_seg_start, seg_e});
+                hipLaunchKernelGGL(k_place_reduce, dim3(n_tiles), dim3(PLACE_THREADS), 0, ctx->stream, skey, d_runstart, n_runs, cap, bmax, kshift_t, ht_fix, SegStarts{d_seg_start, seg_e, 2 * (u32)P.k});
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_scan, dim3(1), dim3(1024), 0, ctx->stream, bmax, n_tiles);
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_place_apply, dim3(std::min<u32>(n_tiles, (u32)ctx->n_cu * 8)), dim3(PLACE_THREADS), 0, ctx->stream,
                                    skey, d_runstart, n_runs, M, cap, n_slots, bmax, ht, d_occ, max_bin, d_occ + max_bin + 1, kshift_t, ht_fix,
                                    fused_fill ? bmax + n_tiles : (u32 *)nullptr, pk_t ? (const u64 *)nullptr : (const u64 *)spos, pk_t ? pk_pos1 : 0u,
-                                   ctx->opt("NO_INLINE_SINGLETONS") ? 0u : 1u, SegStarts{d_seg_start, seg_e});
+                                   ctx->opt("NO_INLINE_SINGLETONS") ? 0u : 1u, SegStarts{d_seg_start, seg_e, 2 * (u32)P.k});
                 KCHK(ctx);
                 if (fused_fill) {
                     hipLaunchKernelGGL(k_fill_tail, dim3((u32)std::min<u64>(div_up(n_slots - cap / 2, 256), (u64)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, ht, n_slots, bmax + n_tiles);

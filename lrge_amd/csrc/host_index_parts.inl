@@ -327,7 +327,7 @@ extern "C" int lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, 
         }
         if (!ix->h_seg_start.empty())        // segment-packed: the low hash byte is the number of the entry's segment
             for (u32 sgm = 0; sgm + 1 < (u32)ix->h_seg_start.size(); ++sgm)
-                for (u64 i = ix->h_seg_start[sgm]; i < ix->h_seg_start[sgm + 1]; ++i) hk[i] = seg_hash(hk[i], sgm, ix->seg_e);
+                for (u64 i = ix->h_seg_start[sgm]; i < ix->h_seg_start[sgm + 1]; ++i) hk[i] = seg_hash(hk[i], sgm, ix->seg_e, 2 * (u32)ix->P.k);
     }
     std::vector<u32> ord(ix->n_entries);
     for (u64 i = 0; i < ix->n_entries; ++i) ord[i] = (u32)i;

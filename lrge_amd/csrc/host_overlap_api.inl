@@ -91,13 +91,13 @@ static std::vector<u32> stream_cuts(const lrge_hip_seqset *s) {
     return cuts;
 }
 struct StageAcc {      // timings / counters of a call made of several passes
-    float ms[LRGE_T_N]; u64 cn[LRGE_C_N];
+    float ms[LRGE_T_N]; u64 cn[LRGE_C_N]; u64 parts = 0;
     StageAcc() { memset(ms, 0, sizeof ms); memset(cn, 0, sizeof cn); }
     void add(const lrge_hip_ctx *ctx) {
         for (int i = 0; i < LRGE_T_N; ++i) ms[i] += ctx->ms[i];
         for (int i = 0; i < LRGE_C_N; ++i) cn[i] = i == LRGE_C_LPG_SPLIT ? ctx->counters[i] : cn[i] + ctx->counters[i];
     }
-    void store(lrge_hip_ctx *ctx) const { memcpy(ctx->ms, ms, sizeof ms); memcpy(ctx->counters, cn, sizeof cn); }
+    void store(lrge_hip_ctx *ctx) const { memcpy(ctx->ms, ms, sizeof ms); memcpy(ctx->counters, cn, sizeof cn); ctx->counters[LRGE_C_INDEX_PARTS] = parts; }
 };
 
 // two-set forward against one (unpartitioned) index, the queries in views if there are too many of them
@@ -154,6 +154,7 @@ extern "C" int lrge_hip_overlap_twoset(lrge_hip_ctx *ctx, const lrge_hip_index *
             }
     }
     const u32 nq = queries->n;
+    acc.parts = ix->parts.size();
     std::vector<u32> c((size_t)nq + 1), h((size_t)nq + 1);
     if (counts) std::fill(counts, counts + nq, 0u);
     if (has_mapping) std::fill(has_mapping, has_mapping + nq, 0u);
@@ -216,6 +217,7 @@ extern "C" int lrge_hip_overlap_inverse(lrge_hip_ctx *ctx, const lrge_hip_index 
     }
     // partitioned index: the parts hold disjoint indexed reads, every part sees all streamed reads and the global mid_occ --
     // a part's counts are the counts of its reads
+    acc.parts = ix->parts.size();
     for (size_t pi = 0; pi < ix->parts.size(); ++pi) {
         rc = inverse_one_index(ctx, ix->parts[pi], streamed, job, counts ? counts + ix->part_r0[pi] : nullptr, acc);
         if (rc) return rc;

@@ -298,8 +298,8 @@ struct lrge_hip_index {
     u64 *d_skey = nullptr;      // [n_mz] sorted keys (kept for index_dump / tests)
     u64 *d_ht = nullptr;        // ordered open-addressing table of {key, start<<24 | min(count, 2^24-1)} pairs (k_index.h)
     u32 pk_pos1 = 0, pk_ybits = 0;   // packed entries (d_skey == d_pos): hash << pk_ybits | rid << pk_pos1 | (pos << 1 | strand)
-    std::vector<u32> h_seg_start;    // segment-packed entries (k_prims.h: index_sort_segpacked): the hash field lacks its low byte = the segment [h_seg_start[s], h_seg_start[s + 1])
-    u32 seg_e = 0;                   // ... and, with seg_e > 0, the top seg_e bits of its second byte: 256 << seg_e segments numbered b0 << seg_e | q (k_index.h: seg_hash)
+    std::vector<u32> h_seg_start;    // segment-packed entries (k_prims.h: index_sort_segpacked): the hash field holds the low 2k - 8 - seg_e bits of the hash's significance
+    u32 seg_e = 0;                   // string, the top 8 + seg_e bits are the number of the segment [h_seg_start[s], h_seg_start[s + 1]) the entry lies in: 256 << seg_e segments (k_index.h: seg_hash)
     u64 ht_cap = 0;             // home slots are [0, ht_cap); slack slots follow
     u32 ht_fix = 0;             // how ht_home() stretches the partial top byte of the hash (k_index.h); fixed at build time
     u64 ht_slots = 0;           // ht_cap + slack

@@ -78,13 +78,17 @@ __device__ __forceinline__ u64 ht_home(u64 key, u64 cap, u32 fix) {
 #define PLACE_TILE (PLACE_THREADS * PLACE_ROWS)
 #define PLACE_COMP 384      // slots a wavefront composes in LDS (64 runs at load 1/2 span ~128)
 
-// The hash of entry `st` of the sorted stream.  seg.start != null: a segment-packed index (k_prims.h: index_sort_segpacked) --
-// the entry holds the hash without the bits its segment implies: the low byte b0 and, with seg.e > 0, the top e bits q of the
-// second byte (a prefix of the byte-reversed order: segment number = b0 << e | q, 256 << e segments).
-struct SegStarts { const u32 *start; u32 e; };
-__host__ __device__ __forceinline__ u64 seg_hash(u64 h, u32 sgm, u32 e) {        // h = the stored bits, sgm = the segment's number
-    const u32 lb = 8 - e;                                                          // bits of the second byte that stay in the entry
-    return (h >> lb) << 16 | (u64)(sgm & ((1u << e) - 1)) << (16 - e) | (h & ((1u << lb) - 1)) << 8 | (sgm >> e);
+// The hash of entry `st` of the sorted stream.  seg.start != null: a segment-packed index (k_prims.h: index_sort_segpacked).
+// The stream is ordered by the byte-reversed hash; written as ONE number, that order is the hash's SIGNIFICANCE STRING
+//     S = b0 . b1 . b2 ... b(m-1)          (b0 = low byte, most significant; the top byte b(m-1) holds tb = nbits - 8 (m - 1) bits)
+// (hash_to_sig: a byte swap with the partial top byte squeezed).  A segment-packed entry keeps the low nr = nbits - 8 - e bits R of
+// S -- the top 8 + e bits are the NUMBER of the segment it lies in (256 << e segments) -- so its hash field compares like the order
+// itself and the LSD passes of the sort may cut R wherever they like (round 5; rounds 3-4 stored the hash's own bytes, which tied
+// the digits to byte boundaries: k = 19 with e = 2 took four keys-only passes over 6 + 8 + 8 + 6 bits, now e = 6 leaves 24 = 3 x 8).
+struct SegStarts { const u32 *start; u32 e, nbits; };
+// (hash_to_sig / sig_to_hash: k_prims.h, beside the sort that packs the entries)
+__host__ __device__ __forceinline__ u64 seg_hash(u64 R, u32 sgm, u32 e, u32 nbits) {        // R = the stored bits, sgm = the segment's number
+    return sig_to_hash((u64)sgm << (nbits - 8 - e) | R, nbits);
 }
 // the last segment whose start is <= st (empty segments share their start with the next)
 __device__ __forceinline__ u32 seg_of(SegStarts seg, u32 st) {
@@ -102,7 +106,7 @@ __device__ __forceinline__ u64 entry_hash(const u64 *__restrict__ skey, u32 st, 
     u32 lo;
     if (hint == 0xFFFFFFFFu) lo = seg_of(seg, st);
     else { const u32 n_seg = 256u << seg.e; lo = hint; while (lo + 1 < n_seg && seg.start[lo + 1] <= st) ++lo; }
-    return seg_hash(h, lo, seg.e);
+    return seg_hash(h, lo, seg.e, seg.nbits);
 }
 
 // d(r) = home(r) + (n_runs - r): slot(r) = prefix-max(d)(r) - (n_runs - r).  Needs cap + n_runs < 2^32.

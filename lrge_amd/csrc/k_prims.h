@@ -259,13 +259,29 @@ struct SegTile { u32 start, len, hbase, hstride, seg, delta, src, pad; };
 // Packed anchors (count-only runs): one u64 = [self 1 | span 8 | qpos bits_qy | sort bits sb], sorted KEYS-ONLY on the
 // low sb bits; the last scatter pass unpacks every record into the (key, value) pair the chain kernels read
 // (key = segment << sh_q | sort bits, value = self << 43 | span << 32 | qpos) -- see k_seed.h for the layouts.
-struct UnpackParams { u32 sb, bits_qy, sh_q, dmask; };   // dmask: digit mask of the pass (the last digit may be narrower than 8 bits)
+// The SIGNIFICANCE STRING of an nbits-bit hash: the index stream is ordered by the byte-reversed hash (k_index.h), i.e. by
+//     S = b0 . b1 . b2 ... b(m-1)          (b0 = low byte, most significant; the top byte b(m-1) holds tb = nbits - 8 (m - 1) bits)
+// read as one number -- a byte swap with the partial top byte squeezed.  Segment-packed index entries (index_sort_segpacked) keep the
+// low bits of S; its top bits are the number of their segment.
+__host__ __device__ __forceinline__ u64 hash_to_sig(u64 h, u32 nbits) {
+    const u32 m = (nbits + 7) >> 3, tb = nbits - 8 * (m - 1);
+    const u64 X = __builtin_bswap64(h) >> (64 - 8 * m);                          // b0 | b1 | ... | b(m-1), whole bytes
+    return (X >> 8) << tb | (X & 0xFFu);                                          // (the top byte's upper bits are zero)
+}
+__host__ __device__ __forceinline__ u64 sig_to_hash(u64 S, u32 nbits) {
+    const u32 m = (nbits + 7) >> 3, tb = nbits - 8 * (m - 1);
+    const u64 X = (S >> tb) << 8 | (S & ((1ULL << tb) - 1));
+    return __builtin_bswap64(X << (64 - 8 * m));
+}
+struct UnpackParams { u32 sb, bits_qy, sh_q, dmask, nbits; };   // dmask: digit mask of the pass (the last digit may be narrower than 8 bits); nbits: hash bits (PACK / PACKQ)
 #define RS_MODE_PAIRS 0
 #define RS_MODE_KEYS 1
 #define RS_MODE_UNPACK 2
-#define RS_MODE_PACK 3      // (hash, y) pairs in, ONE packed u64 out: (hash >> 8) << up.sb | rid << up.bits_qy | (pos << 1 | strand); `shift` addresses the packed value
+#define RS_MODE_PACK 3      // (hash, y) pairs in, ONE packed u64 out: R << up.sb | rid << up.bits_qy | (pos << 1 | strand), R = the low up.nbits - 8 bits of the
+                            // hash's significance string (k_index.h: hash_to_sig; the low hash byte is the segment); `shift` addresses the packed value
 #define RS_MODE_PACKQ 4     // the same, and the pass's digit -- the top e = up.sh_q bits of the second hash byte, `shift` = 16 - e addresses the HASH -- is
-                            // left out of the word as well (the pass makes it part of the segment: index_sort_segpacked with e > 0)
+                            // left out of the word as well: R = the low up.nbits - 8 - e bits (the pass makes the digit part of the segment:
+                            // index_sort_segpacked with e > 0; e <= 7)
 
 // Blocks are observed to be dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Tile t and
 // tile t + 1 of a pass write adjacent runs in every digit's region, so they should meet in ONE L2: XCD x takes the
@@ -346,10 +362,12 @@ __device__ __forceinline__ void rs_load_from_slots(const SlotSrc &S, u32 bid, u6
 
 // DB: digit bits.  The library launches 8 only; the 10-bit instantiation lives with the measurements that ruled it out
 // (tools/micro/sort_forms.h: one 10-bit pass 0.58 + 0.15 + 1.33 ms against 0.43 + 0.05 + 0.88, the whole sort 5.8 against 5.0 ms)
+// sig_nbits != 0: the keys are raw hashes of that many bits and the digit is cut from their significance string (k_index.h:
+// hash_to_sig) -- the first LSD pass of index_sort_segpacked without an A2 pass reads the pairs' hashes
 template <bool SEG, int DB = 8, bool SLOTS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
                                                         u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255, SlotSrc src = SlotSrc(),
-                                                        u32 use_src = 0) {
+                                                        u32 use_src = 0, u32 sig_nbits = 0) {
     constexpr u32 ND = 1u << DB;
     static_assert(!SLOTS || !SEG, "slots feed whole (unsegmented) sorts only");
     __shared__ u32 h[ND];
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
     }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r)
-        if (l0 + (u32)r * 64 < n_tile) atomicAdd(&h[(u32)(kk[r] >> shift) & dmask], 1u);
+        if (l0 + (u32)r * 64 < n_tile) atomicAdd(&h[(u32)((sig_nbits ? hash_to_sig(kk[r], sig_nbits) : kk[r]) >> shift) & dmask], 1u);
     __syncthreads();
     for (u32 d = threadIdx.x; d < ND; d += RS_THREADS) {
         const u64 hi = SEG ? (u64)tiles[bid].hbase + (u64)d * tiles[bid].hstride : (u64)d * nb + bid;
@@ -394,7 +412,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     __shared__ u32 gbase[ND];            // global destination of the tile's digit run minus its local start
     __shared__ u32 wtot[RS_WAVES];
     __shared__ u64 stage[RS_TILE];       // 32 KB: keys, then values
-    __shared__ u32 dloc[MODE == RS_MODE_PACKQ ? 17 : 1];   // PACKQ: the digit is not in the staged word -- tile-local start of every digit's run (at most 16 digits)
+    // PACKQ: the digit is not in the staged word; it is staged beside it, one byte per item, in the rank counters' LDS (free by then)
+    static_assert(sizeof(u32) * RS_WAVES * ND >= RS_TILE || MODE != RS_MODE_PACKQ, "the digit bytes alias the rank counters");
+    u8 *sdig = (u8 *)&cnt[0][0];
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     const u32 bid = xcd_tile(blockIdx.x, gridDim.x);
     const u32 dmask = MODE == RS_MODE_PAIRS ? 255u : up.dmask;
@@ -419,10 +439,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     if (MODE == RS_MODE_PACK) {
         // the low hash byte is implied by the segment the tile lies in (index_sort_segpacked): what is left of the hash and
         // the position fit one word, and every later pass moves 8 bytes per entry instead of 16
-        const u64 pmask = (1ULL << up.bits_qy) - 1;
+        const u64 pmask = (1ULL << up.bits_qy) - 1, rmask = (1ULL << (up.nbits - 8)) - 1;
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r)
-            if (l0 + (u32)r * 64 < n_tile) k[r] = (k[r] >> 8) << up.sb | (v[r] >> 32) << up.bits_qy | (v[r] & pmask);
+            if (l0 + (u32)r * 64 < n_tile) k[r] = (hash_to_sig(k[r], up.nbits) & rmask) << up.sb | (v[r] >> 32) << up.bits_qy | (v[r] & pmask);
     }
     // (PACKQ: the digit comes from the hash itself, so the word is packed only when it is staged)
 #pragma unroll
@@ -462,7 +482,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
             const u32 d = threadIdx.x * DPT + j;
             const u64 hi = SEG ? (u64)tiles[bid].hbase + (u64)d * tiles[bid].hstride : (u64)d * nb + bid;
             gbase[d] = hist_scanned[hi] + (SEG ? tiles[bid].delta : 0u) - dstart;
-            if (MODE == RS_MODE_PACKQ && d <= 16) dloc[d] = dstart;
             u32 run = dstart;
 #pragma unroll
             for (int ww = 0; ww < RS_WAVES; ++ww) { cnt[ww][d] = run; run += c[j][ww]; }
@@ -475,11 +494,18 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     for (int r = 0; r < RS_ITEMS; ++r) {
         u32 d = (u32)(k[r] >> shift) & dmask;
         lpos[r] = cnt[w][d] + rank[r];
-        if (MODE == RS_MODE_PACKQ) {
-            const u32 lb = 8 - up.sh_q;
-            k[r] = ((k[r] >> 16) << lb | ((k[r] >> 8) & ((1u << lb) - 1))) << up.sb | (v[r] >> 32) << up.bits_qy | (v[r] & ((1ULL << up.bits_qy) - 1));
+        if (MODE != RS_MODE_PACKQ && l0 + (u32)r * 64 < n_tile) stage[lpos[r]] = k[r];
+    }
+    if (MODE == RS_MODE_PACKQ) {
+        __syncthreads();                               // every local position is known: the counters' LDS takes the digit bytes
+        const u64 pmask = (1ULL << up.bits_qy) - 1, rmask = (1ULL << (up.nbits - 8 - up.sh_q)) - 1;
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {
+            if (l0 + (u32)r * 64 < n_tile) {
+                sdig[lpos[r]] = (u8)((u32)(k[r] >> shift) & dmask);
+                stage[lpos[r]] = (hash_to_sig(k[r], up.nbits) & rmask) << up.sb | (v[r] >> 32) << up.bits_qy | (v[r] & pmask);
+            }
         }
-        if (l0 + (u32)r * 64 < n_tile) stage[lpos[r]] = k[r];
     }
     __syncthreads();
     u64 ko[RS_ITEMS];
@@ -504,10 +530,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         if (p < n_tile) {
             ko[r] = stage[p];
             u32 d = (u32)(ko[r] >> shift) & dmask;
-            if (MODE == RS_MODE_PACKQ) {           // the digit whose run holds p: the last one that starts at or before it
-                d = 0;
-                for (u32 j = 1; j <= dmask; ++j) d += p >= dloc[j] ? 1u : 0u;
-            }
+            if (MODE == RS_MODE_PACKQ) d = sdig[p];
             keys_out[gbase[d] + p] = ko[r];
         }
     }
@@ -962,13 +985,14 @@ __global__ void k_store_u32(u32 *p, u32 v) { *p = v; }
 
 static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky, u64 *k1, u64 *v1, u64 n, int nbits, u32 ybits, u32 pos1, u32 e,
                                 u64 **res, u32 **d_seg_start) {
-    // e > 0 (round 4): nbits - 8 + ybits exceeds 64 by e bits (large parts: read ids of 19-20 bits), so e more hash bits have to be
-    // implied -- the NEXT bits of the byte-reversed order, the top e bits q of the second byte.  Pass A2 is a most-significant-digit
-    // pass on q inside each of A's 256 segments (pairs in, packed words out: RS_MODE_PACKQ), leaving 256 << e segments numbered
-    // b0 << e | q; the LSD passes behind it are all keys-only, the last one over the 8 - e bits of the second byte that remain.
-    // 32 + 24 + 16 (passes - 1) bytes per entry through the scatters (k = 19, e = 2: 120 instead of 160 for the pair sort).
-    const int passes = (nbits + 7) / 8;
-    auto dbits = [&](int d) { return nbits - 8 * d >= 8 ? 8 : nbits - 8 * d; };
+    // e > 0: e more hash bits are implied by the segment -- the NEXT bits of the byte-reversed order, the top e bits q of the second
+    // byte -- because the word would be too narrow without (large parts: read ids of 19-20 bits) or because what is left of the hash then
+    // takes a pass less.  Pass A2 is a most-significant-digit pass on q inside each of A's 256 segments (pairs in, packed words out:
+    // RS_MODE_PACKQ), leaving 256 << e segments numbered b0 << e | q.  The entry keeps R, the low nr = nbits - 8 - e bits of the hash's
+    // significance string (hash_to_sig): R compares like the order itself, so the keys-only LSD passes behind cut it into 8-bit
+    // digits from the bottom, the last one taking what is left.  k = 19, e = 6: 32 + 24 + 3 x 16 = 104 bytes per entry through the
+    // scatters and five histograms (round 4, e = 2 with byte-aligned digits: 120 and six; the plain pair sort: 160).
+    const int nr = nbits - 8 - (int)e, passes = (nr + 7) / 8;      // LSD passes over R
     const u32 nb = (u32)div_up(n, RS_TILE), n_seg = 256u << e;
     const u32 max_tiles = nb + n_seg;                  // every segment ends in at most one partial tile
     ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * (max_tiles + 1) + 256);
@@ -1007,7 +1031,7 @@ static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky
         {
             StageTimer ts(ctx, LRGE_T_RS_SCATTER);
             hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_PACKQ>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, v1, pi, (u64 *)nullptr, n, 16 - (int)e, cur_tiles, hist,
-                               (const SegTile *)d_tiles, UnpackParams{ybits, pos1, e, qm});
+                               (const SegTile *)d_tiles, UnpackParams{ybits, pos1, e, qm, (u32)nbits});
             KCHK(ctx);
             ts.stop();
         }
@@ -1017,19 +1041,19 @@ static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky
         hipLaunchKernelGGL(k_seg_tile_fill, dim3(div_up(cur_tiles, 256)), dim3(256), 0, ctx->stream, (const u32 *)d_b, (const u32 *)d_tb, n_seg, cur_tiles, (SegTile *)d_tiles);
         KCHK(ctx);
     }
-    // ---- the remaining digits, least significant first: d = passes - 1 (e == 0: pairs in, packed out), then passes - 2 .. 1 ----
-    // digit d >= 2 sits at bit 8 (d - 1) - e of the stored hash bits, digit 1 at bit 0 with 8 - e bits
-    for (int d = passes - 1; d >= 1; --d) {
-        const bool first = !e && d == passes - 1;
-        const u32 dm = (1u << (d == 1 ? 8 - (int)e : dbits(d))) - 1u;
-        const int pshift = (int)ybits + (d == 1 ? 0 : 8 * (d - 1) - (int)e);   // where digit d sits in the packed word
-        if (first) hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, n, 8 * d, cur_tiles, hist, (const SegTile *)d_tiles, dm);
+    // ---- the digits of R, least significant first (e == 0: the first of them reads the pairs and packs) ----
+    for (int j = 0; j < passes; ++j) {
+        const bool first = !e && j == 0;
+        const int w = nr - 8 * j >= 8 ? 8 : nr - 8 * j;
+        const u32 dm = (1u << w) - 1u;
+        const int pshift = (int)ybits + 8 * j;                           // where digit j sits in the packed word
+        if (first) hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, n, 0, cur_tiles, hist, (const SegTile *)d_tiles, dm, SlotSrc(), 0u, (u32)nbits);
         else hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, n, pshift, cur_tiles, hist, (const SegTile *)d_tiles, dm);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * cur_tiles, nullptr); if (rc) return rc;
         StageTimer ts(ctx, LRGE_T_RS_SCATTER);
         if (first) hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_PACK>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, v1, pi, (u64 *)nullptr, n, pshift, cur_tiles, hist,
-                                      (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm});
+                                      (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm, (u32)nbits});
         else hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, (const u64 *)nullptr, po, (u64 *)nullptr, n, pshift, cur_tiles,
                                 hist, (const SegTile *)d_tiles, UnpackParams{0, 0, 0, dm});
         KCHK(ctx);

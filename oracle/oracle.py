@@ -79,11 +79,12 @@ def host_cpus():
 
 
 def default_threads():
-    """OpenMP threads the oracle runs with unless told otherwise: LO_THREADS, else twice the CPUs the host grants (the mapping loop
-    waits on memory: measured best around 2-4 threads per granted CPU), at most the hardware threads."""
+    """OpenMP threads the oracle runs with unless told otherwise: LO_THREADS, else the CPUs the host grants (measured on this pool's
+    boxes, 16 granted CPUs under 256 hardware threads, H. sapiens-scale HiFi reads against 50 000 targets: 8 threads 2 708 reads/s,
+    16: 5 337, 24: 5 311, 32: 5 058, 64: 4 403, 256: 2 646 -- profiles/r05_cpu_port_scaling.txt)."""
     if os.environ.get("LO_THREADS"):
         return max(1, int(os.environ["LO_THREADS"]))
-    return int(max(1, min(os.cpu_count() or 1, round(2 * host_cpus()))))
+    return int(max(1, min(os.cpu_count() or 1, round(host_cpus()))))
 
 
 def lib():

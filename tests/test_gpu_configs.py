@@ -25,7 +25,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-THREADS = 0        # the oracle's default: twice the CPUs the host grants (oracle.default_threads)
+THREADS = 0        # the oracle's default: the CPUs the host grants (oracle.default_threads)
 
 
 def _sets(ctx, q, t):

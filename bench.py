@@ -112,27 +112,29 @@ def cpu_baseline(q, t, budget_s, preset):
 PROFILE_ROUND = "r05"
 
 
-def _committed(config, inverse):
-    """profiles/r05_hbm_traffic[_<config>].json (else round 4's): made by tools/summarize_profiles.py from the FETCH_SIZE / WRITE_SIZE passes of
-    this same command (tools/profile_round.sh)."""
+def _committed(config, inverse, preset_name=None):
+    """profiles/r05_hbm_traffic[_<config>][_ont].json (else round 4's): made by tools/summarize_profiles.py from the FETCH_SIZE / WRITE_SIZE passes of
+    this same command (tools/profile_round.sh).  A collection counts only if it is of this configuration, strategy AND preset."""
     names = []
+    tail = "_inverse" if inverse else ""
     for rnd in (PROFILE_ROUND, "r04"):       # (the newest committed collection of this configuration; the file's name is reported with the figures)
-        names += ["%s_hbm_traffic_%s%s.json" % (rnd, config, "_inverse" if inverse else ""), "%s_hbm_traffic.json" % rnd]
+        names += ["%s_hbm_traffic_%s%s_%s.json" % (rnd, config, tail, (preset_name or "").replace("ava-", "")), "%s_hbm_traffic_%s%s.json" % (rnd, config, tail),
+                  "%s_hbm_traffic.json" % rnd]
     for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
-            if d.get("config") == config and bool(d.get("inverse", False)) == bool(inverse):
+            if d.get("config") == config and bool(d.get("inverse", False)) == bool(inverse) and (preset_name is None or ("preset %s" % preset_name) in (d.get("workload") or "")):
                 return d, name
         except Exception:      # noqa: BLE001
             pass
     return None, None
 
 
-def committed_traffic(config, inverse=False):
+def committed_traffic(config, inverse=False, preset_name=None):
     """HBM bytes per step of the whole path from the round's committed rocprofv3 --pmc passes, next to the algorithmic bytes:
     the counters cannot be read inside a timed run."""
-    d, name = _committed(config, inverse)
+    d, name = _committed(config, inverse, preset_name)
     if d is None:
         return None
     out = {k: d[k] for k in ("fetch_GB_per_step", "write_GB_per_step", "algorithmic_GB_per_step", "traffic_over_algorithmic", "source") if k in d}
@@ -140,10 +142,10 @@ def committed_traffic(config, inverse=False):
     return out
 
 
-def committed_kernel_traffic(config, inverse, kernel):
+def committed_kernel_traffic(config, inverse, kernel, preset_name=None):
     """(HBM bytes per launch of `kernel` [2 x FETCH_SIZE + WRITE_SIZE, averaged over its launches and template instantiations
     in the committed pass], detail) or (None, None)."""
-    d, name = _committed(config, inverse)
+    d, name = _committed(config, inverse, preset_name)
     if d is None:
         return None, None
     n = f = w = 0.0
@@ -255,6 +257,12 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
             if big:
                 c.set_option("POOL_SEG_MAX_MB", "256")      # (every large array gets a segment of its own: what a waiting rank keeps is what it uses)
                 c.set_option("HT_SLOTS_X100", "125")        # (N resident tables on one GPU: the load a part of a partitioned index runs at)
+                # a rank on a GPU of its own takes its share's anchors in ONE batch (~1.4 G seed hits of a 288-GB device); here the planner
+                # sees what the other N - 1 ranks leave free and cut some ranks' shares into 2-5 batches, each paying the chain stage's
+                # longest-group latency again -- the "moving outlier" of round 4 (batches 4-5 -> chain 47-50 ms instead of 13: profiles/
+                # r05_emulated_world8_fwd_resident_runs.txt).  The batch size a GPU of its own would pick is pinned; a batch that really
+                # does not fit is still retried in halves (host_overlap_batch.inl)
+                c.set_option("BATCH_ANCHORS", str(1 << 31))
             comm = grp.comm(c, r)
             comm.turn(True)
             job = RankJob(c, comm, r, N, device)
@@ -278,6 +286,8 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
                 detail = dict(counts_differ=nd, first=[int(x) for x in np.nonzero(counts != mine)[0][:8]] if nd > 0 else [], stats=st, ref_stats=ref_st,
                               estimates_equal=bool(np.array_equal(est_all.view(np.uint32), ref_est.view(np.uint32))))
             res[r] = dict(rank=r, busy_ms_per_step=busy, results_equal_one_gpu=ok, mismatch=detail, streamed_reads_of_rank=hi - lo, shard=job.shard_stats,
+                          work_last_step={k: int(cn.get(k, 0)) for k in ("batches", "lpg_split", "lpg_launches", "lpg_anchors", "chain_launches", "chain_anchors", "chain_glb_anchors",
+                                                                         "groups_chained", "anchors", "anchors_kept", "query_minimizers", "index_parts")},
                           stage_ms={**{"index_" + k: round(v, 3) for k, v in tb.items() if v and k != "total"}, **{k: round(v, 3) for k, v in tm.items() if v}})
             release()
             comm.close(); c.close()
@@ -785,7 +795,7 @@ def main():
         for r_ in fams: r_["kind"] = "family"
         cands.sort(key=lambda r: -r["ms_per_step"])
         for r_ in cands + fams:
-            r_["traffic"], r_["traffic_detail"] = committed_kernel_traffic(a.config, a.inverse, r_["kernel"]) if r_["kind"] == "kernel" else (None, None)
+            r_["traffic"], r_["traffic_detail"] = committed_kernel_traffic(a.config, a.inverse, r_["kernel"], "ava-pb" if preset else "ava-ont") if r_["kind"] == "kernel" else (None, None)
         # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
         # (streamed set: the queries, or the targets with --inverse; for N > 1 rank 0's counters times the world size)
         # M = minimizers of the streamed set, counted ONCE: against a partitioned index every part looks all of them up, and the
@@ -839,7 +849,7 @@ def main():
             # with event pairs), and for k_rs_scatter its denominator is not 8(d)'s (which counts ordering as zero) but what any sort must move
             "roofline_whole_path": whole_path,
             "roofline": {**r_dom, "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS,
-                         "whole_path_traffic": committed_traffic(a.config, a.inverse)},
+                         "whole_path_traffic": committed_traffic(a.config, a.inverse, "ava-pb" if preset else "ava-ont")},
             "roofline_other": cands[1:] + fams,
             "stage_ms_per_step": {**{"index_" + k: v / K for k, v in acc_tb.items() if v and k != "total"},
                                   **{k: v / K for k, v in acc_tm.items() if v}},

@@ -245,6 +245,16 @@ static int comm_small_stage(lrge_hip_comm *c, size_t bytes, Scratch &sc, char **
     return *d ? LRGE_OK : LRGE_ERR_DEVICE;
 }
 
+// RCCL transport: a rank that cannot even stage its vector cannot join the collective either -- it aborts its communicator
+// (ncclCommAbort) so that nothing of this rank lingers in the group, and fails; its peers' pending operations end with their own
+// processes (the launcher tears the job down when one process fails: ADVICE r04).  Untested on hardware: 1-GPU leases only.
+static int comm_rccl_give_up(lrge_hip_comm *c, const char *what) {
+    LRGE_SET_ERR(c->ctx, "RCCL transport: %s failed before the collective could be entered; communicator aborted", what);
+    c->aborted = true;
+    if (c->nccl && g_rccl.CommAbort) { (void)g_rccl.CommAbort(c->nccl); c->nccl = nullptr; }
+    return LRGE_ERR_DEVICE;
+}
+
 // In-place SUM all-reduce of n elements of `esz` bytes (4: u32, 8: u64) in HOST memory.
 static int comm_allreduce_sum_host(lrge_hip_comm *c, void *hbuf, size_t n, int esz, hipStream_t st) {
     lrge_hip_ctx *ctx = c->ctx;
@@ -253,8 +263,8 @@ static int comm_allreduce_sum_host(lrge_hip_comm *c, void *hbuf, size_t n, int e
     const size_t bytes = n * (size_t)esz;
     if (c->nccl) {
         Scratch sc(ctx); char *d = nullptr;
-        if (comm_small_stage(c, bytes, sc, &d)) return LRGE_ERR_DEVICE;
-        HIPCHK(ctx, hipMemcpyAsync(d, hbuf, bytes, hipMemcpyHostToDevice, st));
+        if (comm_small_stage(c, bytes, sc, &d)) return comm_rccl_give_up(c, "the staging allocation");
+        if (hipMemcpyAsync(d, hbuf, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipGetLastError(); return comm_rccl_give_up(c, "the staging copy"); }
         NCCLCHK(ctx, g_rccl.AllReduce(d, d, n, esz == 8 ? LRGE_NCCL_UINT64 : LRGE_NCCL_UINT32, LRGE_NCCL_SUM, c->nccl, st));
         HIPCHK(ctx, hipMemcpyAsync(hbuf, d, bytes, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
@@ -285,8 +295,8 @@ static int comm_allgather_host(lrge_hip_comm *c, const void *hsend, size_t bytes
     if (c->world == 1) { memcpy(hrecv, hsend, bytes); return LRGE_OK; }
     if (c->nccl) {
         Scratch sc(ctx); char *d = nullptr;
-        if (comm_small_stage(c, bytes * ((size_t)c->world + 1), sc, &d)) return LRGE_ERR_DEVICE;
-        HIPCHK(ctx, hipMemcpyAsync(d, hsend, bytes, hipMemcpyHostToDevice, st));
+        if (comm_small_stage(c, bytes * ((size_t)c->world + 1), sc, &d)) return comm_rccl_give_up(c, "the staging allocation");
+        if (hipMemcpyAsync(d, hsend, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipGetLastError(); return comm_rccl_give_up(c, "the staging copy"); }
         NCCLCHK(ctx, g_rccl.AllGather(d, d + bytes, bytes, LRGE_NCCL_UINT8, c->nccl, st));
         HIPCHK(ctx, hipMemcpyAsync(hrecv, d + bytes, bytes * (size_t)c->world, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));

@@ -304,15 +304,46 @@ __device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nma
     m = rw.starts & ~((1ULL << (2 * (h & 31))) - 1);          // (its lowest bit is h itself)
     i32 ppos = h; u32 pc = rw.code(2 * (h & 31));
     m &= m - 1;
-    for (;;) {
-        // the next step's start = the end of the pending run
-        i32 nxt = len; u32 ncode = 4;
+    // next_step: the start of the step behind the pending run (= the end of that run) and its code
+    auto next_step = [&](i32 &nxt, u32 &ncode) {
+        nxt = len; ncode = 4;
         for (;;) {
             if (m) { const u32 b = (u32)__builtin_ctzll(m); nxt = wi * 32 + (i32)(b >> 1); ncode = rw.code(b); m &= m - 1; break; }
             ++wi;
             if (wi * 32 >= len) break;
             rw.next(wi); m = rw.starts;
         }
+    };
+    // Warm-up (round 5): the first K - 1 steps from h cannot yield a k-mer whatever they hold (l starts at 0 there and a k-mer needs l >= K),
+    // so the window sees only "no minimizer" from them -- which leaves a window that holds nothing but "no minimizer" exactly as it is
+    // (no emission needs minx != NONE, and mi is only read beside a valid minx).  They run without the hash, the window and the emission
+    // sites: the run-length queue, the two k-mers and l alone.  18 of the 23 halo steps of every chunk.
+    bool done = false;
+#pragma unroll 1
+    for (int t = 0; t < K - 1; ++t) {
+        i32 nxt; u32 ncode;
+        next_step(nxt, ncode);
+        if (ppos >= e) { done = true; break; }
+        if (pc < 4) {
+            const i32 run = nxt - ppos;
+            const int rl = run > 255 ? 255 : run;
+            constexpr int OW = (K - 1) / 4, OB = ((K - 1) % 4) * 8;
+            const u32 ow = OW == 0 ? hq0 : OW == 1 ? hq1 : OW == 2 ? hq2 : OW == 3 ? hq3 : OW == 4 ? hq4 : hq5;
+            const int oldest = (int)((ow >> OB) & 0xff);
+            hq5 = hq5 << 8 | hq4 >> 24; hq4 = hq4 << 8 | hq3 >> 24; hq3 = hq3 << 8 | hq2 >> 24;
+            hq2 = hq2 << 8 | hq1 >> 24; hq1 = hq1 << 8 | hq0 >> 24; hq0 = hq0 << 8 | (u32)rl;
+            kmer_span += rl - oldest;
+            kf = (kf << 2 | pc) & mask;
+            kr = (kr >> 2) | (u64)(3 ^ pc) << shift1;
+            ++l;
+        } else { l = 0; hq0 = hq1 = hq2 = hq3 = hq4 = hq5 = 0; kmer_span = 0; }
+        if (nxt >= len) { done = true; break; }
+        ppos = nxt; pc = ncode;
+    }
+    for (; !done;) {
+        // the next step's start = the end of the pending run
+        i32 nxt; u32 ncode;
+        next_step(nxt, ncode);
         if (ppos >= e) break;                                  // steps starting at or beyond e belong to later chunks
         u64 ix = ~0ULL; u32 iy = ~0u;
         if (pc < 4) {

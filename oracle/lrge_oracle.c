@@ -486,6 +486,43 @@ int32_t  lo_index_mid_occ(const lo_index_t *ix) { return ix->mid_occ; }
 uint64_t lo_index_n_minimizers(const lo_index_t *ix) { return ix->n_mz; }
 uint64_t lo_index_n_keys(const lo_index_t *ix) { return ix->n_keys; }
 
+/* A PART of a target set too large to index on this host in one piece (tools/c5_allcounts.py: H. sapiens scale in 8 parts, the
+   target-sharded argument of tests/test_host_mirror.py with the oracle on every side): the sketch-order copy is dropped (only the
+   minimizer dump reads it), and the keys whose LOCAL count reaches min_count are listed -- a key that is too frequent over all P parts
+   (count > mid_occ) reaches ceil((mid_occ + 1) / P) in at least one of them, so the union of the parts' lists holds every candidate. */
+void lo_index_strip(lo_index_t *ix) { if (ix) { free(ix->mz); ix->mz = 0; } }
+uint64_t lo_index_keys_at_least(const lo_index_t *ix, uint32_t min_count, uint64_t *out, uint64_t cap)
+{
+    uint64_t i, n = 0;
+    for (i = 0; i < ix->n_keys; ++i)
+        if (ix->off[i + 1] - ix->off[i] >= min_count) { if (out && n < cap) out[n] = ix->key[i]; ++n; }
+    return n;
+}
+/* every distinct key with its local count (saturated at 255), ascending: what is kept of a part whose index is dropped again
+   (tools/c5_allcounts.py --two-pass); returns n_keys */
+uint64_t lo_index_export_key_counts(const lo_index_t *ix, uint64_t *keys, uint8_t *counts)
+{
+    int64_t t;
+#pragma omp parallel for schedule(static)
+    for (t = 0; t < (int64_t)ix->n_keys; ++t) {
+        const uint64_t c = ix->off[t + 1] - ix->off[t];
+        if (keys) keys[t] = ix->key[t];
+        if (counts) counts[t] = (uint8_t)(c < 255 ? c : 255);
+    }
+    return ix->n_keys;
+}
+/* local occurrence counts of n keys (0: absent), whatever lo_index_drop_keys has marked */
+void lo_index_counts_of(const lo_index_t *ix, const uint64_t *keys, uint64_t n, uint32_t *counts)
+{
+    int64_t t;
+#pragma omp parallel for schedule(static)
+    for (t = 0; t < (int64_t)n; ++t) {
+        uint64_t lo = 0, hi = ix->n_keys;
+        while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ix->key[mid] < keys[t]) lo = mid + 1; else hi = mid; }
+        counts[t] = (lo < ix->n_keys && ix->key[lo] == keys[t]) ? (uint32_t)(ix->off[lo + 1] - ix->off[lo]) : 0u;
+    }
+}
+
 uint64_t lo_index_dump_minimizers(const lo_index_t *ix, lo_mm128_t *out, uint64_t cap)
 {
     uint64_t n = ix->n_mz < cap ? ix->n_mz : cap;

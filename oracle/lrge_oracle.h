@@ -84,6 +84,12 @@ int32_t  lo_index_get(const lo_index_t *ix, uint64_t minier, const uint64_t **li
 /* the index is a SHARD of a larger target set: these keys are too frequent over the whole set (count > mid_occ there) and answer so
    here as well (tests of the target-sharded multi-GPU form); returns how many of them the shard holds */
 uint64_t lo_index_drop_keys(lo_index_t *ix, const uint64_t *keys, uint64_t n);
+/* one PART of a target set indexed part by part (see lrge_oracle.c): drop the sketch-order copy; list the keys whose local count is >=
+   min_count (returns their number; the first cap are written); local counts of given keys */
+void     lo_index_strip(lo_index_t *ix);
+uint64_t lo_index_keys_at_least(const lo_index_t *ix, uint32_t min_count, uint64_t *out, uint64_t cap);
+void     lo_index_counts_of(const lo_index_t *ix, const uint64_t *keys, uint64_t n, uint32_t *counts);
+uint64_t lo_index_export_key_counts(const lo_index_t *ix, uint64_t *keys, uint8_t *counts);   /* all keys, counts saturated at 255 */
 /* dump all minimizers in sketch order (rid-major) -- for stage-level parity tests */
 uint64_t lo_index_dump_minimizers(const lo_index_t *ix, lo_mm128_t *out, uint64_t cap);
 

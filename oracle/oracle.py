@@ -114,6 +114,12 @@ def lib():
         L.lo_index_get.argtypes = [vp, C.c_uint64, C.POINTER(u64p)]
         L.lo_index_drop_keys.restype = C.c_uint64
         L.lo_index_drop_keys.argtypes = [vp, vp, C.c_uint64]
+        L.lo_index_strip.argtypes = [vp]
+        L.lo_index_keys_at_least.restype = C.c_uint64
+        L.lo_index_keys_at_least.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
+        L.lo_index_counts_of.argtypes = [vp, vp, C.c_uint64, vp]
+        L.lo_index_export_key_counts.restype = C.c_uint64
+        L.lo_index_export_key_counts.argtypes = [vp, vp, vp]
         L.lo_index_dump_minimizers.restype = C.c_uint64
         L.lo_index_dump_minimizers.argtypes = [vp, vp, C.c_uint64]
         L.lo_anchors.restype = C.c_int64
@@ -234,6 +240,30 @@ class Index:
         out = np.zeros(max(n, 1), dtype=MM128)
         lib().lo_index_dump_minimizers(self.h, out.ctypes.data, n)
         return out[:n]
+
+    def strip(self):
+        """Drop the sketch-order copy of the minimizers (minimizers() returns nothing afterwards): a part of a set indexed in parts."""
+        lib().lo_index_strip(self.h)
+
+    def keys_at_least(self, min_count):
+        n = lib().lo_index_keys_at_least(self.h, int(min_count), None, 0)
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        lib().lo_index_keys_at_least(self.h, int(min_count), out.ctypes.data, n)
+        return out[:n]
+
+    def counts_of(self, keys):
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(max(k.size, 1), dtype=np.uint32)
+        if k.size:
+            lib().lo_index_counts_of(self.h, k.ctypes.data, k.size, out.ctypes.data)
+        return out[:k.size]
+
+    def key_counts(self):
+        """(distinct keys ascending, their local counts saturated at 255)"""
+        n = self.n_keys
+        k = np.zeros(max(n, 1), dtype=np.uint64); c = np.zeros(max(n, 1), dtype=np.uint8)
+        lib().lo_index_export_key_counts(self.h, k.ctypes.data, c.ctypes.data)
+        return k[:n], c[:n]
 
     def drop_keys(self, keys):
         """This index is a shard of a larger target set: `keys` (hashes) are too frequent over the whole set."""

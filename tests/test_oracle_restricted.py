@@ -66,3 +66,44 @@ def test_restricted_index_needs_the_global_mid_occ(oracle):
     b.add(t.bases, t.offsets, t.names)
     with pytest.raises(AssertionError):
         b.finish(0)
+
+
+def test_oracle_index_in_target_parts_equals_the_one_index():
+    """tools/c5_allcounts.py checks EVERY forward count of full-size C5 against the oracle on a host that cannot hold the oracle's index of
+    all 2 000 000 targets: the targets are indexed in P parts (each with the whole set's mid_occ), the keys that are too frequent over
+    ALL parts are found from the parts' own counts (a key above mid_occ overall reaches ceil((mid_occ + 1) / P) in some part) and
+    dropped in every part, and the per-part distinct-target counts add up (disjoint targets: twoset.rs:286-317).  Here the same
+    procedure on a repeat-rich set that fits: equal to the one index, count for count."""
+    import numpy as np
+    from lrge_amd import synth
+    from oracle import oracle as O
+    _, qs, ts = synth.make_config("c2_repeats", 0.04)
+    opt = O.make_opt(O.PRESET_AVA_ONT, dual=True)
+    full = O.Index(O.ReadSet(ts.seqs(), ts.names), opt)
+    Qo = O.ReadSet(qs.seqs(), qs.names)
+    rc, ec, eh = full.twoset_counts(Qo, threads=2)
+    assert rc == 0 and int(ec.sum()) > 0
+    P = 3
+    b = [ts.n * i // P for i in range(P + 1)]
+    parts = []
+    for p in range(P):
+        sub = ts.slice(b[p], b[p + 1])
+        o = O.make_opt(O.PRESET_AVA_ONT, dual=True)
+        o.mid_occ = full.mid_occ
+        ix = O.Index(O.ReadSet(sub.seqs(), sub.names), o)
+        ix.strip()
+        parts.append(ix)
+    thr = full.mid_occ // P + 1
+    cand = np.unique(np.concatenate([ix.keys_at_least(thr) for ix in parts]))
+    tot = sum(ix.counts_of(cand).astype(np.int64) for ix in parts)
+    frequent = cand[tot > full.mid_occ]
+    hashes = full.minimizers()["x"] >> np.uint64(8)
+    keys, cnt = np.unique(hashes, return_counts=True)
+    assert np.array_equal(frequent, keys[cnt > full.mid_occ]) and frequent.size > 0
+    c = np.zeros(qs.n, np.uint32); h = np.zeros(qs.n, np.uint32)
+    for ix in parts:
+        ix.drop_keys(frequent)
+        rc, pc, ph = ix.twoset_counts(Qo, threads=2)
+        assert rc == 0
+        c += pc; h |= ph
+    assert np.array_equal(c, ec) and np.array_equal(h, eh)

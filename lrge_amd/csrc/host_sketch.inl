@@ -19,6 +19,10 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     // chunk range behind the upload's gates where the form allows it
     if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
     u32 n_chunks = (u32)s->n_chunks;
+    // The one-pass form's kernel: k_sketch_tile (k_sketch_tile.h: a lane per step, a workgroup per 16 chunks) into the same per-chunk
+    // slots as k_sketch_direct (a lane per chunk), which stays behind it for the HPC tiles it marks (ST_REDO) and alone under option
+    // SKETCH_LANE_FORM.
+    const bool tile_form = !ctx->opt("SKETCH_LANE_FORM");
     // the upload job whose gates cover this set's words (a view: its root's), and how far the sketch may go behind gate j:
     // every chunk that lies wholly inside the words that have arrived -- with HPC only the chunks of reads that have arrived
     // WHOLLY (a homopolymer-compressed step may run past its chunk, to the end of the read at most)
@@ -33,7 +37,8 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
         if (w1 <= s->h_woff[0]) return 0;
         const u32 r = (u32)(std::upper_bound(s->h_woff.begin(), s->h_woff.end(), w1) - s->h_woff.begin()) - 1;
         if (HPC) return s->h_cs[r];
-        const u64 avail = w1 - s->h_woff[r];                      // words of read r that have arrived: 4 per 128-base chunk
+        u64 avail = w1 - s->h_woff[r];                            // words of read r that have arrived: 4 per 128-base chunk
+        if (tile_form && avail) --avail;                          // (the tile form looks w steps past a chunk's end: one word more)
         return s->h_cs[r] + (u32)std::min<u64>(avail / (SK_CHUNK / 32), (u64)(s->h_cs[r + 1] - s->h_cs[r]));
     };
     // the first gate behind which chunks [.., c1) of this set may be sketched (waited for on the host until its transfer has been
@@ -71,6 +76,27 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
         if (!tx || (!pk && !ty)) { if (tx) sc.drop(tx); if (ty) sc.drop(ty); tx = ty = nullptr; one_pass = false; (void)hipGetLastError(); }
     }
     u32 tot_ovf[2] = {0, 0};
+    // chunks [c0, c1) into the slots sx / sy (indexed by chunk number), counts to d_cnt, overflow flag at d_total + 1
+    auto launch_slots = [&](u32 c0, u32 c1, u64 *sx, u64 *sy, u32 capv) {
+        if (c1 <= c0) return;
+        const dim3 gl((u32)div_up(c1 - c0, SK_THREADS)), gt((u32)div_up(c1 - c0, ST_G));
+#define LRGE_SK_LAUNCH(IK, PKF, P1, YB)                                                                                                             \
+        do {                                                                                                                                        \
+            if (tile_form) {                                                                                                                        \
+                hipLaunchKernelGGL((k_sketch_tile<K, W, HPC, IK, PKF>), gt, dim3(ST_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,      \
+                                   s->d_len, cm, c1, d_cnt, d_total + 1, sx, sy, P1, YB, capv, c0);                                                  \
+                if constexpr (HPC)                                                                                                                  \
+                    hipLaunchKernelGGL((k_sketch_redo<K, W, IK, PKF>), gl, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,       \
+                                       s->d_len, cm, c1, d_cnt, d_total + 1, sx, sy, P1, YB, capv, c0);                                              \
+            } else                                                                                                                                  \
+                hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, IK, PKF>), gl, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,    \
+                                   s->d_len, cm, c1, d_cnt, d_total + 1, sx, sy, P1, YB, capv, c0);                                                  \
+        } while (0)
+        if (pk) LRGE_SK_LAUNCH(true, true, pk_pos1, pk_ybits);
+        else if (index_keys) LRGE_SK_LAUNCH(true, false, 0u, 0u);
+        else LRGE_SK_LAUNCH(false, false, 0u, 0u);
+#undef LRGE_SK_LAUNCH
+    };
     // ---- ranged one-pass form: the slots of the whole set do not fit, those of a range of its chunks do ----
     // Range after range: k_sketch_direct into the SAME slots, scan of the range's counts, compaction behind what the ranges before
     // left.  The output is sized by an estimate (the count is only known at the end); a set that beats the estimate, or a chunk
@@ -94,13 +120,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                     const u32 c1 = (u32)std::min<u64>(c0 + R, n_chunks), len = c1 - (u32)c0;
                     if (gated && wait_chunks(c1) != LRGE_OK) { int rr = seqset_ready(ctx, s); return rr ? rr : LRGE_ERR_DEVICE; }   // this range's reads have arrived; the later ones may still travel
                     u64 *sx = rx - c0 * SK_CAP, *sy = ry ? ry - c0 * SK_CAP : nullptr;      // (the kernels index slots by chunk number)
-                    const dim3 g((u32)div_up(len, SK_THREADS));
-                    if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
-                                               s->d_woff, s->d_len, cm, c1, d_cnt, d_total + 1, sx, sy, pk_pos1, pk_ybits, (u32)SK_CAP, (u32)c0);
-                    else if (index_keys) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
-                                                            s->d_nmask, s->d_woff, s->d_len, cm, c1, d_cnt, d_total + 1, sx, sy, 0u, 0u, (u32)SK_CAP, (u32)c0);
-                    else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, false, false>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
-                                            s->d_woff, s->d_len, cm, c1, d_cnt, d_total + 1, sx, sy, 0u, 0u, (u32)SK_CAP, (u32)c0);
+                    launch_slots((u32)c0, c1, sx, sy, (u32)SK_CAP);
                     KCHK(ctx);
                     int rc = scan_exclusive_u32(ctx, sc, d_cnt + c0, d_cnt + c0, len, d_run + 1);
                     if (rc) return rc;
@@ -150,32 +170,19 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                     if (!gjob->wait_gate((int)j)) break;                         // (the job failed: seqset_ready below reports it)
                     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, gjob->gate_ev[j], 0));
                     {
-                        const dim3 g((u32)div_up(c_end - c_prev, SK_THREADS));
-                        if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
-                                                   s->d_woff, s->d_len, cm, c_end, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap, c_prev);
-                        else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
-                                                s->d_nmask, s->d_woff, s->d_len, cm, c_end, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap, c_prev);
+                        launch_slots(c_prev, c_end, tx, ty, sk_cap);
                         KCHK(ctx);
                         c_prev = c_end;
                     }
                 }
                 int rr = seqset_ready(ctx, s); if (rr) return rr;
                 if (c_prev < n_chunks) {                                          // (whatever a failed / odd gate sequence left)
-                    const dim3 g((u32)div_up(n_chunks - c_prev, SK_THREADS));
-                    if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
-                                               s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap, c_prev);
-                    else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), g, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
-                                            s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap, c_prev);
+                    launch_slots(c_prev, n_chunks, tx, ty, sk_cap);
                     KCHK(ctx);
                 }
             } else if (one_pass) {
                 if (gated && pass == 0) { int rr = seqset_ready(ctx, s); if (rr) return rr; }
-                if (pk) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, true>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
-                                           s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, pk_pos1, pk_ybits, sk_cap);
-                else if (index_keys) hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, false>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack,
-                                                        s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap);
-                else hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, false, false>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask,
-                                        s->d_woff, s->d_len, cm, n_chunks, d_cnt, d_total + 1, tx, ty, 0u, 0u, sk_cap);
+                launch_slots(0u, n_chunks, tx, ty, sk_cap);
             } else {
                 if (gated && pass == 0) { int rr = seqset_ready(ctx, s); if (rr) return rr; }
                 hipLaunchKernelGGL((k_sketch_count<K, W, HPC>), sgrid, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm,

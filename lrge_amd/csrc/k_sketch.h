@@ -16,6 +16,7 @@
 #define SK_CHUNK 128            // bases per lane
 #endif
 #define SK_THREADS 256
+#define ST_REDO 0xFFFFFFFFu     // counts[c] of a chunk the tile form (k_sketch_tile.h) left to k_sketch_direct(only_marked)
 
 // ------------------------------------------------------------------------------------------
 // K0: one thread per 32-base word of the packed image
@@ -247,7 +248,11 @@ struct RunWords {
     __device__ __forceinline__ u32 code(u32 bit) const { return ((ns >> bit) & 1) ? 4u : (u32)((w >> bit) & 3); }
 };
 
-template <int K, int W, typename Emit>
+// POS_OWN = false: the chunk owns the loop steps that START in [s, e) and writes what mm_sketch writes DURING those steps (the
+// minimizer written at a step lies up to w steps back -- possibly in the chunk before).  POS_OWN = true (k_sketch_redo, behind
+// k_sketch_tile.h): the chunk owns the minimizers whose own step ENDS in [s, e), whenever they are written -- the attribution of the
+// tile form, so that the two can share a read: the replay starts one step earlier, goes on for w steps past e, and filters by position.
+template <int K, int W, bool POS_OWN = false, typename Emit>
 __device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nmask, u64 word_base, i32 len, u32 rid, i32 s, i32 e, Emit &&emit) {
     constexpr u64 mask = (1ULL << (2 * K)) - 1;
     constexpr int shift1 = 2 * (K - 1);
@@ -266,11 +271,14 @@ __device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nma
         if (wi * 32 >= len) break;
         rw.next(wi); m = rw.starts;
     }
-    if (p >= e || p >= len) {
-        // this chunk starts no step; it still owns the end-of-read flush if it holds the last base
-        if (!(e == len && s < len)) return;
+    if (!POS_OWN) {
+        if (p >= e || p >= len) {
+            // this chunk starts no step; it still owns the end-of-read flush if it holds the last base
+            if (!(e == len && s < len)) return;
+        }
+        s = p;
     }
-    s = p;
+    const i32 s_pos = s;               // POS_OWN: the owned positions are [s_pos, e)
     // ---- replay start h: HALO steps before it ----
     i32 h = 0;
     if (p > 0) {
@@ -278,7 +286,7 @@ __device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nma
         if (wb != wi || p >= len) rw.load(wb);
         u64 mb = rw.starts;
         if ((p >> 5) == wb) mb &= (1ULL << (2 * (p & 31))) - 1;
-        int need = HALO;
+        int need = POS_OWN ? HALO + 1 : HALO;      // (POS_OWN: the step that holds base s may start in front of it)
         for (;;) {
             const int c = __popcll(mb);
             if (c >= need) {
@@ -323,7 +331,7 @@ __device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nma
     for (int t = 0; t < K - 1; ++t) {
         i32 nxt; u32 ncode;
         next_step(nxt, ncode);
-        if (ppos >= e) { done = true; break; }
+        if (!POS_OWN && ppos >= e) { done = true; break; }
         if (pc < 4) {
             const i32 run = nxt - ppos;
             const int rl = run > 255 ? 255 : run;
@@ -340,11 +348,14 @@ __device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nma
         if (nxt >= len) { done = true; break; }
         ppos = nxt; pc = ncode;
     }
+    bool at_end = done && !POS_OWN ? false : done;             // POS_OWN: the replay ran into the end of the read
+    int past = 0;                                              // POS_OWN: steps taken that start at or beyond e
     for (; !done;) {
         // the next step's start = the end of the pending run
         i32 nxt; u32 ncode;
         next_step(nxt, ncode);
-        if (ppos >= e) break;                                  // steps starting at or beyond e belong to later chunks
+        if (POS_OWN) { if (ppos >= e && ++past > W) break; }    // a minimizer is written at most w steps behind its own
+        else if (ppos >= e) break;                             // steps starting at or beyond e belong to later chunks
         u64 ix = ~0ULL; u32 iy = ~0u;
         if (pc < 4) {
             const i32 run = nxt - ppos;
@@ -366,18 +377,24 @@ __device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nma
             if (l >= K && kmer_span < 256) { ix = mm_hash64(z ? kr : kf, mask) << 8 | (u64)kmer_span; iy = (u32)i << 1 | z; }
         } else { l = 0; hq0 = hq1 = hq2 = hq3 = hq4 = hq5 = 0; kmer_span = 0; }
         const bool owned = ppos >= s;
-        win.template step<K>(ix, iy, l, [&](u64 x, u32 y) { if (owned) emit(x, (u64)rid << 32 | (u64)y); });
-        if (nxt >= len) break;
+        win.template step<K>(ix, iy, l, [&](u64 x, u32 y) {
+            if (POS_OWN) { const i32 pb = (i32)(y >> 1); if (pb >= s_pos && pb < e) emit(x, (u64)rid << 32 | (u64)y); }
+            else if (owned) emit(x, (u64)rid << 32 | (u64)y);
+        });
+        if (nxt >= len) { at_end = true; break; }
         ppos = nxt; pc = ncode;
     }
-    if (e == len && win.minx != win.NONE) emit(win.minx, (u64)rid << 32 | (u64)win.miny);  // final flush by the last chunk
+    if (POS_OWN) {             // the final flush belongs to the chunk that holds the minimizer
+        if (at_end && win.minx != win.NONE) { const i32 pb = (i32)(win.miny >> 1); if (pb >= s_pos && pb < e) emit(win.minx, (u64)rid << 32 | (u64)win.miny); }
+    } else if (e == len && win.minx != win.NONE) emit(win.minx, (u64)rid << 32 | (u64)win.miny);  // final flush by the last chunk
 }
 
 // Runs the state machine over one chunk.  Emission callback is only invoked for owned steps.
-template <int K, int W, bool HPC, typename Emit>
+template <int K, int W, bool HPC, bool POS_OWN = false, typename Emit>
 __device__ __forceinline__ void sketch_chunk(const u64 *pack, const u32 *nmask, u64 word_base, i32 len, u32 rid,
                                              i32 s, i32 e, Emit &&emit) {
-    if constexpr (HPC) { sketch_chunk_hpc<K, W>(pack, nmask, word_base, len, rid, s, e, emit); return; }
+    static_assert(HPC || !POS_OWN, "position ownership exists for the HPC form only (k_sketch_redo)");
+    if constexpr (HPC) { sketch_chunk_hpc<K, W, POS_OWN>(pack, nmask, word_base, len, rid, s, e, emit); return; }
     constexpr u64 mask = (1ULL << (2 * K)) - 1;
     constexpr int shift1 = 2 * (K - 1);
     constexpr int HALO = W + K - 1;
@@ -456,7 +473,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_count(const u64 *__restri
 // one, every 32-byte sector reaches HBM as four partial writes (measured 4x the bytes).  The last <= 4 are
 // kept in registers and leave as one sector-aligned 32-byte run per array whenever the output index
 // reaches a multiple of 4; only the head and the tail of the lane's range are written singly.
-template <int K, int W, bool HPC, bool INDEX_KEYS, bool PK>
+template <int K, int W, bool HPC, bool INDEX_KEYS, bool PK, bool POS_OWN = false>
 __device__ __forceinline__ u32 sketch_write_chunk(const u64 *__restrict__ pack, const u32 *__restrict__ nmask, u64 word_base, i32 len, u32 r,
                                                   i32 s, i32 e, u32 o0, u32 cap, u64 *__restrict__ out_x, u64 *__restrict__ out_y,
                                                   u32 pk_pos1, u32 pk_ybits) {
@@ -469,7 +486,7 @@ __device__ __forceinline__ u32 sketch_write_chunk(const u64 *__restrict__ pack, 
         if (nb >= 1) { out_x[o - 1] = bx3; if (!PK) out_y[o - 1] = by3; }
         nb = 0;
     };
-    sketch_chunk<K, W, HPC>(pack, nmask, word_base, len, r, s, e, [&](u64 x, u64 y) {
+    sketch_chunk<K, W, HPC, POS_OWN>(pack, nmask, word_base, len, r, s, e, [&](u64 x, u64 y) {
         if (found++ >= cap) return;                     // counted, not stored (the caller notices found > cap)
         bx0 = bx1; bx1 = bx2; bx2 = bx3;
         if (PK) bx3 = (x >> 8) << pk_ybits | (y >> 32) << pk_pos1 | (u64)(u32)y;
@@ -531,6 +548,27 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_direct(const u64 *__restr
     const u64 base = (u64)c * SK_CAP;
     const u32 found = sketch_write_chunk<K, W, HPC, INDEX_KEYS, PK>(pack, nmask, woff[r], len, r, s, e, 0u, cap, tmp_x + base,
                                                                     PK ? tmp_y : tmp_y + base, pk_pos1, pk_ybits);
+    counts[c] = found;
+    if (found > cap) *overflow = 1u;
+}
+
+// Behind k_sketch_tile (HPC): the chunks it marked ST_REDO, the sequential way, with the tile form's attribution (POS_OWN above).
+template <int K, int W, bool INDEX_KEYS, bool PK>
+__global__ __launch_bounds__(SK_THREADS) void k_sketch_redo(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
+                                                           const u64 *__restrict__ woff, const u32 *__restrict__ lens,
+                                                           ChunkMap cm, u32 n_chunks, u32 *__restrict__ counts, u32 *__restrict__ overflow,
+                                                           u64 *__restrict__ tmp_x, u64 *__restrict__ tmp_y, u32 pk_pos1, u32 pk_ybits,
+                                                           u32 cap, u32 c_base) {
+    const u32 c = c_base + blockIdx.x * SK_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    if (counts[c] != ST_REDO) return;
+    const u32 r = cm.find(c);
+    const i32 len = (i32)lens[r];
+    const i32 s = (i32)(c - cm.chunk_start[r]) * SK_CHUNK;
+    const i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
+    const u64 base = (u64)c * SK_CAP;
+    const u32 found = sketch_write_chunk<K, W, true, INDEX_KEYS, PK, true>(pack, nmask, woff[r], len, r, s, e, 0u, cap, tmp_x + base,
+                                                                          PK ? tmp_y : tmp_y + base, pk_pos1, pk_ybits);
     counts[c] = found;
     if (found > cap) *overflow = 1u;
 }

@@ -13,6 +13,7 @@
 #include "internal.h"
 #include "k_prims.h"
 #include "k_sketch.h"
+#include "k_sketch_tile.h"
 #include "k_index.h"
 #include "k_seed.h"
 #include "k_chain.h"

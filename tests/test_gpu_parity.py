@@ -27,7 +27,7 @@ def _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset, dual=True):
     return Qd, Td, ixd, Qo, To, ixo
 
 
-@pytest.mark.parametrize("form", ["one-pass", "two-pass", "overflow-fallback", "ranged"])
+@pytest.mark.parametrize("form", ["one-pass", "two-pass", "overflow-fallback", "ranged", "lane-form", "lane-form-ranged"])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
 def test_sketch_parity(ctx, oracle, edge_set, preset, form, knobs):
     # one-pass (per-chunk slots + compaction, the default), the two-pass form (count, scan, write), the fallback from
@@ -39,6 +39,11 @@ def test_sketch_parity(ctx, oracle, edge_set, preset, form, knobs):
         knobs.set("DEBUG_SK_CAP", "9")
     elif form == "ranged":
         knobs.set("DEBUG_SK_RANGE_CHUNKS", "256")
+    # the one-pass forms run k_sketch_tile (a lane per step) since round 5; "lane-form" = k_sketch_direct (a lane per chunk) in its place
+    if form.startswith("lane-form"):
+        knobs.set("SKETCH_LANE_FORM", "1")
+        if form.endswith("ranged"):
+            knobs.set("DEBUG_SK_RANGE_CHUNKS", "256")
     qseqs, qnames, tseqs, tnames = edge_set
     seqs = tseqs + [b"", b"A", b"ACGTTGCA" * 3]            # empty and tiny reads keep their rid
     S = _upload(ctx, seqs)
@@ -93,6 +98,54 @@ def test_hpc_sketch_run_structure(ctx, oracle):
     bad = np.nonzero((x != ex) | (y != ey))[0]
     assert bad.size == 0, "first mismatch at %d: read %d" % (bad[0], int(ey[bad[0]] >> 32))
     assert len(x) > 500
+
+
+@pytest.mark.parametrize("form", ["one-pass", "ranged"])
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_tile_sketch_edges(ctx, oracle, preset, form, knobs):
+    """k_sketch_tile.h decides per step, from x[p-w+1 .. p+w], whether mm_sketch would write the step's minimizer out (the rule of
+    tests/sketch_model.py).  Its edges: equal minima inside one window (low-complexity sequence: the two flush rules), ambiguous bases
+    (the valid-step thresholds w+k-1 / w+k), read lengths around the tile (2048 bases) and chunk sizes, reads of a few bases (many
+    segments per workgroup), and -- HPC -- homopolymer runs across tile edges, long enough that a tile's halo does not hold its w+k
+    steps (those tiles go to k_sketch_redo, whose chunks must fit between tile-form neighbours without a minimizer lost or doubled)."""
+    if form == "ranged":
+        knobs.set("DEBUG_SK_RANGE_CHUNKS", "256")
+    rng = np.random.Generator(np.random.PCG64(77))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rnd = lambda n: bytes(acgt[rng.integers(4, size=n)])
+    seqs = []
+    for ln in (2047, 2048, 2049, 2048 + 19, 2048 + 23, 2048 + 24, 4095, 4096, 4097, 6000, 2048 * 3 + 5, 5, 0, 33, 14, 15, 19, 23, 24, 1):
+        seqs.append(rnd(ln))
+    for unit in (b"AC", b"ACG", b"AAC", b"ACGTAC", b"ACGTACGTT", b"A", b"ACACACACACACACACACACACACT"):     # equal minima in every window
+        seqs.append((unit * 3000)[:5000])
+        s = bytearray((unit * 3000)[:4500]); s[1000] = ord("N"); s[1023] = ord("N"); s[1024] = ord("N"); s[2047] = ord("N"); s[2048] = ord("G"); s[3000:3003] = b"NNN"
+        seqs.append(bytes(s))
+    g = rnd(30000)
+    s = bytearray(g[:9000]); s[::53] = b"N" * len(s[::53]); seqs.append(bytes(s))                          # an ambiguous base every 53
+    s = bytearray(g[:9000]); s[2040:2060] = b"N" * 20; s[4090:4097] = b"N" * 7; seqs.append(bytes(s))      # ... across tile edges
+    for run in (40, 90, 100, 130, 300, 2100, 5000):                                                         # runs around / across tile edges
+        seqs.append(g[:2000] + b"A" * run + g[2000:4200] + b"C" * run + g[4200:9000])
+        seqs.append(g[:2048 - run // 2] + b"T" * run + g[3000:9000])
+        seqs.append(g[:2048] + b"G" * run + g[5000:7000])
+        seqs.append(b"C" * run + g[:3000] + b"A" * run)
+    seqs.append((b"A" * 7 + b"C" * 5 + b"G" * 9 + b"T" * 3) * 400)                                        # long runs only: few steps per tile
+    seqs.append(b"AC" * 20 + b"N" + b"AC" * 1500 + b"N" * 3 + b"CA" * 1200)
+    seqs += [rnd(int(n)) for n in rng.integers(1, 400, size=200)]                                           # many reads per workgroup
+    seqs += [rnd(int(n)) for n in rng.integers(1800, 2400, size=20)]
+    S = _upload(ctx, seqs)
+    x, y = S.sketch(PRESETS[preset])
+    k, hpc = (19, True) if preset == "pb" else (15, False)
+    exp = [oracle.sketch(s, 5, k, rid=i, is_hpc=hpc) for i, s in enumerate(seqs) if len(s)]
+    ex = np.concatenate([e["x"] for e in exp]); ey = np.concatenate([e["y"] for e in exp])
+    if len(x) != len(ex):
+        n = min(len(x), len(ex)); bad = np.nonzero((x[:n] != ex[:n]) | (y[:n] != ey[:n]))[0]
+        at = int(bad[0]) if bad.size else n
+        assert False, "minimizer count differs: %d vs %d; first difference at %d: read %d pos %d (got read %d pos %d)" % (
+            len(x), len(ex), at, int(ey[min(at, len(ey) - 1)] >> 32), int(ey[min(at, len(ey) - 1)] & 0xffffffff) >> 1,
+            int(y[min(at, len(y) - 1)] >> 32), int(y[min(at, len(y) - 1)] & 0xffffffff) >> 1)
+    bad = np.nonzero((x != ex) | (y != ey))[0]
+    assert bad.size == 0, "first mismatch at %d: read %d pos %d" % (bad[0], int(ey[bad[0]] >> 32), int(ey[bad[0]] & 0xffffffff) >> 1)
+    assert len(x) > 5000
 
 
 @pytest.mark.parametrize("packed", [True, False])

@@ -19,10 +19,10 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     // chunk range behind the upload's gates where the form allows it
     if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
     u32 n_chunks = (u32)s->n_chunks;
-    // The one-pass form's kernel: k_sketch_tile (k_sketch_tile.h: a lane per step, a workgroup per 16 chunks) into the same per-chunk
-    // slots as k_sketch_direct (a lane per chunk), which stays behind it for the HPC tiles it marks (ST_REDO) and alone under option
-    // SKETCH_LANE_FORM.
-    const bool tile_form = !ctx->opt("SKETCH_LANE_FORM");
+    // Option SKETCH_TILE_FORM: k_sketch_tile (k_sketch_tile.h: a lane per step, a workgroup per 16 chunks; + k_sketch_redo for the HPC tiles
+    // it marks) in place of k_sketch_direct (a lane per chunk) in the one-pass forms, into the same per-chunk slots.  Exact, and NOT the
+    // default: measured at full-size C5 it is slower with HPC (index sketch 286 against 198 ms) and equal without.
+    const bool tile_form = ctx->opt("SKETCH_TILE_FORM") != nullptr;
     // the upload job whose gates cover this set's words (a view: its root's), and how far the sketch may go behind gate j:
     // every chunk that lies wholly inside the words that have arrived -- with HPC only the chunks of reads that have arrived
     // WHOLLY (a homopolymer-compressed step may run past its chunk, to the end of the read at most)

@@ -27,7 +27,7 @@ def _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset, dual=True):
     return Qd, Td, ixd, Qo, To, ixo
 
 
-@pytest.mark.parametrize("form", ["one-pass", "two-pass", "overflow-fallback", "ranged", "lane-form", "lane-form-ranged"])
+@pytest.mark.parametrize("form", ["one-pass", "two-pass", "overflow-fallback", "ranged", "tile-form", "tile-form-ranged", "tile-form-overflow"])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
 def test_sketch_parity(ctx, oracle, edge_set, preset, form, knobs):
     # one-pass (per-chunk slots + compaction, the default), the two-pass form (count, scan, write), the fallback from
@@ -39,11 +39,13 @@ def test_sketch_parity(ctx, oracle, edge_set, preset, form, knobs):
         knobs.set("DEBUG_SK_CAP", "9")
     elif form == "ranged":
         knobs.set("DEBUG_SK_RANGE_CHUNKS", "256")
-    # the one-pass forms run k_sketch_tile (a lane per step) since round 5; "lane-form" = k_sketch_direct (a lane per chunk) in its place
-    if form.startswith("lane-form"):
-        knobs.set("SKETCH_LANE_FORM", "1")
+    # "tile-form": k_sketch_tile (a lane per step; option SKETCH_TILE_FORM) in place of k_sketch_direct (a lane per chunk) in the one-pass forms
+    if form.startswith("tile-form"):
+        knobs.set("SKETCH_TILE_FORM", "1")
         if form.endswith("ranged"):
             knobs.set("DEBUG_SK_RANGE_CHUNKS", "256")
+        elif form.endswith("overflow"):
+            knobs.set("DEBUG_SK_CAP", "9")
     qseqs, qnames, tseqs, tnames = edge_set
     seqs = tseqs + [b"", b"A", b"ACGTTGCA" * 3]            # empty and tiny reads keep their rid
     S = _upload(ctx, seqs)
@@ -100,7 +102,7 @@ def test_hpc_sketch_run_structure(ctx, oracle):
     assert len(x) > 500
 
 
-@pytest.mark.parametrize("form", ["one-pass", "ranged"])
+@pytest.mark.parametrize("form", ["one-pass", "ranged", "lane-form"])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
 def test_tile_sketch_edges(ctx, oracle, preset, form, knobs):
     """k_sketch_tile.h decides per step, from x[p-w+1 .. p+w], whether mm_sketch would write the step's minimizer out (the rule of
@@ -108,6 +110,8 @@ def test_tile_sketch_edges(ctx, oracle, preset, form, knobs):
     (the valid-step thresholds w+k-1 / w+k), read lengths around the tile (2048 bases) and chunk sizes, reads of a few bases (many
     segments per workgroup), and -- HPC -- homopolymer runs across tile edges, long enough that a tile's halo does not hold its w+k
     steps (those tiles go to k_sketch_redo, whose chunks must fit between tile-form neighbours without a minimizer lost or doubled)."""
+    if form != "lane-form":                # (the same reads through the default kernel: its edges are the chunk's, 128 bases)
+        knobs.set("SKETCH_TILE_FORM", "1")
     if form == "ranged":
         knobs.set("DEBUG_SK_RANGE_CHUNKS", "256")
     rng = np.random.Generator(np.random.PCG64(77))

@@ -860,6 +860,20 @@ def main():
                 cb = cpu_baseline_sampled(spec, Qn, Tn, a.cpu_seconds, preset)
                 out["cpu_baseline"] = cb
                 out["gpu_vs_cpu_port_SAMPLE"] = value / cb["value"]      # (the denominator is a pro-rated SAMPLE: see cpu_baseline.sample)
+                # beside the sample timed in this run: the WHOLE job timed once on the port (round 5, tools/c5_allcounts.py: all 100 000 forward
+                # counts equal the GPU's), quoted from the committed record -- ~6.5 minutes of CPU time do not fit a default bench run
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r05_c5_full_forward_allcounts.json")) as f:
+                        ac = json.load(f)
+                    if a.config == ac.get("config") and a.scale == ac.get("scale") and ac.get("preset") == ("ava-pb" if preset else "ava-ont"):
+                        m = ac["cpu_port_measured"]
+                        cb["measured_full_job"] = {"reads_per_s": m["reads_per_s"], "job_seconds": m["job_seconds"], "index_seconds": m["index_seconds"],
+                                                   "map_seconds": m["map_seconds"], "threads": m["threads"], "counts_equal_gpu": ac["oracle_map"]["counts_equal"],
+                                                   "reads_checked": ac["oracle_map"]["reads_checked"], "note": m["note"],
+                                                   "file": "profiles/r05_c5_full_forward_allcounts.json (a committed record, not timed in this run)"}
+                        out["gpu_vs_cpu_port_MEASURED_FULL_JOB"] = value / m["reads_per_s"]
+                except Exception:      # noqa: BLE001
+                    pass
                 out["parity_vs_oracle_sample"] = None
                 if a.parity_sample > 0 and a.config == "c5_human_twoset" and a.scale == 1.0:
                     # FORWARD counts of a sample of queries against the oracle at full size: the oracle's index restricted to the keys

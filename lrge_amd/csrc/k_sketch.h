@@ -579,9 +579,6 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_redo(const u64 *__restric
 // c_base / out_cap / ovf: the ranged form (host_sketch.inl: a set whose slots do not fit at once is sketched range by range into the
 // same slots): the launch covers chunks [c_base, n_chunks), `*d_total` is the output offset behind the range, and an entry that
 // would land at or beyond out_cap raises *ovf instead (the caller's estimate of the output size was too small: it starts over).
-#ifndef SKC_U
-#define SKC_U 4
-#endif
 template <bool PAIRS>
 __global__ __launch_bounds__(256) void k_sketch_compact(const u64 *__restrict__ tmp_x, const u64 *__restrict__ tmp_y,
                                                         const u32 *__restrict__ offs, const u32 *__restrict__ d_total, u32 n_chunks,
@@ -598,37 +595,16 @@ __global__ __launch_bounds__(256) void k_sketch_compact(const u64 *__restrict__ 
     __syncthreads();
     if (c0 >= n_chunks) return;
     const u32 lo = so[w][0], hi = so[w][64];
-    // SKC_U rows of 64 entries per round, every load of the round in flight before its first store: one row at a time left a
-    // wavefront with a single 512-byte load outstanding behind a six-step LDS search -- bound by that latency, 2.2 TB/s read + write
-    // at full-size C5 (round 5)
-    for (u32 o0 = lo; o0 < hi; o0 += 64 * SKC_U) {
-        u64 vx[SKC_U], vy[SKC_U];
-        bool ok[SKC_U];
+    for (u32 o = lo + lane; o < hi; o += 64) {
+        u32 j = 0;                                       // last chunk with offs <= o
 #pragma unroll
-        for (int t = 0; t < SKC_U; ++t) {
-            const u32 o = o0 + (u32)t * 64 + lane;
-            ok[t] = false; vx[t] = 0; vy[t] = 0;
-            if (o < hi) {
-                u32 j = 0;                                   // last chunk with offs <= o
-#pragma unroll
-                for (int st = 32; st > 0; st >>= 1) if (so[w][j + st] <= o) j += st;
-                const u32 within = o - so[w][j];
-                if (within < SK_CAP) {                       // (else: a chunk that overflowed its slot -- the caller discards this output)
-                    if (o >= out_cap) { if (ovf) *ovf = 1u; }
-                    else {
-                        const u64 src = (u64)(c0 + j) * SK_CAP + within;
-                        vx[t] = tmp_x[src];
-                        if (PAIRS) vy[t] = tmp_y[src];
-                        ok[t] = true;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < SKC_U; ++t) {
-            const u32 o = o0 + (u32)t * 64 + lane;
-            if (ok[t]) { out_x[o] = vx[t]; if (PAIRS) out_y[o] = vy[t]; }
-        }
+        for (int st = 32; st > 0; st >>= 1) if (so[w][j + st] <= o) j += st;
+        const u32 within = o - so[w][j];
+        if (within >= SK_CAP) continue;                  // a chunk that overflowed its slot (the caller discards this output)
+        if (o >= out_cap) { if (ovf) *ovf = 1u; continue; }
+        const u64 src = (u64)(c0 + j) * SK_CAP + within;
+        out_x[o] = tmp_x[src];
+        if (PAIRS) out_y[o] = tmp_y[src];
     }
 }
 

@@ -232,7 +232,7 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
         // pinned chunk buffers + the uploader thread, once per context
         // words per chunk: 64 Mbases for sets up to 4 Gbases (the first chunk is what the index sketch waits for: 0.9 ms at C4), 1/64
         // of the set above that, at most 512 Mbases -- every chunk costs the uploader a round of worker wake-ups and two copies, and
-        // the 447 chunks of full-size C5's targets took 370 ms where 64 take 270 (measured: tools/r4_pack_sweep.sh)
+        // the 447 chunks of full-size C5's targets took 370 ms where 64 take 270 (measured: tools/sweeps/r4_pack_sweep.sh)
         const size_t CH = (size_t)ctx->opt_u64("HOST_PACK_CHUNK_WORDS", std::min<u64>((u64)16 << 20, std::max<u64>((u64)2 << 20, (w / 64 + 65535) & ~65535ull)));
         if (!ctx->hp_stage[0] || ctx->hp_words < CH) {          // (hp_words: the buffers' capacity; a job lays its own chunk size out in them)
             if (ctx->uploader) ctx->uploader->drain();        // an earlier upload's job may still pack into the buffers about to go (it captured them and CH by value)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# build variants of the library with extra -D flags (here, no GPU):  tools/ab_variants.sh build name "-DLPG_B=8" ...
-# then on the GPU box: tools/ab_variants.sh run name1 name2 ...   (alternates with the current build)
+# build variants of the library with extra -D flags (here, no GPU):  tools/sweeps/ab_variants.sh build name "-DLPG_B=8" ...
+# then on the GPU box: tools/sweeps/ab_variants.sh run name1 name2 ...   (alternates with the current build)
 root=$(cd "$(dirname "$0")/.." && pwd)
 if [ "$1" = build ]; then
   name=$2; shift 2

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: the world-of-8 emulations at full-size C5 on BOTH clocks, the forward form three times on the resident clock (the slowest rank
 # used to move from run to run), north_star's literal form (replicated index) beside them, and the host-only pack contention figure.
-#   tools/r5_emulations.sh [fwd3|fwdhost|inv|repl|pack|c4]...   (default: all)
+#   tools/sweeps/r5_emulations.sh [fwd3|fwdhost|inv|repl|pack|c4]...   (default: all)
 root=${GRAFT_REPO_ROOT:-$(pwd)}; cd $root
 out=gpurun_out/r5emu; mkdir -p $out
 what=${*:-fwd3 fwdhost inv repl pack}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# sweep LRGE_HIP_LPG_MAX on a synth config: tools/sweep_cfg.sh <config> <preset> <T...>
+# sweep LRGE_HIP_LPG_MAX on a synth config: tools/sweeps/sweep_cfg.sh <config> <preset> <T...>
 cfg=$1; preset=$2; shift 2
 for m in "$@"; do
   if [ "$m" = auto ]; then unset LRGE_HIP_LPG_MAX; else export LRGE_HIP_LPG_MAX=$m; fi

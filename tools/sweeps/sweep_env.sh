@@ -1,5 +1,5 @@
 #!/bin/bash
-# sweep one environment variable on a synth config: tools/sweep_env.sh <config> <VAR> <values...>
+# sweep one environment variable on a synth config: tools/sweeps/sweep_env.sh <config> <VAR> <values...>
 cfg=$1; var=$2; shift 2
 for m in "$@"; do
   export $var=$m

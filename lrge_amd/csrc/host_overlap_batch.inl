@@ -103,6 +103,11 @@ int OverlapRun::batch(u32 q0, u32 q1, u64 A) {
             A = 0;
             for (u32 c : h_qkept) A += c;
             ctx->counters[LRGE_C_ANCHORS_KEPT] += A;
+            {   // what the planner of the next batches / calls assumes (OverlapRun::plan): the largest share seen lately
+                const double r_ = (double)A / (double)A_all;
+                ctx->kept_ratio = ctx->kept_seen ? std::max(r_, 0.9 * ctx->kept_ratio) : r_;
+                ctx->kept_seen = true;
+            }
             if (A == 0) return LRGE_OK;                       // nothing can chain: every count of the batch stays 0
             // (+8: k_chain_lpg streams anchors in 16-byte pairs and may read one element past the last group)
             aval = bsc.get<u64>(A + 8); akey2 = bsc.get<u64>(A + 8); aval2 = bsc.get<u64>(A + 8);

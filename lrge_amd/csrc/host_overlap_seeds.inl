@@ -360,20 +360,31 @@ int OverlapRun::plan() {
     // anchors (full-size C5: one batch per index part / per view instead of two -- 15 -> 8 batches, chain 273 -> 184 ms,
     // inverse step 1.135 -> 1.041 s, counts identical), ~40 B of scratch per anchor at the peak (four 8-byte arrays through the
     // sort; 16 + group starts + records + marks behind it), budgeted as 48 B out of 4/5 of the free HBM.
-    batch_cap = 1ULL << 31;
+    kl.bits_rpos = std::max<u32>(1, ceil_log2_u64((u64)T->max_len + 1));
+    kl.bits_rid = std::max<u32>(1, ceil_log2_u64((u64)nt));
+    max_bits_q = 63 - (kl.bits_rpos + 1 + kl.bits_rid);
+    min_n = std::max<u32>((u32)P.min_cnt, (u32)div_up((u64)P.min_sc, P.hpc ? 255 : (u64)P.k));
+    // With the dead-pair filter (count-only runs: batch(), k_expand_q) a batch is counted in seed HITS, of which only the survivors --
+    // a quarter at H. sapiens scale, under half on noisy ONT reads -- go through the sort and the chain kernels: the 32-bit positions
+    // that bound a batch are then the hits' slots (offsets relative to the batch: anything below 2^32), and a hit costs its 8-byte slot
+    // plus 40 B per SURVIVOR.  The survivors' share is what this context's recent batches showed (ctx->kept_ratio, + 15 % + 0.02; half
+    // of the hits before the first batch has been seen): 21-24 B per hit at H. sapiens scale.  Full-size C5 (round 5): one batch per
+    // index part under ava-pb instead of two (3.6 G hits, 1.2 G kept), two instead of three under ava-ont.  A batch whose survivors do
+    // not fit after all is retried in halves (run_overlap).
+    const u32 bits_qy_ = std::max<u32>(1, ceil_log2_u64((u64)Q->max_len + 1));
+    const bool filt_expected = !d_chains && !job.dump_anchors && kl.sh_q() + bits_qy_ + 9 <= 64 && !ctx->opt_u64("NO_PACKED", 0) &&
+                               !ctx->opt("NO_GROUP_FILTER") && min_n >= 2 && !ctx->opt("BATCH_HITS_2G");
+    const u64 per_item = filt_expected ? 8 + (u64)std::ceil(40.0 * std::min(1.0, ctx->kept_ratio * 1.15 + 0.02)) : 48;
+    batch_cap = filt_expected ? (1ULL << 32) - (1ULL << 26) : 1ULL << 31;
     {
         size_t mfree = 0, mtotal = 0;
         if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess) {
-            const u64 by_mem = ((u64)mfree + ctx->pool.idle()) / 5 * 4 / 48;     // the pool's idle blocks are reusable too (not the ones in use: a resident index)
+            const u64 by_mem = ((u64)mfree + ctx->pool.idle()) / 5 * 4 / per_item;     // the pool's idle blocks are reusable too (not the ones in use: a resident index)
             if (by_mem < batch_cap) batch_cap = by_mem;
         }
         if (batch_cap < (1ULL << 20)) batch_cap = 1ULL << 20;
     }
     batch_cap = ctx->opt_u64("BATCH_ANCHORS", batch_cap);
-    kl.bits_rpos = std::max<u32>(1, ceil_log2_u64((u64)T->max_len + 1));
-    kl.bits_rid = std::max<u32>(1, ceil_log2_u64((u64)nt));
-    max_bits_q = 63 - (kl.bits_rpos + 1 + kl.bits_rid);
-    min_n = std::max<u32>((u32)P.min_cnt, (u32)div_up((u64)P.min_sc, P.hpc ? 255 : (u64)P.k));
     cp.max_dist_x = std::max(P.max_gap, P.bw); cp.max_dist_y = std::max(P.max_gap, P.bw);
     cp.bw = P.bw; cp.max_skip = P.max_skip; cp.max_iter = P.max_iter; cp.min_cnt = P.min_cnt; cp.min_sc = P.min_sc;
     cp.max_drop = P.bw; cp.pen_gap = P.pen_gap; cp.pen_skip = P.pen_skip;

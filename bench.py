@@ -294,7 +294,9 @@ def main():
                     counts = comm.all_reduce_u32(counts)
                 est_all = ctx.estimates(counts, q_lens, float(avg_t), Tn, 100)
             else:
+                _ta = time.perf_counter()
                 Td = ctx.upload(src_t, ts.offsets, ts.rank, wait=False)      # K0 pack (and PCIe, from the host) on the copy stream
+                _tb = time.perf_counter()
                 Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)      # travels / packs while the index is built
                 if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
                     Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
@@ -336,7 +338,11 @@ def main():
                         est_all = comm.all_gather_f32(est, self.max_shard, self.shard_lens)
                     else:
                         est_all = est
+            _t4 = time.perf_counter()
             med = engine.median(est_all, True, 0.15, 0.65)
+            if os.environ.get("LRGE_BENCH_TICKS") and not a.inverse:      # host wall time of the step's calls (where the GPU idles between two steps)
+                sys.stderr.write("[ticks] upload T %.2f | upload Q + hint %.2f | index %.2f | overlap %.2f | introspection + free %.2f | estimates %.2f | median %.2f ms\n"
+                                 % ((_tb - _ta) * 1e3, (_t0 - _tb) * 1e3, (_t1 - _t0) * 1e3, (_t2 - _t1) * 1e3, (_t3 - _t2) * 1e3, (_t4 - _t3) * 1e3, (time.perf_counter() - _t4) * 1e3))
             for k_ in ("rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes"):   # the index build sorts too
                 cn[k_] = cn.get(k_, 0) + cb_.get(k_, 0)
             return counts, est_all, med, tb, tm, cn, st

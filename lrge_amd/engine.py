@@ -139,7 +139,7 @@ class SeqSet:
         self.ctx = ctx
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.n = offsets.size - 1
-        self.lens = np.diff(offsets).astype(np.uint32)
+        self._offsets, self._lens = offsets, None      # (lens: on first use -- 2 M reads cost 5 ms of host time per upload otherwise)
         if isinstance(bases, (int, np.integer)):          # device pointer to resident ASCII
             ptr, self._src = int(bases), None
         else:
@@ -153,6 +153,13 @@ class SeqSet:
         fn = ctx._lib.lrge_hip_seqset_upload if wait else ctx._lib.lrge_hip_seqset_upload_async
         ctx._check(fn(ctx.h, ptr, offsets.ctypes.data, self.n, None if r is None else r.ctypes.data, C.byref(h)))
         self.h = h
+
+    @property
+    def lens(self):
+        """read lengths (uint32), from the offsets the set was uploaded with"""
+        if self._lens is None:
+            self._lens = np.diff(self._offsets).astype(np.uint32)
+        return self._lens
 
     def wait(self):
         self.ctx._check(self.ctx._lib.lrge_hip_seqset_wait(self.h))

@@ -87,12 +87,18 @@ extern "C" int lrge_hip_index_build(lrge_hip_ctx *ctx, const lrge_hip_seqset *ta
         return index_build_one(ctx, targets, preset, out);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     u64 part_bases = pinned ? ctx->opt_u64("PART_BASES", ONE_INDEX_BASES) : auto_part_bases(ctx, targets, preset);
+    // a job of this size that had to start over with smaller parts last time (the estimate above was too kind: e.g. ASCII reads resident
+    // beside an ava-ont job) starts with the size that worked -- a failed attempt costs its allocations, a trim and the runtime's
+    // hipMalloc again: 6 s per step instead of 1.3 at full-size C5 ava-ont on the resident clock (round 5)
+    if (!pinned && ctx->part_hint_total == targets->total_bases && ctx->part_hint_preset == preset && ctx->part_hint_bases && ctx->part_hint_bases < part_bases)
+        part_bases = ctx->part_hint_bases;
     const int fail_first = (int)ctx->opt_u64("DEBUG_PART_FAIL_ATTEMPTS", 0);          // (tests: the start-over path)
     for (int attempt = 0;; ++attempt) {
         int rc;
         if (attempt < fail_first) { LRGE_SET_ERR(ctx, "index limited to < 2^32 minimizers (injected)"); rc = LRGE_ERR_TOO_MANY; }
         else rc = index_build_parts(ctx, targets, preset, part_bases, out);
         // a part with >= 2^32 minimizers, or one the memory could not hold: smaller parts (the failed attempt released everything)
+        if (rc == LRGE_OK && attempt > 0 && !pinned) { ctx->part_hint_total = targets->total_bases; ctx->part_hint_preset = preset; ctx->part_hint_bases = part_bases; }
         if ((rc != LRGE_ERR_TOO_MANY && rc != LRGE_ERR_DEVICE) || pinned || attempt >= 3 || (part_bases <= ONE_INDEX_BASES / 4 && attempt >= fail_first)) return rc;
         if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] index parts of %llu bases failed (%s): trying half\n", (unsigned long long)part_bases, ctx->err.c_str());
         (void)hipGetLastError();

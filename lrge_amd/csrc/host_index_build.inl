@@ -1,4 +1,22 @@
 // host_index_build.inl -- part of lrge_hip.hip (one translation unit; included there, in this order): index_build_one: sketch -> (restriction + global statistics) -> radix sort -> run heads -> ordered table -> mid_occ, for one index (a whole set, one part of a partitioned index, one rank's restricted index).
+// How many more hash bits than the low byte the SEGMENT of a segment-packed entry implies (index_sort_segpacked): `over`, what the word
+// is too narrow by (full-size C5 in 3 parts has read ids of 20 bits: 2 too many); beyond that, e is chosen so that what is LEFT of the
+// hash, nr = 2k - 8 - e bits, takes as few 8-bit LSD passes as possible (round 5: k = 19 -> e = 6, nr = 24: passes A + A2 + 3 instead of
+// A + A2 + 4; k = 15 -> e = 0, 22 bits in 3 passes either way).  DEBUG_SEG_EXTRA forces an e on small sets; SEG_PACK_EXTRA_MAX caps it
+// (0: never an A2 pass).  ~0u: no e will do.
+static u32 seg_pack_extra(lrge_hip_ctx *ctx, const Preset &P, u32 yb_p) {
+    const u32 over = 2 * (u32)P.k - 8 + yb_p > 64 ? 2 * (u32)P.k - 8 + yb_p - 64 : 0;
+    const u32 e_cap = std::min<u32>(7, (u32)ctx->opt_u64("SEG_PACK_EXTRA_MAX", 7));
+    u32 extra = over;
+    if (ctx->opt("DEBUG_SEG_EXTRA")) extra = std::max<u32>(over, (u32)ctx->opt_u64("DEBUG_SEG_EXTRA", 0));
+    else {
+        auto n_pass = [&](u32 e) { return 1u + (e ? 1u : 0u) + (2 * (u32)P.k - 8 - e + 7) / 8; };
+        for (u32 e = over + 1; e <= e_cap && 2 * (u32)P.k > 16 + e; ++e) if (n_pass(e) < n_pass(extra)) extra = e;
+    }
+    const bool extra_ok = extra == 0 || (extra <= e_cap && 2 * (u32)P.k > 16 + extra);
+    return extra_ok ? extra : ~0u;
+}
+
 static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, int preset, lrge_hip_index **out, const IndexBuildOpts *ro = nullptr) {
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -72,6 +90,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         }
     }
     bool fused = false; u64 *own_hashes = nullptr; u64 n_own = 0;
+    bool segw = false;          // the sketch wrote SEGW entries (below)
     struct PreparedGuard { lrge_hip_ctx *c; ~PreparedGuard() { presketch_drop_prepared(c); } } prepared_guard{ctx};   // (an error between the two steps)
     if (sharded) {
         // this rank sketches its own share of the targets; key sets, kept entries and owned hashes travel (k_route.h)
@@ -99,7 +118,18 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
         // plain build of packed entries: the sort's first pass reads the sketch's per-chunk slots, no compaction in between
         // (k_prims.h: radix_sort_keys_first_pass_from_slots; option NO_SLOT_SORT: compact first, rounds 1-3)
         const bool keep_slots = pk && !ro && !ctx->opt("NO_SLOT_SORT");
-        rc = sketch_device(ctx, sc, targets, preset, true, &so, pk ? pk_pos1 : 0, pk_ybits, nullptr, keep_slots);
+        // SEGW entries (round 5): a build that will take the segment-packed sort below -- pairs too wide for one word, a plain build, a set
+        // large enough -- has its sketch write [word, 16-bit digit pair] instead of (hash, y): 12 bytes per entry instead of 16 through
+        // the slots, the compaction and the sort's first two passes (k_sketch.h PK == 2; k_prims.h index_sort_segw).  Decided before
+        // the count is known: from the bases, at the density the part planner assumes.  option NO_SEGW: pairs, as rounds 3-4.
+        {
+            const u32 yb_p = pk_rid + pk_pos1;
+            const u32 extra = seg_pack_extra(ctx, P, yb_p);
+            const double dens = P.hpc ? 0.24 : 0.32;
+            segw = !pk && !ro && extra != ~0u && 2 * P.k >= 24 && !ctx->opt("NO_SEG_PACK") && !ctx->opt("NO_SEGW") && 2 * (u32)P.k - 16 + yb_p <= 64 &&
+                   (double)targets->total_bases * dens >= (double)ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22);
+        }
+        rc = sketch_device(ctx, sc, targets, preset, true, &so, (pk || segw) ? pk_pos1 : 0, segw ? pk_rid + pk_pos1 : pk_ybits, nullptr, keep_slots, segw);
         if (rc) return rc;
         sc.drop(so.mz_off);
     }
@@ -259,16 +289,25 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             // 2 too many); beyond that, e is chosen so that what is LEFT of the hash, nr = 2k - 8 - e bits, takes as few 8-bit LSD
             // passes as possible (round 5: k = 19 -> e = 6, nr = 24: passes A + A2 + 3 instead of A + A2 + 4; k = 15 -> e = 0, 22 bits
             // in 3 passes either way).  DEBUG_SEG_EXTRA forces an e on small sets; SEG_PACK_EXTRA_MAX caps it (0: never an A2 pass).
-            const u32 over = 2 * (u32)P.k - 8 + yb_p > 64 ? 2 * (u32)P.k - 8 + yb_p - 64 : 0;
-            const u32 e_cap = std::min<u32>(7, (u32)ctx->opt_u64("SEG_PACK_EXTRA_MAX", 7));
-            u32 extra = over;
-            if (ctx->opt("DEBUG_SEG_EXTRA")) extra = std::max<u32>(over, (u32)ctx->opt_u64("DEBUG_SEG_EXTRA", 0));
-            else {
-                auto n_pass = [&](u32 e) { return 1u + (e ? 1u : 0u) + (2 * (u32)P.k - 8 - e + 7) / 8; };
-                for (u32 e = over + 1; e <= e_cap && 2 * (u32)P.k > 16 + e; ++e) if (n_pass(e) < n_pass(extra)) extra = e;
-            }
-            const bool extra_ok = extra == 0 || (extra <= e_cap && 2 * (u32)P.k > 16 + extra);
-            if (pass_from == 0 && extra_ok && 2 * P.k > 16 && !ctx->opt("NO_SEG_PACK") && M >= ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22)) {
+            const u32 extra_ = seg_pack_extra(ctx, P, yb_p);
+            const bool extra_ok = extra_ != ~0u;
+            const u32 extra = extra_ok ? extra_ : 0;
+            if (so.segw && M == 0) {
+                // (nothing to sort: an empty pair stream is an empty SEGW stream)
+            } else if (so.segw) {
+                // (the sketch already wrote what pass A wants: decided above, whatever M turned out to be)
+                sc.drop(v1); v1 = nullptr;
+                u32 *d1 = sc.get<u32>(M + 1);
+                if (!d1) return LRGE_ERR_DEVICE;
+                u64 *rk = nullptr;
+                rc = index_sort_segw(ctx, sc, so.x, (u32 *)so.y, k1, d1, M, 2 * P.k, yb_p, pk_pos1, extra, &rk, &d_seg_start);
+                if (rc) return rc;
+                h_seg_start.assign((256u << extra) + 1, 0u);
+                HIPCHK(ctx, ctx->d2h(h_seg_start.data(), d_seg_start, h_seg_start.size() * 4, ctx->stream));
+                seg_packed = true; kshift_t = yb_p; seg_e = extra;
+                skey = rk; spos = rk;
+                sc.drop(rk == so.x ? k1 : so.x); sc.drop((u32 *)so.y); sc.drop(d1);
+            } else if (pass_from == 0 && extra_ok && 2 * P.k > 16 && !ctx->opt("NO_SEG_PACK") && M >= ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22)) {
                 u64 *rk = nullptr;
                 rc = index_sort_segpacked(ctx, sc, so.x, so.y, k1, v1, M, 2 * P.k, yb_p, pk_pos1, extra, &rk, &d_seg_start);
                 if (rc) return rc;

@@ -9,12 +9,13 @@ struct SketchOut {
     // keep_slots (packed index entries, one-pass form): x stays null -- the entries still sit in the per-chunk slots of k_sketch_direct
     // (chunk c at slots[c * SK_CAP ...), offs[] = exclusive scan of the per-chunk counts) and the index sort's first pass reads them there
     u64 *slots = nullptr; u32 *offs = nullptr; u32 n_chunks = 0;
+    bool segw = false;                // y holds a u32 ARRAY: SEGW entries (k_sketch.h, sketch_write_chunk PK == 2): x = word, y[i] = the two sort digits
 };
 
 // pk_ybits != 0 (index only): packed 8-byte entries in o->x, o->y stays null (k_sketch.h PK)
 template <int K, int W, bool HPC>
 static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o, u32 pk_pos1, u32 pk_ybits,
-                         std::vector<u32> *h_mzoff, bool gated = false, bool keep_slots = false) {
+                         std::vector<u32> *h_mzoff, bool gated = false, bool keep_slots = false, bool segw = false) {
     // gated: the caller has NOT waited for the set's upload (seqset_ready): this function does, as late as it can -- chunk range by
     // chunk range behind the upload's gates where the form allows it
     if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
@@ -22,7 +23,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     // Option SKETCH_TILE_FORM: k_sketch_tile (k_sketch_tile.h: a lane per step, a workgroup per 16 chunks; + k_sketch_redo for the HPC tiles
     // it marks) in place of k_sketch_direct (a lane per chunk) in the one-pass forms, into the same per-chunk slots.  Exact, and NOT the
     // default: measured at full-size C5 it is slower with HPC (index sketch 286 against 198 ms) and equal without.
-    const bool tile_form = ctx->opt("SKETCH_TILE_FORM") != nullptr;
+    const bool tile_form = ctx->opt("SKETCH_TILE_FORM") != nullptr && !segw;      // (the tile form writes pairs or packed words only)
     // the upload job whose gates cover this set's words (a view: its root's), and how far the sketch may go behind gate j:
     // every chunk that lies wholly inside the words that have arrived -- with HPC only the chunks of reads that have arrived
     // WHOLLY (a homopolymer-compressed step may run past its chunk, to the end of the read at most)
@@ -55,7 +56,9 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
         return LRGE_OK;
     };
     const u32 *d_cs = s->d_cs;           // chunk map, uploaded with the set
-    const bool pk = index_keys && pk_ybits;
+    const bool pk = index_keys && pk_ybits && !segw;
+    const u64 ebytes = pk ? 8 : segw ? 12 : 16;          // bytes per entry in the slots and in the output
+    auto get_y = [&](size_t n_) -> u64 * { return segw ? (u64 *)sc.get<u32>(n_) : sc.get<u64>(n_); };      // the second member's array
     ALLOC_OR_FAIL(d_cnt, sc, u32, (size_t)n_chunks + 1);
     ALLOC_OR_FAIL(d_total, sc, u32, 2);  // [1] = overflow flag of the one-pass form
     ALLOC_OR_FAIL(d_mzoff, sc, u32, (size_t)s->n + 1);
@@ -63,7 +66,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     const dim3 sgrid((u32)div_up(n_chunks, SK_THREADS));
     // One pass (k_sketch_direct into per-chunk slots, then k_sketch_compact) when the slots fit comfortably; the
     // two-pass form (count, scan, write) otherwise, when a chunk overflows its slot, or on request.
-    const u64 slot_bytes = (u64)n_chunks * SK_CAP * 8 * (pk ? 1 : 2);
+    const u64 slot_bytes = (u64)n_chunks * SK_CAP * ebytes;
     size_t mfree = (size_t)64 << 30, mtot = 0;
     if (slot_bytes > ((u64)4 << 30)) (void)hipMemGetInfo(&mfree, &mtot);       // (small sets: no need to ask)
     bool one_pass = n_chunks && !ctx->opt("SKETCH_TWO_PASS") && slot_bytes < ((u64)mfree + ctx->pool.idle()) / 4 && !ctx->opt("DEBUG_SK_RANGE_CHUNKS");   // (tests: the ranged form)
@@ -72,7 +75,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     u64 *tx = nullptr, *ty = nullptr;
     if (one_pass) {
         tx = sc.get<u64>((size_t)n_chunks * SK_CAP);
-        ty = pk ? nullptr : sc.get<u64>((size_t)n_chunks * SK_CAP);
+        ty = pk ? nullptr : get_y((size_t)n_chunks * SK_CAP);
         if (!tx || (!pk && !ty)) { if (tx) sc.drop(tx); if (ty) sc.drop(ty); tx = ty = nullptr; one_pass = false; (void)hipGetLastError(); }
     }
     u32 tot_ovf[2] = {0, 0};
@@ -93,6 +96,9 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                                    s->d_len, cm, c1, d_cnt, d_total + 1, sx, sy, P1, YB, capv, c0);                                                  \
         } while (0)
         if (pk) LRGE_SK_LAUNCH(true, true, pk_pos1, pk_ybits);
+        else if (segw)          // (the lane form only: tile_form is off for SEGW entries)
+            hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, 2>), gl, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,
+                               s->d_len, cm, c1, d_cnt, d_total + 1, sx, sy, pk_pos1, pk_ybits, capv, c0);
         else if (index_keys) LRGE_SK_LAUNCH(true, false, 0u, 0u);
         else LRGE_SK_LAUNCH(false, false, 0u, 0u);
 #undef LRGE_SK_LAUNCH
@@ -103,15 +109,15 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     // that overflows its slot, starts over in the two-pass form below.  Full-size C5: index sketch of a 10-Gbase part and the
     // streamed views of the inverse strategy (two passes: 8.3 ps per base; one pass + compaction: 7.3).
     if (n_chunks && !one_pass && !ctx->opt("SKETCH_TWO_PASS") && !ctx->opt("NO_RANGED_SKETCH") && !cap_env) {
-        const u64 per_chunk = (u64)SK_CAP * 8 * (pk ? 1 : 2);
+        const u64 per_chunk = (u64)SK_CAP * ebytes;
         const u64 avail = (u64)mfree + ctx->pool.idle();
         u64 R = std::min<u64>(avail / 8, (u64)24 << 30) / per_chunk / 256 * 256;
         R = ctx->opt_u64("DEBUG_SK_RANGE_CHUNKS", R);
         const u64 est = std::min<u64>((u64)s->total_bases + 1, (u64)((double)s->total_bases * 0.40) + 65536);
-        if (R >= 256 && R < n_chunks && est < (1ULL << 32) && est * 8 * (pk ? 1 : 2) < avail / 2) {
+        if (R >= 256 && R < n_chunks && est < (1ULL << 32) && est * ebytes < avail / 2) {
             if (gated && !gjob) { int rr = seqset_ready(ctx, s); if (rr) return rr; gated = false; }
-            u64 *rx = sc.get<u64>((size_t)R * SK_CAP), *ry = pk ? nullptr : sc.get<u64>((size_t)R * SK_CAP);
-            u64 *dx = sc.get<u64>((size_t)est + 1), *dy = pk ? nullptr : sc.get<u64>((size_t)est + 1);
+            u64 *rx = sc.get<u64>((size_t)R * SK_CAP), *ry = pk ? nullptr : get_y((size_t)R * SK_CAP);
+            u64 *dx = sc.get<u64>((size_t)est + 1), *dy = pk ? nullptr : get_y((size_t)est + 1);
             u32 *d_run = sc.get<u32>(2);                  // [0] output offset behind the ranges done, [1] the current range's count
             if (rx && (pk || ry) && dx && (pk || dy) && d_run) {
                 HIPCHK(ctx, hipMemsetAsync(d_total, 0, 8, ctx->stream));
@@ -119,7 +125,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                 for (u64 c0 = 0; c0 < n_chunks; c0 += R) {
                     const u32 c1 = (u32)std::min<u64>(c0 + R, n_chunks), len = c1 - (u32)c0;
                     if (gated && wait_chunks(c1) != LRGE_OK) { int rr = seqset_ready(ctx, s); return rr ? rr : LRGE_ERR_DEVICE; }   // this range's reads have arrived; the later ones may still travel
-                    u64 *sx = rx - c0 * SK_CAP, *sy = ry ? ry - c0 * SK_CAP : nullptr;      // (the kernels index slots by chunk number)
+                    u64 *sx = rx - c0 * SK_CAP, *sy = !ry ? nullptr : segw ? (u64 *)((u32 *)ry - c0 * SK_CAP) : ry - c0 * SK_CAP;      // (the kernels index slots by chunk number)
                     launch_slots((u32)c0, c1, sx, sy, (u32)SK_CAP);
                     KCHK(ctx);
                     int rc = scan_exclusive_u32(ctx, sc, d_cnt + c0, d_cnt + c0, len, d_run + 1);
@@ -129,6 +135,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                     KCHK(ctx);
                     const dim3 cgrid((u32)div_up(div_up(len, 64), 4));
                     if (pk) hipLaunchKernelGGL(k_sketch_compact<false>, cgrid, dim3(256), 0, ctx->stream, sx, sy, d_cnt, d_run, c1, dx, dy, (u32)c0, (u32)est, d_total + 1);
+                    else if (segw) hipLaunchKernelGGL(k_sketch_compact<2>, cgrid, dim3(256), 0, ctx->stream, sx, sy, d_cnt, d_run, c1, dx, dy, (u32)c0, (u32)est, d_total + 1);
                     else hipLaunchKernelGGL(k_sketch_compact<true>, cgrid, dim3(256), 0, ctx->stream, sx, sy, d_cnt, d_run, c1, dx, dy, (u32)c0, (u32)est, d_total + 1);
                     KCHK(ctx);
                 }
@@ -146,7 +153,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                 sc.drop(rx); if (ry) sc.drop(ry); sc.drop(d_run);
                 if (!h_ovf) {
                     sc.drop(d_cnt); sc.drop(d_total);
-                    o->x = dx; o->y = dy; o->mz_off = d_mzoff; o->n = h_run;
+                    o->x = dx; o->y = dy; o->mz_off = d_mzoff; o->n = h_run; o->segw = segw;
                     return LRGE_OK;
                 }
                 sc.drop(dx); if (dy) sc.drop(dy);          // beat the estimate, or a chunk overflowed its slot: two passes
@@ -216,16 +223,20 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     }
     ALLOC_OR_FAIL(dx, sc, u64, (size_t)total + 1);
     u64 *dy = nullptr;
-    if (!pk) { dy = sc.get<u64>((size_t)total + 1); if (!dy) return LRGE_ERR_DEVICE; }
+    if (!pk) { dy = get_y((size_t)total + 1); if (!dy) return LRGE_ERR_DEVICE; }
     if (n_chunks && one_pass) {
         const dim3 cgrid((u32)div_up(div_up(n_chunks, 64), 4));
         if (pk) hipLaunchKernelGGL(k_sketch_compact<false>, cgrid, dim3(256), 0, ctx->stream, tx, ty, d_cnt, d_total, n_chunks, dx, dy);
+        else if (segw) hipLaunchKernelGGL(k_sketch_compact<2>, cgrid, dim3(256), 0, ctx->stream, tx, ty, d_cnt, d_total, n_chunks, dx, dy);
         else hipLaunchKernelGGL(k_sketch_compact<true>, cgrid, dim3(256), 0, ctx->stream, tx, ty, d_cnt, d_total, n_chunks, dx, dy);
         KCHK(ctx);
         sc.drop(tx); if (ty) sc.drop(ty);
     } else if (n_chunks) {
         if (pk)
             hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, true>), sgrid, dim3(SK_THREADS), 0,
+                               ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, pk_pos1, pk_ybits);
+        else if (segw)
+            hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, 2>), sgrid, dim3(SK_THREADS), 0,
                                ctx->stream, s->d_pack, s->d_nmask, s->d_woff, s->d_len, cm, n_chunks, d_cnt, dx, dy, pk_pos1, pk_ybits);
         else if (index_keys)
             hipLaunchKernelGGL((k_sketch_write<K, W, HPC, true, false>), sgrid, dim3(SK_THREADS), 0,
@@ -237,12 +248,12 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     }
     // (no sync: everything runs in order on ctx->stream; scratch is recycled in stream order)
     sc.drop(d_cnt); sc.drop(d_total);
-    o->x = dx; o->y = dy; o->mz_off = d_mzoff; o->n = total;
+    o->x = dx; o->y = dy; o->mz_off = d_mzoff; o->n = total; o->segw = segw;
     return LRGE_OK;
 }
 
 static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o,
-                         u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr, bool keep_slots = false) {
+                         u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr, bool keep_slots = false, bool segw = false) {
     // A set whose host-side pack is still running on the uploader thread (chunk gates: host_pack.h) is sketched chunk by chunk
     // behind its transfer -- index sketches only (a streamed set's upload hides behind the index build anyway).  Since round 4 also
     // VIEWS of such a set (the parts of a partitioned index: part 0 is sketched, sorted and tabled while parts 1.. still travel)
@@ -254,8 +265,8 @@ static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     int rc = gated ? LRGE_OK : seqset_ready(ctx, s);
     if (rc) return rc;
     StageTimer t(ctx, LRGE_T_SKETCH);
-    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots)
-                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots);
+    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots, segw)
+                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots, segw);
     t.stop();
     return rc;
 }

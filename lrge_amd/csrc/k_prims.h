@@ -283,6 +283,15 @@ struct UnpackParams { u32 sb, bits_qy, sh_q, dmask, nbits; };   // dmask: digit 
                             // left out of the word as well: R = the low up.nbits - 8 - e bits (the pass makes the digit part of the segment:
                             // index_sort_segpacked with e > 0; e <= 7)
 
+// SEGW entries (round 5; k_sketch.h, sketch_write_chunk PK == 2): the sketch hands the sort a WORD per entry -- [the low nbits - 16 bits of the
+// hash's significance string | rid | pos << 1 | strand] -- and, in a u32 array, the string's top 16 bits DIG = b0 << 8 | b1: 12 bytes instead
+// of the pair's 16.  keys_in / keys_out are that u32 array (passed as u64 pointers), vals_in / vals_out the words.
+#define RS_MODE_DW 5        // pass A: (DIG, word) by b0 = DIG >> 8 (`shift` = 8), both members move
+#define RS_MODE_DWQ 6       // pass A2 (e = up.sh_q > 0): by the top e bits of b1 (`shift` = 8 - e, dmask = 2^e - 1); ONE packed u64 out, the word with the
+                            // low 8 - e bits of b1 put on top of its hash field: R << up.sb | y, exactly RS_MODE_PACKQ's output
+#define RS_MODE_DWP 7       // e = 0: the first LSD pass over R: the word takes all of b1 on top of its hash field (RS_MODE_PACK's output) and is ranked
+                            // by its own digit (`shift` addresses the packed value)
+
 // Blocks are observed to be dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Tile t and
 // tile t + 1 of a pass write adjacent runs in every digit's region, so they should meet in ONE L2: XCD x takes the
 // x-th contiguous eighth of the tiles.  A bijection of [0, nb); placement is a speed matter only.
@@ -367,7 +376,7 @@ __device__ __forceinline__ void rs_load_from_slots(const SlotSrc &S, u32 bid, u6
 template <bool SEG, int DB = 8, bool SLOTS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
                                                         u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255, SlotSrc src = SlotSrc(),
-                                                        u32 use_src = 0, u32 sig_nbits = 0) {
+                                                        u32 use_src = 0, u32 sig_nbits = 0, u32 key32 = 0) {       // key32: `keys` is a u32 array (the DIG member of SEGW entries)
     constexpr u32 ND = 1u << DB;
     static_assert(!SLOTS || !SEG, "slots feed whole (unsegmented) sorts only");
     __shared__ u32 h[ND];
@@ -383,7 +392,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
     if (SLOTS) rs_load_from_slots(src, bid, tile0, n_tile, s_offs, kk, 0ULL);
     else {
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS; ++r) kk[r] = l0 + (u32)r * 64 < n_tile ? keys[tile0 + l0 + (u32)r * 64] : 0;
+        for (int r = 0; r < RS_ITEMS; ++r)
+            kk[r] = l0 + (u32)r * 64 < n_tile ? (key32 ? (u64)((const u32 *)keys)[tile0 + l0 + (u32)r * 64] : keys[tile0 + l0 + (u32)r * 64]) : 0;
     }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r)
@@ -413,7 +423,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     __shared__ u32 wtot[RS_WAVES];
     __shared__ u64 stage[RS_TILE];       // 32 KB: keys, then values
     // PACKQ: the digit is not in the staged word; it is staged beside it, one byte per item, in the rank counters' LDS (free by then)
-    static_assert(sizeof(u32) * RS_WAVES * ND >= RS_TILE || MODE != RS_MODE_PACKQ, "the digit bytes alias the rank counters");
+    static_assert(sizeof(u32) * RS_WAVES * ND >= RS_TILE || (MODE != RS_MODE_PACKQ && MODE != RS_MODE_DWQ), "the digit bytes alias the rank counters");
+    constexpr bool DWIN = MODE == RS_MODE_DW || MODE == RS_MODE_DWQ || MODE == RS_MODE_DWP;      // the key member comes from a u32 array
     u8 *sdig = (u8 *)&cnt[0][0];
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     const u32 bid = xcd_tile(blockIdx.x, gridDim.x);
@@ -430,9 +441,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     if (SLOTS) rs_load_from_slots(src, bid, tile0, n_tile, s_offs, k, ~0ULL);
     else {
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS; ++r) k[r] = l0 + (u32)r * 64 < n_tile ? keys_in[base + (u64)r * 64] : ~0ULL;
+        for (int r = 0; r < RS_ITEMS; ++r)
+            k[r] = l0 + (u32)r * 64 < n_tile ? (DWIN ? (u64)((const u32 *)keys_in)[base + (u64)r * 64] : keys_in[base + (u64)r * 64]) : ~0ULL;
     }
-    if (MODE == RS_MODE_PAIRS || MODE == RS_MODE_PACK || MODE == RS_MODE_PACKQ) {
+    if (MODE == RS_MODE_PAIRS || MODE == RS_MODE_PACK || MODE == RS_MODE_PACKQ || DWIN) {
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) v[r] = l0 + (u32)r * 64 < n_tile ? vals_in[base + (u64)r * 64] : 0;
     }
@@ -444,7 +456,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         for (int r = 0; r < RS_ITEMS; ++r)
             if (l0 + (u32)r * 64 < n_tile) k[r] = (hash_to_sig(k[r], up.nbits) & rmask) << up.sb | (v[r] >> 32) << up.bits_qy | (v[r] & pmask);
     }
-    // (PACKQ: the digit comes from the hash itself, so the word is packed only when it is staged)
+    if (MODE == RS_MODE_DWP) {       // the word takes b1 on top of its hash field and is the key from here on
+        const u32 hs = up.sb + up.nbits - 16;
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r)
+            if (l0 + (u32)r * 64 < n_tile) k[r] = v[r] | (k[r] & 0xffULL) << hs;
+    }
+    // (PACKQ / DWQ: the digit comes from the hash itself, so the word is packed only when it is staged)
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const bool valid = l0 + (u32)r * 64 < n_tile;
@@ -494,7 +512,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     for (int r = 0; r < RS_ITEMS; ++r) {
         u32 d = (u32)(k[r] >> shift) & dmask;
         lpos[r] = cnt[w][d] + rank[r];
-        if (MODE != RS_MODE_PACKQ && l0 + (u32)r * 64 < n_tile) stage[lpos[r]] = k[r];
+        if (MODE != RS_MODE_PACKQ && MODE != RS_MODE_DWQ && l0 + (u32)r * 64 < n_tile) stage[lpos[r]] = k[r];
+    }
+    if (MODE == RS_MODE_DWQ) {
+        __syncthreads();                               // every local position is known: the counters' LDS takes the digit bytes
+        const u32 hs = up.sb + up.nbits - 16;
+        const u64 lowb = (1ULL << (8 - up.sh_q)) - 1;
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) {
+            if (l0 + (u32)r * 64 < n_tile) {
+                sdig[lpos[r]] = (u8)((u32)(k[r] >> shift) & dmask);
+                stage[lpos[r]] = v[r] | (k[r] & lowb) << hs;
+            }
+        }
     }
     if (MODE == RS_MODE_PACKQ) {
         __syncthreads();                               // every local position is known: the counters' LDS takes the digit bytes
@@ -530,11 +560,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         if (p < n_tile) {
             ko[r] = stage[p];
             u32 d = (u32)(ko[r] >> shift) & dmask;
-            if (MODE == RS_MODE_PACKQ) d = sdig[p];
-            keys_out[gbase[d] + p] = ko[r];
+            if (MODE == RS_MODE_PACKQ || MODE == RS_MODE_DWQ) d = sdig[p];
+            if (MODE == RS_MODE_DW) ((u32 *)keys_out)[gbase[d] + p] = (u32)ko[r];
+            else keys_out[gbase[d] + p] = ko[r];
         }
     }
-    if (MODE == RS_MODE_KEYS || MODE == RS_MODE_PACK || MODE == RS_MODE_PACKQ) return;
+    if (MODE == RS_MODE_KEYS || MODE == RS_MODE_PACK || MODE == RS_MODE_PACKQ || MODE == RS_MODE_DWQ || MODE == RS_MODE_DWP) return;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
@@ -1059,6 +1090,88 @@ static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky
         KCHK(ctx);
         ts.stop();
         ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (first ? 24 : 16) * n;
+        if (!first) { u64 *t = pi; pi = po; po = t; }
+    }
+    if (d_c) sc.drop(d_c);
+    sc.drop(d_tb);
+    sc.drop(hist); sc.drop((u32 *)d_tiles);
+    *res = pi; *d_seg_start = d_b;
+    return LRGE_OK;
+}
+
+// The same sort over SEGW entries (RS_MODE_DW* above): wx = the words, dy = the u32 DIG array, both as the sketch left them; k1 / d1 =
+// buffers of n + 1 u64 / u32.  Pass A moves 12 bytes per entry instead of 16 (and its histogram reads 4 instead of 8), pass A2 / the
+// first LSD pass reads 12 instead of 16; from there on the entries are the packed words of index_sort_segpacked, bit for bit.
+static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64 *k1, u32 *d1, u64 n, int nbits, u32 ybits, u32 pos1, u32 e,
+                           u64 **res, u32 **d_seg_start) {
+    (void)pos1;
+    const int nr = nbits - 8 - (int)e, passes = (nr + 7) / 8;      // LSD passes over R
+    const u32 nb = (u32)div_up(n, RS_TILE), n_seg = 256u << e;
+    const u32 max_tiles = nb + n_seg;
+    ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * (max_tiles + 1) + 256);
+    // ---- pass A: (DIG, word) by b0 ----
+    {
+        hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)dy, n, 8, nb, hist, (const SegTile *)nullptr, 255u, SlotSrc(), 0u, 0u, 1u);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr); if (rc) return rc;
+        StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+        hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_DW>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)dy, (const u64 *)wx, (u64 *)d1, k1, n, 8, nb, hist,
+                           (const SegTile *)nullptr, UnpackParams{0, 0, 0, 255, 0});
+        KCHK(ctx);
+        ts.stop();
+        ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 24 * n;
+    }
+    u32 *d_b = sc.get<u32>(n_seg + 1), *d_c = e ? sc.get<u32>(257) : nullptr, *d_tb = sc.get<u32>(n_seg + 1);
+    if (!d_b || !d_tb || (e && !d_c)) return LRGE_ERR_DEVICE;
+    u32 *coarse = e ? d_c : d_b;                       // the 256 segments of pass A
+    hipLaunchKernelGGL(k_gather_strided_u32, dim3(1), dim3(256), 0, ctx->stream, hist, (u64)nb, 256u, coarse);
+    hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, ctx->stream, coarse + 256, (u32)n);
+    KCHK(ctx);
+    ALLOC_OR_FAIL(d_tiles, sc, u32, (size_t)max_tiles * (sizeof(SegTile) / 4) + 8);
+    u32 cur_tiles = nb + 256;
+    hipLaunchKernelGGL(k_seg_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)coarse, 256u, d_tb);
+    hipLaunchKernelGGL(k_seg_tile_fill, dim3(div_up(cur_tiles, 256)), dim3(256), 0, ctx->stream, (const u32 *)coarse, (const u32 *)d_tb, 256u, cur_tiles, (SegTile *)d_tiles);
+    KCHK(ctx);
+    u64 *pi = wx, *po = k1;          // (the sketch's word buffer is free once pass A has read it; k1 once the packing pass has)
+    if (e) {
+        // ---- pass A2: inside every segment by the top e bits of b1, packing ----
+        const u32 qm = (1u << e) - 1;
+        hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)d1, n, 8 - (int)e, cur_tiles, hist, (const SegTile *)d_tiles, qm, SlotSrc(), 0u, 0u, 1u);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * cur_tiles, nullptr); if (rc) return rc;
+        hipLaunchKernelGGL(k_seg_fine_starts, dim3(div_up(n_seg + 1, 256)), dim3(256), 0, ctx->stream, (const u32 *)hist, (const u32 *)coarse, (const u32 *)d_tb, e, (u32)n, d_b);
+        KCHK(ctx);
+        {
+            StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+            hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_DWQ>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)d1, (const u64 *)k1, pi, (u64 *)nullptr, n, 8 - (int)e, cur_tiles, hist,
+                               (const SegTile *)d_tiles, UnpackParams{ybits, pos1, e, qm, (u32)nbits});
+            KCHK(ctx);
+            ts.stop();
+        }
+        ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 20 * n;
+        cur_tiles = max_tiles;
+        hipLaunchKernelGGL(k_seg_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)d_b, n_seg, d_tb);
+        hipLaunchKernelGGL(k_seg_tile_fill, dim3(div_up(cur_tiles, 256)), dim3(256), 0, ctx->stream, (const u32 *)d_b, (const u32 *)d_tb, n_seg, cur_tiles, (SegTile *)d_tiles);
+        KCHK(ctx);
+    }
+    // ---- the digits of R, least significant first (e == 0: the first of them reads (DIG, word) and packs) ----
+    for (int j = 0; j < passes; ++j) {
+        const bool first = !e && j == 0;
+        const int w = nr - 8 * j >= 8 ? 8 : nr - 8 * j;
+        const u32 dm = (1u << w) - 1u;
+        const int pshift = (int)ybits + 8 * j;                           // where digit j sits in the packed word
+        // (first: digit 0 of R lies in the word's own hash field -- nbits - 16 >= 8 is the caller's condition -- so the histogram reads the words)
+        hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, first ? k1 : pi, n, pshift, cur_tiles, hist, (const SegTile *)d_tiles, dm);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * cur_tiles, nullptr); if (rc) return rc;
+        StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+        if (first) hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_DWP>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)d1, (const u64 *)k1, pi, (u64 *)nullptr, n, pshift, cur_tiles, hist,
+                                      (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm, (u32)nbits});
+        else hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, (const u64 *)nullptr, po, (u64 *)nullptr, n, pshift, cur_tiles,
+                                hist, (const SegTile *)d_tiles, UnpackParams{0, 0, 0, dm});
+        KCHK(ctx);
+        ts.stop();
+        ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (first ? 20 : 16) * n;
         if (!first) { u64 *t = pi; pi = po; po = t; }
     }
     if (d_c) sc.drop(d_c);

@@ -473,34 +473,48 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_count(const u64 *__restri
 // one, every 32-byte sector reaches HBM as four partial writes (measured 4x the bytes).  The last <= 4 are
 // kept in registers and leave as one sector-aligned 32-byte run per array whenever the output index
 // reaches a multiple of 4; only the head and the tail of the lane's range are written singly.
-template <int K, int W, bool HPC, bool INDEX_KEYS, bool PK, bool POS_OWN = false>
+// PK == 2 (index only, "SEGW": round 5): the entry as the segment-packed index sort wants it (k_prims.h, index_sort_segw) -- out_x gets
+// one word, [the low 2k - 16 bits of the hash's significance string | rid | pos << 1 | strand] (pk_ybits = the width of the y field),
+// and out_y, read as a u32 ARRAY, the top 16 bits of that string: the two digits the sort's first two passes order by.  12 bytes per
+// entry instead of the pair's 16 through the slots, the compaction and those two passes.
+template <int K, int W, bool HPC, bool INDEX_KEYS, int PK, bool POS_OWN = false>
 __device__ __forceinline__ u32 sketch_write_chunk(const u64 *__restrict__ pack, const u32 *__restrict__ nmask, u64 word_base, i32 len, u32 r,
                                                   i32 s, i32 e, u32 o0, u32 cap, u64 *__restrict__ out_x, u64 *__restrict__ out_y,
                                                   u32 pk_pos1, u32 pk_ybits) {
+    static_assert(PK != 2 || (INDEX_KEYS && 2 * K > 16), "SEGW entries are index entries of a hash wider than its two sort digits");
     u32 o = o0, found = 0;
     u64 bx0 = 0, bx1 = 0, bx2 = 0, bx3 = 0, by0 = 0, by1 = 0, by2 = 0, by3 = 0;
+    u32 *const out_d = (u32 *)out_y;                   // (PK == 2)
     u32 nb = 0;   // buffered entries: output indices [o - nb, o), newest in b?3
     auto flush_tail = [&]() {
-        if (nb >= 3) { out_x[o - 3] = bx1; if (!PK) out_y[o - 3] = by1; }
-        if (nb >= 2) { out_x[o - 2] = bx2; if (!PK) out_y[o - 2] = by2; }
-        if (nb >= 1) { out_x[o - 1] = bx3; if (!PK) out_y[o - 1] = by3; }
+        if (nb >= 3) { out_x[o - 3] = bx1; if (PK == 0) out_y[o - 3] = by1; else if (PK == 2) out_d[o - 3] = (u32)by1; }
+        if (nb >= 2) { out_x[o - 2] = bx2; if (PK == 0) out_y[o - 2] = by2; else if (PK == 2) out_d[o - 2] = (u32)by2; }
+        if (nb >= 1) { out_x[o - 1] = bx3; if (PK == 0) out_y[o - 1] = by3; else if (PK == 2) out_d[o - 1] = (u32)by3; }
         nb = 0;
     };
     sketch_chunk<K, W, HPC, POS_OWN>(pack, nmask, word_base, len, r, s, e, [&](u64 x, u64 y) {
         if (found++ >= cap) return;                     // counted, not stored (the caller notices found > cap)
         bx0 = bx1; bx1 = bx2; bx2 = bx3;
-        if (PK) bx3 = (x >> 8) << pk_ybits | (y >> 32) << pk_pos1 | (u64)(u32)y;
-        else bx3 = INDEX_KEYS ? (x >> 8) : x;  // the index keeps only the hash, queries keep hash<<8|span
-        by0 = by1; by1 = by2; by2 = by3; by3 = y;
+        by0 = by1; by1 = by2; by2 = by3;
+        if (PK == 1) bx3 = (x >> 8) << pk_ybits | (y >> 32) << pk_pos1 | (u64)(u32)y;
+        else if (PK == 2) {
+            const u64 S = hash_to_sig(x >> 8, 2 * K);
+            bx3 = (S & ((1ULL << (2 * K - 16)) - 1)) << pk_ybits | (y >> 32) << pk_pos1 | (u64)(u32)y;
+            by3 = S >> (2 * K - 16);
+        } else bx3 = INDEX_KEYS ? (x >> 8) : x;  // the index keeps only the hash, queries keep hash<<8|span
+        if (PK != 2) by3 = y;
         ++o; ++nb;
         if ((o & 3u) == 0) {
             if (nb == 4) {
                 ulonglong2 a, b;
                 a.x = bx0; a.y = bx1; b.x = bx2; b.y = bx3;
                 *(ulonglong2 *)(out_x + o - 4) = a; *(ulonglong2 *)(out_x + o - 2) = b;
-                if (!PK) {
+                if (PK == 0) {
                     a.x = by0; a.y = by1; b.x = by2; b.y = by3;
                     *(ulonglong2 *)(out_y + o - 4) = a; *(ulonglong2 *)(out_y + o - 2) = b;
+                } else if (PK == 2) {
+                    uint4 d4; d4.x = (u32)by0; d4.y = (u32)by1; d4.z = (u32)by2; d4.w = (u32)by3;
+                    *(uint4 *)(out_d + o - 4) = d4;
                 }
                 nb = 0;
             } else flush_tail();
@@ -511,7 +525,7 @@ __device__ __forceinline__ u32 sketch_write_chunk(const u64 *__restrict__ pack, 
 }
 
 // second pass of the two-pass form: offsets from the scanned counts of k_sketch_count
-template <int K, int W, bool HPC, bool INDEX_KEYS, bool PK>
+template <int K, int W, bool HPC, bool INDEX_KEYS, int PK>
 __global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
                                                             const u64 *__restrict__ woff, const u32 *__restrict__ lens,
                                                             ChunkMap cm, u32 n_chunks, const u32 *__restrict__ offs,
@@ -531,7 +545,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_write(const u64 *__restri
 // SK_CAP minimizers (possible in principle: a step can emit up to w of them) raises *overflow and the caller falls
 // back to the two-pass form.
 #define SK_CAP (SK_CHUNK + 8)
-template <int K, int W, bool HPC, bool INDEX_KEYS, bool PK>
+template <int K, int W, bool HPC, bool INDEX_KEYS, int PK>
 __global__ __launch_bounds__(SK_THREADS) void k_sketch_direct(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
                                                              const u64 *__restrict__ woff, const u32 *__restrict__ lens,
                                                              ChunkMap cm, u32 n_chunks, u32 *__restrict__ counts, u32 *__restrict__ overflow,
@@ -547,13 +561,13 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_direct(const u64 *__restr
     i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
     const u64 base = (u64)c * SK_CAP;
     const u32 found = sketch_write_chunk<K, W, HPC, INDEX_KEYS, PK>(pack, nmask, woff[r], len, r, s, e, 0u, cap, tmp_x + base,
-                                                                    PK ? tmp_y : tmp_y + base, pk_pos1, pk_ybits);
+                                                                    PK == 1 ? tmp_y : PK == 2 ? (u64 *)((u32 *)tmp_y + base) : tmp_y + base, pk_pos1, pk_ybits);
     counts[c] = found;
     if (found > cap) *overflow = 1u;
 }
 
 // Behind k_sketch_tile (HPC): the chunks it marked ST_REDO, the sequential way, with the tile form's attribution (POS_OWN above).
-template <int K, int W, bool INDEX_KEYS, bool PK>
+template <int K, int W, bool INDEX_KEYS, int PK>
 __global__ __launch_bounds__(SK_THREADS) void k_sketch_redo(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
                                                            const u64 *__restrict__ woff, const u32 *__restrict__ lens,
                                                            ChunkMap cm, u32 n_chunks, u32 *__restrict__ counts, u32 *__restrict__ overflow,
@@ -568,7 +582,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_redo(const u64 *__restric
     const i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
     const u64 base = (u64)c * SK_CAP;
     const u32 found = sketch_write_chunk<K, W, true, INDEX_KEYS, PK, true>(pack, nmask, woff[r], len, r, s, e, 0u, cap, tmp_x + base,
-                                                                          PK ? tmp_y : tmp_y + base, pk_pos1, pk_ybits);
+                                                                          PK == 1 ? tmp_y : PK == 2 ? (u64 *)((u32 *)tmp_y + base) : tmp_y + base, pk_pos1, pk_ybits);
     counts[c] = found;
     if (found > cap) *overflow = 1u;
 }
@@ -579,7 +593,8 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_redo(const u64 *__restric
 // c_base / out_cap / ovf: the ranged form (host_sketch.inl: a set whose slots do not fit at once is sketched range by range into the
 // same slots): the launch covers chunks [c_base, n_chunks), `*d_total` is the output offset behind the range, and an entry that
 // would land at or beyond out_cap raises *ovf instead (the caller's estimate of the output size was too small: it starts over).
-template <bool PAIRS>
+// PAIRS: 0 = x only, 1 = (x, y) of 8 bytes each, 2 = x + a u32 per entry (tmp_y / out_y read as u32 arrays: the SEGW entries)
+template <int PAIRS>
 __global__ __launch_bounds__(256) void k_sketch_compact(const u64 *__restrict__ tmp_x, const u64 *__restrict__ tmp_y,
                                                         const u32 *__restrict__ offs, const u32 *__restrict__ d_total, u32 n_chunks,
                                                         u64 *__restrict__ out_x, u64 *__restrict__ out_y, u32 c_base = 0, u32 out_cap = 0xFFFFFFFFu,
@@ -604,7 +619,8 @@ __global__ __launch_bounds__(256) void k_sketch_compact(const u64 *__restrict__ 
         if (o >= out_cap) { if (ovf) *ovf = 1u; continue; }
         const u64 src = (u64)(c0 + j) * SK_CAP + within;
         out_x[o] = tmp_x[src];
-        if (PAIRS) out_y[o] = tmp_y[src];
+        if (PAIRS == 1) out_y[o] = tmp_y[src];
+        else if (PAIRS == 2) ((u32 *)out_y)[o] = ((const u32 *)tmp_y)[src];
     }
 }
 

@@ -210,15 +210,20 @@ def test_index_of_tiny_reads(ctx, oracle, slot_sort, knobs):
 
 
 @pytest.mark.parametrize("preset,extra", [("ont", 0), ("pb", 0), ("ont", 1), ("pb", 2), ("ont", 4), ("pb", 3), ("pb", 6), ("ont", 6), ("pb", 7), ("ont", 5)])
-def test_segment_packed_pair_index_is_exact(ctx, oracle, edge_set, tiny_ont, tiny_hifi, preset, extra, knobs):
+@pytest.mark.parametrize("entries", ["segw", "pairs"])
+def test_segment_packed_pair_index_is_exact(ctx, oracle, edge_set, tiny_ont, tiny_hifi, preset, extra, entries, knobs):
     """The (hash, y) pair layout sorted in its segment-packed form (k_prims.h: index_sort_segpacked: the low hash byte first, then
     one packed word per entry inside its 256 segments) only engages above 4 M entries -- C5/10 and full-size C5 run it at scale.
     Forced here onto small sets: index entries, lists, mid_occ and counts must be those of the plain pair sort and of the oracle.
     extra > 0: the form full-size C5 takes in 3 parts (read ids of 20 bits: the word is 2 bits short) -- the top `extra` bits of
     the second hash byte are implied by the segment as well (pass A2, 256 << extra segments).  Round 5: the entry keeps the low bits
     of the hash's significance string, so the keys-only passes cut it in whole bytes whatever `extra` is -- ("pb", 6) is what
-    full-size C5 runs now (24 bits left: three passes), 7 the most the second byte gives."""
+    full-size C5 runs now (24 bits left: three passes), 7 the most the second byte gives.
+    entries: "segw" -- the sketch writes [word, digit pair] entries of 12 bytes for this sort (k_sketch.h PK == 2, index_sort_segw: the
+    default since round 5) -- or "pairs" (option NO_SEGW: (hash, y) pairs of 16 bytes through index_sort_segpacked, rounds 3-4)."""
     from lrge_amd import engine
+    if entries == "pairs":
+        knobs.set("NO_SEGW", "1")
     knobs.set("NO_PACKED_INDEX", "1")
     knobs.set("SEG_PACK_MIN", "1")
     if extra:

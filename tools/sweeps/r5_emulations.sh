@@ -16,6 +16,7 @@ export LRGE_BENCH_EMULATE_TIMEOUT=600
 for w in $what; do
   case $w in
     fwd3) for i in 1 2 3; do timeout 900 python bench.py --emulate-world 8 --clock resident --steps 2 --warmup 1 > $out/fwd_resident_$i.json 2> $out/fwd_resident_$i.err; show $out/fwd_resident_$i.json; done;;
+    fwd1) timeout 900 python bench.py --emulate-world 8 --clock resident --steps 2 --warmup 1 > $out/fwd_resident_final.json 2> $out/fwd_resident_final.err; show $out/fwd_resident_final.json;;
     fwdhost) timeout 900 python bench.py --emulate-world 8 --clock host --steps 2 --warmup 1 > $out/fwd_host.json 2> $out/fwd_host.err; show $out/fwd_host.json;;
     inv) timeout 900 python bench.py --emulate-world 8 --inverse --clock resident --steps 2 --warmup 1 > $out/inv_resident.json 2> $out/inv_resident.err; show $out/inv_resident.json
          timeout 900 python bench.py --emulate-world 8 --inverse --clock host --steps 2 --warmup 1 > $out/inv_host.json 2> $out/inv_host.err; show $out/inv_host.json;;

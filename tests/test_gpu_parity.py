@@ -209,6 +209,30 @@ def test_index_of_tiny_reads(ctx, oracle, slot_sort, knobs):
     ixd.free()
 
 
+@pytest.mark.parametrize("form", ["two-pass", "overflow-fallback", "ranged"])
+@pytest.mark.parametrize("preset,extra", [("ont", 0), ("pb", 6)])
+def test_segw_entries_through_every_sketch_form(ctx, oracle, edge_set, preset, extra, form, knobs):
+    """SEGW index entries (k_sketch.h PK == 2: a word + a u32 with the sort's first two digits, 12 bytes instead of the pair's 16) leave the
+    sketch through the same forms as pairs do: the two-pass form (count, scan, k_sketch_write), the fallback to it when a chunk overflows
+    its slot, and the ranged one-pass form (slots of a range of chunks at a time; what a full-size C5 part takes).  The index -- keys,
+    position lists, statistics -- must be the oracle's in each."""
+    knobs.set("NO_PACKED_INDEX", "1")
+    knobs.set("SEG_PACK_MIN", "1")
+    if extra:
+        knobs.set("DEBUG_SEG_EXTRA", str(extra))
+    knobs.set({"two-pass": "SKETCH_TWO_PASS", "overflow-fallback": "DEBUG_SK_CAP", "ranged": "DEBUG_SK_RANGE_CHUNKS"}[form],
+              {"two-pass": "1", "overflow-fallback": "9", "ranged": "256"}[form])
+    qseqs, qnames, tseqs, tnames = edge_set
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset)
+    keys, pos = ixd.dump()
+    mz = ixo.minimizers()
+    order = np.lexsort((mz["y"], mz["x"] >> np.uint64(8)))
+    assert np.array_equal(keys, (mz["x"] >> np.uint64(8))[order]) and np.array_equal(pos, mz["y"][order])
+    st = ixd.stats()
+    assert st["mid_occ"] == ixo.mid_occ and st["n_keys"] == ixo.n_keys and st["n_minimizers"] == ixo.n_minimizers
+    ixd.free()
+
+
 @pytest.mark.parametrize("preset,extra", [("ont", 0), ("pb", 0), ("ont", 1), ("pb", 2), ("ont", 4), ("pb", 3), ("pb", 6), ("ont", 6), ("pb", 7), ("ont", 5)])
 @pytest.mark.parametrize("entries", ["segw", "pairs"])
 def test_segment_packed_pair_index_is_exact(ctx, oracle, edge_set, tiny_ont, tiny_hifi, preset, extra, entries, knobs):

@@ -357,9 +357,10 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
 #define HT_CAP_NUM 2       // home slots per distinct key = HT_CAP_NUM / HT_CAP_DEN
 #define HT_CAP_DEN 1
 #endif
-        // a part of a partitioned index (a target set of tens of gigabases) gets 1.25 instead of 2 slots per key: the
-        // tables of all parts are resident together and memory, not probe length (+15 % lookup time), is what binds there
-        u64 cap = targets->is_view ? (u64)n_runs * 5 / 4 : (u64)n_runs * HT_CAP_NUM / HT_CAP_DEN;
+        // a part of a partitioned index (a target set of tens of gigabases) gets 1.5 instead of 2 slots per key: the tables of all
+        // parts are resident together.  (1.25 until round 5; swept at full-size C5 ava-pb, profiles/r05_htcap_ab.txt: k_lookup 42.6 ms
+        // per step at 1.25, 34.4 at 1.5, 31.2 at 2.0 -- where the table passes give 7 ms back: 1.5 is the sum's minimum, for 1.6 GB)
+        u64 cap = targets->is_view ? (u64)n_runs * 3 / 2 : (u64)n_runs * HT_CAP_NUM / HT_CAP_DEN;
         if (const char *o = ctx->opt("HT_SLOTS_X100")) cap = (u64)n_runs * std::max<u64>(110, strtoull(o, nullptr, 10)) / 100;    // (several contexts sharing one GPU: memory binds there too)
         if (cap < 1024) cap = 1024;
         if (cap + n_runs >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32/3 distinct minimizers (got %u)", n_runs); return LRGE_ERR_TOO_MANY; }

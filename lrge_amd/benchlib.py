@@ -283,3 +283,95 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
                                                                    "entries": sum(x["entries_sent"] for x in ss) * ss[0]["entry_bytes"],
                                                                    "hashes": sum(x["hashes_sent"] * x.get("hash_bytes", 8) for x in ss)},
                       "ranks": res}))
+
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb2, tm2, cn2, lvl2_all, st, Qn, Tn, q_lens, t_lens):
+    """The roofline bookkeeping of a bench line from the timed steps' HIP-event times and work counters:
+    -> (r_dom = the single kernel with the most time per step, the other kernels, the kernel families, the SURVEY 8(d) whole-path
+    block, its GB/s).  Algorithmic bytes follow SURVEY.md 8(d); see the comments inside."""
+    def roof(kernel, ms_total, launches, bytes_total, bytes_note):
+        launches = max(1, launches)
+        avg_ms = ms_total / launches
+        alg = bytes_total / launches
+        ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS, "traffic": None, "alg_bytes_per_launch": alg, "alg_bytes": bytes_note,
+                "avg_launch_ms": avg_ms, "launches_per_step": launches / K, "ms_per_step": ms_total / K}
+
+    # Candidates, each timed with HIP event pairs on the stream it runs on during the TIMED steps.  `roofline` is the SINGLE
+    # KERNEL with the most time per step (VERDICT r03 item 7); kernel families (all kernels of a sort, of the sketch) are
+    # reported beside it in `roofline_other` with kind = "family".  Algorithmic bytes per launch follow SURVEY.md 8(d):
+    #   k_lookup           16 B per query minimizer (one hash/offset entry per lookup)
+    #   k_chain_lpg        16 B per anchor it chains (8 B key + 8 B value in)
+    #   k_expand           8 B position-list entry in + 8 B anchor out per anchor
+    #   k_rs_scatter       8(d) counts the ORDERING of index entries and anchors as implementation overhead (zero algorithmic
+    #                      bytes); the kindest honest denominator is what any sort must move -- every index entry and every
+    #                      anchor read once and written once per STEP -- dealt over the launches that do the moving: a sort of
+    #                      P passes can reach at most 1/P of the roof on this scale.  (`streamed`: the bytes the launches
+    #                      actually read + write, i.e. the kernel as a streaming kernel.)
+    #   families           index radix sort (k_rs_hist + scan + k_rs_scatter, all passes): one read + one write of every entry;
+    #                      index sketch (k_sketch_direct + k_sketch_compact): L/4 B of packed bases in + one entry out
+    # traffic: HBM bytes per launch of that kernel from the round's committed rocprofv3 --pmc passes of this same command
+    # (profiles/r05_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950); the counters
+    # cannot be read inside a timed run.
+    cands, fams = [], []
+    if acc_cn.get("lookup_launches", 0):
+        cands.append(roof("k_lookup", acc_tm.get("k_lookup", 0.0), acc_cn["lookup_launches"],
+                          16.0 * acc_cn.get("query_minimizers", 0), "16 B x query minimizers (SURVEY 8d: one hash/offset entry per lookup)"))
+    if acc_cn.get("lpg_launches", 0):
+        cands.append(roof("k_chain_lpg", acc_tm.get("chain_lpg", 0.0), acc_cn["lpg_launches"], 16.0 * acc_cn.get("lpg_anchors", 0),
+                          "16 B x anchors chained by the launch (SURVEY 8d: anchor in for chaining)"))
+    n_idx = float(st["n_minimizers"]) if not (world > 1 and not a.inverse) else float(acc_cn.get("rs_scatter_items", 0)) / max(1, K) / 4.0
+    entry_b = 8.0 if (2 * (19 if preset else 15) + int(np.ceil(np.log2((Qn if a.inverse else Tn) + 1))) + int(np.ceil(np.log2(float((q_lens if a.inverse else t_lens).max()) + 1))) + 1) <= 64 else 16.0
+    if acc_tb.get("index_sort", 0.0) > 0 and world == 1:
+        fams.append(roof("index radix sort (k_rs_hist + scan + k_rs_scatter, all passes)", acc_tb["index_sort"], K, 2.0 * entry_b * n_idx * K,
+                         "%d B in + %d B out per index entry: one read and one write of every entry" % (entry_b, entry_b)))
+    if acc_tb.get("sketch", 0.0) > 0 and world == 1:
+        L_idx = float((q_lens if a.inverse else t_lens).sum())
+        fams.append(roof("index sketch (k_sketch_direct + k_sketch_compact)", acc_tb["sketch"], K, (L_idx / 4.0 + entry_b * n_idx) * K,
+                         "L/4 B of packed bases in + %d B per minimizer out" % entry_b))
+    if acc_tm.get("anchor_sort", 0.0) > 0:
+        fams.append(roof("anchor sort (k_seg_sort_local / k_rs_hist + scan + k_rs_scatter)", acc_tm["anchor_sort"], K, 24.0 * acc_cn.get("anchors_kept", acc_cn.get("anchors", 0)),
+                         "8 B packed anchor in + 16 B (key, value) out per anchor that left the expansion"))
+    if acc_tm.get("expand", 0.0) > 0:
+        cands.append(roof("k_expand", acc_tm["expand"], max(1, acc_cn.get("batches", K)), 16.0 * acc_cn.get("anchors", 0),
+                          "8 B position-list entry in + 8 B anchor out per anchor"))
+    # k_rs_scatter: in the timed steps when they run at timer level 2 (big jobs), else in the instrumented step behind them
+    if lvl2_all:
+        sc_ms, sc_n, sc_bytes, sc_how = acc_tm.get("rs_scatter", 0.0) + acc_tb.get("rs_scatter", 0.0), acc_cn.get("rs_scatter_launches", 0), float(acc_cn.get("rs_scatter_bytes", 0)), "event pair around every launch of the timed steps"
+        anchors_moved = float(acc_cn.get("anchors_kept", acc_cn.get("anchors", 0)))      # (what leaves the expansion: the sort moves those)
+    else:
+        sc_ms, sc_n, sc_bytes, sc_how = (tm2.get("rs_scatter", 0.0) + tb2.get("rs_scatter", 0.0)) * K, cn2.get("rs_scatter_launches", 0) * K, float(cn2.get("rs_scatter_bytes", 0)) * K, "one instrumented step after the timed region (event pair around every launch)"
+        anchors_moved = float(cn2.get("anchors_kept", cn2.get("anchors", 0))) * K
+    if sc_n:
+        r_sc = roof("k_rs_scatter", sc_ms, sc_n, 2.0 * entry_b * n_idx * K + 16.0 * anchors_moved,
+                    "what any sort must move, once per step: %d B in + %d B out per index entry, 8 B in + 8 B out per anchor -- dealt over this "
+                    "kernel's launches (SURVEY 8d counts ordering as zero algorithmic bytes)" % (entry_b, entry_b))
+        r_sc["measured"] = sc_how
+        r_sc["streamed"] = {"bytes_per_launch": sc_bytes / sc_n, "GBps": sc_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0,
+                            "what": "bytes the launches read + write (32 / pair, 16 / packed key, 24 unpacking): the kernel as a streaming kernel"}
+        cands.append(r_sc)
+    for r_ in cands: r_["kind"] = "kernel"
+    for r_ in fams: r_["kind"] = "family"
+    cands.sort(key=lambda r: -r["ms_per_step"])
+    for r_ in cands + fams:
+        r_["traffic"], r_["traffic_detail"] = committed_kernel_traffic(a.config, a.inverse, r_["kernel"], "ava-pb" if preset else "ava-ont") if r_["kind"] == "kernel" else (None, None)
+    # whole-path algorithmic bytes (SURVEY.md 8d): B_q summed over queries + B_idx, per step
+    # (streamed set: the queries, or the targets with --inverse; for N > 1 rank 0's counters times the world size)
+    # M = minimizers of the streamed set, counted ONCE: against a partitioned index every part looks all of them up, and the
+    # library's counter adds them up per part (VERDICT r04: 1.122 G = 3 x 374 M had inflated B_q by 24 GB)
+    n_parts = max(1, int(acc_cn.get("index_parts", 0)))
+    L = float((t_lens if a.inverse else q_lens).sum()); M = world * acc_cn.get("query_minimizers", 0) / K / n_parts; H = world * acc_cn.get("anchors", 0) / K
+    B_q = L / 4 + 32 * M + 8 * H + 32 * H + 4 * Qn
+    B_idx = float((q_lens if a.inverse else t_lens).sum()) / 4 + 16 * st["n_minimizers"]
+    e2e_gbps = (B_q + B_idx) / (ms_per_step * 1e-3) / 1e9
+    whole_path = {"what": "SURVEY 8(d), strictly: sum over queries of B_q = L/4 + 32 M + 40 H + 4, plus B_idx = L_T/4 + 16 M_T, over the step's wall time; "
+                          "ordering (every radix pass) counts as ZERO algorithmic bytes",
+                  "alg_GB_per_step": (B_q + B_idx) / 1e9, "B_q_GB": B_q / 1e9, "B_idx_GB": B_idx / 1e9, "alg_GBps": e2e_gbps, "peak_GBps": HBM_PEAK_GBPS,
+                  "frac": e2e_gbps / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": e2e_gbps / 6290.0,
+                  "streamed_minimizers": M, "anchors": H, "index_minimizers": st["n_minimizers"], "index_parts": n_parts}
+    r_dom = cands[0] if cands else {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 0.0, "traffic": None}
+    return r_dom, cands[1:], fams, whole_path, e2e_gbps

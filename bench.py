@@ -72,7 +72,7 @@ def parse():
     return ap.parse_args()
 
 
-from lrge_amd.benchlib import (HBM_PEAK_GBPS, cpu_baseline, cpu_baseline_sampled, committed_traffic, roofline_blocks,  # noqa: E402
+from benchlib import (HBM_PEAK_GBPS, cpu_baseline, cpu_baseline_sampled, committed_traffic, roofline_blocks,  # noqa: E402
                                emulate_world)
 
 
@@ -292,11 +292,21 @@ def main():
                 est_all = ctx.estimates(counts, q_lens, float(avg_t), Tn, 100)
             else:
                 _ta = time.perf_counter()
-                Td = ctx.upload(src_t, ts.offsets, ts.rank, wait=False)      # K0 pack (and PCIe, from the host) on the copy stream
-                _tb = time.perf_counter()
-                Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)      # travels / packs while the index is built
-                if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
-                    Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
+                qshard = self.tshard and not os.environ.get("LRGE_BENCH_NO_QSHARD")
+                if qshard:
+                    # target-sharded form (round 6): every rank maps ALL queries, but sketches only ITS share of them -- the queries travel
+                    # first (they are the small set), each rank runs K1 over its share while its targets travel, the minimizers are
+                    # all-gathered (lrge_hip_seqset_presketch_sharded: 16 B each, once per step and world instead of a sketch per rank)
+                    Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)
+                    _tb = time.perf_counter()
+                    Td = ctx.upload(src_t, ts.offsets, ts.rank, wait=False)
+                    Qd.presketch_sharded(preset, comm)
+                else:
+                    Td = ctx.upload(src_t, ts.offsets, ts.rank, wait=False)      # K0 pack (and PCIe, from the host) on the copy stream
+                    _tb = time.perf_counter()
+                    Qd = ctx.upload(src_q, qs.offsets, qs.rank, wait=False)      # travels / packs while the index is built
+                    if not os.environ.get("LRGE_BENCH_NO_PRESKETCH"):
+                        Qd.presketch(preset)     # the queries are sketched beside the index's sort / table passes (still once per step)
                 _tr = os.environ.get("LRGE_BENCH_TRACE") and self.my == 0 and comm is not None
 
                 def _busy():        # (trace only) flush the turn so that busy_ms is current
@@ -477,8 +487,9 @@ def main():
                        "clock": "host" if clock_host else "resident",
                        "query_reads": Qn, "target_reads": Tn,
                        "parallelism": ("one job, streamed targets cut into %d ranges by bases; query index replicated; counts all-reduced" % world) if a.inverse else
-                                      ("one job, TARGETS cut into %d ranges by bases: every rank indexes its range and maps all queries; occurrence statistics made "
-                                       "global by one all-to-all of (key, count) pairs; the count vectors all-reduced" % world) if job.tshard else
+                                      ("one job, TARGETS cut into %d ranges by bases: every rank indexes its range and maps all queries (sketched once per world: every "
+                                       "rank sketches 1/%d of them, the minimizers all-gathered); occurrence statistics made "
+                                       "global by one all-to-all of (key, count) pairs; the count vectors all-reduced" % (world, world)) if job.tshard else
                                       ("one job, queries cut into %d ranges by bases; the WHOLE target index built on every rank (north_star's literal form: "
                                        "replicated index, one gather of the estimates)" % world) if job.replicated else
                                       ("one job, queries cut into %d ranges by bases; index %s" %

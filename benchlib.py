@@ -1,4 +1,4 @@
-"""benchlib -- the legs of bench.py that are not the timed step: the CPU baseline (the oracle port timed on the host cores, test
+"""benchlib (beside bench.py, NOT part of the product package lrge_amd: it imports the oracle) -- the legs of bench.py that are not the timed step: the CPU baseline (the oracle port timed on the host cores, test
 infrastructure used as the reported baseline only), the committed rocprofv3 counter figures the roofline block quotes, and the
 world-of-N emulation on one GPU (every rank timed alone: a projection input, never a bench result).  bench.py keeps the argument
 parser, the job of one rank and the timed region."""
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
 def cpu_baseline(q, t, budget_s, preset):

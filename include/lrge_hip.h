@@ -323,6 +323,16 @@ int  lrge_hip_median(const float *estimates, uint64_t n, int finite, int has_low
    next lrge_hip_overlap_* call that streams `s` against an index of the same preset consumes the result (once); any
    other use simply sketches in line.  LRGE_HIP_NO_PRESKETCH=1 ignores the hint. */
 int  lrge_hip_seqset_presketch(lrge_hip_ctx *ctx, lrge_hip_seqset *s, int preset);
+/* The streamed set's sketch made ONCE per world instead of once per rank (round 6; the target-sharded forward strategy above has
+   every rank map ALL queries, so every rank used to sketch all of them).  Collective: every rank of `comm` passes the SAME read set
+   (same reads, same order: the ranks cut it by bases from the lengths they all hold); rank r runs mm_sketch (mm2:sketch.c, called per
+   query by mm2:map.c collect_minimizers under Aligner::map, aligner.rs:231-241; twoset.rs:266-334 maps the queries independently of
+   each other, so where a query is sketched is free) over its share only and the minimizers are all-gathered -- 16 bytes each, in read
+   order, exactly the stream one rank's sketch of the whole set yields.  The result is attached to `s` like lrge_hip_seqset_presketch's
+   and consumed (once) by the next lrge_hip_overlap_* call that streams `s` against an index of the same preset.  A failure on one rank
+   fails the call on every rank (it ends with an agreement).  Sets of 2^32 bases or more: LRGE_ERR_TOO_MANY (they are streamed in views
+   and sketched per view). */
+int  lrge_hip_seqset_presketch_sharded(lrge_hip_ctx *ctx, lrge_hip_seqset *s, int preset, lrge_hip_comm *comm);
 
 /* Host only: the k distinct indices in [0, n) that liblrge's sub-sampling draws (lib.rs:189-204), in the order
    rand 0.9.4's index::sample returns them (split_into_hashsets, twoset.rs:632-652, takes the LAST target_num_reads

@@ -21,7 +21,7 @@ C_NAMES = ["query_bases", "query_minimizers", "anchors", "groups", "groups_chain
 EXPORTS = [
     "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error", "lrge_hip_ctx_set_option",
     "lrge_hip_seqset_upload", "lrge_hip_seqset_upload_async", "lrge_hip_seqset_wait", "lrge_hip_host_alloc",
-    "lrge_hip_host_free", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch",
+    "lrge_hip_host_free", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch", "lrge_hip_seqset_presketch_sharded",
     "lrge_hip_index_build", "lrge_hip_index_build_for", "lrge_hip_index_build_sharded", "lrge_hip_index_build_tsharded", "lrge_hip_last_shard_stats", "lrge_hip_index_free",
     "lrge_hip_comm_alltoallv", "lrge_hip_comm_rccl_ranks", "lrge_hip_comm_local_group_serialize", "lrge_hip_comm_local_turn",
     "lrge_hip_comm_busy_ms",
@@ -83,6 +83,7 @@ def lib():
     L.lrge_hip_seqset_size.argtypes = [vp]
     L.lrge_hip_seqset_size.restype = C.c_uint32
     L.lrge_hip_seqset_presketch.argtypes = [vp, vp, C.c_int]
+    L.lrge_hip_seqset_presketch_sharded.argtypes = [vp, vp, C.c_int, vp]
     L.lrge_hip_index_build.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
     L.lrge_hip_index_build_for.argtypes = [vp, vp, C.c_int, vp, vp, C.POINTER(vp)]
     L.lrge_hip_index_build_sharded.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_int, vp, vp, C.POINTER(vp)]

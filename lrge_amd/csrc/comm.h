@@ -408,3 +408,62 @@ static int comm_alltoallv(lrge_hip_comm *c, const void *dsend, const u64 *soff, 
     HIPCHK(ctx, hipStreamSynchronize(st));      // (`allh` is a local)
     return LRGE_OK;
 }
+
+// Variable-size all-gather between DEVICE buffers: rank r contributes `n_mine` elements of `esz` bytes, which land at element
+// roff[r] of `drecv` on every rank (roff: world + 1 prefix sums of the contributions, known to every rank: the caller has
+// all-gathered the counts).  Ordered on `st`.  Same three transports as comm_alltoallv: RCCL = one send / receive pair per peer
+// inside a group (every pair has its own xGMI link; ncclAllGather wants equal sizes), local = a barrier and device-to-device
+// copies out of the other ranks' buffers, host callbacks = an all-gather of the buffers padded to the longest one.
+static int comm_allgatherv(lrge_hip_comm *c, const void *dsend, void *drecv, const u64 *roff, size_t esz, hipStream_t st) {
+    lrge_hip_ctx *ctx = c->ctx;
+    COMM_LIVE(c);
+    const int W = c->world, me = c->rank;
+    const u64 n_mine = roff[me + 1] - roff[me];
+    if (W == 1 || c->nccl) {
+        if (W > 1) {
+            NCCLCHK(ctx, g_rccl.GroupStart());
+            int gerr = 0;      // (a failed Send / Recv must not leave the group open on this thread)
+            for (int p = 0; p < W && !gerr; ++p) {
+                if (p == me) continue;
+                const u64 nr = roff[p + 1] - roff[p];
+                if (n_mine) gerr = g_rccl.Send(dsend, n_mine * esz, LRGE_NCCL_UINT8, p, c->nccl, st);
+                if (nr && !gerr) gerr = g_rccl.Recv((char *)drecv + roff[p] * esz, nr * esz, LRGE_NCCL_UINT8, p, c->nccl, st);
+            }
+            const int gend = g_rccl.GroupEnd();
+            if (gerr || gend) {
+                LRGE_SET_ERR(ctx, "RCCL error %s in the all-gather's send / receive group", g_rccl.GetErrorString ? g_rccl.GetErrorString(gerr ? gerr : gend) : "?");
+                return LRGE_ERR_DEVICE;
+            }
+        }
+        if (n_mine) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[me] * esz, dsend, n_mine * esz, hipMemcpyDeviceToDevice, st));
+        return LRGE_OK;
+    }
+    if (c->grp) {
+        LocalGroup *g = c->grp;
+        HIPCHK_GRP(c, hipStreamSynchronize(st));                   // my buffer is complete before anybody reads it
+        g->slot[(size_t)me] = dsend;
+        if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
+        for (int s = 0; s < W; ++s) {
+            const u64 n = roff[s + 1] - roff[s];
+            if (n) HIPCHK_GRP(c, hipMemcpyAsync((char *)drecv + roff[s] * esz, g->slot[(size_t)s], n * esz, hipMemcpyDefault, st));
+        }
+        HIPCHK_GRP(c, hipStreamSynchronize(st));
+        if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }   // everybody has read: the buffers may change
+        return LRGE_OK;
+    }
+    // host callbacks: all-gather of the buffers padded to the longest contribution
+    u64 mx = 0;
+    for (int r = 0; r < W; ++r) mx = std::max(mx, roff[r + 1] - roff[r]);
+    if (mx == 0) return LRGE_OK;
+    const size_t blk = (size_t)mx * esz;
+    std::vector<char> sendh(blk, 0), allh(blk * (size_t)W);
+    if (n_mine) HIPCHK(ctx, hipMemcpyAsync(sendh.data(), dsend, n_mine * esz, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (c->cb_allgather(c->cb_user, sendh.data(), blk, allh.data()) != 0) { LRGE_SET_ERR(ctx, "host communicator: all-gather callback failed"); return LRGE_ERR_DEVICE; }
+    for (int s = 0; s < W; ++s) {
+        const u64 n = roff[s + 1] - roff[s];
+        if (n) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[s] * esz, allh.data() + blk * (size_t)s, n * esz, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));      // (`allh` is a local)
+    return LRGE_OK;
+}

@@ -281,7 +281,9 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             skey = rk; spos = rk;
             sc.drop(rk == so.x ? k1 : so.x);
         } else {
-            ALLOC_OR_FAIL(v1, sc, u64, M + 1);
+            // (v1, the second buffer of the pair layout, is taken by the branches that sort pairs only: on the SEGW path -- the default
+            // at H. sapiens scale -- it would be 27 GB of transient peak beside the 24 B per entry that path needs)
+            u64 *v1 = nullptr;
             // the pair layout, segment-packed (k_prims.h: index_sort_segpacked): behind the first digit the low hash byte is implied
             // and the rest of the entry fits one word -- fewer bytes through the remaining passes, 8 bytes per entry resident
             const u32 yb_p = pk_rid + pk_pos1;
@@ -296,7 +298,6 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
                 // (nothing to sort: an empty pair stream is an empty SEGW stream)
             } else if (so.segw) {
                 // (the sketch already wrote what pass A wants: decided above, whatever M turned out to be)
-                sc.drop(v1); v1 = nullptr;
                 u32 *d1 = sc.get<u32>(M + 1);
                 if (!d1) return LRGE_ERR_DEVICE;
                 u64 *rk = nullptr;
@@ -308,6 +309,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
                 skey = rk; spos = rk;
                 sc.drop(rk == so.x ? k1 : so.x); sc.drop((u32 *)so.y); sc.drop(d1);
             } else if (pass_from == 0 && extra_ok && 2 * P.k > 16 && !ctx->opt("NO_SEG_PACK") && M >= ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22)) {
+                v1 = sc.get<u64>(M + 1); if (!v1) return LRGE_ERR_DEVICE;
                 u64 *rk = nullptr;
                 rc = index_sort_segpacked(ctx, sc, so.x, so.y, k1, v1, M, 2 * P.k, yb_p, pk_pos1, extra, &rk, &d_seg_start);
                 if (rc) return rc;
@@ -317,6 +319,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
                 skey = rk; spos = rk;
                 sc.drop(rk == so.x ? so.y : so.x); sc.drop(k1); sc.drop(v1);
             } else {
+            v1 = sc.get<u64>(M + 1); if (!v1) return LRGE_ERR_DEVICE;
             u64 *rk, *rv;
             rc = radix_sort_pairs(ctx, sc, so.x, so.y, k1, v1, M, 0, 2 * P.k, &rk, &rv, /*reverse_digits=*/true, nullptr, 0, pass_from, -1);   // see k_index.h
             if (rc) return rc;

@@ -36,6 +36,8 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
         u32 q1 = q0; u64 A = 0;
         while (q1 < q_end && (q1 - q0) < (1u << std::min<u32>(R.max_bits_q, 24)) && (q1 == q0 || A + R.h_qtot[q1] <= R.batch_cap)) { A += R.h_qtot[q1]; ++q1; }
         if (A >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "query %u alone yields %llu anchors (limit 2^32)", q0, (unsigned long long)A); return done(LRGE_ERR_TOO_MANY); }
+        u64 cn_before[LRGE_C_N];                   // (a batch that is retried in halves must leave no trace in the counters: ADVICE r05 -- anchors_kept
+        memcpy(cn_before, ctx->counters, sizeof cn_before);   //  was added before the allocation that failed, and the bench's figures derive from it)
         ctx->counters[LRGE_C_BATCHES] += 1;
         R.kl.bits_q = std::max<u32>(1, ceil_log2_u64((u64)(q1 - q0)));
         R.cp.kl = R.kl; R.cp.q0 = q0;
@@ -46,7 +48,7 @@ static int run_overlap(lrge_hip_ctx *ctx, const lrge_hip_index *ix, const lrge_h
             // needs no memory), so drain both streams, give idle segments back and take the same queries in smaller batches.
             (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); (void)hipGetLastError();
             ctx->pool.trim();
-            ctx->counters[LRGE_C_BATCHES] -= 1; ctx->counters[LRGE_C_ANCHORS] -= A;
+            memcpy(ctx->counters, cn_before, sizeof cn_before);
             R.batch_cap = std::max<u64>(A / 2, 1024);
             ++shrinks;
             if (ctx->opt("VERBOSE")) fprintf(stderr, "[lrge_hip] batch of %llu anchors did not fit (%s): batches of at most %llu from here\n", (unsigned long long)A, ctx->err.c_str(), (unsigned long long)R.batch_cap);

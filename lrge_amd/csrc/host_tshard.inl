@@ -61,7 +61,9 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
     std::vector<u64> s_off((size_t)W + 1, 0), r_off((size_t)W + 1, 0);
     for (int d = 0; d < W; ++d) { s_off[(size_t)d + 1] = s_off[(size_t)d] + mine[(size_t)d]; r_off[(size_t)d + 1] = r_off[(size_t)d] + matrix[(size_t)d * row + (size_t)me]; }
     const u64 n_s = s_off[(size_t)W], n_r = r_off[(size_t)W];
-    const u64 ss[8] = {0, 0, 0, 0, n_s - mine[(size_t)me], n_r - mine[(size_t)me], (u64)8 | (u64)8 << 8, 0};      // (hashes_sent / _recv slots: pairs of 8 bytes)
+    // (hashes_sent / _recv slots: pairs of 8 bytes; the minimizers a sharded presketch of this step's streamed set moved stay in the entries slots)
+    const bool qs = ctx->qshard_fresh; ctx->qshard_fresh = false;
+    const u64 ss[8] = {0, 0, qs ? ctx->shard_stats[2] : 0, qs ? ctx->shard_stats[3] : 0, n_s - mine[(size_t)me], n_r - mine[(size_t)me], (u64)(qs ? 16 : 8) | (u64)8 << 8, 0};
     memcpy(ctx->shard_stats, ss, sizeof ss);
     // ---- A1, C2, C3: the pairs travel ----
     u64 *sh = nullptr, *rh = nullptr;
@@ -147,12 +149,13 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
     }
     if (thres < P.min_mid_occ) thres = P.min_mid_occ;
     if (P.max_mid_occ > P.min_mid_occ && thres > P.max_mid_occ) thres = P.max_mid_occ;
-    const u32 mid_occ = (u32)thres;
+    // (tests: DEBUG_TS_MID_OCC forces the threshold -- on every rank alike -- so that tiny clean data has too-frequent keys at all)
+    const u32 mid_occ = (u32)ctx->opt_u64("DEBUG_TS_MID_OCC", (u64)thres);
     // ---- C5, A2, C6, A3: the too-frequent keys go to everybody ----
     // the list starts at 2^16 keys (mid_occ_frac = 2 x 10^-4 of the keys an owner holds: thousands at H. sapiens scale); an owner with
     // more -- a repeat-rich set -- takes a list of exactly that many and lists again (round 5: was a fixed 32 MB block and a hard
     // limit of 2^22 keys)
-    u32 cap_list = (u32)std::min<u64>(std::max<u64>(n_r, 1), 1u << 16);
+    u32 cap_list = (u32)std::min<u64>(std::max<u64>(n_r, 1), ctx->opt_u64("DEBUG_TS_LIST_CAP", 1u << 16));
     u64 *d_list = nullptr; u32 *d_nf = nullptr;
     std::vector<u64> mine2(2, 0), all2((size_t)2 * W, 0);
     cg.expect(CollectiveGuard::ALLGATHER_U64, 2, 1);
@@ -192,17 +195,23 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
     cg.expect(CollectiveGuard::AGREE);
     auto tail = [&]() -> int {
         if (max_nf) {
+            // everything that can fail on this rank alone between C5 and A2 -- the re-taken list, the room for everybody's lists, the
+            // counts' copy -- lands in `arc`: a rank ALWAYS enters A2 before A3 when max_nf != 0 (a rank that returned from
+            // here went straight to A3 while its peers sat in A2, and over RCCL / host callbacks they would have waited for ever)
+            int arc = LRGE_OK;
             // (the all-gather reads max_nf words of EVERY rank's list: a list that is shorter is re-taken at that size)
             if (cap_list < max_nf) {
-                u64 *bigger = sc.get<u64>(max_nf);
-                if (!bigger) return LRGE_ERR_DEVICE;
-                if (mine2[0]) HIPCHK(ctx, hipMemcpyAsync(bigger, d_list, mine2[0] * 8, hipMemcpyDeviceToDevice, st));
-                d_list = bigger;
+                u64 *bigger = shard_fail_at(ctx, 17) ? nullptr : sc.get<u64>(max_nf);
+                if (!bigger) arc = LRGE_ERR_DEVICE;
+                else {
+                    if (mine2[0] && hipMemcpyAsync(bigger, d_list, mine2[0] * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipGetLastError(); LRGE_SET_ERR(ctx, "target-sharded index build: copying the list of too-frequent keys failed"); arc = LRGE_ERR_DEVICE; }
+                    d_list = bigger;
+                }
             }
-            u64 *d_all = sc.get<u64>(max_nf * (u64)W);
+            u64 *d_all = arc == LRGE_OK ? sc.get<u64>(max_nf * (u64)W) : nullptr;
             std::vector<u32> nof(TS_MAX_WORLD, 0);
             for (int r = 0; r < W; ++r) nof[(size_t)r] = (u32)all2[(size_t)2 * r];
-            int arc = d_all ? LRGE_OK : LRGE_ERR_DEVICE;
+            if (!d_all) arc = LRGE_ERR_DEVICE;
             if (d_all && hipMemcpyAsync(d_nf + 1, nof.data(), TS_MAX_WORLD * 4, hipMemcpyHostToDevice, st) != hipSuccess) arc = LRGE_ERR_DEVICE;
             if (d_all && hipStreamSynchronize(st) != hipSuccess) arc = LRGE_ERR_DEVICE;
             if (shard_fail_at(ctx, 15)) arc = LRGE_ERR_DEVICE;

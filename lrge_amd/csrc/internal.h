@@ -201,6 +201,7 @@ struct lrge_hip_ctx {
     struct PreSketch *presk_prepared = nullptr; struct lrge_hip_seqset *presk_prepared_set = nullptr;   // memory taken, kernels not yet queued
     int timer_level = 1;                     // see StageTimer
     u64 shard_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last sharded index build (lrge_hip_last_shard_stats)
+    bool qshard_fresh = false;               // lrge_hip_seqset_presketch_sharded has just left its exchange volumes in shard_stats: the target-sharded build that follows keeps them
     u64 part_hint_total = 0, part_hint_bases = 0; int part_hint_preset = -1;   // the part size a build of this job had to fall back to (lrge_hip_index_build)
     double kept_ratio = 0.5; bool kept_seen = false;   // survivors per seed hit of the dead-pair filter in this context's recent batches (the batch planner's memory estimate)
     bool ts_build = false;                   // inside lrge_hip_index_build_tsharded: a partitioned local index leaves its occurrence statistics to the collective pass

@@ -39,6 +39,14 @@ struct StCfg {
     static_assert(HPC || NARROW, "the non-HPC form is written for 2k <= 32");
     static_assert(LW <= 32 && W <= 8 && K >= W, "window extraction is one 32-bit funnel");
     using XT = typename std::conditional<NARROW, u32, u64>::type;
+    // The non-HPC form reads its code stream straight out of s_w (u64[NWORDS + 2] seen as dwords) and its ambiguity stream out of
+    // s_m (u32[NWORDS + 2]), with NO slack: the funnel of the last step (q = NSTEPS - 1) fetches dwords d .. d + 2 of the former and
+    // d .. d + 1 of the latter.  Tie the array sizes to those reads, so that another ST_G / SK_CHUNK / HF / K fails to compile
+    // instead of reading past the arrays.
+    static constexpr int C_LAST = (2 * (NSTEPS - 1 - K + 1 + 32)) / 32 + 2;      // largest dword index the k-mer funnel reads
+    static constexpr int N_LAST = (NSTEPS - 1 - LW + 1 + 32) / 32 + 1;           // ... and the valid-step funnel
+    static_assert(HPC || C_LAST < 2 * (NWORDS + 2), "non-HPC code stream: s_w is too short for the last step's funnel");
+    static_assert(HPC || N_LAST < NWORDS + 2, "non-HPC ambiguity stream: s_m is too short for the last step's funnel");
 };
 
 template <typename XT> __device__ __forceinline__ XT st_none() { return (XT)~(XT)0; }

@@ -212,6 +212,7 @@ extern "C" int lrge_hip_last_counters(const lrge_hip_ctx *ctx, uint64_t c[LRGE_C
 #include "host_index_build.inl"
 #include "host_index_parts.inl"
 #include "host_tshard.inl"
+#include "host_qshard.inl"
 #include "host_overlap_seeds.inl"
 #include "host_overlap_batch.inl"
 #include "host_overlap_api.inl"

@@ -181,6 +181,11 @@ class SeqSet:
         own sort and table passes; the next overlap call that streams the set uses it (lrge_hip_seqset_presketch)."""
         self.ctx._check(self.ctx._lib.lrge_hip_seqset_presketch(self.ctx.h, self.h, preset))
 
+    def presketch_sharded(self, preset, comm):
+        """Collective (every rank of `comm` holds the SAME set): this rank sketches its share of the reads, the minimizers are
+        all-gathered, the next overlap call that streams the set uses them (lrge_hip_seqset_presketch_sharded)."""
+        self.ctx._check(self.ctx._lib.lrge_hip_seqset_presketch_sharded(self.ctx.h, self.h, preset, comm.h))
+
     def sketch(self, preset):
         n = C.c_uint64()
         self.ctx._check(self.ctx._lib.lrge_hip_sketch_dump(self.ctx.h, self.h, preset, None, None, 0, C.byref(n)))
@@ -210,8 +215,10 @@ class Index:
             self.build_counters = ctx.counters()
             a = (C.c_uint64 * 8)()
             ctx._lib.lrge_hip_last_shard_stats(ctx.h, C.byref(a))
-            self.shard_stats = dict(keyset_bytes=0, entries_sketched=0, entries_sent=0, entries_recv=0, hashes_sent=int(a[4]), hashes_recv=int(a[5]),
-                                    entry_bytes=8, entries_kept=0, hash_bytes=8)      # (hashes_*: (key, count) pairs, one 8-byte word each)
+            # (hashes_*: (key, count) pairs, one 8-byte word each; entries_*: the 16-byte minimizers a sharded presketch of the streamed
+            # set moved just before this build -- lrge_hip_seqset_presketch_sharded -- else 0)
+            self.shard_stats = dict(keyset_bytes=0, entries_sketched=0, entries_sent=int(a[2]), entries_recv=int(a[3]), hashes_sent=int(a[4]), hashes_recv=int(a[5]),
+                                    entry_bytes=int(a[6]) & 0xFF or 8, entries_kept=0, hash_bytes=8)
             return
         if shard is not None:
             lens = np.ascontiguousarray(shard[0], dtype=np.uint32)

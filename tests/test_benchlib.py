@@ -1,9 +1,9 @@
-"""bench.py's helper legs that run without a GPU (lrge_amd/benchlib.py): the committed rocprofv3 counter figures the roofline block
+"""bench.py's helper legs that run without a GPU (benchlib.py at the repo root): the committed rocprofv3 counter figures the roofline block
 quotes must be those of the SAME configuration, strategy and preset -- never a neighbour's."""
 import json
 import os
 
-from lrge_amd import benchlib
+import benchlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -90,11 +90,13 @@ def _run_world(world, ds, preset, mode):
             c = engine.Context(0)
             comm = grp.comm(c, r)
             lo, hi = bounds[r], bounds[r + 1]
-            if mode == "tshard":       # forward with the TARGETS sharded: every rank maps ALL queries against its share; counts add up
+            if mode in ("tshard", "tshard_q"):       # forward with the TARGETS sharded: every rank maps ALL queries against its share; counts add up
                 t0, t1 = tb[r], tb[r + 1]
                 tsub = ds.t.slice(t0, t1)
                 Td = c.upload(tsub.bases, tsub.offsets, tr[t0:t1])
                 Qd = c.upload(ds.q.bases, ds.q.offsets, qr)
+                if mode == "tshard_q":  # ... and sketches only ITS share of them: the minimizers are all-gathered (round 6)
+                    Qd.presketch_sharded(preset, comm)
                 ix = engine.Index(c, Td, preset, comm=comm, tshard=True)
                 shard_stats.append(ix.shard_stats)
                 counts, has = ix.overlap_twoset(Qd)
@@ -212,6 +214,75 @@ def test_world_of_threads_target_sharded(ctx, tiny_ont, tiny_hifi, preset, layou
         assert np.array_equal(e.view(np.uint32), est.view(np.uint32))
     ss = _run_world.shard_stats
     assert len(ss) == world and sum(x["hashes_sent"] for x in ss) == sum(x["hashes_recv"] for x in ss)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("layout", ["packed", "parts"])
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_world_of_threads_target_sharded_with_sharded_query_sketch(ctx, tiny_ont, tiny_hifi, preset, layout, world, monkeypatch):
+    """lrge_hip_seqset_presketch_sharded (round 6) in front of the target-sharded build: rank r sketches the r-th share of the queries,
+    the minimizers are all-gathered, every rank maps ALL queries from that one sketch -- the same counts, has_mapping, estimates and
+    statistics as the single-GPU run, on every rank; worlds of 2, 3 and 8 (8 ranks over 60 tiny queries: uneven and near-empty shares),
+    both presets, one index and a partitioned one per rank.  The exchange volumes add up: every minimizer of the set is sent by its
+    one sketcher to the world - 1 others."""
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    if layout == "parts":
+        monkeypatch.setenv("LRGE_HIP_PART_BASES", str(int(ds.t.lens().sum()) // (world * 3)))
+    Qd, Td, counts, has, st = _single(ctx, ds, PRESETS[preset])
+    qx, _ = Qd.sketch(PRESETS[preset])
+    avg_t = np.float32(ds.t.lens().sum()) / np.float32(ds.t.n)
+    est = ctx.estimates(counts, ds.q.lens(), float(avg_t), ds.t.n, 100)
+    out, _ = _run_world(world, ds, PRESETS[preset], "tshard_q")
+    for r, (c, h, s, e) in enumerate(out):
+        assert s == st, (r, s, st)
+        assert np.array_equal(c, counts) and np.array_equal(h, has)
+        assert np.array_equal(e.view(np.uint32), est.view(np.uint32))
+    ss = _run_world.shard_stats
+    assert len(ss) == world and ss[0]["entry_bytes"] == 16
+    assert sum(x["entries_recv"] for x in ss) == (world - 1) * len(qx) == sum(x["entries_sent"] for x in ss)
+
+
+@pytest.mark.parametrize("stage", [20, 21, 22, "alloc"])
+@pytest.mark.parametrize("bad_rank", [0, 2])
+def test_a_failing_rank_fails_the_sharded_query_sketch(ctx, tiny_ont, stage, bad_rank):
+    """The contract of every collective call here, for lrge_hip_seqset_presketch_sharded: a rank failing in front of its share's
+    sketch, at the receive buffers or behind the all-gathers joins the next collective in its shape with the status word set -- over
+    the strict host-callback transport and the local one every rank gets an error, nobody hangs, no mismatched collective."""
+    from lrge_amd import _ffi, engine, parallel
+    ds, world = tiny_ont, 3
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    for make in (lambda: parallel.ThreadHostGroup(world, timeout=60.0), lambda: parallel.LocalGroup(world)):
+        grp = make()
+        res = [None] * world
+
+        def rank_main(r):
+            c = engine.Context(0)
+            comm = grp.comm(c, r)
+            try:
+                Qd = c.upload(ds.q.bases, ds.q.offsets, qr)
+                if r == bad_rank:
+                    if stage == "alloc":
+                        c.set_option("DEBUG_ALLOC_FAIL_ALWAYS", "1")
+                    else:
+                        c.set_option("DEBUG_SHARD_FAIL_AT", str(stage))
+                Qd.presketch_sharded(0, comm)
+                res[r] = "sketched"
+            except _ffi.LrgeHipError as e:
+                res[r] = "error: %s" % e
+            finally:
+                c.set_option("DEBUG_ALLOC_FAIL_ALWAYS", None); c.set_option("DEBUG_SHARD_FAIL_AT", None)
+                comm.close(); c.close()
+        th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=180)
+        assert all(not t.is_alive() for t in th), "a rank is still blocked in a collective"
+        assert all(isinstance(x, str) and x.startswith("error") for x in res), res
+        if isinstance(grp, parallel.ThreadHostGroup):
+            assert not grp.faults, grp.faults
+            assert grp.log[0] == grp.log[1] == grp.log[2], grp.log
+        grp.close()
 
 
 def test_target_sharded_global_mid_occ_matters(ctx, oracle, monkeypatch):
@@ -392,13 +463,16 @@ def test_a_failing_rank_fails_the_sharded_build_on_every_transport(ctx, tiny_ont
         grp.close()
 
 
-@pytest.mark.parametrize("stage", [10, 11, 12, 13, 14, 15, 16, "alloc"])
+@pytest.mark.parametrize("stage", [10, 11, 12, 13, 14, 15, 16, 17, "alloc"])
 @pytest.mark.parametrize("bad_rank", [0, 2])
 def test_a_failing_rank_fails_the_target_sharded_build(ctx, tiny_ont, stage, bad_rank):
     """The same contract for lrge_hip_index_build_tsharded: a rank failing before the local build, in the counting pass, at the
     exchange buffers, in front of the statistics, at the list of too-frequent keys or its gathering joins the next collective in
     its shape with the status word set -- over the strict host-callback transport and the local one every rank gets an error,
-    nobody hangs, no mismatched collective, the same sequence of collectives on every rank."""
+    nobody hangs, no mismatched collective, the same sequence of collectives on every rank.
+    Stage 17: the re-taken list of too-frequent keys -- a rank whose own list is shorter than the longest one takes a
+    larger block between C5 and A2; its failure must travel through A2 like every other one.  Clean tiny data has no too-frequent
+    key and lists far below the first capacity, so every rank runs with the threshold forced to 1 and a first capacity of 1."""
     from lrge_amd import _ffi, engine, parallel
     ds, world = tiny_ont, 3
     qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
@@ -413,6 +487,8 @@ def test_a_failing_rank_fails_the_target_sharded_build(ctx, tiny_ont, stage, bad
             try:
                 tsub = ds.t.slice(tb[r], tb[r + 1])
                 Td = c.upload(tsub.bases, tsub.offsets, tr[tb[r]:tb[r + 1]])
+                if stage == 17:
+                    c.set_option("DEBUG_TS_MID_OCC", "1"); c.set_option("DEBUG_TS_LIST_CAP", "1")
                 if r == bad_rank:
                     if stage == "alloc":
                         c.set_option("DEBUG_ALLOC_FAIL_ALWAYS", "1")
@@ -423,7 +499,8 @@ def test_a_failing_rank_fails_the_target_sharded_build(ctx, tiny_ont, stage, bad
             except _ffi.LrgeHipError as e:
                 res[r] = "error: %s" % e
             finally:
-                c.set_option("DEBUG_ALLOC_FAIL_ALWAYS", None); c.set_option("DEBUG_SHARD_FAIL_AT", None)
+                for o in ("DEBUG_ALLOC_FAIL_ALWAYS", "DEBUG_SHARD_FAIL_AT", "DEBUG_TS_MID_OCC", "DEBUG_TS_LIST_CAP"):
+                    c.set_option(o, None)
                 comm.close(); c.close()
         th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
         for t in th:

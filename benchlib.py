@@ -208,11 +208,12 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
             comm.turn(False)
             for it in range(max(1, a.warmup) + a.steps):
                 if it == max(1, a.warmup):
-                    comm.busy_ms(reset=True)
+                    comm.busy_ms(reset=True); comm.standin_ms(reset=True)
                 comm.turn(True)
                 out = job.step(src_q, src_t)
                 comm.turn(False)
             busy = comm.busy_ms() / a.steps
+            standin = comm.standin_ms() / a.steps
             counts, est_all, med, tb, tm, cn, st = out
             lo, hi = job.bounds[r], job.bounds[r + 1]
             mine = ref_counts if (a.inverse or job.tshard) else ref_counts[lo:hi]       # (inverse / target-sharded forward: the all-reduced vector)
@@ -222,7 +223,7 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
                 nd = int((counts != mine).sum()) if len(counts) == len(mine) else -1
                 detail = dict(counts_differ=nd, first=[int(x) for x in np.nonzero(counts != mine)[0][:8]] if nd > 0 else [], stats=st, ref_stats=ref_st,
                               estimates_equal=bool(np.array_equal(est_all.view(np.uint32), ref_est.view(np.uint32))))
-            res[r] = dict(rank=r, busy_ms_per_step=busy, results_equal_one_gpu=ok, mismatch=detail, streamed_reads_of_rank=hi - lo, shard=job.shard_stats,
+            res[r] = dict(rank=r, busy_ms_per_step=busy, standin_copy_ms_per_step=standin, results_equal_one_gpu=ok, mismatch=detail, streamed_reads_of_rank=hi - lo, shard=job.shard_stats,
                           work_last_step={k: int(cn.get(k, 0)) for k in ("batches", "lpg_split", "lpg_launches", "lpg_anchors", "chain_launches", "chain_anchors", "chain_glb_anchors",
                                                                          "groups_chained", "anchors", "anchors_kept", "query_minimizers", "index_parts")},
                           stage_ms={**{"index_" + k: round(v, 3) for k, v in tb.items() if v and k != "total"}, **{k: round(v, 3) for k, v in tm.items() if v}})
@@ -253,6 +254,9 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
         os._exit(1)
     grp.close()
     busy = max(r_["busy_ms_per_step"] for r_ in res)
+    # (the variable-size all-gather of the local transport copies device to device where a node's links deliver straight into HBM: that
+    # time is inside busy_ms AND the link model charges the same bytes, so the link-model projection takes it out first)
+    busy_net = max(r_["busy_ms_per_step"] - r_["standin_copy_ms_per_step"] for r_ in res)
     # link model: the all-gather of the key sets as a ring (per-link bound), the two all-to-alls point to point (every peer
     # has its own link; the slowest pair bounds the exchange)
     ss = [r_["shard"] for r_ in res if r_["shard"]]
@@ -277,7 +281,8 @@ def emulate_world(a, ctx0, RankJob, Qn, engine, parallel, device, q_lens_all, t_
                                    else "forward, queries sharded (target sketch sharded, restricted index per rank)"),
                       "one_gpu_ms_per_step": t_one, "max_rank_busy_ms_per_step": busy,
                       "projected_speedup_compute_only": t_one / busy,
-                      "projected_speedup_with_link_model": None if not link_ms else t_one / (busy + link_ms["keyset_allgather_ring_ms"] + link_ms["alltoall_ms"] + link_ms.get("count_allreduce_ring_ms", 0.0)),
+                      "max_rank_busy_minus_standin_copies_ms_per_step": busy_net,
+                      "projected_speedup_with_link_model": None if not link_ms else t_one / (busy_net + link_ms["keyset_allgather_ring_ms"] + link_ms["alltoall_ms"] + link_ms.get("count_allreduce_ring_ms", 0.0)),
                       "link_model": link_ms, "all_ranks_equal_one_gpu": all(r_["results_equal_one_gpu"] for r_ in res),
                       "exchange_bytes_total": None if not ss else {"keysets": N * (N - 1) * ss[0]["keyset_bytes"],
                                                                    "entries": sum(x["entries_sent"] for x in ss) * ss[0]["entry_bytes"],

@@ -306,6 +306,10 @@ int  lrge_hip_comm_rccl_ranks(const lrge_hip_comm *c, int *n);
 int  lrge_hip_comm_local_group_serialize(void *group, int on);
 int  lrge_hip_comm_local_turn(lrge_hip_comm *c, int begin);
 double lrge_hip_comm_busy_ms(lrge_hip_comm *c, int reset);
+/* (local groups) of that time, the part spent in the device-to-device copies that stand in for the link transfers of the
+   variable-size all-gather (lrge_hip_seqset_presketch_sharded): on a node the links deliver into HBM and no copy is paid, so a
+   projection takes busy - standin and adds the link model's time for the same bytes. */
+double lrge_hip_comm_standin_ms(lrge_hip_comm *c, int reset);
 
 /* per_read_estimate over n reads on the device (f32, no contraction). out[i] = +inf if counts[i]==0 */
 int  lrge_hip_estimates(lrge_hip_ctx *ctx, const uint32_t *counts, const uint32_t *read_lens,

@@ -24,7 +24,7 @@ EXPORTS = [
     "lrge_hip_host_free", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch", "lrge_hip_seqset_presketch_sharded",
     "lrge_hip_index_build", "lrge_hip_index_build_for", "lrge_hip_index_build_sharded", "lrge_hip_index_build_tsharded", "lrge_hip_last_shard_stats", "lrge_hip_index_free",
     "lrge_hip_comm_alltoallv", "lrge_hip_comm_rccl_ranks", "lrge_hip_comm_local_group_serialize", "lrge_hip_comm_local_turn",
-    "lrge_hip_comm_busy_ms",
+    "lrge_hip_comm_busy_ms", "lrge_hip_comm_standin_ms",
     "lrge_hip_comm_unique_id", "lrge_hip_comm_create", "lrge_hip_comm_local_group_create", "lrge_hip_comm_local_group_destroy",
     "lrge_hip_comm_create_local", "lrge_hip_comm_create_host", "lrge_hip_comm_destroy", "lrge_hip_comm_abort", "lrge_hip_comm_rank", "lrge_hip_comm_world",
     "lrge_hip_comm_allreduce_u32", "lrge_hip_comm_allgather", "lrge_hip_index_stats",
@@ -95,6 +95,8 @@ def lib():
     L.lrge_hip_comm_local_turn.argtypes = [vp, C.c_int]
     L.lrge_hip_comm_busy_ms.argtypes = [vp, C.c_int]
     L.lrge_hip_comm_busy_ms.restype = C.c_double
+    L.lrge_hip_comm_standin_ms.argtypes = [vp, C.c_int]
+    L.lrge_hip_comm_standin_ms.restype = C.c_double
     L.lrge_hip_comm_unique_id.argtypes = [vp]
     L.lrge_hip_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.lrge_hip_comm_local_group_create.argtypes = [C.c_int, C.POINTER(vp)]

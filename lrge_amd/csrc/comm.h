@@ -110,6 +110,7 @@ struct lrge_hip_comm {
     bool aborted = false;                // lrge_hip_comm_abort: every later collective of this communicator fails at once
     bool in_turn = false; double busy_ms = 0, t_acquired = 0, alloc_ms0 = 0;     // (serialized local groups)
     double wait_ms = 0;                   // wall time spent inside barriers of the local transport (waiting for the other ranks)
+    double standin_ms = 0;                // (local transport) time inside the device-to-device copies that stand in for link transfers of comm_allgatherv: part of busy_ms, reported beside it
 };
 
 static void comm_turn(lrge_hip_comm *c, bool begin) {
@@ -409,25 +410,30 @@ static int comm_alltoallv(lrge_hip_comm *c, const void *dsend, const u64 *soff, 
     return LRGE_OK;
 }
 
-// Variable-size all-gather between DEVICE buffers: rank r contributes `n_mine` elements of `esz` bytes, which land at element
-// roff[r] of `drecv` on every rank (roff: world + 1 prefix sums of the contributions, known to every rank: the caller has
-// all-gathered the counts).  Ordered on `st`.  Same three transports as comm_alltoallv: RCCL = one send / receive pair per peer
-// inside a group (every pair has its own xGMI link; ncclAllGather wants equal sizes), local = a barrier and device-to-device
-// copies out of the other ranks' buffers, host callbacks = an all-gather of the buffers padded to the longest one.
-static int comm_allgatherv(lrge_hip_comm *c, const void *dsend, void *drecv, const u64 *roff, size_t esz, hipStream_t st) {
+// Variable-size all-gather between DEVICE buffers, k arrays at once: of array j rank r contributes the elements that land at
+// [roff[r], roff[r + 1]) of g[j].recv on every rank (roff: world + 1 prefix sums of the contributions, in elements of esz bytes, known to
+// every rank: the caller has all-gathered the counts).  Ordered on `st`.  ONE synchronisation for all k arrays.  The three transports of
+// comm_alltoallv: RCCL = one send / receive pair per peer and array inside ONE group (every pair of GPUs has its own xGMI link;
+// ncclAllGather wants equal sizes), local = one barrier pair and device-to-device copies out of the other ranks' buffers (their
+// duration is kept in standin_ms: on a node the links deliver into HBM, there is no copy to pay), host callbacks = an all-gather of
+// the arrays padded to the longest contribution.
+struct GatherV { const void *send; void *recv; const u64 *roff; size_t esz; };
+static int comm_allgatherv(lrge_hip_comm *c, const GatherV *g, int k, hipStream_t st) {
     lrge_hip_ctx *ctx = c->ctx;
     COMM_LIVE(c);
     const int W = c->world, me = c->rank;
-    const u64 n_mine = roff[me + 1] - roff[me];
     if (W == 1 || c->nccl) {
         if (W > 1) {
             NCCLCHK(ctx, g_rccl.GroupStart());
             int gerr = 0;      // (a failed Send / Recv must not leave the group open on this thread)
-            for (int p = 0; p < W && !gerr; ++p) {
-                if (p == me) continue;
-                const u64 nr = roff[p + 1] - roff[p];
-                if (n_mine) gerr = g_rccl.Send(dsend, n_mine * esz, LRGE_NCCL_UINT8, p, c->nccl, st);
-                if (nr && !gerr) gerr = g_rccl.Recv((char *)drecv + roff[p] * esz, nr * esz, LRGE_NCCL_UINT8, p, c->nccl, st);
+            for (int j = 0; j < k && !gerr; ++j) {
+                const u64 n_mine = g[j].roff[me + 1] - g[j].roff[me];
+                for (int p = 0; p < W && !gerr; ++p) {
+                    if (p == me) continue;
+                    const u64 nr = g[j].roff[p + 1] - g[j].roff[p];
+                    if (n_mine) gerr = g_rccl.Send(g[j].send, n_mine * g[j].esz, LRGE_NCCL_UINT8, p, c->nccl, st);
+                    if (nr && !gerr) gerr = g_rccl.Recv((char *)g[j].recv + g[j].roff[p] * g[j].esz, nr * g[j].esz, LRGE_NCCL_UINT8, p, c->nccl, st);
+                }
             }
             const int gend = g_rccl.GroupEnd();
             if (gerr || gend) {
@@ -435,35 +441,48 @@ static int comm_allgatherv(lrge_hip_comm *c, const void *dsend, void *drecv, con
                 return LRGE_ERR_DEVICE;
             }
         }
-        if (n_mine) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[me] * esz, dsend, n_mine * esz, hipMemcpyDeviceToDevice, st));
+        for (int j = 0; j < k; ++j) {
+            const u64 n_mine = g[j].roff[me + 1] - g[j].roff[me];
+            if (n_mine && (const char *)g[j].send != (char *)g[j].recv + g[j].roff[me] * g[j].esz)
+                HIPCHK(ctx, hipMemcpyAsync((char *)g[j].recv + g[j].roff[me] * g[j].esz, g[j].send, n_mine * g[j].esz, hipMemcpyDeviceToDevice, st));
+        }
         return LRGE_OK;
     }
     if (c->grp) {
-        LocalGroup *g = c->grp;
-        HIPCHK_GRP(c, hipStreamSynchronize(st));                   // my buffer is complete before anybody reads it
-        g->slot[(size_t)me] = dsend;
+        LocalGroup *grp = c->grp;
+        HIPCHK_GRP(c, hipStreamSynchronize(st));                   // my buffers are complete before anybody reads them
+        grp->slot[(size_t)me] = g;
         if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }
+        const double t0 = DevPool::now_ms();
         for (int s = 0; s < W; ++s) {
-            const u64 n = roff[s + 1] - roff[s];
-            if (n) HIPCHK_GRP(c, hipMemcpyAsync((char *)drecv + roff[s] * esz, g->slot[(size_t)s], n * esz, hipMemcpyDefault, st));
+            const GatherV *gs = (const GatherV *)grp->slot[(size_t)s];
+            for (int j = 0; j < k; ++j) {
+                const u64 n = g[j].roff[s + 1] - g[j].roff[s];
+                char *dst = (char *)g[j].recv + g[j].roff[s] * g[j].esz;
+                if (n && dst != (const char *)gs[j].send) HIPCHK_GRP(c, hipMemcpyAsync(dst, gs[j].send, n * g[j].esz, hipMemcpyDefault, st));
+            }
         }
         HIPCHK_GRP(c, hipStreamSynchronize(st));
+        c->standin_ms += DevPool::now_ms() - t0;
         if (!grp_barrier(c)) { LRGE_SET_ERR(ctx, "local communicator: another rank failed"); return LRGE_ERR_DEVICE; }   // everybody has read: the buffers may change
         return LRGE_OK;
     }
-    // host callbacks: all-gather of the buffers padded to the longest contribution
-    u64 mx = 0;
-    for (int r = 0; r < W; ++r) mx = std::max(mx, roff[r + 1] - roff[r]);
-    if (mx == 0) return LRGE_OK;
-    const size_t blk = (size_t)mx * esz;
-    std::vector<char> sendh(blk, 0), allh(blk * (size_t)W);
-    if (n_mine) HIPCHK(ctx, hipMemcpyAsync(sendh.data(), dsend, n_mine * esz, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    if (c->cb_allgather(c->cb_user, sendh.data(), blk, allh.data()) != 0) { LRGE_SET_ERR(ctx, "host communicator: all-gather callback failed"); return LRGE_ERR_DEVICE; }
-    for (int s = 0; s < W; ++s) {
-        const u64 n = roff[s + 1] - roff[s];
-        if (n) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[s] * esz, allh.data() + blk * (size_t)s, n * esz, hipMemcpyHostToDevice, st));
+    // host callbacks: per array, an all-gather of the buffers padded to the longest contribution
+    for (int j = 0; j < k; ++j) {
+        u64 mx = 0;
+        for (int r = 0; r < W; ++r) mx = std::max(mx, g[j].roff[r + 1] - g[j].roff[r]);
+        if (mx == 0) continue;
+        const size_t esz = g[j].esz, blk = (size_t)mx * esz;
+        const u64 n_mine = g[j].roff[me + 1] - g[j].roff[me];
+        std::vector<char> sendh(blk, 0), allh(blk * (size_t)W);
+        if (n_mine) HIPCHK(ctx, hipMemcpyAsync(sendh.data(), g[j].send, n_mine * esz, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (c->cb_allgather(c->cb_user, sendh.data(), blk, allh.data()) != 0) { LRGE_SET_ERR(ctx, "host communicator: all-gather callback failed"); return LRGE_ERR_DEVICE; }
+        for (int s = 0; s < W; ++s) {
+            const u64 n = g[j].roff[s + 1] - g[j].roff[s];
+            if (n) HIPCHK(ctx, hipMemcpyAsync((char *)g[j].recv + g[j].roff[s] * esz, allh.data() + blk * (size_t)s, n * esz, hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(st));      // (`allh` is a local)
     }
-    HIPCHK(ctx, hipStreamSynchronize(st));      // (`allh` is a local)
     return LRGE_OK;
 }

@@ -93,6 +93,12 @@ extern "C" double lrge_hip_comm_busy_ms(lrge_hip_comm *c, int reset) {
     if (reset) c->busy_ms = 0;
     return v;
 }
+extern "C" double lrge_hip_comm_standin_ms(lrge_hip_comm *c, int reset) {
+    if (!c) return 0.0;
+    const double v = c->standin_ms;
+    if (reset) c->standin_ms = 0;
+    return v;
+}
 
 // host-buffer form of the variable-size all-to-all (the library itself uses the device form inside lrge_hip_index_build_sharded)
 extern "C" int lrge_hip_comm_alltoallv(lrge_hip_comm *c, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off,

@@ -63,7 +63,7 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
     const u64 n_s = s_off[(size_t)W], n_r = r_off[(size_t)W];
     // (hashes_sent / _recv slots: pairs of 8 bytes; the minimizers a sharded presketch of this step's streamed set moved stay in the entries slots)
     const bool qs = ctx->qshard_fresh; ctx->qshard_fresh = false;
-    const u64 ss[8] = {0, 0, qs ? ctx->shard_stats[2] : 0, qs ? ctx->shard_stats[3] : 0, n_s - mine[(size_t)me], n_r - mine[(size_t)me], (u64)(qs ? 16 : 8) | (u64)8 << 8, 0};
+    const u64 ss[8] = {0, 0, qs ? ctx->shard_stats[2] : 0, qs ? ctx->shard_stats[3] : 0, n_s - mine[(size_t)me], n_r - mine[(size_t)me], (u64)(qs ? (ctx->shard_stats[6] & 0xff) : 8) | (u64)8 << 8, 0};
     memcpy(ctx->shard_stats, ss, sizeof ss);
     // ---- A1, C2, C3: the pairs travel ----
     u64 *sh = nullptr, *rh = nullptr;
@@ -200,8 +200,10 @@ static int ts_global_stats(lrge_hip_ctx *ctx, lrge_hip_index *ix, lrge_hip_comm 
             // here went straight to A3 while its peers sat in A2, and over RCCL / host callbacks they would have waited for ever)
             int arc = LRGE_OK;
             // (the all-gather reads max_nf words of EVERY rank's list: a list that is shorter is re-taken at that size)
+            const bool f17 = shard_fail_at(ctx, 17);        // (tests: the re-taken list refused -- or, on the rank whose list is the longest, the room for everybody's)
+            if (!(cap_list < max_nf) && f17) arc = LRGE_ERR_DEVICE;
             if (cap_list < max_nf) {
-                u64 *bigger = shard_fail_at(ctx, 17) ? nullptr : sc.get<u64>(max_nf);
+                u64 *bigger = f17 ? nullptr : sc.get<u64>(max_nf);
                 if (!bigger) arc = LRGE_ERR_DEVICE;
                 else {
                     if (mine2[0] && hipMemcpyAsync(bigger, d_list, mine2[0] * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipGetLastError(); LRGE_SET_ERR(ctx, "target-sharded index build: copying the list of too-frequent keys failed"); arc = LRGE_ERR_DEVICE; }

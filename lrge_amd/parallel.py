@@ -87,6 +87,10 @@ class _Comm:
     def busy_ms(self, reset=False):
         return float(self.ctx._lib.lrge_hip_comm_busy_ms(self.h, 1 if reset else 0))
 
+    def standin_ms(self, reset=False):
+        """(local groups) the part of busy_ms spent in device-to-device copies that stand in for link transfers (lrge_hip_comm_standin_ms)."""
+        return float(self.ctx._lib.lrge_hip_comm_standin_ms(self.h, 1 if reset else 0))
+
     def abort(self):
         """This rank cannot go on (lrge_hip_comm_abort): its peers leave the collectives they are waiting in with an error instead
         of waiting for ever (local transport), every later collective here fails at once."""

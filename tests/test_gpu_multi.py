@@ -88,6 +88,8 @@ def _run_world(world, ds, preset, mode):
     def rank_main(r):
         try:
             c = engine.Context(0)
+            for k_, v_ in getattr(_run_world, "ctx_opts", {}).items():      # (DEBUG_* options are never read from the environment)
+                c.set_option(k_, v_)
             comm = grp.comm(c, r)
             lo, hi = bounds[r], bounds[r + 1]
             if mode in ("tshard", "tshard_q"):       # forward with the TARGETS sharded: every rank maps ALL queries against its share; counts add up
@@ -217,17 +219,20 @@ def test_world_of_threads_target_sharded(ctx, tiny_ont, tiny_hifi, preset, layou
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
-@pytest.mark.parametrize("layout", ["packed", "parts"])
+@pytest.mark.parametrize("layout", ["packed", "parts", "pairs"])
 @pytest.mark.parametrize("preset", ["ont", "pb"])
 def test_world_of_threads_target_sharded_with_sharded_query_sketch(ctx, tiny_ont, tiny_hifi, preset, layout, world, monkeypatch):
     """lrge_hip_seqset_presketch_sharded (round 6) in front of the target-sharded build: rank r sketches the r-th share of the queries,
     the minimizers are all-gathered, every rank maps ALL queries from that one sketch -- the same counts, has_mapping, estimates and
     statistics as the single-GPU run, on every rank; worlds of 2, 3 and 8 (8 ranks over 60 tiny queries: uneven and near-empty shares),
-    both presets, one index and a partitioned one per rank.  The exchange volumes add up: every minimizer of the set is sent by its
-    one sketcher to the world - 1 others."""
+    both presets, one index and a partitioned one per rank; a minimizer travelling as ONE word (the default where it fits) and as an
+    (x, y) pair.
+    The exchange volumes add up: every minimizer of the set is sent by its one sketcher to the world - 1 others."""
     ds = tiny_ont if preset == "ont" else tiny_hifi
     if layout == "parts":
         monkeypatch.setenv("LRGE_HIP_PART_BASES", str(int(ds.t.lens().sum()) // (world * 3)))
+    if layout == "pairs":
+        monkeypatch.setenv("LRGE_HIP_QSHARD_PAIRS", "1")
     Qd, Td, counts, has, st = _single(ctx, ds, PRESETS[preset])
     qx, _ = Qd.sketch(PRESETS[preset])
     avg_t = np.float32(ds.t.lens().sum()) / np.float32(ds.t.n)
@@ -238,7 +243,7 @@ def test_world_of_threads_target_sharded_with_sharded_query_sketch(ctx, tiny_ont
         assert np.array_equal(c, counts) and np.array_equal(h, has)
         assert np.array_equal(e.view(np.uint32), est.view(np.uint32))
     ss = _run_world.shard_stats
-    assert len(ss) == world and ss[0]["entry_bytes"] == 16
+    assert len(ss) == world and ss[0]["entry_bytes"] == (16 if layout == "pairs" else 8)
     assert sum(x["entries_recv"] for x in ss) == (world - 1) * len(qx) == sum(x["entries_sent"] for x in ss)
 
 

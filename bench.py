@@ -72,8 +72,7 @@ def parse():
     return ap.parse_args()
 
 
-from benchlib import (HBM_PEAK_GBPS, cpu_baseline, cpu_baseline_sampled, committed_traffic, roofline_blocks,  # noqa: E402
-                               emulate_world)
+from benchlib import (cpu_baseline, cpu_baseline_sampled, roofline_blocks, emulate_world)  # noqa: E402
 
 
 def main():
@@ -350,7 +349,7 @@ def main():
             if os.environ.get("LRGE_BENCH_TICKS") and not a.inverse:      # host wall time of the step's calls (where the GPU idles between two steps)
                 sys.stderr.write("[ticks] upload T %.2f | upload Q + hint %.2f | index %.2f | overlap %.2f | introspection + free %.2f | estimates %.2f | median %.2f ms\n"
                                  % ((_tb - _ta) * 1e3, (_t0 - _tb) * 1e3, (_t1 - _t0) * 1e3, (_t2 - _t1) * 1e3, (_t3 - _t2) * 1e3, (_t4 - _t3) * 1e3, (time.perf_counter() - _t4) * 1e3))
-            for k_ in ("rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes"):   # the index build sorts too
+            for k_ in ("rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "sketch_launches"):   # the index build sorts (and sketches) too
                 cn[k_] = cn.get(k_, 0) + cb_.get(k_, 0)
             return counts, est_all, med, tb, tm, cn, st
 
@@ -473,7 +472,10 @@ def main():
         ms_per_step = elapsed * 1e3 / K
         value = Qn * K / elapsed
 
-        r_dom, cands_rest, fams, whole_path, e2e_gbps = roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb2, tm2, cn2, lvl2_all, st, Qn, Tn, q_lens, t_lens)
+        roofline, kernels, fams, committed = roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb2, tm2, cn2, lvl2_all, st, Qn, Tn, q_lens, t_lens)
+        # the single kernel with the most time per step among those SURVEY 8(d) gives bytes (k_rs_scatter's launches may sum to more, but 8(d)
+        # counts ordering as zero: its block -- with the builder's own "once in, once out" denominator, labelled -- stays in roofline_other)
+        dom = next((k_ for k_ in kernels if not k_.get("denominator_is_not_8d")), None)
         clock_txt = ("ASCII reads in pinned HOST memory when the clock starts (SURVEY 8d): host-side 2-bit pack + PCIe inside the step"
                      if clock_host else "ASCII reads resident in HBM, 2-bit pack inside the step")
         out = {
@@ -509,12 +511,15 @@ def main():
             "genome_size_abs_error": None if med[1] is None else abs(float(med[1]) - gsize),
             "estimate_q15_q65": [None if med[0] is None else float(med[0]), None if med[2] is None else float(med[2])],
             "mid_occ": st["mid_occ"],
-            # the path's roofline fraction is `roofline_whole_path.frac`; `roofline` below is ONE kernel (the dominant one among those timed
-            # with event pairs), and for k_rs_scatter its denominator is not 8(d)'s (which counts ordering as zero) but what any sort must move
-            "roofline_whole_path": whole_path,
-            "roofline": {**r_dom, "whole_path_alg_GBps": e2e_gbps, "whole_path_frac": e2e_gbps / HBM_PEAK_GBPS,
-                         "whole_path_traffic": committed_traffic(a.config, a.inverse, "ava-pb" if preset else "ava-ont")},
-            "roofline_other": cands_rest + fams,
+            # `roofline` = the PATH: SURVEY 8(d)'s algorithmic bytes (ordering counts as zero) over the step's wall time.  `roofline_dominant_kernel`
+            # = the single event-timed kernel with the most time per step, `roofline_other` = the other kernels and the kernel families
+            # (k_rs_scatter's denominator is not 8(d)'s -- which counts ordering as zero -- but what any sort must move: it says so itself);
+            # bound = "valu": bound by the VALU issue rate, its HBM fraction is for reference.  Everything read from profiles/*.json
+            # (counter passes cannot run inside a timed run) sits under the ONE key `from_committed_profiles`.
+            "roofline": roofline,
+            "roofline_dominant_kernel": dom,
+            "roofline_other": [k_ for k_ in kernels if k_ is not dom] + fams,
+            "from_committed_profiles": committed,
             "stage_ms_per_step": {**{"index_" + k: v / K for k, v in acc_tb.items() if v and k != "total"},
                                   **{k: v / K for k, v in acc_tm.items() if v}},
             "work_per_step": {k: (v if k in ("lpg_split", "index_parts") else v / K) for k, v in acc_cn.items()},
@@ -523,18 +528,25 @@ def main():
             if gen == "cb" and Tn > 400000:
                 cb = cpu_baseline_sampled(spec, Qn, Tn, a.cpu_seconds, preset)
                 out["cpu_baseline"] = cb
-                out["gpu_vs_cpu_port_SAMPLE"] = value / cb["value"]      # (the denominator is a pro-rated SAMPLE: see cpu_baseline.sample)
-                # beside the sample timed in this run: the WHOLE job timed once on the port (round 5, tools/c5_allcounts.py: all 100 000 forward
-                # counts equal the GPU's), quoted from the committed record -- ~6.5 minutes of CPU time do not fit a default bench run
+                out["gpu_vs_cpu_port_SAMPLE"] = value / cb["value"]      # (the denominator is a pro-rated SAMPLE timed in this run: see cpu_baseline.in_run_sample)
+                # The WHOLE job was timed once on the port (round 5, tools/c5_allcounts.py: all 100 000 forward counts equal the GPU's; ~6.5
+                # minutes of CPU time do not fit a default bench run).  When that committed record is of this very configuration it is the
+                # better figure -- the in-run sample pro-rates x40 and understates the port 2.4x -- so it becomes cpu_baseline.value, with
+                # the in-run sample beside it and the record itself under from_committed_profiles
                 try:
                     with open(os.path.join(ROOT, "profiles", "r05_c5_full_forward_allcounts.json")) as f:
                         ac = json.load(f)
                     if a.config == ac.get("config") and a.scale == ac.get("scale") and ac.get("preset") == ("ava-pb" if preset else "ava-ont"):
                         m = ac["cpu_port_measured"]
-                        cb["measured_full_job"] = {"reads_per_s": m["reads_per_s"], "job_seconds": m["job_seconds"], "index_seconds": m["index_seconds"],
-                                                   "map_seconds": m["map_seconds"], "threads": m["threads"], "counts_equal_gpu": ac["oracle_map"]["counts_equal"],
-                                                   "reads_checked": ac["oracle_map"]["reads_checked"], "note": m["note"],
-                                                   "file": "profiles/r05_c5_full_forward_allcounts.json (a committed record, not timed in this run)"}
+                        committed["cpu_port_measured_full_job"] = {"reads_per_s": m["reads_per_s"], "job_seconds": m["job_seconds"], "index_seconds": m["index_seconds"],
+                                                                    "map_seconds": m["map_seconds"], "threads": m["threads"], "counts_equal_gpu": ac["oracle_map"]["counts_equal"],
+                                                                    "reads_checked": ac["oracle_map"]["reads_checked"], "note": m["note"],
+                                                                    "file": "profiles/r05_c5_full_forward_allcounts.json (a committed record, not timed in this run)"}
+                        cb["in_run_sample"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "sample": cb["sample"]}
+                        cb["value"] = m["reads_per_s"]; cb["cores"] = m["threads"]
+                        cb["value_source"] = ("from_committed_profiles.cpu_port_measured_full_job: the whole job timed once on the port (%.0f s on %d threads); "
+                                              "in_run_sample is what THIS run timed" % (m["job_seconds"], m["threads"]))
+                        cb["sample"] = "the whole job: all %d query reads against all %d target reads (committed record); in_run_sample: this run's bounded sample" % (Qn, Tn)
                         out["gpu_vs_cpu_port_MEASURED_FULL_JOB"] = value / m["reads_per_s"]
                 except Exception:      # noqa: BLE001
                     pass

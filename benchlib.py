@@ -96,6 +96,23 @@ def committed_kernel_traffic(config, inverse, kernel, preset_name=None):
                                "correction": "reads x2 (gfx950 tallies 128-B read requests at 64 B), writes x1", "file": "profiles/" + name}
 
 
+def committed_kernel_valu(config, inverse, kernel, preset_name=None):
+    """wave64 VALU instructions per launch of `kernel` (SQ_INSTS_VALU of the committed SQ pass, averaged over its launches and template
+    instantiations) or None."""
+    d, name = _committed(config, inverse, preset_name)
+    if d is None:
+        return None
+    n = v = 0.0
+    for k, e in d.get("kernels", {}).items():
+        if (k == kernel or k.startswith(kernel + "<")) and "valu_insts_per_launch" in e:
+            ln = float(e.get("launches_in_pass", 0))
+            n += ln; v += ln * e["valu_insts_per_launch"]
+    return None if not n else {"valu_wave_insts_per_launch": v / n, "launches_in_pass": n, "file": "profiles/" + name}
+
+
+VALU_PEAK_WAVE_INSTS_PER_S_PER_CU = 2.4e9     # 4 SIMDs x one wave64 VALU instruction every 4 cycles at 2.4 GHz (MI355X_MICROARCH.md; tools/micro/valu_rate.hip measures 2.4-2.7 cycles for the cheap ones)
+
+
 def cpu_baseline_sampled(spec, Qn, Tn, budget_s, preset):
     """The same leg for a job whose target set the host cannot index inside a bench run (H. sapiens-scale: 30 Gbases):
     the oracle indexes 1/F of the target reads (host twin of the generator) and maps query reads against that index
@@ -295,14 +312,16 @@ HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 def roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb2, tm2, cn2, lvl2_all, st, Qn, Tn, q_lens, t_lens):
     """The roofline bookkeeping of a bench line from the timed steps' HIP-event times and work counters:
-    -> (r_dom = the single kernel with the most time per step, the other kernels, the kernel families, the SURVEY 8(d) whole-path
-    block, its GB/s).  Algorithmic bytes follow SURVEY.md 8(d); see the comments inside."""
-    def roof(kernel, ms_total, launches, bytes_total, bytes_note):
+    -> (roofline = the SURVEY 8(d) whole-path block, the single kernels by time per step, the kernel families, the figures quoted from
+    committed profiles).  Algorithmic bytes follow SURVEY.md 8(d); see the comments inside."""
+    def roof(kernel, ms_total, launches, bytes_total, bytes_note, bound="hbm"):
+        # bound = "valu": the kernel is bound by the VALU issue rate (the committed SQ pass says how close it runs to it:
+        # from_committed_profiles.valu_issue); its HBM figures are still SURVEY 8(d)'s bytes over its time, for reference
         launches = max(1, launches)
         avg_ms = ms_total / launches
         alg = bytes_total / launches
         ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        return {"bound": bound, "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": None, "alg_bytes_per_launch": alg, "alg_bytes": bytes_note,
                 "avg_launch_ms": avg_ms, "launches_per_step": launches / K, "ms_per_step": ms_total / K}
 
@@ -328,7 +347,12 @@ def roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb
                           16.0 * acc_cn.get("query_minimizers", 0), "16 B x query minimizers (SURVEY 8d: one hash/offset entry per lookup)"))
     if acc_cn.get("lpg_launches", 0):
         cands.append(roof("k_chain_lpg", acc_tm.get("chain_lpg", 0.0), acc_cn["lpg_launches"], 16.0 * acc_cn.get("lpg_anchors", 0),
-                          "16 B x anchors chained by the launch (SURVEY 8d: anchor in for chaining)"))
+                          "16 B x anchors chained by the launch (SURVEY 8d: anchor in for chaining)", bound="valu"))
+    if acc_cn.get("sketch_launches", 0) and acc_tb.get("k_sketch", 0.0) > 0 and world == 1:
+        # the one-pass index sketch kernel, event pairs around its launches (timer level 2): SURVEY 8(d)'s B_idx = L_T / 4 + 16 M_T dealt over them
+        L_idx_ = float((q_lens if a.inverse else t_lens).sum())
+        cands.append(roof("k_sketch_direct", acc_tb["k_sketch"], acc_cn["sketch_launches"], (L_idx_ / 4.0 + 16.0 * float(st["n_minimizers"])) * K,
+                          "SURVEY 8d's B_idx: L_T / 4 B of packed bases in + 16 B per index minimizer out, dealt over the launches", bound="valu"))
     n_idx = float(st["n_minimizers"]) if not (world > 1 and not a.inverse) else float(acc_cn.get("rs_scatter_items", 0)) / max(1, K) / 4.0
     entry_b = 8.0 if (2 * (19 if preset else 15) + int(np.ceil(np.log2((Qn if a.inverse else Tn) + 1))) + int(np.ceil(np.log2(float((q_lens if a.inverse else t_lens).max()) + 1))) + 1) <= 64 else 16.0
     if acc_tb.get("index_sort", 0.0) > 0 and world == 1:
@@ -342,8 +366,8 @@ def roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb
         fams.append(roof("anchor sort (k_seg_sort_local / k_rs_hist + scan + k_rs_scatter)", acc_tm["anchor_sort"], K, 24.0 * acc_cn.get("anchors_kept", acc_cn.get("anchors", 0)),
                          "8 B packed anchor in + 16 B (key, value) out per anchor that left the expansion"))
     if acc_tm.get("expand", 0.0) > 0:
-        cands.append(roof("k_expand", acc_tm["expand"], max(1, acc_cn.get("batches", K)), 16.0 * acc_cn.get("anchors", 0),
-                          "8 B position-list entry in + 8 B anchor out per anchor"))
+        cands.append(roof("k_expand_q", acc_tm["expand"], max(1, acc_cn.get("batches", K)), 16.0 * acc_cn.get("anchors", 0),
+                          "8 B position-list entry in + 8 B anchor out per seed hit (SURVEY 8d); one `launch` = the <= 3 size-class launches of a batch, timed together"))
     # k_rs_scatter: in the timed steps when they run at timer level 2 (big jobs), else in the instrumented step behind them
     if lvl2_all:
         sc_ms, sc_n, sc_bytes, sc_how = acc_tm.get("rs_scatter", 0.0) + acc_tb.get("rs_scatter", 0.0), acc_cn.get("rs_scatter_launches", 0), float(acc_cn.get("rs_scatter_bytes", 0)), "event pair around every launch of the timed steps"
@@ -356,14 +380,29 @@ def roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb
                     "what any sort must move, once per step: %d B in + %d B out per index entry, 8 B in + 8 B out per anchor -- dealt over this "
                     "kernel's launches (SURVEY 8d counts ordering as zero algorithmic bytes)" % (entry_b, entry_b))
         r_sc["measured"] = sc_how
+        r_sc["denominator_is_not_8d"] = True        # (SURVEY 8(d) gives ordering ZERO algorithmic bytes: this block never leads the line)
         r_sc["streamed"] = {"bytes_per_launch": sc_bytes / sc_n, "GBps": sc_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0,
                             "what": "bytes the launches read + write (32 / pair, 16 / packed key, 24 unpacking): the kernel as a streaming kernel"}
         cands.append(r_sc)
     for r_ in cands: r_["kind"] = "kernel"
     for r_ in fams: r_["kind"] = "family"
     cands.sort(key=lambda r: -r["ms_per_step"])
-    for r_ in cands + fams:
-        r_["traffic"], r_["traffic_detail"] = committed_kernel_traffic(a.config, a.inverse, r_["kernel"], "ava-pb" if preset else "ava-ont") if r_["kind"] == "kernel" else (None, None)
+    # figures from the round's committed rocprofv3 counter passes (they cannot be read inside a timed run) are NOT put into the blocks: a
+    # line timed by the driver must not change because a committed file changed.  They are returned apart (`committed`), keyed by kernel,
+    # and bench.py prints them under ONE key, from_committed_profiles
+    committed = {"kernel_traffic": {}, "valu_issue": {}}
+    pn = "ava-pb" if preset else "ava-ont"
+    for r_ in cands:
+        tr, det = committed_kernel_traffic(a.config, a.inverse, r_["kernel"], pn)
+        if tr is not None:
+            committed["kernel_traffic"][r_["kernel"]] = {"hbm_bytes_per_launch": tr, "over_algorithmic": tr / r_["alg_bytes_per_launch"] if r_["alg_bytes_per_launch"] else None, **det}
+        if r_["bound"] == "valu":
+            v = committed_kernel_valu(a.config, a.inverse, r_["kernel"], pn)
+            if v is not None and r_["avg_launch_ms"] > 0:
+                rate = v["valu_wave_insts_per_launch"] / (r_["avg_launch_ms"] * 1e-3)
+                peak = VALU_PEAK_WAVE_INSTS_PER_S_PER_CU * 256
+                committed["valu_issue"][r_["kernel"]] = {**v, "wave_insts_per_s": rate, "peak_wave_insts_per_s": peak, "issue_frac": rate / peak,
+                                                         "what": "committed SQ_INSTS_VALU per launch over THIS run's event-timed launch duration, against 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz"}
     # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
     # (streamed set: the queries, or the targets with --inverse; for N > 1 rank 0's counters times the world size)
     # M = minimizers of the streamed set, counted ONCE: against a partitioned index every part looks all of them up, and the
@@ -378,5 +417,12 @@ def roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb
                   "alg_GB_per_step": (B_q + B_idx) / 1e9, "B_q_GB": B_q / 1e9, "B_idx_GB": B_idx / 1e9, "alg_GBps": e2e_gbps, "peak_GBps": HBM_PEAK_GBPS,
                   "frac": e2e_gbps / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": e2e_gbps / 6290.0,
                   "streamed_minimizers": M, "anchors": H, "index_minimizers": st["n_minimizers"], "index_parts": n_parts}
-    r_dom = cands[0] if cands else {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 0.0, "traffic": None}
-    return r_dom, cands[1:], fams, whole_path, e2e_gbps
+    wt = committed_traffic(a.config, a.inverse, pn)
+    if wt is not None:
+        committed["whole_path_traffic"] = wt
+    # The path's roofline block = SURVEY 8(d), strictly: the keys of the contract, achieved = the path's algorithmic
+    # bytes over the step's wall time.  The single kernels follow, the one with the most time per step first.
+    roofline = {"bound": "hbm", "kernel": "whole path (SURVEY 8d: every stage of the step)", "achieved": e2e_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": e2e_gbps / HBM_PEAK_GBPS, "traffic": None, "traffic_note": "from_committed_profiles.whole_path_traffic (counters cannot be read in a timed run)",
+                "alg_bytes_per_launch": B_q + B_idx, "avg_launch_ms": ms_per_step, "launches_per_step": 1, **{k: v for k, v in whole_path.items() if k not in ("alg_GBps", "peak_GBps", "frac")}}
+    return roofline, cands, fams, committed

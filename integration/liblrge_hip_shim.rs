@@ -38,6 +38,24 @@ pub struct lrge_hip_params {
     pub max_overhang_ratio: f32,
 }
 
+/// One chain = one mm_reg1_t = one PafRecord (include/lrge_hip.h: lrge_hip_chain; aligner.rs:253-290).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct lrge_hip_chain {
+    pub query: u32,
+    pub target: u32,
+    pub rev: i32,
+    pub score: i32,
+    pub cnt: i32,
+    pub qs: i32,
+    pub qe: i32,
+    pub rs: i32,
+    pub re: i32,
+    pub mlen: i32,
+    pub blen: i32,
+    pub n_seeds: i32,
+}
+
 pub const LRGE_PRESET_AVA_ONT: c_int = 0; // Preset::AvaOnt (preset.rs:26)
 pub const LRGE_PRESET_AVA_PB: c_int = 1; //  Preset::AvaPb  (preset.rs:24)
 
@@ -69,6 +87,12 @@ extern "C" {
                             p: *const lrge_hip_params, counts: *mut u32) -> c_int;
     fn lrge_hip_estimates(ctx: *mut lrge_hip_ctx, counts: *const u32, read_lens: *const u32, n: u32,
                           avg_target_len: f32, n_target_reads: u64, overlap_thresh: u32, out: *mut f32) -> c_int;
+    // the PafRecord stream (overlaps.paf: twoset.rs:244-250,293, :410-416,487, ava.rs:220-226,273)
+    fn lrge_hip_chains(ctx: *mut lrge_hip_ctx, ix: *const lrge_hip_index, queries: *const lrge_hip_seqset, dual: c_int,
+                       out: *mut lrge_hip_chain, cap: u64, n_out: *mut u64) -> c_int;
+    fn lrge_hip_paf_stats(ctx: *mut lrge_hip_ctx, ix: *const lrge_hip_index, queries: *const lrge_hip_seqset,
+                          rep_len: *mut i32, sum_span: *mut u64, n_kept: *mut u32) -> c_int;
+    fn lrge_hip_seqset_presketch_sharded(ctx: *mut lrge_hip_ctx, s: *mut lrge_hip_seqset, preset: c_int, comm: *mut lrge_hip_comm) -> c_int;
     // multi-GPU (one thread per GPU inside this process: liblrge already owns a rayon pool)
     fn lrge_hip_comm_local_group_create(world: c_int, group: *mut *mut c_void) -> c_int;
     fn lrge_hip_comm_local_group_destroy(group: *mut c_void);
@@ -188,6 +212,60 @@ impl Ctx {
     }
 }
 
+impl Ctx {
+    /// Every chain of every read of `queries` against `ix` (two calls: the count, then the records) and the per-query seed
+    /// statistics that complete the tags (rl; avg_k for dv).
+    pub fn chains(&self, ix: &Index, queries: &SeqSet, dual: bool) -> crate::Result<(Vec<lrge_hip_chain>, Vec<i32>, Vec<u64>, Vec<u32>)> {
+        let mut n: u64 = 0;
+        check!(self.h, lrge_hip_chains(self.h, ix.h, queries.h, dual as c_int, ptr::null_mut(), 0, &mut n));
+        let mut out = vec![lrge_hip_chain::default(); (n as usize).max(1)];
+        check!(self.h, lrge_hip_chains(self.h, ix.h, queries.h, dual as c_int, out.as_mut_ptr(), n, &mut n));
+        out.truncate(n as usize);
+        let nq = queries.n as usize;
+        let (mut rl, mut ss, mut nk) = (vec![0i32; nq.max(1)], vec![0u64; nq.max(1)], vec![0u32; nq.max(1)]);
+        check!(self.h, lrge_hip_paf_stats(self.h, ix.h, queries.h, rl.as_mut_ptr(), ss.as_mut_ptr(), nk.as_mut_ptr()));
+        Ok((out, rl, ss, nk))
+    }
+
+    /// `overlaps.paf`, where and as the reference writes it: `tmpdir/overlaps.paf` (twoset.rs:244-250, :410-416, ava.rs:220-226), one
+    /// tab-separated line per mapping in `PafRecord`'s field order (mapping.rs:10-54) with its serialisers (mapping.rs:81-177:
+    /// `tp:A:S`, `cm:i:`, `s1:i:`, `dv:f:` as `0` below f32::EPSILON else four decimals, `rl:i:`), EVERY mapping -- the `-F` filter
+    /// only affects the counts (twoset.rs:293-301 serialises before it tests `is_internal`).  Line order is undefined in the
+    /// reference (rayon workers under a mutex); here it is the library's chain order.  `q` / `t`: the streamed and the indexed set.
+    pub fn write_overlaps_paf(&self, tmpdir: &Path, ix: &Index, qs: &SeqSet, q: &ReadSet, t: &ReadSet, dual: bool) -> crate::Result<()> {
+        use std::io::Write;
+        let (chains, rl, ss, nk) = self.chains(ix, qs, dual)?;
+        let (q_lens, t_lens) = (q.lens(), t.lens());
+        let file = std::fs::File::create(tmpdir.join("overlaps.paf"))?;
+        let mut w = std::io::BufWriter::new(file);
+        for c in &chains {
+            let (qi, ti) = (c.query as usize, c.target as usize);
+            let dv = chain_dv(c, q_lens[qi], t_lens[ti], ss[qi], nk[qi]);
+            let dv_s = if dv < f32::EPSILON { "0".to_string() } else { format!("{dv:.4}") };
+            writeln!(w, "{}\t{}\t{}\t{}\t{}\t{}\t{}\t{}\t{}\t{}\t{}\t0\ttp:A:S\tcm:i:{}\ts1:i:{}\tdv:f:{}\trl:i:{}",
+                     String::from_utf8_lossy(&q.names[qi]), q_lens[qi], c.qs, c.qe, if c.rev != 0 { '-' } else { '+' },
+                     String::from_utf8_lossy(&t.names[ti]), t_lens[ti], c.rs, c.re, c.mlen, c.blen, c.cnt, c.score, dv_s, rl[qi])
+                .map_err(|e| LrgeError::PafWriteError(e.to_string()))?;
+        }
+        w.flush().map_err(|e| LrgeError::PafWriteError(e.to_string()))?;
+        Ok(())
+    }
+}
+
+/// mm_est_err (mm2:esterr.c) for one chain: n_match = cnt, n_tot = the kept seeds the chain spans plus the two end corrections,
+/// avg_k = (float)sum_span / n_kept; dv = (float)(1.0 - pow((double)n_match / n_tot, 1.0 / avg_k)), 0 when n_match >= n_tot,
+/// -1 when the query kept no seed (include/lrge_hip.h: lrge_hip_paf_stats).
+fn chain_dv(c: &lrge_hip_chain, qlen: u32, tlen: u32, sum_span: u64, n_kept: u32) -> f32 {
+    if n_kept == 0 { return -1.0; }
+    let avg_k = sum_span as f32 / n_kept as f32;
+    let n_match = c.cnt as i64;
+    let mut n_tot = c.n_seeds as i64;
+    if c.qs as f32 > avg_k && c.rs as f32 > avg_k { n_tot += 1; }
+    if (qlen as i32 - c.qs) as f32 > avg_k && (tlen as i32 - c.re) as f32 > avg_k { n_tot += 1; }
+    if n_match >= n_tot { return 0.0; }
+    (1.0 - (n_match as f64 / n_tot as f64).powf(1.0 / avg_k as f64)) as f32
+}
+
 impl Drop for Ctx { fn drop(&mut self) { unsafe { lrge_hip_ctx_destroy(self.h) } } }
 impl Drop for SeqSet<'_> { fn drop(&mut self) { unsafe { lrge_hip_seqset_free(self.h) } } }
 impl Drop for Index<'_> { fn drop(&mut self) { unsafe { lrge_hip_index_free(self.h) } } }
@@ -253,6 +331,7 @@ pub struct TwoSetJob<'a> {
     pub use_min_ref: bool,
     pub pacbio: bool,             // Platform::PacBio -> Preset::AvaPb, else AvaOnt (twoset.rs:590-593)
     pub device: i32,
+    pub tmpdir: &'a Path,         // self.tmpdir: `overlaps.paf` is written there (twoset.rs:244; kept with -C)
 }
 
 /// Body of `impl Estimate for TwoSetStrategy { fn generate_estimates }` after `split_fastq` (twoset.rs:587-606):
@@ -274,12 +353,14 @@ pub fn twoset_estimates(job: &TwoSetJob) -> crate::Result<(Vec<f32>, u32)> {
         ctx.presketch(&ts, preset)?;            // the streamed set is sketched beside the index build
         let ix = ctx.index(&qs, preset)?;       // index = query set (twoset.rs:597-599)
         let counts = ctx.overlap_inverse(&ix, q.len(), &ts, &p)?;
+        ctx.write_overlaps_paf(job.tmpdir, &ix, &ts, &t, &q, true)?;    // twoset.rs:410-416,487: the streamed target read is the PAF's query
         let no_mapping = counts.iter().filter(|&&c| c == 0).count() as u32; // twoset.rs:545-569
         (counts, no_mapping)
     } else {
         ctx.presketch(&qs, preset)?;
         let ix = ctx.index(&ts, preset)?;       // twoset.rs:601-603
         let (counts, has) = ctx.overlap_twoset(&ix, &qs, &p)?;
+        ctx.write_overlaps_paf(job.tmpdir, &ix, &qs, &q, &t, true)?;    // twoset.rs:244-250,293
         let no_mapping = has.iter().filter(|&&h| h == 0).count() as u32;    // twoset.rs:303-309
         (counts, no_mapping)
     };
@@ -297,6 +378,7 @@ pub struct AvaJob<'a> {
     pub max_overhang_ratio: f32,
     pub pacbio: bool,
     pub device: i32,
+    pub tmpdir: &'a Path,         // `overlaps.paf` (ava.rs:220-226)
 }
 
 /// Body of `impl Estimate for AvaStrategy { fn generate_estimates }` after `subsample_reads` (ava.rs:369-381).
@@ -318,6 +400,7 @@ pub fn ava_estimates(job: &AvaJob) -> crate::Result<(Vec<f32>, u32)> {
     let ix = ctx.index(&rs, preset)?;
     let p = lrge_hip_params { remove_internal: job.remove_internal as i32, max_overhang_ratio: job.max_overhang_ratio };
     let counts = ctx.overlap_ava(&ix, &rs, &p)?;
+    ctx.write_overlaps_paf(job.tmpdir, &ix, &rs, &r, &r, false)?;      // ava.rs:220-226,273 (NO_DUAL: every pair once)
     let n_target = job.num_reads - 1;                                  // ava.rs:339-346
     let avg = job.sum_len as f32 / n_target as f32;                    // the read's own length is NOT subtracted
     let est = ctx.estimates(&counts, &r.lens(), avg, n_target as u64, 100)?;
@@ -378,6 +461,8 @@ pub fn twoset_estimates_target_sharded(job: &TwoSetJob, devices: &[i32]) -> crat
                 };
                 let ts = ctx.upload(&tsub, &ranks[0][t0..t1])?;
                 let qs = ctx.upload(q, &ranks[1])?;                                 // ALL queries on every rank
+                // ... sketched once per world: every rank runs mm_sketch over its share, the minimizers are all-gathered (collective)
+                check!(ctx.h, lrge_hip_seqset_presketch_sharded(ctx.h, qs.h, preset, comm.h));
                 let mut h = ptr::null_mut();
                 check!(ctx.h, lrge_hip_index_build_tsharded(ctx.h, ts.h, preset, comm.h, &mut h));   // collective, and failure-collective
                 let ix = Index { h, _ctx: &ctx };

@@ -13,10 +13,10 @@ ERR_IO, ERR_PARSE, ERR_TOO_MANY, ERR_TOO_FEW, ERR_DEVICE, ERR_MAP, ERR_DUPLICATE
 PRESET_AVA_ONT, PRESET_AVA_PB = 0, 1
 
 T_NAMES = ["pack", "sketch", "index_sort", "index_table", "qfilter", "lookup", "expand", "anchor_sort", "group",
-           "chain", "chain_glb", "count", "total", "chain_lpg", "rs_scatter", "k_lookup", "index_restrict"]
+           "chain", "chain_glb", "count", "total", "chain_lpg", "rs_scatter", "k_lookup", "index_restrict", "k_sketch"]
 C_NAMES = ["query_bases", "query_minimizers", "anchors", "groups", "groups_chained", "chain_launches", "batches",
            "chain_anchors", "chain_glb_launches", "chain_glb_anchors", "lpg_launches", "lpg_anchors",
-           "rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "lpg_split", "lookup_launches", "table_disp_sum", "anchors_kept", "index_parts"]
+           "rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "lpg_split", "lookup_launches", "table_disp_sum", "anchors_kept", "index_parts", "sketch_launches"]
 
 EXPORTS = [
     "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error", "lrge_hip_ctx_set_option",

@@ -95,6 +95,8 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
                 hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, IK, PKF>), gl, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,    \
                                    s->d_len, cm, c1, d_cnt, d_total + 1, sx, sy, P1, YB, capv, c0);                                                  \
         } while (0)
+        StageTimer tk(ctx, LRGE_T_K_SKETCH);             // (timer level 2: the bench's roofline candidates)
+        if (!tile_form) ctx->counters[LRGE_C_SKETCH_LAUNCHES] += 1;
         if (pk) LRGE_SK_LAUNCH(true, true, pk_pos1, pk_ybits);
         else if (segw)          // (the lane form only: tile_form is off for SEGW entries)
             hipLaunchKernelGGL((k_sketch_direct<K, W, HPC, true, 2>), gl, dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,

@@ -384,9 +384,9 @@ static inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
 
 // Timer levels (lrge_hip_set_timer_level / LRGE_HIP_TIMERS): 0 = the call total and the chain stage only (what a
 // caller that just wants results should pay: two event records per timer are host work between launches), 1 = every
-// stage (default), 2 = also one pair around every k_rs_scatter launch.
+// stage (default), 2 = also one pair around every k_rs_scatter and every k_sketch_direct launch.
 inline int timer_slot_level(int slot) {
-    return (slot == LRGE_T_TOTAL || slot == LRGE_T_CHAIN || slot == LRGE_T_CHAIN_LPG) ? 0 : slot == LRGE_T_RS_SCATTER ? 2 : 1;
+    return (slot == LRGE_T_TOTAL || slot == LRGE_T_CHAIN || slot == LRGE_T_CHAIN_LPG) ? 0 : (slot == LRGE_T_RS_SCATTER || slot == LRGE_T_K_SKETCH) ? 2 : 1;
 }
 inline StageTimer::StageTimer(lrge_hip_ctx *c, int s, hipStream_t on) : ctx(c), slot(s), st(on ? on : c->stream) {
     if (timer_slot_level(s) > ctx->timer_level) { stopped = true; return; }     // not recorded

@@ -273,7 +273,13 @@ __host__ __device__ __forceinline__ u64 sig_to_hash(u64 S, u32 nbits) {
     const u64 X = (S >> tb) << 8 | (S & ((1ULL << tb) - 1));
     return __builtin_bswap64(X << (64 - 8 * m));
 }
-struct UnpackParams { u32 sb, bits_qy, sh_q, dmask, nbits; };   // dmask: digit mask of the pass (the last digit may be narrower than 8 bits); nbits: hash bits (PACK / PACKQ)
+struct UnpackParams {
+    u32 sb, bits_qy, sh_q, dmask, nbits;
+    // nd_out != null (round 6): the scatter also leaves, beside every key it writes, the key's digit of the NEXT pass -- (key >> nd_shift) &
+    // nd_mask, one byte -- so that the next pass's histogram reads 1 byte per entry instead of the 8-byte key (k_rs_hist, key32 == 2).
+    // The bytes of a (tile, digit) run are consecutive like its keys, and neighbouring tiles meet in one L2 (xcd_tile): whole lines go out.
+    u8 *nd_out; u32 nd_shift, nd_mask;
+};   // dmask: digit mask of the pass (the last digit may be narrower than 8 bits); nbits: hash bits (PACK / PACKQ)
 #define RS_MODE_PAIRS 0
 #define RS_MODE_KEYS 1
 #define RS_MODE_UNPACK 2
@@ -376,7 +382,7 @@ __device__ __forceinline__ void rs_load_from_slots(const SlotSrc &S, u32 bid, u6
 template <bool SEG, int DB = 8, bool SLOTS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
                                                         u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255, SlotSrc src = SlotSrc(),
-                                                        u32 use_src = 0, u32 sig_nbits = 0, u32 key32 = 0) {       // key32: `keys` is a u32 array (the DIG member of SEGW entries)
+                                                        u32 use_src = 0, u32 sig_nbits = 0, u32 key32 = 0) {       // key32 = 1: `keys` is a u32 array (the DIG member of SEGW entries); 2: a u8 array of ready-made digits
     constexpr u32 ND = 1u << DB;
     static_assert(!SLOTS || !SEG, "slots feed whole (unsegmented) sorts only");
     __shared__ u32 h[ND];
@@ -387,6 +393,30 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
     const u64 tile0 = SEG ? (u64)(use_src ? tiles[bid].src : tiles[bid].start) : (u64)bid * RS_TILE;
     const u32 n_tile = SEG ? tiles[bid].len : (u32)((n - tile0) < (u64)RS_TILE ? (n - tile0) : (u64)RS_TILE);
     // the whole tile in flight before the first count (the 4-deep unrolled load -> atomic loop ran at 2.7 TB/s)
+    if (!SLOTS && key32 == 2) {
+        // `keys` is the digit-byte array the pass before left (UnpackParams::nd_out): 16 bytes per lane and load, whatever the tile's alignment
+        // (the array has 64 spare bytes behind its last entry; bytes outside [tile0, tile0 + n_tile) are skipped)
+        const u8 *d8 = (const u8 *)keys;
+        const u64 a0 = tile0 & ~15ULL, end = tile0 + n_tile;
+        for (u64 g = a0 + 16ULL * threadIdx.x; g < end; g += 16ULL * RS_THREADS) {
+            const uint4 q = *(const uint4 *)(d8 + g);
+            const u32 v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const u64 i = g + 4 * j + t;
+                    if (i >= tile0 && i < end) atomicAdd(&h[(v[j] >> (8 * t)) & 0xffu], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        for (u32 d = threadIdx.x; d < ND; d += RS_THREADS) {
+            const u64 hi = SEG ? (u64)tiles[bid].hbase + (u64)d * tiles[bid].hstride : (u64)d * nb + bid;
+            hist[hi] = h[d];
+        }
+        return;
+    }
     const u32 l0 = (threadIdx.x >> 6) * (RS_ITEMS * 64) + lane_id();
     u64 kk[RS_ITEMS];
     if (SLOTS) rs_load_from_slots(src, bid, tile0, n_tile, s_offs, kk, 0ULL);
@@ -563,6 +593,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
             if (MODE == RS_MODE_PACKQ || MODE == RS_MODE_DWQ) d = sdig[p];
             if (MODE == RS_MODE_DW) ((u32 *)keys_out)[gbase[d] + p] = (u32)ko[r];
             else keys_out[gbase[d] + p] = ko[r];
+            if (MODE != RS_MODE_DW && MODE != RS_MODE_PAIRS && up.nd_out) up.nd_out[gbase[d] + p] = (u8)((u32)(ko[r] >> up.nd_shift) & up.nd_mask);
         }
     }
     if (MODE == RS_MODE_KEYS || MODE == RS_MODE_PACK || MODE == RS_MODE_PACKQ || MODE == RS_MODE_DWQ || MODE == RS_MODE_DWP) return;
@@ -633,11 +664,18 @@ static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *
     ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * nb);
     const int passes = nbits > 0 ? (nbits + 7) / 8 : 1;
     u64 *ki = pk0, *ko = pk1;
+    // next-pass digit bytes (UnpackParams::nd_out; option NO_DIGIT_BYTES: every histogram reads the packed anchors)
+    u8 *nd = (ctx->opt("NO_DIGIT_BYTES") || passes < 2) ? nullptr : sc.get<u8>(n + 64);
+    if (!nd) { (void)hipGetLastError(); ctx->err.clear(); }
+    bool nd_valid = false;
     for (int p = 0; p < passes; ++p) {
         const int shift = p * 8;
         up.dmask = nbits - shift >= 8 ? 255u : (1u << (nbits - shift)) - 1u;   // bits above nbits are payload, not key
+        up.nd_out = nullptr;
+        if (nd && p + 2 < passes + 1 && p + 1 < passes) { up.nd_out = nd; up.nd_shift = (u32)shift + 8u; up.nd_mask = nbits - (shift + 8) >= 8 ? 255u : (1u << (nbits - (shift + 8))) - 1u; }
         const u32 us = (src_first && p == 0) ? 1u : 0u;
-        hipLaunchKernelGGL(k_rs_hist<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, d_tiles, up.dmask, SlotSrc(), us);
+        if (nd_valid) hipLaunchKernelGGL(k_rs_hist<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)nd, n, 0, nb, hist, d_tiles, up.dmask, SlotSrc(), 0u, 0u, 2u);
+        else hipLaunchKernelGGL(k_rs_hist<true>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, d_tiles, up.dmask, SlotSrc(), us);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
         if (rc) return rc;
@@ -653,8 +691,10 @@ static int radix_sort_packed_seg(lrge_hip_ctx *ctx, Scratch &sc, u64 *pk0, u64 *
             ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n_items;
             ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (p + 1 < passes ? 16 : 24) * n_items;
         }
+        nd_valid = up.nd_out != nullptr;
         u64 *t = ki; ki = ko; ko = t;
     }
+    if (nd) sc.drop(nd);
     sc.drop(hist);
     return LRGE_OK;
 }
@@ -703,11 +743,21 @@ static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64
     ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * nb);
     const int passes = (nbits + 7) / 8;
     u64 *ki = k0, *ko = k1;
-    for (int p = pass_begin; p < (pass_end < 0 ? passes : std::min(pass_end, passes)); ++p) {
+    const int p_end = pass_end < 0 ? passes : std::min(pass_end, passes);
+    // next-pass digit bytes (UnpackParams::nd_out; option NO_DIGIT_BYTES: every histogram reads the keys)
+    u8 *nd = (ctx->opt("NO_DIGIT_BYTES") || p_end - pass_begin < 2) ? nullptr : sc.get<u8>(n + 64);
+    if (!nd) { (void)hipGetLastError(); ctx->err.clear(); }
+    bool nd_valid = false;
+    for (int p = pass_begin; p < p_end; ++p) {
         const int d = reverse_digits ? passes - 1 - p : p;
         const int shift = begin_bit + d * 8;
-        UnpackParams up{0, 0, 0, nbits - d * 8 >= 8 ? 255u : (1u << (nbits - d * 8)) - 1u};
-        hipLaunchKernelGGL((k_rs_hist<false, 8>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, (const SegTile *)nullptr, up.dmask);
+        UnpackParams up{0, 0, 0, nbits - d * 8 >= 8 ? 255u : (1u << (nbits - d * 8)) - 1u, 0, nullptr, 0, 0};
+        if (nd && p + 1 < p_end) {
+            const int d2 = reverse_digits ? passes - 2 - p : p + 1;
+            up.nd_out = nd; up.nd_shift = (u32)(begin_bit + d2 * 8); up.nd_mask = nbits - d2 * 8 >= 8 ? 255u : (1u << (nbits - d2 * 8)) - 1u;
+        }
+        if (nd_valid) hipLaunchKernelGGL((k_rs_hist<false, 8>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)nd, n, 0, nb, hist, (const SegTile *)nullptr, up.dmask, SlotSrc(), 0u, 0u, 2u);
+        else hipLaunchKernelGGL((k_rs_hist<false, 8>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, ki, n, shift, nb, hist, (const SegTile *)nullptr, up.dmask);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
         if (rc) return rc;
@@ -721,8 +771,10 @@ static int radix_sort_keys(lrge_hip_ctx *ctx, Scratch &sc, u64 *k0, u64 *k1, u64
             ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;
             ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 16 * n;
         }
+        nd_valid = up.nd_out != nullptr;
         u64 *t = ki; ki = ko; ko = t;
     }
+    if (nd) sc.drop(nd);
     sc.drop(hist);
     *res = ki;
     return LRGE_OK;
@@ -1027,6 +1079,16 @@ static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky
     const u32 nb = (u32)div_up(n, RS_TILE), n_seg = 256u << e;
     const u32 max_tiles = nb + n_seg;                  // every segment ends in at most one partial tile
     ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * (max_tiles + 1) + 256);
+    // next-pass digit bytes (UnpackParams::nd_out): every scatter that writes packed words also leaves the byte the NEXT pass ranks by, and
+    // that pass's histogram reads 1 byte per entry instead of 8 (option NO_DIGIT_BYTES: the histograms read the words, rounds 3-5)
+    u8 *nd = ctx->opt("NO_DIGIT_BYTES") ? nullptr : sc.get<u8>(n + 64);
+    if (!nd) { (void)hipGetLastError(); ctx->err.clear(); }
+    bool nd_valid = false;                             // nd holds the digits of the pass about to run
+    auto nd_of = [&](int j_next) -> UnpackParams {      // what the scatter in front of LSD pass j_next adds to its parameters
+        UnpackParams q{0, 0, 0, 0, 0, nullptr, 0, 0};
+        if (nd && j_next < passes) { const int w_ = nr - 8 * j_next >= 8 ? 8 : nr - 8 * j_next; q.nd_out = nd; q.nd_shift = ybits + 8u * (u32)j_next; q.nd_mask = (1u << w_) - 1u; }
+        return q;
+    };
     // ---- pass A: pairs by the low hash byte ----
     {
         hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, kx, n, 0, nb, hist, (const SegTile *)nullptr, 255u);
@@ -1061,8 +1123,10 @@ static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky
         KCHK(ctx);
         {
             StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+            const UnpackParams nq = nd_of(0);
             hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_PACKQ>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, v1, pi, (u64 *)nullptr, n, 16 - (int)e, cur_tiles, hist,
-                               (const SegTile *)d_tiles, UnpackParams{ybits, pos1, e, qm, (u32)nbits});
+                               (const SegTile *)d_tiles, UnpackParams{ybits, pos1, e, qm, (u32)nbits, nq.nd_out, nq.nd_shift, nq.nd_mask});
+            nd_valid = nq.nd_out != nullptr;
             KCHK(ctx);
             ts.stop();
         }
@@ -1079,21 +1143,25 @@ static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky
         const u32 dm = (1u << w) - 1u;
         const int pshift = (int)ybits + 8 * j;                           // where digit j sits in the packed word
         if (first) hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, n, 0, cur_tiles, hist, (const SegTile *)d_tiles, dm, SlotSrc(), 0u, (u32)nbits);
+        else if (nd_valid) hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)nd, n, 0, cur_tiles, hist, (const SegTile *)d_tiles, dm, SlotSrc(), 0u, 0u, 2u);
         else hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, n, pshift, cur_tiles, hist, (const SegTile *)d_tiles, dm);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * cur_tiles, nullptr); if (rc) return rc;
         StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+        const UnpackParams nq = nd_of(j + 1);
         if (first) hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_PACK>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, k1, v1, pi, (u64 *)nullptr, n, pshift, cur_tiles, hist,
-                                      (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm, (u32)nbits});
+                                      (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm, (u32)nbits, nq.nd_out, nq.nd_shift, nq.nd_mask});
         else hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, (const u64 *)nullptr, po, (u64 *)nullptr, n, pshift, cur_tiles,
-                                hist, (const SegTile *)d_tiles, UnpackParams{0, 0, 0, dm});
+                                hist, (const SegTile *)d_tiles, UnpackParams{0, 0, 0, dm, 0, nq.nd_out, nq.nd_shift, nq.nd_mask});
         KCHK(ctx);
         ts.stop();
+        nd_valid = nq.nd_out != nullptr;
         ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (first ? 24 : 16) * n;
         if (!first) { u64 *t = pi; pi = po; po = t; }
     }
     if (d_c) sc.drop(d_c);
     sc.drop(d_tb);
+    if (nd) sc.drop(nd);
     sc.drop(hist); sc.drop((u32 *)d_tiles);
     *res = pi; *d_seg_start = d_b;
     return LRGE_OK;
@@ -1109,6 +1177,16 @@ static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64
     const u32 nb = (u32)div_up(n, RS_TILE), n_seg = 256u << e;
     const u32 max_tiles = nb + n_seg;
     ALLOC_OR_FAIL(hist, sc, u32, (u64)256 * (max_tiles + 1) + 256);
+    // next-pass digit bytes (UnpackParams::nd_out): every scatter that writes packed words also leaves the byte the NEXT pass ranks by, and
+    // that pass's histogram reads 1 byte per entry instead of 8 (option NO_DIGIT_BYTES: the histograms read the words, rounds 3-5)
+    u8 *nd = ctx->opt("NO_DIGIT_BYTES") ? nullptr : sc.get<u8>(n + 64);
+    if (!nd) { (void)hipGetLastError(); ctx->err.clear(); }
+    bool nd_valid = false;                             // nd holds the digits of the pass about to run
+    auto nd_of = [&](int j_next) -> UnpackParams {      // what the scatter in front of LSD pass j_next adds to its parameters
+        UnpackParams q{0, 0, 0, 0, 0, nullptr, 0, 0};
+        if (nd && j_next < passes) { const int w_ = nr - 8 * j_next >= 8 ? 8 : nr - 8 * j_next; q.nd_out = nd; q.nd_shift = ybits + 8u * (u32)j_next; q.nd_mask = (1u << w_) - 1u; }
+        return q;
+    };
     // ---- pass A: (DIG, word) by b0 ----
     {
         hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)dy, n, 8, nb, hist, (const SegTile *)nullptr, 255u, SlotSrc(), 0u, 0u, 1u);
@@ -1143,8 +1221,10 @@ static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64
         KCHK(ctx);
         {
             StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+            const UnpackParams nq = nd_of(0);
             hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_DWQ>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)d1, (const u64 *)k1, pi, (u64 *)nullptr, n, 8 - (int)e, cur_tiles, hist,
-                               (const SegTile *)d_tiles, UnpackParams{ybits, pos1, e, qm, (u32)nbits});
+                               (const SegTile *)d_tiles, UnpackParams{ybits, pos1, e, qm, (u32)nbits, nq.nd_out, nq.nd_shift, nq.nd_mask});
+            nd_valid = nq.nd_out != nullptr;
             KCHK(ctx);
             ts.stop();
         }
@@ -1161,21 +1241,25 @@ static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64
         const u32 dm = (1u << w) - 1u;
         const int pshift = (int)ybits + 8 * j;                           // where digit j sits in the packed word
         // (first: digit 0 of R lies in the word's own hash field -- nbits - 16 >= 8 is the caller's condition -- so the histogram reads the words)
-        hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, first ? k1 : pi, n, pshift, cur_tiles, hist, (const SegTile *)d_tiles, dm);
+        if (!first && nd_valid) hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)nd, n, 0, cur_tiles, hist, (const SegTile *)d_tiles, dm, SlotSrc(), 0u, 0u, 2u);
+        else hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, first ? k1 : pi, n, pshift, cur_tiles, hist, (const SegTile *)d_tiles, dm);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * cur_tiles, nullptr); if (rc) return rc;
         StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+        const UnpackParams nq = nd_of(j + 1);
         if (first) hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_DWP>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)d1, (const u64 *)k1, pi, (u64 *)nullptr, n, pshift, cur_tiles, hist,
-                                      (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm, (u32)nbits});
+                                      (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm, (u32)nbits, nq.nd_out, nq.nd_shift, nq.nd_mask});
         else hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, (const u64 *)nullptr, po, (u64 *)nullptr, n, pshift, cur_tiles,
-                                hist, (const SegTile *)d_tiles, UnpackParams{0, 0, 0, dm});
+                                hist, (const SegTile *)d_tiles, UnpackParams{0, 0, 0, dm, 0, nq.nd_out, nq.nd_shift, nq.nd_mask});
         KCHK(ctx);
         ts.stop();
+        nd_valid = nq.nd_out != nullptr;
         ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (first ? 20 : 16) * n;
         if (!first) { u64 *t = pi; pi = po; po = t; }
     }
     if (d_c) sc.drop(d_c);
     sc.drop(d_tb);
+    if (nd) sc.drop(nd);
     sc.drop(hist); sc.drop((u32 *)d_tiles);
     *res = pi; *d_seg_start = d_b;
     return LRGE_OK;

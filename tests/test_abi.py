@@ -80,3 +80,106 @@ def test_name_ranks_follow_strcmp():
     a, b = engine.name_ranks([b"r2", b"r10", b"R1"], [b"r10", b"a"])
     # byte order: "R1" < "a" < "r10" < "r2"
     assert a.tolist() == [4, 2, 0] and b.tolist() == [2, 1]
+
+
+# ---- the Rust seam (integration/liblrge_hip_shim.rs) against include/lrge_hip.h: the shim cannot be compiled here (no Rust toolchain in the
+# image), so at least its `extern "C"` block and its #[repr(C)] structs are held to the header by a parser: same symbols, same arity, the same
+# integer / float widths and pointer-ness per argument and return value, the same struct fields in the same order ----
+_C_KIND = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "float": "f32", "double": "f64", "void": "void",
+           "char": "i8"}
+_RS_KIND = {"c_int": "i32", "i32": "i32", "u32": "u32", "u64": "u64", "usize": "usize", "f32": "f32", "f64": "f64", "c_char": "i8", "c_void": "void"}
+
+
+def _c_decls():
+    txt = open(os.path.join(ROOT, "include", "lrge_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    out = {}
+    for m in re.finditer(r"\b((?:const\s+)?[A-Za-z_0-9]+\s*\**)\s*(lrge_hip_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+
+        def kind(t):
+            t = re.sub(r"\bconst\b", " ", t).strip()
+            t = re.sub(r"\[[^\]]*\]", "*", t)                      # array parameter = pointer
+            if "(" in t:
+                return "ptr"                                       # function pointer
+            if "*" in t:
+                return "ptr"
+            base = t.split()[0] if t.split() else "void"
+            return _C_KIND.get(base, "ptr" if base.endswith("_fn") else base)
+        arg_kinds = []
+        if args.strip() and args.strip() != "void":
+            depth, cur, parts = 0, "", []
+            for ch in args:
+                if ch == "(":
+                    depth += 1
+                if ch == ")":
+                    depth -= 1
+                if ch == "," and depth == 0:
+                    parts.append(cur); cur = ""
+                else:
+                    cur += ch
+            parts.append(cur)
+            for a in parts:
+                a = a.strip()
+                # drop the parameter name (the last identifier) unless the declaration is just a type
+                a2 = re.sub(r"\b[A-Za-z_][A-Za-z_0-9]*\s*(\[[^\]]*\])?$", lambda mm: (mm.group(1) or ""), a).strip() or a
+                arg_kinds.append(kind(a2 if a2 else a))
+        out[name] = (kind(ret), arg_kinds)
+    return out
+
+
+def _rs_decls():
+    txt = open(os.path.join(ROOT, "integration", "liblrge_hip_shim.rs")).read()
+    blk = re.search(r'extern "C" \{(.*?)\n\}', txt, flags=re.S).group(1)
+    blk = re.sub(r"//[^\n]*", "", blk)
+    out = {}
+    for m in re.finditer(r"fn\s+(lrge_hip_[a-z_0-9]+)\s*\((.*?)\)\s*(?:->\s*([^;]+))?;", blk, flags=re.S):
+        name, args, ret = m.group(1), m.group(2), (m.group(3) or "void").strip()
+
+        def kind(t):
+            t = t.strip()
+            if t.startswith("*"):
+                return "ptr"
+            return _RS_KIND.get(t, t)
+        arg_kinds = [kind(a.split(":", 1)[1]) for a in args.split(",") if ":" in a]
+        out[name] = (kind(ret), arg_kinds)
+    return out, txt
+
+
+def test_rust_shim_extern_block_matches_the_header():
+    c = _c_decls()
+    rs, txt = _rs_decls()
+    assert len(rs) >= 25 and {"lrge_hip_chains", "lrge_hip_paf_stats", "lrge_hip_overlap_twoset", "lrge_hip_index_build_tsharded"} <= set(rs)
+    for name, (ret, args) in rs.items():
+        assert name in c, "the shim binds %s, which include/lrge_hip.h does not declare" % name
+        cret, cargs = c[name]
+        assert ret == cret, (name, "return", ret, cret)
+        assert args == cargs, (name, "arguments", args, cargs)
+    # the #[repr(C)] structs: field names, order and widths
+    hdr = open(os.path.join(ROOT, "include", "lrge_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for sname in ("lrge_hip_params", "lrge_hip_chain"):
+        cm = re.search(r"typedef struct \{([^}]*)\}\s*%s;" % sname, hdr, flags=re.S).group(1)
+        cf = []
+        for line in cm.split(";"):
+            line = line.strip()
+            if not line:
+                continue
+            ty, names = line.split(None, 1)
+            cf += [(n.strip(), _C_KIND[ty]) for n in names.split(",")]
+        rm = re.search(r"pub struct %s \{([^}]*)\}" % sname, txt, flags=re.S).group(1)
+        rf = [(n, _RS_KIND[t]) for n, t in re.findall(r"pub\s+([a-z_0-9]+):\s*([a-z0-9_]+)", rm)]
+        assert rf == cf, (sname, rf, cf)
+    # the error codes the shim maps are the header's
+    codes = dict(re.findall(r"#define\s+(LRGE_ERR_[A-Z_]+)\s+\(?(-?\d+)\)?", open(os.path.join(ROOT, "include", "lrge_hip.h")).read()))
+    for code, variant in (("LRGE_ERR_IO", "IoError"), ("LRGE_ERR_PARSE", "FastqParseError"), ("LRGE_ERR_TOO_MANY", "TooManyReadsError"), ("LRGE_ERR_TOO_FEW", "TooFewReadsError"),
+                          ("LRGE_ERR_MAP", "MapError"), ("LRGE_ERR_DUPLICATE_ID", "DuplicateReadIdentifier"), ("LRGE_ERR_PAF_WRITE", "PafWriteError")):
+        assert code in codes, code
+        assert re.search(r"%s\s*=>\s*LrgeError::%s" % (re.escape(codes[code]), variant), txt), (code, codes[code], variant)
+
+
+def test_rust_shim_writes_overlaps_paf_where_the_reference_does():
+    txt = open(os.path.join(ROOT, "integration", "liblrge_hip_shim.rs")).read()
+    assert txt.count("write_overlaps_paf(job.tmpdir") == 3                 # forward, inverse, all-vs-all
+    assert 'tmpdir.join("overlaps.paf")' in txt and "tp:A:S" in txt and "f32::EPSILON" in txt

@@ -129,9 +129,9 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             segw = !pk && !ro && extra != ~0u && 2 * P.k >= 24 && !ctx->opt("NO_SEG_PACK") && !ctx->opt("NO_SEGW") && 2 * (u32)P.k - 16 + yb_p <= 64 &&
                    (double)targets->total_bases * dens >= (double)ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22);
         }
-        rc = sketch_device(ctx, sc, targets, preset, true, &so, (pk || segw) ? pk_pos1 : 0, segw ? pk_rid + pk_pos1 : pk_ybits, nullptr, keep_slots, segw);
+        rc = sketch_device(ctx, sc, targets, preset, true, &so, (pk || segw) ? pk_pos1 : 0, segw ? pk_rid + pk_pos1 : pk_ybits, nullptr, keep_slots, segw, /*wave_ok=*/segw);
         if (rc) return rc;
-        sc.drop(so.mz_off);
+        if (so.mz_off) sc.drop(so.mz_off);
     }
     u64 M = so.n;
     if (M >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "index limited to < 2^32 minimizers (got %llu)", (unsigned long long)M); return LRGE_ERR_TOO_MANY; }
@@ -295,19 +295,22 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             const bool extra_ok = extra_ != ~0u;
             const u32 extra = extra_ok ? extra_ : 0;
             if (so.segw && M == 0) {
-                // (nothing to sort: an empty pair stream is an empty SEGW stream)
+                // (nothing to sort: an empty pair stream is an empty SEGW stream; the wave-dense sketch left no dense arrays at all)
+                if (so.wave_x) { sc.drop(so.wave_x); sc.drop(so.wave_d); sc.drop(so.wave_cnt); sc.drop(so.wave_offs); skey = spos = k1; }
             } else if (so.segw) {
                 // (the sketch already wrote what pass A wants: decided above, whatever M turned out to be)
-                u32 *d1 = sc.get<u32>(M + 1);
+                const bool wave = so.wave_x != nullptr;          // (the wave-dense sketch: 16-bit DIG members, pass A reads the wavefronts' slots)
+                u32 *d1 = wave ? (u32 *)sc.get<wdig_t>(M + 2) : sc.get<u32>(M + 1);
                 if (!d1) return LRGE_ERR_DEVICE;
-                u64 *rk = nullptr;
-                rc = index_sort_segw(ctx, sc, so.x, (u32 *)so.y, k1, d1, M, 2 * P.k, yb_p, pk_pos1, extra, &rk, &d_seg_start);
+                u64 *rk = nullptr, *spare_ = nullptr;
+                WaveSrc ws{so.wave_x, so.wave_d, so.wave_cnt, so.wave_offs, so.n_waves, so.wave_cap};
+                rc = index_sort_segw(ctx, sc, so.x, (u32 *)so.y, k1, d1, M, 2 * P.k, yb_p, pk_pos1, extra, &rk, &d_seg_start, wave ? &ws : nullptr, &spare_);
                 if (rc) return rc;
                 h_seg_start.assign((256u << extra) + 1, 0u);
                 HIPCHK(ctx, ctx->d2h(h_seg_start.data(), d_seg_start, h_seg_start.size() * 4, ctx->stream));
                 seg_packed = true; kshift_t = yb_p; seg_e = extra;
                 skey = rk; spos = rk;
-                sc.drop(rk == so.x ? k1 : so.x); sc.drop((u32 *)so.y); sc.drop(d1);
+                sc.drop(spare_); if (so.y) sc.drop((u32 *)so.y); sc.drop(d1);
             } else if (pass_from == 0 && extra_ok && 2 * P.k > 16 && !ctx->opt("NO_SEG_PACK") && M >= ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22)) {
                 v1 = sc.get<u64>(M + 1); if (!v1) return LRGE_ERR_DEVICE;
                 u64 *rk = nullptr;

@@ -337,7 +337,9 @@ extern "C" int lrge_hip_index_dump(lrge_hip_ctx *ctx, const lrge_hip_index *ix, 
     }
     std::vector<u32> ord(ix->n_entries);
     for (u64 i = 0; i < ix->n_entries; ++i) ord[i] = (u32)i;
-    std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return hk[a] < hk[b]; });
+    // (by hash, then by y: the wave-dense sketch leaves the entries of equal hash inside one 8 192-base window in emission order, not in
+    // position order -- nothing on the device depends on that order, the dump presents the reference's)
+    std::sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return hk[a] != hk[b] ? hk[a] < hk[b] : hp[a] < hp[b]; });
     for (u64 i = 0; i < m; ++i) {
         if (keys) keys[i] = hk[ord[i]];
         if (pos) pos[i] = hp[ord[i]];

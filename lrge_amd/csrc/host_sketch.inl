@@ -10,12 +10,15 @@ struct SketchOut {
     // (chunk c at slots[c * SK_CAP ...), offs[] = exclusive scan of the per-chunk counts) and the index sort's first pass reads them there
     u64 *slots = nullptr; u32 *offs = nullptr; u32 n_chunks = 0;
     bool segw = false;                // y holds a u32 ARRAY: SEGW entries (k_sketch.h, sketch_write_chunk PK == 2): x = word, y[i] = the two sort digits
+    // wave-dense form (k_sketch.h: k_sketch_wave; SEGW entries only): x / y stay null -- wavefront v's entries sit, densely and in emission order,
+    // at wave_x / wave_d [v * wave_cap ...), wave_cnt[v] of them; the index sort's first pass reads them there (k_prims.h: index_sort_segw, WaveSrc)
+    u64 *wave_x = nullptr; wdig_t *wave_d = nullptr; u32 *wave_cnt = nullptr, *wave_offs = nullptr; u32 n_waves = 0, wave_cap = 0;      // wave_offs: exclusive scan of wave_cnt
 };
 
 // pk_ybits != 0 (index only): packed 8-byte entries in o->x, o->y stays null (k_sketch.h PK)
 template <int K, int W, bool HPC>
 static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, bool index_keys, SketchOut *o, u32 pk_pos1, u32 pk_ybits,
-                         std::vector<u32> *h_mzoff, bool gated = false, bool keep_slots = false, bool segw = false) {
+                         std::vector<u32> *h_mzoff, bool gated = false, bool keep_slots = false, bool segw = false, bool wave_ok = false) {
     // gated: the caller has NOT waited for the set's upload (seqset_ready): this function does, as late as it can -- chunk range by
     // chunk range behind the upload's gates where the form allows it
     if (s->n_chunks >= (1ULL << 32)) { LRGE_SET_ERR(ctx, "read set too large for one sketch launch"); return LRGE_ERR_TOO_MANY; }
@@ -64,6 +67,61 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     ALLOC_OR_FAIL(d_mzoff, sc, u32, (size_t)s->n + 1);
     ChunkMap cm{d_cs, s->n};
     const dim3 sgrid((u32)div_up(n_chunks, SK_THREADS));
+    u32 tot_ovf[2] = {0, 0};
+    // ---- wave-dense form (round 6): SEGW index entries written densely per wavefront, no compaction; see k_sketch_wave ----
+    // (option NO_WAVE_SKETCH: the slot-per-chunk forms below, rounds 2-5; WAVE_CAP: entries of room per wavefront, a multiple of 64, <= RS_TILE)
+    if (wave_ok && segw && n_chunks && !tile_form && !ctx->opt("DEBUG_SK_CAP") && !ctx->opt("NO_WAVE_SKETCH") && !ctx->opt("SKETCH_TWO_PASS") && !ctx->opt("DEBUG_SK_RANGE_CHUNKS")) {
+        const u32 n_waves = (u32)div_up(n_chunks, 64);
+        u32 capw = (u32)ctx->opt_u64("WAVE_CAP", HPC ? 2560 : 3328);
+        capw = std::max<u32>(64, capw / 64 * 64);
+        u64 *wx = sc.get<u64>((size_t)n_waves * capw + 8);
+        wdig_t *wd = wx ? sc.get<wdig_t>((size_t)n_waves * capw + 8) : nullptr;
+        u32 *wcnt = wd ? sc.get<u32>((size_t)n_waves + 1) : nullptr, *woffs = wcnt ? sc.get<u32>((size_t)n_waves + 1) : nullptr;
+        if (wx && wd && wcnt && woffs) {
+            HIPCHK(ctx, hipMemsetAsync(d_total, 0, 8, ctx->stream));
+            auto launch_wave = [&](u32 c0, u32 c1) {           // chunks [c0, c1), c0 a multiple of 64
+                if (c1 <= c0) return;
+                StageTimer tk(ctx, LRGE_T_K_SKETCH);
+                ctx->counters[LRGE_C_SKETCH_LAUNCHES] += 1;
+                hipLaunchKernelGGL((k_sketch_wave<K, W, HPC, 2>), dim3((u32)div_up(c1 - c0, SK_THREADS)), dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,
+                                   s->d_len, cm, c1, wcnt, d_total + 1, wx, wd, pk_pos1, pk_ybits, capw, c0);
+            };
+            u32 c_prev = 0;
+            if (gated && gjob) {
+                // (the set's upload is still in flight: the wavefronts whose 64 chunks lie wholly inside the words of upload chunk j run behind gate j)
+                const size_t ng = gjob->gate_w1.size();
+                for (size_t j = 0; j < ng && c_prev < n_chunks; ++j) {
+                    u32 c_end = chunks_behind(gjob->gate_w1[j]);
+                    if (c_end < n_chunks) c_end &= ~63u;
+                    if (c_end <= c_prev) continue;
+                    if (!gjob->wait_gate((int)j)) break;                         // (the job failed: seqset_ready below reports it)
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, gjob->gate_ev[j], 0));
+                    launch_wave(c_prev, c_end);
+                    KCHK(ctx);
+                    c_prev = c_end;
+                }
+            }
+            if (gated) { int rr = seqset_ready(ctx, s); if (rr) return rr; gated = false; }
+            launch_wave(c_prev, n_chunks);
+            KCHK(ctx);
+            int rc = scan_exclusive_u32(ctx, sc, wcnt, woffs, n_waves, d_total);
+            if (rc) return rc;
+            HIPCHK(ctx, ctx->d2h(tot_ovf, d_total, 8, ctx->stream));
+            HIPCHK(ctx, ctx->d2h_sync(ctx->stream));
+            if (!tot_ovf[1]) {
+                if (h_mzoff) h_mzoff->clear();
+                sc.drop(d_cnt); sc.drop(d_total); sc.drop(d_mzoff);
+                o->x = nullptr; o->y = nullptr; o->mz_off = nullptr; o->n = tot_ovf[0]; o->segw = true;
+                o->wave_x = wx; o->wave_d = wd; o->wave_cnt = wcnt; o->wave_offs = woffs; o->n_waves = n_waves; o->wave_cap = capw;
+                return LRGE_OK;
+            }
+            tot_ovf[0] = tot_ovf[1] = 0;          // a wavefront found more than its slot holds: the slot-per-chunk forms
+            sc.drop(wx); sc.drop(wd); sc.drop(wcnt); sc.drop(woffs);
+        } else {
+            if (wx) sc.drop(wx); if (wd) sc.drop(wd); if (wcnt) sc.drop(wcnt); if (woffs) sc.drop(woffs);
+            (void)hipGetLastError(); ctx->err.clear();
+        }
+    }
     // One pass (k_sketch_direct into per-chunk slots, then k_sketch_compact) when the slots fit comfortably; the
     // two-pass form (count, scan, write) otherwise, when a chunk overflows its slot, or on request.
     const u64 slot_bytes = (u64)n_chunks * SK_CAP * ebytes;
@@ -78,7 +136,6 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
         ty = pk ? nullptr : get_y((size_t)n_chunks * SK_CAP);
         if (!tx || (!pk && !ty)) { if (tx) sc.drop(tx); if (ty) sc.drop(ty); tx = ty = nullptr; one_pass = false; (void)hipGetLastError(); }
     }
-    u32 tot_ovf[2] = {0, 0};
     // chunks [c0, c1) into the slots sx / sy (indexed by chunk number), counts to d_cnt, overflow flag at d_total + 1
     auto launch_slots = [&](u32 c0, u32 c1, u64 *sx, u64 *sy, u32 capv) {
         if (c1 <= c0) return;
@@ -255,7 +312,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
 }
 
 static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *s, int preset, bool index_keys, SketchOut *o,
-                         u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr, bool keep_slots = false, bool segw = false) {
+                         u32 pk_pos1 = 0, u32 pk_ybits = 0, std::vector<u32> *h_mzoff = nullptr, bool keep_slots = false, bool segw = false, bool wave_ok = false) {
     // A set whose host-side pack is still running on the uploader thread (chunk gates: host_pack.h) is sketched chunk by chunk
     // behind its transfer -- index sketches only (a streamed set's upload hides behind the index build anyway).  Since round 4 also
     // VIEWS of such a set (the parts of a partitioned index: part 0 is sketched, sorted and tabled while parts 1.. still travel)
@@ -267,8 +324,8 @@ static int sketch_device(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     int rc = gated ? LRGE_OK : seqset_ready(ctx, s);
     if (rc) return rc;
     StageTimer t(ctx, LRGE_T_SKETCH);
-    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots, segw)
-                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots, segw);
+    rc = (preset == LRGE_PRESET_AVA_PB) ? sketch_launch<19, 5, true>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots, segw, wave_ok)
+                                            : sketch_launch<15, 5, false>(ctx, sc, s, index_keys, o, pk_pos1, pk_ybits, h_mzoff, gated, keep_slots, segw, wave_ok);
     t.stop();
     return rc;
 }

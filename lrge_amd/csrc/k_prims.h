@@ -279,6 +279,7 @@ struct UnpackParams {
     // nd_mask, one byte -- so that the next pass's histogram reads 1 byte per entry instead of the 8-byte key (k_rs_hist, key32 == 2).
     // The bytes of a (tile, digit) run are consecutive like its keys, and neighbouring tiles meet in one L2 (xcd_tile): whole lines go out.
     u8 *nd_out; u32 nd_shift, nd_mask;
+    u32 dig16;      // the DIG member of SEGW entries (RS_MODE_DW*: keys_in, and RS_MODE_DW's keys_out) is a u16 array instead of a u32 one (the wave-dense sketch's, round 6)
 };   // dmask: digit mask of the pass (the last digit may be narrower than 8 bits); nbits: hash bits (PACK / PACKQ)
 #define RS_MODE_PAIRS 0
 #define RS_MODE_KEYS 1
@@ -313,7 +314,16 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 nb) {
 // A sort whose FIRST pass reads the sketch's per-chunk slots in place of a dense array (k_sketch.h: k_sketch_direct writes chunk c's
 // entries to slots[c * cap ...), offs[] = exclusive scan of the per-chunk counts): dense index i lives in chunk c = the last one
 // with offs[c] <= i, at slots[c * cap + i - offs[c]].  What that saves is k_sketch_compact: one read and one write of every entry.
-struct SlotSrc { const u64 *slots; const u32 *offs; const u32 *tile_chunk; u32 n_chunks, cap, total; };
+// the DIG member of a wave-dense SEGW entry (k_sketch.h: k_sketch_wave): 16 bits suffice, but 2-byte loads and stores ... see DESIGN section 9
+#ifndef WAVE_DIG_BITS
+#define WAVE_DIG_BITS 32
+#endif
+#if WAVE_DIG_BITS == 16
+typedef u16 wdig_t;
+#else
+typedef u32 wdig_t;
+#endif
+struct SlotSrc { const u64 *slots; const u32 *offs; const u32 *tile_chunk; u32 n_chunks, cap, total; const wdig_t *dig; const u32 *tile_desc; };      // dig: the 16-bit DIG members beside the words (the wave-dense sketch's slots: RS_MODE_DW); tile_desc: see k_tile_desc
 #define SLOT_LDS 384        // chunk offsets a tile keeps in LDS (4096 entries span ~95 chunks of ~43; more: read from memory)
 
 // tile_chunk[t] = the chunk that holds dense index t * RS_TILE (the last c with offs[c] <= it)
@@ -330,7 +340,50 @@ __global__ __launch_bounds__(256) void k_tile_chunks(const u32 *__restrict__ off
 // The chunk offsets the tile needs sit in LDS behind a sentinel (the total); the chunk of a row's first entry moves on from the row
 // before (wave-uniform), the lanes of a row pick theirs among the one to three chunks the row spans.  A tile of more than SLOT_LDS - 2
 // chunks (tiny reads: chunks of a few entries) takes the general path: offsets from memory, one search per entry.
-__device__ __forceinline__ void rs_load_from_slots(const SlotSrc &S, u32 bid, u64 tile0, u32 n_tile, u32 *s_offs, u64 (&k)[RS_ITEMS], u64 fill) {
+// tile_desc[8 t ..]: the slot that holds dense index t * RS_TILE and the offsets of it and the six slots behind it (`total` beyond the last
+// slot) -- ONE 32-byte load tells a tile where its entries lie when it spans at most six slots (the wave-dense sketch's slots hold ~2 000-2 800
+// entries: a tile spans two or three).  The general path below fetches tile_chunk[t], then the offsets into LDS, then synchronises: three
+// dependent trips to memory in front of the tile's own loads, and pass A ran at half its dense speed through it (26 against 13 ms per
+// H. sapiens-scale part).
+__global__ __launch_bounds__(256) void k_tile_desc(const u32 *__restrict__ offs, u32 n_chunks, u32 total, u32 n_tiles, u32 *__restrict__ desc) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const u64 target = (u64)t * RS_TILE;
+    u32 lo = 0, hi = n_chunks - 1;
+    while (lo < hi) { const u32 mid = lo + (hi - lo + 1) / 2; if ((u64)offs[mid] <= target) lo = mid; else hi = mid - 1; }
+    uint4 a, b;
+    auto off_of = [&](u32 c) -> u32 { return c >= n_chunks ? total : offs[c]; };
+    a.x = lo; a.y = off_of(lo); a.z = off_of(lo + 1); a.w = off_of(lo + 2);
+    b.x = off_of(lo + 3); b.y = off_of(lo + 4); b.z = off_of(lo + 5); b.w = off_of(lo + 6);
+    ((uint4 *)desc)[2 * (size_t)t] = a; ((uint4 *)desc)[2 * (size_t)t + 1] = b;
+}
+
+// f(r, src): item r of this lane lives at index `src` of the slot arrays (called for the lane's valid items only, r a compile-time constant
+// after unrolling)
+template <typename F>
+__device__ __forceinline__ void rs_for_slot_items(const SlotSrc &S, u32 bid, u64 tile0, u32 n_tile, u32 *s_offs, F &&f) {
+    if (S.tile_desc) {
+        const uint4 a = ((const uint4 *)S.tile_desc)[2 * (size_t)bid], b = ((const uint4 *)S.tile_desc)[2 * (size_t)bid + 1];
+        const u32 last_ = (u32)tile0 + n_tile - 1;
+        if (b.w > last_) {                                               // (block-uniform) the tile lies inside slots a.x .. a.x + 5
+            const u32 l0_ = (threadIdx.x >> 6) * (RS_ITEMS * 64) + lane_id();
+#pragma unroll
+            for (int r = 0; r < RS_ITEMS; ++r) {
+                const u32 il = l0_ + (u32)r * 64;
+                if (il < n_tile) {
+                    const u32 i = (u32)tile0 + il;
+                    u32 j = 0, o = a.y;
+                    if (i >= a.z) { j = 1; o = a.z; }
+                    if (i >= a.w) { j = 2; o = a.w; }
+                    if (i >= b.x) { j = 3; o = b.x; }
+                    if (i >= b.y) { j = 4; o = b.y; }
+                    if (i >= b.z) { j = 5; o = b.z; }
+                    f(r, (u64)(a.x + j) * S.cap + (i - o));
+                }
+            }
+            return;
+        }
+    }
     const u32 c_lo = S.tile_chunk[bid];
     const u32 left = S.n_chunks - c_lo;                                  // offsets c_lo .. n_chunks - 1 exist; offs[n_chunks] = total
     const u32 n_l = left + 1 < SLOT_LDS ? left + 1 : SLOT_LDS;           // cached: s_offs[j] = off(c_lo + j), j < n_l
@@ -350,12 +403,11 @@ __device__ __forceinline__ void rs_load_from_slots(const SlotSrc &S, u32 bid, u6
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) {
             const u32 i0 = (u32)tile0 + w * (RS_ITEMS * 64) + (u32)r * 64, i = i0 + lane;
-            k[r] = fill;
             if (i0 > last) continue;                                     // (wave-uniform)
             while (s_offs[jr + 1] <= i0) ++jr;                           // wave-uniform: the sentinel stops it
             u32 jm = jr, jc = jr;
             while (s_offs[jc + 1] < i0 + 64 && jc + 1 < n_l - 1) { ++jc; if (i >= s_offs[jc]) jm = jc; }   // chunks that begin inside the row
-            if (i <= last) k[r] = S.slots[(u64)(c_lo + jm) * S.cap + (i - s_offs[jm])];
+            if (i <= last) f(r, (u64)(c_lo + jm) * S.cap + (i - s_offs[jm]));
         }
         return;
     }
@@ -364,15 +416,19 @@ __device__ __forceinline__ void rs_load_from_slots(const SlotSrc &S, u32 bid, u6
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const u32 il = w * (RS_ITEMS * 64) + (u32)r * 64 + lane;
-        k[r] = fill;
         if (il < n_tile) {
             const u32 i = (u32)tile0 + il;
             u32 lo = c, hi = S.n_chunks - 1;                             // last chunk with off <= i
             while (lo < hi) { const u32 mid = lo + (hi - lo + 1) / 2; if (off_of(mid) <= i) lo = mid; else hi = mid - 1; }
             c = lo;
-            k[r] = S.slots[(u64)c * S.cap + (i - off_of(c))];
+            f(r, (u64)c * S.cap + (i - off_of(c)));
         }
     }
+}
+__device__ __forceinline__ void rs_load_from_slots(const SlotSrc &S, u32 bid, u64 tile0, u32 n_tile, u32 *s_offs, u64 (&k)[RS_ITEMS], u64 fill) {
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) k[r] = fill;
+    rs_for_slot_items(S, bid, tile0, n_tile, s_offs, [&](int r, u64 src) { k[r] = S.slots[src]; });
 }
 
 // DB: digit bits.  The library launches 8 only; the 10-bit instantiation lives with the measurements that ruled it out
@@ -382,7 +438,7 @@ __device__ __forceinline__ void rs_load_from_slots(const SlotSrc &S, u32 bid, u6
 template <bool SEG, int DB = 8, bool SLOTS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, u64 n, int shift, u32 nb,
                                                         u32 *__restrict__ hist, const SegTile *__restrict__ tiles, u32 dmask = 255, SlotSrc src = SlotSrc(),
-                                                        u32 use_src = 0, u32 sig_nbits = 0, u32 key32 = 0) {       // key32 = 1: `keys` is a u32 array (the DIG member of SEGW entries); 2: a u8 array of ready-made digits
+                                                        u32 use_src = 0, u32 sig_nbits = 0, u32 key32 = 0) {       // key32 = 1: `keys` is a u32 array (the DIG member of SEGW entries); 3: a u16 array (the same, wave-dense form); 2: a u8 array of ready-made digits
     constexpr u32 ND = 1u << DB;
     static_assert(!SLOTS || !SEG, "slots feed whole (unsegmented) sorts only");
     __shared__ u32 h[ND];
@@ -419,11 +475,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
     }
     const u32 l0 = (threadIdx.x >> 6) * (RS_ITEMS * 64) + lane_id();
     u64 kk[RS_ITEMS];
-    if (SLOTS) rs_load_from_slots(src, bid, tile0, n_tile, s_offs, kk, 0ULL);
+    if (SLOTS && src.dig) {
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) kk[r] = 0;
+        rs_for_slot_items(src, bid, tile0, n_tile, s_offs, [&](int r, u64 si) { kk[r] = (u64)src.dig[si]; });
+    } else if (SLOTS) rs_load_from_slots(src, bid, tile0, n_tile, s_offs, kk, 0ULL);
     else {
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r)
-            kk[r] = l0 + (u32)r * 64 < n_tile ? (key32 ? (u64)((const u32 *)keys)[tile0 + l0 + (u32)r * 64] : keys[tile0 + l0 + (u32)r * 64]) : 0;
+            kk[r] = l0 + (u32)r * 64 < n_tile ? (key32 == 3 ? (u64)((const u16 *)keys)[tile0 + l0 + (u32)r * 64] : key32 ? (u64)((const u32 *)keys)[tile0 + l0 + (u32)r * 64] : keys[tile0 + l0 + (u32)r * 64]) : 0;
     }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r)
@@ -440,7 +500,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
                                                            u64 *__restrict__ keys_out, u64 *__restrict__ vals_out, u64 n,
                                                            int shift, u32 nb, const u32 *__restrict__ hist_scanned,
                                                            const SegTile *__restrict__ tiles, UnpackParams up, SlotSrc src = SlotSrc(), u32 use_src = 0) {
-    static_assert(!SLOTS || (!SEG && MODE == RS_MODE_KEYS), "slots feed whole keys-only sorts only");
+    static_assert(!SLOTS || (!SEG && (MODE == RS_MODE_KEYS || MODE == RS_MODE_DW)), "slots feed the first pass of whole sorts only: packed keys, or SEGW (DIG, word) entries");
     __shared__ u32 s_offs[SLOTS ? SLOT_LDS : 1];
     // 1. per-wave stable ranks (ballot digit matching + per-wave LDS counters)
     // 2. block-local destinations: the tile is first reordered through LDS so that each digit's
@@ -468,13 +528,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     u64 k[RS_ITEMS], v[RS_ITEMS];
     u32 rank[RS_ITEMS];
     // all loads of the tile are issued up front: the values arrive while the keys are being ranked
-    if (SLOTS) rs_load_from_slots(src, bid, tile0, n_tile, s_offs, k, ~0ULL);
+    if (SLOTS && MODE == RS_MODE_DW) {       // the wave-dense sketch's slots: 16-bit DIG members and the words, the same index in both arrays
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; ++r) { k[r] = ~0ULL; v[r] = 0; }
+        rs_for_slot_items(src, bid, tile0, n_tile, s_offs, [&](int r, u64 si) { k[r] = (u64)src.dig[si]; v[r] = src.slots[si]; });
+    } else if (SLOTS) rs_load_from_slots(src, bid, tile0, n_tile, s_offs, k, ~0ULL);
     else {
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r)
-            k[r] = l0 + (u32)r * 64 < n_tile ? (DWIN ? (u64)((const u32 *)keys_in)[base + (u64)r * 64] : keys_in[base + (u64)r * 64]) : ~0ULL;
+            k[r] = l0 + (u32)r * 64 < n_tile ? (DWIN ? (up.dig16 ? (u64)((const u16 *)keys_in)[base + (u64)r * 64] : (u64)((const u32 *)keys_in)[base + (u64)r * 64]) : keys_in[base + (u64)r * 64]) : ~0ULL;
     }
-    if (MODE == RS_MODE_PAIRS || MODE == RS_MODE_PACK || MODE == RS_MODE_PACKQ || DWIN) {
+    if ((MODE == RS_MODE_PAIRS || MODE == RS_MODE_PACK || MODE == RS_MODE_PACKQ || DWIN) && !(SLOTS && MODE == RS_MODE_DW)) {
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; ++r) v[r] = l0 + (u32)r * 64 < n_tile ? vals_in[base + (u64)r * 64] : 0;
     }
@@ -591,7 +655,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
             ko[r] = stage[p];
             u32 d = (u32)(ko[r] >> shift) & dmask;
             if (MODE == RS_MODE_PACKQ || MODE == RS_MODE_DWQ) d = sdig[p];
-            if (MODE == RS_MODE_DW) ((u32 *)keys_out)[gbase[d] + p] = (u32)ko[r];
+            if (MODE == RS_MODE_DW) { if (up.dig16) ((u16 *)keys_out)[gbase[d] + p] = (u16)ko[r]; else ((u32 *)keys_out)[gbase[d] + p] = (u32)ko[r]; }
             else keys_out[gbase[d] + p] = ko[r];
             if (MODE != RS_MODE_DW && MODE != RS_MODE_PAIRS && up.nd_out) up.nd_out[gbase[d] + p] = (u8)((u32)(ko[r] >> up.nd_shift) & up.nd_mask);
         }
@@ -805,45 +869,43 @@ __device__ __forceinline__ u32 hc_boundary_flags(const u32 *__restrict__ seg_sta
     return f;
 }
 
-__device__ __forceinline__ u32 hc_load_flags(const u64 *__restrict__ keys, u64 n, u32 shift, u64 base) {
-    // bit t set: element base + t starts a run
-    u32 f = 0;
-    if (base >= n) return 0;
-    u64 prev = base ? keys[base - 1] >> shift : 0;
-    const bool first = base == 0;
-    if (base + HC_ITEMS <= n) {
-        const ulonglong2 *p = (const ulonglong2 *)(keys + base);
-#pragma unroll
-        for (int t = 0; t < HC_ITEMS / 2; ++t) {
-            const ulonglong2 q = p[t];
-            const u64 a = q.x >> shift, b = q.y >> shift;
-            if (a != prev || (first && t == 0)) f |= 1u << (2 * t);
-            if (b != a) f |= 1u << (2 * t + 1);
-            prev = b;
-        }
-    } else {
-        for (int t = 0; t < HC_ITEMS && base + t < n; ++t) {
-            const u64 a = keys[base + t] >> shift;
-            if (a != prev || (first && t == 0)) f |= 1u << t;
-            prev = a;
-        }
-    }
-    return f;
-}
-
 // flags: the 16 head bits of every thread's line, kept for k_heads_fill (2 bytes instead of re-reading 128 bytes of keys)
+// Round 6: the keys are read COALESCED -- a wavefront owns 1024 consecutive keys and reads them as 16 rows of 64 (lane l, row r: key
+// 64 r + l), the predecessor of a key comes from the lane before (row r - 1's last lane, or one extra load in front of the wavefront),
+// and the head bits travel through one ballot per row into the thread-owned layout above (thread T owns keys 16 T .. 16 T + 15 of its
+// block: bits 16 (T & 3) .. of row T >> 2).  Before, every thread read its own 128-byte line with 16-byte loads: each load instruction
+// of a wavefront touched 64 lines, and the kernel ran at 2.5 TB/s (20 GB of keys per H. sapiens-scale part in 7.9 ms).
 __global__ __launch_bounds__(HC_THREADS) void k_heads_count(const u64 *__restrict__ keys, u64 n, u32 shift, u32 *__restrict__ bcount,
                                                             u16 *__restrict__ flags, const u32 *__restrict__ seg_start = nullptr, u32 n_seg = 0) {
     __shared__ u32 ws[HC_THREADS / 64];
+    __shared__ u64 ball[HC_THREADS / 64][HC_ITEMS];
+    static_assert(HC_ITEMS == 16, "a thread's flags are a u16");
+    const u32 w = threadIdx.x >> 6, lane = lane_id();
+    const u64 wbase = (u64)blockIdx.x * HC_TILE + (u64)w * (64 * HC_ITEMS);      // first key of the wavefront
+    u64 k[HC_ITEMS];
+#pragma unroll
+    for (int r = 0; r < HC_ITEMS; ++r) { const u64 i = wbase + (u64)r * 64 + lane; k[r] = i < n ? keys[i] >> shift : 0; }
+    u64 before = (wbase && wbase <= n) ? keys[wbase - 1] >> shift : 0;             // (wave-uniform address: one broadcast load)
+#pragma unroll
+    for (int r = 0; r < HC_ITEMS; ++r) {
+        const u64 i = wbase + (u64)r * 64 + lane;
+        u64 prev = (u64)(u32)__shfl_up((i32)(u32)k[r], 1, 64) | (u64)(u32)__shfl_up((i32)(u32)(k[r] >> 32), 1, 64) << 32;
+        if (lane == 0) prev = before;
+        const bool head = i < n && (i == 0 || k[r] != prev);
+        const u64 m = __ballot(head);
+        if (lane == 0) ball[w][r] = m;
+        before = (u64)(u32)__shfl((i32)(u32)k[r], 63, 64) | (u64)(u32)__shfl((i32)(u32)(k[r] >> 32), 63, 64) << 32;
+    }
+    // (a wavefront only reads its own row of `ball`: program order is enough, no barrier)
     const u64 base = (u64)blockIdx.x * HC_TILE + (u64)threadIdx.x * HC_ITEMS;
-    u32 f = hc_load_flags(keys, n, shift, base);
+    u32 f = (u32)(ball[w][lane >> 2] >> (16 * (lane & 3))) & 0xffffu;
     if (seg_start && base < n) f |= hc_boundary_flags(seg_start, n_seg, n, base);
     flags[(u64)blockIdx.x * HC_THREADS + threadIdx.x] = (u16)f;
     u32 c = (u32)__popc(f);
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-    if (lane_id() == 0) ws[threadIdx.x >> 6] = c;
+    if (lane == 0) ws[w] = c;
     __syncthreads();
-    if (threadIdx.x == 0) { u32 t = 0; for (int w = 0; w < HC_THREADS / 64; ++w) t += ws[w]; bcount[blockIdx.x] = t; }
+    if (threadIdx.x == 0) { u32 t = 0; for (int ww = 0; ww < HC_THREADS / 64; ++ww) t += ws[ww]; bcount[blockIdx.x] = t; }
 }
 
 __global__ __launch_bounds__(HC_THREADS) void k_heads_fill(const u16 *__restrict__ flags, const u32 *__restrict__ boff,
@@ -1170,9 +1232,15 @@ static int index_sort_segpacked(lrge_hip_ctx *ctx, Scratch &sc, u64 *kx, u64 *ky
 // The same sort over SEGW entries (RS_MODE_DW* above): wx = the words, dy = the u32 DIG array, both as the sketch left them; k1 / d1 =
 // buffers of n + 1 u64 / u32.  Pass A moves 12 bytes per entry instead of 16 (and its histogram reads 4 instead of 8), pass A2 / the
 // first LSD pass reads 12 instead of 16; from there on the entries are the packed words of index_sort_segpacked, bit for bit.
+// WaveSrc (round 6): pass A reads the wave-dense sketch's slots (k_sketch.h: k_sketch_wave) in place of the dense (wx, dy) arrays -- through
+// the slot-source form of its two kernels (SlotSrc) --, DIG members of 16 bits (d1 is then a u16 array too).  The slots are
+// released as soon as pass A has read them and the second word buffer is taken in their place; *spare = the word buffer that does not
+// hold the result.
+struct WaveSrc { u64 *wx; wdig_t *wd; u32 *cnt, *offs; u32 n_waves, cap; };      // offs: exclusive scan of cnt
 static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64 *k1, u32 *d1, u64 n, int nbits, u32 ybits, u32 pos1, u32 e,
-                           u64 **res, u32 **d_seg_start) {
+                           u64 **res, u32 **d_seg_start, const WaveSrc *ws = nullptr, u64 **spare = nullptr) {
     (void)pos1;
+    const u32 dig16 = (ws && sizeof(wdig_t) == 2) ? 1u : 0u, dkey = dig16 ? 3u : 1u;      // width of the DIG arrays (UnpackParams::dig16; k_rs_hist's key32)
     const int nr = nbits - 8 - (int)e, passes = (nr + 7) / 8;      // LSD passes over R
     const u32 nb = (u32)div_up(n, RS_TILE), n_seg = 256u << e;
     const u32 max_tiles = nb + n_seg;
@@ -1188,7 +1256,29 @@ static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64
         return q;
     };
     // ---- pass A: (DIG, word) by b0 ----
-    {
+    const u32 nbA = nb;
+    if (ws) {
+        // dense tiles of RS_TILE entries over the VIRTUAL dense array: entry i lives in the wavefront slot v = the last one with offs[v] <= i,
+        // at index v * cap + i - offs[v] (k_prims.h: SlotSrc / rs_for_slot_items; a tile spans two or three slots of ~2 000-2 800 entries).
+        // (One tile per slot -- half-full tiles, twice as many, digit runs of 8 entries -- took 34 ms per part instead of 16.)
+        ALLOC_OR_FAIL(tile_chunk, sc, u32, (size_t)nb + 1);
+        hipLaunchKernelGGL(k_tile_chunks, dim3((u32)div_up(nb, 256)), dim3(256), 0, ctx->stream, (const u32 *)ws->offs, ws->n_waves, nb, tile_chunk);
+        KCHK(ctx);
+        ALLOC_OR_FAIL(tile_desc, sc, u32, (size_t)nb * 8 + 8);
+        hipLaunchKernelGGL(k_tile_desc, dim3((u32)div_up(nb, 256)), dim3(256), 0, ctx->stream, (const u32 *)ws->offs, ws->n_waves, (u32)n, nb, tile_desc);
+        KCHK(ctx);
+        SlotSrc src{ws->wx, ws->offs, tile_chunk, ws->n_waves, ws->cap, (u32)n, ws->wd, tile_desc};
+        hipLaunchKernelGGL((k_rs_hist<false, 8, true>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)nullptr, n, 8, nb, hist, (const SegTile *)nullptr, 255u, src, 0u, 0u, dkey);
+        KCHK(ctx);
+        int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr); if (rc) return rc;
+        StageTimer ts(ctx, LRGE_T_RS_SCATTER);
+        hipLaunchKernelGGL((k_rs_scatter<false, RS_MODE_DW, 8, true>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)nullptr, (const u64 *)nullptr, (u64 *)d1, k1, n, 8, nb, hist,
+                           (const SegTile *)nullptr, UnpackParams{0, 0, 0, 255, 0, nullptr, 0, 0, dig16}, src);
+        KCHK(ctx);
+        ts.stop();
+        ctx->counters[LRGE_C_RS_SCATTER_LAUNCHES] += 1; ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n; ctx->counters[LRGE_C_RS_SCATTER_BYTES] += (dig16 ? 20 : 24) * n;
+        sc.drop(tile_chunk); sc.drop(tile_desc);
+    } else {
         hipLaunchKernelGGL(k_rs_hist<false>, dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)dy, n, 8, nb, hist, (const SegTile *)nullptr, 255u, SlotSrc(), 0u, 0u, 1u);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr); if (rc) return rc;
@@ -1202,7 +1292,7 @@ static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64
     u32 *d_b = sc.get<u32>(n_seg + 1), *d_c = e ? sc.get<u32>(257) : nullptr, *d_tb = sc.get<u32>(n_seg + 1);
     if (!d_b || !d_tb || (e && !d_c)) return LRGE_ERR_DEVICE;
     u32 *coarse = e ? d_c : d_b;                       // the 256 segments of pass A
-    hipLaunchKernelGGL(k_gather_strided_u32, dim3(1), dim3(256), 0, ctx->stream, hist, (u64)nb, 256u, coarse);
+    hipLaunchKernelGGL(k_gather_strided_u32, dim3(1), dim3(256), 0, ctx->stream, hist, (u64)nbA, 256u, coarse);
     hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, ctx->stream, coarse + 256, (u32)n);
     KCHK(ctx);
     ALLOC_OR_FAIL(d_tiles, sc, u32, (size_t)max_tiles * (sizeof(SegTile) / 4) + 8);
@@ -1210,11 +1300,16 @@ static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64
     hipLaunchKernelGGL(k_seg_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)coarse, 256u, d_tb);
     hipLaunchKernelGGL(k_seg_tile_fill, dim3(div_up(cur_tiles, 256)), dim3(256), 0, ctx->stream, (const u32 *)coarse, (const u32 *)d_tb, 256u, cur_tiles, (SegTile *)d_tiles);
     KCHK(ctx);
+    if (ws) {        // the slots have been read: they go, the second word buffer comes (in stream order: the arena recycles on ctx->stream)
+        sc.drop(ws->wx); sc.drop(ws->wd); sc.drop(ws->cnt); sc.drop(ws->offs);
+        wx = sc.get<u64>(n + 1);
+        if (!wx) return LRGE_ERR_DEVICE;
+    }
     u64 *pi = wx, *po = k1;          // (the sketch's word buffer is free once pass A has read it; k1 once the packing pass has)
     if (e) {
         // ---- pass A2: inside every segment by the top e bits of b1, packing ----
         const u32 qm = (1u << e) - 1;
-        hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)d1, n, 8 - (int)e, cur_tiles, hist, (const SegTile *)d_tiles, qm, SlotSrc(), 0u, 0u, 1u);
+        hipLaunchKernelGGL(k_rs_hist<true>, dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)d1, n, 8 - (int)e, cur_tiles, hist, (const SegTile *)d_tiles, qm, SlotSrc(), 0u, 0u, dkey);
         KCHK(ctx);
         int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * cur_tiles, nullptr); if (rc) return rc;
         hipLaunchKernelGGL(k_seg_fine_starts, dim3(div_up(n_seg + 1, 256)), dim3(256), 0, ctx->stream, (const u32 *)hist, (const u32 *)coarse, (const u32 *)d_tb, e, (u32)n, d_b);
@@ -1223,7 +1318,7 @@ static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64
             StageTimer ts(ctx, LRGE_T_RS_SCATTER);
             const UnpackParams nq = nd_of(0);
             hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_DWQ>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)d1, (const u64 *)k1, pi, (u64 *)nullptr, n, 8 - (int)e, cur_tiles, hist,
-                               (const SegTile *)d_tiles, UnpackParams{ybits, pos1, e, qm, (u32)nbits, nq.nd_out, nq.nd_shift, nq.nd_mask});
+                               (const SegTile *)d_tiles, UnpackParams{ybits, pos1, e, qm, (u32)nbits, nq.nd_out, nq.nd_shift, nq.nd_mask, dig16});
             nd_valid = nq.nd_out != nullptr;
             KCHK(ctx);
             ts.stop();
@@ -1248,7 +1343,7 @@ static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64
         StageTimer ts(ctx, LRGE_T_RS_SCATTER);
         const UnpackParams nq = nd_of(j + 1);
         if (first) hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_DWP>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)d1, (const u64 *)k1, pi, (u64 *)nullptr, n, pshift, cur_tiles, hist,
-                                      (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm, (u32)nbits, nq.nd_out, nq.nd_shift, nq.nd_mask});
+                                      (const SegTile *)d_tiles, UnpackParams{ybits, pos1, 0, dm, (u32)nbits, nq.nd_out, nq.nd_shift, nq.nd_mask, dig16});
         else hipLaunchKernelGGL((k_rs_scatter<true, RS_MODE_KEYS>), dim3(cur_tiles), dim3(RS_THREADS), 0, ctx->stream, pi, (const u64 *)nullptr, po, (u64 *)nullptr, n, pshift, cur_tiles,
                                 hist, (const SegTile *)d_tiles, UnpackParams{0, 0, 0, dm, 0, nq.nd_out, nq.nd_shift, nq.nd_mask});
         KCHK(ctx);
@@ -1262,5 +1357,6 @@ static int index_sort_segw(lrge_hip_ctx *ctx, Scratch &sc, u64 *wx, u32 *dy, u64
     if (nd) sc.drop(nd);
     sc.drop(hist); sc.drop((u32 *)d_tiles);
     *res = pi; *d_seg_start = d_b;
+    if (spare) *spare = po;
     return LRGE_OK;
 }

@@ -566,6 +566,56 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_direct(const u64 *__restr
     if (found > cap) *overflow = 1u;
 }
 
+// WAVE-DENSE form of the one-pass index sketch (round 6).  k_sketch_direct gives every chunk a slot of SK_CAP entries, a quarter to a third
+// full, and k_sketch_compact closes the gaps: one more read and write of every entry (45 ms of an H. sapiens-scale step).  Here a
+// WAVEFRONT owns a slot -- room for `cap` entries behind its 64 chunks -- and fills it densely: whenever some of its lanes reach an
+// emission site of the state machine together, one ballot ranks them, the wavefront's counter (LDS, volatile: lanes that sit at other
+// program points must see every update) moves on by their number, and they write consecutive entries -- 8-byte words (and, PK == 2, the
+// 16-bit digit pair) in runs that the L2 combines into whole lines.  No gaps inside a slot, `wave_cnt[wave]` entries in it: the index
+// sort's first pass reads the slots through its slot-source form (k_prims.h: SlotSrc, rs_for_slot_items) and no compaction runs.
+// The entries of a slot come in the order the lanes EMIT them, not in read order -- inside 8 192 bases.  The index does not care: the
+// sort is by hash, a key's position list is only ever expanded into anchors that are sorted by position again (k_seed.h), and
+// lrge_hip_index_dump orders its output by (hash, y) itself.  A wavefront that finds more than `cap` entries (never on real reads:
+// cap is 1.2-1.25x the mean of 2 040 / 2 780 per 8 192 bases with a deviation of ~50; low-complexity input can) raises *overflow and
+// the caller takes the slot-per-chunk path.
+template <int K, int W, bool HPC, int PK>
+__global__ __launch_bounds__(SK_THREADS) void k_sketch_wave(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,
+                                                           const u64 *__restrict__ woff, const u32 *__restrict__ lens,
+                                                           ChunkMap cm, u32 n_chunks, u32 *__restrict__ wave_cnt, u32 *__restrict__ overflow,
+                                                           u64 *__restrict__ out_x, wdig_t *__restrict__ out_d, u32 pk_pos1, u32 pk_ybits,
+                                                           u32 cap, u32 c_base /* a multiple of 64 */) {
+    static_assert(PK == 1 || PK == 2, "index entries only: packed words, or SEGW words + digit pairs");
+    __shared__ u32 s_cnt[SK_THREADS / 64];
+    const u32 w = threadIdx.x >> 6, lane = lane_id();
+    const u32 c0 = c_base + blockIdx.x * SK_THREADS + 64 * w;            // the wavefront's first chunk
+    if (c0 >= n_chunks) return;                                          // (wave-uniform)
+    volatile u32 *cnt = &s_cnt[w];
+    if (lane == 0) *cnt = 0;                                             // (same wavefront, in-order LDS: no barrier)
+    const u64 sbase = (u64)(c0 >> 6) * cap;
+    const u32 c = c0 + lane;
+    if (c < n_chunks) {
+        const u32 r = cm.find(c);
+        const i32 len = (i32)lens[r];
+        const i32 s = (i32)(c - cm.chunk_start[r]) * SK_CHUNK;
+        const i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
+        sketch_chunk<K, W, HPC>(pack, nmask, woff[r], len, r, s, e, [&](u64 x, u64 y) {
+            const u64 m = __ballot(1);                                   // the lanes at this emission site right now
+            const u32 b = *cnt;                                          // (one broadcast LDS read)
+            if (lane == (u32)__builtin_ctzll(m)) *cnt = b + (u32)__popcll(m);
+            const u32 idx = b + (u32)__popcll(m & lanemask_lt());
+            if (idx < cap) {
+                if (PK == 1) out_x[sbase + idx] = (x >> 8) << pk_ybits | (y >> 32) << pk_pos1 | (u64)(u32)y;
+                else {
+                    const u64 S = hash_to_sig(x >> 8, 2 * K);
+                    out_x[sbase + idx] = (S & ((1ULL << (2 * K - 16)) - 1)) << pk_ybits | (y >> 32) << pk_pos1 | (u64)(u32)y;
+                    out_d[sbase + idx] = (wdig_t)(S >> (2 * K - 16));
+                }
+            }
+        });
+    }
+    if (lane == 0) { const u32 t = *cnt; wave_cnt[c0 >> 6] = t; if (t > cap) *overflow = 1u; }
+}
+
 // Behind k_sketch_tile (HPC): the chunks it marked ST_REDO, the sequential way, with the tile form's attribution (POS_OWN above).
 template <int K, int W, bool INDEX_KEYS, int PK>
 __global__ __launch_bounds__(SK_THREADS) void k_sketch_redo(const u64 *__restrict__ pack, const u32 *__restrict__ nmask,

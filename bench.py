@@ -116,7 +116,22 @@ def main():
         q_lens, t_lens = q.lens(), t.lens()
     t_gen = time.perf_counter() - t_gen
 
+    # which side packs the reads on the host clock: the host's CPUs are shared by the ranks of this node (one process per GPU), and a rank
+    # with fewer than 8 of them ships ASCII over its own PCIe link and packs on the device (lrge_hip_pack_choice).
+    # The library reads LRGE_HIP_RANKS_ON_HOST when the context is created.
+    os.environ.setdefault("LRGE_HIP_RANKS_ON_HOST", str(int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     ctx = engine.Context(local_rank)
+    import ctypes as _C
+    from lrge_amd import _ffi as _ffi_
+    _gr = _C.c_double()
+    _roh = int(os.environ["LRGE_HIP_RANKS_ON_HOST"])
+    _host_side = bool(_ffi_.lib().lrge_hip_pack_choice(_roh, _C.byref(_gr)))
+    if os.environ.get("LRGE_HIP_PACK") in ("host", "device"):
+        _host_side = os.environ["LRGE_HIP_PACK"] == "host"
+    pack_info = {"chosen": "host (AVX2 2-bit pack, packed words over PCIe)" if _host_side else "device (ASCII over the rank's PCIe link, k_pack)",
+                 "granted_cpus": _gr.value, "ranks_on_host": _roh, "cpus_per_rank": _gr.value / max(1, _roh),
+                 "rule": "one rank: host; several: host only if every rank has 8 granted CPUs (LRGE_HIP_PACK overrides)",
+                 "applies_to": "reads handed over in host memory (the `host` clock); resident reads are packed on the device"}
     comm, transport, rccl_thread = None, None, None
     if use_dist:
         # torch.distributed only bootstraps (TCP store over gloo): the data-path collectives are the library's own RCCL
@@ -487,6 +502,7 @@ def main():
                                    % (a.config, gsize / 1e6, cfg["platform"], "--use-min-ref (index = queries, targets streamed)" if a.inverse else "forward",
                                       Qn, Tn, "ava-pb" if preset else "ava-ont", clock_txt),
                        "clock": "host" if clock_host else "resident",
+                       "pack": pack_info,
                        "query_reads": Qn, "target_reads": Tn,
                        "parallelism": ("one job, streamed targets cut into %d ranges by bases; query index replicated; counts all-reduced" % world) if a.inverse else
                                       ("one job, TARGETS cut into %d ranges by bases: every rank indexes its range and maps all queries (sketched once per world: every "

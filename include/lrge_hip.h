@@ -299,6 +299,10 @@ int  lrge_hip_comm_alltoallv(lrge_hip_comm *c, const void *send, const uint64_t 
  * lrge_hip_comm_destroy is still to be called. */
 int  lrge_hip_comm_abort(lrge_hip_comm *c);
 int  lrge_hip_comm_rccl_ranks(const lrge_hip_comm *c, int *n);
+/* librccl data-path calls (collectives, send / receive groups) made through c so far.  With LRGE_HIP_RCCL_WORLD1=1 (read when the RCCL
+   communicator is created) a world of ONE goes through librccl for every collective instead of the world-1 shortcuts -- what lets a
+   1-GPU box execute the RCCL branches with the shapes the sharded builds use (tests). */
+int  lrge_hip_comm_rccl_ops(const lrge_hip_comm *c, uint64_t *n);
 /* Timing emulation of a world on ONE GPU (local groups only): with serialize on, the ranks of the group take turns -- a rank
    computes between lrge_hip_comm_local_turn(c, 1) and (c, 0) and hands the GPU over whenever it waits for the others inside
    a collective; lrge_hip_comm_busy_ms returns the time it held the turn (what its share of the job takes on a GPU of its
@@ -339,6 +343,12 @@ int  lrge_hip_seqset_presketch(lrge_hip_ctx *ctx, lrge_hip_seqset *s, int preset
    fails the call on every rank (it ends with an agreement).  Sets of 2^32 bases or more: LRGE_ERR_TOO_MANY (they are streamed in views
    and sketched per view). */
 int  lrge_hip_seqset_presketch_sharded(lrge_hip_ctx *ctx, lrge_hip_seqset *s, int preset, lrge_hip_comm *comm);
+
+/* Host only: which side packs the reads of a set that starts in host memory when `ranks_on_host` ranks share this host's CPUs (option
+   LRGE_HIP_RANKS_ON_HOST, set by the launcher; LRGE_HIP_PACK = host | device overrides): 1 = the host (2-bit pack with AVX2, packed words
+   over PCIe), 0 = the device (ASCII over the rank's own PCIe link, k_pack).  *granted_cpus (may be NULL) receives the CPUs the host
+   grants this process (affinity mask and cgroup bandwidth).  The rule: one rank -> host; several -> host only if every rank has 8 CPUs. */
+int  lrge_hip_pack_choice(int ranks_on_host, double *granted_cpus);
 
 /* Host only: the k distinct indices in [0, n) that liblrge's sub-sampling draws (lib.rs:189-204), in the order
    rand 0.9.4's index::sample returns them (split_into_hashsets, twoset.rs:632-652, takes the LAST target_num_reads

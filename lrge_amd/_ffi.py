@@ -21,9 +21,9 @@ C_NAMES = ["query_bases", "query_minimizers", "anchors", "groups", "groups_chain
 EXPORTS = [
     "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error", "lrge_hip_ctx_set_option",
     "lrge_hip_seqset_upload", "lrge_hip_seqset_upload_async", "lrge_hip_seqset_wait", "lrge_hip_host_alloc",
-    "lrge_hip_host_free", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch", "lrge_hip_seqset_presketch_sharded",
+    "lrge_hip_host_free", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch", "lrge_hip_seqset_presketch_sharded", "lrge_hip_pack_choice",
     "lrge_hip_index_build", "lrge_hip_index_build_for", "lrge_hip_index_build_sharded", "lrge_hip_index_build_tsharded", "lrge_hip_last_shard_stats", "lrge_hip_index_free",
-    "lrge_hip_comm_alltoallv", "lrge_hip_comm_rccl_ranks", "lrge_hip_comm_local_group_serialize", "lrge_hip_comm_local_turn",
+    "lrge_hip_comm_alltoallv", "lrge_hip_comm_rccl_ranks", "lrge_hip_comm_rccl_ops", "lrge_hip_comm_local_group_serialize", "lrge_hip_comm_local_turn",
     "lrge_hip_comm_busy_ms", "lrge_hip_comm_standin_ms",
     "lrge_hip_comm_unique_id", "lrge_hip_comm_create", "lrge_hip_comm_local_group_create", "lrge_hip_comm_local_group_destroy",
     "lrge_hip_comm_create_local", "lrge_hip_comm_create_host", "lrge_hip_comm_destroy", "lrge_hip_comm_abort", "lrge_hip_comm_rank", "lrge_hip_comm_world",
@@ -83,6 +83,7 @@ def lib():
     L.lrge_hip_seqset_size.argtypes = [vp]
     L.lrge_hip_seqset_size.restype = C.c_uint32
     L.lrge_hip_seqset_presketch.argtypes = [vp, vp, C.c_int]
+    L.lrge_hip_pack_choice.argtypes = [C.c_int, C.POINTER(C.c_double)]
     L.lrge_hip_seqset_presketch_sharded.argtypes = [vp, vp, C.c_int, vp]
     L.lrge_hip_index_build.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
     L.lrge_hip_index_build_for.argtypes = [vp, vp, C.c_int, vp, vp, C.POINTER(vp)]
@@ -91,6 +92,7 @@ def lib():
     L.lrge_hip_last_shard_stats.argtypes = [vp, C.POINTER(C.c_uint64 * 8)]
     L.lrge_hip_comm_alltoallv.argtypes = [vp, vp, vp, vp, vp, C.c_size_t]
     L.lrge_hip_comm_rccl_ranks.argtypes = [vp, C.POINTER(C.c_int)]
+    L.lrge_hip_comm_rccl_ops.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.lrge_hip_comm_local_group_serialize.argtypes = [vp, C.c_int]
     L.lrge_hip_comm_local_turn.argtypes = [vp, C.c_int]
     L.lrge_hip_comm_busy_ms.argtypes = [vp, C.c_int]

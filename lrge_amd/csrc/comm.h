@@ -110,6 +110,11 @@ struct lrge_hip_comm {
     bool aborted = false;                // lrge_hip_comm_abort: every later collective of this communicator fails at once
     bool in_turn = false; double busy_ms = 0, t_acquired = 0, alloc_ms0 = 0;     // (serialized local groups)
     double wait_ms = 0;                   // wall time spent inside barriers of the local transport (waiting for the other ranks)
+    // option RCCL_WORLD1 (read when an RCCL communicator is created): a world of ONE still goes through librccl for every collective --
+    // ncclAllReduce / ncclAllGather of one rank, send / receive pairs with itself inside a group -- instead of the world-1 shortcuts, so
+    // that a 1-GPU box executes the RCCL branches of this file (staging, groups, abort) with the shapes the sharded builds use.
+    // rccl_ops counts the librccl data-path calls made (lrge_hip_comm_rccl_ops).
+    bool force = false; u64 rccl_ops = 0;
     double standin_ms = 0;                // (local transport) time inside the device-to-device copies that stand in for link transfers of comm_allgatherv: part of busy_ms, reported beside it
 };
 
@@ -152,7 +157,7 @@ static bool grp_barrier(lrge_hip_comm *c) {
 
 // a communicator this rank has aborted (lrge_hip_comm_abort) takes part in nothing any more
 #define COMM_LIVE(c)                                                                                                \
-    do { if ((c)->aborted && (c)->world > 1) { LRGE_SET_ERR((c)->ctx, "communicator was aborted"); return LRGE_ERR_DEVICE; } } while (0)
+    do { if ((c)->aborted && ((c)->world > 1 || (c)->force)) { LRGE_SET_ERR((c)->ctx, "communicator was aborted"); return LRGE_ERR_DEVICE; } } while (0)
 
 #define NCCLCHK(ctx, call)                                                                                          \
     do {                                                                                                            \
@@ -163,12 +168,15 @@ static bool grp_barrier(lrge_hip_comm *c) {
         }                                                                                                           \
     } while (0)
 
+static inline bool comm_solo(const lrge_hip_comm *c) { return c->world == 1 && !(c->force && c->nccl); }      // the world-1 shortcuts apply
+
 // In-place SUM all-reduce of n elements of `esz` bytes (4: u32, 8: u64) in DEVICE memory, ordered on `st`.
 static int comm_allreduce_sum(lrge_hip_comm *c, void *dbuf, size_t n, int esz, hipStream_t st) {
     lrge_hip_ctx *ctx = c->ctx;
     COMM_LIVE(c);
-    if (c->world == 1 || n == 0) return LRGE_OK;
+    if (comm_solo(c) || n == 0) return LRGE_OK;
     if (c->nccl) {
+        ++c->rccl_ops;
         NCCLCHK(ctx, g_rccl.AllReduce(dbuf, dbuf, n, esz == 8 ? LRGE_NCCL_UINT64 : LRGE_NCCL_UINT32, LRGE_NCCL_SUM, c->nccl, st));
         return LRGE_OK;
     }
@@ -200,8 +208,8 @@ static int comm_allgather(lrge_hip_comm *c, const void *dsend, size_t bytes, voi
     lrge_hip_ctx *ctx = c->ctx;
     COMM_LIVE(c);
     if (bytes == 0) return LRGE_OK;
-    if (c->world == 1) { HIPCHK(ctx, hipMemcpyAsync(drecv, dsend, bytes, hipMemcpyDeviceToDevice, st)); return LRGE_OK; }
-    if (c->nccl) { NCCLCHK(ctx, g_rccl.AllGather(dsend, drecv, bytes, LRGE_NCCL_UINT8, c->nccl, st)); return LRGE_OK; }
+    if (comm_solo(c)) { HIPCHK(ctx, hipMemcpyAsync(drecv, dsend, bytes, hipMemcpyDeviceToDevice, st)); return LRGE_OK; }
+    if (c->nccl) { ++c->rccl_ops; NCCLCHK(ctx, g_rccl.AllGather(dsend, drecv, bytes, LRGE_NCCL_UINT8, c->nccl, st)); return LRGE_OK; }
     if (c->grp && bytes >= ((size_t)64 << 10)) {
         // threads of one process, a large payload (the key sets of a sharded build): every rank copies the others' buffers
         // device to device instead of meeting in pageable host memory
@@ -260,9 +268,10 @@ static int comm_rccl_give_up(lrge_hip_comm *c, const char *what) {
 static int comm_allreduce_sum_host(lrge_hip_comm *c, void *hbuf, size_t n, int esz, hipStream_t st) {
     lrge_hip_ctx *ctx = c->ctx;
     COMM_LIVE(c);
-    if (c->world == 1 || n == 0) return LRGE_OK;
+    if (comm_solo(c) || n == 0) return LRGE_OK;
     const size_t bytes = n * (size_t)esz;
     if (c->nccl) {
+        ++c->rccl_ops;
         Scratch sc(ctx); char *d = nullptr;
         if (comm_small_stage(c, bytes, sc, &d)) return comm_rccl_give_up(c, "the staging allocation");
         if (hipMemcpyAsync(d, hbuf, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipGetLastError(); return comm_rccl_give_up(c, "the staging copy"); }
@@ -293,8 +302,9 @@ static int comm_allgather_host(lrge_hip_comm *c, const void *hsend, size_t bytes
     lrge_hip_ctx *ctx = c->ctx;
     COMM_LIVE(c);
     if (bytes == 0) return LRGE_OK;
-    if (c->world == 1) { memcpy(hrecv, hsend, bytes); return LRGE_OK; }
+    if (comm_solo(c)) { memcpy(hrecv, hsend, bytes); return LRGE_OK; }
     if (c->nccl) {
+        ++c->rccl_ops;
         Scratch sc(ctx); char *d = nullptr;
         if (comm_small_stage(c, bytes * ((size_t)c->world + 1), sc, &d)) return comm_rccl_give_up(c, "the staging allocation");
         if (hipMemcpyAsync(d, hsend, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipGetLastError(); return comm_rccl_give_up(c, "the staging copy"); }
@@ -319,7 +329,7 @@ static int comm_allgather_host(lrge_hip_comm *c, const void *hsend, size_t bytes
 // did -- so that a rank whose allocation or kernel failed does not leave the others blocked in the next collective.
 // One u32 all-reduce on a host word: no allocation, and no device round trip off RCCL.
 static int comm_agree(lrge_hip_comm *c, int rc, hipStream_t st) {
-    if (!c || c->world == 1) return rc;
+    if (!c || comm_solo(c)) return rc;
     lrge_hip_ctx *ctx = c->ctx;
     if (c->grp && rc) { c->grp->abort(); return rc; }                    // (threads of one process: wake the others directly)
     std::string mine = rc ? ctx->err : std::string();
@@ -343,17 +353,19 @@ static int comm_alltoallv(lrge_hip_comm *c, const void *dsend, const u64 *soff, 
     lrge_hip_ctx *ctx = c->ctx;
     COMM_LIVE(c);
     const int W = c->world, me = c->rank;
-    if (W == 1) {
+    if (comm_solo(c)) {
         const u64 n = soff[1] - soff[0];
         if (n) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[0] * esz, (const char *)dsend + soff[0] * esz, n * esz, hipMemcpyDeviceToDevice, st));
         return LRGE_OK;
     }
     if (c->nccl) {
+        const bool self = W == 1;        // (option RCCL_WORLD1: the rank's own share travels through a send / receive pair too)
+        ++c->rccl_ops;
         NCCLCHK(ctx, g_rccl.GroupStart());
         int gerr = 0;      // a failed Send / Recv must not leave the group open on this thread: later RCCL calls would queue silently
         for (int p = 0; p < W && !gerr; ++p) {
             const u64 ns = soff[p + 1] - soff[p], nr = roff[p + 1] - roff[p];
-            if (p == me) continue;
+            if (p == me && !self) continue;
             if (ns) gerr = g_rccl.Send((const char *)dsend + soff[p] * esz, ns * esz, LRGE_NCCL_UINT8, p, c->nccl, st);
             if (nr && !gerr) gerr = g_rccl.Recv((char *)drecv + roff[p] * esz, nr * esz, LRGE_NCCL_UINT8, p, c->nccl, st);
         }
@@ -363,7 +375,7 @@ static int comm_alltoallv(lrge_hip_comm *c, const void *dsend, const u64 *soff, 
             return LRGE_ERR_DEVICE;
         }
         const u64 n = soff[me + 1] - soff[me];
-        if (n) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[me] * esz, (const char *)dsend + soff[me] * esz, n * esz, hipMemcpyDeviceToDevice, st));
+        if (n && !self) HIPCHK(ctx, hipMemcpyAsync((char *)drecv + roff[me] * esz, (const char *)dsend + soff[me] * esz, n * esz, hipMemcpyDeviceToDevice, st));
         return LRGE_OK;
     }
     if (c->grp) {
@@ -422,14 +434,16 @@ static int comm_allgatherv(lrge_hip_comm *c, const GatherV *g, int k, hipStream_
     lrge_hip_ctx *ctx = c->ctx;
     COMM_LIVE(c);
     const int W = c->world, me = c->rank;
-    if (W == 1 || c->nccl) {
-        if (W > 1) {
+    if (comm_solo(c) || c->nccl) {
+        const bool self = W == 1 && !comm_solo(c);        // (option RCCL_WORLD1: the rank's own share travels through a send / receive pair)
+        if (W > 1 || self) {
+            ++c->rccl_ops;
             NCCLCHK(ctx, g_rccl.GroupStart());
             int gerr = 0;      // (a failed Send / Recv must not leave the group open on this thread)
             for (int j = 0; j < k && !gerr; ++j) {
                 const u64 n_mine = g[j].roff[me + 1] - g[j].roff[me];
                 for (int p = 0; p < W && !gerr; ++p) {
-                    if (p == me) continue;
+                    if (p == me && !self) continue;
                     const u64 nr = g[j].roff[p + 1] - g[j].roff[p];
                     if (n_mine) gerr = g_rccl.Send(g[j].send, n_mine * g[j].esz, LRGE_NCCL_UINT8, p, c->nccl, st);
                     if (nr && !gerr) gerr = g_rccl.Recv((char *)g[j].recv + g[j].roff[p] * g[j].esz, nr * g[j].esz, LRGE_NCCL_UINT8, p, c->nccl, st);
@@ -443,7 +457,7 @@ static int comm_allgatherv(lrge_hip_comm *c, const GatherV *g, int k, hipStream_
         }
         for (int j = 0; j < k; ++j) {
             const u64 n_mine = g[j].roff[me + 1] - g[j].roff[me];
-            if (n_mine && (const char *)g[j].send != (char *)g[j].recv + g[j].roff[me] * g[j].esz)
+            if (n_mine && !self && (const char *)g[j].send != (char *)g[j].recv + g[j].roff[me] * g[j].esz)
                 HIPCHK(ctx, hipMemcpyAsync((char *)g[j].recv + g[j].roff[me] * g[j].esz, g[j].send, n_mine * g[j].esz, hipMemcpyDeviceToDevice, st));
         }
         return LRGE_OK;

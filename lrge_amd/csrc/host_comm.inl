@@ -21,7 +21,7 @@ extern "C" int lrge_hip_comm_create(lrge_hip_ctx *ctx, int rank, int world, cons
     lrge_ncclUniqueId id;
     memcpy(id.internal, id128, 128);
     std::unique_ptr<lrge_hip_comm> c(new lrge_hip_comm());
-    c->ctx = ctx; c->rank = rank; c->world = world;
+    c->ctx = ctx; c->rank = rank; c->world = world; c->force = ctx->opt("RCCL_WORLD1") != nullptr;
     NCCLCHK(ctx, g_rccl.CommInitRank(&c->nccl, world, id, rank));
     if (hipMalloc((void **)&c->d_small, lrge_hip_comm::kSmall) != hipSuccess) { (void)hipGetLastError(); c->d_small = nullptr; }   // (then the pool serves)
     *out = c.release();
@@ -76,6 +76,12 @@ extern "C" int lrge_hip_comm_rccl_ranks(const lrge_hip_comm *c, int *n) {
     if (g_rccl.CommCount(c->nccl, n) != 0) { *n = 0; return LRGE_ERR_DEVICE; }
     return LRGE_OK;
 }
+// librccl data-path calls made through this communicator so far (tests: the RCCL branches really ran)
+extern "C" int lrge_hip_comm_rccl_ops(const lrge_hip_comm *c, uint64_t *n) {
+    if (!c || !n) return LRGE_ERR_INVALID;
+    *n = c->rccl_ops;
+    return LRGE_OK;
+}
 extern "C" int lrge_hip_comm_local_group_serialize(void *grp, int on) {
     if (!grp) return LRGE_ERR_INVALID;
     ((LocalGroup *)grp)->serialize = on != 0;
@@ -128,7 +134,7 @@ extern "C" int lrge_hip_comm_alltoallv(lrge_hip_comm *c, const void *send, const
 extern "C" int lrge_hip_comm_allreduce_u32(lrge_hip_comm *c, uint32_t *inout, size_t n) {
     if (!c || (n && !inout)) return LRGE_ERR_INVALID;
     lrge_hip_ctx *ctx = c->ctx;
-    if (c->world == 1 || n == 0) return LRGE_OK;
+    if (comm_solo(c) || n == 0) return LRGE_OK;
     if (c->nccl) HIPCHK(ctx, hipSetDevice(ctx->device));
     return comm_allreduce_sum_host(c, inout, n, 4, ctx->stream);
 }
@@ -137,7 +143,7 @@ extern "C" int lrge_hip_comm_allgather(lrge_hip_comm *c, const void *send, size_
     if (!c || (bytes && (!send || !recv))) return LRGE_ERR_INVALID;
     lrge_hip_ctx *ctx = c->ctx;
     if (bytes == 0) return LRGE_OK;
-    if (c->world == 1) { memcpy(recv, send, bytes); return LRGE_OK; }
+    if (comm_solo(c)) { memcpy(recv, send, bytes); return LRGE_OK; }
     if (c->nccl) HIPCHK(ctx, hipSetDevice(ctx->device));
     return comm_allgather_host(c, send, bytes, recv, ctx->stream);
 }

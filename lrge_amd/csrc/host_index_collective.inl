@@ -84,7 +84,7 @@ struct CollectiveGuard {
     void expect(int k, size_t n_ = 0, size_t at = 0) { next = k; n = n_; status_at = at; }
     void disarm() { next = NONE; }
     void join_failed() {
-        if (!c || c->world == 1 || next == NONE) { next = NONE; return; }
+        if (!c || comm_solo(c) || next == NONE) { next = NONE; return; }
         const int k = next; next = NONE;
         const std::string mine = c->ctx->err;            // (the join must not overwrite this rank's own error text)
         if (c->grp) c->grp->abort();

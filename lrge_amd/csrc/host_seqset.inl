@@ -102,6 +102,21 @@ static void parallel_memcpy(char *dst, const char *src, size_t n) {
     for (auto &x : th) x.join();
 }
 
+#define PACK_MIN_CPUS_PER_RANK 8.0
+// true: pack on the host (AVX2, host_pack.h) and send packed words; false: send the ASCII and run k_pack.  One rank on the host: always the
+// host (measured best: 0.375 B per base over PCIe instead of 1).  Several: only when every rank has PACK_MIN_CPUS_PER_RANK CPUs of its own.
+static bool pack_on_host(const char *opt, int ranks_on_host, double *granted) {
+    const double q = hp_cpu_quota();
+    if (granted) *granted = q;
+    if (opt && !strcmp(opt, "device")) return false;
+    if (opt && !strcmp(opt, "host")) return true;
+    if (ranks_on_host <= 1) return true;
+    return q / (double)ranks_on_host >= PACK_MIN_CPUS_PER_RANK;
+}
+extern "C" int lrge_hip_pack_choice(int ranks_on_host, double *granted_cpus) {
+    return pack_on_host(nullptr, ranks_on_host, granted_cpus) ? 1 : 0;
+}
+
 static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64_t *offsets, uint32_t n, const uint32_t *name_rank,
                               bool async, lrge_hip_seqset **out) {
     if (!ctx || !out || (n && (!bases || !offsets))) return LRGE_ERR_INVALID;
@@ -168,7 +183,11 @@ static int seqset_upload_impl(lrge_hip_ctx *ctx, const char *bases, const uint64
     const u8 *d_ascii = (const u8 *)src;
     // a set that starts in host memory is packed on the host and travels packed (host_pack.h); option NO_HOST_PACK sends the
     // ASCII and packs on the device as rounds 1-2 did
-    const bool host_pack = kind != 0 && s->total_bases > 0 && !ctx->opt("NO_HOST_PACK");
+    // Which side packs (round 6): the host-side pack needs CPUs -- 16 granted CPUs pack H. sapiens scale in 258 ms whatever the number of
+    // ranks (profiles/r05_pack_contention.json) -- so a rank that is granted fewer than PACK_MIN_CPUS_PER_RANK (8) of them ships the ASCII over
+    // its own PCIe link and runs k_pack (option PACK = host | device | auto; RANKS_ON_HOST = the ranks sharing this host's CPUs, set by the
+    // launcher: lrge_hip_pack_choice states the rule)
+    const bool host_pack = kind != 0 && s->total_bases > 0 && !ctx->opt("NO_HOST_PACK") && pack_on_host(ctx->opt("PACK"), (int)ctx->opt_u64("RANKS_ON_HOST", 1), nullptr);
     if (kind != 0 && s->total_bases && !host_pack) {
         s->stg_ascii = alloc(s->total_bases);
         if (!s->stg_ascii) { LRGE_SET_ERR(ctx, "seqset_upload: device allocation failed: %s", hipGetErrorString(e)); return LRGE_ERR_DEVICE; }

@@ -80,6 +80,13 @@ class _Comm:
         self.ctx._check(self.ctx._lib.lrge_hip_comm_rccl_ranks(self.h, C.byref(n)))
         return n.value
 
+    def rccl_ops(self):
+        """librccl data-path calls made through this communicator so far (lrge_hip_comm_rccl_ops)."""
+        import ctypes as C
+        n = C.c_uint64()
+        self.ctx._check(self.ctx._lib.lrge_hip_comm_rccl_ops(self.h, C.byref(n)))
+        return n.value
+
     def turn(self, begin):
         """Serialized local groups (timing emulation of a world on one GPU): take / give back the GPU."""
         self.ctx._lib.lrge_hip_comm_local_turn(self.h, 1 if begin else 0)

@@ -623,6 +623,90 @@ print("RCCL-OK", int(ref.sum()))
     assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
 
+def test_rccl_world1_forced_through_every_collective_shape():
+    """no multi-GPU node is available, so at least every RCCL BRANCH of comm.h runs on this box -- with
+    LRGE_HIP_RCCL_WORLD1=1 a world of one goes through librccl for every collective instead of the world-1 shortcuts: ncclAllReduce /
+    ncclAllGather on device and staged host vectors, the send / receive groups of the variable-size all-to-all and all-gather (a rank's own
+    share through a pair with itself), the agreements.  The three collective builds and the sharded query sketch give the one-GPU results
+    through it; every injected failure stage (and a device that refuses every allocation: the staging path) fails the call without a
+    hang and leaves a communicator that either still works or says it was aborted; lrge_hip_comm_abort makes every later collective
+    fail at once, and a fresh communicator works again.  (In a child: RCCL keeps process-wide state.)"""
+    code = r'''
+import numpy as np
+from lrge_amd import engine, parallel, synth, _ffi
+ctx = engine.Context(0)
+def fresh():
+    return parallel.RcclComm.create(ctx, 0, 1, parallel.RcclComm.unique_id(ctx))
+comm = fresh()
+ops0 = comm.rccl_ops()
+a = np.arange(1000, dtype=np.uint32)
+assert np.array_equal(comm.all_reduce_u32(a), a)
+e = np.linspace(0, 1, 37).astype(np.float32)
+assert np.array_equal(comm.all_gather_f32(e, 40, [37]), e)
+r, rc = comm.all_to_all_v(np.arange(77, dtype=np.uint64), [77])
+assert np.array_equal(r, np.arange(77, dtype=np.uint64)) and list(rc) == [77]
+assert comm.rccl_ops() >= ops0 + 3, comm.rccl_ops()
+g, q, t = synth.make_config("tiny_twoset")
+qr, tr = engine.name_ranks(q.names, t.names)
+Qd, Td = ctx.upload(q.bases, q.offsets, qr), ctx.upload(t.bases, t.offsets, tr)
+ix0 = engine.Index(ctx, Td, 0); ref = ix0.overlap_twoset(Qd)[0]; st = ix0.stats(); ix0.free()
+def build(kind):
+    if kind == "for":
+        return engine.Index(ctx, Td, 0, streamed=Qd, comm=comm)
+    if kind == "sharded":
+        return engine.Index(ctx, Td, 0, streamed=Qd, comm=comm, shard=(t.lens(), tr, 0))
+    Qd.presketch_sharded(0, comm)
+    return engine.Index(ctx, Td, 0, comm=comm, tshard=True)
+for kind in ("for", "sharded", "tshard"):
+    o0 = comm.rccl_ops()
+    ix = build(kind)
+    assert ix.stats() == st and np.array_equal(ix.overlap_twoset(Qd)[0], ref), kind
+    ix.free()
+    assert comm.rccl_ops() > o0, (kind, "no librccl call was made")
+# every failure stage of the three collective calls: an error, no hang; the communicator afterwards works or says it was aborted
+stages = [(s_, "sharded") for s_ in (1, 2, 3, 4, 5, 6, 7)] + [(s_, "tshard") for s_ in (10, 11, 12, 13, 14, 15, 16, 17, 20, 21, 22)] + [("alloc", "tshard"), ("alloc", "sharded")]
+n_err = 0
+for stage, kind in stages:
+    opts = {"DEBUG_ALLOC_FAIL_ALWAYS": "1"} if stage == "alloc" else {"DEBUG_SHARD_FAIL_AT": str(stage)}
+    if stage in (15, 17):
+        opts.update({"DEBUG_TS_MID_OCC": "1", "DEBUG_TS_LIST_CAP": "1"})
+    for k_, v_ in opts.items():
+        ctx.set_option(k_, v_)
+    try:
+        ix = build(kind); ix.free(); failed = False
+    except _ffi.LrgeHipError:
+        failed = True
+    for k_ in opts:
+        ctx.set_option(k_, None)
+    assert failed or stage in (6,), (stage, kind)        # (stage 6 belongs to the replicated-sketch build)
+    n_err += failed
+    try:
+        ix = build(kind)
+        assert ix.stats() == st and np.array_equal(ix.overlap_twoset(Qd)[0], ref), (stage, kind)
+        ix.free()
+    except _ffi.LrgeHipError as ex:
+        assert "abort" in str(ex).lower(), (stage, kind, str(ex))
+        comm.close(); comm = fresh()
+        ix = build(kind); assert np.array_equal(ix.overlap_twoset(Qd)[0], ref); ix.free()
+assert n_err >= len(stages) - 1
+comm.abort()
+try:
+    comm.all_reduce_u32(a); ok = False
+except _ffi.LrgeHipError:
+    ok = True
+assert ok, "an aborted communicator still ran a collective"
+comm.close()
+comm = fresh()
+assert np.array_equal(comm.all_reduce_u32(a), a)
+comm.close(); ctx.close()
+print("RCCL-FORCED-OK", n_err)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, LRGE_HIP_RCCL_WORLD1="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0 and "RCCL-FORCED-OK" in r.stdout, (r.stdout[-800:], r.stderr[-3000:])
+
+
 def test_bench_world2_on_one_gpu():
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with both ranks
     on this box's one GPU and the collectives on the host transport (RCCL refuses two ranks on one device): the strong-

@@ -292,3 +292,17 @@ def test_cross_shard_duplicate_target_names_are_refused():
         rank, world = 0, 2
     with pytest.raises(ValueError, match="Duplicate read identifier"):
         parallel.twoset_forward_target_sharded(lambda lo, hi: (np.zeros(3, np.uint32),) * 2, lens, World2(), t_ranks=np.array([0, 1, 2, 3, 4, 2, 6, 7]))
+
+
+def test_pack_side_rule():
+    """lrge_hip_pack_choice: one rank on the host packs on the host; several do only when every rank has 8 of the
+    CPUs the host grants (affinity mask and cgroup bandwidth) -- else the ASCII travels over each rank's own PCIe link and k_pack runs."""
+    import ctypes as C
+    from lrge_amd import _ffi
+    L = _ffi.lib()
+    g = C.c_double()
+    assert L.lrge_hip_pack_choice(1, C.byref(g)) == 1 and g.value >= 1.0
+    q = g.value
+    for w in (2, 4, 8, 64, 4096):
+        assert L.lrge_hip_pack_choice(w, None) == (1 if q / w >= 8.0 else 0), (w, q)
+    assert L.lrge_hip_pack_choice(4096, None) == 0

@@ -364,7 +364,7 @@ def main():
             if os.environ.get("LRGE_BENCH_TICKS") and not a.inverse:      # host wall time of the step's calls (where the GPU idles between two steps)
                 sys.stderr.write("[ticks] upload T %.2f | upload Q + hint %.2f | index %.2f | overlap %.2f | introspection + free %.2f | estimates %.2f | median %.2f ms\n"
                                  % ((_tb - _ta) * 1e3, (_t0 - _tb) * 1e3, (_t1 - _t0) * 1e3, (_t2 - _t1) * 1e3, (_t3 - _t2) * 1e3, (_t4 - _t3) * 1e3, (time.perf_counter() - _t4) * 1e3))
-            for k_ in ("rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "sketch_launches"):   # the index build sorts (and sketches) too
+            for k_ in ("rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "sketch_launches", "sketch_wave_launches"):   # the index build sorts (and sketches) too
                 cn[k_] = cn.get(k_, 0) + cb_.get(k_, 0)
             return counts, est_all, med, tb, tm, cn, st
 

@@ -46,7 +46,7 @@ def cpu_baseline(q, t, budget_s, preset):
         (np.concatenate(counts) if counts else np.zeros(0, np.uint32)), ix.mid_occ
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def _committed(config, inverse, preset_name=None):
@@ -54,7 +54,7 @@ def _committed(config, inverse, preset_name=None):
     this same command (tools/profile_round.sh).  A collection counts only if it is of this configuration, strategy AND preset."""
     names = []
     tail = "_inverse" if inverse else ""
-    for rnd in (PROFILE_ROUND, "r04"):       # (the newest committed collection of this configuration; the file's name is reported with the figures)
+    for rnd in (PROFILE_ROUND, "r05", "r04"):       # (the newest committed collection of this configuration; the file's name is reported with the figures)
         names += ["%s_hbm_traffic_%s%s_%s.json" % (rnd, config, tail, (preset_name or "").replace("ava-", "")), "%s_hbm_traffic_%s%s.json" % (rnd, config, tail),
                   "%s_hbm_traffic.json" % rnd]
     for name in names:
@@ -348,10 +348,12 @@ def roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb
     if acc_cn.get("lpg_launches", 0):
         cands.append(roof("k_chain_lpg", acc_tm.get("chain_lpg", 0.0), acc_cn["lpg_launches"], 16.0 * acc_cn.get("lpg_anchors", 0),
                           "16 B x anchors chained by the launch (SURVEY 8d: anchor in for chaining)", bound="valu"))
-    if acc_cn.get("sketch_launches", 0) and acc_tb.get("k_sketch", 0.0) > 0 and world == 1:
-        # the one-pass index sketch kernel, event pairs around its launches (timer level 2): SURVEY 8(d)'s B_idx = L_T / 4 + 16 M_T dealt over them
+    n_sk = acc_cn.get("sketch_launches", 0) + acc_cn.get("sketch_wave_launches", 0)
+    if n_sk and acc_tb.get("k_sketch", 0.0) > 0 and world == 1:
+        # the one-pass index sketch kernel (k_sketch_wave: the wave-dense form, round 6; k_sketch_direct where that does not apply), event pairs
+        # around its launches (timer level 2): SURVEY 8(d)'s B_idx = L_T / 4 + 16 M_T dealt over them
         L_idx_ = float((q_lens if a.inverse else t_lens).sum())
-        cands.append(roof("k_sketch_direct", acc_tb["k_sketch"], acc_cn["sketch_launches"], (L_idx_ / 4.0 + 16.0 * float(st["n_minimizers"])) * K,
+        cands.append(roof("k_sketch_wave" if acc_cn.get("sketch_wave_launches", 0) >= acc_cn.get("sketch_launches", 0) else "k_sketch_direct", acc_tb["k_sketch"], n_sk, (L_idx_ / 4.0 + 16.0 * float(st["n_minimizers"])) * K,
                           "SURVEY 8d's B_idx: L_T / 4 B of packed bases in + 16 B per index minimizer out, dealt over the launches", bound="valu"))
     n_idx = float(st["n_minimizers"]) if not (world > 1 and not a.inverse) else float(acc_cn.get("rs_scatter_items", 0)) / max(1, K) / 4.0
     entry_b = 8.0 if (2 * (19 if preset else 15) + int(np.ceil(np.log2((Qn if a.inverse else Tn) + 1))) + int(np.ceil(np.log2(float((q_lens if a.inverse else t_lens).max()) + 1))) + 1) <= 64 else 16.0
@@ -360,7 +362,7 @@ def roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb
                          "%d B in + %d B out per index entry: one read and one write of every entry" % (entry_b, entry_b)))
     if acc_tb.get("sketch", 0.0) > 0 and world == 1:
         L_idx = float((q_lens if a.inverse else t_lens).sum())
-        fams.append(roof("index sketch (k_sketch_direct + k_sketch_compact)", acc_tb["sketch"], K, (L_idx / 4.0 + entry_b * n_idx) * K,
+        fams.append(roof("index sketch (K1: k_sketch_wave, or k_sketch_direct + k_sketch_compact)", acc_tb["sketch"], K, (L_idx / 4.0 + entry_b * n_idx) * K,
                          "L/4 B of packed bases in + %d B per minimizer out" % entry_b))
     if acc_tm.get("anchor_sort", 0.0) > 0:
         fams.append(roof("anchor sort (k_seg_sort_local / k_rs_hist + scan + k_rs_scatter)", acc_tm["anchor_sort"], K, 24.0 * acc_cn.get("anchors_kept", acc_cn.get("anchors", 0)),

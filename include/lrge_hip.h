@@ -86,7 +86,7 @@ enum {
     LRGE_T_CHAIN_GLB /* (unused: retired kernel) */, LRGE_T_COUNT, LRGE_T_TOTAL,
     LRGE_T_CHAIN_LPG, LRGE_T_RS_SCATTER, LRGE_T_K_LOOKUP /* k_lookup alone (it also counts inside LRGE_T_LOOKUP) */,
     LRGE_T_INDEX_RESTRICT /* lrge_hip_index_build_for: entry filter + global occurrence statistics */,
-    LRGE_T_K_SKETCH /* k_sketch_direct alone: the one-pass sketch kernel's launches (they also count inside LRGE_T_SKETCH) */, LRGE_T_N
+    LRGE_T_K_SKETCH /* the one-pass index sketch kernel alone (k_sketch_wave, or k_sketch_direct: see the two launch counters; they also count inside LRGE_T_SKETCH) */, LRGE_T_N
 };
 /* Work counters of the last overlap call (for the roofline's algorithmic bytes). */
 enum {
@@ -106,6 +106,7 @@ enum {
     LRGE_C_INDEX_PARTS /* parts of the (partitioned) index the last overlap call went through, 0 = one index: LRGE_C_QUERY_MINIMIZERS and
                           LRGE_C_LOOKUP_LAUNCHES count every streamed minimizer once PER PART */,
     LRGE_C_SKETCH_LAUNCHES /* k_sketch_direct launches of the last index build / overlap call (LRGE_T_K_SKETCH) */,
+    LRGE_C_SKETCH_WAVE_LAUNCHES /* k_sketch_wave launches (the wave-dense form of the index sketch; LRGE_T_K_SKETCH times whichever ran) */,
     LRGE_C_N
 };
 

@@ -16,7 +16,7 @@ T_NAMES = ["pack", "sketch", "index_sort", "index_table", "qfilter", "lookup", "
            "chain", "chain_glb", "count", "total", "chain_lpg", "rs_scatter", "k_lookup", "index_restrict", "k_sketch"]
 C_NAMES = ["query_bases", "query_minimizers", "anchors", "groups", "groups_chained", "chain_launches", "batches",
            "chain_anchors", "chain_glb_launches", "chain_glb_anchors", "lpg_launches", "lpg_anchors",
-           "rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "lpg_split", "lookup_launches", "table_disp_sum", "anchors_kept", "index_parts", "sketch_launches"]
+           "rs_scatter_launches", "rs_scatter_items", "rs_scatter_bytes", "lpg_split", "lookup_launches", "table_disp_sum", "anchors_kept", "index_parts", "sketch_launches", "sketch_wave_launches"]
 
 EXPORTS = [
     "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error", "lrge_hip_ctx_set_option",

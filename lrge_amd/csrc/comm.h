@@ -168,7 +168,7 @@ static bool grp_barrier(lrge_hip_comm *c) {
         }                                                                                                           \
     } while (0)
 
-static inline bool comm_solo(const lrge_hip_comm *c) { return c->world == 1 && !(c->force && c->nccl); }      // the world-1 shortcuts apply
+static inline bool comm_solo(const lrge_hip_comm *c) { return c->world == 1 && !c->force; }      // the world-1 shortcuts apply
 
 // In-place SUM all-reduce of n elements of `esz` bytes (4: u32, 8: u64) in DEVICE memory, ordered on `st`.
 static int comm_allreduce_sum(lrge_hip_comm *c, void *dbuf, size_t n, int esz, hipStream_t st) {

@@ -82,7 +82,7 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
             auto launch_wave = [&](u32 c0, u32 c1) {           // chunks [c0, c1), c0 a multiple of 64
                 if (c1 <= c0) return;
                 StageTimer tk(ctx, LRGE_T_K_SKETCH);
-                ctx->counters[LRGE_C_SKETCH_LAUNCHES] += 1;
+                ctx->counters[LRGE_C_SKETCH_WAVE_LAUNCHES] += 1;
                 hipLaunchKernelGGL((k_sketch_wave<K, W, HPC, 2>), dim3((u32)div_up(c1 - c0, SK_THREADS)), dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,
                                    s->d_len, cm, c1, wcnt, d_total + 1, wx, wd, pk_pos1, pk_ybits, capw, c0);
             };

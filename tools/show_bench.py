@@ -15,9 +15,15 @@ for f in sys.argv[1:]:
     w = d["work_per_step"]
     print("  work", {k: w.get(k) for k in ("anchors", "anchors_kept", "groups", "groups_chained", "chain_anchors", "batches", "lpg_split")})
     ro = d["roofline"]
-    print("  roofline", ro["kernel"], r(ro["ms_per_step"]), round(ro["frac"], 4), "traffic", ro.get("traffic"), "| whole path frac", round(ro["whole_path_frac"], 4))
-    for o in d["roofline_other"]:
-        print("     ", o["kind"], o["kernel"][:44], r(o["ms_per_step"]), round(o["frac"], 4))
+    print("  roofline", ro["kernel"], r(ro.get("avg_launch_ms")), "frac", round(ro["frac"], 4), "achieved GB/s", r(ro["achieved"]))
+    dk = d.get("roofline_dominant_kernel")
+    for o in ([dk] if dk else []) + d["roofline_other"]:
+        print("     ", o.get("kind"), o["kernel"][:44], o.get("bound"), r(o["ms_per_step"]), round(o["frac"], 4))
+    fc = d.get("from_committed_profiles") or {}
+    if fc.get("valu_issue"):
+        print("  valu issue", {k: round(v["issue_frac"], 3) for k, v in fc["valu_issue"].items()})
+    if d.get("config", {}).get("pack"):
+        print("  pack", d["config"]["pack"]["chosen"], "granted", d["config"]["pack"]["granted_cpus"])
     if d.get("parity_vs_oracle_sample"):
         print("  parity", {k: v for k, v in d["parity_vs_oracle_sample"].items() if k != "oracle"})
     if d.get("cpu_baseline"):

@@ -83,7 +83,8 @@ per_step = max(1.0, float(bench.get("work_per_step", {}).get("lookup_launches", 
 steps_in_pass = max(1, int(round((look[0]["FETCH_SIZE"][0] if look else per_step) / per_step)))
 tot_f = sum(v["FETCH_SIZE"][1] for v in fetch.values() if "FETCH_SIZE" in v) * 1024 / steps_in_pass
 tot_w = sum(v["WRITE_SIZE"][1] for v in write.values() if "WRITE_SIZE" in v) * 1024 / steps_in_pass
-alg = bench.get("roofline", {}).get("whole_path_alg_GBps", 0.0) * bench.get("ms_per_step", 0.0) * 1e-3
+ro_ = bench.get("roofline", {})
+alg = (ro_.get("alg_GB_per_step") if ro_.get("alg_GB_per_step") is not None else ro_.get("whole_path_alg_GBps", 0.0) * bench.get("ms_per_step", 0.0) * 1e-3)       # (round 6: `roofline` is the whole-path block)
 cfg_name = (bench.get("config", {}).get("workload") or "").split(":")[0]
 out.update({"config": cfg_name, "inverse": "--use-min-ref" in (bench.get("config", {}).get("workload") or ""), "steps_in_pass": steps_in_pass,
             "clock": bench.get("config", {}).get("clock"), "fetch_GB_per_step": tot_f / 1e9, "write_GB_per_step": tot_w / 1e9, "algorithmic_GB_per_step": alg,

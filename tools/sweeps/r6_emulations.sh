@@ -15,9 +15,9 @@ except Exception as e: print('$1', 'unreadable', e)
 export LRGE_BENCH_EMULATE_TIMEOUT=600
 for w in $what; do
   case $w in
-    fwd) timeout 900 python bench.py --emulate-world 8 --clock resident --steps 2 --warmup 1 > $out/fwd_resident.json 2> $out/fwd_resident.err; show $out/fwd_resident.json;;
-    fwdold) LRGE_BENCH_NO_QSHARD=1 timeout 900 python bench.py --emulate-world 8 --clock resident --steps 2 --warmup 1 > $out/fwd_resident_noqshard.json 2> $out/fwd_resident_noqshard.err; show $out/fwd_resident_noqshard.json;;
-    fwdhost) timeout 900 python bench.py --emulate-world 8 --clock host --steps 2 --warmup 1 > $out/fwd_host.json 2> $out/fwd_host.err; show $out/fwd_host.json;;
-    inv) timeout 900 python bench.py --emulate-world 8 --inverse --clock resident --steps 2 --warmup 1 > $out/inv_resident.json 2> $out/inv_resident.err; show $out/inv_resident.json;;
+    fwd) timeout 900 python bench.py --emulate-world 8 --clock resident --steps 3 --warmup 1 > $out/fwd_resident.json 2> $out/fwd_resident.err; show $out/fwd_resident.json;;
+    fwdold) LRGE_BENCH_NO_QSHARD=1 timeout 900 python bench.py --emulate-world 8 --clock resident --steps 3 --warmup 1 > $out/fwd_resident_noqshard.json 2> $out/fwd_resident_noqshard.err; show $out/fwd_resident_noqshard.json;;
+    fwdhost) timeout 900 python bench.py --emulate-world 8 --clock host --steps 3 --warmup 1 > $out/fwd_host.json 2> $out/fwd_host.err; show $out/fwd_host.json;;
+    inv) timeout 900 python bench.py --emulate-world 8 --inverse --clock resident --steps 3 --warmup 1 > $out/inv_resident.json 2> $out/inv_resident.err; show $out/inv_resident.json;;
   esac
 done

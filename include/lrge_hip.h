@@ -345,6 +345,14 @@ int  lrge_hip_seqset_presketch(lrge_hip_ctx *ctx, lrge_hip_seqset *s, int preset
    and sketched per view). */
 int  lrge_hip_seqset_presketch_sharded(lrge_hip_ctx *ctx, lrge_hip_seqset *s, int preset, lrge_hip_comm *comm);
 
+/* Host only: every record of an input file in any format liblrge accepts (io.rs:35-184: FASTA / FASTQ, SAM, unaligned BAM, unaligned
+   CRAM 3.0; plain, gzip, bzip2, xz, zstd) through cb(user, name, name length, bases, base count) -- the C++ readers of
+   include/lrge_io.hpp / lrge_cram.hpp behind a C entry point, for hosts that do not parse a format themselves.  A mapped record
+   is refused with the reference's message (io.rs:162-167).  LRGE_ERR_IO: the file cannot be read; LRGE_ERR_PARSE: malformed
+   input; the message goes to errbuf (may be NULL). */
+int  lrge_hip_read_records(const char *path, void (*cb)(void *user, const char *name, uint64_t name_len, const char *bases, uint64_t n_bases),
+                           void *user, char *errbuf, uint64_t errcap);
+
 /* Host only: which side packs the reads of a set that starts in host memory when `ranks_on_host` ranks share this host's CPUs (option
    LRGE_HIP_RANKS_ON_HOST, set by the launcher; LRGE_HIP_PACK = host | device overrides): 1 = the host (2-bit pack with AVX2, packed words
    over PCIe), 0 = the device (ASCII over the rank's own PCIe link, k_pack).  *granted_cpus (may be NULL) receives the CPUs the host

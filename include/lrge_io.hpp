@@ -11,7 +11,8 @@
 // piece (the strategies keep every sampled read in memory anyway).  gzip (incl. BGZF and multi-member) goes through
 // zlib; bzip2 / xz / zstd through the system's shared libraries, bound at run time because this image ships them
 // without headers (libbz2.so.1, liblzma.so.5, libzstd.so.1) -- a missing library is an error naming it, never a
-// silent fallback.  CRAM is recognised and refused: its codecs (rANS, external reference) are out of scope.
+// silent fallback.  Unaligned CRAM 3.0 (round 6): lrge_cram.hpp -- containers, every encoding of the specification, raw / gzip / bzip2 /
+// lzma / rANS 4x8 blocks; CRAM 3.1's extra codecs are an error naming the codec.
 #pragma once
 #include <dlfcn.h>
 #include <zlib.h>
@@ -320,12 +321,18 @@ inline void parse_bam(const std::string &d, const Callback &cb) {
 }
 }  // namespace detail
 
+}  // namespace io
+}  // namespace lrge
+#include "lrge_cram.hpp"
+namespace lrge {
+namespace io {
+
 inline void iter_records(const std::string &path, const Callback &cb) {   // io.rs:154-184
     std::string data = decompress(slurp(path));
     switch (sniff(data)) {
     case Kind::Bam: detail::parse_bam(data, cb); break;
     case Kind::Sam: detail::parse_sam(data, cb); break;
-    case Kind::Cram: throw IoError("CRAM input is recognised but not supported by this build (convert with `samtools fastq`)");
+    case Kind::Cram: cram::parse(data, cb, MAPPED_MSG); break;
     default: detail::parse_fastx(data, cb);
     }
 }

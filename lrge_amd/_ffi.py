@@ -21,7 +21,7 @@ C_NAMES = ["query_bases", "query_minimizers", "anchors", "groups", "groups_chain
 EXPORTS = [
     "lrge_hip_device_count", "lrge_hip_ctx_create", "lrge_hip_ctx_destroy", "lrge_hip_last_error", "lrge_hip_ctx_set_option",
     "lrge_hip_seqset_upload", "lrge_hip_seqset_upload_async", "lrge_hip_seqset_wait", "lrge_hip_host_alloc",
-    "lrge_hip_host_free", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch", "lrge_hip_seqset_presketch_sharded", "lrge_hip_pack_choice",
+    "lrge_hip_host_free", "lrge_hip_seqset_free", "lrge_hip_seqset_size", "lrge_hip_seqset_presketch", "lrge_hip_seqset_presketch_sharded", "lrge_hip_pack_choice", "lrge_hip_read_records",
     "lrge_hip_index_build", "lrge_hip_index_build_for", "lrge_hip_index_build_sharded", "lrge_hip_index_build_tsharded", "lrge_hip_last_shard_stats", "lrge_hip_index_free",
     "lrge_hip_comm_alltoallv", "lrge_hip_comm_rccl_ranks", "lrge_hip_comm_rccl_ops", "lrge_hip_comm_local_group_serialize", "lrge_hip_comm_local_turn",
     "lrge_hip_comm_busy_ms", "lrge_hip_comm_standin_ms",

@@ -23,6 +23,8 @@ def _sources():
         out += [os.path.join(root, f) for f in files]
     out.append(os.path.join(os.path.dirname(_HERE), "include", "lrge_hip.h"))
     out.append(os.path.join(os.path.dirname(_HERE), "include", "lrge_rand.hpp"))
+    out.append(os.path.join(os.path.dirname(_HERE), "include", "lrge_io.hpp"))
+    out.append(os.path.join(os.path.dirname(_HERE), "include", "lrge_cram.hpp"))
     return out
 
 
@@ -30,7 +32,7 @@ def build_lib(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= _newest(_sources()):
         return LIB_PATH
-    cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "lrge_hip.hip")]
+    cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "lrge_hip.hip"), "-lz", "-ldl"]      # (zlib: the host-side readers of include/lrge_io.hpp)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -44,7 +46,7 @@ def build_cli(force=False):
     """The C++ host mirror (include/lrge_hip.hpp) + lrge-compatible driver, linked against liblrge_hip.so."""
     src = os.path.join(os.path.dirname(_HERE), "tools", "lrge_hip_cli.cpp")
     inc = os.path.join(os.path.dirname(_HERE), "include")
-    hdrs = [os.path.join(inc, h) for h in ("lrge_hip.hpp", "lrge_hip.h", "lrge_rand.hpp", "lrge_io.hpp")]
+    hdrs = [os.path.join(inc, h) for h in ("lrge_hip.hpp", "lrge_hip.h", "lrge_rand.hpp", "lrge_io.hpp", "lrge_cram.hpp")]
     if not force and os.path.exists(CLI_PATH) and os.path.getmtime(CLI_PATH) >= max([os.path.getmtime(src), os.path.getmtime(LIB_PATH)] +
                                                                                     [os.path.getmtime(h) for h in hdrs]):
         return CLI_PATH

@@ -137,3 +137,17 @@ extern "C" int lrge_hip_chacha_block(const uint32_t key[8], uint64_t counter, in
     lrge::rand09::chacha_block(key, counter, 0, rounds, out);
     return LRGE_OK;
 }
+
+// Host only (round 6): the records of an input file in any format liblrge accepts (io.rs:35-184; include/lrge_io.hpp, lrge_cram.hpp) --
+// FASTA / FASTQ, SAM / unaligned BAM / unaligned CRAM 3.0, plain or gzip / bzip2 / xz / zstd -- through a callback(user, name, name
+// length, bases, base count).  What non-C++ hosts use for the formats they do not parse themselves (lrge_amd/readio.py: CRAM).
+// Errors (message in errbuf): LRGE_ERR_IO for an unreadable file, LRGE_ERR_PARSE for malformed input or a mapped record.
+extern "C" int lrge_hip_read_records(const char *path, void (*cb)(void *, const char *, uint64_t, const char *, uint64_t), void *user,
+                                     char *errbuf, uint64_t errcap) {
+    if (!path || !cb) return LRGE_ERR_INVALID;
+    auto fail = [&](int rc, const char *what) { if (errbuf && errcap) { snprintf(errbuf, (size_t)errcap, "%s", what); } g_last_error = what; return rc; };
+    try {
+        lrge::io::iter_records(path, [&](const std::string &n, const std::string &s) { cb(user, n.data(), (uint64_t)n.size(), s.data(), (uint64_t)s.size()); });
+    } catch (const std::exception &e) { return fail(strncmp(e.what(), "cannot open", 11) == 0 ? LRGE_ERR_IO : LRGE_ERR_PARSE, e.what()); }
+    return LRGE_OK;
+}

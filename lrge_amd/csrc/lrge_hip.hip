@@ -26,6 +26,7 @@
 #include "k_route.h"
 #include "k_tshard.h"
 #include "../../include/lrge_rand.hpp"
+#include "../../include/lrge_io.hpp"
 
 static thread_local std::string g_last_error;  // failures that happen before a ctx exists
 static std::mutex g_live_mu;

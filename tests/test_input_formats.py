@@ -123,8 +123,8 @@ def test_empty_cram_and_garbage(tmp_path, cli):
     rc, _, err = _dump(cli, e)
     assert rc != 0 and "Is the file empty?" in err
     c = tmp_path / "x.cram"
-    c.write_bytes(b"CRAM\x03\x00" + b"\0" * 40)
-    with pytest.raises(ValueError, match="CRAM"):
+    c.write_bytes(b"CRAM\x03\x00" + b"\0" * 40)          # a CRAM magic over garbage: an error, not a crash
+    with pytest.raises(ValueError):
         list(readio.iter_records(str(c)))
     assert _dump(cli, c)[0] != 0
     g = tmp_path / "garbage"
@@ -137,3 +137,99 @@ def test_empty_cram_and_garbage(tmp_path, cli):
     with pytest.raises(Exception):
         list(readio.iter_records(str(t)))
     assert _dump(cli, t)[0] != 0
+
+
+# ---- unaligned CRAM 3.0 (round 6; io.rs:93,154-184 reads it through noodles): include/lrge_cram.hpp against tests/cram_writer.py, an
+# independent writer of the same specification (no CRAM file and no CRAM tool exists in this image) ----
+def _cram_reads(n=57):
+    import numpy as np
+    rng = np.random.default_rng(7)
+    reads = []
+    for i in range(n):
+        ln = int(rng.integers(1, 4000)) if i % 11 else 1
+        reads.append((b"read-%04d/%d" % (i, i % 3), bytes(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), size=ln, p=[.24, .24, .24, .24, .01, .0075, .0075, .0075, .0075]))))
+    return reads
+
+
+@pytest.mark.parametrize("method", ["raw", "gzip", "bzip2", "lzma", "rans0", "rans1"])
+@pytest.mark.parametrize("variant", ["external", "core"])
+def test_cram_every_block_method_and_both_layouts(tmp_path, cli, method, variant):
+    """Every block compression method of CRAM 3.0 x the two layouts of the per-record integers: every series in an external block of its
+    own, or flags / lengths / positions / tag lines bit-packed into the core block (HUFFMAN, BETA, GAMMA, zero-bit HUFFMAN, SUBEXP).
+    Names with a stop byte, one tag on every other record, qualities present, detached records with mate fields among them."""
+    import cram_writer
+    reads = _cram_reads()
+    p = tmp_path / "u.cram"
+    p.write_bytes(cram_writer.write_cram(reads, variant=variant, method=method, records_per_slice=20, slices_per_container=2))
+    assert list(readio.iter_records(str(p))) == reads
+    rc, recs, err = _dump(cli, p)
+    assert rc == 0 and recs == reads, err
+    assert readio.count_records(str(p)) == len(reads)
+
+
+@pytest.mark.parametrize("opts", [dict(with_quality=False), dict(with_tags=False), dict(name_form="len"), dict(records_per_slice=1, slices_per_container=3),
+                                  dict(records_per_slice=1000)])
+def test_cram_shapes(tmp_path, cli, opts):
+    """No qualities, no tags, names as BYTE_ARRAY_LEN, one record per slice and three slices per container, one slice for everything."""
+    import cram_writer
+    reads = _cram_reads(23)
+    p = tmp_path / "s.cram"
+    p.write_bytes(cram_writer.write_cram(reads, **opts))
+    assert list(readio.iter_records(str(p))) == reads
+    assert _dump(cli, p)[1] == reads
+    # gzip around the whole file: io.rs:71-90 decompresses before it sniffs
+    z = tmp_path / "s.cram.gz"
+    z.write_bytes(gzip.compress(p.read_bytes()))
+    assert list(readio.iter_records(str(z))) == reads
+
+
+def test_cram_refusals(tmp_path, cli):
+    """A mapped record is refused with the reference's message (io.rs:162-167); a block in a CRAM 3.1 codec is an error that names the codec
+    when the reader needs the block (bases), and no obstacle when it does not (qualities are never read); truncation is an error; an
+    empty file (header and EOF containers only) has no records."""
+    import cram_writer
+    reads = _cram_reads(9)
+    m = tmp_path / "mapped.cram"
+    m.write_bytes(cram_writer.write_cram(reads, mapped_at=4))
+    with pytest.raises(ValueError, match="Mapped records are not supported"):
+        list(readio.iter_records(str(m)))
+    rc, _, err = _dump(cli, m)
+    assert rc != 0 and MAPPED in err
+    q = tmp_path / "qs31.cram"
+    q.write_bytes(cram_writer.write_cram(reads, method_for={"QS": "nx16"}))
+    assert list(readio.iter_records(str(q))) == reads
+    b = tmp_path / "ba31.cram"
+    b.write_bytes(cram_writer.write_cram(reads, method_for={"BA": "nx16"}))
+    with pytest.raises(ValueError, match="rANS Nx16"):
+        list(readio.iter_records(str(b)))
+    assert _dump(cli, b)[0] != 0
+    t = tmp_path / "trunc.cram"
+    t.write_bytes(cram_writer.write_cram(reads)[:-60])
+    with pytest.raises(ValueError):
+        list(readio.iter_records(str(t)))
+    e = tmp_path / "empty.cram"
+    e.write_bytes(cram_writer.write_cram([]))
+    assert list(readio.iter_records(str(e))) == []
+    with pytest.raises(ValueError, match="Is the file empty"):
+        readio.count_records(str(e))
+
+
+def test_rans4x8_round_trips():
+    """The rANS 4x8 decoder against the test writer's encoder, both orders: skewed and flat distributions, every byte value, runs of
+    consecutive symbols (the run-length coded frequency tables), lengths 0 .. 9 (the four interleaved states and the order-1 quarters)."""
+    import ctypes as C
+    import numpy as np
+    import cram_writer
+    from lrge_amd import _ffi
+    rng = np.random.default_rng(3)
+    cases = [bytes(range(256)) * 3, b"", b"A", b"AC", b"ACG", b"ACGT", b"ACGTA", b"ACGTACGTA", bytes(rng.integers(0, 256, 5000, dtype=np.uint8)),
+             bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 20000, p=[.7, .1, .1, .1])), b"\x00" * 1000, bytes([5, 6, 7, 8, 9] * 400)]
+    for data in cases:
+        for order in (0, 1):
+            # through a one-record CRAM whose base block is the data: the decoder has no other entry point
+            import tempfile
+            with tempfile.TemporaryDirectory() as d:
+                p = os.path.join(d, "r.cram")
+                seq = data.replace(b"\n", b"N") or b"A"
+                open(p, "wb").write(cram_writer.write_cram([(b"x", seq)], method="rans%d" % order, with_tags=False, with_quality=False))
+                assert list(readio.iter_records(p)) == [(b"x", seq)], (len(data), order)

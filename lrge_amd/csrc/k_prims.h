@@ -869,44 +869,48 @@ __device__ __forceinline__ u32 hc_boundary_flags(const u32 *__restrict__ seg_sta
     return f;
 }
 
+// (Round 6 tried the keys read COALESCED -- a wavefront owning 1 024 consecutive keys as 16 rows of 64, the predecessor by a DPP shift, the
+// head bits through one ballot per row into the thread-owned layout below: exact, and SLOWER -- 4.5-4.8 ms per launch against 3.7 for a
+// 20-GB part, with LDS permutes or with DPP alike.  Each thread reading its own 128-byte line with eight 16-byte loads stays.)
+__device__ __forceinline__ u32 hc_load_flags(const u64 *__restrict__ keys, u64 n, u32 shift, u64 base) {
+    // bit t set: element base + t starts a run
+    u32 f = 0;
+    if (base >= n) return 0;
+    u64 prev = base ? keys[base - 1] >> shift : 0;
+    const bool first = base == 0;
+    if (base + HC_ITEMS <= n) {
+        const ulonglong2 *p = (const ulonglong2 *)(keys + base);
+#pragma unroll
+        for (int t = 0; t < HC_ITEMS / 2; ++t) {
+            const ulonglong2 q = p[t];
+            const u64 a = q.x >> shift, b = q.y >> shift;
+            if (a != prev || (first && t == 0)) f |= 1u << (2 * t);
+            if (b != a) f |= 1u << (2 * t + 1);
+            prev = b;
+        }
+    } else {
+        for (int t = 0; t < HC_ITEMS && base + t < n; ++t) {
+            const u64 a = keys[base + t] >> shift;
+            if (a != prev || (first && t == 0)) f |= 1u << t;
+            prev = a;
+        }
+    }
+    return f;
+}
+
 // flags: the 16 head bits of every thread's line, kept for k_heads_fill (2 bytes instead of re-reading 128 bytes of keys)
-// Round 6: the keys are read COALESCED -- a wavefront owns 1024 consecutive keys and reads them as 16 rows of 64 (lane l, row r: key
-// 64 r + l), the predecessor of a key comes from the lane before (row r - 1's last lane, or one extra load in front of the wavefront),
-// and the head bits travel through one ballot per row into the thread-owned layout above (thread T owns keys 16 T .. 16 T + 15 of its
-// block: bits 16 (T & 3) .. of row T >> 2).  Before, every thread read its own 128-byte line with 16-byte loads: each load instruction
-// of a wavefront touched 64 lines, and the kernel ran at 2.5 TB/s (20 GB of keys per H. sapiens-scale part in 7.9 ms).
 __global__ __launch_bounds__(HC_THREADS) void k_heads_count(const u64 *__restrict__ keys, u64 n, u32 shift, u32 *__restrict__ bcount,
                                                             u16 *__restrict__ flags, const u32 *__restrict__ seg_start = nullptr, u32 n_seg = 0) {
     __shared__ u32 ws[HC_THREADS / 64];
-    __shared__ u64 ball[HC_THREADS / 64][HC_ITEMS];
-    static_assert(HC_ITEMS == 16, "a thread's flags are a u16");
-    const u32 w = threadIdx.x >> 6, lane = lane_id();
-    const u64 wbase = (u64)blockIdx.x * HC_TILE + (u64)w * (64 * HC_ITEMS);      // first key of the wavefront
-    u64 k[HC_ITEMS];
-#pragma unroll
-    for (int r = 0; r < HC_ITEMS; ++r) { const u64 i = wbase + (u64)r * 64 + lane; k[r] = i < n ? keys[i] >> shift : 0; }
-    u64 before = (wbase && wbase <= n) ? keys[wbase - 1] >> shift : 0;             // (wave-uniform address: one broadcast load)
-#pragma unroll
-    for (int r = 0; r < HC_ITEMS; ++r) {
-        const u64 i = wbase + (u64)r * 64 + lane;
-        // the lane before's key by a DPP wavefront shift (lane 0 takes `before`), the row's last key by a scalar lane read: no LDS permutes
-        // (a first form with four ds_bpermute per row ran SLOWER than the per-thread lines it replaced: 4.8 against 3.7 ms per launch)
-        const u64 prev = (u64)(u32)wave_shr1_i32((i32)(u32)k[r], (i32)(u32)before) | (u64)(u32)wave_shr1_i32((i32)(u32)(k[r] >> 32), (i32)(u32)(before >> 32)) << 32;
-        const bool head = i < n && (i == 0 || k[r] != prev);
-        const u64 m = __ballot(head);
-        if (lane == 0) ball[w][r] = m;
-        before = (u64)(u32)__builtin_amdgcn_readlane((i32)(u32)k[r], 63) | (u64)(u32)__builtin_amdgcn_readlane((i32)(u32)(k[r] >> 32), 63) << 32;
-    }
-    // (a wavefront only reads its own row of `ball`: program order is enough, no barrier)
     const u64 base = (u64)blockIdx.x * HC_TILE + (u64)threadIdx.x * HC_ITEMS;
-    u32 f = (u32)(ball[w][lane >> 2] >> (16 * (lane & 3))) & 0xffffu;
+    u32 f = hc_load_flags(keys, n, shift, base);
     if (seg_start && base < n) f |= hc_boundary_flags(seg_start, n_seg, n, base);
     flags[(u64)blockIdx.x * HC_THREADS + threadIdx.x] = (u16)f;
     u32 c = (u32)__popc(f);
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-    if (lane == 0) ws[w] = c;
+    if (lane_id() == 0) ws[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) { u32 t = 0; for (int ww = 0; ww < HC_THREADS / 64; ++ww) t += ws[ww]; bcount[blockIdx.x] = t; }
+    if (threadIdx.x == 0) { u32 t = 0; for (int w = 0; w < HC_THREADS / 64; ++w) t += ws[w]; bcount[blockIdx.x] = t; }
 }
 
 __global__ __launch_bounds__(HC_THREADS) void k_heads_fill(const u16 *__restrict__ flags, const u32 *__restrict__ boff,

@@ -404,7 +404,8 @@ def roofline_blocks(a, preset, world, K, ms_per_step, acc_tb, acc_tm, acc_cn, tb
                 rate = v["valu_wave_insts_per_launch"] / (r_["avg_launch_ms"] * 1e-3)
                 peak = VALU_PEAK_WAVE_INSTS_PER_S_PER_CU * 256
                 committed["valu_issue"][r_["kernel"]] = {**v, "wave_insts_per_s": rate, "peak_wave_insts_per_s": peak, "issue_frac": rate / peak,
-                                                         "what": "committed SQ_INSTS_VALU per launch over THIS run's event-timed launch duration, against 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz"}
+                                                         "what": "committed SQ_INSTS_VALU per launch over THIS run's event-timed launch duration, against the NOMINAL rate of 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz; "
+                                                                 "measured (tools/micro/valu_rate.hip) the cheap instructions issue every 2.4-2.7 cycles, so a fraction at or above 1.0 means the SIMDs are saturated, not a counting error"}
     # whole-path algorithmic bytes: B_q summed over queries + B_idx, per step
     # (streamed set: the queries, or the targets with --inverse; for N > 1 rank 0's counters times the world size)
     # M = minimizers of the streamed set, counted ONCE: against a partitioned index every part looks all of them up, and the

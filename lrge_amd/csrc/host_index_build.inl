@@ -129,7 +129,7 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
             segw = !pk && !ro && extra != ~0u && 2 * P.k >= 24 && !ctx->opt("NO_SEG_PACK") && !ctx->opt("NO_SEGW") && 2 * (u32)P.k - 16 + yb_p <= 64 &&
                    (double)targets->total_bases * dens >= (double)ctx->opt_u64("SEG_PACK_MIN", 1ULL << 22);
         }
-        rc = sketch_device(ctx, sc, targets, preset, true, &so, (pk || segw) ? pk_pos1 : 0, segw ? pk_rid + pk_pos1 : pk_ybits, nullptr, keep_slots, segw, /*wave_ok=*/segw);
+        rc = sketch_device(ctx, sc, targets, preset, true, &so, (pk || segw) ? pk_pos1 : 0, segw ? pk_rid + pk_pos1 : pk_ybits, nullptr, keep_slots, segw, /*wave_ok=*/true);
         if (rc) return rc;
         if (so.mz_off) sc.drop(so.mz_off);
     }
@@ -264,7 +264,20 @@ static int index_build_one(lrge_hip_ctx *ctx, const lrge_hip_seqset *targets, in
     {
         StageTimer t(ctx, LRGE_T_INDEX_SORT);
         ALLOC_OR_FAIL(k1, sc, u64, M + 1);
-        if (pk && so.slots) {
+        if (pk && so.wave_x) {
+            // packed entries out of the wave-dense sketch: the first pass reads the wavefronts' slots (one 32-byte descriptor per tile)
+            if (M) {
+                ALLOC_OR_FAIL(k0, sc, u64, M + 1);
+                rc = radix_sort_keys_first_pass_from_slots(ctx, sc, so.wave_x, so.wave_offs, so.n_waves, so.wave_cap, k1, M, (int)pk_ybits, 2 * P.k, /*reverse_digits=*/true);
+                if (rc) return rc;
+                sc.drop(so.wave_x); sc.drop(so.wave_cnt); sc.drop(so.wave_offs);
+                u64 *rk = k1;
+                rc = radix_sort_keys(ctx, sc, k1, k0, M, (int)pk_ybits, 2 * P.k, &rk, /*reverse_digits=*/true, 1, -1);
+                if (rc) return rc;
+                skey = rk; spos = rk;
+                sc.drop(rk == k1 ? k0 : k1);
+            } else { sc.drop(so.wave_x); sc.drop(so.wave_cnt); sc.drop(so.wave_offs); skey = spos = k1; }
+        } else if (pk && so.slots) {
             ALLOC_OR_FAIL(k0, sc, u64, M + 1);
             rc = radix_sort_keys_first_pass_from_slots(ctx, sc, so.slots, so.offs, so.n_chunks, (u32)SK_CAP, k1, M, (int)pk_ybits, 2 * P.k, /*reverse_digits=*/true);
             if (rc) return rc;

@@ -68,23 +68,26 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
     ChunkMap cm{d_cs, s->n};
     const dim3 sgrid((u32)div_up(n_chunks, SK_THREADS));
     u32 tot_ovf[2] = {0, 0};
-    // ---- wave-dense form (round 6): SEGW index entries written densely per wavefront, no compaction; see k_sketch_wave ----
+    // ---- wave-dense form (round 6): index entries (SEGW, or packed words for the sort that reads slots) written densely per wavefront, no
+    // compaction; see k_sketch_wave ----
     // (option NO_WAVE_SKETCH: the slot-per-chunk forms below, rounds 2-5; WAVE_CAP: entries of room per wavefront, a multiple of 64, <= RS_TILE)
-    if (wave_ok && segw && n_chunks && !tile_form && !ctx->opt("DEBUG_SK_CAP") && !ctx->opt("NO_WAVE_SKETCH") && !ctx->opt("SKETCH_TWO_PASS") && !ctx->opt("DEBUG_SK_RANGE_CHUNKS")) {
+    if (wave_ok && (segw || (pk && keep_slots)) && n_chunks && !tile_form && !ctx->opt("DEBUG_SK_CAP") && !ctx->opt("NO_WAVE_SKETCH") && !ctx->opt("SKETCH_TWO_PASS") && !ctx->opt("DEBUG_SK_RANGE_CHUNKS")) {
         const u32 n_waves = (u32)div_up(n_chunks, 64);
         u32 capw = (u32)ctx->opt_u64("WAVE_CAP", HPC ? 2560 : 3328);
         capw = std::max<u32>(64, capw / 64 * 64);
         u64 *wx = sc.get<u64>((size_t)n_waves * capw + 8);
-        wdig_t *wd = wx ? sc.get<wdig_t>((size_t)n_waves * capw + 8) : nullptr;
-        u32 *wcnt = wd ? sc.get<u32>((size_t)n_waves + 1) : nullptr, *woffs = wcnt ? sc.get<u32>((size_t)n_waves + 1) : nullptr;
-        if (wx && wd && wcnt && woffs) {
+        wdig_t *wd = (wx && segw) ? sc.get<wdig_t>((size_t)n_waves * capw + 8) : nullptr;      // (packed 8-byte entries have no digit member)
+        u32 *wcnt = (wx && (wd || !segw)) ? sc.get<u32>((size_t)n_waves + 1) : nullptr, *woffs = wcnt ? sc.get<u32>((size_t)n_waves + 1) : nullptr;
+        if (wx && (wd || !segw) && wcnt && woffs) {
             HIPCHK(ctx, hipMemsetAsync(d_total, 0, 8, ctx->stream));
             auto launch_wave = [&](u32 c0, u32 c1) {           // chunks [c0, c1), c0 a multiple of 64
                 if (c1 <= c0) return;
                 StageTimer tk(ctx, LRGE_T_K_SKETCH);
                 ctx->counters[LRGE_C_SKETCH_WAVE_LAUNCHES] += 1;
-                hipLaunchKernelGGL((k_sketch_wave<K, W, HPC, 2>), dim3((u32)div_up(c1 - c0, SK_THREADS)), dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,
-                                   s->d_len, cm, c1, wcnt, d_total + 1, wx, wd, pk_pos1, pk_ybits, capw, c0);
+                if (segw) hipLaunchKernelGGL((k_sketch_wave<K, W, HPC, 2>), dim3((u32)div_up(c1 - c0, SK_THREADS)), dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,
+                                             s->d_len, cm, c1, wcnt, d_total + 1, wx, wd, pk_pos1, pk_ybits, capw, c0);
+                else hipLaunchKernelGGL((k_sketch_wave<K, W, HPC, 1>), dim3((u32)div_up(c1 - c0, SK_THREADS)), dim3(SK_THREADS), 0, ctx->stream, s->d_pack, s->d_nmask, s->d_woff,
+                                        s->d_len, cm, c1, wcnt, d_total + 1, wx, (wdig_t *)nullptr, pk_pos1, pk_ybits, capw, c0);
             };
             u32 c_prev = 0;
             if (gated && gjob) {
@@ -111,12 +114,12 @@ static int sketch_launch(lrge_hip_ctx *ctx, Scratch &sc, const lrge_hip_seqset *
             if (!tot_ovf[1]) {
                 if (h_mzoff) h_mzoff->clear();
                 sc.drop(d_cnt); sc.drop(d_total); sc.drop(d_mzoff);
-                o->x = nullptr; o->y = nullptr; o->mz_off = nullptr; o->n = tot_ovf[0]; o->segw = true;
+                o->x = nullptr; o->y = nullptr; o->mz_off = nullptr; o->n = tot_ovf[0]; o->segw = segw;
                 o->wave_x = wx; o->wave_d = wd; o->wave_cnt = wcnt; o->wave_offs = woffs; o->n_waves = n_waves; o->wave_cap = capw;
                 return LRGE_OK;
             }
             tot_ovf[0] = tot_ovf[1] = 0;          // a wavefront found more than its slot holds: the slot-per-chunk forms
-            sc.drop(wx); sc.drop(wd); sc.drop(wcnt); sc.drop(woffs);
+            sc.drop(wx); if (wd) sc.drop(wd); sc.drop(wcnt); sc.drop(woffs);
         } else {
             if (wx) sc.drop(wx); if (wd) sc.drop(wd); if (wcnt) sc.drop(wcnt); if (woffs) sc.drop(woffs);
             (void)hipGetLastError(); ctx->err.clear();

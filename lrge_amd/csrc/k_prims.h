@@ -776,7 +776,15 @@ static int radix_sort_keys_first_pass_from_slots(lrge_hip_ctx *ctx, Scratch &sc,
     ALLOC_OR_FAIL(tile_chunk, sc, u32, (size_t)nb + 1);
     hipLaunchKernelGGL(k_tile_chunks, dim3((u32)div_up(nb, 256)), dim3(256), 0, ctx->stream, offs, n_chunks, nb, tile_chunk);
     KCHK(ctx);
-    SlotSrc src{slots, offs, tile_chunk, n_chunks, cap, (u32)n};
+    // large slots (the wave-dense sketch's: ~2 000-2 800 entries each): one 32-byte descriptor per tile instead of the offsets-through-LDS path
+    u32 *tile_desc = nullptr;
+    if (cap >= 1024) {
+        tile_desc = sc.get<u32>((size_t)nb * 8 + 8);
+        if (!tile_desc) return LRGE_ERR_DEVICE;
+        hipLaunchKernelGGL(k_tile_desc, dim3((u32)div_up(nb, 256)), dim3(256), 0, ctx->stream, offs, n_chunks, (u32)n, nb, tile_desc);
+        KCHK(ctx);
+    }
+    SlotSrc src{slots, offs, tile_chunk, n_chunks, cap, (u32)n, nullptr, tile_desc};
     hipLaunchKernelGGL((k_rs_hist<false, 8, true>), dim3(nb), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)nullptr, n, shift, nb, hist, (const SegTile *)nullptr, up.dmask, src);
     KCHK(ctx);
     int rc = scan_exclusive_u32(ctx, sc, hist, hist, (u64)256 * nb, nullptr);
@@ -791,7 +799,7 @@ static int radix_sort_keys_first_pass_from_slots(lrge_hip_ctx *ctx, Scratch &sc,
         ctx->counters[LRGE_C_RS_SCATTER_ITEMS] += n;
         ctx->counters[LRGE_C_RS_SCATTER_BYTES] += 16 * n;
     }
-    sc.drop(hist); sc.drop(tile_chunk);
+    sc.drop(hist); sc.drop(tile_chunk); if (tile_desc) sc.drop(tile_desc);
     return LRGE_OK;
 }
 
@@ -898,14 +906,23 @@ __device__ __forceinline__ u32 hc_load_flags(const u64 *__restrict__ keys, u64 n
     return f;
 }
 
-// flags: the 16 head bits of every thread's line, kept for k_heads_fill (2 bytes instead of re-reading 128 bytes of keys)
+// flags: the 16 head bits of every thread's line, kept for k_heads_fill (instead of re-reading 128 bytes of keys); stored as a dword per
+// thread since round 6 (HFLAG_BITS=16: the u16 array of rounds 2-5 -- 2-byte stores and loads are slow on this chip)
+#ifndef HFLAG_BITS
+#define HFLAG_BITS 32
+#endif
+#if HFLAG_BITS == 16
+typedef u16 hflag_t;
+#else
+typedef u32 hflag_t;
+#endif
 __global__ __launch_bounds__(HC_THREADS) void k_heads_count(const u64 *__restrict__ keys, u64 n, u32 shift, u32 *__restrict__ bcount,
-                                                            u16 *__restrict__ flags, const u32 *__restrict__ seg_start = nullptr, u32 n_seg = 0) {
+                                                            hflag_t *__restrict__ flags, const u32 *__restrict__ seg_start = nullptr, u32 n_seg = 0) {
     __shared__ u32 ws[HC_THREADS / 64];
     const u64 base = (u64)blockIdx.x * HC_TILE + (u64)threadIdx.x * HC_ITEMS;
     u32 f = hc_load_flags(keys, n, shift, base);
     if (seg_start && base < n) f |= hc_boundary_flags(seg_start, n_seg, n, base);
-    flags[(u64)blockIdx.x * HC_THREADS + threadIdx.x] = (u16)f;
+    flags[(u64)blockIdx.x * HC_THREADS + threadIdx.x] = (hflag_t)f;
     u32 c = (u32)__popc(f);
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
     if (lane_id() == 0) ws[threadIdx.x >> 6] = c;
@@ -913,7 +930,7 @@ __global__ __launch_bounds__(HC_THREADS) void k_heads_count(const u64 *__restric
     if (threadIdx.x == 0) { u32 t = 0; for (int w = 0; w < HC_THREADS / 64; ++w) t += ws[w]; bcount[blockIdx.x] = t; }
 }
 
-__global__ __launch_bounds__(HC_THREADS) void k_heads_fill(const u16 *__restrict__ flags, const u32 *__restrict__ boff,
+__global__ __launch_bounds__(HC_THREADS) void k_heads_fill(const hflag_t *__restrict__ flags, const u32 *__restrict__ boff,
                                                            u32 *__restrict__ starts) {
     __shared__ u32 ws[HC_THREADS / 64];
     __shared__ u32 tile[HC_TILE];            // the block's heads, in order: they leave as one coalesced run
@@ -939,7 +956,7 @@ static int compact_heads_async(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, 
     if (n == 0) { HIPCHK(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream)); return LRGE_OK; }
     const u32 nb = (u32)div_up(n, HC_TILE);
     ALLOC_OR_FAIL(bc, sc, u32, (size_t)nb + 1);
-    ALLOC_OR_FAIL(fl, sc, u16, (size_t)nb * HC_THREADS);
+    ALLOC_OR_FAIL(fl, sc, hflag_t, (size_t)nb * HC_THREADS);
     hipLaunchKernelGGL(k_heads_count, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc, fl);
     KCHK(ctx);
     int rc = scan_exclusive_u32(ctx, sc, bc, bc, nb, d_count);
@@ -958,7 +975,7 @@ static int compact_heads(lrge_hip_ctx *ctx, Scratch &sc, const u64 *keys, u64 n,
     const u32 nb = (u32)div_up(n, HC_TILE);
     ALLOC_OR_FAIL(bc, sc, u32, (size_t)nb + 1);
     ALLOC_OR_FAIL(d_tot, sc, u32, 1);
-    ALLOC_OR_FAIL(fl, sc, u16, (size_t)nb * HC_THREADS);
+    ALLOC_OR_FAIL(fl, sc, hflag_t, (size_t)nb * HC_THREADS);
     hipLaunchKernelGGL(k_heads_count, dim3(nb), dim3(HC_THREADS), 0, ctx->stream, keys, n, shift, bc, fl, seg_start, n_seg);
     KCHK(ctx);
     int rc = scan_exclusive_u32(ctx, sc, bc, bc, nb, d_tot);

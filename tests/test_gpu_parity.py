@@ -1098,3 +1098,46 @@ print("SUM", int(out[0].sum()))
         assert r.returncode == 0, r.stderr[-2000:]
         sums.append([l for l in r.stdout.splitlines() if l.startswith("SUM")][0])
     assert sums[0] == sums[1] and int(sums[0].split()[1]) > 0
+
+
+@pytest.mark.parametrize("form", ["wave", "wave_overflow", "chunk_slots"])
+@pytest.mark.parametrize("layout", ["segw", "packed"])
+@pytest.mark.parametrize("preset", ["ont", "pb"])
+def test_wave_dense_index_sketch_and_its_fallbacks(ctx, oracle, edge_set, tiny_ont, tiny_hifi, preset, layout, form, knobs):
+    """Round 6: index entries out of the wave-dense sketch (k_sketch_wave: a wavefront fills its slot densely, in emission order; the
+    sort's first pass reads the slots) -- SEGW entries and packed words -- must give the index of the oracle (entries by (hash, y), lists,
+    mid_occ, key and minimizer counts) and its counts; so must the fallback a wavefront takes when its slot overflows (WAVE_CAP = 64:
+    every wavefront with more than 64 minimizers raises the flag and the build takes the slot-per-chunk path) and the slot-per-chunk form
+    itself (NO_WAVE_SKETCH).  The edge set holds reads of 1 .. k + w bases, ambiguity runs, homopolymers and identical reads."""
+    from lrge_amd import engine
+    if layout == "segw":
+        knobs.set("NO_PACKED_INDEX", "1"); knobs.set("SEG_PACK_MIN", "1")
+    if form == "wave_overflow":
+        knobs.set("WAVE_CAP", "64")
+    if form == "chunk_slots":
+        knobs.set("NO_WAVE_SKETCH", "1")
+    qseqs, qnames, tseqs, tnames = edge_set
+    Qd, Td, ixd, Qo, To, ixo = _both_sets(ctx, oracle, qseqs, qnames, tseqs, tnames, preset)
+    keys, pos = ixd.dump()
+    mz = ixo.minimizers()
+    order = np.lexsort((mz["y"], mz["x"] >> np.uint64(8)))
+    assert np.array_equal(keys, (mz["x"] >> np.uint64(8))[order]) and np.array_equal(pos, mz["y"][order])
+    st = ixd.stats()
+    assert st["mid_occ"] == ixo.mid_occ and st["n_keys"] == ixo.n_keys and st["n_minimizers"] == ixo.n_minimizers
+    ixd.free()
+    ds = tiny_ont if preset == "ont" else tiny_hifi
+    qr, tr = engine.name_ranks(ds.q.names, ds.t.names)
+    Q2, T2 = ctx.upload(ds.q.bases, ds.q.offsets, qr), ctx.upload(ds.t.bases, ds.t.offsets, tr)
+    launches0 = ctx.counters().get("sketch_wave_launches", 0)
+    ix = engine.Index(ctx, T2, PRESETS[preset])
+    cb = ix.build_counters
+    if form == "chunk_slots":
+        assert cb.get("sketch_wave_launches", 0) == 0
+    else:
+        assert cb.get("sketch_wave_launches", 0) >= 1, cb          # the wave-dense kernel really ran (and, with WAVE_CAP = 64, overflowed)
+    counts, has = ix.overlap_twoset(Q2)
+    opt = oracle.make_opt(oracle.PRESET_AVA_PB if preset == "pb" else oracle.PRESET_AVA_ONT, dual=True)
+    ixo2 = oracle.Index(oracle.ReadSet(ds.t.seqs(), ds.t.names), opt)
+    rc, ec, eh = ixo2.twoset_counts(oracle.ReadSet(ds.q.seqs(), ds.q.names), threads=8)
+    assert rc == 0 and np.array_equal(counts, ec) and np.array_equal(has, eh) and ix.stats()["mid_occ"] == ixo2.mid_occ
+    ix.free()

@@ -233,3 +233,38 @@ def test_rans4x8_round_trips():
                 seq = data.replace(b"\n", b"N") or b"A"
                 open(p, "wb").write(cram_writer.write_cram([(b"x", seq)], method="rans%d" % order, with_tags=False, with_quality=False))
                 assert list(readio.iter_records(p)) == [(b"x", seq)], (len(data), order)
+
+
+def test_damaged_files_end_in_an_error_never_in_a_crash(tmp_path, cli):
+    """Seeded damage (overwritten bytes, single bit flips, a 0x7fffffff where a length may stand, truncation) to files of every container
+    the reader decodes itself: the process ends with records or with an error message -- no signal, no hang, no allocation by a length field
+    the file cannot back.  (A bounded sample for the suite; the longer campaigns of the same generator are in DESIGN.md 8.)"""
+    import random
+
+    import cram_writer
+    reads = _cram_reads(23)
+    seeds = {"cram_" + m + "_" + v: cram_writer.write_cram(reads, variant=v, method=m, records_per_slice=10, slices_per_container=2)
+             for m, v in (("raw", "core"), ("gzip", "external"), ("rans0", "core"), ("rans1", "external"))}
+    seeds["fq.gz"] = gzip.compress(_fastq())
+    seeds["sam"] = _sam()
+    rng = random.Random(20260930)
+    for name, data in sorted(seeds.items()):
+        for it in range(40):
+            b = bytearray(data)
+            kind = it % 4
+            if kind == 0:
+                for _ in range(rng.randrange(1, 4)):
+                    b[rng.randrange(len(b))] = rng.randrange(256)
+            elif kind == 1:
+                b = b[:rng.randrange(1, len(b))]
+            elif kind == 2:
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            else:
+                i = rng.randrange(len(b))
+                b[i:i + 4] = b"\xff\xff\xff\x7f"
+            p = tmp_path / ("%s.%d" % (name, it))
+            p.write_bytes(bytes(b))
+            out = subprocess.run([cli, "--dump-records", str(p)], capture_output=True, timeout=60)
+            assert out.returncode in (0, 1), (name, it, kind, out.returncode, out.stderr[-300:])
+            if out.returncode:
+                assert out.stderr.strip(), (name, it)

@@ -72,6 +72,8 @@ inline std::string rans4x8_decode(const unsigned char *in, size_t n) {
     const uint32_t csz = c.u32le(), usz = c.u32le();
     if (order > 1) throw Err("CRAM: rANS order " + std::to_string(order));
     if (c.left() < csz) throw Err("CRAM: truncated rANS stream");
+    // a symbol costs at least log2(4096 / 4095) bits: a size field beyond that is not backed by the stream (and nothing is allocated for it)
+    if ((uint64_t)usz > ((uint64_t)c.left() + 16) * 24000) throw Err("CRAM: rANS size field exceeds what the stream can hold");
     std::string out(usz, '\0');
     if (usz == 0) return out;
     constexpr uint32_t TOT = 4096, LOW = 1u << 23;
@@ -102,7 +104,7 @@ inline std::string rans4x8_decode(const unsigned char *in, size_t n) {
             const unsigned char s = t->R[m];
             out[i] = (char)s;
             r = (uint32_t)t->F[s] * (r >> 12) + m - t->C[s];
-            while (r < LOW && c.left()) r = (r << 8) | c.u8();
+            while (r < LOW) { if (!c.left()) throw Err("CRAM: rANS stream exhausted"); r = (r << 8) | c.u8(); }
         }
         return out;
     }
@@ -129,7 +131,7 @@ inline std::string rans4x8_decode(const unsigned char *in, size_t n) {
         const unsigned char s = t->R[m];
         out[idx[k]++] = (char)s;
         R[k] = (uint32_t)t->F[s] * (R[k] >> 12) + m - t->C[s];
-        while (R[k] < LOW && c.left()) R[k] = (R[k] << 8) | c.u8();
+        while (R[k] < LOW) { if (!c.left()) throw Err("CRAM: rANS stream exhausted"); R[k] = (R[k] << 8) | c.u8(); }
         last[k] = s;
     };
     for (uint32_t i = 0; i < q; ++i) { step(0); step(1); step(2); step(3); }
@@ -450,7 +452,7 @@ inline void parse(const std::string &file, const Callback &cb, const char *mappe
                 if (!(bf & 0x4)) throw Err(mapped_msg);                       // io.rs:162-167: mapped records are refused
                 if (rl < 0) throw Err("CRAM: negative read length");
                 seq.clear();
-                if (!(cf & 0x8)) { const Encoding &ba = H.series("BA"); seq.resize((size_t)rl); for (int32_t i = 0; i < rl; ++i) seq[(size_t)i] = (char)S.read_byte(ba); }
+                if (!(cf & 0x8)) { const Encoding &ba = H.series("BA"); seq.clear(); seq.reserve((size_t)std::min<int32_t>(rl, 1 << 20)); for (int32_t i = 0; i < rl; ++i) seq.push_back((char)S.read_byte(ba)); }
                 if (cf & 0x1) {       // qualities: skipped -- without touching their block when it is theirs alone (any codec will do then)
                     const Encoding &qs = H.series("QS");
                     if (!(qs.id == 1 && S.lazy.count(qs.ext_id))) for (int32_t i = 0; i < rl; ++i) (void)S.read_byte(qs);

@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   ref=${2:-HEAD}; tmp=$(mktemp -d)
   (cd "$root" && git archive "$ref" lrge_amd/csrc include | tar -x -C "$tmp")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -I"$tmp/include" -I"$tmp/lrge_amd/csrc" \
-      -o "$root/lrge_amd/_lib/liblrge_hip_ref.so" "$tmp/lrge_amd/csrc/lrge_hip.hip"
+      -o "$root/lrge_amd/_lib/liblrge_hip_ref.so" "$tmp/lrge_amd/csrc/lrge_hip.hip" -lz -ldl
   rm -rf "$tmp"; echo "built ref from $ref"
 else
   n=${2:-3}

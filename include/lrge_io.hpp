@@ -12,7 +12,7 @@
 // zlib; bzip2 / xz / zstd through the system's shared libraries, bound at run time because this image ships them
 // without headers (libbz2.so.1, liblzma.so.5, libzstd.so.1) -- a missing library is an error naming it, never a
 // silent fallback.  Unaligned CRAM 3.0 (round 6): lrge_cram.hpp -- containers, every encoding of the specification, raw / gzip / bzip2 /
-// lzma / rANS 4x8 blocks; CRAM 3.1's extra codecs are an error naming the codec.
+// lzma / rANS 4x8 blocks, and of CRAM 3.1 rANS Nx16 + the name tokeniser; the arithmetic coder and fqzcomp are an error naming the codec.
 #pragma once
 #include <dlfcn.h>
 #include <zlib.h>

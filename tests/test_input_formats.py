@@ -184,7 +184,7 @@ def test_cram_shapes(tmp_path, cli, opts):
 
 
 def test_cram_refusals(tmp_path, cli):
-    """A mapped record is refused with the reference's message (io.rs:162-167); a block in a CRAM 3.1 codec is an error that names the codec
+    """A mapped record is refused with the reference's message (io.rs:162-167); a block in one of the two CRAM 3.1 codecs this reader does not decode (the adaptive arithmetic coder, fqzcomp) is an error that names the codec
     when the reader needs the block (bases), and no obstacle when it does not (qualities are never read); truncation is an error; an
     empty file (header and EOF containers only) has no records."""
     import cram_writer
@@ -196,11 +196,11 @@ def test_cram_refusals(tmp_path, cli):
     rc, _, err = _dump(cli, m)
     assert rc != 0 and MAPPED in err
     q = tmp_path / "qs31.cram"
-    q.write_bytes(cram_writer.write_cram(reads, method_for={"QS": "nx16"}))
+    q.write_bytes(cram_writer.write_cram(reads, minor=1, method_for={"QS": "fqz"}))
     assert list(readio.iter_records(str(q))) == reads
     b = tmp_path / "ba31.cram"
-    b.write_bytes(cram_writer.write_cram(reads, method_for={"BA": "nx16"}))
-    with pytest.raises(ValueError, match="rANS Nx16"):
+    b.write_bytes(cram_writer.write_cram(reads, minor=1, method_for={"BA": "arith"}))
+    with pytest.raises(ValueError, match="adaptive arithmetic coder"):
         list(readio.iter_records(str(b)))
     assert _dump(cli, b)[0] != 0
     t = tmp_path / "trunc.cram"
@@ -293,3 +293,103 @@ def test_rans_size_fields_that_lie(tmp_path, cli, order):
         t0 = time.perf_counter()
         out = subprocess.run([cli, "--dump-records", str(p)], capture_output=True, timeout=15)
         assert out.returncode == 1 and msg in out.stderr.decode() and time.perf_counter() - t0 < 5, out.stderr[-300:]
+
+
+# ---- CRAM 3.1 (round 6): rANS Nx16 and the name tokeniser, what samtools >= 1.22 writes by default ----
+@pytest.mark.parametrize("form", sorted(__import__("cram_writer").NX16_FORMS) if os.path.isdir(os.path.dirname(os.path.abspath(__file__))) else [])
+def test_cram31_rans_nx16_every_form(tmp_path, cli, form):
+    """Every series of the file in one form of rANS Nx16: orders 0 and 1, 4 and 32 interleaved states, 10- and 12-bit order-1 tables, the
+    table itself compressed, bit packing, run lengths (metadata raw and compressed), both, striping (the sub-streams carry no size), and
+    data stored as they are; names through the name tokeniser."""
+    import cram_writer
+    reads = _cram_reads(31)
+    p = tmp_path / "v31.cram"
+    p.write_bytes(cram_writer.write_cram(reads, minor=1, method=form, method_for={"RN": "tok3"}, records_per_slice=12, slices_per_container=2))
+    assert list(readio.iter_records(str(p))) == reads
+    rc, recs, err = _dump(cli, p)
+    assert rc == 0 and recs == reads, err
+
+
+def _roundtrip_block(tmp_path, data, method, tag):
+    """through a one-record CRAM whose tag value block is `data` -- no: whose BASES are the data (the decoders have no other entry point)"""
+    import cram_writer
+    seq = bytes(data) or b"A"
+    p = tmp_path / ("rt_%s.cram" % tag)
+    p.write_bytes(cram_writer.write_cram([(b"x", seq)], minor=1, method="raw", method_for={"BA": method}, with_tags=False, with_quality=False))
+    assert list(readio.iter_records(str(p))) == [(b"x", seq)], (method, len(seq))
+
+
+def test_rans_nx16_round_trips(tmp_path):
+    """The decoder against the test writer's encoder over the shapes that matter: lengths around the interleave (0 .. 2 N + 1), one symbol,
+    two / four / sixteen / seventeen symbols (the packing classes), long runs, every byte value, skewed and flat distributions."""
+    import numpy as np
+    import cram_writer
+    rng = np.random.default_rng(5)
+    nl = bytes([10])
+    cases = [b"A" * n for n in (1, 2, 3, 4, 5, 9, 31, 32, 33, 65, 67)] + [b"ACGT"[:k] * 37 for k in (1, 2, 3, 4)] + \
+            [bytes(range(65, 65 + 16)) * 9, bytes(range(65, 65 + 17)) * 9, bytes(b for b in range(256) if b != 10) * 2,
+             bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 30000, p=[.7, .1, .1, .1])), b"A" * 3000 + b"C" * 5 + b"G" * 700 + b"ACGT" * 50,
+             bytes(rng.integers(65, 91, 7000, dtype=np.uint8))]
+    for ci, data in enumerate(cases):
+        assert nl not in data
+        for form in sorted(cram_writer.NX16_FORMS):
+            if "pack" in form and len(set(data)) > 16 and False:
+                continue
+            _roundtrip_block(tmp_path, data, form, "%d_%s" % (ci, form))
+
+
+def test_name_tokeniser_shapes(tmp_path, cli):
+    """Names that exercise every token type: matches, deltas with and without leading zeros, numbers that grow a digit, duplicates,
+    names of different token counts, single characters; with and without the implied TYPE streams and the duplicate-stream references;
+    the token streams in several rANS Nx16 forms."""
+    import cram_writer
+    base = [b"m64011_190830_220126/%d/ccs" % (i * 7) for i in range(40)] + [b"m64011_190830_220126/%d/ccs" % 273] * 3 + \
+           [b"read-%04d/%d" % (i, i % 3) for i in range(95, 130)] + [b"x", b"x", b"a.b.c.d.e", b"a.b.c", b"00012", b"00013", b"0009", b"0010", b"9", b"10", b"255", b"511",
+            b"SRR28370649.%d" % 4294967295, b"SRR28370649.%d" % 1, b"@weird name:with spaces;and;more", b"1234567890123456789"]
+    for opts in (dict(), dict(implied_type=False, dup_streams=False), dict(stream_opts=dict(order=1)), dict(stream_opts=dict(rle=True, pack=True)), dict(stream_opts=dict(cat=True))):
+        reads = [(n, b"ACGT" * (1 + i % 5)) for i, n in enumerate(base)]
+        body = cram_writer.tok3([n for n, _ in reads], **opts)
+        p = tmp_path / "tok.cram"
+        orig = cram_writer.compress
+        try:
+            cram_writer.compress = lambda data, method, _o=orig, _b=body: _b if method == "tok3" else _o(data, method)
+            p.write_bytes(cram_writer.write_cram(reads, minor=1, method="nx16_o1", method_for={"RN": "tok3"}))
+        finally:
+            cram_writer.compress = orig
+        assert list(readio.iter_records(str(p))) == reads, opts
+        assert _dump(cli, p)[1] == reads
+
+
+def test_cram31_damage_and_integrity(tmp_path, cli):
+    """A flipped bit inside a rANS Nx16 body is an error (the states do not return to their start), never different bases; seeded damage
+    to CRAM 3.1 files ends in records or an error message."""
+    import random
+
+    import cram_writer
+    reads = _cram_reads(17)
+    rng = random.Random(31)
+    for form in ("nx16_o0", "nx16_o1", "nx16_packrle", "nx16_stripe", "nx16_o1ct"):
+        data = cram_writer.write_cram(reads, minor=1, method=form, method_for={"RN": "tok3"})
+        wrong = 0
+        for it in range(40):
+            b = bytearray(data)
+            kind = it % 4
+            if kind == 0:
+                for _ in range(rng.randrange(1, 4)):
+                    b[rng.randrange(len(b))] = rng.randrange(256)
+            elif kind == 1:
+                b = b[:rng.randrange(1, len(b))]
+            elif kind == 2:
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            else:
+                i = rng.randrange(len(b))
+                b[i:i + 4] = b"\xff\xff\xff\x7f"
+            p = tmp_path / ("%s.%d" % (form, it))
+            p.write_bytes(bytes(b))
+            out = subprocess.run([cli, "--dump-records", str(p)], capture_output=True, timeout=15)
+            assert out.returncode in (0, 1), (form, it, kind, out.returncode, out.stderr[-300:])
+            if out.returncode == 0:
+                recs = [tuple(l.split(b"\t")) for l in out.stdout.split(b"\n") if l]
+                wrong += [s for _, s in recs] != [s for _, s in reads]
+        # damage that leaves the file readable may change a name or a flag byte; bases that differ without an error must stay the exception
+        assert wrong <= 2, (form, wrong)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Damage campaign against the host-side input readers (include/lrge_io.hpp, include/lrge_cram.hpp) through `lrge-hip --dump-records`, a
 host-only mode: seeded damage -- overwritten bytes, one flipped bit, 0x7fffffff where a length may stand, truncation -- to CRAM 3.0 files of
-every block method and both layouts (tests/cram_writer.py), gzip FASTQ, FASTQ and SAM.  A case passes when the process ends by itself
+every block method and both layouts and CRAM 3.1 files of every rANS Nx16 form (tests/cram_writer.py), gzip FASTQ, FASTQ and SAM.  A case passes when the process ends by itself
 within the time limit with exit code 0 or 1 (records, or an error message); a signal, another code or a timeout is reported and the file
 kept under --keep.  tests/test_input_formats.py runs a bounded sample of the same generator; the two findings of the first campaigns
 (a rANS size field the stream cannot back; a rANS stream that ends early) are regression tests there.
@@ -35,6 +35,8 @@ def main():
     reads = T._cram_reads(23)
     files = {"cram_%s_%s" % (m, v): cram_writer.write_cram(reads, variant=v, method=m, records_per_slice=10, slices_per_container=2)
              for m in ("raw", "gzip", "bzip2", "lzma", "rans0", "rans1") for v in ("external", "core")}
+    for form in sorted(cram_writer.NX16_FORMS):                       # CRAM 3.1: rANS Nx16 in every form, names through the name tokeniser
+        files["cram31_" + form] = cram_writer.write_cram(reads, minor=1, method=form, method_for={"RN": "tok3"}, records_per_slice=10, slices_per_container=2)
     files["fq"], files["sam"], files["fq.gz"] = T._fastq(), T._sam(), gzip.compress(T._fastq())
     seeds = list(range(int(a.seeds.split("-")[0]), int(a.seeds.split("-")[1]) + 1)) if "-" in a.seeds else [int(x) for x in a.seeds.split(",")]
     os.makedirs(a.keep, exist_ok=True)

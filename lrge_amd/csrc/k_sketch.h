@@ -208,8 +208,8 @@ struct MinWindow {  // shift-register form of mm_sketch's ring buffer + running 
 // ---- homopolymer-compressed sketch (ava-pb): the steps of mm_sketch's loop as bits ----
 // With HPC a step of the scalar loop is a whole homopolymer run (or one ambiguous base).  Scanned base by base -- "while the
 // next base equals this one" -- the lanes of a wavefront wait for the longest run among them at every step (~4 bases for
-// random sequence) and pay a word lookup per base.  Here the steps of a 32-base word are found at once: bit 2j of `starts`
-// is set when base j begins a step (it differs from base j - 1, or either of them is ambiguous), ~10 operations per word,
+// random sequence) and pay a word lookup per base.  Here the steps of 16 bases are found at once: bit 2j of `starts`
+// is set when base j begins a step (it differs from base j - 1, or either of them is ambiguous), ~10 operations per half word,
 // and the loop goes from set bit to set bit: the run's length is the distance to the next one.
 #define SK_EVEN 0x5555555555555555ULL
 __device__ __forceinline__ u64 spread32(u32 m) {      // bit j -> bit 2j
@@ -221,31 +221,45 @@ __device__ __forceinline__ u64 spread32(u32 m) {      // bit j -> bit 2j
     x = (x | x << 1) & SK_EVEN;
     return x;
 }
-struct RunWords {
-    const u64 *pack; const u32 *nmask; i32 len;
-    u64 w, ns, starts;      // the current word: codes, ambiguity mask (bit 2j), step starts (bit 2j), clipped to the read
-    __device__ __forceinline__ void init(const u64 *p, const u32 *nm, u64 word_base, i32 l) { pack = p + word_base; nmask = nm + word_base; len = l; }
-    // prev2 / prevN: code and ambiguity of the last base of word wi - 1 (wi == 0: prevN = true, base 0 always starts a step)
-    __device__ __forceinline__ void set(i32 wi, u64 word, u32 m, u64 prev2, bool prevN) {
-        w = word;
-        ns = m ? spread32(m) : 0ULL;
-        const u64 x = w ^ (w << 2 | prev2);
-        u64 eq = ~(x | x >> 1) & SK_EVEN;
-        eq &= ~(ns | ns << 2 | (prevN ? 1ULL : 0ULL));
-        starts = ~eq & SK_EVEN;
-        const i32 nvalid = len - wi * 32;
-        if (nvalid < 32) starts &= (1ULL << (2 * nvalid)) - 1;
+// HALF WORDS (round 6): the lanes of a wavefront use up their words at different steps, so the block that fetches the next one and finds
+// its starts runs in nearly every step of the wavefront whatever its share of the lanes -- its price per run counts, not how often a lane
+// needs it.  On 16 bases at a time every operation is one 32-bit instruction (a 64-bit shift, compare, find-first-set is two to four).
+#define SK_EVEN32 0x55555555u
+__device__ __forceinline__ u32 spread16(u32 m) {      // bit j -> bit 2j, j < 16
+    u32 x = m & 0xFFFFu;
+    x = (x | x << 8) & 0x00FF00FFu;
+    x = (x | x << 4) & 0x0F0F0F0Fu;
+    x = (x | x << 2) & 0x33333333u;
+    x = (x | x << 1) & SK_EVEN32;
+    return x;
+}
+struct RunWords {            // "word" = 16 bases = one half of a packed word
+    static constexpr int LOG = 4, N = 16;
+    const u32 *pack; const u32 *nmask; i32 len;
+    u32 w, ns, starts;      // the current half: codes, ambiguity mask (bit 2j), step starts (bit 2j), clipped to the read
+    __device__ __forceinline__ void init(const u64 *p, const u32 *nm, u64 word_base, i32 l) { pack = (const u32 *)(p + word_base); nmask = nm + word_base; len = l; }
+    __device__ __forceinline__ u32 amb(i32 wi) const { return (nmask[wi >> 1] >> ((wi & 1) * 16)) & 0xFFFFu; }
+    // prev2 / prevN: code and ambiguity of the last base of half wi - 1 (wi == 0: prevN = true, base 0 always starts a step)
+    __device__ __forceinline__ void set(i32 wi, u32 half, u32 m, u32 prev2, bool prevN) {
+        w = half;
+        ns = m ? spread16(m) : 0u;
+        const u32 x = w ^ (w << 2 | prev2);
+        u32 eq = ~(x | x >> 1) & SK_EVEN32;
+        eq &= ~(ns | ns << 2 | (prevN ? 1u : 0u));
+        starts = ~eq & SK_EVEN32;
+        const i32 nvalid = len - wi * N;
+        if (nvalid < N) starts &= (1u << (2 * nvalid)) - 1;
     }
-    __device__ __forceinline__ void load(i32 wi) {                 // random access: fetches word wi - 1 too
-        u64 prev2 = 0; bool prevN = true;
-        if (wi > 0) { prev2 = pack[wi - 1] >> 62; prevN = (nmask[wi - 1] >> 31) != 0; }
-        set(wi, pack[wi], nmask[wi], prev2, prevN);
+    __device__ __forceinline__ void load(i32 wi) {                 // random access: fetches half wi - 1 too
+        u32 prev2 = 0; bool prevN = true;
+        if (wi > 0) { prev2 = pack[wi - 1] >> 30; prevN = (amb(wi - 1) >> 15) != 0; }
+        set(wi, pack[wi], amb(wi), prev2, prevN);
     }
-    __device__ __forceinline__ void next(i32 wi) {                 // word wi, the current one being wi - 1
-        const u64 prev2 = w >> 62; const bool prevN = (ns >> 62) != 0;
-        set(wi, pack[wi], nmask[wi], prev2, prevN);
+    __device__ __forceinline__ void next(i32 wi) {                 // half wi, the current one being wi - 1
+        const u32 prev2 = w >> 30; const bool prevN = (ns >> 30) != 0;
+        set(wi, pack[wi], amb(wi), prev2, prevN);
     }
-    __device__ __forceinline__ u32 code(u32 bit) const { return ((ns >> bit) & 1) ? 4u : (u32)((w >> bit) & 3); }
+    __device__ __forceinline__ u32 code(u32 bit) const { return ((ns >> bit) & 1) ? 4u : ((w >> bit) & 3); }
 };
 
 // POS_OWN = false: the chunk owns the loop steps that START in [s, e) and writes what mm_sketch writes DURING those steps (the
@@ -261,14 +275,14 @@ __device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nma
     if (len <= 0) return;
     RunWords rw; rw.init(pack, nmask, word_base, len);
     // ---- the first owned step: the first one that STARTS in [s, e) ----
-    i32 wi = s >> 5;
+    i32 wi = s >> RunWords::LOG;
     rw.load(wi);
-    u64 m = rw.starts & ~((1ULL << (2 * (s & 31))) - 1);
+    u32 m = rw.starts & ~((1u << (2 * (s & (RunWords::N - 1)))) - 1);
     i32 p = len;
     for (;;) {
-        if (m) { p = wi * 32 + (i32)(__builtin_ctzll(m) >> 1); break; }
+        if (m) { p = wi * RunWords::N + (i32)(__builtin_ctz(m) >> 1); break; }
         ++wi;
-        if (wi * 32 >= len) break;
+        if (wi * RunWords::N >= len) break;
         rw.next(wi); m = rw.starts;
     }
     if (!POS_OWN) {
@@ -282,16 +296,16 @@ __device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nma
     // ---- replay start h: HALO steps before it ----
     i32 h = 0;
     if (p > 0) {
-        i32 wb = (p - 1) >> 5;
+        i32 wb = (p - 1) >> RunWords::LOG;
         if (wb != wi || p >= len) rw.load(wb);
-        u64 mb = rw.starts;
-        if ((p >> 5) == wb) mb &= (1ULL << (2 * (p & 31))) - 1;
+        u32 mb = rw.starts;
+        if ((p >> RunWords::LOG) == wb) mb &= (1u << (2 * (p & (RunWords::N - 1)))) - 1;
         int need = POS_OWN ? HALO + 1 : HALO;      // (POS_OWN: the step that holds base s may start in front of it)
         for (;;) {
-            const int c = __popcll(mb);
+            const int c = __popc(mb);
             if (c >= need) {
-                for (int t = 1; t < need; ++t) mb &= ~(1ULL << (63 - __builtin_clzll(mb)));
-                h = wb * 32 + ((63 - __builtin_clzll(mb)) >> 1);
+                for (int t = 1; t < need; ++t) mb &= ~(1u << (31 - __builtin_clz(mb)));
+                h = wb * RunWords::N + ((31 - __builtin_clz(mb)) >> 1);
                 break;
             }
             need -= c;
@@ -307,18 +321,18 @@ __device__ __forceinline__ void sketch_chunk_hpc(const u64 *pack, const u32 *nma
     // byte 0 = newest, byte K-1 = the run that leaves the k-mer at the next push, 0 while fewer than K runs are held
     u32 hq0 = 0, hq1 = 0, hq2 = 0, hq3 = 0, hq4 = 0, hq5 = 0;
     (void)hq3; (void)hq4; (void)hq5;
-    wi = h >> 5;
+    wi = h >> RunWords::LOG;
     rw.load(wi);
-    m = rw.starts & ~((1ULL << (2 * (h & 31))) - 1);          // (its lowest bit is h itself)
-    i32 ppos = h; u32 pc = rw.code(2 * (h & 31));
+    m = rw.starts & ~((1u << (2 * (h & (RunWords::N - 1)))) - 1);          // (its lowest bit is h itself)
+    i32 ppos = h; u32 pc = rw.code(2 * (h & (RunWords::N - 1)));
     m &= m - 1;
     // next_step: the start of the step behind the pending run (= the end of that run) and its code
     auto next_step = [&](i32 &nxt, u32 &ncode) {
         nxt = len; ncode = 4;
         for (;;) {
-            if (m) { const u32 b = (u32)__builtin_ctzll(m); nxt = wi * 32 + (i32)(b >> 1); ncode = rw.code(b); m &= m - 1; break; }
+            if (m) { const u32 b = (u32)__builtin_ctz(m); nxt = wi * RunWords::N + (i32)(b >> 1); ncode = rw.code(b); m &= m - 1; break; }
             ++wi;
-            if (wi * 32 >= len) break;
+            if (wi * RunWords::N >= len) break;
             rw.next(wi); m = rw.starts;
         }
     };

@@ -603,8 +603,11 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_wave(const u64 *__restric
     const u32 w = threadIdx.x >> 6, lane = lane_id();
     const u32 c0 = c_base + blockIdx.x * SK_THREADS + 64 * w;            // the wavefront's first chunk
     if (c0 >= n_chunks) return;                                          // (wave-uniform)
-    volatile u32 *cnt = &s_cnt[w];
-    if (lane == 0) *cnt = 0;                                             // (same wavefront, in-order LDS: no barrier)
+    // the counter is read and written through wavefront-scope atomics ON THE LDS ARRAY ITSELF: a volatile generic pointer to it compiles to
+    // flat loads / stores with system-scope bits and a wait for every global store of the wavefront in front of each of them
+    auto cnt_get = [&]() -> u32 { return __hip_atomic_load(&s_cnt[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+    auto cnt_set = [&](u32 v) { __hip_atomic_store(&s_cnt[w], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+    if (lane == 0) cnt_set(0);                                           // (same wavefront, in-order LDS: no barrier)
     const u64 sbase = (u64)(c0 >> 6) * cap;
     const u32 c = c0 + lane;
     if (c < n_chunks) {
@@ -614,8 +617,8 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_wave(const u64 *__restric
         const i32 e = s + SK_CHUNK < len ? s + SK_CHUNK : len;
         sketch_chunk<K, W, HPC>(pack, nmask, woff[r], len, r, s, e, [&](u64 x, u64 y) {
             const u64 m = __ballot(1);                                   // the lanes at this emission site right now
-            const u32 b = *cnt;                                          // (one broadcast LDS read)
-            if (lane == (u32)__builtin_ctzll(m)) *cnt = b + (u32)__popcll(m);
+            const u32 b = cnt_get();                                     // (one broadcast LDS read)
+            if (lane == (u32)__builtin_ctzll(m)) cnt_set(b + (u32)__popcll(m));
             const u32 idx = b + (u32)__popcll(m & lanemask_lt());
             if (idx < cap) {
                 if (PK == 1) out_x[sbase + idx] = (x >> 8) << pk_ybits | (y >> 32) << pk_pos1 | (u64)(u32)y;
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_wave(const u64 *__restric
             }
         });
     }
-    if (lane == 0) { const u32 t = *cnt; wave_cnt[c0 >> 6] = t; if (t > cap) *overflow = 1u; }
+    if (lane == 0) { const u32 t = cnt_get(); wave_cnt[c0 >> 6] = t; if (t > cap) *overflow = 1u; }
 }
 
 // Behind k_sketch_tile (HPC): the chunks it marked ST_REDO, the sequential way, with the tile form's attribution (POS_OWN above).

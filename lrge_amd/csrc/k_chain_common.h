@@ -15,9 +15,11 @@ __device__ __forceinline__ u32 grec_state(u64 r) { return (u32)(r >> 56); }
 
 // Loads of data this wave stored earlier (grec, tmark).  A group is private to one wavefront, and a
 // CU's L1 is coherent with that CU's own stores once they have drained (vmcnt), so ordinary cached
-// loads are correct; `volatile` only stops the compiler from reusing a value across our stores.
-__device__ __forceinline__ u64 ld_u64_l2(const u64 *p) { return *(const volatile u64 *)p; }
-__device__ __forceinline__ u32 ld_u32_l2(const u32 *p) { return *(const volatile u32 *)p; }
+// loads are correct; the loads only have to stop the compiler from reusing a value across our stores.  Relaxed atomics of WAVEFRONT
+// scope say exactly that and compile to plain global loads; `volatile` (rounds 2-5) compiled to FLAT loads with system-scope bits --
+// past the L1, and every one of them waiting on both memory counters.
+__device__ __forceinline__ u64 ld_u64_l2(const u64 *p) { return __hip_atomic_load(const_cast<u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ u32 ld_u32_l2(const u32 *p) { return __hip_atomic_load(const_cast<u32 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ void drain_stores() { __builtin_amdgcn_s_waitcnt(0x0070 | 0x0f00); }  // vmcnt(0)
 
 // resolve one 64-candidate chunk of the scalar predecessor loop (used by the out-of-line slow path).

@@ -25,12 +25,12 @@ struct SeedParams {
 };
 
 // y value (rid << 32 | pos << 1 | strand) of index entry i
-__device__ __forceinline__ u64 index_y(const SeedParams &sp, u64 i) {
-    const u64 r = sp.pos[i];
+__device__ __forceinline__ u64 index_y_of(const SeedParams &sp, u64 r) {        // ... from the entry's word
     if (sp.pk_ybits == 0) return r;
     const u64 yb = r & ((1ULL << sp.pk_ybits) - 1);
     return (yb >> sp.pk_pos1) << 32 | (yb & ((1ULL << sp.pk_pos1) - 1));
 }
+__device__ __forceinline__ u64 index_y(const SeedParams &sp, u64 i) { return index_y_of(sp, sp.pos[i]); }
 
 // hit j of a list that lives at `st` (k_lookup): the inline position of a singleton, or entry st + j of pos[]
 __device__ __forceinline__ u64 list_y(const SeedParams &sp, u64 st, u32 j) {
@@ -184,24 +184,40 @@ __device__ __forceinline__ void expand_wave_chunk(const u64 w0, const u64 mz_beg
     }
     u32 o = aoff[w0] - aoff[mz_begin];                           // anchors written so far (wave-uniform); aoff: scan over ALL query minimizers
     o = (u32)__builtin_amdgcn_readfirstlane((i32)o);
-    for (u32 c0 = 0; c0 < total; c0 += 64) {
+    // ONE ROUND AHEAD (round 6): the kernel is bound by its chain of dependent trips to memory (position list -> target's name rank ->
+    // its length), so the position-list load of round c0 + 64 is issued before round c0 is worked on: its (minimizer, hit) pair needs
+    // only the scanned counts, which are in registers.
+    // locate: the lane's hit of the round that starts at c0 -- the largest lane l with rs[l] <= r (zero-length lists share their rs with
+    // the next one and lose) -- and its position-list entry, on its way
+    // (h: the entry's WORD -- what a packed index needs to make a y of it waits until the word is used, or the load would be waited for here)
+    auto locate = [&](const u32 c0, u32 &l, bool &inr, bool &inl, u64 &h) {
         const u32 r = c0 + lane;
-        // largest lane l with rs[l] <= r (zero-length lists share their rs with the next one and lose)
-        u32 l = 0;
+        l = 0;
 #pragma unroll
         for (u32 step = 32; step > 0; step >>= 1) {
             const u32 v = (u32)__shfl((i32)rs, (int)(l + step), 64);
             l = v <= r ? l + step : l;
         }
         const u32 j = r - (u32)__shfl((i32)rs, (int)l, 64);
-        const u64 st = shfl_u64(m_st, (int)l); const u32 q = (u32)__shfl((i32)m_q, (int)l, 64);
+        const u64 st = shfl_u64(m_st, (int)l);
+        inr = r < total;
+        h = !inr ? 0 : (st & HT_INLINE) ? st : sp.pos[(st & ~HT_INLINE) + j];
+        inl = (st & HT_INLINE) != 0;
+    };
+    u32 l_next; bool in_next, inl_next; u64 h_next;
+    locate(0, l_next, in_next, inl_next, h_next);
+    for (u32 c0 = 0; c0 < total; c0 += 64) {
+        const u32 r = c0 + lane;
+        const u32 l = l_next; bool keep = in_next; const bool inl = inl_next; const u64 hw = h_next;
+        if (c0 + 64 < total) locate(c0 + 64, l_next, in_next, inl_next, h_next);      // (wave-uniform)
+        const u32 q = (u32)__shfl((i32)m_q, (int)l, 64);
         const u32 qpos = (u32)__shfl((i32)m_qpos, (int)l, 64), fl = (u32)__shfl((i32)m_flags, (int)l, 64);
         const u32 ql = (u32)__shfl((i32)m_ql, (int)l, 64), qr = (u32)__shfl((i32)m_qr, (int)l, 64);
         const u32 rk = (u32)__shfl((i32)m_rank, (int)l, 64);
-        bool keep = r < total;
+        (void)r;
         u64 key = 0, val = 0;
         if (keep) {
-            const u64 h = list_y(sp, st, j);
+            const u64 h = inl ? (hw & ~HT_INLINE) : index_y_of(sp, hw);
             const u32 rid = (u32)(h >> 32), rpos = (u32)h >> 1, qstrand = fl & 1, span = fl >> 8;
             u64 self = 0;
             if (sp.check_names) {

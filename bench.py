@@ -545,19 +545,23 @@ def main():
                 cb = cpu_baseline_sampled(spec, Qn, Tn, a.cpu_seconds, preset)
                 out["cpu_baseline"] = cb
                 out["gpu_vs_cpu_port_SAMPLE"] = value / cb["value"]      # (the denominator is a pro-rated SAMPLE timed in this run: see cpu_baseline.in_run_sample)
-                # The WHOLE job was timed once on the port (round 5, tools/c5_allcounts.py: all 100 000 forward counts equal the GPU's; ~6.5
+                # The WHOLE job was timed once on the port (rounds 5 and 6, tools/c5_allcounts.py: all 100 000 forward counts equal the GPU's; ~6.5
                 # minutes of CPU time do not fit a default bench run).  When that committed record is of this very configuration it is the
                 # better figure -- the in-run sample pro-rates x40 and understates the port 2.4x -- so it becomes cpu_baseline.value, with
                 # the in-run sample beside it and the record itself under from_committed_profiles
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r05_c5_full_forward_allcounts.json")) as f:
+                    # (round 6: one record per preset, timed with that round's code; round 5's ava-pb record otherwise)
+                    rec = "r06_c5_full_forward_allcounts_%s.json" % ("ava_pb" if preset else "ava_ont")
+                    if not os.path.exists(os.path.join(ROOT, "profiles", rec)):
+                        rec = "r05_c5_full_forward_allcounts.json"
+                    with open(os.path.join(ROOT, "profiles", rec)) as f:
                         ac = json.load(f)
                     if a.config == ac.get("config") and a.scale == ac.get("scale") and ac.get("preset") == ("ava-pb" if preset else "ava-ont"):
                         m = ac["cpu_port_measured"]
                         committed["cpu_port_measured_full_job"] = {"reads_per_s": m["reads_per_s"], "job_seconds": m["job_seconds"], "index_seconds": m["index_seconds"],
                                                                     "map_seconds": m["map_seconds"], "threads": m["threads"], "counts_equal_gpu": ac["oracle_map"]["counts_equal"],
                                                                     "reads_checked": ac["oracle_map"]["reads_checked"], "note": m["note"],
-                                                                    "file": "profiles/r05_c5_full_forward_allcounts.json (a committed record, not timed in this run)"}
+                                                                    "file": "profiles/%s (a committed record, not timed in this run)" % rec}
                         cb["in_run_sample"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "sample": cb["sample"]}
                         cb["value"] = m["reads_per_s"]; cb["cores"] = m["threads"]
                         cb["value_source"] = ("from_committed_profiles.cpu_port_measured_full_job: the whole job timed once on the port (%.0f s on %d threads); "

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_direct(const u64 *__restr
 // WAVE-DENSE form of the one-pass index sketch (round 6).  k_sketch_direct gives every chunk a slot of SK_CAP entries, a quarter to a third
 // full, and k_sketch_compact closes the gaps: one more read and write of every entry (45 ms of an H. sapiens-scale step).  Here a
 // WAVEFRONT owns a slot -- room for `cap` entries behind its 64 chunks -- and fills it densely: whenever some of its lanes reach an
-// emission site of the state machine together, one ballot ranks them, the wavefront's counter (LDS, volatile: lanes that sit at other
+// emission site of the state machine together, one ballot ranks them, the wavefront's counter (LDS, wavefront-scope atomics: lanes that sit at other
 // program points must see every update) moves on by their number, and they write consecutive entries -- 8-byte words (and, PK == 2, the
 // 16-bit digit pair) in runs that the L2 combines into whole lines.  No gaps inside a slot, `wave_cnt[wave]` entries in it: the index
 // sort's first pass reads the slots through its slot-source form (k_prims.h: SlotSrc, rs_for_slot_items) and no compaction runs.
